@@ -1,0 +1,102 @@
+"""Shared helpers: fixture loading and the step-script runner used by both the
+oracle tests (CPU) and the GPU parity tests (same scripts, same expectations)."""
+import json
+import math
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def b(x):
+    return x.encode() if isinstance(x, str) else x
+
+
+def close(actual, expected, tol):
+    """assert_close of distances.rs:485-491: |a-e| <= tol*max(1,|a|,|e|)."""
+    scale = max(1.0, abs(actual), abs(expected))
+    return abs(actual - expected) <= tol * scale
+
+
+def same_f32(a, b_):
+    """bit equality of two f32 values (distinguishes -0.0 from 0.0)."""
+    return np.float32(a).tobytes() == np.float32(b_).tobytes()
+
+
+class IndexAdapter:
+    """Uniform view of an index for run_steps: methods raise `error_type`
+    carrying the reference's error string."""
+
+    error_type = Exception
+
+    def insert(self, id_, vector): ...
+    def insert_many(self, items): ...
+    def delete(self, id_): ...
+    def search(self, query, limit): ...
+    def __len__(self): ...
+    dimension = None
+
+
+def run_steps(index, steps, error_type):
+    for i, st in enumerate(steps):
+        op = st["op"]
+        where = "step %d (%s)" % (i, op)
+        try:
+            if op == "insert":
+                res = index.insert(st["id"], st["vector"])
+            elif op == "insert_many":
+                res = index.insert_many([(it[0], it[1]) for it in st["items"]])
+            elif op == "delete":
+                res = index.delete(st["id"])
+            elif op == "search":
+                res = index.search(st["query"], st["limit"])
+            elif op == "expect_len":
+                assert len(index) == st["len"], where
+                continue
+            elif op == "expect_dimension":
+                assert index.dimension == st["dimension"], where
+                continue
+            else:
+                raise AssertionError("unknown op " + op)
+        except error_type as e:
+            assert "expect_error" in st, "%s raised %r" % (where, e)
+            if st["expect_error"] is not True:
+                assert str(e) == st["expect_error"], where
+            continue
+        assert "expect_error" not in st, "%s should have failed with %r" % (where, st["expect_error"])
+        if op != "search":
+            continue
+        hits = res
+        if "expect" in st:
+            assert [(h[0], h[1]) for h in hits] == [(b(e[0]), e[1]) for e in st["expect"]], where
+        if "expect_ids" in st:
+            assert [h[0] for h in hits] == [b(x) for x in st["expect_ids"]], where
+        if "expect_first_id" in st:
+            assert hits and hits[0][0] == b(st["expect_first_id"]), where
+        if "expect_len" in st:
+            assert len(hits) == st["expect_len"], where
+        if st.get("expect_finite"):
+            assert all(math.isfinite(h[1]) for h in hits), where
+        if "expect_close" in st:
+            for h, e in zip(hits, st["expect_close"]):
+                assert h[0] == b(e[0]) and close(h[1], e[1], st["rel_tol"]), where
+
+
+def total_key(x):
+    """f32::total_cmp as a sortable int."""
+    bits = int(np.float32(x).view(np.int32))
+    return bits ^ ((bits >> 31) & 0x7FFFFFFF) if bits < 0 else bits
+
+
+def full_sort(rows, raw_fn, rank_fn, limit):
+    """The reference tests' differential oracle: score everything, sort by
+    (rank.total_cmp, id bytes), truncate (flat.rs:222-241, search.rs:131-155)."""
+    scored = [(b(i), raw_fn(v)) for i, v in rows]
+    scored.sort(key=lambda t: (total_key(rank_fn(t[1])), t[0]))
+    return scored[:limit]
