@@ -1,0 +1,186 @@
+/*
+ * vettore_flat.h -- C ABI of libvettore_hip.so, the MI355X (gfx950) drop-in for
+ * the flat-index hot path of elchemista/vettore v0.3.2.
+ *
+ * Every entry point is what a NIF shim for `Vettore.Nifs` (or the plugin module
+ * `Vettore.Index.FlatGpu`) binds in place of the Rust function
+ * cited next to it.  Citations are paths under /root/reference.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no exceptions cross the boundary;
+ *  - every function returns a VT_* status; vt_strerror() maps the reference's
+ *    error statuses to the reference's exact error strings, so the shim can
+ *    build `{:error, "dimension mismatch"}` verbatim;
+ *  - ids are arbitrary byte strings (Elixir binaries): pointer + length, or for
+ *    batches one concatenated buffer plus `off[count + 1]` offsets;
+ *  - ragged vector batches use the same layout (values + `off[count + 1]` in
+ *    elements) so that a wrong-length row is reported as "dimension mismatch"
+ *    exactly like native/vettore/src/flat.rs:69-85 does;
+ *  - all compute runs on the GPU; there is no CPU fallback.  Without a usable
+ *    HIP device the calls fail with VT_ERR_DEVICE.
+ *  - thread safety: one index handle serialises its calls internally (the
+ *    reference's RwLock, nifs.rs:266-309); different handles are independent.
+ */
+#ifndef VETTORE_FLAT_H
+#define VETTORE_FLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VT_ABI_VERSION 1
+
+/* Metric codes == Metric::from_code, native/vettore/src/distances.rs:24-38,
+ * mirrored by lib/vettore/collection.ex:1306-1315. */
+enum {
+  VT_L2 = 0,
+  VT_L2_SQUARED = 1,
+  VT_COSINE = 2,
+  VT_INNER_PRODUCT = 3,
+  VT_NEG_INNER_PRODUCT = 4,
+  VT_MANHATTAN = 5,
+  VT_CHEBYSHEV = 6,
+  VT_HAMMING = 7,
+  VT_JACCARD = 8
+};
+
+/* Status codes.  1..7 carry the reference's error strings. */
+enum {
+  VT_OK = 0,
+  VT_ERR_EMPTY = 1,          /* "vector must not be empty"            flat.rs:138 */
+  VT_ERR_DIMENSION = 2,      /* "dimension mismatch"                  flat.rs:141, distances.rs:44 */
+  VT_ERR_NON_FINITE = 3,     /* "vector contains a non-finite value"  distances.rs:135 */
+  VT_ERR_OVERFLOW = 4,       /* "metric overflow"                     distances.rs:67 */
+  VT_ERR_UNKNOWN_METRIC = 5, /* "unknown metric"                      distances.rs:36 */
+  VT_ERR_PREFIX = 6,         /* "invalid prefix dimensions"           search.rs:47 */
+  VT_ERR_DIMS_POSITIVE = 7,  /* "dimensions must be positive"         distances.rs:463 */
+  /* statuses the reference cannot produce */
+  VT_ERR_NOMEM = 16,
+  VT_ERR_DEVICE = 17,        /* HIP error / no gfx950 device; see vt_last_error() */
+  VT_ERR_UNSUPPORTED = 18,   /* shape outside what the device kernels cover; vt_last_error() */
+  VT_ERR_ARGUMENT = 19       /* NULL handle and the like (the shim's badarg) */
+};
+
+/* Lane order of wide::f32x8::reduce_add used for every 8-float chunk
+ * (distances.rs:197-308).  The reference does not pin it (third-party crate,
+ * build-flag dependent); the device kernels reproduce whichever is selected
+ * bit for bit.  Default VT_ORDER_PAIR.  See DESIGN.md "summation order". */
+enum { VT_ORDER_PAIR = 0, VT_ORDER_AVX = 1, VT_ORDER_SEQ = 2 };
+
+const char *vt_strerror(int status);
+/* Detail text of the calling thread's last VT_ERR_DEVICE / VT_ERR_UNSUPPORTED. */
+const char *vt_last_error(void);
+int vt_abi_version(void);
+/* Number of visible HIP devices (0 if none); never fails. */
+int vt_device_count(void);
+
+/* ------------------------------------------------------------------ hits
+ * Vec<(String, f32)> as returned by flat_search / vector_top_k /
+ * binary_top_k: ascending by (rank, id bytes). */
+typedef struct vt_hits vt_hits;
+size_t vt_hits_len(const vt_hits *hits);
+/* id bytes of hit i (owned by `hits`, valid until vt_hits_free). */
+const char *vt_hits_id(const vt_hits *hits, size_t i, size_t *len);
+/* raw metric value of hit i (the f32 the NIF widens to a BEAM double). */
+float vt_hits_raw(const vt_hits *hits, size_t i);
+/* f32::total_cmp sort key of rank_value(metric, raw) as an order-preserving
+ * u32 (distances.rs:113-119, flat.rs:34-40): what a multi-shard merge compares
+ * before falling back to the id bytes. */
+uint32_t vt_hits_rank_key(const vt_hits *hits, size_t i);
+void vt_hits_free(vt_hits *hits);
+
+/* ----------------------------------------------------------- flat index
+ * FlatResource(RwLock<FlatIndex>), flat.rs:13-17, :131-134. */
+typedef struct vt_flat vt_flat;
+
+/* flat_new_<metric>/0, nifs.rs:200-257.  `device` = HIP device ordinal. */
+int vt_flat_new(int metric_code, int device, vt_flat **out);
+/* ResourceArc drop: frees HBM, streams, pinned staging. */
+void vt_flat_free(vt_flat *index);
+
+/* flat_insert/3, nifs.rs:259-271 -> FlatIndex::insert flat.rs:59-66. */
+int vt_flat_insert(vt_flat *index, const char *id, size_t id_len,
+                   const float *vector, size_t n);
+/* flat_insert_many/2, nifs.rs:273-284 -> FlatIndex::insert_many flat.rs:69-85:
+ * validates every row first (atomic), last duplicate id wins. */
+int vt_flat_insert_many(vt_flat *index, size_t count, const char *ids,
+                        const size_t *id_off, const float *values,
+                        const size_t *value_off);
+/* flat_delete/2, nifs.rs:286-295 -> FlatIndex::delete flat.rs:88-93.
+ * Unknown id is a no-op; an emptied index forgets its dimension. */
+int vt_flat_delete(vt_flat *index, const char *id, size_t id_len);
+/* flat_search/3, nifs.rs:297-309 -> FlatIndex::search flat.rs:96-124.
+ * limit == 0 returns an empty list before the query is validated. */
+int vt_flat_search(vt_flat *index, const float *query, size_t n, size_t limit,
+                   vt_hits **out);
+
+size_t vt_flat_len(const vt_flat *index);
+/* FlatIndex.dimension: -1 = None. */
+long vt_flat_dimension(const vt_flat *index);
+int vt_flat_metric(const vt_flat *index);
+int vt_flat_set_reduce_order(vt_flat *index, int order);
+/* Order used by indexes created afterwards and by the stateless helpers. */
+int vt_set_default_reduce_order(int order);
+
+/* Bulk extensions (SURVEY.md 8b "vt_flat_load_matrix"): same semantics as
+ * insert_many of `count` rows of equal length `d`, without the ragged layout.
+ * _device takes a pointer to a row-major f32 [count][d] matrix already in this
+ * device's HBM; finiteness is then checked by a device kernel. */
+int vt_flat_load_matrix(vt_flat *index, size_t count, size_t d, const char *ids,
+                        const size_t *id_off, const float *rows);
+int vt_flat_load_device_matrix(vt_flat *index, size_t count, size_t d,
+                               const char *ids, const size_t *id_off,
+                               const void *device_rows);
+
+/* quantized_search, lib/vettore/collection.ex:276-295: sign-bit Hamming
+ * candidate pass (search.rs:76-92 over compress_sign_bits of every stored row,
+ * distances.rs:413-437) followed by exact rerank (search.rs:38-73; cosine
+ * reranks with the f64 `cosine`, search.rs:56-60). */
+int vt_flat_quantized_search(vt_flat *index, const float *query, size_t n,
+                             size_t candidates, size_t limit, vt_hits **out);
+
+/* ------------------------------------------------- stateless NIF helpers
+ * vector_top_k/5, nifs.rs:151-162 -> search.rs:38-73. */
+int vt_vector_top_k(int device, size_t count, const char *ids,
+                    const size_t *id_off, const float *values,
+                    const size_t *value_off, const float *query, size_t nq,
+                    int metric_code, size_t dimensions, size_t limit,
+                    vt_hits **out);
+/* binary_top_k/4, nifs.rs:164-175 -> search.rs:76-92. */
+int vt_binary_top_k(int device, size_t count, const char *ids,
+                    const size_t *id_off, const uint64_t *words,
+                    const size_t *word_off, const uint64_t *query, size_t nq,
+                    size_t dimensions, size_t limit, vt_hits **out);
+/* normalize_l2/1, nifs.rs:107-111 -> distances.rs:350-361 (rows of a
+ * [count][d] matrix; count == 1 is the NIF call). */
+int vt_normalize_l2(int device, size_t count, size_t d, const float *in,
+                    float *out);
+/* compress_sign_bits/1, nifs.rs:125-129 -> distances.rs:413-423.
+ * out has count * ((d + 63) / 64) words. */
+int vt_compress_sign_bits(int device, size_t count, size_t d, const float *in,
+                          uint64_t *out);
+
+/* ------------------------------------------------------------ profiling
+ * Device-side timing of the dominant kernels with HIP events on the stream the
+ * kernels are launched on (bench.py's roofline figure). */
+typedef struct vt_profile {
+  uint64_t scan_launches;   /* flat scan + fused top-k kernel launches */
+  double scan_ms;           /* sum of their durations (hipEventElapsedTime) */
+  uint64_t scan_rows;       /* rows scanned by those launches */
+  uint64_t scan_bytes;      /* algorithmic bytes: rows * d * 4 */
+  uint64_t hamming_launches;
+  double hamming_ms;
+  uint64_t hamming_bytes;   /* rows * ceil(d/64) * 8 */
+  uint64_t merge_launches;
+  double merge_ms;
+} vt_profile;
+int vt_flat_set_profiling(vt_flat *index, int enabled);
+int vt_flat_get_profile(vt_flat *index, vt_profile *out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,107 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports
+every symbol include/vettore_flat.h declares, reports the reference's error
+strings, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vettore_flat.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import vettore_amd._lib as L
+    return L.load()
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    names = declared_functions()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(lib, name), "libvettore_hip.so does not export " + name
+
+
+def test_python_binding_covers_the_header():
+    import vettore_amd._lib as L
+    assert sorted(L.SYMBOLS) == declared_functions()
+
+
+def test_error_strings_are_the_references(lib):
+    # native/vettore/src/flat.rs:138,141; distances.rs:36,67,135,463; search.rs:47
+    want = {
+        1: "vector must not be empty",
+        2: "dimension mismatch",
+        3: "vector contains a non-finite value",
+        4: "metric overflow",
+        5: "unknown metric",
+        6: "invalid prefix dimensions",
+        7: "dimensions must be positive",
+    }
+    for code, text in want.items():
+        assert lib.vt_strerror(code).decode() == text
+    assert lib.vt_abi_version() == 1
+
+
+def test_header_cites_the_reference_interface():
+    text = open(HEADER).read()
+    for cite in ("nifs.rs:259-271", "nifs.rs:273-284", "nifs.rs:286-295", "nifs.rs:297-309", "nifs.rs:151-162",
+                 "nifs.rs:164-175", "nifs.rs:107-111", "nifs.rs:125-129", "flat.rs:96-124"):
+        assert cite in text, cite
+
+
+def test_argument_validation_happens_before_the_device(lib):
+    """Statuses that need no GPU: metric decode and helper argument checks
+    follow the reference's order (nifs.rs:158-161, search.rs:46-48, :82-84)."""
+    h = C.c_void_p()
+    assert lib.vt_flat_new(9, 0, C.byref(h)) == 5          # unknown metric
+    assert lib.vt_flat_new(-1, 0, C.byref(h)) == 5
+    one = (C.c_float * 1)(1.0)
+    off = (C.c_size_t * 1)(0)
+    out = C.c_void_p()
+    assert lib.vt_vector_top_k(0, 0, b"", off, one, off, one, 1, 9, 1, 1, C.byref(out)) == 5
+    assert lib.vt_vector_top_k(0, 0, b"", off, one, off, one, 1, 0, 0, 1, C.byref(out)) == 6   # prefix 0
+    assert lib.vt_vector_top_k(0, 0, b"", off, one, off, one, 1, 0, 2, 1, C.byref(out)) == 6   # prefix > len
+    nan = (C.c_float * 1)(float("nan"))
+    assert lib.vt_vector_top_k(0, 0, b"", off, one, off, nan, 1, 0, 1, 1, C.byref(out)) == 3
+    q = (C.c_uint64 * 1)(0)
+    assert lib.vt_binary_top_k(0, 0, b"", off, q, off, q, 0, 0, 1, C.byref(out)) == 7         # dims == 0
+    assert lib.vt_binary_top_k(0, 0, b"", off, q, off, q, 0, 1, 1, C.byref(out)) == 2         # no query words
+    assert lib.vt_binary_top_k(0, 0, b"", off, q, off, q, 1, 1, 1, C.byref(out)) == 0         # empty batch ok
+    assert lib.vt_hits_len(out) == 0
+    lib.vt_hits_free(out)
+    assert lib.vt_normalize_l2(0, 1, 1, nan, one) == 3
+
+
+def test_no_cpu_fallback_without_a_device(lib):
+    if lib.vt_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    h = C.c_void_p()
+    assert lib.vt_flat_new(2, 0, C.byref(h)) == 17         # VT_ERR_DEVICE
+    assert b"no CPU fallback" in lib.vt_last_error()
+    from vettore_amd import nifs
+    with pytest.raises(RuntimeError, match="device error"):
+        nifs.flat_new_cosine()
+
+
+def test_product_does_not_touch_the_oracle():
+    """The oracle is test infrastructure: nothing under vettore_amd/ may import,
+    link or load it."""
+    pkg = os.path.join(ROOT, "vettore_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r'#include\s*[<"][^>"]*oracle|libvt_oracle|^\s*(import|from)\s+oracle', text, re.M), f
+    import subprocess
+    so = os.path.join(pkg, "lib", "libvettore_hip.so")
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "oracle" not in needed

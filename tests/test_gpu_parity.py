@@ -1,0 +1,471 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through
+the C ABI of libvettore_hip.so, against (a) the reference's golden fixtures and
+(b) the CPU oracle on the same seeded inputs.
+
+Bar: ids/ranking identical AND raw scores bit-identical (the kernels reproduce
+the reference's f32 operation order exactly, for each selectable lane order of
+wide::f32x8::reduce_add), so no tolerance is needed; the 1e-5 relative bound of
+BASELINE.json is asserted as well where an independent f64 value exists.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import support
+from support import b, close, load, run_steps, same_f32
+
+pytestmark = pytest.mark.gpu
+
+ORDERS = [0, 1, 2]
+TOL = 1e-5  # BASELINE.json: f32 scores within 1e-5 (relative, distances.rs:485-491 convention)
+
+
+class GpuError(Exception):
+    pass
+
+
+@pytest.fixture(scope="module")
+def nifs():
+    from vettore_amd import nifs as n
+    import vettore_amd._lib as L
+    assert L.load().vt_device_count() >= 1, "no HIP device: GPU tests need the real hardware"
+    return n
+
+
+def unwrap(res):
+    if res == "ok":
+        return None
+    if res[0] == "ok":
+        return res[1]
+    raise GpuError(res[1])
+
+
+class GpuIndex:
+    """support.run_steps adapter over the Python mirror of Vettore.Nifs."""
+
+    def __init__(self, nifs, metric_code, order=0):
+        self.n = nifs
+        self.ref = nifs._flat_new(metric_code)
+        nifs.flat_set_reduce_order(self.ref, order)
+
+    def insert(self, id_, vector):
+        return unwrap(self.n.flat_insert(self.ref, id_, vector))
+
+    def insert_many(self, items):
+        return unwrap(self.n.flat_insert_many(self.ref, items))
+
+    def delete(self, id_):
+        return unwrap(self.n.flat_delete(self.ref, id_))
+
+    def search(self, query, limit):
+        return unwrap(self.n.flat_search(self.ref, query, limit))
+
+    def __len__(self):
+        return len(self.ref)
+
+    @property
+    def dimension(self):
+        return self.ref.dimension
+
+
+def bits(hits):
+    return [(h[0], np.float32(h[1]).tobytes()) for h in hits]
+
+
+# ------------------------------------------------- reference golden fixtures
+def test_flat_rs_scripts(nifs, oracle_mod):
+    for case in load("flat_rs.json"):
+        if case.get("differential"):
+            continue
+        ix = GpuIndex(nifs, oracle_mod.METRIC_CODE[case["metric"]])
+        run_steps(ix, case["steps"], GpuError)
+
+
+@pytest.mark.parametrize("order", ORDERS)
+def test_flat_rs_all_metrics_match_oracle_bitwise(nifs, oracle_mod, order):
+    case = next(c for c in load("flat_rs.json") if c.get("differential"))
+    oracle_mod.set_reduce_order(order)
+    try:
+        for name in case["metrics"]:
+            m = oracle_mod.METRIC_CODE[name]
+            g = GpuIndex(nifs, m, order)
+            o = oracle_mod.FlatIndex(m)
+            items = [(r[0], r[1]) for r in case["rows"]]
+            g.insert_many(items)
+            o.insert_many(items)
+            for limit in case["limits"]:
+                assert bits(g.search(case["query"], limit)) == bits(o.search(case["query"], limit)), (name, limit)
+    finally:
+        oracle_mod.set_reduce_order(0)
+
+
+def test_distances_tail_lengths_bitwise(nifs, oracle_mod):
+    """distances.rs:570-609: chunked kernel + scalar tail for len 1..40 (len 0 is
+    rejected by the index: "vector must not be empty")."""
+    c = load("distances_rs.json")["simd_and_tail_kernels_match_scalar_oracles"]
+    for order in ORDERS:
+        oracle_mod.set_reduce_order(order)
+        for v in c["vectors"]:
+            if v["len"] == 0:
+                continue
+            for m in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+                g = GpuIndex(nifs, m, order)
+                g.insert("x", v["right"])
+                got = g.search(v["left"], 1)
+                want = oracle_mod.compute(m, v["left"], v["right"])
+                assert same_f32(got[0][1], want), (order, m, v["len"])
+                exact = None
+                l64 = np.asarray(v["left"], dtype=np.float64)
+                r64 = np.asarray(v["right"], dtype=np.float64)
+                if m == 3:
+                    exact = float(np.sum(l64 * r64))
+                elif m == 1:
+                    exact = float(np.sum((l64 - r64) ** 2))
+                elif m == 5:
+                    exact = float(np.sum(np.abs(l64 - r64)))
+                if exact is not None:
+                    assert close(got[0][1], exact, c["tolerance"])
+    oracle_mod.set_reduce_order(0)
+
+
+def test_distances_overflow_recovery(nifs, oracle_mod):
+    c = load("distances_rs.json")["recovers_representable_results_after_f32_intermediate_overflow"]
+    code = oracle_mod.METRIC_CODE
+    for name, l, r, want, tol in c["close"]:
+        g = GpuIndex(nifs, code[name])
+        g.insert("x", r)
+        got = g.search(l, 1)[0][1]
+        assert close(got, want, tol) and same_f32(got, oracle_mod.compute(code[name], l, r))
+    for name, l, r, want, sign in c["exact"]:
+        g = GpuIndex(nifs, code[name])
+        g.insert("x", r)
+        got = g.search(l, 1)[0][1]
+        assert same_f32(got, want), (name, got)
+    for name, l, r in c["errors"]:
+        g = GpuIndex(nifs, code[name])
+        g.insert("x", r)
+        with pytest.raises(GpuError, match="metric overflow"):
+            g.search(l, 1)
+
+
+def test_normalize_and_sign_bits(nifs, oracle_mod):
+    d = load("distances_rs.json")
+    c = d["validates_dimensions_normalization_and_finite_values"]
+    for v, want in c["normalize_l2"]:
+        assert list(unwrap(nifs.normalize_l2(v))) == [np.float32(x) for x in want]
+    for v, want, tol in c["normalize_l2_close"]:
+        got = unwrap(nifs.normalize_l2(v))
+        assert all(abs(float(g) - w) < tol for g, w in zip(got, want))
+    for bad in d["cosine_and_normalization_obey_numerical_invariants"]["non_finite"]:
+        assert nifs.normalize_l2([bad]) == ("error", "vector contains a non-finite value")
+    c = d["packs_bits_and_masks_unused_coordinates"]
+    for v, words in c["compress"]:
+        assert nifs.compress_sign_bits(v) == words
+    rng = np.random.default_rng(11)
+    for n in (1, 7, 63, 64, 65, 200, 768, 1000):
+        v = rng.uniform(-1, 1, n).astype(np.float32)
+        v[rng.integers(0, n)] = 0.0
+        if n > 2:
+            v[1] = -0.0
+        assert np.array_equal(unwrap(nifs.normalize_l2(v)).view(np.uint32), oracle_mod.normalize_l2(v).view(np.uint32)), n
+        assert nifs.compress_sign_bits(v) == [int(w) for w in oracle_mod.compress_sign_bits(v)], n
+
+
+# ---------------------------------------------------------------- search.rs
+def _expect_call(res, call):
+    if "expect_error" in call:
+        assert res == ("error", call["expect_error"]), res
+        return
+    hits = unwrap(res)
+    if "expect" in call:
+        assert hits == [(b(e[0]), e[1]) for e in call["expect"]]
+    if "expect_first_id" in call:
+        assert hits[0][0] == b(call["expect_first_id"])
+
+
+def test_search_rs_vector_top_k(nifs, oracle_mod):
+    d = load("search_rs.json")
+    code = oracle_mod.METRIC_CODE
+    c = d["vector_top_k_handles_prefixes_similarity_and_ties"]
+    for call in c["calls"]:
+        _expect_call(nifs.vector_top_k([(v[0], v[1]) for v in c["vectors"]], call["query"], code[call["metric"]],
+                                       call["dimensions"], call["limit"]), call)
+    for key in ("vector_top_k_rejects_bad_dimensions_and_values",
+                "vector_top_k_validates_queries_and_only_reads_the_requested_prefix"):
+        for call in d[key]["calls"]:
+            _expect_call(nifs.vector_top_k([(v[0], v[1]) for v in call["vectors"]], call["query"],
+                                           code[call["metric"]], call["dimensions"], call["limit"]), call)
+    c = d["stable_ties_do_not_depend_on_candidate_order"]
+    for vectors in (c["forward"], list(reversed(c["forward"]))):
+        _expect_call(nifs.vector_top_k([(v[0], v[1]) for v in vectors], c["query"], code[c["metric"]],
+                                       c["dimensions"], c["limit"]), c)
+
+
+def test_search_rs_vector_top_k_full_grid_bitwise(nifs, oracle_mod):
+    c = load("search_rs.json")["vector_top_k_matches_full_sort_for_every_metric_and_limit"]
+    rows = [(r[0], r[1]) for r in c["rows"]]
+    for name in c["metrics"]:
+        m = oracle_mod.METRIC_CODE[name]
+        for dims in c["dimensions"]:
+            for limit in c["limits"]:
+                got = unwrap(nifs.vector_top_k(rows, c["query"], m, dims, limit))
+                want = oracle_mod.vector_top_k(rows, c["query"], m, dims, limit)
+                assert bits(got) == bits(want), (name, dims, limit)
+
+
+def test_search_rs_binary_top_k(nifs, oracle_mod):
+    d = load("search_rs.json")
+    c = d["binary_top_k_masks_padding_and_orders_ids"]
+    q = nifs.compress_sign_bits(c["query_vector"])
+    vecs = [(v[0], nifs.compress_sign_bits(v[1])) for v in c["vectors"]]
+    assert unwrap(nifs.binary_top_k(vecs, q, c["dimensions"], c["limit"])) == [(b(e[0]), e[1]) for e in c["expect"]]
+    for call in d["binary_top_k_validates_empty_batches_limits_and_word_boundaries"]["calls"]:
+        _expect_call(nifs.binary_top_k([(v[0], v[1]) for v in call["vectors"]], call["query"], call["dimensions"],
+                                       call["limit"]), call)
+
+
+# ----------------------------------------- Elixir tests through the NIF surface
+def test_elixir_all_metrics_through_collection(nifs):
+    from vettore_amd.collection import Collection
+    c = load("elixir_nif.json")["all_supported_metrics_return_stable_top_k_results"]
+    for name in c["metrics"]:
+        ok, col = Collection.new(dimensions=2, metric=name, index="flat")
+        assert ok == "ok"
+        assert col.put_many([{"id": r[0], "vector": r[1]} for r in c["rows"]]) == "ok"
+        ok, results = col.search(c["query"], {"limit": c["limit"]})
+        assert ok == "ok" and [r.id for r in results] == [b(x) for x in c["expect_ids"]], name
+        assert col.close() == "ok"
+
+
+def test_elixir_phantom_id_and_ok_unit(nifs):
+    from vettore_amd.collection import Collection
+    from vettore_amd.index_flat import FlatGpu
+    from vettore_amd.collection import Embedding
+    c = load("elixir_nif.json")["phantom_native_id_and_ok_unit"]
+    ok, col = Collection.new(dimensions=1, metric="l2")
+    assert FlatGpu.put(col, Embedding(id="bad", vector=[])) == ("error", c["put_empty_error"])
+    assert nifs.flat_insert(col.index_state, c["flat_insert"][0], c["flat_insert"][1]) == ("ok", ())
+    assert col.search([0.0], {"limit": 1}) == ("ok", [])
+    assert FlatGpu.new("l2", {"unknown": True}) == ("error", "invalid_flat_options")
+    assert FlatGpu.new("unknown", []) == ("error", ("unsupported_flat_metric", "unknown"))
+    assert FlatGpu.search(col, [0.0], {"unknown": True}) == ("error", "invalid_search_options")
+
+
+def test_elixir_batched_helpers(nifs):
+    c = load("elixir_nif.json")["batched_native_helpers"]
+    vecs = [(v[0], v[1]) for v in c["vectors"]]
+    for mc in c["metric_codes"]:
+        hits = unwrap(nifs.vector_top_k(vecs, c["query"], mc, c["dimensions"], c["limit"]))
+        assert [h[0] for h in hits] == [b(x) for x in c["expect_ids"]], mc
+    assert nifs.vector_top_k(vecs, c["query"], c["unknown_metric"][0], 2, 2) == ("error", c["unknown_metric"][1])
+    assert nifs.vector_top_k(vecs, c["query"], 0, 0, 2) == ("error", c["bad_prefix"][2])
+    bn = c["binary"]
+    assert unwrap(nifs.binary_top_k([(v[0], v[1]) for v in bn["vectors"]], bn["query"], bn["dimensions"],
+                                    bn["limit"])) == [(b(e[0]), e[1]) for e in bn["expect"]]
+
+
+def test_elixir_cosine_collection_and_result_values(nifs):
+    from vettore_amd.collection import Collection
+    from vettore_amd.index_flat import result_values
+    d = load("elixir_nif.json")
+    c = d["cosine_collection_result_semantics"]
+    ok, col = Collection.new(dimensions=2, metric="cosine", normalize="l2", score="raw")
+    assert col.put_many([{"id": r[0], "vector": r[1]} for r in c["rows"]]) == "ok"
+    assert col.put({"id": "right", "vector": [0.5, 0.5]}) == ("error", "duplicate_id")
+    ok, results = col.search(c["query"], {"limit": c["limit"]})
+    first = results[0]
+    assert (first.id, first.score, first.distance, first.metric) == (b"right", 1.0, 0.0, "cosine")
+    for metric, raw, mode, want in d["result_values"]["table"]:
+        assert list(result_values(metric, raw, mode)) == want
+    a = d["adapter_validation"]
+    ok, col = Collection.new(dimensions=a["dimensions"], metric=a["metric"])
+    for lim in a["invalid_limits"]:
+        assert col.search([0.0, 0.0], {"limit": lim}) == ("error", "invalid_limit")
+    assert col.search(a["dimension_mismatch_query"], {"limit": 1}) == ("error", "dimension_mismatch")
+
+
+def test_elixir_quantized_search(nifs):
+    from vettore_amd.collection import Collection
+    d = load("elixir_nif.json")
+    c = d["binary_quantized_search"]
+    ok, col = Collection.new(dimensions=2, metric=c["metric"], index="flat")
+    assert col.put_many([{"id": r[0], "vector": r[1]} for r in c["rows"]]) == "ok"
+    assert col.get(c["binary_vector_of"][0])[1].binary_vector == c["binary_vector_of"][1]
+    ok, results = col.quantized_search(c["query"], {"candidates": c["candidates"], "limit": c["limit"]})
+    assert [(r.id, r.distance) for r in results] == [(b(e["id"]), e["distance"]) for e in c["expect"]]
+    c = d["full_candidate_adaptive_modes_agree_with_exact_flat_search"]
+    ok, col = Collection.new(dimensions=4, metric=c["metric"], index="flat")
+    assert col.put_many([{"id": r[0], "vector": r[1]} for r in c["rows"]]) == "ok"
+    ok, exact = col.search(c["query"], {"limit": c["limit"]})
+    ok, quant = col.quantized_search(c["query"], {"candidates": c["candidates"], "limit": c["limit"]})
+    assert [r.id for r in quant] == [r.id for r in exact]
+
+
+# ------------------------------------------- seeded random parity vs the oracle
+def make_corpus(n, d, seed, normalize, oracle_mod, dup_frac=0.01, tie_block=0):
+    """iid uniform(-1,1), 1% verbatim duplicate rows, ids
+    "doc-<i>" (bytewise order != numeric order)."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1.0, 1.0, size=(n, d)).astype(np.float32)
+    ndup = int(n * dup_frac)
+    if ndup:
+        src = rng.integers(0, n, ndup)
+        dst = rng.integers(0, n, ndup)
+        x[dst] = x[src]
+    if tie_block:
+        x[n // 2:n // 2 + tie_block] = x[n // 2]
+    if normalize:
+        x = np.stack([oracle_mod.normalize_l2(r) for r in x])
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    return x, ids
+
+
+@pytest.mark.parametrize("d", [8, 24, 100, 7, 384])
+@pytest.mark.parametrize("order", ORDERS)
+def test_random_parity_all_metrics(nifs, oracle_mod, d, order):
+    n = 5000
+    oracle_mod.set_reduce_order(order)
+    try:
+        x, ids = make_corpus(n, d, 20260721 + d, False, oracle_mod, tie_block=40)
+        x[:, d // 2] = np.where(np.arange(n) % 3 == 0, 0.0, x[:, d // 2])  # exercise hamming/jaccard zeros
+        packed = oracle_mod.pack_ids(ids)
+        rng = np.random.default_rng(20260722)
+        queries = rng.uniform(-1, 1, size=(3, d)).astype(np.float32)
+        queries[0] = x[n // 2]  # hits the identical-row block exactly
+        for m in range(9):
+            g = GpuIndex(nifs, m, order)
+            unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+            for q in queries:
+                for k in (1, 10, 64, 100, 300):
+                    got = g.search(q, k)
+                    want = oracle_mod.matrix_search(m, x, packed, q, k)
+                    assert bits(got) == bits(want), (d, order, m, k)
+    finally:
+        oracle_mod.set_reduce_order(0)
+
+
+def test_cosine_config1_parity(nifs, oracle_mod):
+    """BASELINE.json configs[0]: flat cosine, d=384, N=10k, limit=10 (the
+    reference's own CPU-runnable case) + the tie set of SURVEY.md 8d."""
+    n, d = 10000, 384
+    x, ids = make_corpus(n, d, 20260721, True, oracle_mod, tie_block=64)
+    packed = oracle_mod.pack_ids(ids)
+    g = GpuIndex(nifs, 2)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(20260722)
+    for i in range(20):
+        q = oracle_mod.normalize_l2(rng.uniform(-1, 1, d).astype(np.float32))
+        if i == 0:
+            q = x[n // 2]
+        got = g.search(q, 10 if i else 80)
+        want = oracle_mod.matrix_search(2, x, packed, q, 10 if i else 80)
+        assert bits(got) == bits(want), i
+        exact = x.astype(np.float64) @ q.astype(np.float64)
+        by_id = {ids[j]: exact[j] for j in range(n)}
+        assert all(close(h[1], by_id[h[0]], TOL) for h in got)
+
+
+def test_mutations_follow_the_oracle(nifs, oracle_mod):
+    """Random insert / upsert / delete / search interleaving (flat.rs:59-93):
+    swap-delete, slab growth and id-rank maintenance must stay invisible."""
+    rng = np.random.default_rng(5)
+    d = 16
+    for m in (0, 2, 3):
+        g = GpuIndex(nifs, m)
+        o = oracle_mod.FlatIndex(m)
+        live = []
+        for step in range(400):
+            op = rng.integers(0, 10)
+            if op < 5 or not live:
+                cnt = int(rng.integers(1, 40))
+                items = [("id-%d" % rng.integers(0, 600), rng.uniform(-1, 1, d).astype(np.float32)) for _ in range(cnt)]
+                g.insert_many(items)
+                o.insert_many(items)
+                live = list({*live, *[i for i, _ in items]})
+            elif op < 8:
+                victim = live.pop(int(rng.integers(0, len(live))))
+                g.delete(victim)
+                o.delete(victim)
+            else:
+                g.delete("missing-%d" % step)
+                o.delete("missing-%d" % step)
+            assert len(g) == len(o) and g.dimension == o.dimension
+            q = rng.uniform(-1, 1, d).astype(np.float32)
+            k = int(rng.integers(1, 30))
+            if len(o) == 0:
+                continue
+            assert bits(g.search(q, k)) == bits(o.search(q, k)), (m, step)
+
+
+def test_sorted_and_unsorted_id_arrival(nifs, oracle_mod):
+    """id-rank fast path (ascending appends) and the re-sort path agree."""
+    rng = np.random.default_rng(9)
+    d, n = 8, 3000
+    x = np.round(rng.uniform(-1, 1, size=(n, d)) * 4).astype(np.float32) / 4  # many exact ties
+    sorted_ids = sorted(b"k%05d" % i for i in range(n))
+    shuffled = list(sorted_ids)
+    rng.shuffle(shuffled)
+    q = x[0]
+    outs = []
+    for ids in (sorted_ids, shuffled):
+        g = GpuIndex(nifs, 0)
+        for s in range(0, n, 500):
+            g.insert_many([(ids[i], x[i]) for i in range(s, s + 500)])
+        outs.append((bits(g.search(q, 200)), bits(oracle_mod.matrix_search(0, x, oracle_mod.pack_ids(ids), q, 200))))
+    assert outs[0][0] == outs[0][1] and outs[1][0] == outs[1][1]
+
+
+@pytest.mark.parametrize("metric", [0, 2, 3])
+def test_quantized_search_matches_oracle_composition(nifs, oracle_mod, metric):
+    """collection.ex:276-295 = binary_top_k over compress_sign_bits(rows) then
+    vector_top_k (f64 cosine for metric 2) -- composed from oracle pieces."""
+    n, d = 4000, 200
+    x, ids = make_corpus(n, d, 77 + metric, metric == 2, oracle_mod)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(3)
+    obits = [(ids[i], oracle_mod.compress_sign_bits(x[i])) for i in range(n)]
+    by_id = {ids[i]: x[i] for i in range(n)}
+    for cand, limit in ((100, 10), (300, 20), (n, 10)):
+        q = rng.uniform(-1, 1, d).astype(np.float32)
+        if metric == 2:
+            q = oracle_mod.normalize_l2(q)
+        c = oracle_mod.binary_top_k(obits, oracle_mod.compress_sign_bits(q), d, cand)
+        want = oracle_mod.vector_top_k([(cid, by_id[cid]) for cid, _ in c], q, metric, d, limit)
+        got = unwrap(nifs.flat_quantized_search(g.ref, q, cand, limit))
+        assert bits(got) == bits(want), (metric, cand, limit)
+
+
+# --------------------------------------------- full-size checks (BASELINE sizes)
+def test_config2_full_size_properties_and_spot_parity(nifs, oracle_mod):
+    """BASELINE.json configs[1]: flat cosine, d=768, N=1M, single query.
+    Spot parity against the oracle on 2 queries (about 1 s of CPU each) plus
+    size-independent properties on more."""
+    n, d = 1_000_000, 768
+    rng = np.random.default_rng(20260721)
+    x = rng.uniform(-1.0, 1.0, size=(n, d)).astype(np.float32)
+    x /= np.sqrt(np.sum(x.astype(np.float64) ** 2, axis=1, keepdims=True)).astype(np.float32)
+    dup = rng.integers(0, n, n // 100)
+    x[rng.integers(0, n, n // 100)] = x[dup]
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    packed = oracle_mod.pack_ids(ids)
+    g = GpuIndex(nifs, 2)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    assert len(g) == n
+    qrng = np.random.default_rng(20260722)
+    for i in range(2):
+        q = oracle_mod.normalize_l2(qrng.uniform(-1, 1, d).astype(np.float32))
+        assert bits(g.search(q, 10)) == bits(oracle_mod.matrix_search(2, x, packed, q, 10)), i
+    id_to_row = None
+    for i in range(8):
+        row = int(qrng.integers(0, n))
+        hits = g.search(x[row], 10)
+        # idempotence / self-hit: a stored row is its own best match (or ties with its verbatim duplicates)
+        top = hits[0]
+        assert close(top[1], 1.0, 1e-5)
+        # sortedness under the reference order: (rank = 1 - raw in f32, id bytes)
+        keys = [(support.total_key(np.float32(1.0) - np.float32(h[1])), h[0]) for h in hits]
+        assert keys == sorted(keys)
+        # limit monotonicity: top-5 is a prefix of top-10
+        assert bits(g.search(x[row], 5)) == bits(hits[:5])

@@ -1,0 +1,85 @@
+"""The N>1 path on CPU: two processes, gloo backend.  Each rank owns half of
+the rows; the GPU shard search is replaced by the oracle (test stand-in), so
+this exercises exactly the exchange + merge code that runs over RCCL on the
+GPUs, and checks that the merged result equals one index over all rows."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, outq):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import oracle
+    from support import total_key
+    from vettore_amd.sharded import ShardedFlat
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        results = []
+        for metric, d, long_ids in ((2, 16, False), (0, 8, False), (3, 8, True)):
+            rng = np.random.default_rng(100 + metric)
+            n = 600
+            x = np.round(rng.uniform(-1, 1, size=(n, d)) * 8).astype(np.float32) / 8   # plenty of exact ties
+            prefix = b"x" * 70 if long_ids else b""
+            ids = [prefix + b"doc-%d" % (i + 1) for i in range(n)]
+            lo, hi = rank * n // world, (rank + 1) * n // world
+            shard = oracle.FlatIndex(metric)
+            shard.insert_matrix(ids[lo:hi], x[lo:hi])
+
+            def local(q, limit, shard=shard, metric=metric):
+                hits = shard.search(q, limit)
+                return [(i, r, total_key(oracle.rank_value(metric, r)) + (1 << 31)) for i, r in hits]
+
+            sf = ShardedFlat(None, dist, None, local_search=local)
+            for qi in range(4):
+                q = x[(qi * 37) % n] if qi % 2 == 0 else rng.uniform(-1, 1, d).astype(np.float32)
+                got = sf.search(q, 10)
+                whole = oracle.matrix_search(metric, x, oracle.pack_ids(ids), q, 10)
+                results.append(got == whole)
+        outq.put((rank, all(results), len(results)))
+    except Exception as e:  # surface the failure instead of letting the parent time out
+        outq.put((rank, False, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_search_equals_single_index():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(o[0] for o in outs) == [0, 1]
+    assert all(o[1] for o in outs) and all(o[2] == 12 for o in outs), outs
+
+
+def test_pack_unpack_roundtrip():
+    sys.path.insert(0, ROOT)
+    from vettore_amd.sharded import pack_hits, unpack_hits, merge_shards
+    hits = [(b"a", 0.5, 7), (b"b" * 80, -0.0, 9)]
+    got, flag = unpack_hits(pack_hits(hits, 4), 4)
+    assert flag and got[0] == hits[0] and got[1][0] is None and got[1][2] == 9
+    assert np.float32(got[1][1]).tobytes() == np.float32(-0.0).tobytes()
+    merged = merge_shards([[(b"b", 1.0, 5), (b"z", 2.0, 6)], [(b"a", 1.0, 5)]], 2)
+    assert merged == [(b"a", 1.0), (b"b", 1.0)]

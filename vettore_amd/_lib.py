@@ -1,0 +1,103 @@
+"""ctypes binding of libvettore_hip.so (include/vettore_flat.h).
+
+The library is the product: if it is missing or cannot be loaded, importing
+fails loudly -- there is no Python or CPU fallback for any compute call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvettore_hip.so")
+
+VT_OK = 0
+ORDER_PAIR, ORDER_AVX, ORDER_SEQ = 0, 1, 2
+
+# every symbol include/vettore_flat.h declares
+SYMBOLS = [
+    "vt_strerror", "vt_last_error", "vt_abi_version", "vt_device_count",
+    "vt_hits_len", "vt_hits_id", "vt_hits_raw", "vt_hits_rank_key", "vt_hits_free",
+    "vt_flat_new", "vt_flat_free", "vt_flat_insert", "vt_flat_insert_many", "vt_flat_delete",
+    "vt_flat_search", "vt_flat_len", "vt_flat_dimension", "vt_flat_metric",
+    "vt_flat_set_reduce_order", "vt_set_default_reduce_order",
+    "vt_flat_load_matrix", "vt_flat_load_device_matrix", "vt_flat_quantized_search",
+    "vt_vector_top_k", "vt_binary_top_k", "vt_normalize_l2", "vt_compress_sign_bits",
+    "vt_flat_set_profiling", "vt_flat_get_profile",
+]
+
+
+class Profile(C.Structure):
+    _fields_ = [
+        ("scan_launches", C.c_uint64), ("scan_ms", C.c_double), ("scan_rows", C.c_uint64),
+        ("scan_bytes", C.c_uint64), ("hamming_launches", C.c_uint64), ("hamming_ms", C.c_double),
+        ("hamming_bytes", C.c_uint64), ("merge_launches", C.c_uint64), ("merge_ms", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `make` (hipcc --offload-arch=gfx950). "
+            "vettore_amd has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    f32p, u64p, szp, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_size_t), C.c_void_p
+    L.vt_strerror.restype = C.c_char_p
+    L.vt_strerror.argtypes = [C.c_int]
+    L.vt_last_error.restype = C.c_char_p
+    L.vt_abi_version.restype = C.c_int
+    L.vt_device_count.restype = C.c_int
+    L.vt_hits_len.restype = C.c_size_t
+    L.vt_hits_len.argtypes = [vp]
+    L.vt_hits_id.restype = C.POINTER(C.c_char)
+    L.vt_hits_id.argtypes = [vp, C.c_size_t, szp]
+    L.vt_hits_raw.restype = C.c_float
+    L.vt_hits_raw.argtypes = [vp, C.c_size_t]
+    L.vt_hits_rank_key.restype = C.c_uint32
+    L.vt_hits_rank_key.argtypes = [vp, C.c_size_t]
+    L.vt_hits_free.restype = None
+    L.vt_hits_free.argtypes = [vp]
+    L.vt_flat_new.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.vt_flat_free.restype = None
+    L.vt_flat_free.argtypes = [vp]
+    L.vt_flat_insert.argtypes = [vp, C.c_char_p, C.c_size_t, f32p, C.c_size_t]
+    L.vt_flat_insert_many.argtypes = [vp, C.c_size_t, C.c_char_p, szp, f32p, szp]
+    L.vt_flat_delete.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.vt_flat_search.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.vt_flat_len.restype = C.c_size_t
+    L.vt_flat_len.argtypes = [vp]
+    L.vt_flat_dimension.restype = C.c_long
+    L.vt_flat_dimension.argtypes = [vp]
+    L.vt_flat_metric.argtypes = [vp]
+    L.vt_flat_set_reduce_order.argtypes = [vp, C.c_int]
+    L.vt_set_default_reduce_order.argtypes = [C.c_int]
+    L.vt_flat_load_matrix.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_char_p, szp, f32p]
+    L.vt_flat_load_device_matrix.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_char_p, szp, vp]
+    L.vt_flat_quantized_search.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.vt_vector_top_k.argtypes = [C.c_int, C.c_size_t, C.c_char_p, szp, f32p, szp, f32p, C.c_size_t, C.c_int,
+                                  C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.vt_binary_top_k.argtypes = [C.c_int, C.c_size_t, C.c_char_p, szp, u64p, szp, u64p, C.c_size_t, C.c_size_t,
+                                  C.c_size_t, C.POINTER(vp)]
+    L.vt_normalize_l2.argtypes = [C.c_int, C.c_size_t, C.c_size_t, f32p, f32p]
+    L.vt_compress_sign_bits.argtypes = [C.c_int, C.c_size_t, C.c_size_t, f32p, u64p]
+    L.vt_flat_set_profiling.argtypes = [vp, C.c_int]
+    L.vt_flat_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
+    _lib = L
+    return L
+
+
+def error_text(status: int) -> str:
+    """The reference's error string for statuses 1..7, else status + detail."""
+    L = load()
+    msg = L.vt_strerror(status).decode()
+    if status >= 16:
+        detail = L.vt_last_error().decode()
+        if detail:
+            msg = "%s: %s" % (msg, detail)
+    return msg

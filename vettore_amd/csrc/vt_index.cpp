@@ -1,0 +1,1098 @@
+// vt_index.cpp -- host side of libvettore_hip.so: the C ABI of
+// include/vettore_flat.h, the id table, and the orchestration of the gfx950
+// kernels in vt_device.hip.  It mirrors native/vettore/src/nifs.rs (boundary),
+// flat.rs (index semantics) and search.rs (stateless helpers) of the reference;
+// all metric arithmetic and all selection run on the GPU.
+#include "../../include/vettore_flat.h"
+#include "vt_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+int g_default_order = VT_ORDER_PAIR;
+
+int fail(int status, const std::string &detail) {
+  g_last_error = detail;
+  return status;
+}
+
+#define VT_HIP(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return fail(VT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+  } while (0)
+
+#define VT_TRY(expr)          \
+  do {                        \
+    int _s = (expr);          \
+    if (_s != VT_OK) return _s; \
+  } while (0)
+
+inline uint32_t round_up_u32(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// flat.rs:136-144 validate_vector: empty, then dimension, then finiteness.
+int validate_vector(const float *v, size_t n, long dimension) {
+  if (n == 0) return VT_ERR_EMPTY;
+  if (dimension >= 0 && n != (size_t)dimension) return VT_ERR_DIMENSION;
+  for (size_t i = 0; i < n; ++i)
+    if (!std::isfinite(v[i])) return VT_ERR_NON_FINITE;
+  return VT_OK;
+}
+
+int validate_finite(const float *v, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (!std::isfinite(v[i])) return VT_ERR_NON_FINITE;
+  return VT_OK;
+}
+
+inline bool id_less(const std::string &a, const std::string &b) { return a < b; }  // bytewise, like Rust String::cmp
+
+// Sorts `idx` with `less` on several threads (chunk sort + pairwise merges).
+template <typename Less>
+void parallel_sort(std::vector<uint32_t> &idx, Less less) {
+  const size_t n = idx.size();
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t parts = 1;
+  while (parts * 2 <= std::min<size_t>(hw ? hw : 1, 32) && n / (parts * 2) >= (1u << 16)) parts *= 2;
+  if (parts == 1) {
+    std::sort(idx.begin(), idx.end(), less);
+    return;
+  }
+  std::vector<size_t> cut(parts + 1);
+  for (size_t i = 0; i <= parts; ++i) cut[i] = n * i / parts;
+  {
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < parts; ++i)
+      th.emplace_back([&, i] { std::sort(idx.begin() + cut[i], idx.begin() + cut[i + 1], less); });
+    for (auto &t : th) t.join();
+  }
+  for (size_t width = 1; width < parts; width *= 2) {
+    std::vector<std::thread> th;
+    for (size_t i = 0; i + width < parts; i += 2 * width) {
+      const size_t lo = cut[i], mid = cut[i + width], hi = cut[std::min(i + 2 * width, parts)];
+      th.emplace_back([&, lo, mid, hi] { std::inplace_merge(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, less); });
+    }
+    for (auto &t : th) t.join();
+  }
+}
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t count = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    count = 0;
+  }
+  int ensure(size_t want) {
+    if (want <= count) return VT_OK;
+    release();
+    VT_HIP(hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T)));
+    count = want;
+    return VT_OK;
+  }
+};
+
+template <typename T>
+struct PinnedBuf {
+  T *p = nullptr;
+  size_t count = 0;
+  ~PinnedBuf() { release(); }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    count = 0;
+  }
+  int ensure(size_t want) {
+    if (want <= count) return VT_OK;
+    release();
+    VT_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(T), hipHostMallocDefault));
+    count = want;
+    return VT_OK;
+  }
+};
+
+// Result block the merge kernel fills and one D2H copy brings back.
+struct ResultBlock {
+  int status;
+  uint32_t count;
+  uint32_t pad[2];
+  vt::Entry e[vt::kMaxFusedK];
+};
+
+// Per-device execution context: stream, scratch, profiling.
+struct Ctx {
+  int device = 0;
+  int num_cus = 256;
+  int blocks_per_cu = 2;
+  hipStream_t stream = nullptr;
+  DevBuf<float> dQ;
+  DevBuf<uint64_t> dQbits;
+  DevBuf<vt::Entry> dPartial;
+  DevBuf<ResultBlock> dRes;
+  DevBuf<uint32_t> dRows;
+  DevBuf<vt::Entry> dCand;
+  PinnedBuf<float> hQ;
+  PinnedBuf<ResultBlock> hRes;
+  PinnedBuf<unsigned char> hStage;
+  bool profiling = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  vt_profile prof{};
+
+  ~Ctx() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  int init(int dev) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      return fail(VT_ERR_DEVICE, "no HIP device visible: libvettore_hip has no CPU fallback");
+    if (dev < 0 || dev >= ndev) return fail(VT_ERR_DEVICE, "device ordinal out of range");
+    device = dev;
+    VT_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    VT_HIP(hipGetDeviceProperties(&prop, dev));
+    num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = std::getenv("VT_BLOCKS_PER_CU")) {
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 8) blocks_per_cu = v;
+    }
+    VT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    VT_HIP(hipEventCreate(&ev0));
+    VT_HIP(hipEventCreate(&ev1));
+    VT_TRY(dRes.ensure(1));
+    VT_TRY(hRes.ensure(1));
+    return VT_OK;
+  }
+  int bind() {
+    VT_HIP(hipSetDevice(device));
+    return VT_OK;
+  }
+  // Tiles are dealt to waves statically, so the grid must be fully resident:
+  // blocks per CU = what LDS admits, capped (VT_BLOCKS_PER_CU overrides).
+  uint32_t grid_for(uint32_t units, size_t lds_bytes) const {
+    size_t per_cu = lds_bytes ? (160 * 1024) / lds_bytes : 8;
+    per_cu = std::max<size_t>(1, std::min<size_t>(per_cu, (size_t)blocks_per_cu));
+    const uint32_t want = (units + vt::kWavesPerBlock - 1) / vt::kWavesPerBlock;
+    return std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)(num_cus * per_cu)));
+  }
+};
+
+}  // namespace
+
+struct vt_hits {
+  std::vector<std::string> ids;
+  std::vector<float> raw;
+  std::vector<uint32_t> rank_key;
+};
+
+struct vt_flat {
+  std::mutex mu;
+  Ctx ctx;
+  int metric = 0;
+  int order = g_default_order;
+  // corpus
+  uint32_t n = 0, cap = 0;
+  long dim = -1;    // FlatIndex.dimension (None = -1)
+  uint32_t ld = 0;  // row stride of the slab in floats, multiple of 8
+  float *dX = nullptr;
+  DevBuf<uint32_t> dRank;
+  DevBuf<uint64_t> dBits;
+  bool bits_valid = false;
+  // ids
+  std::vector<std::string> ids;  // by row
+  std::unordered_map<std::string, uint32_t> row_of;
+  std::vector<uint32_t> rank_host;  // by row
+  bool ranks_clean = true;          // rank_host/dRank describe the current rows
+  std::string max_id;               // upper bound of all ids while ranks_clean
+  uint32_t max_rank = 0;
+
+  ~vt_flat() {
+    (void)hipSetDevice(ctx.device);
+    if (dX) (void)hipFree(dX);
+  }
+};
+
+namespace {
+
+// ------------------------------------------------------------------ selection
+// Selects the `want` smallest keys among `m` entries already on the device
+// (rerank candidates: m is small) and appends them to `out` in ascending order.
+// One merge launch covers want <= kMaxFusedK; larger requests repeat it on the
+// entries above the last key returned.
+int collect_from_entries(Ctx &c, const vt::Entry *dEntries, uint32_t m, size_t want, std::vector<vt::Entry> &out) {
+  uint32_t remaining = m;
+  const vt::Entry *src = dEntries;
+  DevBuf<vt::Entry> work;
+  std::vector<vt::Entry> host, keep;
+  const size_t goal = out.size() + std::min<size_t>(want, m);
+  while (remaining > 0 && out.size() < goal) {
+    const uint32_t k = (uint32_t)std::min<size_t>({(size_t)vt::kMaxFusedK, (size_t)remaining, goal - out.size()});
+    VT_HIP(hipMemsetAsync(c.dRes.p, 0, 16, c.stream));
+    VT_HIP(vt::launch_merge(src, remaining, k, c.dRes.p->e, &c.dRes.p->count, c.stream));
+    VT_HIP(hipMemcpyAsync(c.hRes.p, c.dRes.p, 16 + (size_t)k * sizeof(vt::Entry), hipMemcpyDeviceToHost, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    const uint32_t got = c.hRes.p->count;
+    for (uint32_t i = 0; i < got; ++i) out.push_back(c.hRes.p->e[i]);
+    if (got < k || out.size() >= goal) break;
+    const uint64_t lo = c.hRes.p->e[got - 1].key;
+    host.resize(remaining);
+    VT_HIP(hipMemcpy(host.data(), src, (size_t)remaining * sizeof(vt::Entry), hipMemcpyDeviceToHost));
+    keep.clear();
+    for (const auto &e : host)
+      if (e.key != vt::kEmptyKey && e.key > lo) keep.push_back(e);
+    remaining = (uint32_t)keep.size();
+    if (!remaining) break;
+    VT_TRY(work.ensure(remaining));
+    VT_HIP(hipMemcpy(work.p, keep.data(), (size_t)remaining * sizeof(vt::Entry), hipMemcpyHostToDevice));
+    src = work.p;
+  }
+  return VT_OK;
+}
+
+struct ScanJob {
+  const float *X;
+  size_t stride;
+  const uint32_t *id_rank;
+  const uint32_t *gather;
+  uint32_t gather_stride;
+  uint32_t n;
+  uint32_t d;
+  int metric;
+  int order;
+  uint32_t q_nonzero;
+};
+
+// Scan + merge passes until `want` hits are collected (ascending by key).
+// The query must already be in c.dQ (padded to round_up(d, 8)).
+int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out, bool count_profile) {
+  const size_t lds = vt::scan_lds_bytes(j.d);
+  if (lds == 0)
+    return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(j.d) + " exceeds the scan kernel's LDS panel");
+  if (j.metric == VT_JACCARD && j.d >= 4096)
+    return fail(VT_ERR_UNSUPPORTED, "jaccard on device supports d < 4096");
+  const uint32_t ntiles = (j.n + vt::kTileRows - 1) / vt::kTileRows;
+  const uint32_t blocks = c.grid_for(ntiles, lds);
+  const uint32_t waves = vt::scan_waves(blocks);
+  uint64_t lo = 0;
+  bool has_lo = false;
+  size_t total = std::min<size_t>(want, j.n);
+  while (out.size() < total) {
+    const uint32_t k = (uint32_t)std::min<size_t>((size_t)vt::kMaxFusedK, total - out.size());
+    VT_TRY(c.dPartial.ensure((size_t)waves * k));
+    vt::ScanArgs a{};
+    a.X = j.X;
+    a.stride = j.stride;
+    a.q = c.dQ.p;
+    a.id_rank = j.id_rank;
+    a.gather = j.gather;
+    a.gather_stride = j.gather_stride;
+    a.n = j.n;
+    a.d = j.d;
+    a.metric = j.metric;
+    a.order = j.order;
+    a.k = k;
+    a.lo_key = lo;
+    a.has_lo = has_lo ? 1 : 0;
+    a.q_nonzero = j.q_nonzero;
+    a.partial = c.dPartial.p;
+    a.status = &c.dRes.p->status;
+    VT_HIP(hipMemsetAsync(c.dRes.p, 0, 16, c.stream));
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+    VT_HIP(vt::launch_scan(a, blocks, c.stream));
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+    VT_HIP(vt::launch_merge(c.dPartial.p, waves * k, k, c.dRes.p->e, &c.dRes.p->count, c.stream));
+    VT_HIP(hipMemcpyAsync(c.hRes.p, c.dRes.p, 16 + (size_t)k * sizeof(vt::Entry), hipMemcpyDeviceToHost, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    if (c.profiling && count_profile) {
+      float ms = 0.f;
+      VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+      c.prof.scan_launches += 1;
+      c.prof.scan_ms += ms;
+      c.prof.scan_rows += j.n;
+      c.prof.scan_bytes += (uint64_t)j.n * j.d * 4;
+      c.prof.merge_launches += 1;
+    }
+    if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
+    const uint32_t got = c.hRes.p->count;
+    for (uint32_t i = 0; i < got; ++i) out.push_back(c.hRes.p->e[i]);
+    if (got < k) break;
+    lo = c.hRes.p->e[got - 1].key;
+    has_lo = true;
+  }
+  return VT_OK;
+}
+
+int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint32_t *id_rank, uint32_t n, uint32_t d,
+                size_t want, std::vector<vt::Entry> &out, bool count_profile) {
+  const uint32_t words = (d + 63) / 64;
+  const size_t lds = vt::hamming_lds_bytes(words);
+  if (lds == 0) return fail(VT_ERR_UNSUPPORTED, "dimension too large for the hamming kernel's LDS");
+  const uint32_t ntiles = (n + 63) / 64;
+  const uint32_t blocks = c.grid_for(ntiles, lds);
+  const uint32_t waves = vt::scan_waves(blocks);
+  uint64_t lo = 0;
+  bool has_lo = false;
+  const size_t total = std::min<size_t>(want, n);
+  while (out.size() < total) {
+    const uint32_t k = (uint32_t)std::min<size_t>((size_t)vt::kMaxFusedK, total - out.size());
+    VT_TRY(c.dPartial.ensure((size_t)waves * k));
+    vt::HammingArgs a{};
+    a.bits = bits;
+    a.qbits = qbits;
+    a.id_rank = id_rank;
+    a.n = n;
+    a.words = words;
+    a.d = d;
+    a.k = k;
+    a.lo_key = lo;
+    a.has_lo = has_lo ? 1 : 0;
+    a.partial = c.dPartial.p;
+    VT_HIP(hipMemsetAsync(c.dRes.p, 0, 16, c.stream));
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+    VT_HIP(vt::launch_hamming(a, blocks, c.stream));
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+    VT_HIP(vt::launch_merge(c.dPartial.p, waves * k, k, c.dRes.p->e, &c.dRes.p->count, c.stream));
+    VT_HIP(hipMemcpyAsync(c.hRes.p, c.dRes.p, 16 + (size_t)k * sizeof(vt::Entry), hipMemcpyDeviceToHost, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    if (c.profiling && count_profile) {
+      float ms = 0.f;
+      VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+      c.prof.hamming_launches += 1;
+      c.prof.hamming_ms += ms;
+      c.prof.hamming_bytes += (uint64_t)n * words * 8;
+    }
+    const uint32_t got = c.hRes.p->count;
+    for (uint32_t i = 0; i < got; ++i) out.push_back(c.hRes.p->e[i]);
+    if (got < k) break;
+    lo = c.hRes.p->e[got - 1].key;
+    has_lo = true;
+  }
+  return VT_OK;
+}
+
+// Uploads a query of n floats into c.dQ padded with zeros to round_up(n, 8).
+int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero) {
+  const uint32_t ld = round_up_u32((uint32_t)n, 8);
+  VT_TRY(c.dQ.ensure(ld));
+  VT_TRY(c.hQ.ensure(ld));
+  std::memcpy(c.hQ.p, q, n * sizeof(float));
+  for (size_t i = n; i < ld; ++i) c.hQ.p[i] = 0.0f;
+  if (q_nonzero) {
+    uint32_t nz = 0;
+    for (size_t i = 0; i < n; ++i) nz += q[i] != 0.0f ? 1u : 0u;
+    *q_nonzero = nz;
+  }
+  VT_HIP(hipMemcpyAsync(c.dQ.p, c.hQ.p, (size_t)ld * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  return VT_OK;
+}
+
+inline uint32_t rank_key_of(uint64_t key) { return (uint32_t)(key >> 32); }
+
+// ------------------------------------------------------------------ index ops
+int index_reserve(vt_flat *ix, uint32_t want_rows) {
+  if (want_rows <= ix->cap) return VT_OK;
+  uint64_t nc = std::max<uint64_t>(want_rows, (uint64_t)ix->cap * 2);
+  nc = std::max<uint64_t>(nc, 1024);
+  nc = (nc + vt::kTileRows - 1) / vt::kTileRows * vt::kTileRows;
+  if (nc > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
+  float *nx = nullptr;
+  VT_HIP(hipMalloc(reinterpret_cast<void **>(&nx), (size_t)nc * ix->ld * sizeof(float)));
+  if (ix->dX && ix->n)
+    VT_HIP(hipMemcpyAsync(nx, ix->dX, (size_t)ix->n * ix->ld * sizeof(float), hipMemcpyDeviceToDevice, ix->ctx.stream));
+  // rows n..cap are scanned by the last tile: keep them defined
+  VT_HIP(hipMemsetAsync(nx + (size_t)ix->n * ix->ld, 0, (size_t)(nc - ix->n) * ix->ld * sizeof(float), ix->ctx.stream));
+  VT_HIP(hipStreamSynchronize(ix->ctx.stream));
+  if (ix->dX) VT_HIP(hipFree(ix->dX));
+  ix->dX = nx;
+  ix->cap = (uint32_t)nc;
+  return VT_OK;
+}
+
+// Sets the dimension of an empty index (first insert after creation/emptying).
+int index_set_dim(vt_flat *ix, size_t d) {
+  if (d > 0x7fffffffu) return fail(VT_ERR_UNSUPPORTED, "dimension too large");
+  if (vt::scan_lds_bytes((uint32_t)d) == 0)
+    return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(d) + " exceeds the scan kernel's LDS panel");
+  const uint32_t ld = round_up_u32((uint32_t)d, 8);
+  if (ld != ix->ld) {
+    if (ix->dX) VT_HIP(hipFree(ix->dX));
+    ix->dX = nullptr;
+    ix->cap = 0;
+    ix->ld = ld;
+  }
+  ix->dim = (long)d;
+  return VT_OK;
+}
+
+// Row for `id`: existing row, or a fresh one appended (ids/rank bookkeeping).
+uint32_t index_row_for(vt_flat *ix, const char *id, size_t len, bool *is_new) {
+  std::string key(id, len);
+  auto it = ix->row_of.find(key);
+  if (it != ix->row_of.end()) {
+    *is_new = false;
+    return it->second;
+  }
+  const uint32_t r = ix->n++;
+  *is_new = true;
+  if (ix->ranks_clean) {
+    // ids arriving in ascending order (snapshot rebuild sorts by id,
+    // collection.ex:427-433) keep ranks valid without a re-sort
+    if (r == 0 || id_less(ix->max_id, key)) {
+      const uint32_t rk = r == 0 ? 0 : ix->max_rank + 1;
+      if (r != 0 && ix->max_rank == 0xFFFFFFFFu) ix->ranks_clean = false;
+      ix->rank_host.push_back(rk);
+      ix->max_rank = rk;
+      ix->max_id = key;
+    } else {
+      ix->ranks_clean = false;
+      ix->rank_host.push_back(0);
+    }
+  } else {
+    ix->rank_host.push_back(0);
+  }
+  ix->row_of.emplace(key, r);
+  ix->ids.push_back(std::move(key));
+  return r;
+}
+
+// Recomputes id_rank (position of each row's id in bytewise order) if stale
+// and makes the device copy current.
+int index_sync_ranks(vt_flat *ix, bool force_upload) {
+  if (!ix->ranks_clean) {
+    std::vector<uint32_t> order(ix->n);
+    for (uint32_t i = 0; i < ix->n; ++i) order[i] = i;
+    const std::vector<std::string> &ids = ix->ids;
+    parallel_sort(order, [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+    ix->rank_host.resize(ix->n);
+    for (uint32_t i = 0; i < ix->n; ++i) ix->rank_host[order[i]] = i;
+    if (ix->n) {
+      ix->max_id = ids[order[ix->n - 1]];
+      ix->max_rank = ix->n - 1;
+    }
+    ix->ranks_clean = true;
+    force_upload = true;
+  }
+  if (force_upload && ix->n) {
+    VT_TRY(ix->dRank.ensure(std::max<size_t>(ix->cap, ix->n)));
+    VT_HIP(hipMemcpyAsync(ix->dRank.p, ix->rank_host.data(), (size_t)ix->n * sizeof(uint32_t), hipMemcpyHostToDevice,
+                          ix->ctx.stream));
+    VT_HIP(hipStreamSynchronize(ix->ctx.stream));
+  }
+  return VT_OK;
+}
+
+struct RowSource {
+  const float *host = nullptr;    // host rows (ragged or dense)
+  const size_t *off = nullptr;    // ragged offsets; null => dense with `d`
+  const float *device = nullptr;  // dense device matrix [count][d]
+  size_t d = 0;
+};
+
+// Shared body of insert / insert_many / load_matrix: rows are already validated.
+int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *id_off, const RowSource &src) {
+  if (count == 0) return VT_OK;
+  Ctx &c = ix->ctx;
+  const size_t d = (size_t)ix->dim;
+  if ((uint64_t)ix->n + count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
+  VT_TRY(index_reserve(ix, ix->n + (uint32_t)count));
+  const uint32_t n_before = ix->n;
+  std::vector<uint32_t> target(count);
+  bool all_appended_in_order = true;
+  for (size_t i = 0; i < count; ++i) {
+    bool is_new = false;
+    target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new);
+    if (!is_new || target[i] != n_before + i) all_appended_in_order = false;
+  }
+  ix->bits_valid = false;
+  const uint32_t ld = ix->ld;
+  if (src.device) {
+    if (all_appended_in_order) {
+      float *dst = ix->dX + (size_t)n_before * ld;
+      if (ld == d) VT_HIP(hipMemcpyAsync(dst, src.device, count * d * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+      else VT_HIP(vt::launch_pad_rows(src.device, (uint32_t)count, (uint32_t)d, dst, ld, c.stream));
+    } else {
+      for (size_t i = 0; i < count; ++i) {
+        float *dst = ix->dX + (size_t)target[i] * ld;
+        VT_HIP(hipMemsetAsync(dst, 0, (size_t)ld * sizeof(float), c.stream));
+        VT_HIP(hipMemcpyAsync(dst, src.device + i * d, d * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+      }
+    }
+    VT_HIP(hipStreamSynchronize(c.stream));
+  } else {
+    // pinned staging, rows padded to ld; runs of consecutive target rows go in one copy
+    const size_t row_bytes = (size_t)ld * sizeof(float);
+    const size_t stage_rows = std::max<size_t>(1, std::min<size_t>(count, (64u << 20) / row_bytes));
+    VT_TRY(c.hStage.ensure(stage_rows * row_bytes));
+    float *stage = reinterpret_cast<float *>(c.hStage.p);
+    size_t i = 0;
+    while (i < count) {
+      const size_t chunk = std::min(stage_rows, count - i);
+      for (size_t j = 0; j < chunk; ++j) {
+        const float *row = src.off ? src.host + src.off[i + j] : src.host + (i + j) * src.d;
+        float *dst = stage + j * ld;
+        std::memcpy(dst, row, d * sizeof(float));
+        for (size_t t = d; t < ld; ++t) dst[t] = 0.0f;
+      }
+      size_t j = 0;
+      while (j < chunk) {
+        size_t e = j + 1;
+        while (e < chunk && target[i + e] == target[i + e - 1] + 1) ++e;
+        VT_HIP(hipMemcpyAsync(ix->dX + (size_t)target[i + j] * ld, stage + j * ld, (e - j) * row_bytes,
+                              hipMemcpyHostToDevice, c.stream));
+        j = e;
+      }
+      VT_HIP(hipStreamSynchronize(c.stream));
+      i += chunk;
+    }
+  }
+  // keep device ranks current when they stayed valid (sorted appends)
+  if (ix->ranks_clean && ix->n > n_before) {
+    uint32_t from = n_before;
+    if (ix->dRank.count < ix->cap) {
+      VT_TRY(ix->dRank.ensure(ix->cap));
+      from = 0;
+    }
+    VT_HIP(hipMemcpyAsync(ix->dRank.p + from, ix->rank_host.data() + from, (size_t)(ix->n - from) * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+  }
+  return VT_OK;
+}
+
+int make_hits(const vt_flat *ix, const std::vector<vt::Entry> &entries, vt_hits **out) {
+  auto h = std::make_unique<vt_hits>();
+  h->ids.reserve(entries.size());
+  for (const auto &e : entries) {
+    h->ids.push_back(ix->ids[e.row]);
+    h->raw.push_back(e.raw);
+    h->rank_key.push_back(rank_key_of(e.key));
+  }
+  *out = h.release();
+  return VT_OK;
+}
+
+int empty_hits(vt_hits **out) {
+  *out = new vt_hits();
+  return VT_OK;
+}
+
+// Per-device context for the stateless helpers.
+std::mutex g_ctx_mu;
+std::unordered_map<int, std::unique_ptr<Ctx>> g_ctx;
+int stateless_ctx(int device, Ctx **out) {
+  std::lock_guard<std::mutex> g(g_ctx_mu);
+  auto it = g_ctx.find(device);
+  if (it == g_ctx.end()) {
+    auto c = std::make_unique<Ctx>();
+    VT_TRY(c->init(device));
+    it = g_ctx.emplace(device, std::move(c)).first;
+  }
+  *out = it->second.get();
+  return (*out)->bind();
+}
+
+// id_rank for an ad-hoc batch of ids (ties between equal ids: input order).
+void ranks_for_ids(const char *ids, const size_t *id_off, size_t count, std::vector<uint32_t> &rank) {
+  std::vector<uint32_t> order(count);
+  for (size_t i = 0; i < count; ++i) order[i] = (uint32_t)i;
+  auto view = [&](uint32_t i) { return std::pair<const char *, size_t>(ids + id_off[i], id_off[i + 1] - id_off[i]); };
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    auto x = view(a), y = view(b);
+    const size_t m = std::min(x.second, y.second);
+    const int c = m ? std::memcmp(x.first, y.first, m) : 0;
+    if (c) return c < 0;
+    return x.second < y.second;
+  });
+  rank.resize(count);
+  for (size_t i = 0; i < count; ++i) rank[order[i]] = (uint32_t)i;
+}
+
+int hits_from_batch(const char *ids, const size_t *id_off, const std::vector<vt::Entry> &entries, vt_hits **out) {
+  auto h = std::make_unique<vt_hits>();
+  for (const auto &e : entries) {
+    h->ids.emplace_back(ids + id_off[e.row], id_off[e.row + 1] - id_off[e.row]);
+    h->raw.push_back(e.raw);
+    h->rank_key.push_back(rank_key_of(e.key));
+  }
+  *out = h.release();
+  return VT_OK;
+}
+
+}  // namespace
+
+// =============================================================== C ABI
+extern "C" {
+
+const char *vt_strerror(int status) {
+  switch (status) {
+    case VT_OK: return "ok";
+    case VT_ERR_EMPTY: return "vector must not be empty";
+    case VT_ERR_DIMENSION: return "dimension mismatch";
+    case VT_ERR_NON_FINITE: return "vector contains a non-finite value";
+    case VT_ERR_OVERFLOW: return "metric overflow";
+    case VT_ERR_UNKNOWN_METRIC: return "unknown metric";
+    case VT_ERR_PREFIX: return "invalid prefix dimensions";
+    case VT_ERR_DIMS_POSITIVE: return "dimensions must be positive";
+    case VT_ERR_NOMEM: return "out of memory";
+    case VT_ERR_DEVICE: return "device error";
+    case VT_ERR_UNSUPPORTED: return "unsupported on device";
+    case VT_ERR_ARGUMENT: return "bad argument";
+    default: return "unknown status";
+  }
+}
+
+const char *vt_last_error(void) { return g_last_error.c_str(); }
+int vt_abi_version(void) { return VT_ABI_VERSION; }
+
+int vt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+size_t vt_hits_len(const vt_hits *h) { return h ? h->ids.size() : 0; }
+const char *vt_hits_id(const vt_hits *h, size_t i, size_t *len) {
+  *len = h->ids[i].size();
+  return h->ids[i].data();
+}
+float vt_hits_raw(const vt_hits *h, size_t i) { return h->raw[i]; }
+uint32_t vt_hits_rank_key(const vt_hits *h, size_t i) { return h->rank_key[i]; }
+void vt_hits_free(vt_hits *h) { delete h; }
+
+int vt_flat_new(int metric_code, int device, vt_flat **out) {
+  if (!out) return VT_ERR_ARGUMENT;
+  *out = nullptr;
+  if (metric_code < VT_L2 || metric_code > VT_JACCARD) return VT_ERR_UNKNOWN_METRIC;
+  auto ix = std::make_unique<vt_flat>();
+  ix->metric = metric_code;
+  VT_TRY(ix->ctx.init(device));
+  *out = ix.release();
+  return VT_OK;
+}
+
+void vt_flat_free(vt_flat *ix) { delete ix; }
+
+size_t vt_flat_len(const vt_flat *ix) { return ix ? ix->n : 0; }
+long vt_flat_dimension(const vt_flat *ix) { return ix ? ix->dim : -1; }
+int vt_flat_metric(const vt_flat *ix) { return ix ? ix->metric : -1; }
+
+int vt_set_default_reduce_order(int order) {
+  if (order < VT_ORDER_PAIR || order > VT_ORDER_SEQ) return VT_ERR_ARGUMENT;
+  g_default_order = order;
+  return VT_OK;
+}
+
+int vt_flat_set_reduce_order(vt_flat *ix, int order) {
+  if (!ix || order < VT_ORDER_PAIR || order > VT_ORDER_SEQ) return VT_ERR_ARGUMENT;
+  std::lock_guard<std::mutex> g(ix->mu);
+  ix->order = order;
+  return VT_OK;
+}
+
+int vt_flat_insert(vt_flat *ix, const char *id, size_t id_len, const float *vector, size_t n) {
+  if (!ix || (!id && id_len) || (!vector && n)) return VT_ERR_ARGUMENT;
+  std::lock_guard<std::mutex> g(ix->mu);
+  VT_TRY(ix->ctx.bind());
+  // flat.rs:59-66
+  VT_TRY(validate_vector(vector, n, ix->dim));
+  if (ix->dim < 0) VT_TRY(index_set_dim(ix, n));
+  const size_t id_off[2] = {0, id_len};
+  const size_t val_off[2] = {0, n};
+  RowSource src;
+  src.host = vector;
+  src.off = val_off;
+  return index_store_rows(ix, 1, id ? id : "", id_off, src);
+}
+
+int vt_flat_insert_many(vt_flat *ix, size_t count, const char *ids, const size_t *id_off, const float *values,
+                        const size_t *value_off) {
+  if (!ix || (count && (!id_off || !value_off))) return VT_ERR_ARGUMENT;
+  std::lock_guard<std::mutex> g(ix->mu);
+  VT_TRY(ix->ctx.bind());
+  // flat.rs:69-85: expected = own dimension, else the first row's length;
+  // every row is validated before anything is stored.
+  long expected = ix->dim;
+  if (expected < 0 && count > 0) expected = (long)(value_off[1] - value_off[0]);
+  for (size_t i = 0; i < count; ++i)
+    VT_TRY(validate_vector(values + value_off[i], value_off[i + 1] - value_off[i], expected));
+  if (count == 0) return VT_OK;
+  if (ix->dim < 0) VT_TRY(index_set_dim(ix, (size_t)expected));
+  RowSource src;
+  src.host = values;
+  src.off = value_off;
+  return index_store_rows(ix, count, ids, id_off, src);
+}
+
+int vt_flat_load_matrix(vt_flat *ix, size_t count, size_t d, const char *ids, const size_t *id_off, const float *rows) {
+  if (!ix || (count && (!id_off || !rows))) return VT_ERR_ARGUMENT;
+  std::lock_guard<std::mutex> g(ix->mu);
+  VT_TRY(ix->ctx.bind());
+  long expected = ix->dim;
+  if (expected < 0 && count > 0) expected = (long)d;
+  for (size_t i = 0; i < count; ++i) VT_TRY(validate_vector(rows + i * d, d, expected));
+  if (count == 0) return VT_OK;
+  if (ix->dim < 0) VT_TRY(index_set_dim(ix, d));
+  RowSource src;
+  src.host = rows;
+  src.d = d;
+  return index_store_rows(ix, count, ids, id_off, src);
+}
+
+int vt_flat_load_device_matrix(vt_flat *ix, size_t count, size_t d, const char *ids, const size_t *id_off,
+                               const void *device_rows) {
+  if (!ix || (count && (!id_off || !device_rows))) return VT_ERR_ARGUMENT;
+  std::lock_guard<std::mutex> g(ix->mu);
+  Ctx &c = ix->ctx;
+  VT_TRY(c.bind());
+  if (count == 0) return VT_OK;
+  if (count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
+  long expected = ix->dim < 0 ? (long)d : ix->dim;
+  if (d == 0) return VT_ERR_EMPTY;
+  if ((long)d != expected) return VT_ERR_DIMENSION;
+  const float *rows = static_cast<const float *>(device_rows);
+  VT_HIP(hipDeviceSynchronize());  // the producer may have used another stream
+  VT_HIP(hipMemsetAsync(c.dRes.p, 0, 16, c.stream));
+  VT_HIP(vt::launch_check_finite(rows, d, (uint32_t)count, (uint32_t)d, &c.dRes.p->status, c.stream));
+  VT_HIP(hipMemcpyAsync(c.hRes.p, c.dRes.p, 16, hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  if (c.hRes.p->status != 0) return VT_ERR_NON_FINITE;
+  if (ix->dim < 0) VT_TRY(index_set_dim(ix, d));
+  RowSource src;
+  src.device = rows;
+  src.d = d;
+  return index_store_rows(ix, count, ids, id_off, src);
+}
+
+int vt_flat_delete(vt_flat *ix, const char *id, size_t id_len) {
+  if (!ix || (!id && id_len)) return VT_ERR_ARGUMENT;
+  std::lock_guard<std::mutex> g(ix->mu);
+  Ctx &c = ix->ctx;
+  VT_TRY(c.bind());
+  // flat.rs:88-93
+  auto it = ix->row_of.find(std::string(id ? id : "", id_len));
+  if (it != ix->row_of.end()) {
+    const uint32_t r = it->second, last = ix->n - 1;
+    ix->row_of.erase(it);
+    if (r != last) {
+      // swap-delete: the last row moves into the hole and keeps its rank
+      VT_HIP(hipMemcpyAsync(ix->dX + (size_t)r * ix->ld, ix->dX + (size_t)last * ix->ld, (size_t)ix->ld * sizeof(float),
+                            hipMemcpyDeviceToDevice, c.stream));
+      ix->ids[r] = std::move(ix->ids[last]);
+      ix->row_of[ix->ids[r]] = r;
+      ix->rank_host[r] = ix->rank_host[last];
+      if (ix->ranks_clean && ix->dRank.p)
+        VT_HIP(hipMemcpyAsync(ix->dRank.p + r, ix->dRank.p + last, sizeof(uint32_t), hipMemcpyDeviceToDevice, c.stream));
+    }
+    VT_HIP(hipMemsetAsync(ix->dX + (size_t)last * ix->ld, 0, (size_t)ix->ld * sizeof(float), c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    ix->ids.pop_back();
+    ix->rank_host.pop_back();
+    ix->n -= 1;
+    ix->bits_valid = false;
+  }
+  if (ix->n == 0) {
+    ix->dim = -1;
+    ix->ranks_clean = true;
+    ix->max_id.clear();
+    ix->max_rank = 0;
+  }
+  return VT_OK;
+}
+
+int vt_flat_search(vt_flat *ix, const float *query, size_t n, size_t limit, vt_hits **out) {
+  if (!ix || !out || (!query && n)) return VT_ERR_ARGUMENT;
+  *out = nullptr;
+  std::lock_guard<std::mutex> g(ix->mu);
+  Ctx &c = ix->ctx;
+  VT_TRY(c.bind());
+  // flat.rs:96-124
+  if (limit == 0) return empty_hits(out);
+  VT_TRY(validate_vector(query, n, ix->dim));
+  if (ix->n == 0) return empty_hits(out);
+  VT_TRY(index_sync_ranks(ix, false));
+  uint32_t qnz = 0;
+  VT_TRY(upload_query(c, query, n, &qnz));
+  ScanJob j{};
+  j.X = ix->dX;
+  j.stride = ix->ld;
+  j.id_rank = ix->dRank.p;
+  j.gather = nullptr;
+  j.gather_stride = 0;
+  j.n = ix->n;
+  j.d = (uint32_t)ix->dim;
+  j.metric = ix->metric;
+  j.order = ix->order;
+  j.q_nonzero = qnz;
+  std::vector<vt::Entry> entries;
+  VT_TRY(run_scan(c, j, limit, entries, true));
+  return make_hits(ix, entries, out);
+}
+
+int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out) {
+  if (!ix || !out || (!query && n)) return VT_ERR_ARGUMENT;
+  *out = nullptr;
+  std::lock_guard<std::mutex> g(ix->mu);
+  Ctx &c = ix->ctx;
+  VT_TRY(c.bind());
+  // collection.ex:276-295: prepare_query validates the query against the
+  // collection's dimension; an empty store yields no candidates.
+  VT_TRY(validate_vector(query, n, ix->dim));
+  if (ix->n == 0 || candidates == 0 || limit == 0) return empty_hits(out);
+  const uint32_t d = (uint32_t)ix->dim;
+  const uint32_t words = (d + 63) / 64;
+  VT_TRY(index_sync_ranks(ix, false));
+  if (!ix->bits_valid) {
+    // compress_sign_bits of every stored row (collection.ex:926): kept in HBM
+    VT_TRY(ix->dBits.ensure((size_t)std::max<uint32_t>(ix->cap, ix->n) * words + 2));
+    VT_HIP(vt::launch_sign_pack(ix->dX, ix->ld, ix->n, d, ix->dBits.p, c.stream));
+    ix->bits_valid = true;
+  }
+  uint32_t qnz = 0;
+  VT_TRY(upload_query(c, query, n, &qnz));
+  VT_TRY(c.dQbits.ensure(words));
+  VT_HIP(vt::launch_sign_pack(c.dQ.p, round_up_u32(d, 8), 1, d, c.dQbits.p, c.stream));
+  // stage 1: binary_top_k (search.rs:76-92)
+  std::vector<vt::Entry> cand;
+  VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits.p, ix->dRank.p, ix->n, d, candidates, cand, true));
+  if (cand.empty()) return empty_hits(out);
+  // stage 2: vector_top_k over the candidates (search.rs:38-73)
+  std::vector<uint32_t> rows(cand.size());
+  for (size_t i = 0; i < cand.size(); ++i) rows[i] = cand[i].row;
+  VT_TRY(c.dRows.ensure(rows.size()));
+  VT_HIP(hipMemcpyAsync(c.dRows.p, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+  std::vector<vt::Entry> entries;
+  if (ix->metric == VT_COSINE) {
+    VT_TRY(c.dCand.ensure(rows.size()));
+    vt::CosineRerankArgs a{};
+    a.X = ix->dX;
+    a.stride = ix->ld;
+    a.q = c.dQ.p;
+    a.id_rank = ix->dRank.p;
+    a.gather = c.dRows.p;
+    a.gather_stride = 1;
+    a.n = (uint32_t)rows.size();
+    a.d = d;
+    a.out = c.dCand.p;
+    a.status = &c.dRes.p->status;
+    VT_HIP(hipMemsetAsync(c.dRes.p, 0, 16, c.stream));
+    VT_HIP(vt::launch_cosine_rerank(a, c.stream));
+    VT_HIP(hipMemcpyAsync(c.hRes.p, c.dRes.p, 16, hipMemcpyDeviceToHost, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
+    VT_TRY(collect_from_entries(c, c.dCand.p, (uint32_t)rows.size(), limit, entries));
+  } else {
+    ScanJob j{};
+    j.X = ix->dX;
+    j.stride = ix->ld;
+    j.id_rank = ix->dRank.p;
+    j.gather = c.dRows.p;
+    j.gather_stride = 1;
+    j.n = (uint32_t)rows.size();
+    j.d = d;
+    j.metric = ix->metric;
+    j.order = ix->order;
+    j.q_nonzero = qnz;
+    VT_TRY(run_scan(c, j, limit, entries, false));
+  }
+  return make_hits(ix, entries, out);
+}
+
+int vt_vector_top_k(int device, size_t count, const char *ids, const size_t *id_off, const float *values,
+                    const size_t *value_off, const float *query, size_t nq, int metric_code, size_t dimensions,
+                    size_t limit, vt_hits **out) {
+  if (!out || (count && (!id_off || !value_off))) return VT_ERR_ARGUMENT;
+  *out = nullptr;
+  // nifs.rs:158-161: metric decode first, then search.rs:38-73
+  if (metric_code < VT_L2 || metric_code > VT_JACCARD) return VT_ERR_UNKNOWN_METRIC;
+  if (dimensions == 0 || dimensions > nq) return VT_ERR_PREFIX;
+  VT_TRY(validate_finite(query, dimensions));
+  // the reference walks the batch in order and stops at the first error;
+  // rows before the first invalid one may still overflow and win the race
+  size_t good = count;
+  int first_error = VT_OK;
+  for (size_t i = 0; i < count; ++i) {
+    const size_t len = value_off[i + 1] - value_off[i];
+    int e = VT_OK;
+    if (dimensions > len) e = VT_ERR_DIMENSION;
+    else e = validate_finite(values + value_off[i], dimensions);
+    if (e != VT_OK) {
+      good = i;
+      first_error = e;
+      break;
+    }
+  }
+  if (dimensions > 0x7fffffffu || vt::scan_lds_bytes((uint32_t)dimensions) == 0)
+    return fail(VT_ERR_UNSUPPORTED, "prefix dimension exceeds the scan kernel's LDS panel");
+  if (count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
+  Ctx *cp = nullptr;
+  VT_TRY(stateless_ctx(device, &cp));
+  Ctx &c = *cp;
+  std::lock_guard<std::mutex> g(g_ctx_mu);
+  std::vector<vt::Entry> entries;
+  if (good > 0) {
+    const uint32_t d = (uint32_t)dimensions, ld = round_up_u32(d, 8);
+    const uint32_t n = (uint32_t)good;
+    const uint32_t cap = round_up_u32(n, vt::kTileRows);
+    std::vector<float> packed((size_t)cap * ld, 0.0f);
+    for (size_t i = 0; i < good; ++i) std::memcpy(&packed[i * ld], values + value_off[i], (size_t)d * sizeof(float));
+    std::vector<uint32_t> rank;
+    ranks_for_ids(ids, id_off, good, rank);
+    DevBuf<float> dX;
+    DevBuf<uint32_t> dRank, dRows;
+    VT_TRY(dX.ensure(packed.size()));
+    VT_TRY(dRank.ensure(n));
+    VT_HIP(hipMemcpyAsync(dX.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, c.stream));
+    VT_HIP(hipMemcpyAsync(dRank.p, rank.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+    uint32_t qnz = 0;
+    VT_TRY(upload_query(c, query, dimensions, &qnz));
+    const size_t want = first_error == VT_OK ? limit : (size_t)1;  // only the overflow flag matters then
+    if (metric_code == VT_COSINE) {
+      std::vector<uint32_t> rows(n);
+      for (uint32_t i = 0; i < n; ++i) rows[i] = i;
+      VT_TRY(dRows.ensure(n));
+      VT_HIP(hipMemcpyAsync(dRows.p, rows.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+      VT_TRY(c.dCand.ensure(n));
+      vt::CosineRerankArgs a{};
+      a.X = dX.p;
+      a.stride = ld;
+      a.q = c.dQ.p;
+      a.id_rank = dRank.p;
+      a.gather = dRows.p;
+      a.gather_stride = 1;
+      a.n = n;
+      a.d = d;
+      a.out = c.dCand.p;
+      a.status = &c.dRes.p->status;
+      VT_HIP(hipMemsetAsync(c.dRes.p, 0, 16, c.stream));
+      VT_HIP(vt::launch_cosine_rerank(a, c.stream));
+      VT_HIP(hipMemcpyAsync(c.hRes.p, c.dRes.p, 16, hipMemcpyDeviceToHost, c.stream));
+      VT_HIP(hipStreamSynchronize(c.stream));
+      if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
+      if (limit > 0) VT_TRY(collect_from_entries(c, c.dCand.p, n, want, entries));
+    } else {
+      ScanJob j{};
+      j.X = dX.p;
+      j.stride = ld;
+      j.id_rank = dRank.p;
+      j.n = n;
+      j.d = d;
+      j.metric = metric_code;
+      j.order = g_default_order;
+      j.q_nonzero = qnz;
+      // limit == 0 still has to surface "metric overflow": scan for one hit
+      VT_TRY(run_scan(c, j, std::max<size_t>(want, 1), entries, false));
+      if (limit == 0) entries.clear();
+    }
+  }
+  if (first_error != VT_OK) return first_error;
+  return hits_from_batch(ids, id_off, entries, out);
+}
+
+int vt_binary_top_k(int device, size_t count, const char *ids, const size_t *id_off, const uint64_t *words,
+                    const size_t *word_off, const uint64_t *query, size_t nq, size_t dimensions, size_t limit,
+                    vt_hits **out) {
+  if (!out || (count && (!id_off || !word_off))) return VT_ERR_ARGUMENT;
+  *out = nullptr;
+  // search.rs:82-84: the query is validated against itself first
+  const size_t W = (dimensions + 63) / 64;
+  if (dimensions == 0) return VT_ERR_DIMS_POSITIVE;
+  if (nq != W) return VT_ERR_DIMENSION;
+  for (size_t i = 0; i < count; ++i)
+    if (word_off[i + 1] - word_off[i] != W) return VT_ERR_DIMENSION;
+  if (count == 0 || limit == 0) return empty_hits(out);
+  if (count > 0xFFFFFFF0ull || dimensions > 0x7fffffffu) return fail(VT_ERR_UNSUPPORTED, "batch too large");
+  Ctx *cp = nullptr;
+  VT_TRY(stateless_ctx(device, &cp));
+  Ctx &c = *cp;
+  std::lock_guard<std::mutex> g(g_ctx_mu);
+  const uint32_t n = (uint32_t)count;
+  std::vector<uint64_t> packed((size_t)n * W + 2, 0);
+  for (size_t i = 0; i < count; ++i) std::memcpy(&packed[i * W], words + word_off[i], W * sizeof(uint64_t));
+  std::vector<uint32_t> rank;
+  ranks_for_ids(ids, id_off, count, rank);
+  DevBuf<uint64_t> dBits, dQ;
+  DevBuf<uint32_t> dRank;
+  VT_TRY(dBits.ensure(packed.size()));
+  VT_TRY(dQ.ensure(W));
+  VT_TRY(dRank.ensure(n));
+  VT_HIP(hipMemcpyAsync(dBits.p, packed.data(), packed.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
+  VT_HIP(hipMemcpyAsync(dQ.p, query, W * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
+  VT_HIP(hipMemcpyAsync(dRank.p, rank.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+  std::vector<vt::Entry> entries;
+  VT_TRY(run_hamming(c, dBits.p, dQ.p, dRank.p, n, (uint32_t)dimensions, limit, entries, false));
+  return hits_from_batch(ids, id_off, entries, out);
+}
+
+int vt_normalize_l2(int device, size_t count, size_t d, const float *in, float *out) {
+  if ((count && d) && (!in || !out)) return VT_ERR_ARGUMENT;
+  // distances.rs:350-361: finiteness first
+  VT_TRY(validate_finite(in, count * d));
+  if (count == 0 || d == 0) return VT_OK;
+  if (count > 0xFFFFFFF0ull || d > 0x7fffffffu) return fail(VT_ERR_UNSUPPORTED, "batch too large");
+  Ctx *cp = nullptr;
+  VT_TRY(stateless_ctx(device, &cp));
+  Ctx &c = *cp;
+  std::lock_guard<std::mutex> g(g_ctx_mu);
+  DevBuf<float> dIn, dOut;
+  VT_TRY(dIn.ensure(count * d));
+  VT_TRY(dOut.ensure(count * d));
+  VT_HIP(hipMemcpyAsync(dIn.p, in, count * d * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  VT_HIP(vt::launch_normalize_l2(dIn.p, (uint32_t)count, (uint32_t)d, dOut.p, c.stream));
+  VT_HIP(hipMemcpyAsync(out, dOut.p, count * d * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  return VT_OK;
+}
+
+int vt_compress_sign_bits(int device, size_t count, size_t d, const float *in, uint64_t *out) {
+  if ((count && d) && (!in || !out)) return VT_ERR_ARGUMENT;
+  if (count == 0 || d == 0) return VT_OK;
+  if (count > 0xFFFFFFF0ull || d > 0x7fffffffu) return fail(VT_ERR_UNSUPPORTED, "batch too large");
+  Ctx *cp = nullptr;
+  VT_TRY(stateless_ctx(device, &cp));
+  Ctx &c = *cp;
+  std::lock_guard<std::mutex> g(g_ctx_mu);
+  const size_t W = (d + 63) / 64;
+  DevBuf<float> dIn;
+  DevBuf<uint64_t> dOut;
+  VT_TRY(dIn.ensure(count * d));
+  VT_TRY(dOut.ensure(count * W));
+  VT_HIP(hipMemcpyAsync(dIn.p, in, count * d * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  VT_HIP(vt::launch_sign_pack(dIn.p, d, (uint32_t)count, (uint32_t)d, dOut.p, c.stream));
+  VT_HIP(hipMemcpyAsync(out, dOut.p, count * W * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  return VT_OK;
+}
+
+int vt_flat_set_profiling(vt_flat *ix, int enabled) {
+  if (!ix) return VT_ERR_ARGUMENT;
+  std::lock_guard<std::mutex> g(ix->mu);
+  ix->ctx.profiling = enabled != 0;
+  return VT_OK;
+}
+
+int vt_flat_get_profile(vt_flat *ix, vt_profile *out, int reset) {
+  if (!ix || !out) return VT_ERR_ARGUMENT;
+  std::lock_guard<std::mutex> g(ix->mu);
+  *out = ix->ctx.prof;
+  if (reset) ix->ctx.prof = vt_profile{};
+  return VT_OK;
+}
+
+}  // extern "C"

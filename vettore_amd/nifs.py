@@ -1,0 +1,300 @@
+"""Python mirror of `Vettore.Nifs` for the flat-index hot path
+(/root/reference/lib/vettore_nifs.ex:58-174, native/vettore/src/nifs.rs).
+
+Same function names, argument meaning and return shapes as the Elixir stubs,
+with Elixir terms spelled as Python values:
+
+    {:ok, value}        -> ("ok", value)
+    {:ok, {}}           -> ("ok", ())          (Rustler's encoding of Ok(()))
+    {:error, "string"}  -> ("error", "string") (the reference's exact strings)
+    bare reference      -> FlatRef
+
+Every call goes through the C ABI of libvettore_hip.so into HIP kernels; badly
+typed arguments raise (the NIF's ArgumentError / badarg).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+DEVICE = 0  # HIP device ordinal used by flat_new_* and the stateless helpers
+USIZE_MAX = (1 << 64) - 1
+_F32_MAX = float(np.finfo(np.float32).max)
+
+METRICS = [
+    "l2", "l2_squared", "cosine", "inner_product", "negative_inner_product",
+    "manhattan", "chebyshev", "hamming", "jaccard",
+]
+METRIC_CODE = {name: i for i, name in enumerate(METRICS)}
+
+
+def set_device(device: int):
+    global DEVICE
+    DEVICE = int(device)
+
+
+class FlatRef:
+    """The `reference()` returned by flat_new_*: owns a vt_flat handle; the
+    finalizer plays the role of the ResourceArc destructor."""
+
+    def __init__(self, handle, metric: int):
+        self._h = handle
+        self.metric = metric
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.load().vt_flat_free(h)
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise ValueError("flat index already freed")
+        return self._h
+
+    def __len__(self):
+        return _lib.load().vt_flat_len(self.handle)
+
+    @property
+    def dimension(self):
+        d = _lib.load().vt_flat_dimension(self.handle)
+        return None if d < 0 else d
+
+
+def _bytes(x) -> bytes:
+    if isinstance(x, str):
+        return x.encode()
+    if isinstance(x, (bytes, bytearray)):
+        return bytes(x)
+    raise TypeError("badarg: id must be a binary")
+
+
+def _f32_list(v) -> np.ndarray:
+    """Rustler decodes [float] into Vec<f32>: non-floats and doubles outside
+    the f32 range are badarg; NaN/inf doubles narrow to f32 NaN/inf."""
+    a = np.asarray(v, dtype=np.float64).reshape(-1) if not isinstance(v, np.ndarray) else v.reshape(-1)
+    if a.dtype != np.float32:
+        a64 = np.asarray(a, dtype=np.float64)
+        finite = np.isfinite(a64)
+        if np.any(np.abs(a64[finite]) > _F32_MAX):
+            raise TypeError("badarg: float out of f32 range")
+        with np.errstate(over="ignore"):
+            a = a64.astype(np.float32)
+    return np.ascontiguousarray(a)
+
+
+def _u64_list(v) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(v, dtype=np.uint64).reshape(-1))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _szp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_size_t))
+
+
+def _pack_ids(ids: Iterable) -> Tuple[bytes, np.ndarray]:
+    bs = [_bytes(i) for i in ids]
+    off = np.zeros(len(bs) + 1, dtype=np.uintp)
+    if bs:
+        off[1:] = np.cumsum([len(b) for b in bs])
+    return b"".join(bs), off
+
+
+def _pack_ragged(rows: Sequence[np.ndarray], dtype) -> Tuple[np.ndarray, np.ndarray]:
+    off = np.zeros(len(rows) + 1, dtype=np.uintp)
+    if rows:
+        off[1:] = np.cumsum([r.size for r in rows])
+    vals = np.ascontiguousarray(np.concatenate(rows)) if rows and off[-1] else np.zeros(0, dtype)
+    return vals.astype(dtype, copy=False), off
+
+
+def _err(status: int):
+    return ("error", _lib.error_text(status))
+
+
+def _take_hits(h) -> List[Tuple[bytes, float]]:
+    L = _lib.load()
+    out = []
+    try:
+        ln = C.c_size_t()
+        for i in range(L.vt_hits_len(h)):
+            p = L.vt_hits_id(h, i, C.byref(ln))
+            out.append((C.string_at(p, ln.value), float(L.vt_hits_raw(h, i))))
+    finally:
+        L.vt_hits_free(h)
+    return out
+
+
+def _take_hits_with_keys(h):
+    L = _lib.load()
+    out = []
+    try:
+        ln = C.c_size_t()
+        for i in range(L.vt_hits_len(h)):
+            p = L.vt_hits_id(h, i, C.byref(ln))
+            out.append((C.string_at(p, ln.value), float(L.vt_hits_raw(h, i)), int(L.vt_hits_rank_key(h, i))))
+    finally:
+        L.vt_hits_free(h)
+    return out
+
+
+# ----------------------------------------------------------------- flat_new_*
+def _flat_new(metric: int) -> FlatRef:
+    h = C.c_void_p()
+    st = _lib.load().vt_flat_new(metric, DEVICE, C.byref(h))
+    if st != 0:
+        raise RuntimeError("flat_new: " + _lib.error_text(st))
+    return FlatRef(h, metric)
+
+
+def flat_new_l2(): return _flat_new(0)                       # nifs.rs:200-204
+def flat_new_l2_squared(): return _flat_new(1)               # nifs.rs:206-210
+def flat_new_cosine(): return _flat_new(2)                   # nifs.rs:212-216
+def flat_new_inner_product(): return _flat_new(3)            # nifs.rs:218-222
+def flat_new_negative_inner_product(): return _flat_new(4)   # nifs.rs:224-228
+def flat_new_manhattan(): return _flat_new(5)                # nifs.rs:230-234
+def flat_new_chebyshev(): return _flat_new(6)                # nifs.rs:236-240
+def flat_new_hamming(): return _flat_new(7)                  # nifs.rs:242-246
+def flat_new_jaccard(): return _flat_new(8)                  # nifs.rs:248-252
+
+
+def flat_insert(index: FlatRef, id_, vector):
+    """nifs.rs:259-271."""
+    b, v = _bytes(id_), _f32_list(vector)
+    st = _lib.load().vt_flat_insert(index.handle, b, len(b), _fp(v), v.size)
+    return ("ok", ()) if st == 0 else _err(st)
+
+
+def flat_insert_many(index: FlatRef, vectors: Sequence[Tuple[object, Sequence[float]]]):
+    """nifs.rs:273-284."""
+    ids, ioff = _pack_ids(i for i, _ in vectors)
+    vals, voff = _pack_ragged([_f32_list(v) for _, v in vectors], np.float32)
+    st = _lib.load().vt_flat_insert_many(index.handle, len(vectors), ids, _szp(ioff), _fp(vals), _szp(voff))
+    return ("ok", ()) if st == 0 else _err(st)
+
+
+def flat_delete(index: FlatRef, id_):
+    """nifs.rs:286-295."""
+    b = _bytes(id_)
+    st = _lib.load().vt_flat_delete(index.handle, b, len(b))
+    return ("ok", ()) if st == 0 else _err(st)
+
+
+def flat_search(index: FlatRef, query, limit: int):
+    """nifs.rs:297-309 -> [(id, raw)] ascending by (rank, id)."""
+    if not isinstance(limit, int) or limit < 0 or limit > USIZE_MAX:
+        raise TypeError("badarg: limit must fit usize")
+    q = _f32_list(query)
+    h = C.c_void_p()
+    st = _lib.load().vt_flat_search(index.handle, _fp(q), q.size, limit, C.byref(h))
+    return ("ok", _take_hits(h)) if st == 0 else _err(st)
+
+
+def flat_search_with_keys(index: FlatRef, query, limit: int):
+    """flat_search plus each hit's rank sort key (for cross-shard merges)."""
+    q = _f32_list(query)
+    h = C.c_void_p()
+    st = _lib.load().vt_flat_search(index.handle, _fp(q), q.size, limit, C.byref(h))
+    return ("ok", _take_hits_with_keys(h)) if st == 0 else _err(st)
+
+
+# -------------------------------------------------------- stateless helpers
+def vector_top_k(vectors, query, metric_code: int, dimensions: int, limit: int):
+    """nifs.rs:151-162."""
+    if not isinstance(metric_code, int) or not 0 <= metric_code <= 255:
+        raise TypeError("badarg: metric_code is a u8")
+    ids, ioff = _pack_ids(i for i, _ in vectors)
+    vals, voff = _pack_ragged([_f32_list(v) for _, v in vectors], np.float32)
+    q = _f32_list(query)
+    h = C.c_void_p()
+    st = _lib.load().vt_vector_top_k(DEVICE, len(vectors), ids, _szp(ioff), _fp(vals), _szp(voff), _fp(q), q.size,
+                                     metric_code, dimensions, limit, C.byref(h))
+    return ("ok", _take_hits(h)) if st == 0 else _err(st)
+
+
+def binary_top_k(vectors, query, dimensions: int, limit: int):
+    """nifs.rs:164-175."""
+    ids, ioff = _pack_ids(i for i, _ in vectors)
+    vals, voff = _pack_ragged([_u64_list(v) for _, v in vectors], np.uint64)
+    q = _u64_list(query)
+    h = C.c_void_p()
+    st = _lib.load().vt_binary_top_k(DEVICE, len(vectors), ids, _szp(ioff), _up(vals), _szp(voff), _up(q), q.size,
+                                     dimensions, limit, C.byref(h))
+    return ("ok", _take_hits(h)) if st == 0 else _err(st)
+
+
+def normalize_l2(vector):
+    """nifs.rs:107-111."""
+    v = _f32_list(vector)
+    out = np.empty_like(v)
+    st = _lib.load().vt_normalize_l2(DEVICE, 1, v.size, _fp(v), _fp(out))
+    return ("ok", out) if st == 0 else _err(st)
+
+
+def compress_sign_bits(vector):
+    """nifs.rs:125-129: bare list of u64 words."""
+    v = _f32_list(vector)
+    words = np.zeros((v.size + 63) // 64, dtype=np.uint64)
+    st = _lib.load().vt_compress_sign_bits(DEVICE, 1, v.size, _fp(v), _up(words))
+    if st != 0:
+        raise RuntimeError("compress_sign_bits: " + _lib.error_text(st))
+    return [int(w) for w in words]
+
+
+# -------------------------------------------- bulk / device-side extensions
+def flat_load_matrix(index: FlatRef, ids: Sequence, matrix: np.ndarray):
+    """insert_many of equal-length rows from one dense host matrix."""
+    m = np.ascontiguousarray(matrix, dtype=np.float32)
+    idb, ioff = _pack_ids(ids)
+    st = _lib.load().vt_flat_load_matrix(index.handle, m.shape[0], m.shape[1], idb, _szp(ioff), _fp(m.reshape(-1)))
+    return ("ok", ()) if st == 0 else _err(st)
+
+
+def flat_load_device_matrix(index: FlatRef, ids_packed: Tuple[bytes, np.ndarray], device_ptr: int, count: int, d: int):
+    """insert_many of `count` rows already resident in this device's HBM
+    (row-major f32 [count][d] at `device_ptr`)."""
+    idb, ioff = ids_packed
+    st = _lib.load().vt_flat_load_device_matrix(index.handle, count, d, idb, _szp(ioff), C.c_void_p(device_ptr))
+    return ("ok", ()) if st == 0 else _err(st)
+
+
+def flat_quantized_search(index: FlatRef, query, candidates: int, limit: int):
+    """collection.ex:276-295 as one native call on the resident corpus."""
+    q = _f32_list(query)
+    h = C.c_void_p()
+    st = _lib.load().vt_flat_quantized_search(index.handle, _fp(q), q.size, candidates, limit, C.byref(h))
+    return ("ok", _take_hits(h)) if st == 0 else _err(st)
+
+
+def flat_set_reduce_order(index: FlatRef, order: int):
+    st = _lib.load().vt_flat_set_reduce_order(index.handle, order)
+    return "ok" if st == 0 else _err(st)
+
+
+def set_default_reduce_order(order: int):
+    st = _lib.load().vt_set_default_reduce_order(order)
+    return "ok" if st == 0 else _err(st)
+
+
+def flat_set_profiling(index: FlatRef, enabled: bool):
+    _lib.load().vt_flat_set_profiling(index.handle, 1 if enabled else 0)
+
+
+def flat_get_profile(index: FlatRef, reset: bool = False) -> dict:
+    p = _lib.Profile()
+    _lib.load().vt_flat_get_profile(index.handle, C.byref(p), 1 if reset else 0)
+    return {name: getattr(p, name) for name, _ in _lib.Profile._fields_}
+
+
+pack_ids = _pack_ids
