@@ -7,7 +7,7 @@ ARCH    ?= gfx950
 CSRC    := vettore_amd/csrc
 LIBDIR  := vettore_amd/lib
 # -ffp-contract=off: the reference never fuses a*b+c; the kernels must not either.
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function
 
 all: $(LIBDIR)/libvettore_hip.so oracle
 

@@ -27,6 +27,9 @@
 
 #include <float.h>
 
+// rustc never contracts a*b+c; neither may this file, whatever the command line says.
+#pragma clang fp contract(off)
+
 namespace vt {
 
 namespace {
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       float raw = acc;
       const int metric = a.metric;
       if (metric == M_NIP) raw = -acc;
-      else if (metric == M_L2) raw = finite_f32(acc) ? __fsqrt_rn(acc) : acc;
+      else if (metric == M_L2) raw = finite_f32(acc) ? __builtin_sqrtf(acc) : acc;
       else if (metric == M_HAM) raw = acc;
       else if (metric == M_JAC) {
         const uint32_t tot = (uint32_t)acc;
