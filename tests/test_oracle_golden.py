@@ -320,3 +320,10 @@ def test_reduce_orders_differ_only_in_last_bits(oracle_mod):
     oracle_mod.set_reduce_order(0)
     exact = float(np.dot(a.astype(np.float64), c.astype(np.float64)))
     assert all(close(v, exact, 2e-6) for v in vals)
+
+
+def test_order_probe_separates_the_three_orders(oracle_mod):
+    """the probe a maintainer runs on the reference build."""
+    import order_probe
+    t = order_probe.table()
+    assert {k: v[0] for k, v in t.items()} == {"PAIR": 0xbfefdf3c, "AVX": 0x40480000, "SEQ": 0x3f9020c4}
