@@ -7,11 +7,16 @@ ARCH    ?= gfx950
 CSRC    := vettore_amd/csrc
 LIBDIR  := vettore_amd/lib
 # -ffp-contract=off: the reference never fuses a*b+c; the kernels must not either.
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
+            -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function
+
+DEVSRC  := vt_kernels vt_scan_dot vt_scan_l2 vt_scan_misc vt_scan_general
+DEVOBJ  := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(DEVSRC)))
+DEVHDR  := $(CSRC)/vt_device.h $(CSRC)/vt_common.cuh $(CSRC)/vt_scan.cuh
 
 all: $(LIBDIR)/libvettore_hip.so oracle
 
-$(LIBDIR)/vt_device.o: $(CSRC)/vt_device.hip $(CSRC)/vt_device.h
+$(LIBDIR)/%.o: $(CSRC)/%.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -19,7 +24,7 @@ $(LIBDIR)/vt_index.o: $(CSRC)/vt_index.cpp $(CSRC)/vt_device.h include/vettore_f
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
-$(LIBDIR)/libvettore_hip.so: $(LIBDIR)/vt_device.o $(LIBDIR)/vt_index.o
+$(LIBDIR)/libvettore_hip.so: $(DEVOBJ) $(LIBDIR)/vt_index.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
 
 oracle:

@@ -321,7 +321,7 @@ def make_corpus(n, d, seed, normalize, oracle_mod, dup_frac=0.01, tie_block=0):
     return x, ids
 
 
-@pytest.mark.parametrize("d", [8, 24, 100, 7, 384])
+@pytest.mark.parametrize("d", [8, 24, 100, 7, 200, 384])
 @pytest.mark.parametrize("order", ORDERS)
 def test_random_parity_all_metrics(nifs, oracle_mod, d, order):
     n = 5000
@@ -343,6 +343,27 @@ def test_random_parity_all_metrics(nifs, oracle_mod, d, order):
                     assert bits(got) == bits(want), (d, order, m, k)
     finally:
         oracle_mod.set_reduce_order(0)
+
+
+@pytest.mark.parametrize("d", [1024, 1536, 1540, 3072, 4100])
+def test_wide_rows_use_column_panels(nifs, oracle_mod, d):
+    """Rows wider than one LDS panel (96 chunks) are walked in column panels with
+    the running sum carried across them; the tail chunk lands in the last one."""
+    n = 1500
+    x, ids = make_corpus(n, d, 99 + d, False, oracle_mod, tie_block=20)
+    packed = oracle_mod.pack_ids(ids)
+    rng = np.random.default_rng(d)
+    q = rng.uniform(-1, 1, d).astype(np.float32)
+    for order in ORDERS:
+        oracle_mod.set_reduce_order(order)
+        try:
+            for m in (0, 2, 3, 5, 6, 7):
+                g = GpuIndex(nifs, m, order)
+                unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+                for k in (10, 100):
+                    assert bits(g.search(q, k)) == bits(oracle_mod.matrix_search(m, x, packed, q, k)), (d, order, m, k)
+        finally:
+            oracle_mod.set_reduce_order(0)
 
 
 def test_cosine_config1_parity(nifs, oracle_mod):

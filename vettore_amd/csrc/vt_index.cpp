@@ -120,19 +120,13 @@ struct PinnedBuf {
   int ensure(size_t want) {
     if (want <= count) return VT_OK;
     release();
-    VT_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(T), hipHostMallocDefault));
+    VT_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(T), hipHostMallocMapped));
     count = want;
     return VT_OK;
   }
 };
 
-// Result block the merge kernel fills and one D2H copy brings back.
-struct ResultBlock {
-  int status;
-  uint32_t count;
-  uint32_t pad[2];
-  vt::Entry e[vt::kMaxFusedK];
-};
+using vt::ResultBlock;
 
 // Per-device execution context: stream, scratch, profiling.
 struct Ctx {
@@ -142,12 +136,16 @@ struct Ctx {
   hipStream_t stream = nullptr;
   DevBuf<float> dQ;
   DevBuf<uint64_t> dQbits;
-  DevBuf<vt::Entry> dPartial;
-  DevBuf<ResultBlock> dRes;
+  DevBuf<uint64_t> dPartKeys;
+  DevBuf<vt::Payload> dPartPay;
+  DevBuf<int> dStatus;  // "metric overflow" flag: set by scan kernels, moved out and cleared by the select kernel
+  DevBuf<int> dFlag;    // scratch flag of the ingest kernels
   DevBuf<uint32_t> dRows;
-  DevBuf<vt::Entry> dCand;
+  DevBuf<uint64_t> dCandKeys;
+  DevBuf<vt::Payload> dCandPay;
   PinnedBuf<float> hQ;
-  PinnedBuf<ResultBlock> hRes;
+  PinnedBuf<ResultBlock> hRes;  // written by the select kernel through the host mapping
+  ResultBlock *dResMapped = nullptr;
   PinnedBuf<unsigned char> hStage;
   bool profiling = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -176,8 +174,11 @@ struct Ctx {
     VT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     VT_HIP(hipEventCreate(&ev0));
     VT_HIP(hipEventCreate(&ev1));
-    VT_TRY(dRes.ensure(1));
+    VT_TRY(dStatus.ensure(1));
+    VT_TRY(dFlag.ensure(1));
+    VT_HIP(hipMemset(dStatus.p, 0, sizeof(int)));
     VT_TRY(hRes.ensure(1));
+    VT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dResMapped), hRes.p, 0));
     return VT_OK;
   }
   int bind() {
@@ -210,7 +211,7 @@ struct vt_flat {
   // corpus
   uint32_t n = 0, cap = 0;
   long dim = -1;    // FlatIndex.dimension (None = -1)
-  uint32_t ld = 0;  // row stride of the slab in floats, multiple of 8
+  uint32_t ld = 0;  // row stride of the slab in floats = padded_dim(dim), multiple of 64
   float *dX = nullptr;
   DevBuf<uint32_t> dRank;
   DevBuf<uint64_t> dBits;
@@ -232,36 +233,30 @@ struct vt_flat {
 namespace {
 
 // ------------------------------------------------------------------ selection
-// Selects the `want` smallest keys among `m` entries already on the device
-// (rerank candidates: m is small) and appends them to `out` in ascending order.
-// One merge launch covers want <= kMaxFusedK; larger requests repeat it on the
-// entries above the last key returned.
-int collect_from_entries(Ctx &c, const vt::Entry *dEntries, uint32_t m, size_t want, std::vector<vt::Entry> &out) {
-  uint32_t remaining = m;
-  const vt::Entry *src = dEntries;
-  DevBuf<vt::Entry> work;
-  std::vector<vt::Entry> host, keep;
+// One select launch + stream sync; the k winners arrive in c.hRes (pinned,
+// written by the kernel through the host mapping).
+int select_pass(Ctx &c, const uint64_t *keys, const vt::Payload *pay, uint32_t m, uint32_t k, uint64_t lo, bool has_lo) {
+  VT_HIP(vt::launch_select(keys, pay, m, k, lo, has_lo ? 1 : 0, c.dStatus.p, c.dResMapped, c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  return VT_OK;
+}
+
+// Selects the `want` smallest keys among `m` candidates already on the device
+// (rerank candidates) and appends them to `out` in ascending order.
+int collect_from_keys(Ctx &c, const uint64_t *keys, const vt::Payload *pay, uint32_t m, size_t want,
+                      std::vector<vt::Entry> &out) {
   const size_t goal = out.size() + std::min<size_t>(want, m);
-  while (remaining > 0 && out.size() < goal) {
-    const uint32_t k = (uint32_t)std::min<size_t>({(size_t)vt::kMaxFusedK, (size_t)remaining, goal - out.size()});
-    VT_HIP(hipMemsetAsync(c.dRes.p, 0, 16, c.stream));
-    VT_HIP(vt::launch_merge(src, remaining, k, c.dRes.p->e, &c.dRes.p->count, c.stream));
-    VT_HIP(hipMemcpyAsync(c.hRes.p, c.dRes.p, 16 + (size_t)k * sizeof(vt::Entry), hipMemcpyDeviceToHost, c.stream));
-    VT_HIP(hipStreamSynchronize(c.stream));
+  uint64_t lo = 0;
+  bool has_lo = false;
+  while (out.size() < goal) {
+    const uint32_t k = (uint32_t)std::min<size_t>((size_t)vt::kMaxFusedK, goal - out.size());
+    VT_TRY(select_pass(c, keys, pay, m, k, lo, has_lo));
+    if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
     const uint32_t got = c.hRes.p->count;
     for (uint32_t i = 0; i < got; ++i) out.push_back(c.hRes.p->e[i]);
-    if (got < k || out.size() >= goal) break;
-    const uint64_t lo = c.hRes.p->e[got - 1].key;
-    host.resize(remaining);
-    VT_HIP(hipMemcpy(host.data(), src, (size_t)remaining * sizeof(vt::Entry), hipMemcpyDeviceToHost));
-    keep.clear();
-    for (const auto &e : host)
-      if (e.key != vt::kEmptyKey && e.key > lo) keep.push_back(e);
-    remaining = (uint32_t)keep.size();
-    if (!remaining) break;
-    VT_TRY(work.ensure(remaining));
-    VT_HIP(hipMemcpy(work.p, keep.data(), (size_t)remaining * sizeof(vt::Entry), hipMemcpyHostToDevice));
-    src = work.p;
+    if (got < k) break;
+    lo = c.hRes.p->e[got - 1].key;
+    has_lo = true;
   }
   return VT_OK;
 }
@@ -279,12 +274,12 @@ struct ScanJob {
   uint32_t q_nonzero;
 };
 
-// Scan + merge passes until `want` hits are collected (ascending by key).
-// The query must already be in c.dQ (padded to round_up(d, 8)).
+// Scan + select passes until `want` hits are collected (ascending by key).
+// The query must already be in c.dQ (padded to padded_dim(d)).
 int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out, bool count_profile) {
   const size_t lds = vt::scan_lds_bytes(j.d);
   if (lds == 0)
-    return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(j.d) + " exceeds the scan kernel's LDS panel");
+    return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(j.d) + " exceeds what the scan kernel stages in LDS");
   if (j.metric == VT_JACCARD && j.d >= 4096)
     return fail(VT_ERR_UNSUPPORTED, "jaccard on device supports d < 4096");
   const uint32_t ntiles = (j.n + vt::kTileRows - 1) / vt::kTileRows;
@@ -292,10 +287,11 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
   const uint32_t waves = vt::scan_waves(blocks);
   uint64_t lo = 0;
   bool has_lo = false;
-  size_t total = std::min<size_t>(want, j.n);
+  const size_t total = std::min<size_t>(want, j.n);
   while (out.size() < total) {
     const uint32_t k = (uint32_t)std::min<size_t>((size_t)vt::kMaxFusedK, total - out.size());
-    VT_TRY(c.dPartial.ensure((size_t)waves * k));
+    VT_TRY(c.dPartKeys.ensure((size_t)waves * k));
+    VT_TRY(c.dPartPay.ensure((size_t)waves * k));
     vt::ScanArgs a{};
     a.X = j.X;
     a.stride = j.stride;
@@ -311,15 +307,13 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
     a.lo_key = lo;
     a.has_lo = has_lo ? 1 : 0;
     a.q_nonzero = j.q_nonzero;
-    a.partial = c.dPartial.p;
-    a.status = &c.dRes.p->status;
-    VT_HIP(hipMemsetAsync(c.dRes.p, 0, 16, c.stream));
+    a.part_keys = c.dPartKeys.p;
+    a.part_pay = c.dPartPay.p;
+    a.status = c.dStatus.p;
     if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
     VT_HIP(vt::launch_scan(a, blocks, c.stream));
     if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
-    VT_HIP(vt::launch_merge(c.dPartial.p, waves * k, k, c.dRes.p->e, &c.dRes.p->count, c.stream));
-    VT_HIP(hipMemcpyAsync(c.hRes.p, c.dRes.p, 16 + (size_t)k * sizeof(vt::Entry), hipMemcpyDeviceToHost, c.stream));
-    VT_HIP(hipStreamSynchronize(c.stream));
+    VT_TRY(select_pass(c, c.dPartKeys.p, c.dPartPay.p, waves * k, k, 0, false));
     if (c.profiling && count_profile) {
       float ms = 0.f;
       VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
@@ -352,7 +346,8 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
   const size_t total = std::min<size_t>(want, n);
   while (out.size() < total) {
     const uint32_t k = (uint32_t)std::min<size_t>((size_t)vt::kMaxFusedK, total - out.size());
-    VT_TRY(c.dPartial.ensure((size_t)waves * k));
+    VT_TRY(c.dPartKeys.ensure((size_t)waves * k));
+    VT_TRY(c.dPartPay.ensure((size_t)waves * k));
     vt::HammingArgs a{};
     a.bits = bits;
     a.qbits = qbits;
@@ -363,14 +358,12 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
     a.k = k;
     a.lo_key = lo;
     a.has_lo = has_lo ? 1 : 0;
-    a.partial = c.dPartial.p;
-    VT_HIP(hipMemsetAsync(c.dRes.p, 0, 16, c.stream));
+    a.part_keys = c.dPartKeys.p;
+    a.part_pay = c.dPartPay.p;
     if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
     VT_HIP(vt::launch_hamming(a, blocks, c.stream));
     if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
-    VT_HIP(vt::launch_merge(c.dPartial.p, waves * k, k, c.dRes.p->e, &c.dRes.p->count, c.stream));
-    VT_HIP(hipMemcpyAsync(c.hRes.p, c.dRes.p, 16 + (size_t)k * sizeof(vt::Entry), hipMemcpyDeviceToHost, c.stream));
-    VT_HIP(hipStreamSynchronize(c.stream));
+    VT_TRY(select_pass(c, c.dPartKeys.p, c.dPartPay.p, waves * k, k, 0, false));
     if (c.profiling && count_profile) {
       float ms = 0.f;
       VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
@@ -387,9 +380,9 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
   return VT_OK;
 }
 
-// Uploads a query of n floats into c.dQ padded with zeros to round_up(n, 8).
+// Uploads a query of n floats into c.dQ padded with zeros to padded_dim(n).
 int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero) {
-  const uint32_t ld = round_up_u32((uint32_t)n, 8);
+  const uint32_t ld = vt::padded_dim((uint32_t)n);
   VT_TRY(c.dQ.ensure(ld));
   VT_TRY(c.hQ.ensure(ld));
   std::memcpy(c.hQ.p, q, n * sizeof(float));
@@ -429,8 +422,8 @@ int index_reserve(vt_flat *ix, uint32_t want_rows) {
 int index_set_dim(vt_flat *ix, size_t d) {
   if (d > 0x7fffffffu) return fail(VT_ERR_UNSUPPORTED, "dimension too large");
   if (vt::scan_lds_bytes((uint32_t)d) == 0)
-    return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(d) + " exceeds the scan kernel's LDS panel");
-  const uint32_t ld = round_up_u32((uint32_t)d, 8);
+    return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(d) + " exceeds what the scan kernel stages in LDS");
+  const uint32_t ld = vt::padded_dim((uint32_t)d);
   if (ld != ix->ld) {
     if (ix->dX) VT_HIP(hipFree(ix->dX));
     ix->dX = nullptr;
@@ -768,11 +761,12 @@ int vt_flat_load_device_matrix(vt_flat *ix, size_t count, size_t d, const char *
   if ((long)d != expected) return VT_ERR_DIMENSION;
   const float *rows = static_cast<const float *>(device_rows);
   VT_HIP(hipDeviceSynchronize());  // the producer may have used another stream
-  VT_HIP(hipMemsetAsync(c.dRes.p, 0, 16, c.stream));
-  VT_HIP(vt::launch_check_finite(rows, d, (uint32_t)count, (uint32_t)d, &c.dRes.p->status, c.stream));
-  VT_HIP(hipMemcpyAsync(c.hRes.p, c.dRes.p, 16, hipMemcpyDeviceToHost, c.stream));
+  int non_finite = 0;
+  VT_HIP(hipMemsetAsync(c.dFlag.p, 0, sizeof(int), c.stream));
+  VT_HIP(vt::launch_check_finite(rows, d, (uint32_t)count, (uint32_t)d, c.dFlag.p, c.stream));
+  VT_HIP(hipMemcpyAsync(&non_finite, c.dFlag.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(hipStreamSynchronize(c.stream));
-  if (c.hRes.p->status != 0) return VT_ERR_NON_FINITE;
+  if (non_finite != 0) return VT_ERR_NON_FINITE;
   if (ix->dim < 0) VT_TRY(index_set_dim(ix, d));
   RowSource src;
   src.device = rows;
@@ -867,7 +861,7 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
   uint32_t qnz = 0;
   VT_TRY(upload_query(c, query, n, &qnz));
   VT_TRY(c.dQbits.ensure(words));
-  VT_HIP(vt::launch_sign_pack(c.dQ.p, round_up_u32(d, 8), 1, d, c.dQbits.p, c.stream));
+  VT_HIP(vt::launch_sign_pack(c.dQ.p, vt::padded_dim(d), 1, d, c.dQbits.p, c.stream));
   // stage 1: binary_top_k (search.rs:76-92)
   std::vector<vt::Entry> cand;
   VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits.p, ix->dRank.p, ix->n, d, candidates, cand, true));
@@ -879,7 +873,8 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
   VT_HIP(hipMemcpyAsync(c.dRows.p, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
   std::vector<vt::Entry> entries;
   if (ix->metric == VT_COSINE) {
-    VT_TRY(c.dCand.ensure(rows.size()));
+    VT_TRY(c.dCandKeys.ensure(rows.size()));
+    VT_TRY(c.dCandPay.ensure(rows.size()));
     vt::CosineRerankArgs a{};
     a.X = ix->dX;
     a.stride = ix->ld;
@@ -889,14 +884,11 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
     a.gather_stride = 1;
     a.n = (uint32_t)rows.size();
     a.d = d;
-    a.out = c.dCand.p;
-    a.status = &c.dRes.p->status;
-    VT_HIP(hipMemsetAsync(c.dRes.p, 0, 16, c.stream));
+    a.out_keys = c.dCandKeys.p;
+    a.out_pay = c.dCandPay.p;
+    a.status = c.dStatus.p;
     VT_HIP(vt::launch_cosine_rerank(a, c.stream));
-    VT_HIP(hipMemcpyAsync(c.hRes.p, c.dRes.p, 16, hipMemcpyDeviceToHost, c.stream));
-    VT_HIP(hipStreamSynchronize(c.stream));
-    if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
-    VT_TRY(collect_from_entries(c, c.dCand.p, (uint32_t)rows.size(), limit, entries));
+    VT_TRY(collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, (uint32_t)rows.size(), limit, entries));
   } else {
     ScanJob j{};
     j.X = ix->dX;
@@ -939,7 +931,7 @@ int vt_vector_top_k(int device, size_t count, const char *ids, const size_t *id_
     }
   }
   if (dimensions > 0x7fffffffu || vt::scan_lds_bytes((uint32_t)dimensions) == 0)
-    return fail(VT_ERR_UNSUPPORTED, "prefix dimension exceeds the scan kernel's LDS panel");
+    return fail(VT_ERR_UNSUPPORTED, "prefix dimension exceeds what the scan kernel stages in LDS");
   if (count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
   Ctx *cp = nullptr;
   VT_TRY(stateless_ctx(device, &cp));
@@ -947,7 +939,7 @@ int vt_vector_top_k(int device, size_t count, const char *ids, const size_t *id_
   std::lock_guard<std::mutex> g(g_ctx_mu);
   std::vector<vt::Entry> entries;
   if (good > 0) {
-    const uint32_t d = (uint32_t)dimensions, ld = round_up_u32(d, 8);
+    const uint32_t d = (uint32_t)dimensions, ld = vt::padded_dim(d);
     const uint32_t n = (uint32_t)good;
     const uint32_t cap = round_up_u32(n, vt::kTileRows);
     std::vector<float> packed((size_t)cap * ld, 0.0f);
@@ -955,7 +947,7 @@ int vt_vector_top_k(int device, size_t count, const char *ids, const size_t *id_
     std::vector<uint32_t> rank;
     ranks_for_ids(ids, id_off, good, rank);
     DevBuf<float> dX;
-    DevBuf<uint32_t> dRank, dRows;
+    DevBuf<uint32_t> dRank;
     VT_TRY(dX.ensure(packed.size()));
     VT_TRY(dRank.ensure(n));
     VT_HIP(hipMemcpyAsync(dX.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, c.stream));
@@ -964,28 +956,24 @@ int vt_vector_top_k(int device, size_t count, const char *ids, const size_t *id_
     VT_TRY(upload_query(c, query, dimensions, &qnz));
     const size_t want = first_error == VT_OK ? limit : (size_t)1;  // only the overflow flag matters then
     if (metric_code == VT_COSINE) {
-      std::vector<uint32_t> rows(n);
-      for (uint32_t i = 0; i < n; ++i) rows[i] = i;
-      VT_TRY(dRows.ensure(n));
-      VT_HIP(hipMemcpyAsync(dRows.p, rows.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
-      VT_TRY(c.dCand.ensure(n));
+      VT_TRY(c.dCandKeys.ensure(n));
+      VT_TRY(c.dCandPay.ensure(n));
       vt::CosineRerankArgs a{};
       a.X = dX.p;
       a.stride = ld;
       a.q = c.dQ.p;
       a.id_rank = dRank.p;
-      a.gather = dRows.p;
-      a.gather_stride = 1;
+      a.gather = nullptr;
+      a.gather_stride = 0;
       a.n = n;
       a.d = d;
-      a.out = c.dCand.p;
-      a.status = &c.dRes.p->status;
-      VT_HIP(hipMemsetAsync(c.dRes.p, 0, 16, c.stream));
+      a.out_keys = c.dCandKeys.p;
+      a.out_pay = c.dCandPay.p;
+      a.status = c.dStatus.p;
       VT_HIP(vt::launch_cosine_rerank(a, c.stream));
-      VT_HIP(hipMemcpyAsync(c.hRes.p, c.dRes.p, 16, hipMemcpyDeviceToHost, c.stream));
-      VT_HIP(hipStreamSynchronize(c.stream));
-      if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
-      if (limit > 0) VT_TRY(collect_from_entries(c, c.dCand.p, n, want, entries));
+      // limit == 0 still has to surface "metric overflow": select one
+      VT_TRY(collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, n, std::max<size_t>(want, 1), entries));
+      if (limit == 0) entries.clear();
     } else {
       ScanJob j{};
       j.X = dX.p;

@@ -1,0 +1,409 @@
+// vt_scan.cuh -- K1: flat scan + fused wave64 top-k (gfx950).
+//
+// Replaces the hot loop of FlatIndex::search (native/vettore/src/flat.rs:104-118)
+// and of vector_top_k (search.rs:49-70) together with the distance kernels
+// (distances.rs:197-347).
+//
+// Arithmetic contract: every raw metric value is computed with exactly the
+// reference's f32 operation order: per 8-float chunk eight separately rounded
+// products (no FMA), one horizontal add in the lane order of
+// wide::f32x8::reduce_add, then `acc += chunk_sum` sequentially over the chunks,
+// then the scalar tail.  The result is bit-identical to the CPU oracle for the
+// selected order, not merely within tolerance.
+//
+// How that is made HBM-bound:
+//   * the corpus is one row-major slab (row stride a multiple of 256 B).  A wave
+//     owns a tile of 32 rows and walks it in column panels of <= 96 chunks; a
+//     panel is read as a run of fully coalesced 1-KiB wave loads (16 B/lane,
+//     nontemporal), kU deep in flight in a register ring that runs ahead across
+//     panel and tile boundaries;
+//   * the query sits in LDS; each lane pair holds one 8-float chunk, so a chunk
+//     sum is 4 v_mul + 3..7 v_add, one of them a DPP quad_perm add;
+//   * chunk sums go to a per-wave LDS panel S[32 rows][<=96 chunks] (row stride
+//     4*odd dwords: conflict-free ds_read_b128).  After a panel's last load lane
+//     r walks row r's sums in order -- the reference's sequential `acc +=` chain
+//     -- so 32 chains advance in parallel, once per panel (~1% of its time);
+//   * after the last panel each lane owns a finished row: finiteness / f64
+//     recovery, rank key, compare with the wave's k-th best (wave-uniform
+//     threshold); the rare rows that pass are inserted one by one into a
+//     register-resident wave-wide list.
+// LDS per block is fixed (4 waves x 13.5 KiB + the query), whatever d is.
+#pragma once
+#include "vt_common.cuh"
+
+namespace vt {
+namespace dev {
+
+constexpr uint32_t kPanelChunks = 96;  // max chunks per column panel (768 floats, 3 KiB per row)
+
+struct ScanShape {
+  uint32_t ld;         // floats read per row = padded_dim(d), multiple of 64
+  uint32_t cfull;      // full 8-float chunks per row (d / 8)
+  uint32_t tail;       // d % 8
+  uint32_t npanel;     // column panels per row
+  uint32_t pc;         // chunks per panel (multiple of 8)
+  uint32_t pc_last;    // chunks in the last panel (multiple of 8)
+  uint32_t ss;         // dwords per LDS panel row, 4 * odd
+  uint32_t tail_base;  // dword offset of the 8 tail-product slots in a panel row
+  uint32_t ntiles;
+};
+
+inline bool make_scan_shape(uint32_t d, uint32_t n, ScanShape *out) {
+  if (d == 0) return false;
+  ScanShape p;
+  p.ld = padded_dim(d);
+  p.cfull = d / 8;
+  p.tail = d % 8;
+  const uint32_t cpr = p.ld / 8;
+  uint32_t np = (cpr + kPanelChunks - 1) / kPanelChunks;
+  uint32_t pc = round_up((cpr + np - 1) / np, 8);
+  while (np > 1 && (np - 1) * pc >= cpr) {
+    --np;
+    pc = round_up((cpr + np - 1) / np, 8);
+  }
+  if (pc > kPanelChunks + 8) return false;
+  p.npanel = np;
+  p.pc = pc;
+  p.pc_last = cpr - (np - 1) * pc;
+  p.tail_base = pc;
+  p.ss = pc + 12;  // pc % 8 == 0 -> (pc + 12) / 4 is odd
+  p.ntiles = (n + kTileRows - 1) / kTileRows;
+  *out = p;
+  return true;
+}
+
+struct ScanDev {
+  ScanArgs a;
+  ScanShape p;
+};
+
+// ---- per-element operation of each metric family ---------------------------
+template <int OP>
+__device__ __forceinline__ float elem(int op_rt, float q, float x) {
+  const int op = OP >= 0 ? OP : op_rt;
+  switch (op) {
+    case OP_DOT: return q * x;
+    case OP_L2: {
+      const float t = q - x;
+      return t * t;
+    }
+    case OP_L1:
+    case OP_LINF: return fabsf(q - x);
+    case OP_HAM: return ((q != 0.0f) != (x != 0.0f)) ? 1.0f : 0.0f;
+    default:  // OP_JAC: hamming count + 4096 * (x != 0); exact in f32 for d < 4096
+      return (((q != 0.0f) != (x != 0.0f)) ? 1.0f : 0.0f) + ((x != 0.0f) ? 4096.0f : 0.0f);
+  }
+}
+
+template <int OP>
+__device__ __forceinline__ float comb(int op_rt, float a, float b) {
+  const int op = OP >= 0 ? OP : op_rt;
+  return op == OP_LINF ? fmaxf(a, b) : a + b;
+}
+
+// wide::f32x8::reduce_add of the chunk held by a lane pair (even lane: l0..l3,
+// odd lane: l4..l7); both lanes return the chunk sum.
+template <int OP, int ORDER>
+__device__ __forceinline__ float chunk_sum(int op_rt, int order_rt, float p0, float p1, float p2, float p3, int odd) {
+  const int order = ORDER >= 0 ? ORDER : order_rt;
+  if (order == 1) {  // AVX: ((l0+l4)+(l2+l6)) + ((l1+l5)+(l3+l7))
+    const float u0 = comb<OP>(op_rt, p0, dpp_xor1(p0));
+    const float u1 = comb<OP>(op_rt, p1, dpp_xor1(p1));
+    const float u2 = comb<OP>(op_rt, p2, dpp_xor1(p2));
+    const float u3 = comb<OP>(op_rt, p3, dpp_xor1(p3));
+    const float t = comb<OP>(op_rt, odd ? u1 : u0, odd ? u3 : u2);
+    return comb<OP>(op_rt, t, dpp_xor1(t));
+  }
+  float e;
+  if (order == 2)  // SEQ: (((l0+l1)+l2)+l3) + (((l4+l5)+l6)+l7)
+    e = comb<OP>(op_rt, comb<OP>(op_rt, comb<OP>(op_rt, p0, p1), p2), p3);
+  else  // PAIR: ((l0+l1)+(l2+l3)) + ((l4+l5)+(l6+l7))
+    e = comb<OP>(op_rt, comb<OP>(op_rt, p0, p1), comb<OP>(op_rt, p2, p3));
+  return comb<OP>(op_rt, e, dpp_xor1(e));
+}
+
+// distances.rs:70-90 recover_metric_overflow (+ the f64 branch of l2(),
+// distances.rs:140-147), run by the one lane whose f32 result was non-finite.
+__device__ __noinline__ static bool recover_overflow(int metric, const float *q, const float *x, uint32_t d,
+                                                     float *out) {
+  double acc = 0.0;
+  switch (metric) {
+    case M_L2:
+    case M_L2SQ:
+      for (uint32_t i = 0; i < d; ++i) {
+        const double t = (double)q[i] - (double)x[i];
+        acc += t * t;
+      }
+      if (metric == M_L2) {
+        // l2(): (f64 sqrt) as f32, accepted when finite; compute()'s later
+        // recovery reaches the same value or fails identically.
+        const float v = (float)sqrt(acc);
+        if (finite_f32(v)) {
+          *out = v;
+          return true;
+        }
+        return false;
+      }
+      return f64_to_f32(acc, out);
+    case M_COS:
+    case M_IP:
+    case M_NIP:
+      for (uint32_t i = 0; i < d; ++i) acc += (double)q[i] * (double)x[i];
+      return f64_to_f32(metric == M_NIP ? -acc : acc, out);
+    case M_L1:
+      for (uint32_t i = 0; i < d; ++i) acc += fabs((double)q[i] - (double)x[i]);
+      return f64_to_f32(acc, out);
+    case M_LINF:
+      for (uint32_t i = 0; i < d; ++i) acc = fmax(acc, fabs((double)q[i] - (double)x[i]));
+      return f64_to_f32(acc, out);
+    default: return false;
+  }
+}
+
+// Position of a wave in its stream of 1-KiB segments: tile t, column panel p,
+// segment s of that panel (all wave-uniform), and this lane's (row in tile,
+// column in panel) of the 4 floats it loads there.
+struct Cursor {
+  uint32_t t, p, s;
+  uint32_t rowi, col;
+};
+
+// OP / ORDER < 0: taken from the arguments at run time.
+// GENERAL: rows addressed through `gather` and/or a stride != ld (prefix scan).
+// PADDED: d % 64 != 0 -- some chunks of a row are padding or the scalar tail.
+template <int OP, int ORDER, int R, bool GENERAL, bool PADDED>
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const ScanDev sd) {
+  extern __shared__ __align__(16) float lds[];
+  const ScanArgs &a = sd.a;
+  const ScanShape &p = sd.p;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int odd = lane & 1;
+  float *qs = lds;
+  float *S = lds + p.ld + wib * (kTileRows * p.ss);
+
+  for (uint32_t i = threadIdx.x; i < p.ld; i += blockDim.x) qs[i] = a.q[i];
+  __syncthreads();
+
+  const int op_rt = metric_op(a.metric);
+  const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+  const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
+  const uint32_t ntiles = p.ntiles;
+
+  WaveTopK<R> tk;
+  tk.init(a.k, lane);
+
+  if (wave_global < ntiles) {
+    const uint32_t last_tile = wave_global + ((ntiles - 1 - wave_global) / total_waves) * total_waves;
+    // the two panel widths (floats) and this lane's start/step within them
+    const uint32_t pw0 = p.pc * 8, pw1 = p.pc_last * 8;
+    const uint32_t l4 = (uint32_t)lane * 4u;
+    const uint32_t ir0 = l4 / pw0, ic0 = l4 - ir0 * pw0;
+    const uint32_t ir1 = l4 / pw1, ic1 = l4 - ir1 * pw1;
+    const uint32_t sr0 = 256u / pw0, sc0 = 256u - sr0 * pw0;
+    const uint32_t sr1 = 256u / pw1, sc1 = 256u - sr1 * pw1;
+    const uint32_t lastp = p.npanel - 1;
+
+    auto enter_panel = [&](Cursor &c) {
+      const bool last = c.p == lastp;
+      c.rowi = last ? ir1 : ir0;
+      c.col = last ? ic1 : ic0;
+    };
+    auto step_lane = [&](Cursor &c) {
+      const bool last = c.p == lastp;
+      const uint32_t pw = last ? pw1 : pw0;
+      c.rowi += last ? sr1 : sr0;
+      c.col += last ? sc1 : sc0;
+      if (c.col >= pw) {
+        c.col -= pw;
+        c.rowi += 1;
+      }
+    };
+    auto advance = [&](Cursor &c) {
+      const uint32_t nseg = c.p == lastp ? p.pc_last : p.pc;
+      c.s += 1;
+      if (c.s == nseg) {
+        c.s = 0;
+        c.p += 1;
+        if (c.p == p.npanel) {
+          c.p = 0;
+          c.t += total_waves;
+        }
+        enter_panel(c);
+      } else {
+        step_lane(c);
+      }
+    };
+    auto load_at = [&](const Cursor &c) -> f32x4 {
+      const uint32_t t = c.t < last_tile ? c.t : last_tile;  // clamp at the end of the stream
+      const uint32_t colf = c.p * pw0 + c.col;
+      if (!GENERAL) {
+        const float *base = a.X + (size_t)t * (kTileRows * (size_t)a.stride);
+        return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (c.rowi * (uint32_t)a.stride + colf)));
+      }
+      const uint32_t gi = t * kTileRows + c.rowi;
+      uint32_t src = 0;
+      if (gi < a.n) src = a.gather ? a.gather[(size_t)gi * a.gather_stride] : gi;
+      return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.X + (size_t)src * a.stride + colf));
+    };
+
+    Cursor pf;
+    pf.t = wave_global;
+    pf.p = 0;
+    pf.s = 0;
+    enter_panel(pf);
+    f32x4 buf[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      buf[u] = load_at(pf);
+      advance(pf);
+    }
+
+    for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
+      const uint32_t grow = t * kTileRows + lane;  // lanes 0..31 own a row
+      const bool row_valid = lane < kTileRows && grow < a.n;
+      uint32_t src_row = grow;
+      if (GENERAL && row_valid && a.gather) src_row = a.gather[(size_t)grow * a.gather_stride];
+      uint32_t my_rank = src_row;
+      if (row_valid && a.id_rank) my_rank = a.id_rank[src_row];
+
+      float acc = 0.0f;
+      Cursor cc;
+      cc.t = t;
+      for (cc.p = 0; cc.p < p.npanel; ++cc.p) {
+        const uint32_t nseg = cc.p == lastp ? p.pc_last : p.pc;
+        const uint32_t c0 = cc.p * p.pc;  // first chunk of the panel
+        enter_panel(cc);
+        for (uint32_t s = 0; s < nseg; s += kU) {
+#pragma unroll
+          for (int u = 0; u < kU; ++u) {
+            const f32x4 x = buf[u];
+            buf[u] = load_at(pf);
+            advance(pf);
+
+            const f32x4 qv = *reinterpret_cast<const f32x4 *>(qs + c0 * 8 + cc.col);
+            const float p0 = elem<OP>(op_rt, qv.x, x.x);
+            const float p1 = elem<OP>(op_rt, qv.y, x.y);
+            const float p2 = elem<OP>(op_rt, qv.z, x.z);
+            const float p3 = elem<OP>(op_rt, qv.w, x.w);
+            const uint32_t cl = cc.col >> 3;  // chunk within the panel
+            float *Srow = S + cc.rowi * p.ss;
+            if (!PADDED || c0 + cl < p.cfull) {
+              const float sum = chunk_sum<OP, ORDER>(op_rt, a.order, p0, p1, p2, p3, odd);
+              if (!odd) Srow[cl] = sum;
+            } else if (c0 + cl == p.cfull) {
+              // tail chunk: the reference adds these products one by one
+              *reinterpret_cast<f32x4 *>(Srow + p.tail_base + odd * 4) = f32x4{p0, p1, p2, p3};
+            }
+            step_lane(cc);
+          }
+        }
+
+        // panel complete: lane r continues row r's sequential chain
+        wave_lds_fence();
+        if (lane < kTileRows) {
+          const float *Sr = S + lane * p.ss;
+          uint32_t nsum = nseg;
+          if (PADDED) nsum = p.cfull > c0 ? (p.cfull - c0 < nseg ? p.cfull - c0 : nseg) : 0;
+          uint32_t c = 0;
+          for (; c + 4 <= nsum; c += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(Sr + c);
+            acc = comb<OP>(op_rt, acc, v.x);
+            acc = comb<OP>(op_rt, acc, v.y);
+            acc = comb<OP>(op_rt, acc, v.z);
+            acc = comb<OP>(op_rt, acc, v.w);
+          }
+          if (PADDED) {
+            for (; c < nsum; ++c) acc = comb<OP>(op_rt, acc, Sr[c]);
+            if (p.tail && p.cfull >= c0 && p.cfull < c0 + nseg)
+              for (uint32_t j = 0; j < p.tail; ++j) acc = comb<OP>(op_rt, acc, Sr[p.tail_base + j]);
+          }
+        }
+        wave_lds_fence();
+      }
+
+      // distances.rs:42-68 compute(): value, finiteness, f64 recovery
+      const int metric = a.metric;
+      float raw = acc;
+      if (metric == M_NIP) raw = -acc;
+      else if (metric == M_L2) raw = finite_f32(acc) ? __builtin_sqrtf(acc) : acc;
+      else if (OP == OP_JAC || (OP < 0 && metric == M_JAC)) {
+        const uint32_t tot = (uint32_t)acc;
+        const uint32_t xnz = tot >> 12, ham = tot & 4095u;
+        const uint32_t uni = (a.q_nonzero + xnz + ham) >> 1;
+        const uint32_t inter = (a.q_nonzero + xnz - ham) >> 1;
+        raw = uni == 0 ? 0.0f : 1.0f - (float)inter / (float)uni;
+      }
+      bool valid = row_valid;
+      if (valid && !finite_f32(raw)) {
+        float rec;
+        if (recover_overflow(metric, qs, a.X + (size_t)src_row * a.stride, a.d, &rec)) {
+          raw = rec;
+        } else {
+          atomicMax(a.status, kErrOverflow);
+          valid = false;
+        }
+      }
+      // distances.rs:113-119 rank_value, flat.rs:34-40 ordering
+      float rank = raw;
+      if (metric == M_COS) rank = 1.0f - raw;
+      else if (metric == M_IP) rank = -raw;
+      const uint64_t key = ((uint64_t)orderable(rank) << 32) | my_rank;
+      if (a.has_lo) valid = valid && key > a.lo_key;
+      tk.offer(valid, key, src_row, raw, lane);
+    }
+  }
+  tk.store(a.part_keys + (size_t)wave_global * a.k, a.part_pay + (size_t)wave_global * a.k, a.k, lane);
+}
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+template <typename K>
+inline hipError_t allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes);
+}
+
+template <int OP, int ORDER, int R, bool GENERAL, bool PADDED>
+inline hipError_t launch_scan_t(const ScanDev &sd, uint32_t blocks, size_t lds, hipStream_t s) {
+  auto kern = scan_topk_kernel<OP, ORDER, R, GENERAL, PADDED>;
+  hipError_t e = allow_lds(kern, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, sd);
+  return hipGetLastError();
+}
+
+// One translation unit per operation family instantiates its kernels.
+hipError_t launch_scan_dot(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
+hipError_t launch_scan_l2(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
+hipError_t launch_scan_misc(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
+hipError_t launch_scan_general(const ScanDev &sd, uint32_t blocks, size_t lds, hipStream_t s);
+
+// order (0..2) x list registers (k <= 64 -> 1, else 4) x padded
+#define VT_SCAN_DISPATCH_ORDERED(OPV)                                                          \
+  do {                                                                                         \
+    const int order = sd.a.order;                                                              \
+    const bool big = sd.a.k > 64;                                                              \
+    if (!padded) {                                                                             \
+      if (!big) {                                                                              \
+        if (order == 0) return launch_scan_t<OPV, 0, 1, false, false>(sd, blocks, lds, s);     \
+        if (order == 1) return launch_scan_t<OPV, 1, 1, false, false>(sd, blocks, lds, s);     \
+        return launch_scan_t<OPV, 2, 1, false, false>(sd, blocks, lds, s);                     \
+      }                                                                                        \
+      if (order == 0) return launch_scan_t<OPV, 0, 4, false, false>(sd, blocks, lds, s);       \
+      if (order == 1) return launch_scan_t<OPV, 1, 4, false, false>(sd, blocks, lds, s);       \
+      return launch_scan_t<OPV, 2, 4, false, false>(sd, blocks, lds, s);                       \
+    }                                                                                          \
+    if (!big) {                                                                                \
+      if (order == 0) return launch_scan_t<OPV, 0, 1, false, true>(sd, blocks, lds, s);        \
+      if (order == 1) return launch_scan_t<OPV, 1, 1, false, true>(sd, blocks, lds, s);        \
+      return launch_scan_t<OPV, 2, 1, false, true>(sd, blocks, lds, s);                        \
+    }                                                                                          \
+    if (order == 0) return launch_scan_t<OPV, 0, 4, false, true>(sd, blocks, lds, s);          \
+    if (order == 1) return launch_scan_t<OPV, 1, 4, false, true>(sd, blocks, lds, s);          \
+    return launch_scan_t<OPV, 2, 4, false, true>(sd, blocks, lds, s);                          \
+  } while (0)
+
+}  // namespace dev
+}  // namespace vt

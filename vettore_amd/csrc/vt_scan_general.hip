@@ -1,0 +1,12 @@
+// K1 instantiations for gathered rows (rerank of candidate lists, stateless
+// vector_top_k batches): operation and lane order at run time.
+#include "vt_scan.cuh"
+
+namespace vt {
+namespace dev {
+hipError_t launch_scan_general(const ScanDev &sd, uint32_t blocks, size_t lds, hipStream_t s) {
+  if (sd.a.k <= 64) return launch_scan_t<-1, -1, 1, true, true>(sd, blocks, lds, s);
+  return launch_scan_t<-1, -1, 4, true, true>(sd, blocks, lds, s);
+}
+}  // namespace dev
+}  // namespace vt

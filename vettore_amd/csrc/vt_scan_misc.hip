@@ -1,0 +1,28 @@
+// K1 instantiations: manhattan (lane order at run time), chebyshev, float
+// hamming and jaccard (order-insensitive: max / exact small-integer sums).
+#include "vt_scan.cuh"
+
+namespace vt {
+namespace dev {
+
+#define VT_SCAN_DISPATCH_FIXED(OPV, ORD)                                                      \
+  do {                                                                                        \
+    const bool big = sd.a.k > 64;                                                             \
+    if (!padded) {                                                                            \
+      if (!big) return launch_scan_t<OPV, ORD, 1, false, false>(sd, blocks, lds, s);          \
+      return launch_scan_t<OPV, ORD, 4, false, false>(sd, blocks, lds, s);                    \
+    }                                                                                         \
+    if (!big) return launch_scan_t<OPV, ORD, 1, false, true>(sd, blocks, lds, s);             \
+    return launch_scan_t<OPV, ORD, 4, false, true>(sd, blocks, lds, s);                       \
+  } while (0)
+
+hipError_t launch_scan_misc(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s) {
+  switch (metric_op(sd.a.metric)) {
+    case OP_L1: VT_SCAN_DISPATCH_FIXED(OP_L1, -1);
+    case OP_LINF: VT_SCAN_DISPATCH_FIXED(OP_LINF, 0);
+    case OP_HAM: VT_SCAN_DISPATCH_FIXED(OP_HAM, 0);
+    default: VT_SCAN_DISPATCH_FIXED(OP_JAC, 0);
+  }
+}
+}  // namespace dev
+}  // namespace vt
