@@ -458,6 +458,21 @@ def test_quantized_search_matches_oracle_composition(nifs, oracle_mod, metric):
         assert bits(got) == bits(want), (metric, cand, limit)
 
 
+def test_binary_top_k_with_massive_ties(nifs, oracle_mod):
+    """One-word codes: only 65 distinct distances over 200k rows, so the k-th key
+    sits in a crowded radix bin and ties are decided by id bytes alone."""
+    rng = np.random.default_rng(64)
+    n, d = 200_000, 64
+    words = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+    ids = [b"r%d" % i for i in range(n)]
+    vecs = [(ids[i], [int(words[i])]) for i in range(n)]
+    q = [int(words[123])]
+    for limit in (10, 100, 700):
+        got = unwrap(nifs.binary_top_k(vecs, q, d, limit))
+        want = oracle_mod.binary_top_k(vecs, q, d, limit)
+        assert got == want, limit
+
+
 # --------------------------------------------- full-size checks (BASELINE sizes)
 def test_config2_full_size_properties_and_spot_parity(nifs, oracle_mod):
     """BASELINE.json configs[1]: flat cosine, d=768, N=1M, single query.

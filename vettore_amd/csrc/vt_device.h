@@ -73,22 +73,33 @@ hipError_t launch_scan(const ScanArgs &a, uint32_t blocks, hipStream_t s);
 hipError_t launch_select(const uint64_t *keys, const Payload *pay, uint32_t m, uint32_t k, uint64_t lo_key, int has_lo,
                          int *dev_status, ResultBlock *out, hipStream_t s);
 
+// K4's bit-matrix layout: per tile of 64 rows, word pair j of all 64 rows is
+// contiguous -- [tile][pair][row % 64][2] u64 (an odd word count is padded with a
+// zero word).  Index of word `w` of row `r`:
+__host__ __device__ inline size_t hamming_word_index(uint32_t r, uint32_t w, uint32_t pairs) {
+  return ((size_t)(r / 64) * pairs + (w >> 1)) * 128 + (size_t)(r % 64) * 2 + (w & 1);
+}
+// u64 words the tiled matrix of n rows occupies.
+inline size_t hamming_matrix_words(uint32_t n, uint32_t words) {
+  return (size_t)((n + 63) / 64) * ((words + 1) / 2) * 128;
+}
+
 struct HammingArgs {
-  const uint64_t *bits;    // [n][words]
-  const uint64_t *qbits;   // [words] (device)
+  const uint64_t *bits;    // tiled layout above, hamming_matrix_words(n, words) words, zero-filled padding
+  const uint64_t *qbits;   // [words] plain (device)
   const uint32_t *id_rank; // per row or null
-  uint32_t n, words, d, k;
+  uint32_t n, words, pairs, d, k;  // pairs = (words + 1) / 2
   uint64_t lo_key;
   int has_lo;
   uint64_t *part_keys;
   Payload *part_pay;
 };
-size_t hamming_lds_bytes(uint32_t words);
 hipError_t launch_hamming(const HammingArgs &a, uint32_t blocks, hipStream_t s);
 
-// rows[n][stride] (first d columns) -> bits[n][ceil(d/64)], bit j%64 of word
-// j/64 set iff v[j] >= 0.0 (distances.rs:413-423).
-hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32_t d, uint64_t *bits, hipStream_t s);
+// rows[n][stride] (first d columns) -> sign bits, bit j%64 of word j/64 set iff
+// v[j] >= 0.0 (distances.rs:413-423).  tiled: K4's layout, else plain [n][words].
+hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32_t d, uint64_t *bits, int tiled,
+                            hipStream_t s);
 
 // *flag |= 1 if any of the first d columns of any row is non-finite.
 hipError_t launch_check_finite(const float *rows, size_t stride, uint32_t n, uint32_t d, int *flag, hipStream_t s);

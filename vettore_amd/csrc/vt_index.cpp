@@ -336,10 +336,8 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
 int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint32_t *id_rank, uint32_t n, uint32_t d,
                 size_t want, std::vector<vt::Entry> &out, bool count_profile) {
   const uint32_t words = (d + 63) / 64;
-  const size_t lds = vt::hamming_lds_bytes(words);
-  if (lds == 0) return fail(VT_ERR_UNSUPPORTED, "dimension too large for the hamming kernel's LDS");
   const uint32_t ntiles = (n + 63) / 64;
-  const uint32_t blocks = c.grid_for(ntiles, lds);
+  const uint32_t blocks = c.grid_for(ntiles, 0);
   const uint32_t waves = vt::scan_waves(blocks);
   uint64_t lo = 0;
   bool has_lo = false;
@@ -354,6 +352,7 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
     a.id_rank = id_rank;
     a.n = n;
     a.words = words;
+    a.pairs = (words + 1) / 2;
     a.d = d;
     a.k = k;
     a.lo_key = lo;
@@ -854,14 +853,16 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
   VT_TRY(index_sync_ranks(ix, false));
   if (!ix->bits_valid) {
     // compress_sign_bits of every stored row (collection.ex:926): kept in HBM
-    VT_TRY(ix->dBits.ensure((size_t)std::max<uint32_t>(ix->cap, ix->n) * words + 2));
-    VT_HIP(vt::launch_sign_pack(ix->dX, ix->ld, ix->n, d, ix->dBits.p, c.stream));
+    const size_t bwords = vt::hamming_matrix_words(std::max<uint32_t>(ix->cap, ix->n), words);
+    VT_TRY(ix->dBits.ensure(bwords));
+    VT_HIP(hipMemsetAsync(ix->dBits.p, 0, bwords * sizeof(uint64_t), c.stream));
+    VT_HIP(vt::launch_sign_pack(ix->dX, ix->ld, ix->n, d, ix->dBits.p, 1, c.stream));
     ix->bits_valid = true;
   }
   uint32_t qnz = 0;
   VT_TRY(upload_query(c, query, n, &qnz));
   VT_TRY(c.dQbits.ensure(words));
-  VT_HIP(vt::launch_sign_pack(c.dQ.p, vt::padded_dim(d), 1, d, c.dQbits.p, c.stream));
+  VT_HIP(vt::launch_sign_pack(c.dQ.p, vt::padded_dim(d), 1, d, c.dQbits.p, 0, c.stream));
   // stage 1: binary_top_k (search.rs:76-92)
   std::vector<vt::Entry> cand;
   VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits.p, ix->dRank.p, ix->n, d, candidates, cand, true));
@@ -1011,8 +1012,11 @@ int vt_binary_top_k(int device, size_t count, const char *ids, const size_t *id_
   Ctx &c = *cp;
   std::lock_guard<std::mutex> g(g_ctx_mu);
   const uint32_t n = (uint32_t)count;
-  std::vector<uint64_t> packed((size_t)n * W + 2, 0);
-  for (size_t i = 0; i < count; ++i) std::memcpy(&packed[i * W], words + word_off[i], W * sizeof(uint64_t));
+  // K4 reads the tiled layout: [tile of 64 rows][word pair][row][2]
+  const uint32_t pairs = (uint32_t)((W + 1) / 2);
+  std::vector<uint64_t> packed(vt::hamming_matrix_words(n, (uint32_t)W), 0);
+  for (size_t i = 0; i < count; ++i)
+    for (size_t w = 0; w < W; ++w) packed[vt::hamming_word_index((uint32_t)i, (uint32_t)w, pairs)] = words[word_off[i] + w];
   std::vector<uint32_t> rank;
   ranks_for_ids(ids, id_off, count, rank);
   DevBuf<uint64_t> dBits, dQ;
@@ -1062,7 +1066,7 @@ int vt_compress_sign_bits(int device, size_t count, size_t d, const float *in, u
   VT_TRY(dIn.ensure(count * d));
   VT_TRY(dOut.ensure(count * W));
   VT_HIP(hipMemcpyAsync(dIn.p, in, count * d * sizeof(float), hipMemcpyHostToDevice, c.stream));
-  VT_HIP(vt::launch_sign_pack(dIn.p, d, (uint32_t)count, (uint32_t)d, dOut.p, c.stream));
+  VT_HIP(vt::launch_sign_pack(dIn.p, d, (uint32_t)count, (uint32_t)d, dOut.p, 0, c.stream));
   VT_HIP(hipMemcpyAsync(out, dOut.p, count * W * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(hipStreamSynchronize(c.stream));
   return VT_OK;

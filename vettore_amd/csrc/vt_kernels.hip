@@ -12,29 +12,69 @@ namespace {
 // ---------------------------------------------------------------------------
 // K3: top-k of the partial lists, sorted ascending.  Replaces `hits.sort()`
 // (flat.rs:120-121, search.rs:107-110) and the cross-wave merge the reference's
-// single heap never needed.  One 1024-thread block: MSD radix select on the u64
-// keys (8-bit digits, starting at the highest bit in which the keys differ),
-// then compaction of the k winners and a rank sort in LDS.  Keys are unique
-// (id_rank is unique per row), so "<= threshold" selects exactly k.
+// single heap never needed.  One 1024-thread block, MSD radix select on the u64
+// keys with 8-bit digits starting at the highest bit in which the keys differ:
+//   pass 1  range + count of the live keys,
+//   pass 2  histogram of the first digit -> the bin holding the k-th key,
+//   pass 3  keys below that bin are winners; keys in it move to an LDS list,
+//   then the remaining digits are resolved on the LDS list only.
+// Keys are unique (id_rank is unique per row), so "<= threshold" selects
+// exactly k.  The winners are rank-sorted in LDS and written, with the status
+// word of the scan, straight into the host-mapped result block.
 // ---------------------------------------------------------------------------
+constexpr uint32_t kSelCand = 4096;  // LDS candidate list capacity
+
+struct SelectBin {
+  uint32_t bin, below, count;
+};
+
+// Finds the histogram bin containing the krem-th smallest (1-based); wave 0 only.
+__device__ __forceinline__ void select_find_bin(const uint32_t *hist, uint32_t krem, int lane, SelectBin *out) {
+  const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+  const uint32_t mine = h0 + h1 + h2 + h3;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += t;
+  }
+  const uint32_t excl = incl - mine;
+  if (excl < krem && krem <= incl) {
+    uint32_t below = excl, b = 4 * lane, c = h0;
+    if (below + c < krem) {
+      below += c; b += 1; c = h1;
+      if (below + c < krem) {
+        below += c; b += 1; c = h2;
+        if (below + c < krem) { below += c; b += 1; c = h3; }
+      }
+    }
+    out->bin = b;
+    out->below = below;
+    out->count = c;
+  }
+}
+
 __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__restrict__ keys,
                                                            const Payload *__restrict__ pay, uint32_t m, uint32_t k,
                                                            uint64_t lo_key, int has_lo, int *dev_status,
                                                            ResultBlock *out) {
   extern __shared__ __align__(16) unsigned char smem[];
-  uint64_t *sel_key = reinterpret_cast<uint64_t *>(smem);         // [k]
-  uint32_t *sel_idx = reinterpret_cast<uint32_t *>(sel_key + k);  // [k]
+  uint64_t *sel_key = reinterpret_cast<uint64_t *>(smem);  // [k]
+  uint64_t *cand_key = sel_key + k;                        // [kSelCand]
+  uint32_t *sel_idx = reinterpret_cast<uint32_t *>(cand_key + kSelCand);  // [k]
+  uint32_t *cand_idx = sel_idx + k;                                       // [kSelCand]
   __shared__ uint32_t hist[256];
   __shared__ uint64_t red_min[16], red_max[16];
   __shared__ uint32_t red_cnt[16];
-  __shared__ uint32_t s_bin, s_below, s_bincount, s_sel;
+  __shared__ SelectBin s_bin;
+  __shared__ uint32_t s_sel, s_ncand;
   const uint32_t tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
 
   auto live = [&](uint64_t key) { return key != kEmptyKey && (!has_lo || key > lo_key); };
 
-  // pass A: range and count of the live keys
+  // pass 1: range and count of the live keys
   uint64_t mn = ~0ull, mx = 0;
   uint32_t cnt = 0;
   for (uint32_t i = tid; i < m; i += 1024) {
@@ -57,7 +97,11 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
     red_max[wave] = mx;
     red_cnt[wave] = cnt;
   }
-  if (tid == 0) s_sel = 0;
+  if (tid == 0) {
+    s_sel = 0;
+    s_ncand = 0;
+  }
+  if (tid < 256) hist[tid] = 0;
   __syncthreads();
   mn = ~0ull;
   mx = 0;
@@ -68,69 +112,129 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
     nvalid += red_cnt[w];
   }
 
-  uint64_t T = ~0ull - 1;  // select every live key
+  uint64_t T = ~0ull - 1;  // threshold over the global keys: select every live key <= T
+  bool from_cand = false;  // the remaining winners are cand keys <= Tc
+  uint64_t Tc = 0;
   if (nvalid > k && mn != mx) {
     uint32_t krem = k;
     int hb = 63 - __clzll((long long)(mn ^ mx));
     uint64_t mask = hb == 63 ? 0ull : (~0ull << (hb + 1));
     uint64_t prefix = mx & mask;
-    for (;;) {
-      const int width = hb + 1 < 8 ? hb + 1 : 8;
-      const int shift = hb + 1 - width;
-      const uint32_t dmask = (1u << width) - 1;
-      if (tid < 256) hist[tid] = 0;
-      __syncthreads();
+    int width = hb + 1 < 8 ? hb + 1 : 8;
+    int shift = hb + 1 - width;
+    uint32_t dmask = (1u << width) - 1;
+    // pass 2: first digit
+    for (uint32_t i = tid; i < m; i += 1024) {
+      const uint64_t key = keys[i];
+      if (live(key)) atomicAdd(&hist[(uint32_t)(key >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) select_find_bin(hist, krem, lane, &s_bin);
+    __syncthreads();
+    SelectBin sb = s_bin;
+    krem -= sb.below;
+    prefix |= (uint64_t)sb.bin << shift;
+    mask |= (uint64_t)dmask << shift;
+    if (sb.count == krem || shift == 0) {
+      T = prefix | (shift ? ((1ull << shift) - 1) : 0ull);  // the whole bin is selected
+    } else if (sb.count <= kSelCand) {
+      // pass 3: winners below the bin, the bin itself into LDS
+      const uint64_t bin_lo = prefix, bin_hi = prefix | ((1ull << shift) - 1);
       for (uint32_t i = tid; i < m; i += 1024) {
         const uint64_t key = keys[i];
-        if (live(key) && (key & mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & dmask], 1u);
-      }
-      __syncthreads();
-      if (wave == 0) {
-        // bins 4*lane .. 4*lane+3; inclusive scan over lanes
-        const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-        const uint32_t mine = h0 + h1 + h2 + h3;
-        uint32_t incl = mine;
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-          const uint32_t t = __shfl_up(incl, o, kWave);
-          if (lane >= o) incl += t;
-        }
-        const uint32_t excl = incl - mine;
-        if (excl < krem && krem <= incl) {
-          uint32_t below = excl, b = 4 * lane, c = h0;
-          if (below + c < krem) {
-            below += c; b += 1; c = h1;
-            if (below + c < krem) {
-              below += c; b += 1; c = h2;
-              if (below + c < krem) { below += c; b += 1; c = h3; }
-            }
+        if (!live(key) || key > bin_hi) continue;
+        if (key < bin_lo) {
+          const uint32_t pos = atomicAdd(&s_sel, 1u);
+          if (pos < k) {
+            sel_key[pos] = key;
+            sel_idx[pos] = i;
           }
-          s_bin = b;
-          s_below = below;
-          s_bincount = c;
+        } else {
+          const uint32_t pos = atomicAdd(&s_ncand, 1u);
+          if (pos < kSelCand) {
+            cand_key[pos] = key;
+            cand_idx[pos] = i;
+          }
         }
       }
       __syncthreads();
-      const uint32_t b = s_bin, bincount = s_bincount;
-      krem -= s_below;
-      prefix |= (uint64_t)b << shift;
-      mask |= (uint64_t)dmask << shift;
-      if (bincount == krem || shift == 0) {  // the whole bin is selected / exact key reached
-        T = prefix | (shift ? ((1ull << shift) - 1) : 0ull);
-        break;
-      }
+      const uint32_t ncand = s_ncand < kSelCand ? s_ncand : kSelCand;
+      // remaining digits on the LDS list
       hb = shift - 1;
+      for (;;) {
+        width = hb + 1 < 8 ? hb + 1 : 8;
+        shift = hb + 1 - width;
+        dmask = (1u << width) - 1;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < ncand; i += 1024) {
+          const uint64_t key = cand_key[i];
+          if ((key & mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & dmask], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) select_find_bin(hist, krem, lane, &s_bin);
+        __syncthreads();
+        sb = s_bin;
+        krem -= sb.below;
+        prefix |= (uint64_t)sb.bin << shift;
+        mask |= (uint64_t)dmask << shift;
+        if (sb.count == krem || shift == 0) {
+          Tc = prefix | (shift ? ((1ull << shift) - 1) : 0ull);
+          break;
+        }
+        hb = shift - 1;
+      }
+      from_cand = true;
+      for (uint32_t i = tid; i < ncand; i += 1024) {
+        const uint64_t key = cand_key[i];
+        if (key <= Tc) {
+          const uint32_t pos = atomicAdd(&s_sel, 1u);
+          if (pos < k) {
+            sel_key[pos] = key;
+            sel_idx[pos] = cand_idx[i];
+          }
+        }
+      }
+    } else {
+      // crowded bin (more than kSelCand keys share the digit): keep resolving on the global keys
+      hb = shift - 1;
+      for (;;) {
+        width = hb + 1 < 8 ? hb + 1 : 8;
+        shift = hb + 1 - width;
+        dmask = (1u << width) - 1;
+        __syncthreads();
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < m; i += 1024) {
+          const uint64_t key = keys[i];
+          if (live(key) && (key & mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & dmask], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) select_find_bin(hist, krem, lane, &s_bin);
+        __syncthreads();
+        sb = s_bin;
+        krem -= sb.below;
+        prefix |= (uint64_t)sb.bin << shift;
+        mask |= (uint64_t)dmask << shift;
+        if (sb.count == krem || shift == 0) {
+          T = prefix | (shift ? ((1ull << shift) - 1) : 0ull);
+          break;
+        }
+        hb = shift - 1;
+      }
     }
   }
 
-  // compaction of the winners
-  for (uint32_t i = tid; i < m; i += 1024) {
-    const uint64_t key = keys[i];
-    if (live(key) && key <= T) {
-      const uint32_t pos = atomicAdd(&s_sel, 1u);
-      if (pos < k) {
-        sel_key[pos] = key;
-        sel_idx[pos] = i;
+  if (!from_cand) {
+    // compaction of the winners straight from the global keys
+    for (uint32_t i = tid; i < m; i += 1024) {
+      const uint64_t key = keys[i];
+      if (live(key) && key <= T) {
+        const uint32_t pos = atomicAdd(&s_sel, 1u);
+        if (pos < k) {
+          sel_key[pos] = key;
+          sel_idx[pos] = i;
+        }
       }
     }
   }
@@ -161,64 +265,54 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
 // ---------------------------------------------------------------------------
 // K4: packed sign-bit Hamming scan + fused top-k.  Replaces binary_top_k
 // (search.rs:76-92) + packed_hamming (distances.rs:426-437, word_mask :472-481).
-// A wave reads a tile of 64 rows (64*words u64) as coalesced 16-B-per-lane
-// loads, counts bits per word, and regroups the per-word counts by row in LDS.
+//
+// The bit matrix is the index's own derived structure, so it is stored the way
+// a wave wants to read it: per tile of 64 rows, word pair j of all 64 rows is
+// contiguous ([tile][pair][row][2] u64).  Lane r then reads row r's words with
+// fully coalesced 16-B loads (1 KiB per wave instruction) and owns the row's
+// whole popcount: no cross-lane step, no LDS.  The query words are wave-uniform
+// (scalar loads, SGPR operands).  PAIRS > 0 unrolls the row completely so every
+// load of a tile is in flight before the first popcount.
 // ---------------------------------------------------------------------------
-template <int R>
+template <int R, int PAIRS>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(const HammingArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t W = a.words;
-  uint64_t *qs = reinterpret_cast<uint64_t *>(smem);  // [W] query words, [W] masks
-  uint64_t *ms = qs + W;
-  uint32_t *cnt = reinterpret_cast<uint32_t *>(ms + W) + wib * (kWave * W);  // [64*W] per wave
-  const uint32_t rem = a.d % 64;
-  for (uint32_t i = threadIdx.x; i < W; i += blockDim.x) {
-    qs[i] = a.qbits[i];
-    ms[i] = (i + 1 == W && rem != 0) ? ((1ull << rem) - 1) : ~0ull;
-  }
-  __syncthreads();
-
+  const uint32_t pairs = PAIRS > 0 ? (uint32_t)PAIRS : a.pairs;
   const uint32_t total_waves = gridDim.x * kWavesPerBlock;
   const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
   const uint32_t ntiles = (a.n + kWave - 1) / kWave;
-  const uint32_t tile_words = kWave * W;
-  const uint32_t nload = (tile_words + 127) / 128;  // 2 words per lane per load
-  const uint64_t total_words = (uint64_t)a.n * W;
+  const uint32_t last_word = a.words - 1;
+  const uint32_t rem = a.d % 64;
+  const uint64_t last_mask = rem ? ((1ull << rem) - 1) : ~0ull;  // distances.rs:472-481 word_mask
+  const u64x2 *bits = reinterpret_cast<const u64x2 *>(a.bits);
 
   WaveTopK<R> tk;
   tk.init(a.k, lane);
   for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
-    const uint64_t tile_base = (uint64_t)t * tile_words;
-    uint32_t w0 = (2u * lane) % W;  // word index within its row
-    const uint32_t stepw = 128u % W;
-    for (uint32_t j = 0; j < nload; ++j) {
-      const uint32_t f = j * 128u + 2u * lane;  // word offset in tile
-      if (f < tile_words) {
-        const uint64_t g = tile_base + f;
-        uint64_t x0 = 0, x1 = 0;
-        if (g + 1 < total_words) {
-          const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(a.bits + g));
-          x0 = v.x;
-          x1 = v.y;
-        } else if (g < total_words) {
-          x0 = a.bits[g];
-        }
-        const uint32_t w1 = (w0 + 1 == W) ? 0 : w0 + 1;
-        const uint32_t c0 = __popcll((x0 ^ qs[w0]) & ms[w0]);
-        const uint32_t c1 = __popcll((x1 ^ qs[w1]) & ms[w1]);
-        cnt[f] = c0;
-        if (f + 1 < tile_words) cnt[f + 1] = c1;
-      }
-      w0 += stepw;
-      if (w0 >= W) w0 -= W;
-    }
-    wave_lds_fence();
-    const uint32_t grow = t * kWave + lane;
+    const u64x2 *base = bits + ((size_t)t * pairs * kWave + lane);
     uint32_t ham = 0;
-    for (uint32_t i = 0; i < W; ++i) ham += cnt[lane * W + i];
-    wave_lds_fence();
+    if (PAIRS > 0) {
+      u64x2 v[PAIRS > 0 ? PAIRS : 1];
+#pragma unroll
+      for (int j = 0; j < PAIRS; ++j) v[j] = __builtin_nontemporal_load(base + (size_t)j * kWave);
+#pragma unroll
+      for (int j = 0; j < PAIRS; ++j) {
+        const uint32_t w0 = 2 * j, w1 = 2 * j + 1;
+        const uint64_t q0 = a.qbits[w0], q1 = w1 < a.words ? a.qbits[w1] : 0ull;
+        const uint64_t m0 = w0 == last_word ? last_mask : ~0ull, m1 = w1 == last_word ? last_mask : ~0ull;
+        ham += __popcll((v[j].x ^ q0) & m0) + __popcll((v[j].y ^ q1) & m1);
+      }
+    } else {
+      for (uint32_t j = 0; j < pairs; ++j) {
+        const u64x2 v = __builtin_nontemporal_load(base + (size_t)j * kWave);
+        const uint32_t w0 = 2 * j, w1 = 2 * j + 1;
+        const uint64_t q0 = a.qbits[w0], q1 = w1 < a.words ? a.qbits[w1] : 0ull;
+        const uint64_t m0 = w0 == last_word ? last_mask : ~0ull, m1 = w1 == last_word ? last_mask : ~0ull;
+        ham += __popcll((v.x ^ q0) & m0) + __popcll((v.y ^ q1) & m1);
+      }
+    }
+    const uint32_t grow = t * kWave + lane;
     bool valid = grow < a.n;
     const uint32_t my_rank = (valid && a.id_rank) ? a.id_rank[grow] : grow;
     const float raw = (float)ham;  // distance as f32 (distances.rs:436)
@@ -232,11 +326,13 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
 // ---------------------------------------------------------------------------
 // K5: sign packing (compress_sign_bits, distances.rs:413-423).  One wave per
 // 64 coordinates: lane j tests v[j] >= 0.0, the wave ballot IS the word.
+// tiled != 0 writes K4's [tile][pair][row][2] layout, else plain [row][word].
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sign_pack_kernel(const float *__restrict__ rows, size_t stride, uint32_t n,
-                                                        uint32_t d, uint64_t *__restrict__ bits) {
+                                                        uint32_t d, uint64_t *__restrict__ bits, int tiled) {
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t W = (d + 63) / 64;
+  const uint32_t pairs = (W + 1) / 2;
   const uint64_t total = (uint64_t)n * W;
   const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / kWave);
   for (uint64_t w = (uint64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6); w < total; w += nwaves) {
@@ -245,7 +341,10 @@ __global__ __launch_bounds__(256) void sign_pack_kernel(const float *__restrict_
     bool bit = false;
     if (j < d) bit = rows[(size_t)r * stride + j] >= 0.0f;
     const uint64_t word = __ballot(bit);
-    if (lane == 0) bits[w] = word;
+    if (lane == 0) {
+      const size_t at = tiled ? hamming_word_index(r, wi, pairs) : (size_t)w;
+      bits[at] = word;
+    }
   }
 }
 
@@ -356,36 +455,42 @@ hipError_t launch_scan(const ScanArgs &a, uint32_t blocks, hipStream_t s) {
 hipError_t launch_select(const uint64_t *keys, const Payload *pay, uint32_t m, uint32_t k, uint64_t lo_key, int has_lo,
                          int *dev_status, ResultBlock *out, hipStream_t s) {
   if (k == 0 || k > (uint32_t)kMaxFusedK) return hipErrorInvalidValue;
-  const size_t lds = (size_t)k * 12;
+  const size_t lds = ((size_t)k + kSelCand) * 12;
   hipLaunchKernelGGL(select_topk_kernel, dim3(1), dim3(1024), lds, s, keys, pay, m, k, lo_key, has_lo, dev_status, out);
   return hipGetLastError();
 }
 
-size_t hamming_lds_bytes(uint32_t words) {
-  const size_t bytes = (size_t)words * 16 + (size_t)kWavesPerBlock * kWave * words * 4;
-  return bytes <= kMaxLds ? bytes : 0;
-}
-
-hipError_t launch_hamming(const HammingArgs &a, uint32_t blocks, hipStream_t s) {
-  const size_t lds = hamming_lds_bytes(a.words);
-  if (lds == 0 || a.k == 0 || a.k > (uint32_t)kMaxFusedK) return hipErrorInvalidValue;
-  if (a.k <= 64) {
-    auto kern = hamming_topk_kernel<1>;
-    hipError_t e = allow_lds(kern, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
-  } else {
-    auto kern = hamming_topk_kernel<4>;
-    hipError_t e = allow_lds(kern, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+template <int R>
+hipError_t launch_hamming_r(const HammingArgs &a, uint32_t blocks, hipStream_t s) {
+#define VT_HAM_CASE(P)                                                                                     \
+  case P:                                                                                                  \
+    hipLaunchKernelGGL((hamming_topk_kernel<R, P>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0, s, a);  \
+    break;
+  switch (a.pairs) {
+    VT_HAM_CASE(1)
+    VT_HAM_CASE(2)
+    VT_HAM_CASE(3)
+    VT_HAM_CASE(4)
+    VT_HAM_CASE(6)
+    VT_HAM_CASE(8)
+    VT_HAM_CASE(12)
+    VT_HAM_CASE(16)
+    default:
+      hipLaunchKernelGGL((hamming_topk_kernel<R, 0>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0, s, a);
   }
+#undef VT_HAM_CASE
   return hipGetLastError();
 }
 
-hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32_t d, uint64_t *bits, hipStream_t s) {
+hipError_t launch_hamming(const HammingArgs &a, uint32_t blocks, hipStream_t s) {
+  if (a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.words == 0 || a.pairs != (a.words + 1) / 2) return hipErrorInvalidValue;
+  return a.k <= 64 ? launch_hamming_r<1>(a, blocks, s) : launch_hamming_r<4>(a, blocks, s);
+}
+
+hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32_t d, uint64_t *bits, int tiled,
+                            hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(sign_pack_kernel, dim3(2048), dim3(256), 0, s, rows, stride, n, d, bits);
+  hipLaunchKernelGGL(sign_pack_kernel, dim3(2048), dim3(256), 0, s, rows, stride, n, d, bits, tiled);
   return hipGetLastError();
 }
 
