@@ -79,49 +79,83 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-// Wave-wide list of the k smallest keys seen so far, spread over the lanes'
-// registers: slot = lane + 64*j.  `thr` (wave-uniform) is the largest key in
-// the list, i.e. the k-th best; a candidate enters only if key < thr.
+// Wave-wide buffer holding (at least) the k smallest keys seen so far, spread
+// over the lanes' registers: slot (lane, j), 64*R slots, k < 64*R.
+//  * `thr` (wave-uniform) is an upper bound: only keys < thr can still be among
+//    the k smallest.  It is the exact k-th smallest as of the last compaction.
+//  * A candidate that passes is written into any free slot (a wave-uniform
+//    free-slot bitmask per register row): ~20 instructions, no reduction.
+//  * When no slot is free, compact(): a 64-step bitwise search finds the k-th
+//    smallest key of the buffer, everything above it is dropped, thr tightens.
+//    One compaction buys 64*R - k cheap insertions.
 template <int R>
 struct WaveTopK {
   uint64_t key[R];
   uint32_t row[R];
   float raw[R];
-  uint64_t thr;
+  uint64_t freem[R];  // wave-uniform
+  uint64_t thr;       // wave-uniform
+  uint32_t k;
 
-  __device__ __forceinline__ void init(uint32_t k, int lane) {
+  __device__ __forceinline__ void init(uint32_t k_, int lane) {
+    (void)lane;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-      key[j] = (uint32_t)(lane + kWave * j) < k ? kEmptyKey : 0ull;
+      key[j] = kEmptyKey;
       row[j] = 0;
       raw[j] = 0.f;
+      freem[j] = ~0ull;
     }
     thr = kEmptyKey;
+    k = k_;
+  }
+
+  // Keeps the k smallest keys, frees every other slot, tightens thr.
+  __device__ __forceinline__ void compact() {
+    uint32_t live = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) live += __popcll(__ballot(key[j] != kEmptyKey));
+    if (live > k) {
+      uint64_t T = 0;  // k-th smallest: the largest T with count(key < T) < k
+      for (int b = 63; b >= 0; --b) {
+        const uint64_t c = T | (1ull << b);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) cnt += __popcll(__ballot(key[j] < c));
+        if (cnt < k) T = c;
+      }
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        if (key[j] > T) key[j] = kEmptyKey;
+      thr = T;
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) freem[j] = __ballot(key[j] == kEmptyKey);
   }
 
   // Wave-uniform arguments; precondition ck < thr.
   __device__ __forceinline__ void push(uint64_t ck, uint32_t crow, float craw, int lane) {
-    bool has = false;
+    bool any = false;
 #pragma unroll
-    for (int j = 0; j < R; ++j) has |= (key[j] == thr);
-    const uint64_t b = __ballot(has);
-    const int owner = __ffsll((unsigned long long)b) - 1;
-    if (lane == owner) {
-      bool done = false;
+    for (int j = 0; j < R; ++j) any |= freem[j] != 0;
+    if (!any) {
+      compact();
+      if (!(ck < thr)) return;
+    }
+    bool done = false;
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
-        if (!done && key[j] == thr) {
+    for (int j = 0; j < R; ++j) {
+      if (!done && freem[j] != 0) {
+        const int l = __ffsll((unsigned long long)freem[j]) - 1;
+        freem[j] &= freem[j] - 1;
+        if (lane == l) {
           key[j] = ck;
           row[j] = crow;
           raw[j] = craw;
-          done = true;
         }
+        done = true;
       }
     }
-    uint64_t lm = 0;
-#pragma unroll
-    for (int j = 0; j < R; ++j) lm = key[j] > lm ? key[j] : lm;
-    thr = uniform_u64(wave_max_u64(lm));
   }
 
   // Offers one candidate per lane (valid lanes only).
@@ -139,18 +173,26 @@ struct WaveTopK {
     }
   }
 
-  __device__ __forceinline__ void store(uint64_t *keys, Payload *pay, uint32_t k, int lane) const {
+  // Writes the k best (unsorted) to keys/pay[0..k), padding with kEmptyKey.
+  __device__ __forceinline__ void store(uint64_t *keys, Payload *pay, int lane) {
+    compact();
+    uint32_t base = 0;
+    const uint64_t lt = (1ull << lane) - 1;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-      const uint32_t slot = lane + kWave * j;
-      if (slot < k) {
-        keys[slot] = key[j];
+      const bool has = key[j] != kEmptyKey;
+      const uint64_t m = __ballot(has);
+      const uint32_t pos = base + __popcll(m & lt);
+      if (has && pos < k) {
+        keys[pos] = key[j];
         Payload p;
         p.row = row[j];
         p.raw = raw[j];
-        pay[slot] = p;
+        pay[pos] = p;
       }
+      base += __popcll(m);
     }
+    for (uint32_t i = base + lane; i < k; i += kWave) keys[i] = kEmptyKey;
   }
 };
 

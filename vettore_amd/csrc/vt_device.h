@@ -27,7 +27,8 @@ static_assert(sizeof(Entry) == 16 && sizeof(Payload) == 8, "layout");
 constexpr uint64_t kEmptyKey = ~0ull;
 constexpr int kTileRows = 32;     // rows per wave tile in the scan kernel
 constexpr int kWavesPerBlock = 4;
-constexpr int kMaxFusedK = 256;   // largest k one scan pass selects
+constexpr int kMaxFusedK = 192;   // largest k one scan pass selects (wave buffer: 256 slots)
+constexpr int kSmallK = 40;       // k <= kSmallK uses a 64-slot wave buffer
 constexpr uint32_t kRowAlign = 64;  // slab row stride is a multiple of 64 floats (256 B)
 
 // What the select kernel hands back (lives in pinned host memory: the kernel

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
     if (a.has_lo) valid = valid && key > a.lo_key;
     tk.offer(valid, key, grow, raw, lane);
   }
-  tk.store(a.part_keys + (size_t)wave_global * a.k, a.part_pay + (size_t)wave_global * a.k, a.k, lane);
+  tk.store(a.part_keys + (size_t)wave_global * a.k, a.part_pay + (size_t)wave_global * a.k, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -484,7 +484,7 @@ hipError_t launch_hamming_r(const HammingArgs &a, uint32_t blocks, hipStream_t s
 
 hipError_t launch_hamming(const HammingArgs &a, uint32_t blocks, hipStream_t s) {
   if (a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.words == 0 || a.pairs != (a.words + 1) / 2) return hipErrorInvalidValue;
-  return a.k <= 64 ? launch_hamming_r<1>(a, blocks, s) : launch_hamming_r<4>(a, blocks, s);
+  return a.k <= (uint32_t)kSmallK ? launch_hamming_r<1>(a, blocks, s) : launch_hamming_r<4>(a, blocks, s);
 }
 
 hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32_t d, uint64_t *bits, int tiled,

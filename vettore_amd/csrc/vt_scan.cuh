@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       tk.offer(valid, key, src_row, raw, lane);
     }
   }
-  tk.store(a.part_keys + (size_t)wave_global * a.k, a.part_pay + (size_t)wave_global * a.k, a.k, lane);
+  tk.store(a.part_keys + (size_t)wave_global * a.k, a.part_pay + (size_t)wave_global * a.k, lane);
 }
 
 constexpr size_t kMaxLds = 160 * 1024;
@@ -380,11 +380,11 @@ hipError_t launch_scan_l2(const ScanDev &sd, uint32_t blocks, size_t lds, bool p
 hipError_t launch_scan_misc(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
 hipError_t launch_scan_general(const ScanDev &sd, uint32_t blocks, size_t lds, hipStream_t s);
 
-// order (0..2) x list registers (k <= 64 -> 1, else 4) x padded
+// order (0..2) x buffer registers (k <= kSmallK -> 1, else 4) x padded
 #define VT_SCAN_DISPATCH_ORDERED(OPV)                                                          \
   do {                                                                                         \
     const int order = sd.a.order;                                                              \
-    const bool big = sd.a.k > 64;                                                              \
+    const bool big = sd.a.k > kSmallK;                                                              \
     if (!padded) {                                                                             \
       if (!big) {                                                                              \
         if (order == 0) return launch_scan_t<OPV, 0, 1, false, false>(sd, blocks, lds, s);     \

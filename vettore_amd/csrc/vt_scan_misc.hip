@@ -7,7 +7,7 @@ namespace dev {
 
 #define VT_SCAN_DISPATCH_FIXED(OPV, ORD)                                                      \
   do {                                                                                        \
-    const bool big = sd.a.k > 64;                                                             \
+    const bool big = sd.a.k > (uint32_t)kSmallK;                                                             \
     if (!padded) {                                                                            \
       if (!big) return launch_scan_t<OPV, ORD, 1, false, false>(sd, blocks, lds, s);          \
       return launch_scan_t<OPV, ORD, 4, false, false>(sd, blocks, lds, s);                    \
