@@ -79,122 +79,116 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-// Wave-wide buffer holding (at least) the k smallest keys seen so far, spread
-// over the lanes' registers: slot (lane, j), 64*R slots, k < 64*R.
+// Wave-private candidate buffer in LDS holding (at least) the k smallest keys
+// seen so far: keys[CAP] + payload[CAP], k + 64 <= CAP.
 //  * `thr` (wave-uniform) is an upper bound: only keys < thr can still be among
 //    the k smallest.  It is the exact k-th smallest as of the last compaction.
-//  * A candidate that passes is written into any free slot (a wave-uniform
-//    free-slot bitmask per register row): ~20 instructions, no reduction.
-//  * When no slot is free, compact(): a 64-step bitwise search finds the k-th
-//    smallest key of the buffer, everything above it is dropped, thr tightens.
-//    One compaction buys 64*R - k cheap insertions.
-template <int R>
+//  * offer(): every lane whose candidate passes appends it at n + (its rank among
+//    the passing lanes) -- one ballot, one popcount, two ds_write_b64, whatever
+//    the number of hits; nothing is serialised.
+//  * when a full wave of hits might not fit, compact(): the lanes pull the
+//    buffer into registers, a 64-step bitwise search (ballot + popcount per
+//    step) finds the k-th smallest key, the survivors are written back densely
+//    and thr tightens.  One compaction buys CAP - k - 63 insertions.
+template <int CAP>
 struct WaveTopK {
-  uint64_t key[R];
-  uint32_t row[R];
-  float raw[R];
-  uint64_t freem[R];  // wave-uniform
-  uint64_t thr;       // wave-uniform
+  static constexpr int kRegs = (CAP + kWave - 1) / kWave;
+  uint64_t *bk;  // LDS keys[CAP]
+  uint64_t *bp;  // LDS payload[CAP]: row | raw bits << 32
+  uint32_t n;    // wave-uniform: entries in the buffer
   uint32_t k;
+  uint64_t thr;  // wave-uniform
 
-  __device__ __forceinline__ void init(uint32_t k_, int lane) {
-    (void)lane;
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      key[j] = kEmptyKey;
-      row[j] = 0;
-      raw[j] = 0.f;
-      freem[j] = ~0ull;
-    }
-    thr = kEmptyKey;
+  static constexpr size_t lds_bytes() { return (size_t)CAP * 16; }
+
+  __device__ __forceinline__ void init(void *lds, uint32_t k_) {
+    bk = reinterpret_cast<uint64_t *>(lds);
+    bp = bk + CAP;
+    n = 0;
     k = k_;
+    thr = kEmptyKey;
   }
 
-  // Keeps the k smallest keys, frees every other slot, tightens thr.
-  __device__ __forceinline__ void compact() {
-    uint32_t live = 0;
+  // Keeps the k smallest keys at bk/bp[0..n), tightens thr.
+  __device__ __forceinline__ void compact(int lane) {
+    wave_lds_fence();
+    uint64_t key[kRegs], pay[kRegs];
 #pragma unroll
-    for (int j = 0; j < R; ++j) live += __popcll(__ballot(key[j] != kEmptyKey));
-    if (live > k) {
-      uint64_t T = 0;  // k-th smallest: the largest T with count(key < T) < k
+    for (int j = 0; j < kRegs; ++j) {
+      const uint32_t i = lane + kWave * j;
+      const bool in = i < n && i < (uint32_t)CAP;
+      key[j] = in ? bk[i] : kEmptyKey;
+      pay[j] = in ? bp[i] : 0ull;
+    }
+    uint64_t T = kEmptyKey;
+    if (n > k) {
+      T = 0;  // k-th smallest: the largest T with count(key < T) < k
       for (int b = 63; b >= 0; --b) {
         const uint64_t c = T | (1ull << b);
         uint32_t cnt = 0;
 #pragma unroll
-        for (int j = 0; j < R; ++j) cnt += __popcll(__ballot(key[j] < c));
+        for (int j = 0; j < kRegs; ++j) cnt += __popcll(__ballot(key[j] < c));
         if (cnt < k) T = c;
       }
-#pragma unroll
-      for (int j = 0; j < R; ++j)
-        if (key[j] > T) key[j] = kEmptyKey;
       thr = T;
     }
+    wave_lds_fence();
+    const uint64_t lt = (1ull << lane) - 1;
+    uint32_t base = 0;
 #pragma unroll
-    for (int j = 0; j < R; ++j) freem[j] = __ballot(key[j] == kEmptyKey);
-  }
-
-  // Wave-uniform arguments; precondition ck < thr.
-  __device__ __forceinline__ void push(uint64_t ck, uint32_t crow, float craw, int lane) {
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < R; ++j) any |= freem[j] != 0;
-    if (!any) {
-      compact();
-      if (!(ck < thr)) return;
-    }
-    bool done = false;
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      if (!done && freem[j] != 0) {
-        const int l = __ffsll((unsigned long long)freem[j]) - 1;
-        freem[j] &= freem[j] - 1;
-        if (lane == l) {
-          key[j] = ck;
-          row[j] = crow;
-          raw[j] = craw;
-        }
-        done = true;
+    for (int j = 0; j < kRegs; ++j) {
+      const bool has = key[j] != kEmptyKey && key[j] <= T;
+      const uint64_t m = __ballot(has);
+      const uint32_t pos = base + __popcll(m & lt);
+      if (has && pos < k) {
+        bk[pos] = key[j];
+        bp[pos] = pay[j];
       }
+      base += __popcll(m);
     }
+    n = base < k ? base : k;
+    wave_lds_fence();
   }
 
   // Offers one candidate per lane (valid lanes only).
   __device__ __forceinline__ void offer(bool valid, uint64_t ck, uint32_t crow, float craw, int lane) {
-    uint64_t m = __ballot(valid && ck < thr);
-    while (m) {
-      const int src = __ffsll((unsigned long long)m) - 1;
-      m &= m - 1;
-      const uint64_t k2 = readlane_u64(ck, src);
-      if (k2 < thr) {
-        const uint32_t r2 = __builtin_amdgcn_readlane(crow, src);
-        const float f2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(craw), src));
-        push(k2, r2, f2, lane);
-      }
+    bool hit = valid && ck < thr;
+    uint64_t m = __ballot(hit);
+    if (!m) return;
+    if (n + (uint32_t)__popcll(m) > (uint32_t)CAP) {
+      compact(lane);
+      hit = hit && ck < thr;
+      m = __ballot(hit);
+      if (!m) return;
     }
+    if (hit) {
+      const uint32_t pos = n + __popcll(m & ((1ull << lane) - 1));
+      bk[pos] = ck;
+      bp[pos] = (uint64_t)crow | ((uint64_t)__float_as_uint(craw) << 32);
+    }
+    n += __popcll(m);
   }
 
   // Writes the k best (unsorted) to keys/pay[0..k), padding with kEmptyKey.
   __device__ __forceinline__ void store(uint64_t *keys, Payload *pay, int lane) {
-    compact();
-    uint32_t base = 0;
-    const uint64_t lt = (1ull << lane) - 1;
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      const bool has = key[j] != kEmptyKey;
-      const uint64_t m = __ballot(has);
-      const uint32_t pos = base + __popcll(m & lt);
-      if (has && pos < k) {
-        keys[pos] = key[j];
-        Payload p;
-        p.row = row[j];
-        p.raw = raw[j];
-        pay[pos] = p;
+    compact(lane);
+    for (uint32_t i = lane; i < k; i += kWave) {
+      if (i < n) {
+        keys[i] = bk[i];
+        const uint64_t p = bp[i];
+        Payload q;
+        q.row = (uint32_t)p;
+        q.raw = __uint_as_float((uint32_t)(p >> 32));
+        pay[i] = q;
+      } else {
+        keys[i] = kEmptyKey;
       }
-      base += __popcll(m);
     }
-    for (uint32_t i = base + lane; i < k; i += kWave) keys[i] = kEmptyKey;
   }
 };
+
+constexpr int kCapSmall = 128;  // k <= 64
+constexpr int kCapLarge = 320;  // k <= 256
 
 // distances.rs:92-98 f64_to_f32
 __device__ __forceinline__ bool f64_to_f32(double v, float *out) {

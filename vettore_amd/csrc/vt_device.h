@@ -27,8 +27,8 @@ static_assert(sizeof(Entry) == 16 && sizeof(Payload) == 8, "layout");
 constexpr uint64_t kEmptyKey = ~0ull;
 constexpr int kTileRows = 32;     // rows per wave tile in the scan kernel
 constexpr int kWavesPerBlock = 4;
-constexpr int kMaxFusedK = 192;   // largest k one scan pass selects (wave buffer: 256 slots)
-constexpr int kSmallK = 40;       // k <= kSmallK uses a 64-slot wave buffer
+constexpr int kMaxFusedK = 256;   // largest k one scan pass selects (320-slot wave buffer)
+constexpr int kSmallK = 64;       // k <= kSmallK uses the 128-slot wave buffer
 constexpr uint32_t kRowAlign = 64;  // slab row stride is a multiple of 64 floats (256 B)
 
 // What the select kernel hands back (lives in pinned host memory: the kernel
@@ -62,8 +62,10 @@ struct ScanArgs {
   int *status;             // device int; atomicMax'ed to VT_ERR_OVERFLOW on "metric overflow"
 };
 
-// LDS bytes per block the scan kernel needs for dimension d (0 = unsupported).
-size_t scan_lds_bytes(uint32_t d);
+// LDS bytes per block the scan kernel needs for dimension d and list size k (0 = unsupported).
+size_t scan_lds_bytes(uint32_t d, uint32_t k);
+// LDS bytes per block of the hamming kernel for list size k.
+size_t hamming_lds_bytes(uint32_t k);
 inline uint32_t scan_waves(uint32_t blocks) { return blocks * kWavesPerBlock; }
 hipError_t launch_scan(const ScanArgs &a, uint32_t blocks, hipStream_t s);
 

@@ -277,19 +277,20 @@ struct ScanJob {
 // Scan + select passes until `want` hits are collected (ascending by key).
 // The query must already be in c.dQ (padded to padded_dim(d)).
 int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out, bool count_profile) {
-  const size_t lds = vt::scan_lds_bytes(j.d);
-  if (lds == 0)
+  if (vt::scan_lds_bytes(j.d, 1) == 0)
     return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(j.d) + " exceeds what the scan kernel stages in LDS");
   if (j.metric == VT_JACCARD && j.d >= 4096)
     return fail(VT_ERR_UNSUPPORTED, "jaccard on device supports d < 4096");
   const uint32_t ntiles = (j.n + vt::kTileRows - 1) / vt::kTileRows;
-  const uint32_t blocks = c.grid_for(ntiles, lds);
-  const uint32_t waves = vt::scan_waves(blocks);
+  // very wide rows leave no LDS for the large candidate buffer: smaller passes
+  const size_t kmax = vt::scan_lds_bytes(j.d, vt::kMaxFusedK) ? (size_t)vt::kMaxFusedK : (size_t)vt::kSmallK;
   uint64_t lo = 0;
   bool has_lo = false;
   const size_t total = std::min<size_t>(want, j.n);
   while (out.size() < total) {
-    const uint32_t k = (uint32_t)std::min<size_t>((size_t)vt::kMaxFusedK, total - out.size());
+    const uint32_t k = (uint32_t)std::min<size_t>(kmax, total - out.size());
+    const uint32_t blocks = c.grid_for(ntiles, vt::scan_lds_bytes(j.d, k));
+    const uint32_t waves = vt::scan_waves(blocks);
     VT_TRY(c.dPartKeys.ensure((size_t)waves * k));
     VT_TRY(c.dPartPay.ensure((size_t)waves * k));
     vt::ScanArgs a{};
@@ -337,13 +338,13 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
                 size_t want, std::vector<vt::Entry> &out, bool count_profile) {
   const uint32_t words = (d + 63) / 64;
   const uint32_t ntiles = (n + 63) / 64;
-  const uint32_t blocks = c.grid_for(ntiles, 0);
-  const uint32_t waves = vt::scan_waves(blocks);
   uint64_t lo = 0;
   bool has_lo = false;
   const size_t total = std::min<size_t>(want, n);
   while (out.size() < total) {
     const uint32_t k = (uint32_t)std::min<size_t>((size_t)vt::kMaxFusedK, total - out.size());
+    const uint32_t blocks = c.grid_for(ntiles, vt::hamming_lds_bytes(k));
+    const uint32_t waves = vt::scan_waves(blocks);
     VT_TRY(c.dPartKeys.ensure((size_t)waves * k));
     VT_TRY(c.dPartPay.ensure((size_t)waves * k));
     vt::HammingArgs a{};
@@ -420,7 +421,7 @@ int index_reserve(vt_flat *ix, uint32_t want_rows) {
 // Sets the dimension of an empty index (first insert after creation/emptying).
 int index_set_dim(vt_flat *ix, size_t d) {
   if (d > 0x7fffffffu) return fail(VT_ERR_UNSUPPORTED, "dimension too large");
-  if (vt::scan_lds_bytes((uint32_t)d) == 0)
+  if (vt::scan_lds_bytes((uint32_t)d, 1) == 0)
     return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(d) + " exceeds what the scan kernel stages in LDS");
   const uint32_t ld = vt::padded_dim((uint32_t)d);
   if (ld != ix->ld) {
@@ -931,7 +932,7 @@ int vt_vector_top_k(int device, size_t count, const char *ids, const size_t *id_
       break;
     }
   }
-  if (dimensions > 0x7fffffffu || vt::scan_lds_bytes((uint32_t)dimensions) == 0)
+  if (dimensions > 0x7fffffffu || vt::scan_lds_bytes((uint32_t)dimensions, 1) == 0)
     return fail(VT_ERR_UNSUPPORTED, "prefix dimension exceeds what the scan kernel stages in LDS");
   if (count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
   Ctx *cp = nullptr;

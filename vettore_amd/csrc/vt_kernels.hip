@@ -274,7 +274,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
 // (scalar loads, SGPR operands).  PAIRS > 0 unrolls the row completely so every
 // load of a tile is in flight before the first popcount.
 // ---------------------------------------------------------------------------
-template <int R, int PAIRS>
+template <int CAP, int PAIRS>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(const HammingArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -286,9 +286,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
   const uint32_t rem = a.d % 64;
   const uint64_t last_mask = rem ? ((1ull << rem) - 1) : ~0ull;  // distances.rs:472-481 word_mask
   const u64x2 *bits = reinterpret_cast<const u64x2 *>(a.bits);
+  extern __shared__ __align__(16) unsigned char hsmem[];
 
-  WaveTopK<R> tk;
-  tk.init(a.k, lane);
+  WaveTopK<CAP> tk;
+  tk.init(hsmem + wib * WaveTopK<CAP>::lds_bytes(), a.k);
   for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
     const u64x2 *base = bits + ((size_t)t * pairs * kWave + lane);
     uint32_t ham = 0;
@@ -423,24 +424,29 @@ __global__ __launch_bounds__(64) void normalize_l2_kernel(const float *__restric
   }
 }
 
-size_t scan_lds_for(const ScanShape &p) {
-  return ((size_t)p.ld + (size_t)kWavesPerBlock * kTileRows * p.ss) * sizeof(float);
+size_t scan_lds_for(const ScanShape &p, uint32_t k) {
+  const size_t buf = k <= (uint32_t)kSmallK ? WaveTopK<kCapSmall>::lds_bytes() : WaveTopK<kCapLarge>::lds_bytes();
+  return ((size_t)p.ld + (size_t)kWavesPerBlock * kTileRows * p.ss) * sizeof(float) + kWavesPerBlock * buf;
 }
 
 }  // namespace
 
-size_t scan_lds_bytes(uint32_t d) {
+size_t scan_lds_bytes(uint32_t d, uint32_t k) {
   ScanShape p;
   if (!make_scan_shape(d, 1, &p)) return 0;
-  const size_t bytes = scan_lds_for(p);
+  const size_t bytes = scan_lds_for(p, k);
   return bytes <= kMaxLds ? bytes : 0;
+}
+
+size_t hamming_lds_bytes(uint32_t k) {
+  return kWavesPerBlock * (k <= (uint32_t)kSmallK ? WaveTopK<kCapSmall>::lds_bytes() : WaveTopK<kCapLarge>::lds_bytes());
 }
 
 hipError_t launch_scan(const ScanArgs &a, uint32_t blocks, hipStream_t s) {
   ScanDev sd;
   sd.a = a;
   if (!make_scan_shape(a.d, a.n, &sd.p)) return hipErrorInvalidValue;
-  const size_t lds = scan_lds_for(sd.p);
+  const size_t lds = scan_lds_for(sd.p, a.k);
   if (lds > kMaxLds || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.stride < sd.p.ld || a.stride % 4 != 0)
     return hipErrorInvalidValue;
   if (a.gather != nullptr) return launch_scan_general(sd, blocks, lds, s);
@@ -460,11 +466,12 @@ hipError_t launch_select(const uint64_t *keys, const Payload *pay, uint32_t m, u
   return hipGetLastError();
 }
 
-template <int R>
+template <int CAP>
 hipError_t launch_hamming_r(const HammingArgs &a, uint32_t blocks, hipStream_t s) {
-#define VT_HAM_CASE(P)                                                                                     \
-  case P:                                                                                                  \
-    hipLaunchKernelGGL((hamming_topk_kernel<R, P>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0, s, a);  \
+  const size_t lds = kWavesPerBlock * WaveTopK<CAP>::lds_bytes();
+#define VT_HAM_CASE(P)                                                                                        \
+  case P:                                                                                                     \
+    hipLaunchKernelGGL((hamming_topk_kernel<CAP, P>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a); \
     break;
   switch (a.pairs) {
     VT_HAM_CASE(1)
@@ -476,7 +483,7 @@ hipError_t launch_hamming_r(const HammingArgs &a, uint32_t blocks, hipStream_t s
     VT_HAM_CASE(12)
     VT_HAM_CASE(16)
     default:
-      hipLaunchKernelGGL((hamming_topk_kernel<R, 0>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0, s, a);
+      hipLaunchKernelGGL((hamming_topk_kernel<CAP, 0>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
   }
 #undef VT_HAM_CASE
   return hipGetLastError();
@@ -484,7 +491,7 @@ hipError_t launch_hamming_r(const HammingArgs &a, uint32_t blocks, hipStream_t s
 
 hipError_t launch_hamming(const HammingArgs &a, uint32_t blocks, hipStream_t s) {
   if (a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.words == 0 || a.pairs != (a.words + 1) / 2) return hipErrorInvalidValue;
-  return a.k <= (uint32_t)kSmallK ? launch_hamming_r<1>(a, blocks, s) : launch_hamming_r<4>(a, blocks, s);
+  return a.k <= (uint32_t)kSmallK ? launch_hamming_r<kCapSmall>(a, blocks, s) : launch_hamming_r<kCapLarge>(a, blocks, s);
 }
 
 hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32_t d, uint64_t *bits, int tiled,

@@ -25,9 +25,10 @@
 //     -- so 32 chains advance in parallel, once per panel (~1% of its time);
 //   * after the last panel each lane owns a finished row: finiteness / f64
 //     recovery, rank key, compare with the wave's k-th best (wave-uniform
-//     threshold); the rare rows that pass are inserted one by one into a
-//     register-resident wave-wide list.
-// LDS per block is fixed (4 waves x 13.5 KiB + the query), whatever d is.
+//     threshold); rows that pass are appended, all at once, to a wave-private LDS
+//     buffer that is compacted to its k best when it fills (WaveTopK).
+// LDS per block is fixed (4 waves x (13.5 KiB panel + 2 or 5 KiB candidate buffer)
+// + the query), whatever d is.
 #pragma once
 #include "vt_common.cuh"
 
@@ -171,7 +172,7 @@ struct Cursor {
 // OP / ORDER < 0: taken from the arguments at run time.
 // GENERAL: rows addressed through `gather` and/or a stride != ld (prefix scan).
 // PADDED: d % 64 != 0 -- some chunks of a row are padding or the scalar tail.
-template <int OP, int ORDER, int R, bool GENERAL, bool PADDED>
+template <int OP, int ORDER, int CAP, bool GENERAL, bool PADDED>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const ScanDev sd) {
   extern __shared__ __align__(16) float lds[];
   const ScanArgs &a = sd.a;
@@ -181,6 +182,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
   const int odd = lane & 1;
   float *qs = lds;
   float *S = lds + p.ld + wib * (kTileRows * p.ss);
+  unsigned char *tkbuf = reinterpret_cast<unsigned char *>(lds + p.ld + kWavesPerBlock * (kTileRows * p.ss)) +
+                         wib * WaveTopK<CAP>::lds_bytes();
 
   for (uint32_t i = threadIdx.x; i < p.ld; i += blockDim.x) qs[i] = a.q[i];
   __syncthreads();
@@ -190,8 +193,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
   const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
   const uint32_t ntiles = p.ntiles;
 
-  WaveTopK<R> tk;
-  tk.init(a.k, lane);
+  WaveTopK<CAP> tk;
+  tk.init(tkbuf, a.k);
 
   if (wave_global < ntiles) {
     const uint32_t last_tile = wave_global + ((ntiles - 1 - wave_global) / total_waves) * total_waves;
@@ -365,9 +368,9 @@ inline hipError_t allow_lds(K kernel, size_t bytes) {
                              (int)bytes);
 }
 
-template <int OP, int ORDER, int R, bool GENERAL, bool PADDED>
+template <int OP, int ORDER, int CAP, bool GENERAL, bool PADDED>
 inline hipError_t launch_scan_t(const ScanDev &sd, uint32_t blocks, size_t lds, hipStream_t s) {
-  auto kern = scan_topk_kernel<OP, ORDER, R, GENERAL, PADDED>;
+  auto kern = scan_topk_kernel<OP, ORDER, CAP, GENERAL, PADDED>;
   hipError_t e = allow_lds(kern, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, sd);
@@ -387,22 +390,22 @@ hipError_t launch_scan_general(const ScanDev &sd, uint32_t blocks, size_t lds, h
     const bool big = sd.a.k > kSmallK;                                                              \
     if (!padded) {                                                                             \
       if (!big) {                                                                              \
-        if (order == 0) return launch_scan_t<OPV, 0, 1, false, false>(sd, blocks, lds, s);     \
-        if (order == 1) return launch_scan_t<OPV, 1, 1, false, false>(sd, blocks, lds, s);     \
-        return launch_scan_t<OPV, 2, 1, false, false>(sd, blocks, lds, s);                     \
+        if (order == 0) return launch_scan_t<OPV, 0, kCapSmall, false, false>(sd, blocks, lds, s);     \
+        if (order == 1) return launch_scan_t<OPV, 1, kCapSmall, false, false>(sd, blocks, lds, s);     \
+        return launch_scan_t<OPV, 2, kCapSmall, false, false>(sd, blocks, lds, s);                     \
       }                                                                                        \
-      if (order == 0) return launch_scan_t<OPV, 0, 4, false, false>(sd, blocks, lds, s);       \
-      if (order == 1) return launch_scan_t<OPV, 1, 4, false, false>(sd, blocks, lds, s);       \
-      return launch_scan_t<OPV, 2, 4, false, false>(sd, blocks, lds, s);                       \
+      if (order == 0) return launch_scan_t<OPV, 0, kCapLarge, false, false>(sd, blocks, lds, s);       \
+      if (order == 1) return launch_scan_t<OPV, 1, kCapLarge, false, false>(sd, blocks, lds, s);       \
+      return launch_scan_t<OPV, 2, kCapLarge, false, false>(sd, blocks, lds, s);                       \
     }                                                                                          \
     if (!big) {                                                                                \
-      if (order == 0) return launch_scan_t<OPV, 0, 1, false, true>(sd, blocks, lds, s);        \
-      if (order == 1) return launch_scan_t<OPV, 1, 1, false, true>(sd, blocks, lds, s);        \
-      return launch_scan_t<OPV, 2, 1, false, true>(sd, blocks, lds, s);                        \
+      if (order == 0) return launch_scan_t<OPV, 0, kCapSmall, false, true>(sd, blocks, lds, s);        \
+      if (order == 1) return launch_scan_t<OPV, 1, kCapSmall, false, true>(sd, blocks, lds, s);        \
+      return launch_scan_t<OPV, 2, kCapSmall, false, true>(sd, blocks, lds, s);                        \
     }                                                                                          \
-    if (order == 0) return launch_scan_t<OPV, 0, 4, false, true>(sd, blocks, lds, s);          \
-    if (order == 1) return launch_scan_t<OPV, 1, 4, false, true>(sd, blocks, lds, s);          \
-    return launch_scan_t<OPV, 2, 4, false, true>(sd, blocks, lds, s);                          \
+    if (order == 0) return launch_scan_t<OPV, 0, kCapLarge, false, true>(sd, blocks, lds, s);          \
+    if (order == 1) return launch_scan_t<OPV, 1, kCapLarge, false, true>(sd, blocks, lds, s);          \
+    return launch_scan_t<OPV, 2, kCapLarge, false, true>(sd, blocks, lds, s);                          \
   } while (0)
 
 }  // namespace dev

@@ -5,8 +5,8 @@
 namespace vt {
 namespace dev {
 hipError_t launch_scan_general(const ScanDev &sd, uint32_t blocks, size_t lds, hipStream_t s) {
-  if (sd.a.k <= (uint32_t)kSmallK) return launch_scan_t<-1, -1, 1, true, true>(sd, blocks, lds, s);
-  return launch_scan_t<-1, -1, 4, true, true>(sd, blocks, lds, s);
+  if (sd.a.k <= (uint32_t)kSmallK) return launch_scan_t<-1, -1, kCapSmall, true, true>(sd, blocks, lds, s);
+  return launch_scan_t<-1, -1, kCapLarge, true, true>(sd, blocks, lds, s);
 }
 }  // namespace dev
 }  // namespace vt

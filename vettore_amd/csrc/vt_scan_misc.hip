@@ -9,11 +9,11 @@ namespace dev {
   do {                                                                                        \
     const bool big = sd.a.k > (uint32_t)kSmallK;                                                             \
     if (!padded) {                                                                            \
-      if (!big) return launch_scan_t<OPV, ORD, 1, false, false>(sd, blocks, lds, s);          \
-      return launch_scan_t<OPV, ORD, 4, false, false>(sd, blocks, lds, s);                    \
+      if (!big) return launch_scan_t<OPV, ORD, kCapSmall, false, false>(sd, blocks, lds, s);          \
+      return launch_scan_t<OPV, ORD, kCapLarge, false, false>(sd, blocks, lds, s);                    \
     }                                                                                         \
-    if (!big) return launch_scan_t<OPV, ORD, 1, false, true>(sd, blocks, lds, s);             \
-    return launch_scan_t<OPV, ORD, 4, false, true>(sd, blocks, lds, s);                       \
+    if (!big) return launch_scan_t<OPV, ORD, kCapSmall, false, true>(sd, blocks, lds, s);             \
+    return launch_scan_t<OPV, ORD, kCapLarge, false, true>(sd, blocks, lds, s);                       \
   } while (0)
 
 hipError_t launch_scan_misc(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s) {
