@@ -140,6 +140,7 @@ struct Ctx {
   DevBuf<vt::Payload> dPartPay;
   DevBuf<int> dStatus;  // "metric overflow" flag: set by scan kernels, moved out and cleared by the select kernel
   DevBuf<int> dFlag;    // scratch flag of the ingest kernels
+  DevBuf<ResultBlock> dStage;  // stage-1 winners of quantized_search, consumed on the device
   DevBuf<uint32_t> dRows;
   DevBuf<uint64_t> dCandKeys;
   DevBuf<vt::Payload> dCandPay;
@@ -311,11 +312,12 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
     a.part_keys = c.dPartKeys.p;
     a.part_pay = c.dPartPay.p;
     a.status = c.dStatus.p;
-    if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+    const bool timed = c.profiling && count_profile;
+    if (timed) VT_HIP(hipEventRecord(c.ev0, c.stream));
     VT_HIP(vt::launch_scan(a, blocks, c.stream));
-    if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+    if (timed) VT_HIP(hipEventRecord(c.ev1, c.stream));
     VT_TRY(select_pass(c, c.dPartKeys.p, c.dPartPay.p, waves * k, k, 0, false));
-    if (c.profiling && count_profile) {
+    if (timed) {
       float ms = 0.f;
       VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
       c.prof.scan_launches += 1;
@@ -864,46 +866,87 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
   VT_TRY(upload_query(c, query, n, &qnz));
   VT_TRY(c.dQbits.ensure(words));
   VT_HIP(vt::launch_sign_pack(c.dQ.p, vt::padded_dim(d), 1, d, c.dQbits.p, 0, c.stream));
-  // stage 1: binary_top_k (search.rs:76-92)
-  std::vector<vt::Entry> cand;
-  VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits.p, ix->dRank.p, ix->n, d, candidates, cand, true));
-  if (cand.empty()) return empty_hits(out);
-  // stage 2: vector_top_k over the candidates (search.rs:38-73)
-  std::vector<uint32_t> rows(cand.size());
-  for (size_t i = 0; i < cand.size(); ++i) rows[i] = cand[i].row;
-  VT_TRY(c.dRows.ensure(rows.size()));
-  VT_HIP(hipMemcpyAsync(c.dRows.p, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
   std::vector<vt::Entry> entries;
+  const size_t ncand = std::min<size_t>(candidates, ix->n);
+  const uint32_t *gather = nullptr;
+  uint32_t gather_stride = 1;
+  bool timed_hamming = false;
+  if (ncand <= (size_t)vt::kMaxFusedK) {
+    // stage 1 stays on the device: hamming scan -> select into a device block
+    // whose Entry.row column is the gather list of stage 2 (no host round trip)
+    const uint32_t k1 = (uint32_t)ncand;
+    const uint32_t blocks = c.grid_for((ix->n + 63) / 64, vt::hamming_lds_bytes(k1));
+    const uint32_t waves = vt::scan_waves(blocks);
+    VT_TRY(c.dPartKeys.ensure((size_t)waves * k1));
+    VT_TRY(c.dPartPay.ensure((size_t)waves * k1));
+    VT_TRY(c.dStage.ensure(1));
+    vt::HammingArgs h{};
+    h.bits = ix->dBits.p;
+    h.qbits = c.dQbits.p;
+    h.id_rank = ix->dRank.p;
+    h.n = ix->n;
+    h.words = words;
+    h.pairs = (words + 1) / 2;
+    h.d = d;
+    h.k = k1;
+    h.part_keys = c.dPartKeys.p;
+    h.part_pay = c.dPartPay.p;
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+    VT_HIP(vt::launch_hamming(h, blocks, c.stream));
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+    timed_hamming = c.profiling;
+    VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, waves * k1, k1, 0, 0, c.dStatus.p, c.dStage.p, c.stream));
+    gather = &c.dStage.p->e[0].row;
+    gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
+  } else {
+    // stage 1: binary_top_k (search.rs:76-92), candidate rows via the host
+    std::vector<vt::Entry> cand;
+    VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits.p, ix->dRank.p, ix->n, d, candidates, cand, true));
+    std::vector<uint32_t> rows(cand.size());
+    for (size_t i = 0; i < cand.size(); ++i) rows[i] = cand[i].row;
+    VT_TRY(c.dRows.ensure(rows.size()));
+    VT_HIP(hipMemcpyAsync(c.dRows.p, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));  // `rows` is pageable and dies with this scope
+    gather = c.dRows.p;
+  }
+  // stage 2: vector_top_k over the candidates (search.rs:38-73)
   if (ix->metric == VT_COSINE) {
-    VT_TRY(c.dCandKeys.ensure(rows.size()));
-    VT_TRY(c.dCandPay.ensure(rows.size()));
+    VT_TRY(c.dCandKeys.ensure(ncand));
+    VT_TRY(c.dCandPay.ensure(ncand));
     vt::CosineRerankArgs a{};
     a.X = ix->dX;
     a.stride = ix->ld;
     a.q = c.dQ.p;
     a.id_rank = ix->dRank.p;
-    a.gather = c.dRows.p;
-    a.gather_stride = 1;
-    a.n = (uint32_t)rows.size();
+    a.gather = gather;
+    a.gather_stride = gather_stride;
+    a.n = (uint32_t)ncand;
     a.d = d;
     a.out_keys = c.dCandKeys.p;
     a.out_pay = c.dCandPay.p;
     a.status = c.dStatus.p;
     VT_HIP(vt::launch_cosine_rerank(a, c.stream));
-    VT_TRY(collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, (uint32_t)rows.size(), limit, entries));
+    VT_TRY(collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, (uint32_t)ncand, limit, entries));
   } else {
     ScanJob j{};
     j.X = ix->dX;
     j.stride = ix->ld;
     j.id_rank = ix->dRank.p;
-    j.gather = c.dRows.p;
-    j.gather_stride = 1;
-    j.n = (uint32_t)rows.size();
+    j.gather = gather;
+    j.gather_stride = gather_stride;
+    j.n = (uint32_t)ncand;
     j.d = d;
     j.metric = ix->metric;
     j.order = ix->order;
     j.q_nonzero = qnz;
     VT_TRY(run_scan(c, j, limit, entries, false));
+  }
+  if (timed_hamming) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    c.prof.hamming_launches += 1;
+    c.prof.hamming_ms += ms;
+    c.prof.hamming_bytes += (uint64_t)ix->n * words * 8;
   }
   return make_hits(ix, entries, out);
 }

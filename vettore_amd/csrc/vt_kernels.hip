@@ -54,6 +54,22 @@ __device__ __forceinline__ void select_find_bin(const uint32_t *hist, uint32_t k
   }
 }
 
+// Visits keys[i] for i = tid, tid + 1024, ... with 8 independent loads in flight
+// per thread (one block has to stream up to a few MB out of L2 by itself).
+template <typename F>
+__device__ __forceinline__ void for_each_key(const uint64_t *__restrict__ keys, uint32_t m, uint32_t tid, F f) {
+  constexpr uint32_t kStride = 1024, kUnroll = 8;
+  uint32_t i = tid;
+  for (; i + (kUnroll - 1) * kStride < m; i += kUnroll * kStride) {
+    uint64_t v[kUnroll];
+#pragma unroll
+    for (uint32_t u = 0; u < kUnroll; ++u) v[u] = keys[i + u * kStride];
+#pragma unroll
+    for (uint32_t u = 0; u < kUnroll; ++u) f(v[u], i + u * kStride);
+  }
+  for (; i < m; i += kStride) f(keys[i], i);
+}
+
 __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__restrict__ keys,
                                                            const Payload *__restrict__ pay, uint32_t m, uint32_t k,
                                                            uint64_t lo_key, int has_lo, int *dev_status,
@@ -77,14 +93,13 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
   // pass 1: range and count of the live keys
   uint64_t mn = ~0ull, mx = 0;
   uint32_t cnt = 0;
-  for (uint32_t i = tid; i < m; i += 1024) {
-    const uint64_t key = keys[i];
+  for_each_key(keys, m, tid, [&](uint64_t key, uint32_t) {
     if (live(key)) {
       mn = key < mn ? key : mn;
       mx = key > mx ? key : mx;
       cnt += 1;
     }
-  }
+  });
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     const uint64_t a = __shfl_xor(mn, o, kWave), b = __shfl_xor(mx, o, kWave);
@@ -124,10 +139,9 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
     int shift = hb + 1 - width;
     uint32_t dmask = (1u << width) - 1;
     // pass 2: first digit
-    for (uint32_t i = tid; i < m; i += 1024) {
-      const uint64_t key = keys[i];
+    for_each_key(keys, m, tid, [&](uint64_t key, uint32_t) {
       if (live(key)) atomicAdd(&hist[(uint32_t)(key >> shift) & dmask], 1u);
-    }
+    });
     __syncthreads();
     if (wave == 0) select_find_bin(hist, krem, lane, &s_bin);
     __syncthreads();
@@ -140,9 +154,8 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
     } else if (sb.count <= kSelCand) {
       // pass 3: winners below the bin, the bin itself into LDS
       const uint64_t bin_lo = prefix, bin_hi = prefix | ((1ull << shift) - 1);
-      for (uint32_t i = tid; i < m; i += 1024) {
-        const uint64_t key = keys[i];
-        if (!live(key) || key > bin_hi) continue;
+      for_each_key(keys, m, tid, [&](uint64_t key, uint32_t i) {
+        if (!live(key) || key > bin_hi) return;
         if (key < bin_lo) {
           const uint32_t pos = atomicAdd(&s_sel, 1u);
           if (pos < k) {
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
             cand_idx[pos] = i;
           }
         }
-      }
+      });
       __syncthreads();
       const uint32_t ncand = s_ncand < kSelCand ? s_ncand : kSelCand;
       // remaining digits on the LDS list
@@ -205,10 +218,9 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
         __syncthreads();
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < m; i += 1024) {
-          const uint64_t key = keys[i];
+        for_each_key(keys, m, tid, [&](uint64_t key, uint32_t) {
           if (live(key) && (key & mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & dmask], 1u);
-        }
+        });
         __syncthreads();
         if (wave == 0) select_find_bin(hist, krem, lane, &s_bin);
         __syncthreads();
@@ -227,8 +239,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
 
   if (!from_cand) {
     // compaction of the winners straight from the global keys
-    for (uint32_t i = tid; i < m; i += 1024) {
-      const uint64_t key = keys[i];
+    for_each_key(keys, m, tid, [&](uint64_t key, uint32_t i) {
       if (live(key) && key <= T) {
         const uint32_t pos = atomicAdd(&s_sel, 1u);
         if (pos < k) {
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
           sel_idx[pos] = i;
         }
       }
-    }
+    });
   }
   __syncthreads();
   const uint32_t nsel = s_sel < k ? s_sel : k;
