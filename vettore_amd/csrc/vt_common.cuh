@@ -169,6 +169,29 @@ struct WaveTopK {
     n += __popcll(m);
   }
 
+  // Block-level merge at the end of a kernel: every wave compacts, wave 0 then
+  // absorbs the other waves' buffers (`wave_bytes` apart in LDS) and is the only
+  // one left holding a list.  Must be called by all waves of the block.
+  __device__ __forceinline__ void merge_block(int wib, int nwaves, uint32_t *s_counts, int lane) {
+    compact(lane);
+    if (lane == 0) s_counts[wib] = n;
+    __syncthreads();
+    if (wib == 0) {
+      for (int w = 1; w < nwaves; ++w) {
+        const uint64_t *ok = bk + (size_t)w * 2 * CAP;  // wave w's keys (its payload follows at + CAP)
+        const uint64_t *op = ok + CAP;
+        const uint32_t cnt = s_counts[w];
+        for (uint32_t base = 0; base < cnt; base += kWave) {
+          const uint32_t i = base + lane;
+          const bool valid = i < cnt;
+          const uint64_t ck = valid ? ok[i] : kEmptyKey;
+          const uint64_t cp = valid ? op[i] : 0ull;
+          offer(valid, ck, (uint32_t)cp, __uint_as_float((uint32_t)(cp >> 32)), lane);
+        }
+      }
+    }
+  }
+
   // Writes the k best (unsorted) to keys/pay[0..k), padding with kEmptyKey.
   __device__ __forceinline__ void store(uint64_t *keys, Payload *pay, int lane) {
     compact(lane);

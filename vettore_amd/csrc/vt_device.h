@@ -57,8 +57,8 @@ struct ScanArgs {
   uint64_t lo_key;         // keep only keys > lo_key when has_lo
   int has_lo;
   uint32_t q_nonzero;      // count of query coordinates != 0 (Jaccard)
-  uint64_t *part_keys;     // [grid_waves][k]
-  Payload *part_pay;       // [grid_waves][k]
+  uint64_t *part_keys;     // [grid_blocks][k]: one merged list per block
+  Payload *part_pay;       // [grid_blocks][k]
   int *status;             // device int; atomicMax'ed to VT_ERR_OVERFLOW on "metric overflow"
 };
 
@@ -66,7 +66,8 @@ struct ScanArgs {
 size_t scan_lds_bytes(uint32_t d, uint32_t k);
 // LDS bytes per block of the hamming kernel for list size k.
 size_t hamming_lds_bytes(uint32_t k);
-inline uint32_t scan_waves(uint32_t blocks) { return blocks * kWavesPerBlock; }
+// Partial lists a launch with `blocks` blocks produces (one per block).
+inline uint32_t scan_lists(uint32_t blocks) { return blocks; }
 hipError_t launch_scan(const ScanArgs &a, uint32_t blocks, hipStream_t s);
 
 // K3: selects the k smallest of keys[0..m) (kEmptyKey ignored) by radix select,

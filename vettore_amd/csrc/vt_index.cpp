@@ -291,7 +291,7 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
   while (out.size() < total) {
     const uint32_t k = (uint32_t)std::min<size_t>(kmax, total - out.size());
     const uint32_t blocks = c.grid_for(ntiles, vt::scan_lds_bytes(j.d, k));
-    const uint32_t waves = vt::scan_waves(blocks);
+    const uint32_t waves = vt::scan_lists(blocks);
     VT_TRY(c.dPartKeys.ensure((size_t)waves * k));
     VT_TRY(c.dPartPay.ensure((size_t)waves * k));
     vt::ScanArgs a{};
@@ -346,7 +346,7 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
   while (out.size() < total) {
     const uint32_t k = (uint32_t)std::min<size_t>((size_t)vt::kMaxFusedK, total - out.size());
     const uint32_t blocks = c.grid_for(ntiles, vt::hamming_lds_bytes(k));
-    const uint32_t waves = vt::scan_waves(blocks);
+    const uint32_t waves = vt::scan_lists(blocks);
     VT_TRY(c.dPartKeys.ensure((size_t)waves * k));
     VT_TRY(c.dPartPay.ensure((size_t)waves * k));
     vt::HammingArgs a{};
@@ -876,7 +876,7 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
     // whose Entry.row column is the gather list of stage 2 (no host round trip)
     const uint32_t k1 = (uint32_t)ncand;
     const uint32_t blocks = c.grid_for((ix->n + 63) / 64, vt::hamming_lds_bytes(k1));
-    const uint32_t waves = vt::scan_waves(blocks);
+    const uint32_t waves = vt::scan_lists(blocks);
     VT_TRY(c.dPartKeys.ensure((size_t)waves * k1));
     VT_TRY(c.dPartPay.ensure((size_t)waves * k1));
     VT_TRY(c.dStage.ensure(1));

@@ -332,7 +332,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
     if (a.has_lo) valid = valid && key > a.lo_key;
     tk.offer(valid, key, grow, raw, lane);
   }
-  tk.store(a.part_keys + (size_t)wave_global * a.k, a.part_pay + (size_t)wave_global * a.k, lane);
+  __shared__ uint32_t s_counts[kWavesPerBlock];
+  tk.merge_block(wib, kWavesPerBlock, s_counts, lane);
+  if (wib == 0) tk.store(a.part_keys + (size_t)blockIdx.x * a.k, a.part_pay + (size_t)blockIdx.x * a.k, lane);
 }
 
 // ---------------------------------------------------------------------------

@@ -356,7 +356,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       tk.offer(valid, key, src_row, raw, lane);
     }
   }
-  tk.store(a.part_keys + (size_t)wave_global * a.k, a.part_pay + (size_t)wave_global * a.k, lane);
+  // one list per block: wave 0 absorbs the other waves' buffers
+  __shared__ uint32_t s_counts[kWavesPerBlock];
+  tk.merge_block(wib, kWavesPerBlock, s_counts, lane);
+  if (wib == 0) tk.store(a.part_keys + (size_t)blockIdx.x * a.k, a.part_pay + (size_t)blockIdx.x * a.k, lane);
 }
 
 constexpr size_t kMaxLds = 160 * 1024;
