@@ -10,7 +10,7 @@ LIBDIR  := vettore_amd/lib
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
             -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function
 
-DEVSRC  := vt_kernels vt_scan_dot vt_scan_l2 vt_scan_misc vt_scan_general
+DEVSRC  := vt_kernels vt_batch vt_scan_dot vt_scan_l2 vt_scan_misc vt_scan_general
 DEVOBJ  := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(DEVSRC)))
 DEVHDR  := $(CSRC)/vt_device.h $(CSRC)/vt_common.cuh $(CSRC)/vt_scan.cuh
 

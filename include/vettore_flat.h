@@ -117,6 +117,15 @@ int vt_flat_delete(vt_flat *index, const char *id, size_t id_len);
 int vt_flat_search(vt_flat *index, const float *query, size_t n, size_t limit,
                    vt_hits **out);
 
+/* Extension (SURVEY.md 8b "vt_flat_search_batch"): `nq` queries of `d` floats
+ * each, stored back to back, against the same index.  out[i] receives query
+ * i's hits -- identical (ids, order, raw bits) to nq vt_flat_search calls; the
+ * first invalid query fails the whole call like its own flat_search would.
+ * Dot-family metrics take the FP32-MFMA path: Q x D^T nominates candidates,
+ * the exact kernel re-scores them, an error bound proves completeness. */
+int vt_flat_search_batch(vt_flat *index, const float *queries, size_t nq, size_t d,
+                         size_t limit, vt_hits **out);
+
 size_t vt_flat_len(const vt_flat *index);
 /* FlatIndex.dimension: -1 = None. */
 long vt_flat_dimension(const vt_flat *index);
@@ -176,6 +185,11 @@ typedef struct vt_profile {
   uint64_t hamming_bytes;   /* rows * ceil(d/64) * 8 */
   uint64_t merge_launches;
   double merge_ms;
+  uint64_t batch_launches;  /* MFMA candidate passes (one per <= 256 queries) */
+  double batch_ms;
+  double batch_flops;       /* 2 * rows * padded queries * padded dims per pass */
+  uint64_t batch_queries;
+  uint64_t batch_fallbacks; /* queries the bound could not certify (re-run singly) */
 } vt_profile;
 int vt_flat_set_profiling(vt_flat *index, int enabled);
 int vt_flat_get_profile(vt_flat *index, vt_profile *out, int reset);

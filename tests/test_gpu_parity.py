@@ -473,6 +473,56 @@ def test_binary_top_k_with_massive_ties(nifs, oracle_mod):
         assert got == want, limit
 
 
+@pytest.mark.parametrize("metric", [2, 3, 4, 0])
+def test_batched_search_equals_single_queries(nifs, oracle_mod, metric):
+    """vt_flat_search_batch: dot-family metrics go through the FP32-MFMA candidate
+    pass + exact rescoring; every query must still equal the oracle bit for bit
+    (BASELINE.json configs[2] shape, scaled down).  L2 takes the per-query path."""
+    n, d = 20000, 192
+    x, ids = make_corpus(n, d, 500 + metric, metric == 2, oracle_mod, tie_block=48)
+    packed = oracle_mod.pack_ids(ids)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(8)
+    nifs.flat_set_profiling(g.ref, True)
+    for nq, k in ((8, 10), (37, 1), (256, 10), (300, 64)):
+        qs = rng.uniform(-1, 1, size=(nq, d)).astype(np.float32)
+        qs[0] = x[n // 2]  # sits on the block of identical rows
+        if metric == 2:
+            qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+        got = unwrap(nifs.flat_search_batch(g.ref, qs, k))
+        assert len(got) == nq
+        for i in range(nq):
+            assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, x, packed, qs[i], k)), (metric, nq, k, i)
+    prof = nifs.flat_get_profile(g.ref)
+    if metric != 0:
+        assert prof["batch_launches"] >= 5 and prof["batch_fallbacks"] <= prof["batch_queries"] // 10, prof
+    else:
+        assert prof["batch_launches"] == 0
+    # validation order and empty cases follow flat_search
+    assert nifs.flat_search_batch(g.ref, np.zeros((3, d + 1), np.float32), 5) == ("error", "dimension mismatch")
+    bad = np.zeros((9, d), np.float32)
+    bad[4, 3] = np.inf
+    assert nifs.flat_search_batch(g.ref, bad, 5) == ("error", "vector contains a non-finite value")
+    assert unwrap(nifs.flat_search_batch(g.ref, bad, 0)) == [[]] * 9
+
+
+def test_batched_search_large_values_fall_back_safely(nifs, oracle_mod):
+    """Huge coordinates blow the error margin (or overflow the MFMA sum): the
+    bound must refuse and the per-query path must still give the exact answer."""
+    n, d = 6000, 64
+    rng = np.random.default_rng(21)
+    x = (rng.uniform(-1, 1, size=(n, d)) * 1e18).astype(np.float32)
+    ids = [b"r%d" % i for i in range(n)]
+    g = GpuIndex(nifs, 3)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    qs = (rng.uniform(-1, 1, size=(16, d)) * 1e18).astype(np.float32)
+    got = unwrap(nifs.flat_search_batch(g.ref, qs, 5))
+    packed = oracle_mod.pack_ids(ids)
+    for i in range(16):
+        assert bits(got[i]) == bits(oracle_mod.matrix_search(3, x, packed, qs[i], 5)), i
+
+
 # --------------------------------------------- full-size checks (BASELINE sizes)
 def test_config2_full_size_properties_and_spot_parity(nifs, oracle_mod):
     """BASELINE.json configs[1]: flat cosine, d=768, N=1M, single query.

@@ -52,6 +52,36 @@ def run(metric, rows, dim, limit, quantized=False, steps=30, order=0):
     del ref
 
 
+def run_batch(metric, rows, dim, nq, limit, normalize, steps=4):
+    dev = torch.device("cuda", 0)
+    x = build_shard(torch, dev, rows, dim, 1234)
+    if not normalize:
+        x.mul_(torch.linalg.vector_norm(torch.rand((rows, 1), device=dev) + 0.5, dim=1, keepdim=True) * 16)
+    ref = nifs._flat_new(metric)
+    assert nifs.flat_load_device_matrix(ref, doc_ids(0, rows), x.data_ptr(), rows, dim) == ("ok", ())
+    del x
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(1)
+    qs = rng.uniform(-1, 1, size=(nq, dim)).astype(np.float32)
+    if normalize:
+        qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    assert nifs.flat_search_batch(ref, qs, limit)[0] == "ok"
+    nifs.flat_set_profiling(ref, True)
+    nifs.flat_get_profile(ref, reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        res = nifs.flat_search_batch(ref, qs, limit)
+    dt = (time.perf_counter() - t0) / steps
+    p = nifs.flat_get_profile(ref, reset=True)
+    out = {"batch": nq, "metric": nifs.METRICS[metric], "rows": rows, "dim": dim, "limit": limit,
+           "e2e_ms_per_batch": round(dt * 1e3, 3), "qps": round(nq / dt, 1),
+           "mfma_ms": round(p["batch_ms"] / max(1, p["batch_launches"]), 3),
+           "mfma_TFLOPs": round(p["batch_flops"] / max(1e-9, p["batch_ms"]) / 1e9, 1),
+           "fallbacks": p["batch_fallbacks"], "queries": p["batch_queries"]}
+    print(json.dumps(out), flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     R = 2_000_000
@@ -69,6 +99,11 @@ if __name__ == "__main__":
     if which in ("all", "quantized"):
         run(2, R, 768, 10, quantized=True)
         run(2, 10_000_000, 768, 10, quantized=True)
+    if which in ("all", "batch"):
+        run_batch(3, 2_000_000, 768, 256, 10, False)
+        run_batch(2, 2_000_000, 768, 256, 10, True)
+        run_batch(3, 2_000_000, 768, 64, 10, False)
+        run_batch(3, 10_000_000, 768, 256, 10, False, steps=3)
     if which in ("all", "small"):
         for rows in (10_000, 100_000, 1_000_000):
             run(2, rows, 768, 10, steps=100)

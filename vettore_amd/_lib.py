@@ -19,7 +19,7 @@ SYMBOLS = [
     "vt_strerror", "vt_last_error", "vt_abi_version", "vt_device_count",
     "vt_hits_len", "vt_hits_id", "vt_hits_raw", "vt_hits_rank_key", "vt_hits_free",
     "vt_flat_new", "vt_flat_free", "vt_flat_insert", "vt_flat_insert_many", "vt_flat_delete",
-    "vt_flat_search", "vt_flat_len", "vt_flat_dimension", "vt_flat_metric",
+    "vt_flat_search", "vt_flat_search_batch", "vt_flat_len", "vt_flat_dimension", "vt_flat_metric",
     "vt_flat_set_reduce_order", "vt_set_default_reduce_order",
     "vt_flat_load_matrix", "vt_flat_load_device_matrix", "vt_flat_quantized_search",
     "vt_vector_top_k", "vt_binary_top_k", "vt_normalize_l2", "vt_compress_sign_bits",
@@ -32,6 +32,8 @@ class Profile(C.Structure):
         ("scan_launches", C.c_uint64), ("scan_ms", C.c_double), ("scan_rows", C.c_uint64),
         ("scan_bytes", C.c_uint64), ("hamming_launches", C.c_uint64), ("hamming_ms", C.c_double),
         ("hamming_bytes", C.c_uint64), ("merge_launches", C.c_uint64), ("merge_ms", C.c_double),
+        ("batch_launches", C.c_uint64), ("batch_ms", C.c_double), ("batch_flops", C.c_double),
+        ("batch_queries", C.c_uint64), ("batch_fallbacks", C.c_uint64),
     ]
 
 
@@ -70,6 +72,7 @@ def load() -> C.CDLL:
     L.vt_flat_insert_many.argtypes = [vp, C.c_size_t, C.c_char_p, szp, f32p, szp]
     L.vt_flat_delete.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.vt_flat_search.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.vt_flat_search_batch.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.vt_flat_len.restype = C.c_size_t
     L.vt_flat_len.argtypes = [vp]
     L.vt_flat_dimension.restype = C.c_long

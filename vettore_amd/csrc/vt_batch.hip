@@ -1,0 +1,307 @@
+// vt_batch.hip -- K2: query batches on the FP32 matrix cores (gfx950).
+//
+// The reference answers B queries with B independent scans (flat.rs:96-124).
+// Here S = X * Q^T (N x B) is a genuine dense GEMM, so it runs on
+// v_mfma_f32_32x32x2_f32.  MFMA sums each dot product as one fmaf chain, which
+// is NOT the reference's chunked order, so the MFMA pass only nominates
+// candidates; the exact K1 arithmetic then re-scores them (vt_scan.cuh, batch
+// mode), and the host accepts a query's result only if a rigorous bound proves
+// that no row outside the candidate set can reach the top k (vt_index.cpp,
+// vt_flat_search_batch).  Ranking and scores therefore stay bit-identical to
+// the reference; S itself is never materialised.
+//
+//   pass 0  scores of a strided sample of row tiles, dense, -> per-query
+//           threshold tau_b = 3rd best sample score (sample_tau_kernel);
+//   pass 1  every row tile: S tile in accumulators, epilogue appends
+//           (score, row) with score >= tau_b to the query's candidate list.
+//
+// Work split: a wave owns 32 rows x (NT*32) queries (NT*16 accumulator VGPRs);
+// its X operand comes straight from HBM as 16-B fragments (each lane pair reads
+// one whole 128-B line of its row per 32-wide k chunk -- X is touched once, so
+// no LDS round trip); the Q chunk (all queries x 32 k) is shared by the block
+// through LDS (row stride 36 floats: conflict-free ds_read_b128), register
+// staged and double buffered.  k is permuted inside a chunk (lane half h owns
+// k = 16h..16h+15) -- harmless for a sum that only nominates candidates.
+#include "vt_common.cuh"
+
+namespace vt {
+
+using namespace dev;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBWaves = 4;          // waves per block
+constexpr int kBRows = kBWaves * 32;  // rows per block tile
+constexpr int kQStride = 36;        // LDS floats per query row of a 32-k chunk
+
+template <int NT, bool DENSE>
+__global__ __launch_bounds__(kBWaves *kWave) void mfma_scores_kernel(const BatchScoreArgs a) {
+  extern __shared__ __align__(16) float qlds[];  // [2][NT*32][kQStride]
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int NQ = NT * 32;
+  const uint32_t nchunk = a.ld / 32;
+  const uint32_t ntiles = (a.n + kBRows - 1) / kBRows;
+
+  // thresholds of the 8 query columns this lane sees (column = 32*t + r)
+  float tau[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) tau[t] = DENSE ? 0.f : a.tau[t * 32 + r];
+
+  // Q chunk staging: thread i moves 16-B pieces i, i+256, ... of the [NQ][32] chunk
+  constexpr int kPieces = NQ * 8 / (kBWaves * kWave);  // float4 pieces per thread
+  auto stage_load = [&](uint32_t c, f32x4 *regs) {
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+      const uint32_t piece = threadIdx.x + i * (kBWaves * kWave);
+      const uint32_t qrow = piece >> 3, part = piece & 7;
+      regs[i] = *reinterpret_cast<const f32x4 *>(a.Q + (size_t)qrow * a.ld + c * 32 + part * 4);
+    }
+  };
+  auto stage_store = [&](int buf, const f32x4 *regs) {
+    float *dst = qlds + buf * (NQ * kQStride);
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+      const uint32_t piece = threadIdx.x + i * (kBWaves * kWave);
+      const uint32_t qrow = piece >> 3, part = piece & 7;
+      *reinterpret_cast<f32x4 *>(dst + qrow * kQStride + part * 4) = regs[i];
+    }
+  };
+
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // DENSE (pass 0) visits a strided sample of the tiles
+    const uint32_t rtile = DENSE ? tile * a.sample_stride : tile;
+    const uint32_t row0 = rtile * kBRows + wib * 32;
+    // rows past the end are clamped for the load and masked in the epilogue
+    const uint32_t lrow = row0 + r < a.n_total ? row0 + r : a.n_total - 1;
+    const float *xrow = a.X + (size_t)lrow * a.stride + h * 16;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    f32x4 xa[4], xn[4], qreg[kPieces];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xa[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xrow + j * 4));
+    stage_load(0, qreg);
+    __syncthreads();  // previous tile's readers are done with buffer 0
+    stage_store(0, qreg);
+    __syncthreads();
+
+    for (uint32_t c = 0; c < nchunk; ++c) {
+      const int buf = c & 1;
+      const bool more = c + 1 < nchunk;
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          xn[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xrow + (c + 1) * 32 + j * 4));
+        stage_load(c + 1, qreg);
+      }
+      const float *qb = qlds + buf * (NQ * kQStride) + r * kQStride + h * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 qv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) qv[t] = *reinterpret_cast<const f32x4 *>(qb + t * 32 * kQStride + j * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j][e], qv[t][e], acc[t], 0, 0, 0);
+        }
+      }
+      if (more) {
+        stage_store(buf ^ 1, qreg);  // the other buffer: its readers finished before the last barrier
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xa[j] = xn[j];
+      }
+      __syncthreads();
+    }
+
+    // epilogue: C layout of 32x32: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const uint32_t qcol = t * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const uint32_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const float s = acc[t][i];
+        if (DENSE) {
+          // dense sample matrix [query][sample row]
+          const uint32_t srow = tile * kBRows + wib * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          a.sample[(size_t)qcol * a.sample_rows + srow] = row < a.n_total ? s : -INFINITY;
+        } else if (s >= tau[t] && row < a.n_total) {
+          const uint32_t pos = atomicAdd(&a.cand_count[qcol], 1u);
+          if (pos < a.cand_cap) {
+            BatchCand cnd;
+            cnd.score = s;
+            cnd.row = row;
+            a.cand[(size_t)qcol * a.cand_cap + pos] = cnd;
+          }
+        }
+      }
+    }
+  }
+}
+
+// tau_b = the `rank`-th largest of the query's sample scores (one block per query).
+__global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict__ sample, uint32_t sample_rows,
+                                                         uint32_t rank, float *__restrict__ tau) {
+  __shared__ float s_best[256];
+  __shared__ uint32_t s_idx[256];
+  __shared__ float s_cut;
+  __shared__ uint32_t s_cutidx;
+  const float *v = sample + (size_t)blockIdx.x * sample_rows;
+  float cut = INFINITY;      // values >= cut (ties by index) were already taken
+  uint32_t cutidx = 0xFFFFFFFFu;
+  float result = -INFINITY;
+  for (uint32_t round = 0; round < rank; ++round) {
+    float best = -INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < sample_rows; i += blockDim.x) {
+      const float x = v[i];
+      const bool taken = x > cut || (x == cut && i <= cutidx);
+      if (!taken && (x > best || (x == best && i < bi))) {
+        best = x;
+        bi = i;
+      }
+    }
+    s_best[threadIdx.x] = best;
+    s_idx[threadIdx.x] = bi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float b = -INFINITY;
+      uint32_t ix = 0xFFFFFFFFu;
+      for (int t = 0; t < 256; ++t)
+        if (s_best[t] > b || (s_best[t] == b && s_idx[t] < ix)) {
+          b = s_best[t];
+          ix = s_idx[t];
+        }
+      s_cut = b;
+      s_cutidx = ix;
+    }
+    __syncthreads();
+    cut = s_cut;
+    cutidx = s_cutidx;
+    result = cut;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tau[blockIdx.x] = result;
+}
+
+// max over rows of sum x^2 (f64 accumulation): the row-norm bound of the error margin.
+__global__ __launch_bounds__(256) void max_sqnorm_kernel(const float *__restrict__ X, size_t stride, uint32_t n,
+                                                         uint32_t d, unsigned long long *out_bits) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  double best = 0.0;
+  for (uint32_t row = wave; row < n; row += nwaves) {
+    const float *x = X + (size_t)row * stride;
+    double s = 0.0;
+    for (uint32_t j = lane; j < d; j += kWave) s += (double)x[j] * (double)x[j];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, kWave);
+    best = s > best ? s : best;
+  }
+  if (lane == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(best));  // s >= 0: bits are monotone
+}
+
+// Batched K3: block b selects the k smallest of keys[b][0..m) (rank sort; m is small).
+__global__ __launch_bounds__(256) void batch_select_kernel(const uint64_t *__restrict__ keys,
+                                                           const Payload *__restrict__ pay, uint32_t m, uint32_t k,
+                                                           Entry *__restrict__ out, uint32_t *__restrict__ out_count) {
+  extern __shared__ __align__(16) unsigned char bsm[];
+  uint64_t *sk = reinterpret_cast<uint64_t *>(bsm);  // [m]
+  const uint64_t *kb = keys + (size_t)blockIdx.x * m;
+  const Payload *pb = pay + (size_t)blockIdx.x * m;
+  __shared__ uint32_t s_live;
+  if (threadIdx.x == 0) s_live = 0;
+  for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) sk[i] = kb[i];
+  __syncthreads();
+  uint32_t live = 0;
+  for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+    const uint64_t ki = sk[i];
+    if (ki == kEmptyKey) continue;
+    live += 1;
+    uint32_t pos = 0;
+    for (uint32_t x = 0; x < m; ++x) {
+      const uint64_t kx = sk[x];
+      pos += (kx < ki || (kx == ki && x < i)) ? 1u : 0u;
+    }
+    if (pos < k) {
+      Entry e;
+      e.key = ki;
+      e.row = pb[i].row;
+      e.raw = pb[i].raw;
+      out[(size_t)blockIdx.x * k + pos] = e;
+    }
+  }
+  atomicAdd(&s_live, live);
+  __syncthreads();
+  if (threadIdx.x == 0) out_count[blockIdx.x] = s_live < k ? s_live : k;
+}
+
+template <int NT>
+hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
+  const size_t lds = (size_t)2 * NT * 32 * kQStride * sizeof(float);
+  if (dense) {
+    auto kern = mfma_scores_kernel<NT, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBWaves * kWave), lds, s, a);
+  } else {
+    auto kern = mfma_scores_kernel<NT, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBWaves * kWave), lds, s, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+uint32_t batch_rows_per_block() { return kBRows; }
+
+hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
+  if (a.ld % 32 != 0 || a.nq_pad % 32 != 0 || a.nq_pad == 0 || a.nq_pad > 256) return hipErrorInvalidValue;
+  switch (a.nq_pad / 32) {
+    case 1: return launch_scores_nt<1>(a, dense, blocks, s);
+    case 2: return launch_scores_nt<2>(a, dense, blocks, s);
+    case 3: case 4: {
+      if (a.nq_pad != 128) return hipErrorInvalidValue;
+      return launch_scores_nt<4>(a, dense, blocks, s);
+    }
+    case 8: return launch_scores_nt<8>(a, dense, blocks, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t rank, float *tau,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(sample_tau_kernel, dim3(nq), dim3(256), 0, s, sample, sample_rows, rank, tau);
+  return hipGetLastError();
+}
+
+hipError_t launch_max_sqnorm(const float *X, size_t stride, uint32_t n, uint32_t d, unsigned long long *out_bits,
+                             hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(max_sqnorm_kernel, dim3(1024), dim3(256), 0, s, X, stride, n, d, out_bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_select(const uint64_t *keys, const Payload *pay, uint32_t nq, uint32_t m, uint32_t k, Entry *out,
+                               uint32_t *out_count, hipStream_t s) {
+  if (m == 0 || m > 4096) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(batch_select_kernel, dim3(nq), dim3(256), (size_t)m * 8, s, keys, pay, m, k, out, out_count);
+  return hipGetLastError();
+}
+
+}  // namespace vt

@@ -60,6 +60,11 @@ struct ScanArgs {
   uint64_t *part_keys;     // [grid_blocks][k]: one merged list per block
   Payload *part_pay;       // [grid_blocks][k]
   int *status;             // device int; atomicMax'ed to VT_ERR_OVERFLOW on "metric overflow"
+  // Batch mode (gathered scans only, grid.y = queries): query b = blockIdx.y uses
+  // q + b * padded_dim(d), gather + b * batch_cap * gather_stride, scans
+  // min(batch_counts[b], batch_cap) rows and writes list (b * grid.x + blockIdx.x).
+  const uint32_t *batch_counts;
+  uint32_t batch_cap;
 };
 
 // LDS bytes per block the scan kernel needs for dimension d and list size k (0 = unsupported).
@@ -69,6 +74,8 @@ size_t hamming_lds_bytes(uint32_t k);
 // Partial lists a launch with `blocks` blocks produces (one per block).
 inline uint32_t scan_lists(uint32_t blocks) { return blocks; }
 hipError_t launch_scan(const ScanArgs &a, uint32_t blocks, hipStream_t s);
+// Batch mode: `blocks` per query x `nq` queries.
+hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hipStream_t s);
 
 // K3: selects the k smallest of keys[0..m) (kEmptyKey ignored) by radix select,
 // writes them sorted ascending with their payloads to out->e, out->count;
@@ -128,6 +135,38 @@ struct CosineRerankArgs {
   int *status;
 };
 hipError_t launch_cosine_rerank(const CosineRerankArgs &a, hipStream_t s);
+
+// ---- K2: query batches on the FP32 matrix cores (vt_batch.hip) ----------------
+struct BatchCand {
+  float score;   // MFMA (approximate-order) dot product
+  uint32_t row;
+};
+struct BatchScoreArgs {
+  const float *X;         // slab
+  size_t stride;
+  const float *Q;         // [nq_pad][ld] queries, zero padded (device)
+  uint32_t ld;            // padded_dim(d)
+  uint32_t nq_pad;        // 32, 64, 128 or 256
+  uint32_t n;             // rows covered by this launch (pass 0: sample rows)
+  uint32_t n_total;       // rows in the index
+  uint32_t sample_stride; // pass 0: tile i of the launch is row tile i * sample_stride
+  float *sample;          // pass 0: [nq_pad][sample_rows] dense scores
+  uint32_t sample_rows;
+  const float *tau;       // pass 1: per-query candidate threshold
+  BatchCand *cand;        // pass 1: [nq_pad][cand_cap]
+  uint32_t *cand_count;   // pass 1: [nq_pad], may exceed cand_cap (overflow)
+  uint32_t cand_cap;
+};
+uint32_t batch_rows_per_block();
+hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s);
+hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t rank, float *tau,
+                             hipStream_t s);
+// *out_bits = bit pattern of max_i sum_j x_ij^2 (as f64); zero it first.
+hipError_t launch_max_sqnorm(const float *X, size_t stride, uint32_t n, uint32_t d, unsigned long long *out_bits,
+                             hipStream_t s);
+// Block b: the k smallest of keys[b][0..m) sorted ascending -> out[b][0..k), out_count[b].
+hipError_t launch_batch_select(const uint64_t *keys, const Payload *pay, uint32_t nq, uint32_t m, uint32_t k, Entry *out,
+                               uint32_t *out_count, hipStream_t s);
 
 // normalize_l2 (distances.rs:350-361) on rows: out = (x / sqrt(f64 sum x^2)) as f32.
 hipError_t launch_normalize_l2(const float *in, uint32_t n, uint32_t d, float *out, hipStream_t s);

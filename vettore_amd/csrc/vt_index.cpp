@@ -141,6 +141,16 @@ struct Ctx {
   DevBuf<int> dStatus;  // "metric overflow" flag: set by scan kernels, moved out and cleared by the select kernel
   DevBuf<int> dFlag;    // scratch flag of the ingest kernels
   DevBuf<ResultBlock> dStage;  // stage-1 winners of quantized_search, consumed on the device
+  // batched search (K2)
+  DevBuf<float> dBQ, dBTau, dBSample;
+  DevBuf<vt::BatchCand> dBCand;
+  DevBuf<uint32_t> dBCount, dBOutCount;
+  DevBuf<vt::Entry> dBOut;
+  DevBuf<unsigned long long> dBNorm;
+  PinnedBuf<float> hBQ, hBTau;
+  PinnedBuf<uint32_t> hBCount, hBOutCount;
+  PinnedBuf<vt::Entry> hBOut;
+  hipEvent_t ev2 = nullptr, ev3 = nullptr;
   DevBuf<uint32_t> dRows;
   DevBuf<uint64_t> dCandKeys;
   DevBuf<vt::Payload> dCandPay;
@@ -155,6 +165,8 @@ struct Ctx {
   ~Ctx() {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev2) (void)hipEventDestroy(ev2);
+    if (ev3) (void)hipEventDestroy(ev3);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -175,6 +187,8 @@ struct Ctx {
     VT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     VT_HIP(hipEventCreate(&ev0));
     VT_HIP(hipEventCreate(&ev1));
+    VT_HIP(hipEventCreate(&ev2));
+    VT_HIP(hipEventCreate(&ev3));
     VT_TRY(dStatus.ensure(1));
     VT_TRY(dFlag.ensure(1));
     VT_HIP(hipMemset(dStatus.p, 0, sizeof(int)));
@@ -217,6 +231,7 @@ struct vt_flat {
   DevBuf<uint32_t> dRank;
   DevBuf<uint64_t> dBits;
   bool bits_valid = false;
+  double max_sqnorm = -1.0;  // max_i sum_j x_ij^2, < 0 = stale (error margin of the batched path)
   // ids
   std::vector<std::string> ids;  // by row
   std::unordered_map<std::string, uint32_t> row_of;
@@ -516,6 +531,7 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
     if (!is_new || target[i] != n_before + i) all_appended_in_order = false;
   }
   ix->bits_valid = false;
+  ix->max_sqnorm = -1.0;
   const uint32_t ld = ix->ld;
   if (src.device) {
     if (all_appended_in_order) {
@@ -585,6 +601,206 @@ int make_hits(const vt_flat *ix, const std::vector<vt::Entry> &entries, vt_hits 
 
 int empty_hits(vt_hits **out) {
   *out = new vt_hits();
+  return VT_OK;
+}
+
+// flat.rs:96-124 with the handle's lock held.
+int search_locked(vt_flat *ix, const float *query, size_t n, size_t limit, vt_hits **out) {
+  Ctx &c = ix->ctx;
+  if (limit == 0) return empty_hits(out);
+  VT_TRY(validate_vector(query, n, ix->dim));
+  if (ix->n == 0) return empty_hits(out);
+  VT_TRY(index_sync_ranks(ix, false));
+  uint32_t qnz = 0;
+  VT_TRY(upload_query(c, query, n, &qnz));
+  ScanJob j{};
+  j.X = ix->dX;
+  j.stride = ix->ld;
+  j.id_rank = ix->dRank.p;
+  j.gather = nullptr;
+  j.gather_stride = 0;
+  j.n = ix->n;
+  j.d = (uint32_t)ix->dim;
+  j.metric = ix->metric;
+  j.order = ix->order;
+  j.q_nonzero = qnz;
+  std::vector<vt::Entry> entries;
+  VT_TRY(run_scan(c, j, limit, entries, true));
+  return make_hits(ix, entries, out);
+}
+
+// ---------------------------------------------------------------- K2 host side
+// One group of <= 256 queries through the matrix cores.  `done[i]` is set for
+// every query whose exact top-k was proven complete; the others are left for
+// the single-query path.
+int batch_group(vt_flat *ix, const float *queries, size_t nq, size_t limit, vt_hits **out, std::vector<char> &done) {
+  Ctx &c = ix->ctx;
+  const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
+  const uint32_t k = (uint32_t)std::min<size_t>(limit, n);
+  uint32_t nq_pad = 32;
+  while (nq_pad < nq) nq_pad *= 2;
+  const uint32_t rows_per_block = vt::batch_rows_per_block();
+  const uint32_t ntiles_total = (n + rows_per_block - 1) / rows_per_block;
+  // pass-0 sample: about 128 row tiles spread over the corpus
+  const uint32_t stride = std::max<uint32_t>(1, ntiles_total / 128);
+  const uint32_t ntiles_sample = (ntiles_total + stride - 1) / stride;
+  const uint32_t sample_rows = ntiles_sample * rows_per_block;
+  // tau = rank-th best sample score: about rank * n / sample_rows rows pass
+  const double ratio = (double)sample_rows / (double)n;
+  uint32_t rank = (uint32_t)std::ceil(8.0 * k * std::min(1.0, ratio));
+  rank = std::max<uint32_t>(3, std::min<uint32_t>(rank, std::min<uint32_t>(sample_rows, n)));
+  const uint32_t cand_cap = 8192;
+  constexpr uint32_t kBlocksPerQuery = 4;
+
+  VT_TRY(c.dBQ.ensure((size_t)nq_pad * ld));
+  VT_TRY(c.hBQ.ensure((size_t)nq_pad * ld));
+  VT_TRY(c.dBTau.ensure(nq_pad));
+  VT_TRY(c.hBTau.ensure(nq_pad));
+  VT_TRY(c.dBSample.ensure((size_t)nq_pad * sample_rows));
+  VT_TRY(c.dBCand.ensure((size_t)nq_pad * cand_cap));
+  VT_TRY(c.dBCount.ensure(nq_pad));
+  VT_TRY(c.hBCount.ensure(nq_pad));
+  VT_TRY(c.dBOut.ensure((size_t)nq_pad * k));
+  VT_TRY(c.hBOut.ensure((size_t)nq_pad * k));
+  VT_TRY(c.dBOutCount.ensure(nq_pad));
+  VT_TRY(c.hBOutCount.ensure(nq_pad));
+  VT_TRY(c.dBNorm.ensure(1));
+  VT_TRY(c.dPartKeys.ensure((size_t)nq_pad * kBlocksPerQuery * k));
+  VT_TRY(c.dPartPay.ensure((size_t)nq_pad * kBlocksPerQuery * k));
+
+  std::vector<double> qnorm(nq);
+  std::memset(c.hBQ.p, 0, (size_t)nq_pad * ld * sizeof(float));
+  for (size_t i = 0; i < nq; ++i) {
+    std::memcpy(c.hBQ.p + i * ld, queries + i * d, (size_t)d * sizeof(float));
+    double s = 0.0;
+    for (uint32_t j = 0; j < d; ++j) s += (double)queries[i * d + j] * (double)queries[i * d + j];
+    qnorm[i] = std::sqrt(s);
+  }
+  VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  if (ix->max_sqnorm < 0.0) {
+    unsigned long long bits = 0;
+    VT_HIP(hipMemsetAsync(c.dBNorm.p, 0, sizeof(unsigned long long), c.stream));
+    VT_HIP(vt::launch_max_sqnorm(ix->dX, ix->ld, n, d, c.dBNorm.p, c.stream));
+    VT_HIP(hipMemcpyAsync(&bits, c.dBNorm.p, sizeof(bits), hipMemcpyDeviceToHost, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    std::memcpy(&ix->max_sqnorm, &bits, sizeof(double));
+  }
+
+  vt::BatchScoreArgs a{};
+  a.X = ix->dX;
+  a.stride = ix->ld;
+  a.Q = c.dBQ.p;
+  a.ld = ld;
+  a.nq_pad = nq_pad;
+  a.n_total = n;
+  // pass 0: dense scores of the sample -> tau
+  a.n = sample_rows;
+  a.sample_stride = stride;
+  a.sample = c.dBSample.p;
+  a.sample_rows = sample_rows;
+  const uint32_t grid_cap = (uint32_t)c.num_cus;
+  VT_HIP(vt::launch_batch_scores(a, true, std::min<uint32_t>(ntiles_sample, grid_cap), c.stream));
+  VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, nq_pad, rank, c.dBTau.p, c.stream));
+  // pass 1: all rows, candidates with score >= tau
+  a.n = n;
+  a.sample = nullptr;
+  a.tau = c.dBTau.p;
+  a.cand = c.dBCand.p;
+  a.cand_count = c.dBCount.p;
+  a.cand_cap = cand_cap;
+  VT_HIP(hipMemsetAsync(c.dBCount.p, 0, (size_t)nq_pad * sizeof(uint32_t), c.stream));
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev2, c.stream));
+  VT_HIP(vt::launch_batch_scores(a, false, std::min<uint32_t>(ntiles_total, grid_cap), c.stream));
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev3, c.stream));
+  // exact rescoring of every query's candidates with the K1 arithmetic
+  vt::ScanArgs sa{};
+  sa.X = ix->dX;
+  sa.stride = ix->ld;
+  sa.q = c.dBQ.p;
+  sa.id_rank = ix->dRank.p;
+  sa.gather = &c.dBCand.p->row;
+  sa.gather_stride = sizeof(vt::BatchCand) / sizeof(uint32_t);
+  sa.n = cand_cap;
+  sa.d = d;
+  sa.metric = ix->metric;
+  sa.order = ix->order;
+  sa.k = k;
+  sa.part_keys = c.dPartKeys.p;
+  sa.part_pay = c.dPartPay.p;
+  sa.status = c.dStatus.p;
+  sa.batch_counts = c.dBCount.p;
+  sa.batch_cap = cand_cap;
+  VT_HIP(vt::launch_scan_batch(sa, kBlocksPerQuery, nq_pad, c.stream));
+  VT_HIP(vt::launch_batch_select(c.dPartKeys.p, c.dPartPay.p, nq_pad, kBlocksPerQuery * k, k, c.dBOut.p, c.dBOutCount.p,
+                                 c.stream));
+  int status = 0;
+  VT_HIP(hipMemcpyAsync(c.hBOut.p, c.dBOut.p, (size_t)nq_pad * k * sizeof(vt::Entry), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(c.hBOutCount.p, c.dBOutCount.p, (size_t)nq_pad * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(c.hBCount.p, c.dBCount.p, (size_t)nq_pad * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(c.hBTau.p, c.dBTau.p, (size_t)nq_pad * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(&status, c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  if (c.profiling) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev2, c.ev3));
+    c.prof.batch_launches += 1;
+    c.prof.batch_ms += ms;
+    c.prof.batch_flops += 2.0 * (double)n * (double)nq_pad * (double)ld;
+    c.prof.batch_queries += nq;
+  }
+  if (status != 0) return VT_OK;  // an exact rescoring overflowed somewhere: let the single-query path decide
+
+  // A query is accepted when no row outside its candidate set can reach the
+  // top k: every such row y has mfma(y) < tau, hence exact(y) < tau + eps, where
+  // eps bounds |mfma - reference| <= 2 * gamma_d * |q|.|x| (both are d-term f32
+  // sums of the same products).
+  const double u = std::ldexp(1.0, -24);
+  const double gamma = 2.5 * (double)d * u;
+  const double xnorm = std::sqrt(ix->max_sqnorm);
+  for (size_t i = 0; i < nq; ++i) {
+    const uint32_t cnt = c.hBCount.p[i];
+    if (cnt > cand_cap || c.hBOutCount.p[i] < k) continue;
+    const vt::Entry *e = c.hBOut.p + i * k;
+    const double dot_k = ix->metric == VT_NEG_INNER_PRODUCT ? -(double)e[k - 1].raw : (double)e[k - 1].raw;
+    const double eps = gamma * qnorm[i] * xnorm;
+    if (!((double)c.hBTau.p[i] + eps <= dot_k)) continue;
+    std::vector<vt::Entry> entries(e, e + k);
+    VT_TRY(make_hits(ix, entries, &out[i]));
+    done[i] = 1;
+  }
+  return VT_OK;
+}
+
+int batch_locked(vt_flat *ix, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
+  // every query is validated like flat_search would (flat.rs:97-101), in order
+  if (limit == 0) {
+    for (size_t i = 0; i < nq; ++i) VT_TRY(empty_hits(&out[i]));
+    return VT_OK;
+  }
+  for (size_t i = 0; i < nq; ++i) VT_TRY(validate_vector(queries + i * d, d, ix->dim));
+  if (ix->n == 0) {
+    for (size_t i = 0; i < nq; ++i) VT_TRY(empty_hits(&out[i]));
+    return VT_OK;
+  }
+  std::vector<char> done(nq, 0);
+  const bool dot_family = ix->metric == VT_COSINE || ix->metric == VT_INNER_PRODUCT || ix->metric == VT_NEG_INNER_PRODUCT;
+  const bool use_mfma = dot_family && nq >= 8 && limit <= (size_t)vt::kMaxFusedK && ix->n >= 4096 &&
+                        std::getenv("VT_BATCH_NO_MFMA") == nullptr;
+  if (use_mfma) {
+    VT_TRY(index_sync_ranks(ix, false));
+    for (size_t g0 = 0; g0 < nq; g0 += 256) {
+      const size_t gn = std::min<size_t>(256, nq - g0);
+      std::vector<char> gdone(gn, 0);
+      VT_TRY(batch_group(ix, queries + g0 * d, gn, limit, out + g0, gdone));
+      for (size_t i = 0; i < gn; ++i) done[g0 + i] = gdone[i];
+    }
+  }
+  for (size_t i = 0; i < nq; ++i) {
+    if (done[i]) continue;
+    ix->ctx.prof.batch_fallbacks += use_mfma ? 1 : 0;
+    VT_TRY(search_locked(ix, queries + i * d, d, limit, &out[i]));
+  }
   return VT_OK;
 }
 
@@ -802,6 +1018,7 @@ int vt_flat_delete(vt_flat *ix, const char *id, size_t id_len) {
     ix->rank_host.pop_back();
     ix->n -= 1;
     ix->bits_valid = false;
+    ix->max_sqnorm = -1.0;
   }
   if (ix->n == 0) {
     ix->dim = -1;
@@ -816,29 +1033,22 @@ int vt_flat_search(vt_flat *ix, const float *query, size_t n, size_t limit, vt_h
   if (!ix || !out || (!query && n)) return VT_ERR_ARGUMENT;
   *out = nullptr;
   std::lock_guard<std::mutex> g(ix->mu);
-  Ctx &c = ix->ctx;
-  VT_TRY(c.bind());
-  // flat.rs:96-124
-  if (limit == 0) return empty_hits(out);
-  VT_TRY(validate_vector(query, n, ix->dim));
-  if (ix->n == 0) return empty_hits(out);
-  VT_TRY(index_sync_ranks(ix, false));
-  uint32_t qnz = 0;
-  VT_TRY(upload_query(c, query, n, &qnz));
-  ScanJob j{};
-  j.X = ix->dX;
-  j.stride = ix->ld;
-  j.id_rank = ix->dRank.p;
-  j.gather = nullptr;
-  j.gather_stride = 0;
-  j.n = ix->n;
-  j.d = (uint32_t)ix->dim;
-  j.metric = ix->metric;
-  j.order = ix->order;
-  j.q_nonzero = qnz;
-  std::vector<vt::Entry> entries;
-  VT_TRY(run_scan(c, j, limit, entries, true));
-  return make_hits(ix, entries, out);
+  VT_TRY(ix->ctx.bind());
+  return search_locked(ix, query, n, limit, out);
+}
+
+int vt_flat_search_batch(vt_flat *ix, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
+  if (!ix || !out || (nq && !queries && d)) return VT_ERR_ARGUMENT;
+  for (size_t i = 0; i < nq; ++i) out[i] = nullptr;
+  std::lock_guard<std::mutex> g(ix->mu);
+  VT_TRY(ix->ctx.bind());
+  int st = batch_locked(ix, queries, nq, d, limit, out);
+  if (st != VT_OK)
+    for (size_t i = 0; i < nq; ++i) {
+      delete out[i];
+      out[i] = nullptr;
+    }
+  return st;
 }
 
 int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out) {

@@ -462,13 +462,23 @@ hipError_t launch_scan(const ScanArgs &a, uint32_t blocks, hipStream_t s) {
   const size_t lds = scan_lds_for(sd.p, a.k);
   if (lds > kMaxLds || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.stride < sd.p.ld || a.stride % 4 != 0)
     return hipErrorInvalidValue;
-  if (a.gather != nullptr) return launch_scan_general(sd, blocks, lds, s);
+  if (a.gather != nullptr) return launch_scan_general(sd, blocks, 1, lds, s);
   const bool padded = (a.d % kRowAlign) != 0;
   switch (metric_op(a.metric)) {
     case OP_DOT: return launch_scan_dot(sd, blocks, lds, padded, s);
     case OP_L2: return launch_scan_l2(sd, blocks, lds, padded, s);
     default: return launch_scan_misc(sd, blocks, lds, padded, s);
   }
+}
+
+hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hipStream_t s) {
+  ScanDev sd;
+  sd.a = a;
+  if (!make_scan_shape(a.d, a.batch_cap, &sd.p)) return hipErrorInvalidValue;
+  const size_t lds = scan_lds_for(sd.p, a.k);
+  if (lds > kMaxLds || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.stride < sd.p.ld || !a.gather || !a.batch_counts)
+    return hipErrorInvalidValue;
+  return launch_scan_general(sd, blocks, nq, lds, s);
 }
 
 hipError_t launch_select(const uint64_t *keys, const Payload *pay, uint32_t m, uint32_t k, uint64_t lo_key, int has_lo,

@@ -185,13 +185,26 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
   unsigned char *tkbuf = reinterpret_cast<unsigned char *>(lds + p.ld + kWavesPerBlock * (kTileRows * p.ss)) +
                          wib * WaveTopK<CAP>::lds_bytes();
 
-  for (uint32_t i = threadIdx.x; i < p.ld; i += blockDim.x) qs[i] = a.q[i];
+  // batch mode (gathered scans): blockIdx.y selects the query and its row list
+  const float *qsrc = a.q;
+  const uint32_t *gather = a.gather;
+  uint32_t nrows = a.n;
+  uint32_t list_base = 0;
+  if (GENERAL && a.batch_counts) {
+    const uint32_t b = blockIdx.y;
+    const uint32_t c = a.batch_counts[b];
+    nrows = c < a.batch_cap ? c : a.batch_cap;
+    qsrc += (size_t)b * p.ld;
+    gather += (size_t)b * a.batch_cap * a.gather_stride;
+    list_base = b * gridDim.x;
+  }
+  for (uint32_t i = threadIdx.x; i < p.ld; i += blockDim.x) qs[i] = qsrc[i];
   __syncthreads();
 
   const int op_rt = metric_op(a.metric);
   const uint32_t total_waves = gridDim.x * kWavesPerBlock;
   const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
-  const uint32_t ntiles = p.ntiles;
+  const uint32_t ntiles = GENERAL ? (nrows + kTileRows - 1) / kTileRows : p.ntiles;
 
   WaveTopK<CAP> tk;
   tk.init(tkbuf, a.k);
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       }
       const uint32_t gi = t * kTileRows + c.rowi;
       uint32_t src = 0;
-      if (gi < a.n) src = a.gather ? a.gather[(size_t)gi * a.gather_stride] : gi;
+      if (gi < nrows) src = gather ? gather[(size_t)gi * a.gather_stride] : gi;
       return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.X + (size_t)src * a.stride + colf));
     };
 
@@ -264,9 +277,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
 
     for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
       const uint32_t grow = t * kTileRows + lane;  // lanes 0..31 own a row
-      const bool row_valid = lane < kTileRows && grow < a.n;
+      const bool row_valid = lane < kTileRows && grow < nrows;
       uint32_t src_row = grow;
-      if (GENERAL && row_valid && a.gather) src_row = a.gather[(size_t)grow * a.gather_stride];
+      if (GENERAL && row_valid && gather) src_row = gather[(size_t)grow * a.gather_stride];
       uint32_t my_rank = src_row;
       if (row_valid && a.id_rank) my_rank = a.id_rank[src_row];
 
@@ -359,7 +372,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
   // one list per block: wave 0 absorbs the other waves' buffers
   __shared__ uint32_t s_counts[kWavesPerBlock];
   tk.merge_block(wib, kWavesPerBlock, s_counts, lane);
-  if (wib == 0) tk.store(a.part_keys + (size_t)blockIdx.x * a.k, a.part_pay + (size_t)blockIdx.x * a.k, lane);
+  if (wib == 0)
+    tk.store(a.part_keys + (size_t)(list_base + blockIdx.x) * a.k, a.part_pay + (size_t)(list_base + blockIdx.x) * a.k,
+             lane);
 }
 
 constexpr size_t kMaxLds = 160 * 1024;
@@ -372,11 +387,11 @@ inline hipError_t allow_lds(K kernel, size_t bytes) {
 }
 
 template <int OP, int ORDER, int CAP, bool GENERAL, bool PADDED>
-inline hipError_t launch_scan_t(const ScanDev &sd, uint32_t blocks, size_t lds, hipStream_t s) {
+inline hipError_t launch_scan_t(const ScanDev &sd, uint32_t blocks, size_t lds, hipStream_t s, uint32_t nq = 1) {
   auto kern = scan_topk_kernel<OP, ORDER, CAP, GENERAL, PADDED>;
   hipError_t e = allow_lds(kern, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, sd);
+  hipLaunchKernelGGL(kern, dim3(blocks, nq), dim3(kWavesPerBlock * kWave), lds, s, sd);
   return hipGetLastError();
 }
 
@@ -384,7 +399,7 @@ inline hipError_t launch_scan_t(const ScanDev &sd, uint32_t blocks, size_t lds, 
 hipError_t launch_scan_dot(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
 hipError_t launch_scan_l2(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
 hipError_t launch_scan_misc(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
-hipError_t launch_scan_general(const ScanDev &sd, uint32_t blocks, size_t lds, hipStream_t s);
+hipError_t launch_scan_general(const ScanDev &sd, uint32_t blocks, uint32_t nq, size_t lds, hipStream_t s);
 
 // order (0..2) x buffer registers (k <= kSmallK -> 1, else 4) x padded
 #define VT_SCAN_DISPATCH_ORDERED(OPV)                                                          \

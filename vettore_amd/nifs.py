@@ -201,6 +201,20 @@ def flat_search(index: FlatRef, query, limit: int):
     return ("ok", _take_hits(h)) if st == 0 else _err(st)
 
 
+def flat_search_batch(index: FlatRef, queries, limit: int):
+    """Extension: `queries` is an [nq][d] matrix; returns ("ok", [hits per query]),
+    each list identical to flat_search of that query."""
+    q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32))
+    if q.ndim != 2:
+        raise TypeError("badarg: queries must be a matrix")
+    nq, d = q.shape
+    outs = (C.c_void_p * max(nq, 1))()
+    st = _lib.load().vt_flat_search_batch(index.handle, _fp(q.reshape(-1)), nq, d, limit, outs)
+    if st != 0:
+        return _err(st)
+    return ("ok", [_take_hits(C.c_void_p(outs[i])) for i in range(nq)])
+
+
 def flat_search_with_keys(index: FlatRef, query, limit: int):
     """flat_search plus each hit's rank sort key (for cross-shard merges)."""
     q = _f32_list(query)
