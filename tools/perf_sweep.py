@@ -65,13 +65,24 @@ def run_batch(metric, rows, dim, nq, limit, normalize, steps=4):
     qs = rng.uniform(-1, 1, size=(nq, dim)).astype(np.float32)
     if normalize:
         qs /= np.linalg.norm(qs, axis=1, keepdims=True)
-    assert nifs.flat_search_batch(ref, qs, limit)[0] == "ok"
+    import ctypes as C
+    from vettore_amd import _lib
+    L = _lib.load()
+    outs = (C.c_void_p * nq)()
+    qp = qs.ctypes.data_as(C.POINTER(C.c_float))
+
+    def call():  # the C ABI call itself; hit lists are freed, not unpacked into Python objects
+        assert L.vt_flat_search_batch(ref.handle, qp, nq, dim, limit, outs) == 0
+        for i in range(nq):
+            L.vt_hits_free(C.c_void_p(outs[i]))
+
+    call()
     nifs.flat_set_profiling(ref, True)
     nifs.flat_get_profile(ref, reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        res = nifs.flat_search_batch(ref, qs, limit)
+        call()
     dt = (time.perf_counter() - t0) / steps
     p = nifs.flat_get_profile(ref, reset=True)
     out = {"batch": nq, "metric": nifs.METRICS[metric], "rows": rows, "dim": dim, "limit": limit,

@@ -19,9 +19,13 @@
 // its X operand comes straight from HBM as 16-B fragments (each lane pair reads
 // one whole 128-B line of its row per 32-wide k chunk -- X is touched once, so
 // no LDS round trip); the Q chunk (all queries x 32 k) is shared by the block
-// through LDS (row stride 36 floats: conflict-free ds_read_b128), register
-// staged and double buffered.  k is permuted inside a chunk (lane half h owns
-// k = 16h..16h+15) -- harmless for a sum that only nominates candidates.
+// through LDS, double buffered, filled by LDS-DMA (global_load_lds, 16 B/lane,
+// no staging registers): the image is linear [query][8 slots of 16 B] and the
+// 16-B slot index is XOR-swizzled with (query >> 1) & 7 -- applied to the
+// per-lane SOURCE address on the way in and to the read address on the way out
+// -- which makes every ds_read_b128 conflict-free.  k is permuted inside a chunk
+// (lane half h owns k = 16h..16h+15) -- harmless for a sum that only nominates
+// candidates.
 #include "vt_common.cuh"
 
 namespace vt {
@@ -34,7 +38,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBWaves = 4;          // waves per block
 constexpr int kBRows = kBWaves * 32;  // rows per block tile
-constexpr int kQStride = 36;        // LDS floats per query row of a 32-k chunk
+constexpr int kQStride = 32;        // LDS floats per query row of a 32-k chunk (linear, swizzled slots)
+
+// Cold path of the epilogue: some score of this lane's 16 (one query column, 16
+// rows) reaches the threshold.  Kept out of line so the hot loop stays lean.
+__device__ __noinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v, float tau, uint32_t qcol,
+                                               uint32_t row0, int h) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    const float s = v[i];
+    if (s >= tau && row < a.n_total) {
+      const uint32_t pos = atomicAdd(&a.cand_count[qcol], 1u);
+      if (pos < a.cand_cap) {
+        BatchCand cnd;
+        cnd.score = s;
+        cnd.row = row;
+        a.cand[(size_t)qcol * a.cand_cap + pos] = cnd;
+      }
+    }
+  }
+}
 
 template <int NT, bool DENSE>
 __global__ __launch_bounds__(kBWaves *kWave) void mfma_scores_kernel(const BatchScoreArgs a) {
@@ -51,25 +75,24 @@ __global__ __launch_bounds__(kBWaves *kWave) void mfma_scores_kernel(const Batch
 #pragma unroll
   for (int t = 0; t < NT; ++t) tau[t] = DENSE ? 0.f : a.tau[t * 32 + r];
 
-  // Q chunk staging: thread i moves 16-B pieces i, i+256, ... of the [NQ][32] chunk
-  constexpr int kPieces = NQ * 8 / (kBWaves * kWave);  // float4 pieces per thread
-  auto stage_load = [&](uint32_t c, f32x4 *regs) {
-#pragma unroll
-    for (int i = 0; i < kPieces; ++i) {
-      const uint32_t piece = threadIdx.x + i * (kBWaves * kWave);
-      const uint32_t qrow = piece >> 3, part = piece & 7;
-      regs[i] = *reinterpret_cast<const f32x4 *>(a.Q + (size_t)qrow * a.ld + c * 32 + part * 4);
-    }
-  };
-  auto stage_store = [&](int buf, const f32x4 *regs) {
+  // Q chunk staging by LDS-DMA: one wave instruction fills 8 query rows (1 KiB);
+  // lane L lands in row L/8, physical slot L%8 and fetches logical slot
+  // (L%8) ^ ((row >> 1) & 7) of that row.
+  constexpr int kDmaPerWave = NQ / 8 / kBWaves;  // wave instructions per wave per chunk
+  auto stage_dma = [&](uint32_t c, int buf) {
     float *dst = qlds + buf * (NQ * kQStride);
 #pragma unroll
-    for (int i = 0; i < kPieces; ++i) {
-      const uint32_t piece = threadIdx.x + i * (kBWaves * kWave);
-      const uint32_t qrow = piece >> 3, part = piece & 7;
-      *reinterpret_cast<f32x4 *>(dst + qrow * kQStride + part * 4) = regs[i];
+    for (int i = 0; i < kDmaPerWave; ++i) {
+      const uint32_t row0q = (uint32_t)(wib * kDmaPerWave + i) * 8;
+      const uint32_t qrow = row0q + (lane >> 3);
+      const uint32_t slot = (lane & 7) ^ ((qrow >> 1) & 7);
+      const float *src = a.Q + (size_t)qrow * a.ld + c * 32 + slot * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(dst + row0q * kQStride), 16, 0, 0);
     }
   };
+  // physical 16-B slot of logical slot s in query row q
+  auto qslot = [&](uint32_t q, uint32_t s) { return s ^ ((q >> 1) & 7); };
 
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // DENSE (pass 0) visits a strided sample of the tiles
@@ -85,12 +108,10 @@ __global__ __launch_bounds__(kBWaves *kWave) void mfma_scores_kernel(const Batch
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    f32x4 xa[4], xn[4], qreg[kPieces];
+    f32x4 xa[4], xn[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) xa[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xrow + j * 4));
-    stage_load(0, qreg);
-    __syncthreads();  // previous tile's readers are done with buffer 0
-    stage_store(0, qreg);
+    stage_dma(0, 0);  // buffer 0: its last readers passed the barrier that ended the previous tile
     __syncthreads();
 
     for (uint32_t c = 0; c < nchunk; ++c) {
@@ -100,14 +121,15 @@ __global__ __launch_bounds__(kBWaves *kWave) void mfma_scores_kernel(const Batch
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           xn[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xrow + (c + 1) * 32 + j * 4));
-        stage_load(c + 1, qreg);
+        stage_dma(c + 1, buf ^ 1);  // the other buffer: its readers finished before the last barrier
       }
-      const float *qb = qlds + buf * (NQ * kQStride) + r * kQStride + h * 16;
+      const float *qb = qlds + buf * (NQ * kQStride) + r * kQStride;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x4 qv[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) qv[t] = *reinterpret_cast<const f32x4 *>(qb + t * 32 * kQStride + j * 4);
+        for (int t = 0; t < NT; ++t)
+          qv[t] = *reinterpret_cast<const f32x4 *>(qb + t * 32 * kQStride + qslot(t * 32 + r, 4 * h + j) * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -116,34 +138,29 @@ __global__ __launch_bounds__(kBWaves *kWave) void mfma_scores_kernel(const Batch
         }
       }
       if (more) {
-        stage_store(buf ^ 1, qreg);  // the other buffer: its readers finished before the last barrier
 #pragma unroll
         for (int j = 0; j < 4; ++j) xa[j] = xn[j];
       }
-      __syncthreads();
+      __syncthreads();  // DMA of chunk c+1 has landed (vmcnt(0) precedes the barrier), chunk c is consumed
     }
 
     // epilogue: C layout of 32x32: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const uint32_t qcol = t * 32 + r;
+      if (DENSE) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const uint32_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const float s = acc[t][i];
-        if (DENSE) {
+        for (int i = 0; i < 16; ++i) {
+          const uint32_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
           // dense sample matrix [query][sample row]
           const uint32_t srow = tile * kBRows + wib * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          a.sample[(size_t)qcol * a.sample_rows + srow] = row < a.n_total ? s : -INFINITY;
-        } else if (s >= tau[t] && row < a.n_total) {
-          const uint32_t pos = atomicAdd(&a.cand_count[qcol], 1u);
-          if (pos < a.cand_cap) {
-            BatchCand cnd;
-            cnd.score = s;
-            cnd.row = row;
-            a.cand[(size_t)qcol * a.cand_cap + pos] = cnd;
-          }
+          a.sample[(size_t)qcol * a.sample_rows + srow] = row < a.n_total ? acc[t][i] : -INFINITY;
         }
+      } else {
+        float mx = acc[t][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, acc[t][i]);
+        if (mx >= tau[t]) append_candidates(a, acc[t], tau[t], qcol, row0, h);
       }
     }
   }
