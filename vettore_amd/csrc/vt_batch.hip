@@ -36,8 +36,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBWaves = 4;          // waves per block
-constexpr int kBRows = kBWaves * 32;  // rows per block tile
+constexpr int kRowWaves = 4;           // row groups (of 32 rows) per block
+constexpr int kBRows = kRowWaves * 32;  // rows per block tile
 constexpr int kQStride = 32;        // LDS floats per query row of a 32-k chunk (linear, swizzled slots)
 
 // Cold path of the epilogue: some score of this lane's 16 (one query column, 16
@@ -60,30 +60,38 @@ __device__ __noinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v
   }
 }
 
-template <int NT, bool DENSE>
-__global__ __launch_bounds__(kBWaves *kWave) void mfma_scores_kernel(const BatchScoreArgs a) {
+// NT: 32-query tiles in the batch; QSPLIT: waves sharing a row group, each taking
+// NT / QSPLIT of the query tiles (keeps a wave under 256 registers so two waves
+// fit a SIMD and cover each other's LDS / barrier waits).
+template <int NT, int QSPLIT, bool DENSE>
+__global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(const BatchScoreArgs a) {
   extern __shared__ __align__(16) float qlds[];  // [2][NT*32][kQStride]
+  constexpr int kBWaves = kRowWaves * QSPLIT;
+  constexpr int NTW = NT / QSPLIT;  // query tiles per wave
   const int lane = threadIdx.x & (kWave - 1);
-  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wib = wid % kRowWaves;      // row group of this wave
+  const int qpart = wid / kRowWaves;    // which share of the query tiles
   const int r = lane & 31, h = lane >> 5;
   constexpr int NQ = NT * 32;
   const uint32_t nchunk = a.ld / 32;
   const uint32_t ntiles = (a.n + kBRows - 1) / kBRows;
 
   // thresholds of the 8 query columns this lane sees (column = 32*t + r)
-  float tau[NT];
+  float tau[NTW];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) tau[t] = DENSE ? 0.f : a.tau[t * 32 + r];
+  for (int t = 0; t < NTW; ++t) tau[t] = DENSE ? 0.f : a.tau[(qpart * NTW + t) * 32 + r];
 
   // Q chunk staging by LDS-DMA: one wave instruction fills 8 query rows (1 KiB);
   // lane L lands in row L/8, physical slot L%8 and fetches logical slot
   // (L%8) ^ ((row >> 1) & 7) of that row.
-  constexpr int kDmaPerWave = NQ / 8 / kBWaves;  // wave instructions per wave per chunk
+  constexpr int kDmaPerWave = (NQ / 8 + kBWaves - 1) / kBWaves;  // wave instructions per wave per chunk
   auto stage_dma = [&](uint32_t c, int buf) {
     float *dst = qlds + buf * (NQ * kQStride);
 #pragma unroll
     for (int i = 0; i < kDmaPerWave; ++i) {
-      const uint32_t row0q = (uint32_t)(wib * kDmaPerWave + i) * 8;
+      const uint32_t row0q = (uint32_t)(wid * kDmaPerWave + i) * 8;
+      if (row0q >= (uint32_t)NQ) break;  // wave-uniform (NQ / 8 not a multiple of the wave count)
       const uint32_t qrow = row0q + (lane >> 3);
       const uint32_t slot = (lane & 7) ^ ((qrow >> 1) & 7);
       const float *src = a.Q + (size_t)qrow * a.ld + c * 32 + slot * 4;
@@ -102,9 +110,9 @@ __global__ __launch_bounds__(kBWaves *kWave) void mfma_scores_kernel(const Batch
     const uint32_t lrow = row0 + r < a.n_total ? row0 + r : a.n_total - 1;
     const float *xrow = a.X + (size_t)lrow * a.stride + h * 16;
 
-    f32x16 acc[NT];
+    f32x16 acc[NTW];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
@@ -123,17 +131,19 @@ __global__ __launch_bounds__(kBWaves *kWave) void mfma_scores_kernel(const Batch
           xn[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xrow + (c + 1) * 32 + j * 4));
         stage_dma(c + 1, buf ^ 1);  // the other buffer: its readers finished before the last barrier
       }
-      const float *qb = qlds + buf * (NQ * kQStride) + r * kQStride;
+      // the swizzle depends only on r (tile bases are multiples of 32 rows), so the
+      // per-tile address is a constant offset from four per-lane bases
+      const float *qb = qlds + buf * (NQ * kQStride) + (qpart * NTW * 32 + r) * kQStride;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        f32x4 qv[NT];
+        const float *qj = qb + qslot(r, 4 * h + j) * 4;
+        f32x4 qv[NTW];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-          qv[t] = *reinterpret_cast<const f32x4 *>(qb + t * 32 * kQStride + qslot(t * 32 + r, 4 * h + j) * 4);
+        for (int t = 0; t < NTW; ++t) qv[t] = *reinterpret_cast<const f32x4 *>(qj + t * 32 * kQStride);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t)
+          for (int t = 0; t < NTW; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j][e], qv[t][e], acc[t], 0, 0, 0);
         }
       }
@@ -146,8 +156,8 @@ __global__ __launch_bounds__(kBWaves *kWave) void mfma_scores_kernel(const Batch
 
     // epilogue: C layout of 32x32: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const uint32_t qcol = t * 32 + r;
+    for (int t = 0; t < NTW; ++t) {
+      const uint32_t qcol = (qpart * NTW + t) * 32 + r;
       if (DENSE) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -264,21 +274,22 @@ __global__ __launch_bounds__(256) void batch_select_kernel(const uint64_t *__res
   if (threadIdx.x == 0) out_count[blockIdx.x] = s_live < k ? s_live : k;
 }
 
-template <int NT>
+template <int NT, int QSPLIT>
 hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
   const size_t lds = (size_t)2 * NT * 32 * kQStride * sizeof(float);
+  const dim3 block(kRowWaves * QSPLIT * kWave);
   if (dense) {
-    auto kern = mfma_scores_kernel<NT, true>;
+    auto kern = mfma_scores_kernel<NT, QSPLIT, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBWaves * kWave), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
   } else {
-    auto kern = mfma_scores_kernel<NT, false>;
+    auto kern = mfma_scores_kernel<NT, QSPLIT, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBWaves * kWave), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
   }
   return hipGetLastError();
 }
@@ -290,13 +301,10 @@ uint32_t batch_rows_per_block() { return kBRows; }
 hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
   if (a.ld % 32 != 0 || a.nq_pad % 32 != 0 || a.nq_pad == 0 || a.nq_pad > 256) return hipErrorInvalidValue;
   switch (a.nq_pad / 32) {
-    case 1: return launch_scores_nt<1>(a, dense, blocks, s);
-    case 2: return launch_scores_nt<2>(a, dense, blocks, s);
-    case 3: case 4: {
-      if (a.nq_pad != 128) return hipErrorInvalidValue;
-      return launch_scores_nt<4>(a, dense, blocks, s);
-    }
-    case 8: return launch_scores_nt<8>(a, dense, blocks, s);
+    case 1: return launch_scores_nt<1, 1>(a, dense, blocks, s);
+    case 2: return launch_scores_nt<2, 1>(a, dense, blocks, s);
+    case 4: return launch_scores_nt<4, 1>(a, dense, blocks, s);
+    case 8: return launch_scores_nt<8, 2>(a, dense, blocks, s);
     default: return hipErrorInvalidValue;
   }
 }
