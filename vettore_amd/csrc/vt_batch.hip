@@ -28,6 +28,8 @@
 // candidates.
 #include "vt_common.cuh"
 
+#include <cstdlib>
+
 namespace vt {
 
 using namespace dev;
@@ -39,6 +41,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kRowWaves = 4;           // row groups (of 32 rows) per block
 constexpr int kBRows = kRowWaves * 32;  // rows per block tile
 constexpr int kQStride = 32;        // LDS floats per query row of a 32-k chunk (linear, swizzled slots)
+
+template <bool NT_HINT>
+__device__ __forceinline__ f32x4 xload(const float *p) {
+  if (NT_HINT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+  return *reinterpret_cast<const f32x4 *>(p);
+}
 
 // Cold path of the epilogue: some score of this lane's 16 (one query column, 16
 // rows) reaches the threshold.  Kept out of line so the hot loop stays lean.
@@ -63,7 +71,7 @@ __device__ __noinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v
 // NT: 32-query tiles in the batch; QSPLIT: waves sharing a row group, each taking
 // NT / QSPLIT of the query tiles (keeps a wave under 256 registers so two waves
 // fit a SIMD and cover each other's LDS / barrier waits).
-template <int NT, int QSPLIT, bool DENSE>
+template <int NT, int QSPLIT, bool DENSE, bool XNT>
 __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(const BatchScoreArgs a) {
   extern __shared__ __align__(16) float qlds[];  // [2][NT*32][kQStride]
   constexpr int kBWaves = kRowWaves * QSPLIT;
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
 
     f32x4 xa[4], xn[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xa[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xrow + j * 4));
+    for (int j = 0; j < 4; ++j) xa[j] = xload<XNT>(xrow + j * 4);
     stage_dma(0, 0);  // buffer 0: its last readers passed the barrier that ended the previous tile
     __syncthreads();
 
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
       if (more) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          xn[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xrow + (c + 1) * 32 + j * 4));
+          xn[j] = xload<XNT>(xrow + (c + 1) * 32 + j * 4);
         stage_dma(c + 1, buf ^ 1);  // the other buffer: its readers finished before the last barrier
       }
       // the swizzle depends only on r (tile bases are multiples of 32 rows), so the
@@ -278,14 +286,23 @@ template <int NT, int QSPLIT>
 hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
   const size_t lds = (size_t)2 * NT * 32 * kQStride * sizeof(float);
   const dim3 block(kRowWaves * QSPLIT * kWave);
+  static const bool xnt = std::getenv("VT_BATCH_XNT") != nullptr;
+  if (!dense && xnt) {
+    auto kern = mfma_scores_kernel<NT, QSPLIT, false, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
+    return hipGetLastError();
+  }
   if (dense) {
-    auto kern = mfma_scores_kernel<NT, QSPLIT, true>;
+    auto kern = mfma_scores_kernel<NT, QSPLIT, true, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
   } else {
-    auto kern = mfma_scores_kernel<NT, QSPLIT, false>;
+    auto kern = mfma_scores_kernel<NT, QSPLIT, false, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
@@ -304,7 +321,10 @@ hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blo
     case 1: return launch_scores_nt<1, 1>(a, dense, blocks, s);
     case 2: return launch_scores_nt<2, 1>(a, dense, blocks, s);
     case 4: return launch_scores_nt<4, 1>(a, dense, blocks, s);
-    case 8: return launch_scores_nt<8, 2>(a, dense, blocks, s);
+    case 8: {
+      static const bool split = std::getenv("VT_BATCH_QSPLIT2") != nullptr;
+      return split ? launch_scores_nt<8, 2>(a, dense, blocks, s) : launch_scores_nt<8, 1>(a, dense, blocks, s);
+    }
     default: return hipErrorInvalidValue;
   }
 }
