@@ -15,15 +15,15 @@
 //   pass 1  every row tile: S tile in accumulators, epilogue appends
 //           (score, row) with score >= tau_b to the query's candidate list.
 //
-// Work split: a wave owns 32 rows x (NT*32) queries (NT*16 accumulator VGPRs);
-// its X operand comes straight from HBM as 16-B fragments (each lane pair reads
-// one whole 128-B line of its row per 32-wide k chunk -- X is touched once, so
-// no LDS round trip); the Q chunk (all queries x 32 k) is shared by the block
-// through LDS, double buffered, filled by LDS-DMA (global_load_lds, 16 B/lane,
-// no staging registers): the image is linear [query][8 slots of 16 B] and the
-// 16-B slot index is XOR-swizzled with (query >> 1) & 7 -- applied to the
-// per-lane SOURCE address on the way in and to the read address on the way out
-// -- which makes every ds_read_b128 conflict-free.  k is permuted inside a chunk
+// Work split: a wave owns 32 rows x (NT*32) queries (NT*16 accumulator VGPRs).
+// Both operands of a 32-wide k chunk go through LDS, double buffered, filled by
+// LDS-DMA (global_load_lds, 16 B/lane, whole 128-B lines, no staging
+// registers): the Q chunk (all queries) is shared by the block, each wave's 32
+// X rows are private to it.  The images are linear [row][8 slots of 16 B] and
+// the slot index is XOR-swizzled with (row >> 1) & 7 -- applied to the per-lane
+// SOURCE address on the way in and to the read address on the way out -- which
+// makes every ds_read_b128 conflict-free.  (Fragment-shaped X loads straight to
+// registers were measured 6-20 % slower: 32 B per row per instruction.)  k is permuted inside a chunk
 // (lane half h owns k = 16h..16h+15) -- harmless for a sum that only nominates
 // candidates.
 #include "vt_common.cuh"
@@ -73,7 +73,7 @@ __device__ __noinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v
 // fit a SIMD and cover each other's LDS / barrier waits).
 template <int NT, int QSPLIT, bool DENSE, bool XNT>
 __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(const BatchScoreArgs a) {
-  extern __shared__ __align__(16) float qlds[];  // [2][NT*32][kQStride]
+  extern __shared__ __align__(16) float qlds[];  // [2][NT*32][32] queries, then [2][waves*32][32] rows
   constexpr int kBWaves = kRowWaves * QSPLIT;
   constexpr int NTW = NT / QSPLIT;  // query tiles per wave
   const int lane = threadIdx.x & (kWave - 1);
@@ -109,14 +109,29 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
   };
   // physical 16-B slot of logical slot s in query row q
   auto qslot = [&](uint32_t q, uint32_t s) { return s ^ ((q >> 1) & 7); };
+  // this wave's 32 X rows of chunk c: 4 wave instructions of 8 whole lines each
+  float *xlds = qlds + 2 * (NQ * kQStride) + wid * (32 * kQStride);
+  auto stage_x = [&](const float *tile_rows, uint32_t row_limit, uint32_t c, int buf) {
+    float *dst = xlds + buf * (kBWaves * 32 * kQStride);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t xr = (uint32_t)i * 8 + (lane >> 3);  // row within the wave's 32
+      const uint32_t slot = (lane & 7) ^ ((xr >> 1) & 7);
+      const uint32_t lr = xr < row_limit ? xr : row_limit;  // rows past the end: reread a valid one, masked later
+      const float *src = tile_rows + (size_t)lr * a.stride + c * 32 + slot * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(dst + i * 8 * kQStride), 16, 0, 0);
+    }
+  };
 
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // DENSE (pass 0) visits a strided sample of the tiles
     const uint32_t rtile = DENSE ? tile * a.sample_stride : tile;
     const uint32_t row0 = rtile * kBRows + wib * 32;
     // rows past the end are clamped for the load and masked in the epilogue
-    const uint32_t lrow = row0 + r < a.n_total ? row0 + r : a.n_total - 1;
-    const float *xrow = a.X + (size_t)lrow * a.stride + h * 16;
+    const uint32_t base_row = row0 < a.n_total ? row0 : a.n_total - 1;
+    const float *tile_rows = a.X + (size_t)base_row * a.stride;
+    const uint32_t row_limit = a.n_total - 1 - base_row;  // last valid row offset from base_row
 
     f32x16 acc[NTW];
 #pragma unroll
@@ -124,9 +139,7 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    f32x4 xa[4], xn[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) xa[j] = xload<XNT>(xrow + j * 4);
+    stage_x(tile_rows, row_limit, 0, 0);
     stage_dma(0, 0);  // buffer 0: its last readers passed the barrier that ended the previous tile
     __syncthreads();
 
@@ -134,17 +147,17 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
       const int buf = c & 1;
       const bool more = c + 1 < nchunk;
       if (more) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          xn[j] = xload<XNT>(xrow + (c + 1) * 32 + j * 4);
-        stage_dma(c + 1, buf ^ 1);  // the other buffer: its readers finished before the last barrier
+        stage_x(tile_rows, row_limit, c + 1, buf ^ 1);
+        stage_dma(c + 1, buf ^ 1);  // the other buffers: their readers finished before the last barrier
       }
+      const float *xb = xlds + buf * (kBWaves * 32 * kQStride) + r * kQStride;
       // the swizzle depends only on r (tile bases are multiples of 32 rows), so the
       // per-tile address is a constant offset from four per-lane bases
       const float *qb = qlds + buf * (NQ * kQStride) + (qpart * NTW * 32 + r) * kQStride;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float *qj = qb + qslot(r, 4 * h + j) * 4;
+        const f32x4 xa = *reinterpret_cast<const f32x4 *>(xb + qslot(r, 4 * h + j) * 4);
         f32x4 qv[NTW];
 #pragma unroll
         for (int t = 0; t < NTW; ++t) qv[t] = *reinterpret_cast<const f32x4 *>(qj + t * 32 * kQStride);
@@ -152,12 +165,8 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
           for (int t = 0; t < NTW; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j][e], qv[t][e], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], qv[t][e], acc[t], 0, 0, 0);
         }
-      }
-      if (more) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xa[j] = xn[j];
       }
       __syncthreads();  // DMA of chunk c+1 has landed (vmcnt(0) precedes the barrier), chunk c is consumed
     }
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(256) void batch_select_kernel(const uint64_t *__res
 
 template <int NT, int QSPLIT>
 hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
-  const size_t lds = (size_t)2 * NT * 32 * kQStride * sizeof(float);
+  const size_t lds = (size_t)2 * (NT * 32 + kRowWaves * QSPLIT * 32) * kQStride * sizeof(float);
   const dim3 block(kRowWaves * QSPLIT * kWave);
   static const bool xnt = std::getenv("VT_BATCH_XNT") != nullptr;
   if (!dense && xnt) {
