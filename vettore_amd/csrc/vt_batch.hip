@@ -73,7 +73,7 @@ __device__ __noinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v
 // fit a SIMD and cover each other's LDS / barrier waits).
 template <int NT, int QSPLIT, bool DENSE, bool XNT>
 __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(const BatchScoreArgs a) {
-  extern __shared__ __align__(16) float qlds[];  // [2][NT*32][32] queries, then [2][waves*32][32] rows
+  extern __shared__ __align__(16) float qlds[];  // [3][NT*32][32] queries, then [3][waves*32][32] rows
   constexpr int kBWaves = kRowWaves * QSPLIT;
   constexpr int NTW = NT / QSPLIT;  // query tiles per wave
   const int lane = threadIdx.x & (kWave - 1);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
   // physical 16-B slot of logical slot s in query row q
   auto qslot = [&](uint32_t q, uint32_t s) { return s ^ ((q >> 1) & 7); };
   // this wave's 32 X rows of chunk c: 4 wave instructions of 8 whole lines each
-  float *xlds = qlds + 2 * (NQ * kQStride) + wid * (32 * kQStride);
+  float *xlds = qlds + 3 * (NQ * kQStride) + wid * (32 * kQStride);
   auto stage_x = [&](const float *tile_rows, uint32_t row_limit, uint32_t c, int buf) {
     float *dst = xlds + buf * (kBWaves * 32 * kQStride);
 #pragma unroll
@@ -139,16 +139,29 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
+    // Three LDS stages: the DMA runs two chunks ahead of the MFMAs, so an HBM
+    // round trip has ~2 chunk times to land.  Raw s_barrier + counted vmcnt: a
+    // __syncthreads() would drain the DMA that is meant to stay in flight.
+    constexpr int kDmaPerChunk = kDmaPerWave + 4;  // this wave's DMA instructions per chunk
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the previous tile's stages
     stage_x(tile_rows, row_limit, 0, 0);
-    stage_dma(0, 0);  // buffer 0: its last readers passed the barrier that ended the previous tile
-    __syncthreads();
+    stage_dma(0, 0);
+    if (nchunk > 1) {
+      stage_x(tile_rows, row_limit, 1, 1);
+      stage_dma(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerChunk) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
 
+    int buf = 0;
     for (uint32_t c = 0; c < nchunk; ++c) {
-      const int buf = c & 1;
-      const bool more = c + 1 < nchunk;
-      if (more) {
-        stage_x(tile_rows, row_limit, c + 1, buf ^ 1);
-        stage_dma(c + 1, buf ^ 1);  // the other buffers: their readers finished before the last barrier
+      const int buf2 = buf == 0 ? 2 : buf - 1;  // stage of chunk c + 2 == stage read in iteration c - 1
+      const bool ahead2 = c + 2 < nchunk;
+      if (ahead2) {
+        stage_x(tile_rows, row_limit, c + 2, buf2);
+        stage_dma(c + 2, buf2);
       }
       const float *xb = xlds + buf * (kBWaves * 32 * kQStride) + r * kQStride;
       // the swizzle depends only on r (tile bases are multiples of 32 rows), so the
@@ -168,7 +181,11 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], qv[t][e], acc[t], 0, 0, 0);
         }
       }
-      __syncthreads();  // DMA of chunk c+1 has landed (vmcnt(0) precedes the barrier), chunk c is consumed
+      // chunk c + 1 must have landed for everyone before anyone reads it
+      if (ahead2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerChunk) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      buf = buf == 2 ? 0 : buf + 1;
     }
 
     // epilogue: C layout of 32x32: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
@@ -293,7 +310,7 @@ __global__ __launch_bounds__(256) void batch_select_kernel(const uint64_t *__res
 
 template <int NT, int QSPLIT>
 hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
-  const size_t lds = (size_t)2 * (NT * 32 + kRowWaves * QSPLIT * 32) * kQStride * sizeof(float);
+  const size_t lds = (size_t)3 * (NT * 32 + kRowWaves * QSPLIT * 32) * kQStride * sizeof(float);
   const dim3 block(kRowWaves * QSPLIT * kWave);
   static const bool xnt = std::getenv("VT_BATCH_XNT") != nullptr;
   if (!dense && xnt) {
