@@ -90,38 +90,46 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
 #pragma unroll
   for (int t = 0; t < NTW; ++t) tau[t] = DENSE ? 0.f : a.tau[(qpart * NTW + t) * 32 + r];
 
-  // Q chunk staging by LDS-DMA: one wave instruction fills 8 query rows (1 KiB);
-  // lane L lands in row L/8, physical slot L%8 and fetches logical slot
-  // (L%8) ^ ((row >> 1) & 7) of that row.
-  constexpr int kDmaPerWave = (NQ / 8 + kBWaves - 1) / kBWaves;  // wave instructions per wave per chunk
-  auto stage_dma = [&](uint32_t c, int buf) {
-    float *dst = qlds + buf * (NQ * kQStride);
-#pragma unroll
-    for (int i = 0; i < kDmaPerWave; ++i) {
-      const uint32_t row0q = (uint32_t)(wid * kDmaPerWave + i) * 8;
-      if (row0q >= (uint32_t)NQ) break;  // wave-uniform (NQ / 8 not a multiple of the wave count)
-      const uint32_t qrow = row0q + (lane >> 3);
-      const uint32_t slot = (lane & 7) ^ ((qrow >> 1) & 7);
-      const float *src = a.Q + (size_t)qrow * a.ld + c * 32 + slot * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)(dst + row0q * kQStride), 16, 0, 0);
-    }
-  };
-  // physical 16-B slot of logical slot s in query row q
+  // Staging by LDS-DMA: one wave instruction fills 8 rows (1 KiB); lane L lands
+  // in row L/8, physical slot L%8 and fetches logical slot (L%8) ^ ((row >> 1) & 7)
+  // of that row.  Per-lane source pointers are set up once and advanced by the
+  // chunk; the pieces are issued one at a time so they can be spread between
+  // the MFMAs of a chunk.
+  constexpr int kDmaPerWave = NQ / 8 / kBWaves;  // Q pieces per wave per chunk
+  static_assert(kDmaPerWave * 8 * kBWaves == NQ, "query rows split evenly over the waves");
+  // physical 16-B slot of logical slot s in row q
   auto qslot = [&](uint32_t q, uint32_t s) { return s ^ ((q >> 1) & 7); };
-  // this wave's 32 X rows of chunk c: 4 wave instructions of 8 whole lines each
-  float *xlds = qlds + 3 * (NQ * kQStride) + wid * (32 * kQStride);
-  auto stage_x = [&](const float *tile_rows, uint32_t row_limit, uint32_t c, int buf) {
-    float *dst = xlds + buf * (kBWaves * 32 * kQStride);
+  const float *qsrc[kDmaPerWave];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t xr = (uint32_t)i * 8 + (lane >> 3);  // row within the wave's 32
-      const uint32_t slot = (lane & 7) ^ ((xr >> 1) & 7);
-      const uint32_t lr = xr < row_limit ? xr : row_limit;  // rows past the end: reread a valid one, masked later
-      const float *src = tile_rows + (size_t)lr * a.stride + c * 32 + slot * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)(dst + i * 8 * kQStride), 16, 0, 0);
-    }
+  for (int i = 0; i < kDmaPerWave; ++i) {
+    const uint32_t qrow = (uint32_t)(wid * kDmaPerWave + i) * 8 + (lane >> 3);
+    qsrc[i] = a.Q + (size_t)qrow * a.ld + qslot(qrow, lane & 7) * 4;
+  }
+  auto dma_q = [&](int i, uint32_t c, int buf) {
+    float *dst = qlds + buf * (NQ * kQStride) + (wid * kDmaPerWave + i) * 8 * kQStride;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qsrc[i] + c * 32),
+                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+  };
+  // this wave's 32 X rows: 4 pieces of 8 whole lines each
+  float *xlds = qlds + 3 * (NQ * kQStride) + wid * (32 * kQStride);
+  const float *xsrc[4];
+  auto dma_x = [&](int i, uint32_t c, int buf) {
+    float *dst = xlds + buf * (kBWaves * 32 * kQStride) + i * 8 * kQStride;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xsrc[i] + c * 32),
+                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+  };
+  // all of a chunk's pieces, or the share that goes with step j of the MFMA loop
+  auto dma_chunk = [&](uint32_t c, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_x(i, c, buf);
+#pragma unroll
+    for (int i = 0; i < kDmaPerWave; ++i) dma_q(i, c, buf);
+  };
+  auto dma_step = [&](int j, uint32_t c, int buf) {
+    dma_x(j, c, buf);
+#pragma unroll
+    for (int i = 0; i < kDmaPerWave; ++i)
+      if (i % 4 == j) dma_q(i, c, buf);
   };
 
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -129,9 +137,13 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
     const uint32_t rtile = DENSE ? tile * a.sample_stride : tile;
     const uint32_t row0 = rtile * kBRows + wib * 32;
     // rows past the end are clamped for the load and masked in the epilogue
-    const uint32_t base_row = row0 < a.n_total ? row0 : a.n_total - 1;
-    const float *tile_rows = a.X + (size_t)base_row * a.stride;
-    const uint32_t row_limit = a.n_total - 1 - base_row;  // last valid row offset from base_row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t xr = (uint32_t)i * 8 + (lane >> 3);  // row within the wave's 32
+      uint32_t grow = row0 + xr;
+      grow = grow < a.n_total ? grow : a.n_total - 1;
+      xsrc[i] = a.X + (size_t)grow * a.stride + qslot(xr, lane & 7) * 4;
+    }
 
     f32x16 acc[NTW];
 #pragma unroll
@@ -144,11 +156,9 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
     // __syncthreads() would drain the DMA that is meant to stay in flight.
     constexpr int kDmaPerChunk = kDmaPerWave + 4;  // this wave's DMA instructions per chunk
     __builtin_amdgcn_s_barrier();  // every wave is done reading the previous tile's stages
-    stage_x(tile_rows, row_limit, 0, 0);
-    stage_dma(0, 0);
+    dma_chunk(0, 0);
     if (nchunk > 1) {
-      stage_x(tile_rows, row_limit, 1, 1);
-      stage_dma(1, 1);
+      dma_chunk(1, 1);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerChunk) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -159,26 +169,38 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
     for (uint32_t c = 0; c < nchunk; ++c) {
       const int buf2 = buf == 0 ? 2 : buf - 1;  // stage of chunk c + 2 == stage read in iteration c - 1
       const bool ahead2 = c + 2 < nchunk;
-      if (ahead2) {
-        stage_x(tile_rows, row_limit, c + 2, buf2);
-        stage_dma(c + 2, buf2);
-      }
       const float *xb = xlds + buf * (kBWaves * 32 * kQStride) + r * kQStride;
       // the swizzle depends only on r (tile bases are multiples of 32 rows), so the
       // per-tile address is a constant offset from four per-lane bases
       const float *qb = qlds + buf * (NQ * kQStride) + (qpart * NTW * 32 + r) * kQStride;
+      // software pipeline over the four 8-k steps: fragments of step j+1 are read
+      // and a quarter of the next DMA is issued while step j's MFMAs run
+      f32x4 xa, qv[NTW], xa_n, qv_n[NTW];
+      {
+        const uint32_t so = qslot(r, 4 * h) * 4;
+        xa = *reinterpret_cast<const f32x4 *>(xb + so);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) qv[t] = *reinterpret_cast<const f32x4 *>(qb + so + t * 32 * kQStride);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float *qj = qb + qslot(r, 4 * h + j) * 4;
-        const f32x4 xa = *reinterpret_cast<const f32x4 *>(xb + qslot(r, 4 * h + j) * 4);
-        f32x4 qv[NTW];
+        if (j < 3) {
+          const uint32_t so = qslot(r, 4 * h + j + 1) * 4;
+          xa_n = *reinterpret_cast<const f32x4 *>(xb + so);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) qv[t] = *reinterpret_cast<const f32x4 *>(qj + t * 32 * kQStride);
+          for (int t = 0; t < NTW; ++t) qv_n[t] = *reinterpret_cast<const f32x4 *>(qb + so + t * 32 * kQStride);
+        }
+        if (ahead2) dma_step(j, c + 2, buf2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
           for (int t = 0; t < NTW; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], qv[t][e], acc[t], 0, 0, 0);
+        }
+        if (j < 3) {
+          xa = xa_n;
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) qv[t] = qv_n[t];
         }
       }
       // chunk c + 1 must have landed for everyone before anyone reads it
@@ -347,10 +369,7 @@ hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blo
     case 1: return launch_scores_nt<1, 1>(a, dense, blocks, s);
     case 2: return launch_scores_nt<2, 1>(a, dense, blocks, s);
     case 4: return launch_scores_nt<4, 1>(a, dense, blocks, s);
-    case 8: {
-      static const bool split = std::getenv("VT_BATCH_QSPLIT2") != nullptr;
-      return split ? launch_scores_nt<8, 2>(a, dense, blocks, s) : launch_scores_nt<8, 1>(a, dense, blocks, s);
-    }
+    case 8: return launch_scores_nt<8, 1>(a, dense, blocks, s);
     default: return hipErrorInvalidValue;
   }
 }
