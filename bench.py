@@ -43,6 +43,11 @@ def parse():
     ap.add_argument("--limit", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--mode", choices=["single", "batch", "quantized"], default="single",
+                    help="single: BASELINE.json metric (default); batch: configs[2] (dot, 256-query batches, "
+                         "FP32 MFMA); quantized: configs[4] (sign-bit Hamming pass + exact rerank)")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--candidates", type=int, default=100)
     return ap.parse_args()
 
 
@@ -118,6 +123,78 @@ def pmc_traffic(rows, dim):
     return None
 
 
+def run_side_mode(a, torch, nifs, device):
+    """configs[2] / configs[4] on one GPU: same corpus generator, own JSON line."""
+    import ctypes as C
+    from vettore_amd import _lib
+    L = _lib.load()
+    batch = a.mode == "batch"
+    x = build_shard(torch, device, a.rows, a.dim, SEED_CORPUS)
+    if batch:  # configs[2]: metric :dot -> :inner_product, no normalisation (collection.ex:1302, :1319)
+        x.mul_(torch.empty((a.rows, 1), device=device).uniform_(8.0, 24.0))
+        ref = nifs.flat_new_inner_product()
+    else:
+        ref = nifs.flat_new_cosine()
+    assert nifs.flat_load_device_matrix(ref, doc_ids(0, a.rows), x.data_ptr(), a.rows, a.dim) == ("ok", ())
+    del x
+    torch.cuda.empty_cache()
+    qrng = np.random.default_rng(SEED_QUERY)
+    per = a.batch if batch else 1
+    nq = (a.steps + a.warmup) * per
+    qs = qrng.uniform(-1, 1, size=(nq, a.dim)).astype(np.float32)
+    if not batch:
+        qs /= np.linalg.norm(qs.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+    outs = (C.c_void_p * per)()
+
+    def step(i):
+        q = qs[i * per:(i + 1) * per]
+        qp = q.ctypes.data_as(C.POINTER(C.c_float))
+        if batch:
+            assert L.vt_flat_search_batch(ref.handle, qp, per, a.dim, a.limit, outs) == 0
+            for j in range(per):
+                L.vt_hits_free(C.c_void_p(outs[j]))
+        else:
+            h = C.c_void_p()
+            assert L.vt_flat_quantized_search(ref.handle, qp, a.dim, a.candidates, a.limit, C.byref(h)) == 0
+            L.vt_hits_free(h)
+
+    for i in range(a.warmup):
+        step(i)
+    nifs.flat_set_profiling(ref, True)
+    nifs.flat_get_profile(ref, reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, a.warmup + a.steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    p = nifs.flat_get_profile(ref, reset=True)
+    out = {
+        "value": a.steps * per / dt, "unit": "queries/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if batch else "u64", "data": "synthetic",
+    }
+    if batch:
+        ms = p["batch_ms"] / max(1, p["batch_launches"])
+        tf = p["batch_flops"] / max(1e-9, p["batch_ms"]) / 1e9
+        out["metric"] = "queries/sec, flat dot top-%d, N=%d d=%d, batch=%d" % (a.limit, a.rows, a.dim, per)
+        out["config"] = {"workload": "index: :flat, metric: :dot, d=%d, N=%d, batch=%d queries (MFMA Q x D^T + exact rescoring)"
+                         % (a.dim, a.rows, per), "fallback_queries": p["batch_fallbacks"]}
+        out["roofline"] = {"bound": "mfma", "kernel": "mfma_scores_kernel", "achieved": tf, "peak": 157.3,
+                           "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None, "avg_launch_ms": ms,
+                           "algorithmic_flops_per_launch": p["batch_flops"] / max(1, p["batch_launches"])}
+    else:
+        ms = p["hamming_ms"] / max(1, p["hamming_launches"])
+        gbs = p["hamming_bytes"] / max(1, p["hamming_launches"]) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out["metric"] = "queries/sec, quantized_search (sign-bit Hamming top-%d + exact cosine rerank top-%d), N=%d d=%d" % (
+            a.candidates, a.limit, a.rows, a.dim)
+        out["config"] = {"workload": "quantized_search candidates=%d limit=%d, d=%d, N=%d" % (a.candidates, a.limit, a.dim, a.rows)}
+        out["roofline"] = {"bound": "hbm", "kernel": "hamming_topk_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+                           "algorithmic_bytes_per_launch": p["hamming_bytes"] / max(1, p["hamming_launches"])}
+    print(json.dumps(out))
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -138,6 +215,12 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
     nifs.set_device(local_rank)
+    if a.mode != "single":
+        if world > 1:
+            sys.exit("--mode %s is a single-GPU measurement" % a.mode)
+        if a.mode == "batch" and a.steps == 200:
+            a.steps, a.warmup = 8, 2
+        return run_side_mode(a, torch, nifs, device)
 
     # ---- corpus: this rank's row block of the N-row corpus ------------------
     per = a.rows // world

@@ -28,8 +28,6 @@
 // candidates.
 #include "vt_common.cuh"
 
-#include <cstdlib>
-
 namespace vt {
 
 using namespace dev;
@@ -41,12 +39,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kRowWaves = 4;           // row groups (of 32 rows) per block
 constexpr int kBRows = kRowWaves * 32;  // rows per block tile
 constexpr int kQStride = 32;        // LDS floats per query row of a 32-k chunk (linear, swizzled slots)
-
-template <bool NT_HINT>
-__device__ __forceinline__ f32x4 xload(const float *p) {
-  if (NT_HINT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
-  return *reinterpret_cast<const f32x4 *>(p);
-}
 
 // Cold path of the epilogue: some score of this lane's 16 (one query column, 16
 // rows) reaches the threshold.  Kept out of line so the hot loop stays lean.
@@ -71,7 +63,7 @@ __device__ __noinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v
 // NT: 32-query tiles in the batch; QSPLIT: waves sharing a row group, each taking
 // NT / QSPLIT of the query tiles (keeps a wave under 256 registers so two waves
 // fit a SIMD and cover each other's LDS / barrier waits).
-template <int NT, int QSPLIT, bool DENSE, bool XNT>
+template <int NT, int QSPLIT, bool DENSE>
 __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(const BatchScoreArgs a) {
   extern __shared__ __align__(16) float qlds[];  // [3][NT*32][32] queries, then [3][waves*32][32] rows
   constexpr int kBWaves = kRowWaves * QSPLIT;
@@ -334,23 +326,14 @@ template <int NT, int QSPLIT>
 hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
   const size_t lds = (size_t)3 * (NT * 32 + kRowWaves * QSPLIT * 32) * kQStride * sizeof(float);
   const dim3 block(kRowWaves * QSPLIT * kWave);
-  static const bool xnt = std::getenv("VT_BATCH_XNT") != nullptr;
-  if (!dense && xnt) {
-    auto kern = mfma_scores_kernel<NT, QSPLIT, false, true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
-    return hipGetLastError();
-  }
   if (dense) {
-    auto kern = mfma_scores_kernel<NT, QSPLIT, true, false>;
+    auto kern = mfma_scores_kernel<NT, QSPLIT, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
   } else {
-    auto kern = mfma_scores_kernel<NT, QSPLIT, false, false>;
+    auto kern = mfma_scores_kernel<NT, QSPLIT, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
