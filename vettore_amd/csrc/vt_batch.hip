@@ -203,6 +203,19 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
     }
 
     // epilogue: C layout of 32x32: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+    if (a.xnorm2) {
+      // L2 family: rank by s = 2 q.x - |x|^2 (larger s <=> smaller |q - x|^2)
+      float xn[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const uint32_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        xn[i] = a.xnorm2[row < a.n_total ? row : a.n_total - 1];
+      }
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 2.0f * acc[t][i] - xn[i];
+    }
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const uint32_t qcol = (qpart * NTW + t) * 32 + r;
@@ -269,9 +282,11 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
   if (threadIdx.x == 0) tau[blockIdx.x] = result;
 }
 
-// max over rows of sum x^2 (f64 accumulation): the row-norm bound of the error margin.
-__global__ __launch_bounds__(256) void max_sqnorm_kernel(const float *__restrict__ X, size_t stride, uint32_t n,
-                                                         uint32_t d, unsigned long long *out_bits) {
+// Per-row squared norms (f64 accumulation, stored as f32) and their maximum: the
+// L2-family score term and the row-norm bound of the error margin.
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict__ X, size_t stride, uint32_t n,
+                                                         uint32_t d, float *__restrict__ xnorm2,
+                                                         unsigned long long *out_bits) {
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
@@ -282,6 +297,7 @@ __global__ __launch_bounds__(256) void max_sqnorm_kernel(const float *__restrict
     for (uint32_t j = lane; j < d; j += kWave) s += (double)x[j] * (double)x[j];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, kWave);
+    if (lane == 0) xnorm2[row] = (float)s;
     best = s > best ? s : best;
   }
   if (lane == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(best));  // s >= 0: bits are monotone
@@ -363,10 +379,10 @@ hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t
   return hipGetLastError();
 }
 
-hipError_t launch_max_sqnorm(const float *X, size_t stride, uint32_t n, uint32_t d, unsigned long long *out_bits,
-                             hipStream_t s) {
+hipError_t launch_row_sqnorms(const float *X, size_t stride, uint32_t n, uint32_t d, float *xnorm2,
+                              unsigned long long *out_bits, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(max_sqnorm_kernel, dim3(1024), dim3(256), 0, s, X, stride, n, d, out_bits);
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(2048), dim3(256), 0, s, X, stride, n, d, xnorm2, out_bits);
   return hipGetLastError();
 }
 

@@ -156,14 +156,16 @@ struct BatchScoreArgs {
   BatchCand *cand;        // pass 1: [nq_pad][cand_cap]
   uint32_t *cand_count;   // pass 1: [nq_pad], may exceed cand_cap (overflow)
   uint32_t cand_cap;
+  const float *xnorm2;    // null: score = q.x; else score = 2 q.x - xnorm2[row] (= |q|^2 - |q - x|^2)
 };
 uint32_t batch_rows_per_block();
 hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s);
 hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t rank, float *tau,
                              hipStream_t s);
-// *out_bits = bit pattern of max_i sum_j x_ij^2 (as f64); zero it first.
-hipError_t launch_max_sqnorm(const float *X, size_t stride, uint32_t n, uint32_t d, unsigned long long *out_bits,
-                             hipStream_t s);
+// xnorm2[i] = (f32) sum_j x_ij^2 (f64 accumulation); *out_bits = bit pattern of
+// the f64 maximum over the rows (zero it first).
+hipError_t launch_row_sqnorms(const float *X, size_t stride, uint32_t n, uint32_t d, float *xnorm2,
+                              unsigned long long *out_bits, hipStream_t s);
 // Block b: the k smallest of keys[b][0..m) sorted ascending -> out[b][0..k), out_count[b].
 hipError_t launch_batch_select(const uint64_t *keys, const Payload *pay, uint32_t nq, uint32_t m, uint32_t k, Entry *out,
                                uint32_t *out_count, hipStream_t s);

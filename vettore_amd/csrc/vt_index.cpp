@@ -232,6 +232,7 @@ struct vt_flat {
   DevBuf<uint64_t> dBits;
   bool bits_valid = false;
   double max_sqnorm = -1.0;  // max_i sum_j x_ij^2, < 0 = stale (error margin of the batched path)
+  DevBuf<float> dXnorm2;     // per-row squared norms, valid with max_sqnorm
   // ids
   std::vector<std::string> ids;  // by row
   std::unordered_map<std::string, uint32_t> row_of;
@@ -679,8 +680,9 @@ int batch_group(vt_flat *ix, const float *queries, size_t nq, size_t limit, vt_h
   VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, c.stream));
   if (ix->max_sqnorm < 0.0) {
     unsigned long long bits = 0;
+    VT_TRY(ix->dXnorm2.ensure(std::max<uint32_t>(ix->cap, n)));
     VT_HIP(hipMemsetAsync(c.dBNorm.p, 0, sizeof(unsigned long long), c.stream));
-    VT_HIP(vt::launch_max_sqnorm(ix->dX, ix->ld, n, d, c.dBNorm.p, c.stream));
+    VT_HIP(vt::launch_row_sqnorms(ix->dX, ix->ld, n, d, ix->dXnorm2.p, c.dBNorm.p, c.stream));
     VT_HIP(hipMemcpyAsync(&bits, c.dBNorm.p, sizeof(bits), hipMemcpyDeviceToHost, c.stream));
     VT_HIP(hipStreamSynchronize(c.stream));
     std::memcpy(&ix->max_sqnorm, &bits, sizeof(double));
@@ -693,6 +695,8 @@ int batch_group(vt_flat *ix, const float *queries, size_t nq, size_t limit, vt_h
   a.ld = ld;
   a.nq_pad = nq_pad;
   a.n_total = n;
+  const bool l2_family = ix->metric == VT_L2 || ix->metric == VT_L2_SQUARED;
+  a.xnorm2 = l2_family ? ix->dXnorm2.p : nullptr;
   // pass 0: dense scores of the sample -> tau
   a.n = sample_rows;
   a.sample_stride = stride;
@@ -752,19 +756,37 @@ int batch_group(vt_flat *ix, const float *queries, size_t nq, size_t limit, vt_h
   if (status != 0) return VT_OK;  // an exact rescoring overflowed somewhere: let the single-query path decide
 
   // A query is accepted when no row outside its candidate set can reach the
-  // top k: every such row y has mfma(y) < tau, hence exact(y) < tau + eps, where
-  // eps bounds |mfma - reference| <= 2 * gamma_d * |q|.|x| (both are d-term f32
-  // sums of the same products).
+  // top k.  Every such row y has score_mfma(y) < tau.  With u = 2^-24 and X the
+  // largest row norm, both the MFMA sum and the reference's chunked sum are
+  // d-term f32 sums of the same products, so
+  //   dot family:  |dot_mfma - dot_ref| <= 2 gamma_d |q| X            =: eps
+  //                => dot_ref(y) < tau + eps; accepted if tau + eps (+ slack) <= dot_k;
+  //   L2 family:   score = 2 q.x - |x|^2 = |q|^2 - |q - x|^2, so
+  //                l2sq_ref(y) > |q|^2 - tau - eps with eps = 3.5 d u (|q| + X)^2;
+  //                accepted if l2sq_k (+ slack) <= |q|^2 - tau - eps.
+  // The slack keeps y strictly behind the k-th hit even after the f32 rank
+  // (1 - raw for cosine, sqrt for L2) collapses nearby values onto equal keys,
+  // where the id tie-break could otherwise let y in.
   const double u = std::ldexp(1.0, -24);
-  const double gamma = 2.5 * (double)d * u;
   const double xnorm = std::sqrt(ix->max_sqnorm);
   for (size_t i = 0; i < nq; ++i) {
     const uint32_t cnt = c.hBCount.p[i];
     if (cnt > cand_cap || c.hBOutCount.p[i] < k) continue;
     const vt::Entry *e = c.hBOut.p + i * k;
-    const double dot_k = ix->metric == VT_NEG_INNER_PRODUCT ? -(double)e[k - 1].raw : (double)e[k - 1].raw;
-    const double eps = gamma * qnorm[i] * xnorm;
-    if (!((double)c.hBTau.p[i] + eps <= dot_k)) continue;
+    const double tau = (double)c.hBTau.p[i];
+    const double raw_k = (double)e[k - 1].raw;
+    bool accept = false;
+    if (l2_family) {
+      const double eps = 3.5 * (double)d * u * (qnorm[i] + xnorm) * (qnorm[i] + xnorm);
+      const double l2sq_k = (ix->metric == VT_L2 ? raw_k * raw_k : raw_k) * (1.0 + 16.0 * u);
+      accept = l2sq_k <= qnorm[i] * qnorm[i] * (1.0 - 4.0 * u) - tau - eps;
+    } else {
+      const double eps = 2.5 * (double)d * u * qnorm[i] * xnorm;
+      const double dot_k = ix->metric == VT_NEG_INNER_PRODUCT ? -raw_k : raw_k;
+      const double slack = ix->metric == VT_COSINE ? 4.0 * u * std::max(1.0, std::fabs(1.0 - dot_k)) : 0.0;
+      accept = tau + eps + slack <= dot_k;
+    }
+    if (!accept) continue;  // also taken when anything above is NaN
     std::vector<vt::Entry> entries(e, e + k);
     VT_TRY(make_hits(ix, entries, &out[i]));
     done[i] = 1;
@@ -784,8 +806,9 @@ int batch_locked(vt_flat *ix, const float *queries, size_t nq, size_t d, size_t 
     return VT_OK;
   }
   std::vector<char> done(nq, 0);
-  const bool dot_family = ix->metric == VT_COSINE || ix->metric == VT_INNER_PRODUCT || ix->metric == VT_NEG_INNER_PRODUCT;
-  const bool use_mfma = dot_family && nq >= 8 && limit <= (size_t)vt::kMaxFusedK && ix->n >= 4096 &&
+  const bool mfma_metric = ix->metric == VT_COSINE || ix->metric == VT_INNER_PRODUCT ||
+                           ix->metric == VT_NEG_INNER_PRODUCT || ix->metric == VT_L2 || ix->metric == VT_L2_SQUARED;
+  const bool use_mfma = mfma_metric && nq >= 8 && limit <= (size_t)vt::kMaxFusedK && ix->n >= 4096 &&
                         std::getenv("VT_BATCH_NO_MFMA") == nullptr;
   if (use_mfma) {
     VT_TRY(index_sync_ranks(ix, false));
