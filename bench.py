@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--mode", choices=["single", "batch", "quantized"], default="single",
                     help="single: BASELINE.json metric (default); batch: configs[2] (dot, 256-query batches, "
                          "FP32 MFMA); quantized: configs[4] (sign-bit Hamming pass + exact rerank)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the all_gather exchange even on one rank (prices the multi-GPU merge step)")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--candidates", type=int, default=100)
     return ap.parse_args()
@@ -212,8 +214,11 @@ def main():
 
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    use_dist = world > 1 or a.force_exchange
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     nifs.set_device(local_rank)
     if a.mode != "single":
         if world > 1:
@@ -234,7 +239,7 @@ def main():
     assert res == ("ok", ()), res
     del x
     torch.cuda.empty_cache()
-    sharded = ShardedFlat(ref, dist if world > 1 else None, device)
+    sharded = ShardedFlat(ref, dist if use_dist else None, device, force_exchange=a.force_exchange)
 
     qrng = np.random.default_rng(SEED_QUERY)
     nq = a.steps + a.warmup
@@ -314,7 +319,7 @@ def main():
                 "effective_GBps": rps * a.dim * 4 / 1e9,
             }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

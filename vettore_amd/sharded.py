@@ -66,8 +66,9 @@ class ShardedFlat:
     (tests run the exchange on CPU/gloo with a stand-in shard)."""
 
     def __init__(self, ref, dist=None, device=None,
-                 local_search: Optional[Callable] = None):
+                 local_search: Optional[Callable] = None, force_exchange: bool = False):
         self.ref, self.dist, self.device = ref, dist, device
+        self.force_exchange = force_exchange  # run the collective even on one rank (measures its cost)
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
         self._local = local_search
@@ -87,7 +88,7 @@ class ShardedFlat:
 
     def search(self, query, limit: int) -> List[Tuple[bytes, float]]:
         hits = self._local_search(query, limit)
-        if self.dist is None or self.world == 1:
+        if self.dist is None or (self.world == 1 and not self.force_exchange):
             return [(h[0], h[1]) for h in hits]
         torch = self._torch
         mine = torch.from_numpy(pack_hits(hits, limit))
