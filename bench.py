@@ -318,9 +318,13 @@ def main():
                 "sample": "%d queries over %d rows x %d (%.1f s); rows/s scaled to N=%d" % (sq, srows, a.dim, sdt, a.rows),
                 "effective_GBps": rps * a.dim * 4 / 1e9,
             }
-        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL's version banner sits in libc's stdout buffer: flush it first so
+        # that the JSON line is the last line of output
+        C.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
