@@ -382,20 +382,41 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float *__restrict__
   }
 }
 
-// K6 (cosine part): one candidate per lane, sequential f64 sums in index order
-// (distances.rs:179-185 f64_dot), then distances.rs:160-177.
+// K6 (cosine part): exact rerank value of distances.rs:160-177.  One wave per
+// candidate: the wave stages the row and the query in LDS with coalesced loads,
+// then lanes 0..2 run the three sequential f64 sums |q|^2, |x|^2, q.x in index
+// order side by side (distances.rs:179-185 f64_dot is a sequential fold; products
+// of two f32 are exact in f64, so only the order of the additions matters).
 __global__ __launch_bounds__(64) void cosine_rerank_kernel(const CosineRerankArgs a) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
+  extern __shared__ __align__(16) float crs[];  // [ld] query, [ld] row
+  const uint32_t i = blockIdx.x;
+  const int lane = threadIdx.x;
   const uint32_t src = a.gather ? a.gather[(size_t)i * a.gather_stride] : i;
+  const uint32_t ld4 = (a.d + 3) / 4 * 4;
+  float *qs = crs, *xs = crs + ld4;
   const float *x = a.X + (size_t)src * a.stride;
-  double qq = 0.0, xx = 0.0, qx = 0.0;
-  for (uint32_t j = 0; j < a.d; ++j) {
-    const double qv = (double)a.q[j], xv = (double)x[j];
-    qq += qv * qv;
-    xx += xv * xv;
-    qx += qv * xv;
+  for (uint32_t j = lane; j < a.d; j += kWave) {
+    qs[j] = a.q[j];
+    xs[j] = x[j];
   }
+  wave_lds_fence();
+  double acc = 0.0;
+  if (lane < 3) {
+    const float *A = lane == 1 ? xs : qs;  // lane 0: q.q   lane 1: x.x   lane 2: q.x
+    const float *B = lane == 0 ? qs : xs;
+    uint32_t j = 0;
+    for (; j + 4 <= a.d; j += 4) {
+      const f32x4 av = *reinterpret_cast<const f32x4 *>(A + j);
+      const f32x4 bv = *reinterpret_cast<const f32x4 *>(B + j);
+      acc += (double)av.x * (double)bv.x;
+      acc += (double)av.y * (double)bv.y;
+      acc += (double)av.z * (double)bv.z;
+      acc += (double)av.w * (double)bv.w;
+    }
+    for (; j < a.d; ++j) acc += (double)A[j] * (double)B[j];
+  }
+  const double qq = __shfl(acc, 0, kWave), xx = __shfl(acc, 1, kWave), qx = __shfl(acc, 2, kWave);
+  if (lane != 0) return;
   const double ln = sqrt(qq), rn = sqrt(xx);
   float raw = 0.0f;
   bool ok = true;
@@ -538,7 +559,11 @@ hipError_t launch_pad_rows(const float *src, uint32_t n, uint32_t d, float *dst,
 
 hipError_t launch_cosine_rerank(const CosineRerankArgs &a, hipStream_t s) {
   if (a.n == 0) return hipSuccess;
-  hipLaunchKernelGGL(cosine_rerank_kernel, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+  const size_t lds = (size_t)2 * ((a.d + 3) / 4 * 4) * sizeof(float);
+  if (lds > kMaxLds) return hipErrorInvalidValue;
+  hipError_t e = allow_lds(cosine_rerank_kernel, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(cosine_rerank_kernel, dim3(a.n), dim3(64), lds, s, a);
   return hipGetLastError();
 }
 
