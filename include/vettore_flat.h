@@ -151,6 +151,15 @@ int vt_flat_load_device_matrix(vt_flat *index, size_t count, size_t d,
 int vt_flat_quantized_search(vt_flat *index, const float *query, size_t n,
                              size_t candidates, size_t limit, vt_hits **out);
 
+/* funnel_search, lib/vettore/collection.ex:245-260, :674-691: for every prefix
+ * length in `stages` (1..dimensions, else "invalid prefix dimensions") keep the
+ * `candidates` best rows by vector_top_k on that prefix (search.rs:38-73; a
+ * cosine collection scores prefixes with the f64 `cosine`), the first stage over
+ * the whole corpus, then exact rerank on the full vectors, top `limit`. */
+int vt_flat_funnel_search(vt_flat *index, const float *query, size_t n,
+                          const size_t *stages, size_t nstages, size_t candidates,
+                          size_t limit, vt_hits **out);
+
 /* ------------------------------------------------- stateless NIF helpers
  * vector_top_k/5, nifs.rs:151-162 -> search.rs:38-73. */
 int vt_vector_top_k(int device, size_t count, const char *ids,

@@ -458,6 +458,46 @@ def test_quantized_search_matches_oracle_composition(nifs, oracle_mod, metric):
         assert bits(got) == bits(want), (metric, cand, limit)
 
 
+@pytest.mark.parametrize("metric", [2, 0, 3])
+def test_funnel_search_matches_oracle_composition(nifs, oracle_mod, metric):
+    """collection.ex:245-260, :674-691: per stage vector_top_k on a prefix (f64
+    cosine for metric 2), first stage over the whole corpus, then exact rerank --
+    composed from oracle pieces, compared bit for bit."""
+    n, d = 6000, 200
+    x, ids = make_corpus(n, d, 310 + metric, metric == 2, oracle_mod, tie_block=30)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(4)
+    rows = [(ids[i], x[i]) for i in range(n)]
+    for stages, cand, limit in (([64], 100, 10), ([13, 100], 50, 5), ([128, 200], 300, 20), ([200], 10, 10)):
+        q = rng.uniform(-1, 1, d).astype(np.float32)
+        if metric == 2:
+            q = oracle_mod.normalize_l2(q)
+        cur = rows
+        for st in stages:
+            kept = oracle_mod.vector_top_k(cur, q, metric, st, cand)
+            by_id = dict(cur)
+            cur = [(i, by_id[i]) for i, _ in kept]
+        want = oracle_mod.vector_top_k(cur, q, metric, d, limit)
+        got = unwrap(nifs.flat_funnel_search(g.ref, q, stages, cand, limit))
+        assert bits(got) == bits(want), (metric, stages, cand, limit)
+    assert nifs.flat_funnel_search(g.ref, q, [0], 10, 5) == ("error", "invalid prefix dimensions")
+    assert nifs.flat_funnel_search(g.ref, q, [d + 1], 10, 5) == ("error", "invalid prefix dimensions")
+    assert nifs.flat_funnel_search(g.ref, q, [], 10, 5) == ("error", "invalid prefix dimensions")
+
+
+def test_elixir_funnel_equals_flat_with_full_candidates(nifs):
+    """test/vector_adversarial_test.exs:376-421: funnel_search(stages: [2, 4], candidates: 64) ids == flat ids."""
+    from vettore_amd.collection import Collection
+    c = load("elixir_nif.json")["full_candidate_adaptive_modes_agree_with_exact_flat_search"]
+    ok, col = Collection.new(dimensions=4, metric=c["metric"], index="flat")
+    assert col.put_many([{"id": r[0], "vector": r[1]} for r in c["rows"]]) == "ok"
+    ok, exact = col.search(c["query"], {"limit": c["limit"]})
+    ok, funnel = col.funnel_search(c["query"], {"stages": [2, 4], "candidates": c["candidates"], "limit": c["limit"]})
+    assert [r.id for r in funnel] == [r.id for r in exact]
+    assert col.funnel_search(c["query"], {"stages": [5]}) == ("error", "invalid_stages")
+
+
 def test_binary_top_k_with_massive_ties(nifs, oracle_mod):
     """One-word codes: only 65 distinct distances over 200k rows, so the k-th key
     sits in a crowded radix bin and ties are decided by id bytes alone."""

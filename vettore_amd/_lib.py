@@ -21,7 +21,7 @@ SYMBOLS = [
     "vt_flat_new", "vt_flat_free", "vt_flat_insert", "vt_flat_insert_many", "vt_flat_delete",
     "vt_flat_search", "vt_flat_search_batch", "vt_flat_len", "vt_flat_dimension", "vt_flat_metric",
     "vt_flat_set_reduce_order", "vt_set_default_reduce_order",
-    "vt_flat_load_matrix", "vt_flat_load_device_matrix", "vt_flat_quantized_search",
+    "vt_flat_load_matrix", "vt_flat_load_device_matrix", "vt_flat_quantized_search", "vt_flat_funnel_search",
     "vt_vector_top_k", "vt_binary_top_k", "vt_normalize_l2", "vt_compress_sign_bits",
     "vt_flat_set_profiling", "vt_flat_get_profile",
 ]
@@ -83,6 +83,7 @@ def load() -> C.CDLL:
     L.vt_flat_load_matrix.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_char_p, szp, f32p]
     L.vt_flat_load_device_matrix.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_char_p, szp, vp]
     L.vt_flat_quantized_search.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.vt_flat_funnel_search.argtypes = [vp, f32p, C.c_size_t, szp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.vt_vector_top_k.argtypes = [C.c_int, C.c_size_t, C.c_char_p, szp, f32p, szp, f32p, C.c_size_t, C.c_int,
                                   C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.vt_binary_top_k.argtypes = [C.c_int, C.c_size_t, C.c_char_p, szp, u64p, szp, u64p, C.c_size_t, C.c_size_t,

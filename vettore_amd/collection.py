@@ -193,6 +193,48 @@ class Collection:
             return ("error", ("unsupported_option", bad[0]))
         return self.index_mod.search(self, query, opts)
 
+    # -- collection.ex:234-260 -----------------------------------------------
+    def funnel_search(self, query, opts=None):
+        opts = {} if opts is None else opts
+        if not isinstance(opts, dict):
+            return ("error", "invalid_options")
+        bad = [k for k in opts if k not in ("limit", "candidates", "stages", "dimensions")]
+        if bad:
+            return ("error", ("unsupported_option", bad[0]))
+        limit = opts.get("limit", 10)
+        if not (isinstance(limit, int) and 0 < limit <= MAX_NIF_USIZE):
+            return ("error", "invalid_limit")
+        candidates = opts.get("candidates", max(limit * 10, limit))
+        if not (isinstance(candidates, int) and candidates >= limit and 0 < candidates <= MAX_NIF_USIZE):
+            return ("error", "invalid_candidates")
+        if "stages" in opts:                                        # collection.ex:660-672
+            stages = opts["stages"]
+        elif "dimensions" in opts:
+            stages = [opts["dimensions"]]
+        else:
+            stages = [min(self.dimensions, 128)]
+        if not (isinstance(stages, list) and stages and
+                all(isinstance(s, int) and 0 < s <= self.dimensions for s in stages)):
+            return ("error", "invalid_stages")                      # collection.ex:905-913
+        q = self.prepare_query(query)
+        if q[0] != "ok":
+            return q
+        res = nifs.flat_funnel_search(self.index_state, q[1], stages, candidates, limit)
+        if res[0] != "ok":
+            return res
+        return ("ok", self._hydrate(res[1]))
+
+    def _hydrate(self, hits):
+        out: List[Result] = []
+        for id_, raw in hits:
+            got = self.get(id_)
+            if got[0] != "ok":
+                continue
+            score, distance = result_values(self.metric, raw, self.score)
+            out.append(Result(id=id_, value=got[1].value, score=score, distance=distance, metric=self.metric,
+                              metadata=got[1].metadata))
+        return out
+
     # -- collection.ex:266-295 -----------------------------------------------
     def quantized_search(self, query, opts=None):
         opts = {} if opts is None else opts

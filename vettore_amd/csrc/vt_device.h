@@ -40,7 +40,7 @@ struct ResultBlock {
   Entry e[kMaxFusedK];
 };
 
-inline uint32_t padded_dim(uint32_t d) { return (d + kRowAlign - 1) / kRowAlign * kRowAlign; }
+__host__ __device__ inline uint32_t padded_dim(uint32_t d) { return (d + kRowAlign - 1) / kRowAlign * kRowAlign; }
 
 struct ScanArgs {
   const float *X;          // row-major rows, `stride` floats apart, 256-B aligned
@@ -169,6 +169,25 @@ hipError_t launch_row_sqnorms(const float *X, size_t stride, uint32_t n, uint32_
 // Block b: the k smallest of keys[b][0..m) sorted ascending -> out[b][0..k), out_count[b].
 hipError_t launch_batch_select(const uint64_t *keys, const Payload *pay, uint32_t nq, uint32_t m, uint32_t k, Entry *out,
                                uint32_t *out_count, hipStream_t s);
+
+// K6b: exact f64 cosine (distances.rs:160-177) of the first d coordinates of
+// EVERY row against the query, fused top-k -- stage 1 of funnel_search on a
+// cosine collection (collection.ex:245-260 -> search.rs:56-60).
+struct CosineScanArgs {
+  const float *X;
+  size_t stride;
+  const float *q;          // device, padded with zeros to padded_dim(d)
+  double qq;               // f64_dot(q, q) over the first d coordinates (sequential, host)
+  const uint32_t *id_rank;
+  uint32_t n, d, k;
+  uint64_t lo_key;
+  int has_lo;
+  uint64_t *part_keys;     // [grid_blocks][k]
+  Payload *part_pay;
+  int *status;
+};
+size_t cosine_scan_lds_bytes(uint32_t d, uint32_t k);
+hipError_t launch_cosine_scan(const CosineScanArgs &a, uint32_t blocks, hipStream_t s);
 
 // normalize_l2 (distances.rs:350-361) on rows: out = (x / sqrt(f64 sum x^2)) as f32.
 hipError_t launch_normalize_l2(const float *in, uint32_t n, uint32_t d, float *out, hipStream_t s);

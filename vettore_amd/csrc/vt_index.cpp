@@ -630,6 +630,91 @@ int search_locked(vt_flat *ix, const float *query, size_t n, size_t limit, vt_hi
   return make_hits(ix, entries, out);
 }
 
+// Exact f64-cosine scan of the first `d` coordinates of every row (K6b), passes
+// of <= kMaxFusedK until `want` hits are collected.  Query already in c.dQ.
+int run_cosine_scan(Ctx &c, vt_flat *ix, uint32_t d, double qq, size_t want, std::vector<vt::Entry> &out) {
+  const size_t kmax = vt::cosine_scan_lds_bytes(d, vt::kMaxFusedK) ? (size_t)vt::kMaxFusedK : (size_t)vt::kSmallK;
+  if (vt::cosine_scan_lds_bytes(d, 1) == 0) return fail(VT_ERR_UNSUPPORTED, "prefix too long for the cosine scan kernel");
+  uint64_t lo = 0;
+  bool has_lo = false;
+  const size_t total = std::min<size_t>(want, ix->n);
+  while (out.size() < total) {
+    const uint32_t k = (uint32_t)std::min<size_t>(kmax, total - out.size());
+    const uint32_t blocks = c.grid_for((ix->n + 63) / 64, vt::cosine_scan_lds_bytes(d, k));
+    VT_TRY(c.dPartKeys.ensure((size_t)blocks * k));
+    VT_TRY(c.dPartPay.ensure((size_t)blocks * k));
+    vt::CosineScanArgs a{};
+    a.X = ix->dX;
+    a.stride = ix->ld;
+    a.q = c.dQ.p;
+    a.qq = qq;
+    a.id_rank = ix->dRank.p;
+    a.n = ix->n;
+    a.d = d;
+    a.k = k;
+    a.lo_key = lo;
+    a.has_lo = has_lo ? 1 : 0;
+    a.part_keys = c.dPartKeys.p;
+    a.part_pay = c.dPartPay.p;
+    a.status = c.dStatus.p;
+    VT_HIP(vt::launch_cosine_scan(a, blocks, c.stream));
+    VT_TRY(select_pass(c, c.dPartKeys.p, c.dPartPay.p, blocks * k, k, 0, false));
+    if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
+    const uint32_t got = c.hRes.p->count;
+    for (uint32_t i = 0; i < got; ++i) out.push_back(c.hRes.p->e[i]);
+    if (got < k) break;
+    lo = c.hRes.p->e[got - 1].key;
+    has_lo = true;
+  }
+  return VT_OK;
+}
+
+// One vector_top_k stage (search.rs:38-73) on the resident corpus: prefix length
+// `d`, over all rows (`rows` empty) or over the candidate rows of the previous
+// stage; keeps `want` hits.
+int funnel_stage(vt_flat *ix, const float *query, uint32_t d, const std::vector<uint32_t> &rows, bool all_rows,
+                 size_t want, uint32_t qnz, std::vector<vt::Entry> &out) {
+  Ctx &c = ix->ctx;
+  if (!all_rows) {
+    VT_TRY(c.dRows.ensure(rows.size()));
+    VT_HIP(hipMemcpyAsync(c.dRows.p, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+  }
+  if (ix->metric == VT_COSINE) {
+    double qq = 0.0;  // f64_dot(q, q) over the prefix (distances.rs:179-185)
+    for (uint32_t j = 0; j < d; ++j) qq += (double)query[j] * (double)query[j];
+    if (all_rows) return run_cosine_scan(c, ix, d, qq, want, out);
+    VT_TRY(c.dCandKeys.ensure(rows.size()));
+    VT_TRY(c.dCandPay.ensure(rows.size()));
+    vt::CosineRerankArgs a{};
+    a.X = ix->dX;
+    a.stride = ix->ld;
+    a.q = c.dQ.p;
+    a.id_rank = ix->dRank.p;
+    a.gather = c.dRows.p;
+    a.gather_stride = 1;
+    a.n = (uint32_t)rows.size();
+    a.d = d;
+    a.out_keys = c.dCandKeys.p;
+    a.out_pay = c.dCandPay.p;
+    a.status = c.dStatus.p;
+    VT_HIP(vt::launch_cosine_rerank(a, c.stream));
+    return collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, (uint32_t)rows.size(), want, out);
+  }
+  ScanJob j{};
+  j.X = ix->dX;
+  j.stride = ix->ld;
+  j.id_rank = ix->dRank.p;
+  j.gather = all_rows ? nullptr : c.dRows.p;
+  j.gather_stride = 1;
+  j.n = all_rows ? ix->n : (uint32_t)rows.size();
+  j.d = d;
+  j.metric = ix->metric;
+  j.order = ix->order;
+  j.q_nonzero = qnz;
+  return run_scan(c, j, want, out, false);
+}
+
 // ---------------------------------------------------------------- K2 host side
 // One group of <= 256 queries through the matrix cores.  `done[i]` is set for
 // every query whose exact top-k was proven complete; the others are left for
@@ -1181,6 +1266,45 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
     c.prof.hamming_ms += ms;
     c.prof.hamming_bytes += (uint64_t)ix->n * words * 8;
   }
+  return make_hits(ix, entries, out);
+}
+
+int vt_flat_funnel_search(vt_flat *ix, const float *query, size_t n, const size_t *stages, size_t nstages,
+                          size_t candidates, size_t limit, vt_hits **out) {
+  if (!ix || !out || (!query && n) || (nstages && !stages)) return VT_ERR_ARGUMENT;
+  *out = nullptr;
+  std::lock_guard<std::mutex> g(ix->mu);
+  Ctx &c = ix->ctx;
+  VT_TRY(c.bind());
+  // collection.ex:245-260: prepare_query validates the query against the
+  // collection; stages are prefix lengths 1..dimensions (collection.ex:905-913)
+  VT_TRY(validate_vector(query, n, ix->dim));
+  if (nstages == 0) return VT_ERR_PREFIX;
+  for (size_t i = 0; i < nstages; ++i)
+    if (stages[i] == 0 || stages[i] > n) return VT_ERR_PREFIX;
+  if (ix->n == 0 || candidates == 0 || limit == 0) return empty_hits(out);
+  VT_TRY(index_sync_ranks(ix, false));
+  uint32_t qnz_full = 0;
+  VT_TRY(upload_query(c, query, n, &qnz_full));
+  std::vector<uint32_t> rows;
+  bool all_rows = true;
+  auto qnz_of = [&](size_t d) {
+    uint32_t nz = 0;
+    for (size_t j = 0; j < d; ++j) nz += query[j] != 0.0f ? 1u : 0u;
+    return nz;
+  };
+  // funnel_stage_embeddings (collection.ex:674-691): each stage keeps `candidates` rows
+  for (size_t i = 0; i < nstages; ++i) {
+    std::vector<vt::Entry> kept;
+    VT_TRY(funnel_stage(ix, query, (uint32_t)stages[i], rows, all_rows, candidates, qnz_of(stages[i]), kept));
+    rows.resize(kept.size());
+    for (size_t r = 0; r < kept.size(); ++r) rows[r] = kept[r].row;
+    all_rows = false;
+    if (rows.empty()) return empty_hits(out);
+  }
+  // exact_rerank on the full vectors (collection.ex:821-851)
+  std::vector<vt::Entry> entries;
+  VT_TRY(funnel_stage(ix, query, (uint32_t)ix->dim, rows, false, limit, qnz_full, entries));
   return make_hits(ix, entries, out);
 }
 

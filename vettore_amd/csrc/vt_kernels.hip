@@ -438,6 +438,99 @@ __global__ __launch_bounds__(64) void cosine_rerank_kernel(const CosineRerankArg
   a.out_pay[i] = p;
 }
 
+// K6b: exact f64 cosine of a prefix of every row + fused top-k.  The reference
+// folds |x|^2 and q.x sequentially in f64, element by element, so the K1 trick
+// applies one level down: a wave owns 64 rows and walks them in panels of 64
+// floats; a panel is read with coalesced 16-B loads (4 rows x 256 B per wave
+// instruction), parked in a wave-private LDS panel S[64][68] (stride 4*odd), and
+// lane r then runs row r's two f64 chains over it -- 64 chains in parallel.
+constexpr int kCsRows = 64, kCsPanel = 64, kCsStride = 68;
+
+template <int CAP>
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_kernel(const CosineScanArgs a) {
+  extern __shared__ __align__(16) float cs_lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t ldq = padded_dim(a.d);
+  float *qs = cs_lds;
+  float *S = cs_lds + ldq + wib * (kCsRows * kCsStride);
+  unsigned char *tkbuf = reinterpret_cast<unsigned char *>(cs_lds + ldq + kWavesPerBlock * (kCsRows * kCsStride)) +
+                         wib * WaveTopK<CAP>::lds_bytes();
+  for (uint32_t i = threadIdx.x; i < ldq; i += blockDim.x) qs[i] = a.q[i];
+  __syncthreads();
+
+  const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+  const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
+  const uint32_t ntiles = (a.n + kCsRows - 1) / kCsRows;
+  const uint32_t npanel = (a.d + kCsPanel - 1) / kCsPanel;
+  const double ln = sqrt(a.qq);
+
+  WaveTopK<CAP> tk;
+  tk.init(tkbuf, a.k);
+  for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
+    const uint32_t grow = t * kCsRows + lane;
+    const bool valid_row = grow < a.n;
+    const uint32_t my_rank = (valid_row && a.id_rank) ? a.id_rank[grow] : grow;
+    double xx = 0.0, qx = 0.0;
+    for (uint32_t p = 0; p < npanel; ++p) {
+      f32x4 v[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        uint32_t r = t * kCsRows + 4 * s + (lane >> 4);
+        r = r < a.n ? r : a.n - 1;
+        v[s] = __builtin_nontemporal_load(
+            reinterpret_cast<const f32x4 *>(a.X + (size_t)r * a.stride + p * kCsPanel + (lane & 15) * 4));
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        *reinterpret_cast<f32x4 *>(S + (4 * s + (lane >> 4)) * kCsStride + (lane & 15) * 4) = v[s];
+      wave_lds_fence();
+      const uint32_t cnt = a.d - p * kCsPanel < (uint32_t)kCsPanel ? a.d - p * kCsPanel : (uint32_t)kCsPanel;
+      const float *Sr = S + lane * kCsStride;
+      const float *qp = qs + p * kCsPanel;
+      uint32_t j = 0;
+      for (; j + 4 <= cnt; j += 4) {
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(Sr + j);
+        const f32x4 qv = *reinterpret_cast<const f32x4 *>(qp + j);
+        xx += (double)xv.x * (double)xv.x;
+        qx += (double)qv.x * (double)xv.x;
+        xx += (double)xv.y * (double)xv.y;
+        qx += (double)qv.y * (double)xv.y;
+        xx += (double)xv.z * (double)xv.z;
+        qx += (double)qv.z * (double)xv.z;
+        xx += (double)xv.w * (double)xv.w;
+        qx += (double)qv.w * (double)xv.w;
+      }
+      for (; j < cnt; ++j) {
+        const double xd = (double)Sr[j];
+        xx += xd * xd;
+        qx += (double)qp[j] * xd;
+      }
+      wave_lds_fence();
+    }
+    // distances.rs:160-177
+    const double rn = sqrt(xx);
+    float raw = 0.0f;
+    bool valid = valid_row;
+    if (!(ln == 0.0 || rn == 0.0)) {
+      double sim = qx / (ln * rn);
+      if (!isfinite(sim)) {
+        if (valid) atomicMax(a.status, kErrOverflow);
+        valid = false;
+      } else {
+        sim = sim < -1.0 ? -1.0 : (sim > 1.0 ? 1.0 : sim);
+        raw = (float)sim;
+      }
+    }
+    const uint64_t key = ((uint64_t)orderable(1.0f - raw) << 32) | my_rank;
+    if (a.has_lo) valid = valid && key > a.lo_key;
+    tk.offer(valid, key, grow, raw, lane);
+  }
+  __shared__ uint32_t s_counts[kWavesPerBlock];
+  tk.merge_block(wib, kWavesPerBlock, s_counts, lane);
+  if (wib == 0) tk.store(a.part_keys + (size_t)blockIdx.x * a.k, a.part_pay + (size_t)blockIdx.x * a.k, lane);
+}
+
 // K7: normalize_l2 (distances.rs:350-361), one row per lane.
 __global__ __launch_bounds__(64) void normalize_l2_kernel(const float *__restrict__ in, uint32_t n, uint32_t d,
                                                           float *__restrict__ out) {
@@ -564,6 +657,30 @@ hipError_t launch_cosine_rerank(const CosineRerankArgs &a, hipStream_t s) {
   hipError_t e = allow_lds(cosine_rerank_kernel, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(cosine_rerank_kernel, dim3(a.n), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+size_t cosine_scan_lds_bytes(uint32_t d, uint32_t k) {
+  const size_t buf = k <= (uint32_t)kSmallK ? WaveTopK<kCapSmall>::lds_bytes() : WaveTopK<kCapLarge>::lds_bytes();
+  const size_t bytes = ((size_t)padded_dim(d) + (size_t)kWavesPerBlock * kCsRows * kCsStride) * sizeof(float) +
+                       kWavesPerBlock * buf;
+  return bytes <= kMaxLds ? bytes : 0;
+}
+
+hipError_t launch_cosine_scan(const CosineScanArgs &a, uint32_t blocks, hipStream_t s) {
+  const size_t lds = cosine_scan_lds_bytes(a.d, a.k);
+  if (lds == 0 || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.n == 0) return hipErrorInvalidValue;
+  if (a.k <= (uint32_t)kSmallK) {
+    auto kern = cosine_scan_kernel<kCapSmall>;
+    hipError_t e = allow_lds(kern, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+  } else {
+    auto kern = cosine_scan_kernel<kCapLarge>;
+    hipError_t e = allow_lds(kern, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+  }
   return hipGetLastError();
 }
 

@@ -291,6 +291,15 @@ def flat_quantized_search(index: FlatRef, query, candidates: int, limit: int):
     return ("ok", _take_hits(h)) if st == 0 else _err(st)
 
 
+def flat_funnel_search(index: FlatRef, query, stages: Sequence[int], candidates: int, limit: int):
+    """collection.ex:245-260 as one native call on the resident corpus."""
+    q = _f32_list(query)
+    st = np.ascontiguousarray(np.asarray(list(stages), dtype=np.uintp))
+    h = C.c_void_p()
+    rc = _lib.load().vt_flat_funnel_search(index.handle, _fp(q), q.size, _szp(st), st.size, candidates, limit, C.byref(h))
+    return ("ok", _take_hits(h)) if rc == 0 else _err(rc)
+
+
 def flat_set_reduce_order(index: FlatRef, order: int):
     st = _lib.load().vt_flat_set_reduce_order(index.handle, order)
     return "ok" if st == 0 else _err(st)
