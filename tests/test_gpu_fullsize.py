@@ -1,0 +1,94 @@
+"""Full BASELINE.json sizes on one MI355X, checked through size-independent
+properties (the oracle would need minutes per query here).  The corpus is
+generated in HBM with torch and handed to the index by device pointer."""
+import numpy as np
+import pytest
+
+import support
+
+pytestmark = pytest.mark.gpu
+
+N, D = 10_000_000, 768
+
+
+@pytest.fixture(scope="module")
+def corpus():
+    import torch  # first: shares its HIP runtime with the library
+    from vettore_amd import nifs
+    from bench import build_shard, doc_ids
+    dev = torch.device("cuda", 0)
+    x = build_shard(torch, dev, N, D, 20260721)
+    # a block of 64 identical rows and a few planted near-duplicates of row 12345
+    x[5_000_000:5_000_064] = x[5_000_000]
+    host_rows = {i: x[i].cpu().numpy() for i in (0, 12345, 5_000_000, 5_000_063, N - 1)}
+    return torch, nifs, x, doc_ids, host_rows
+
+
+def _index(nifs, metric_new, x, doc_ids, start, count):
+    ref = metric_new()
+    ptr = x.data_ptr() + start * D * 4
+    assert nifs.flat_load_device_matrix(ref, doc_ids(start, count), ptr, count, D) == ("ok", ())
+    return ref
+
+
+def _rank_keys(metric, hits):
+    import oracle
+    return [(support.total_key(oracle.rank_value(metric, np.float32(h[1]))), h[0]) for h in hits]
+
+
+def test_north_star_size_cosine_properties(corpus, oracle_mod):
+    """configs: flat cosine, d=768, N=10M.  Self-hit, reference ordering,
+    id tie-break inside a block of identical rows, limit monotonicity, batched ==
+    single, quantized search finds planted exact matches."""
+    torch, nifs, x, doc_ids, host = corpus
+    ref = _index(nifs, nifs.flat_new_cosine, x, doc_ids, 0, N)
+    assert len(ref) == N
+    for row in (0, 12345, N - 1):
+        st, hits = nifs.flat_search(ref, host[row], 10)
+        assert st == "ok" and hits[0][0] == b"doc-%d" % (row + 1) and support.close(hits[0][1], 1.0, 1e-5)
+        keys = _rank_keys(2, hits)
+        assert keys == sorted(keys)
+        assert nifs.flat_search(ref, host[row], 5)[1] == hits[:5]
+    # 64 identical rows: all tie exactly; the reference order is by id BYTES
+    st, hits = nifs.flat_search(ref, host[5_000_000], 70)
+    tied = [h for h in hits if np.float32(h[1]).tobytes() == np.float32(hits[0][1]).tobytes()]
+    expect = sorted(b"doc-%d" % (i + 1) for i in range(5_000_000, 5_000_064))
+    assert [h[0] for h in tied[:64]] == expect
+    # batched (MFMA + exact rescoring) == single, bit for bit
+    qs = np.stack([host[0], host[12345], host[5_000_000]] + [
+        oracle_mod.normalize_l2(np.random.default_rng(s).uniform(-1, 1, D).astype(np.float32)) for s in range(13)])
+    st, batch = nifs.flat_search_batch(ref, qs, 10)
+    assert st == "ok"
+    for i, q in enumerate(qs):
+        single = nifs.flat_search(ref, q, 10)[1]
+        assert [(h[0], np.float32(h[1]).tobytes()) for h in batch[i]] == \
+               [(h[0], np.float32(h[1]).tobytes()) for h in single], i
+    # quantized: an exact copy has Hamming distance 0, so it survives the candidate pass
+    st, qhits = nifs.flat_quantized_search(ref, host[12345], 100, 10)
+    assert st == "ok" and qhits[0][0] == b"doc-12346" and len(qhits) == 10
+    keys = _rank_keys(2, qhits)
+    assert keys == sorted(keys)
+    del ref
+
+
+def test_config4_shape_l2_shards_merge_to_the_single_index(corpus, oracle_mod):
+    """configs[3] on one GPU: the 10M rows as 4 row-block shards (each its own
+    index and id-rank space) merged by (rank key, id bytes) must equal the one
+    index over all rows -- the property the RCCL merge relies on."""
+    torch, nifs, x, doc_ids, host = corpus
+    from vettore_amd.sharded import merge_shards
+    whole = _index(nifs, nifs.flat_new_l2, x, doc_ids, 0, N)
+    rng = np.random.default_rng(4)
+    queries = [host[5_000_000], host[N - 1]] + [rng.uniform(-1, 1, D).astype(np.float32) * 0.05 for _ in range(3)]
+    singles = [nifs.flat_search(whole, q, 10)[1] for q in queries]
+    del whole
+    torch.cuda.empty_cache()
+    per = N // 4
+    shards = [_index(nifs, nifs.flat_new_l2, x, doc_ids, r * per, per) for r in range(4)]
+    for q, want in zip(queries, singles):
+        parts = [nifs.flat_search_with_keys(s, q, 10)[1] for s in shards]
+        got = merge_shards(parts, 10)
+        assert [(h[0], np.float32(h[1]).tobytes()) for h in got] == \
+               [(h[0], np.float32(h[1]).tobytes()) for h in want]
+        keys = _rank_keys(0, got)
+        assert keys == sorted(keys)
