@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -34,6 +35,21 @@ int fail(int status, const std::string &detail) {
       return fail(VT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));       \
   } while (0)
 
+// No exception may cross the C ABI: allocation failures and anything unexpected
+// become statuses.
+template <typename F>
+int guarded(F &&f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc &) {
+    return fail(VT_ERR_NOMEM, "out of host memory");
+  } catch (const std::exception &e) {
+    return fail(VT_ERR_DEVICE, e.what());
+  } catch (...) {
+    return fail(VT_ERR_DEVICE, "unknown exception");
+  }
+}
+
 #define VT_TRY(expr)          \
   do {                        \
     int _s = (expr);          \
@@ -41,6 +57,7 @@ int fail(int status, const std::string &detail) {
   } while (0)
 
 inline uint32_t round_up_u32(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+constexpr uint32_t kUnranked = 0xFFFFFFFFu;  // id_rank of a row inserted out of id order, until the next re-rank
 
 // flat.rs:136-144 validate_vector: empty, then dimension, then finiteness.
 int validate_vector(const float *v, size_t n, long dimension) {
@@ -467,16 +484,16 @@ uint32_t index_row_for(vt_flat *ix, const char *id, size_t len, bool *is_new) {
     // collection.ex:427-433) keep ranks valid without a re-sort
     if (r == 0 || id_less(ix->max_id, key)) {
       const uint32_t rk = r == 0 ? 0 : ix->max_rank + 1;
-      if (r != 0 && ix->max_rank == 0xFFFFFFFFu) ix->ranks_clean = false;
+      if (r != 0 && ix->max_rank >= kUnranked - 1) ix->ranks_clean = false;
       ix->rank_host.push_back(rk);
       ix->max_rank = rk;
       ix->max_id = key;
     } else {
       ix->ranks_clean = false;
-      ix->rank_host.push_back(0);
+      ix->rank_host.push_back(kUnranked);
     }
   } else {
-    ix->rank_host.push_back(0);
+    ix->rank_host.push_back(kUnranked);
   }
   ix->row_of.emplace(key, r);
   ix->ids.push_back(std::move(key));
@@ -487,10 +504,19 @@ uint32_t index_row_for(vt_flat *ix, const char *id, size_t len, bool *is_new) {
 // and makes the device copy current.
 int index_sync_ranks(vt_flat *ix, bool force_upload) {
   if (!ix->ranks_clean) {
-    std::vector<uint32_t> order(ix->n);
-    for (uint32_t i = 0; i < ix->n; ++i) order[i] = i;
+    // Rows that kept a rank from before are still in the right relative order
+    // (ranks only need to be order-isomorphic to the ids): sort them by rank
+    // (integers), sort only the unranked newcomers by id (strings), and merge.
     const std::vector<std::string> &ids = ix->ids;
-    parallel_sort(order, [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+    std::vector<uint32_t> ranked, fresh;
+    ranked.reserve(ix->n);
+    for (uint32_t i = 0; i < ix->n; ++i) (ix->rank_host[i] == kUnranked ? fresh : ranked).push_back(i);
+    const std::vector<uint32_t> &rk = ix->rank_host;
+    parallel_sort(ranked, [&rk](uint32_t a, uint32_t b) { return rk[a] < rk[b]; });
+    parallel_sort(fresh, [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+    std::vector<uint32_t> order(ix->n);
+    std::merge(ranked.begin(), ranked.end(), fresh.begin(), fresh.end(), order.begin(),
+               [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
     ix->rank_host.resize(ix->n);
     for (uint32_t i = 0; i < ix->n; ++i) ix->rank_host[order[i]] = i;
     if (ix->n) {
@@ -996,6 +1022,7 @@ uint32_t vt_hits_rank_key(const vt_hits *h, size_t i) { return h->rank_key[i]; }
 void vt_hits_free(vt_hits *h) { delete h; }
 
 int vt_flat_new(int metric_code, int device, vt_flat **out) {
+  return guarded([&]() -> int {
   if (!out) return VT_ERR_ARGUMENT;
   *out = nullptr;
   if (metric_code < VT_L2 || metric_code > VT_JACCARD) return VT_ERR_UNKNOWN_METRIC;
@@ -1004,6 +1031,7 @@ int vt_flat_new(int metric_code, int device, vt_flat **out) {
   VT_TRY(ix->ctx.init(device));
   *out = ix.release();
   return VT_OK;
+  });
 }
 
 void vt_flat_free(vt_flat *ix) { delete ix; }
@@ -1019,13 +1047,16 @@ int vt_set_default_reduce_order(int order) {
 }
 
 int vt_flat_set_reduce_order(vt_flat *ix, int order) {
+  return guarded([&]() -> int {
   if (!ix || order < VT_ORDER_PAIR || order > VT_ORDER_SEQ) return VT_ERR_ARGUMENT;
   std::lock_guard<std::mutex> g(ix->mu);
   ix->order = order;
   return VT_OK;
+  });
 }
 
 int vt_flat_insert(vt_flat *ix, const char *id, size_t id_len, const float *vector, size_t n) {
+  return guarded([&]() -> int {
   if (!ix || (!id && id_len) || (!vector && n)) return VT_ERR_ARGUMENT;
   std::lock_guard<std::mutex> g(ix->mu);
   VT_TRY(ix->ctx.bind());
@@ -1038,10 +1069,12 @@ int vt_flat_insert(vt_flat *ix, const char *id, size_t id_len, const float *vect
   src.host = vector;
   src.off = val_off;
   return index_store_rows(ix, 1, id ? id : "", id_off, src);
+  });
 }
 
 int vt_flat_insert_many(vt_flat *ix, size_t count, const char *ids, const size_t *id_off, const float *values,
                         const size_t *value_off) {
+  return guarded([&]() -> int {
   if (!ix || (count && (!id_off || !value_off))) return VT_ERR_ARGUMENT;
   std::lock_guard<std::mutex> g(ix->mu);
   VT_TRY(ix->ctx.bind());
@@ -1057,9 +1090,11 @@ int vt_flat_insert_many(vt_flat *ix, size_t count, const char *ids, const size_t
   src.host = values;
   src.off = value_off;
   return index_store_rows(ix, count, ids, id_off, src);
+  });
 }
 
 int vt_flat_load_matrix(vt_flat *ix, size_t count, size_t d, const char *ids, const size_t *id_off, const float *rows) {
+  return guarded([&]() -> int {
   if (!ix || (count && (!id_off || !rows))) return VT_ERR_ARGUMENT;
   std::lock_guard<std::mutex> g(ix->mu);
   VT_TRY(ix->ctx.bind());
@@ -1072,10 +1107,12 @@ int vt_flat_load_matrix(vt_flat *ix, size_t count, size_t d, const char *ids, co
   src.host = rows;
   src.d = d;
   return index_store_rows(ix, count, ids, id_off, src);
+  });
 }
 
 int vt_flat_load_device_matrix(vt_flat *ix, size_t count, size_t d, const char *ids, const size_t *id_off,
                                const void *device_rows) {
+  return guarded([&]() -> int {
   if (!ix || (count && (!id_off || !device_rows))) return VT_ERR_ARGUMENT;
   std::lock_guard<std::mutex> g(ix->mu);
   Ctx &c = ix->ctx;
@@ -1098,9 +1135,11 @@ int vt_flat_load_device_matrix(vt_flat *ix, size_t count, size_t d, const char *
   src.device = rows;
   src.d = d;
   return index_store_rows(ix, count, ids, id_off, src);
+  });
 }
 
 int vt_flat_delete(vt_flat *ix, const char *id, size_t id_len) {
+  return guarded([&]() -> int {
   if (!ix || (!id && id_len)) return VT_ERR_ARGUMENT;
   std::lock_guard<std::mutex> g(ix->mu);
   Ctx &c = ix->ctx;
@@ -1135,17 +1174,21 @@ int vt_flat_delete(vt_flat *ix, const char *id, size_t id_len) {
     ix->max_rank = 0;
   }
   return VT_OK;
+  });
 }
 
 int vt_flat_search(vt_flat *ix, const float *query, size_t n, size_t limit, vt_hits **out) {
+  return guarded([&]() -> int {
   if (!ix || !out || (!query && n)) return VT_ERR_ARGUMENT;
   *out = nullptr;
   std::lock_guard<std::mutex> g(ix->mu);
   VT_TRY(ix->ctx.bind());
   return search_locked(ix, query, n, limit, out);
+  });
 }
 
 int vt_flat_search_batch(vt_flat *ix, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
+  return guarded([&]() -> int {
   if (!ix || !out || (nq && !queries && d)) return VT_ERR_ARGUMENT;
   for (size_t i = 0; i < nq; ++i) out[i] = nullptr;
   std::lock_guard<std::mutex> g(ix->mu);
@@ -1157,9 +1200,11 @@ int vt_flat_search_batch(vt_flat *ix, const float *queries, size_t nq, size_t d,
       out[i] = nullptr;
     }
   return st;
+  });
 }
 
 int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out) {
+  return guarded([&]() -> int {
   if (!ix || !out || (!query && n)) return VT_ERR_ARGUMENT;
   *out = nullptr;
   std::lock_guard<std::mutex> g(ix->mu);
@@ -1267,10 +1312,12 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
     c.prof.hamming_bytes += (uint64_t)ix->n * words * 8;
   }
   return make_hits(ix, entries, out);
+  });
 }
 
 int vt_flat_funnel_search(vt_flat *ix, const float *query, size_t n, const size_t *stages, size_t nstages,
                           size_t candidates, size_t limit, vt_hits **out) {
+  return guarded([&]() -> int {
   if (!ix || !out || (!query && n) || (nstages && !stages)) return VT_ERR_ARGUMENT;
   *out = nullptr;
   std::lock_guard<std::mutex> g(ix->mu);
@@ -1306,11 +1353,13 @@ int vt_flat_funnel_search(vt_flat *ix, const float *query, size_t n, const size_
   std::vector<vt::Entry> entries;
   VT_TRY(funnel_stage(ix, query, (uint32_t)ix->dim, rows, false, limit, qnz_full, entries));
   return make_hits(ix, entries, out);
+  });
 }
 
 int vt_vector_top_k(int device, size_t count, const char *ids, const size_t *id_off, const float *values,
                     const size_t *value_off, const float *query, size_t nq, int metric_code, size_t dimensions,
                     size_t limit, vt_hits **out) {
+  return guarded([&]() -> int {
   if (!out || (count && (!id_off || !value_off))) return VT_ERR_ARGUMENT;
   *out = nullptr;
   // nifs.rs:158-161: metric decode first, then search.rs:38-73
@@ -1393,11 +1442,13 @@ int vt_vector_top_k(int device, size_t count, const char *ids, const size_t *id_
   }
   if (first_error != VT_OK) return first_error;
   return hits_from_batch(ids, id_off, entries, out);
+  });
 }
 
 int vt_binary_top_k(int device, size_t count, const char *ids, const size_t *id_off, const uint64_t *words,
                     const size_t *word_off, const uint64_t *query, size_t nq, size_t dimensions, size_t limit,
                     vt_hits **out) {
+  return guarded([&]() -> int {
   if (!out || (count && (!id_off || !word_off))) return VT_ERR_ARGUMENT;
   *out = nullptr;
   // search.rs:82-84: the query is validated against itself first
@@ -1431,9 +1482,11 @@ int vt_binary_top_k(int device, size_t count, const char *ids, const size_t *id_
   std::vector<vt::Entry> entries;
   VT_TRY(run_hamming(c, dBits.p, dQ.p, dRank.p, n, (uint32_t)dimensions, limit, entries, false));
   return hits_from_batch(ids, id_off, entries, out);
+  });
 }
 
 int vt_normalize_l2(int device, size_t count, size_t d, const float *in, float *out) {
+  return guarded([&]() -> int {
   if ((count && d) && (!in || !out)) return VT_ERR_ARGUMENT;
   // distances.rs:350-361: finiteness first
   VT_TRY(validate_finite(in, count * d));
@@ -1451,9 +1504,11 @@ int vt_normalize_l2(int device, size_t count, size_t d, const float *in, float *
   VT_HIP(hipMemcpyAsync(out, dOut.p, count * d * sizeof(float), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(hipStreamSynchronize(c.stream));
   return VT_OK;
+  });
 }
 
 int vt_compress_sign_bits(int device, size_t count, size_t d, const float *in, uint64_t *out) {
+  return guarded([&]() -> int {
   if ((count && d) && (!in || !out)) return VT_ERR_ARGUMENT;
   if (count == 0 || d == 0) return VT_OK;
   if (count > 0xFFFFFFF0ull || d > 0x7fffffffu) return fail(VT_ERR_UNSUPPORTED, "batch too large");
@@ -1471,21 +1526,26 @@ int vt_compress_sign_bits(int device, size_t count, size_t d, const float *in, u
   VT_HIP(hipMemcpyAsync(out, dOut.p, count * W * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(hipStreamSynchronize(c.stream));
   return VT_OK;
+  });
 }
 
 int vt_flat_set_profiling(vt_flat *ix, int enabled) {
+  return guarded([&]() -> int {
   if (!ix) return VT_ERR_ARGUMENT;
   std::lock_guard<std::mutex> g(ix->mu);
   ix->ctx.profiling = enabled != 0;
   return VT_OK;
+  });
 }
 
 int vt_flat_get_profile(vt_flat *ix, vt_profile *out, int reset) {
+  return guarded([&]() -> int {
   if (!ix || !out) return VT_ERR_ARGUMENT;
   std::lock_guard<std::mutex> g(ix->mu);
   *out = ix->ctx.prof;
   if (reset) ix->ctx.prof = vt_profile{};
   return VT_OK;
+  });
 }
 
 }  // extern "C"
