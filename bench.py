@@ -280,14 +280,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_dist:
+        search = lambda q: sharded.search(q, a.limit)  # noqa: E731
+    else:
+        # one rank, no exchange: the step is the C-ABI call itself (the hit list is
+        # freed, not unpacked into Python objects -- a NIF would build BEAM terms here)
+        L = _lib.load()
+        hp = C.c_void_p()
+
+        def search(q):
+            st = L.vt_flat_search(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), a.dim, a.limit, C.byref(hp))
+            assert st == 0, st
+            n_hits = L.vt_hits_len(hp)
+            L.vt_hits_free(hp)
+            return range(n_hits)
+
     for i in range(a.warmup):
-        sharded.search(qs[i], a.limit)
+        search(qs[i])
     nifs.flat_set_profiling(ref, True)
     nifs.flat_get_profile(ref, reset=True)
     sync()
     t0 = time.perf_counter()
     for i in range(a.warmup, nq):
-        hits = sharded.search(qs[i], a.limit)
+        hits = search(qs[i])
     sync()
     dt = time.perf_counter() - t0
     prof = nifs.flat_get_profile(ref, reset=True)

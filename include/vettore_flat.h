@@ -90,6 +90,12 @@ float vt_hits_raw(const vt_hits *hits, size_t i);
  * u32 (distances.rs:113-119, flat.rs:34-40): what a multi-shard merge compares
  * before falling back to the id bytes. */
 uint32_t vt_hits_rank_key(const vt_hits *hits, size_t i);
+/* Serialises up to `cap` hits as fixed 64-byte records -- u32 rank_key, f32 raw,
+ * u32 id_len, then the first 52 id bytes (zero padded) -- the wire format of the
+ * cross-shard merge.  Returns the number of records written. */
+#define VT_HIT_RECORD_BYTES 64
+#define VT_HIT_RECORD_ID_BYTES 52
+size_t vt_hits_pack(const vt_hits *hits, void *records, size_t cap);
 void vt_hits_free(vt_hits *hits);
 
 /* ----------------------------------------------------------- flat index

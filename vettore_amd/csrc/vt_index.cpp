@@ -1019,6 +1019,20 @@ const char *vt_hits_id(const vt_hits *h, size_t i, size_t *len) {
 }
 float vt_hits_raw(const vt_hits *h, size_t i) { return h->raw[i]; }
 uint32_t vt_hits_rank_key(const vt_hits *h, size_t i) { return h->rank_key[i]; }
+size_t vt_hits_pack(const vt_hits *h, void *records, size_t cap) {
+  if (!h || !records) return 0;
+  const size_t n = std::min(cap, h->ids.size());
+  unsigned char *out = static_cast<unsigned char *>(records);
+  for (size_t i = 0; i < n; ++i, out += VT_HIT_RECORD_BYTES) {
+    const uint32_t len = (uint32_t)h->ids[i].size();
+    std::memset(out, 0, VT_HIT_RECORD_BYTES);
+    std::memcpy(out, &h->rank_key[i], 4);
+    std::memcpy(out + 4, &h->raw[i], 4);
+    std::memcpy(out + 8, &len, 4);
+    std::memcpy(out + 12, h->ids[i].data(), std::min<size_t>(len, VT_HIT_RECORD_ID_BYTES));
+  }
+  return n;
+}
 void vt_hits_free(vt_hits *h) { delete h; }
 
 int vt_flat_new(int metric_code, int device, vt_flat **out) {

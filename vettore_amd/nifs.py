@@ -215,6 +215,40 @@ def flat_search_batch(index: FlatRef, queries, limit: int):
     return ("ok", [_take_hits(C.c_void_p(outs[i])) for i in range(nq)])
 
 
+def flat_search_packed(index: FlatRef, query, limit: int, records: np.ndarray):
+    """flat_search whose hits land as 64-byte wire records (vt_hits_pack) in the
+    caller's uint8 array [>= limit][64]; returns ("ok", (count, any_long_id)) with
+    one C call for the search and one for the serialisation."""
+    q = _f32_list(query)
+    L = _lib.load()
+    h = C.c_void_p()
+    st = L.vt_flat_search(index.handle, _fp(q), q.size, limit, C.byref(h))
+    if st != 0:
+        return _err(st)
+    try:
+        cap = records.shape[0]
+        n = L.vt_hits_pack(h, records.ctypes.data_as(C.c_void_p), cap)
+        lens = records[:n, 8:12].view(np.uint32).reshape(-1)
+        long_ids = None
+        if n and int(lens.max()) > 52:  # ids that do not fit a record travel separately
+            ln = C.c_size_t()
+            long_ids = [C.string_at(L.vt_hits_id(h, i, C.byref(ln)), ln.value) for i in range(n)]
+    finally:
+        L.vt_hits_free(h)
+    return ("ok", (int(n), long_ids))
+
+
+def unpack_records(records: np.ndarray, count: int):
+    """[(id, raw, rank_key)] from `count` wire records (ids longer than 52 bytes come back as None)."""
+    out = []
+    for i in range(count):
+        rec = records[i]
+        w = rec[:12].view(np.uint32)
+        n = int(w[2])
+        out.append((bytes(rec[12:12 + n]) if n <= 52 else None, float(rec[4:8].view(np.float32)[0]), int(w[0])))
+    return out
+
+
 def flat_search_with_keys(index: FlatRef, query, limit: int):
     """flat_search plus each hit's rank sort key (for cross-shard merges)."""
     q = _f32_list(query)

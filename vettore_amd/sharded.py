@@ -73,6 +73,7 @@ class ShardedFlat:
         self.rank = dist.get_rank() if dist is not None else 0
         self._local = local_search
         self._torch = None
+        self._bufs = {}
         if dist is not None:
             import torch
             self._torch = torch
@@ -86,24 +87,51 @@ class ShardedFlat:
             raise RuntimeError(res[1])
         return res[1]
 
+    def _buffers(self, limit):
+        """Per-limit exchange buffers: a pinned host send block and the gathered block."""
+        buf = self._bufs.get(limit)
+        if buf is None:
+            torch = self._torch
+            on_gpu = self.device is not None and getattr(self.device, "type", "cpu") != "cpu"
+            send_host = torch.zeros(((limit + 1), REC), dtype=torch.uint8)
+            if on_gpu:
+                send_host = send_host.pin_memory()
+            send_dev = torch.empty_like(send_host, device=self.device) if on_gpu else send_host
+            gathered = torch.empty(self.world * (limit + 1) * REC, dtype=torch.uint8, device=send_dev.device)
+            buf = self._bufs[limit] = (send_host, send_host.numpy(), send_dev, gathered, on_gpu)
+        return buf
+
     def search(self, query, limit: int) -> List[Tuple[bytes, float]]:
-        hits = self._local_search(query, limit)
         if self.dist is None or (self.world == 1 and not self.force_exchange):
-            return [(h[0], h[1]) for h in hits]
-        torch = self._torch
-        mine = torch.from_numpy(pack_hits(hits, limit))
-        if self.device is not None and getattr(self.device, "type", "cpu") != "cpu":
-            mine = mine.to(self.device, non_blocking=True)
-        gathered = torch.empty(self.world * mine.numel(), dtype=torch.uint8, device=mine.device)
-        self.dist.all_gather_into_tensor(gathered, mine)
+            return [(h[0], h[1]) for h in self._local_search(query, limit)]
+        send_host, send_np, send_dev, gathered, on_gpu = self._buffers(limit)
+        long_ids = None
+        if self._local is None:
+            # the library serialises its hits straight into the pinned send block
+            from . import nifs
+            res = nifs.flat_search_packed(self.ref, query, limit, send_np[1:])
+            if res[0] != "ok":
+                raise RuntimeError(res[1])
+            count, long_ids = res[1]
+            head = send_np[0].view(np.uint32)
+            head[0] = count
+            head[1] = 1 if long_ids is not None else 0
+        else:
+            hits = self._local(query, limit)
+            send_np[:] = pack_hits(hits, limit).reshape(limit + 1, REC)
+            if any(len(h[0]) > MAX_ID for h in hits):
+                long_ids = [h[0] for h in hits]
+        if on_gpu:
+            send_dev.copy_(send_host, non_blocking=True)
+        self.dist.all_gather_into_tensor(gathered, send_dev.reshape(-1))
         host = gathered.cpu().numpy().reshape(self.world, -1)
-        per_rank, long_ids = [], False
+        per_rank, any_long = [], False
         for r in range(self.world):
             h, flag = unpack_hits(host[r], limit)
             per_rank.append(h)
-            long_ids |= flag
-        if long_ids:  # ids longer than MAX_ID bytes: second exchange carries them whole
+            any_long |= flag
+        if any_long:  # ids longer than MAX_ID bytes: second exchange carries them whole
             objs = [None] * self.world
-            self.dist.all_gather_object(objs, [h[0] for h in hits])
+            self.dist.all_gather_object(objs, long_ids if long_ids is not None else [h[0] for h in per_rank[self.rank]])
             per_rank = [[(objs[r][i], h[1], h[2]) for i, h in enumerate(per_rank[r])] for r in range(self.world)]
         return merge_shards(per_rank, limit)
