@@ -28,6 +28,8 @@
 // candidates.
 #include "vt_common.cuh"
 
+#include <cstdlib>
+
 namespace vt {
 
 using namespace dev;
@@ -36,8 +38,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kRowWaves = 4;           // row groups (of 32 rows) per block
-constexpr int kBRows = kRowWaves * 32;  // rows per block tile
+constexpr int kRowWaves = 4;  // waves per block, each owning RT * 32 rows of the block's tile
 constexpr int kQStride = 32;        // LDS floats per query row of a 32-k chunk (linear, swizzled slots)
 
 // Cold path of the epilogue: some score of this lane's 16 (one query column, 16
@@ -60,96 +61,98 @@ __device__ __noinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v
   }
 }
 
-// NT: 32-query tiles in the batch; QSPLIT: waves sharing a row group, each taking
-// NT / QSPLIT of the query tiles (keeps a wave under 256 registers so two waves
-// fit a SIMD and cover each other's LDS / barrier waits).
-template <int NT, int QSPLIT, bool DENSE>
-__global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(const BatchScoreArgs a) {
-  extern __shared__ __align__(16) float qlds[];  // [3][NT*32][32] queries, then [3][waves*32][32] rows
-  constexpr int kBWaves = kRowWaves * QSPLIT;
-  constexpr int NTW = NT / QSPLIT;  // query tiles per wave
+// NT: 32-query tiles in the batch (a wave covers them all); RT: 32-row groups per
+// wave (RT = 2: 64 rows x 256 queries = 256 accumulator registers, 256 MFMAs per
+// barrier); NS: LDS stages (the DMA runs NS - 1 chunks ahead of the MFMAs).
+template <int NT, int RT, int NS, bool DENSE>
+__global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const BatchScoreArgs a) {
+  extern __shared__ __align__(16) float qlds[];  // [NS][NT*32][32] queries, then [NS][4 waves][RT*32][32] rows
+  constexpr int NQ = NT * 32;
+  constexpr int kWaveRows = RT * 32;
+  constexpr int kTileRowsB = kRowWaves * kWaveRows;
   const int lane = threadIdx.x & (kWave - 1);
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wib = wid % kRowWaves;      // row group of this wave
-  const int qpart = wid / kRowWaves;    // which share of the query tiles
   const int r = lane & 31, h = lane >> 5;
-  constexpr int NQ = NT * 32;
   const uint32_t nchunk = a.ld / 32;
-  const uint32_t ntiles = (a.n + kBRows - 1) / kBRows;
+  const uint32_t ntiles = (a.n + kTileRowsB - 1) / kTileRowsB;
 
-  // thresholds of the 8 query columns this lane sees (column = 32*t + r)
-  float tau[NTW];
+  // thresholds of the query columns this lane sees (column = 32*t + r)
+  float tau[NT];
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) tau[t] = DENSE ? 0.f : a.tau[(qpart * NTW + t) * 32 + r];
+  for (int t = 0; t < NT; ++t) tau[t] = DENSE ? 0.f : a.tau[t * 32 + r];
 
   // Staging by LDS-DMA: one wave instruction fills 8 rows (1 KiB); lane L lands
   // in row L/8, physical slot L%8 and fetches logical slot (L%8) ^ ((row >> 1) & 7)
   // of that row.  Per-lane source pointers are set up once and advanced by the
   // chunk; the pieces are issued one at a time so they can be spread between
   // the MFMAs of a chunk.
-  constexpr int kDmaPerWave = NQ / 8 / kBWaves;  // Q pieces per wave per chunk
-  static_assert(kDmaPerWave * 8 * kBWaves == NQ, "query rows split evenly over the waves");
+  constexpr int kDmaQ = NQ / 8 / kRowWaves;  // Q pieces per wave per chunk
+  constexpr int kDmaX = RT * 4;              // X pieces per wave per chunk
+  static_assert(kDmaQ * 8 * kRowWaves == NQ, "query rows split evenly over the waves");
+  constexpr int kDmaPerChunk = kDmaQ + kDmaX;
   // physical 16-B slot of logical slot s in row q
   auto qslot = [&](uint32_t q, uint32_t s) { return s ^ ((q >> 1) & 7); };
-  const float *qsrc[kDmaPerWave];
+  const float *qsrc[kDmaQ];
 #pragma unroll
-  for (int i = 0; i < kDmaPerWave; ++i) {
-    const uint32_t qrow = (uint32_t)(wid * kDmaPerWave + i) * 8 + (lane >> 3);
+  for (int i = 0; i < kDmaQ; ++i) {
+    const uint32_t qrow = (uint32_t)(wid * kDmaQ + i) * 8 + (lane >> 3);
     qsrc[i] = a.Q + (size_t)qrow * a.ld + qslot(qrow, lane & 7) * 4;
   }
-  auto dma_q = [&](int i, uint32_t c, int buf) {
-    float *dst = qlds + buf * (NQ * kQStride) + (wid * kDmaPerWave + i) * 8 * kQStride;
+  auto dma_q = [&](int i, uint32_t c, int stage) {
+    float *dst = qlds + stage * (NQ * kQStride) + (wid * kDmaQ + i) * 8 * kQStride;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qsrc[i] + c * 32),
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
   };
-  // this wave's 32 X rows: 4 pieces of 8 whole lines each
-  float *xlds = qlds + 3 * (NQ * kQStride) + wid * (32 * kQStride);
-  const float *xsrc[4];
-  auto dma_x = [&](int i, uint32_t c, int buf) {
-    float *dst = xlds + buf * (kBWaves * 32 * kQStride) + i * 8 * kQStride;
+  // this wave's RT*32 X rows: RT*4 pieces of 8 whole lines each
+  float *xlds = qlds + NS * (NQ * kQStride) + wid * (kWaveRows * kQStride);
+  const float *xsrc[kDmaX];
+  auto dma_x = [&](int i, uint32_t c, int stage) {
+    float *dst = xlds + stage * (kRowWaves * kWaveRows * kQStride) + i * 8 * kQStride;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xsrc[i] + c * 32),
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
   };
   // all of a chunk's pieces, or the share that goes with step j of the MFMA loop
-  auto dma_chunk = [&](uint32_t c, int buf) {
+  auto dma_chunk = [&](uint32_t c, int stage) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_x(i, c, buf);
+    for (int i = 0; i < kDmaX; ++i) dma_x(i, c, stage);
 #pragma unroll
-    for (int i = 0; i < kDmaPerWave; ++i) dma_q(i, c, buf);
+    for (int i = 0; i < kDmaQ; ++i) dma_q(i, c, stage);
   };
-  auto dma_step = [&](int j, uint32_t c, int buf) {
-    dma_x(j, c, buf);
+  auto dma_step = [&](int j, uint32_t c, int stage) {
 #pragma unroll
-    for (int i = 0; i < kDmaPerWave; ++i)
-      if (i % 4 == j) dma_q(i, c, buf);
+    for (int i = 0; i < kDmaX; ++i)
+      if (i % 4 == j) dma_x(i, c, stage);
+#pragma unroll
+    for (int i = 0; i < kDmaQ; ++i)
+      if (i % 4 == j) dma_q(i, c, stage);
   };
 
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // DENSE (pass 0) visits a strided sample of the tiles
     const uint32_t rtile = DENSE ? tile * a.sample_stride : tile;
-    const uint32_t row0 = rtile * kBRows + wib * 32;
+    const uint32_t row0 = rtile * kTileRowsB + wid * kWaveRows;
     // rows past the end are clamped for the load and masked in the epilogue
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t xr = (uint32_t)i * 8 + (lane >> 3);  // row within the wave's 32
+    for (int i = 0; i < kDmaX; ++i) {
+      const uint32_t xr = (uint32_t)i * 8 + (lane >> 3);  // row within the wave's rows
       uint32_t grow = row0 + xr;
       grow = grow < a.n_total ? grow : a.n_total - 1;
       xsrc[i] = a.X + (size_t)grow * a.stride + qslot(xr, lane & 7) * 4;
     }
 
-    f32x16 acc[NTW];
+    f32x16 acc[RT][NT];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t)
+    for (int g = 0; g < RT; ++g)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[g][t][i] = 0.f;
 
-    // Three LDS stages: the DMA runs two chunks ahead of the MFMAs, so an HBM
-    // round trip has ~2 chunk times to land.  Raw s_barrier + counted vmcnt: a
-    // __syncthreads() would drain the DMA that is meant to stay in flight.
-    constexpr int kDmaPerChunk = kDmaPerWave + 4;  // this wave's DMA instructions per chunk
+    // NS LDS stages, DMA NS-1 chunks ahead of the MFMAs.  Raw s_barrier + counted
+    // vmcnt: a __syncthreads() would drain the DMA that is meant to stay in flight.
     __builtin_amdgcn_s_barrier();  // every wave is done reading the previous tile's stages
     dma_chunk(0, 0);
-    if (nchunk > 1) {
+    if (NS == 3 && nchunk > 1) {
       dma_chunk(1, 1);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerChunk) : "memory");
     } else {
@@ -157,81 +160,90 @@ __global__ __launch_bounds__(kRowWaves *QSPLIT *kWave) void mfma_scores_kernel(c
     }
     __builtin_amdgcn_s_barrier();
 
-    int buf = 0;
+    int stage = 0;
     for (uint32_t c = 0; c < nchunk; ++c) {
-      const int buf2 = buf == 0 ? 2 : buf - 1;  // stage of chunk c + 2 == stage read in iteration c - 1
-      const bool ahead2 = c + 2 < nchunk;
-      const float *xb = xlds + buf * (kBWaves * 32 * kQStride) + r * kQStride;
+      const int stage_a = (stage + NS - 1) % NS;  // stage of chunk c + NS - 1 == the one read in iteration c - 1
+      const bool ahead = c + (NS - 1) < nchunk;
+      const float *xb = xlds + stage * (kRowWaves * kWaveRows * kQStride) + r * kQStride;
       // the swizzle depends only on r (tile bases are multiples of 32 rows), so the
       // per-tile address is a constant offset from four per-lane bases
-      const float *qb = qlds + buf * (NQ * kQStride) + (qpart * NTW * 32 + r) * kQStride;
+      const float *qb = qlds + stage * (NQ * kQStride) + r * kQStride;
       // software pipeline over the four 8-k steps: fragments of step j+1 are read
       // and a quarter of the next DMA is issued while step j's MFMAs run
-      f32x4 xa, qv[NTW], xa_n, qv_n[NTW];
+      f32x4 xa[RT], qv[NT], xa_n[RT], qv_n[NT];
       {
         const uint32_t so = qslot(r, 4 * h) * 4;
-        xa = *reinterpret_cast<const f32x4 *>(xb + so);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) qv[t] = *reinterpret_cast<const f32x4 *>(qb + so + t * 32 * kQStride);
+        for (int g = 0; g < RT; ++g) xa[g] = *reinterpret_cast<const f32x4 *>(xb + so + g * 32 * kQStride);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) qv[t] = *reinterpret_cast<const f32x4 *>(qb + so + t * 32 * kQStride);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (j < 3) {
           const uint32_t so = qslot(r, 4 * h + j + 1) * 4;
-          xa_n = *reinterpret_cast<const f32x4 *>(xb + so);
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) qv_n[t] = *reinterpret_cast<const f32x4 *>(qb + so + t * 32 * kQStride);
+          for (int g = 0; g < RT; ++g) xa_n[g] = *reinterpret_cast<const f32x4 *>(xb + so + g * 32 * kQStride);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) qv_n[t] = *reinterpret_cast<const f32x4 *>(qb + so + t * 32 * kQStride);
         }
-        if (ahead2) dma_step(j, c + 2, buf2);
+        if (ahead) dma_step(j, c + (NS - 1), stage_a);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
-          for (int t = 0; t < NTW; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], qv[t][e], acc[t], 0, 0, 0);
+          for (int g = 0; g < RT; ++g)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              acc[g][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[g][e], qv[t][e], acc[g][t], 0, 0, 0);
         }
         if (j < 3) {
-          xa = xa_n;
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) qv[t] = qv_n[t];
+          for (int g = 0; g < RT; ++g) xa[g] = xa_n[g];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) qv[t] = qv_n[t];
         }
       }
       // chunk c + 1 must have landed for everyone before anyone reads it
-      if (ahead2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerChunk) : "memory");
+      if (NS == 3 && ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerChunk) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      buf = buf == 2 ? 0 : buf + 1;
+      stage = stage == NS - 1 ? 0 : stage + 1;
     }
 
     // epilogue: C layout of 32x32: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
-    if (a.xnorm2) {
-      // L2 family: rank by s = 2 q.x - |x|^2 (larger s <=> smaller |q - x|^2)
-      float xn[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const uint32_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        xn[i] = a.xnorm2[row < a.n_total ? row : a.n_total - 1];
-      }
-#pragma unroll
-      for (int t = 0; t < NTW; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 2.0f * acc[t][i] - xn[i];
-    }
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const uint32_t qcol = (qpart * NTW + t) * 32 + r;
-      if (DENSE) {
+    for (int g = 0; g < RT; ++g) {
+      const uint32_t grow0 = row0 + g * 32;
+      if (a.xnorm2) {
+        // L2 family: rank by s = 2 q.x - |x|^2 (larger s <=> smaller |q - x|^2)
+        float xn[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const uint32_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          // dense sample matrix [query][sample row]
-          const uint32_t srow = tile * kBRows + wib * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          a.sample[(size_t)qcol * a.sample_rows + srow] = row < a.n_total ? acc[t][i] : -INFINITY;
+          const uint32_t row = grow0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          xn[i] = a.xnorm2[row < a.n_total ? row : a.n_total - 1];
         }
-      } else {
-        float mx = acc[t][0];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, acc[t][i]);
-        if (mx >= tau[t]) append_candidates(a, acc[t], tau[t], qcol, row0, h);
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[g][t][i] = 2.0f * acc[g][t][i] - xn[i];
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const uint32_t qcol = t * 32 + r;
+        if (DENSE) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const uint32_t off = (i & 3) + 8 * (i >> 2) + 4 * h;
+            // dense sample matrix [query][sample row]
+            const uint32_t srow = tile * kTileRowsB + wid * kWaveRows + g * 32 + off;
+            a.sample[(size_t)qcol * a.sample_rows + srow] = grow0 + off < a.n_total ? acc[g][t][i] : -INFINITY;
+          }
+        } else {
+          float mx = acc[g][t][0];
+#pragma unroll
+          for (int i = 1; i < 16; ++i) mx = fmaxf(mx, acc[g][t][i]);
+          if (mx >= tau[t]) append_candidates(a, acc[g][t], tau[t], qcol, grow0, h);
+        }
       }
     }
   }
@@ -338,18 +350,18 @@ __global__ __launch_bounds__(256) void batch_select_kernel(const uint64_t *__res
   if (threadIdx.x == 0) out_count[blockIdx.x] = s_live < k ? s_live : k;
 }
 
-template <int NT, int QSPLIT>
+template <int NT, int RT, int NS>
 hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
-  const size_t lds = (size_t)3 * (NT * 32 + kRowWaves * QSPLIT * 32) * kQStride * sizeof(float);
-  const dim3 block(kRowWaves * QSPLIT * kWave);
+  const size_t lds = (size_t)NS * (NT * 32 + kRowWaves * RT * 32) * kQStride * sizeof(float);
+  const dim3 block(kRowWaves * kWave);
   if (dense) {
-    auto kern = mfma_scores_kernel<NT, QSPLIT, true>;
+    auto kern = mfma_scores_kernel<NT, RT, NS, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
   } else {
-    auto kern = mfma_scores_kernel<NT, QSPLIT, false>;
+    auto kern = mfma_scores_kernel<NT, RT, NS, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
@@ -358,17 +370,23 @@ hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks
   return hipGetLastError();
 }
 
+bool batch_wide() {
+  static const bool narrow = std::getenv("VT_BATCH_RT1") != nullptr;  // A/B switch: 32 rows per wave, 3 stages
+  return !narrow;
+}
+
 }  // namespace
 
-uint32_t batch_rows_per_block() { return kBRows; }
+uint32_t batch_rows_per_block() { return kRowWaves * 32 * (batch_wide() ? 2 : 1); }
 
 hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
   if (a.ld % 32 != 0 || a.nq_pad % 32 != 0 || a.nq_pad == 0 || a.nq_pad > 256) return hipErrorInvalidValue;
+  const bool wide = batch_wide();
   switch (a.nq_pad / 32) {
-    case 1: return launch_scores_nt<1, 1>(a, dense, blocks, s);
-    case 2: return launch_scores_nt<2, 1>(a, dense, blocks, s);
-    case 4: return launch_scores_nt<4, 1>(a, dense, blocks, s);
-    case 8: return launch_scores_nt<8, 1>(a, dense, blocks, s);
+    case 1: return wide ? launch_scores_nt<1, 2, 2>(a, dense, blocks, s) : launch_scores_nt<1, 1, 3>(a, dense, blocks, s);
+    case 2: return wide ? launch_scores_nt<2, 2, 2>(a, dense, blocks, s) : launch_scores_nt<2, 1, 3>(a, dense, blocks, s);
+    case 4: return wide ? launch_scores_nt<4, 2, 2>(a, dense, blocks, s) : launch_scores_nt<4, 1, 3>(a, dense, blocks, s);
+    case 8: return wide ? launch_scores_nt<8, 2, 2>(a, dense, blocks, s) : launch_scores_nt<8, 1, 3>(a, dense, blocks, s);
     default: return hipErrorInvalidValue;
   }
 }
