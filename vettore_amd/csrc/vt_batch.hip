@@ -118,13 +118,18 @@ __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const Bat
 #pragma unroll
     for (int i = 0; i < kDmaQ; ++i) dma_q(i, c, stage);
   };
+  // With two stages the chunk must land within the iteration that issues it, so
+  // its pieces go out with the first two steps; with three stages they spread
+  // over all four.
+  constexpr int kDmaSteps = NS == 2 ? 2 : 4;
   auto dma_step = [&](int j, uint32_t c, int stage) {
+    if (j >= kDmaSteps) return;
 #pragma unroll
     for (int i = 0; i < kDmaX; ++i)
-      if (i % 4 == j) dma_x(i, c, stage);
+      if (i % kDmaSteps == j) dma_x(i, c, stage);
 #pragma unroll
     for (int i = 0; i < kDmaQ; ++i)
-      if (i % 4 == j) dma_q(i, c, stage);
+      if (i % kDmaSteps == j) dma_q(i, c, stage);
   };
 
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -168,24 +173,26 @@ __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const Bat
       // the swizzle depends only on r (tile bases are multiples of 32 rows), so the
       // per-tile address is a constant offset from four per-lane bases
       const float *qb = qlds + stage * (NQ * kQStride) + r * kQStride;
-      // software pipeline over the four 8-k steps: fragments of step j+1 are read
-      // and a quarter of the next DMA is issued while step j's MFMAs run
-      f32x4 xa[RT], qv[NT], xa_n[RT], qv_n[NT];
-      {
-        const uint32_t so = qslot(r, 4 * h) * 4;
+      // software pipeline over the four 8-k steps (RT == 1): fragments of step j+1
+      // are read while step j's MFMAs run; with 64 rows per wave the accumulators
+      // already take half the register file, so the fragments are read per step
+      // (there are twice as many MFMAs per read to hide them behind).
+      constexpr bool kPipe = RT == 1;
+      f32x4 xa[RT], qv[NT], xa_n[kPipe ? RT : 1], qv_n[kPipe ? NT : 1];
+      auto read_frags = [&](int j, f32x4 *xd, f32x4 *qd) {
+        const uint32_t so = qslot(r, 4 * h + j) * 4;
 #pragma unroll
-        for (int g = 0; g < RT; ++g) xa[g] = *reinterpret_cast<const f32x4 *>(xb + so + g * 32 * kQStride);
+        for (int g = 0; g < RT; ++g) xd[g] = *reinterpret_cast<const f32x4 *>(xb + so + g * 32 * kQStride);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) qv[t] = *reinterpret_cast<const f32x4 *>(qb + so + t * 32 * kQStride);
-      }
+        for (int t = 0; t < NT; ++t) qd[t] = *reinterpret_cast<const f32x4 *>(qb + so + t * 32 * kQStride);
+      };
+      if (kPipe) read_frags(0, xa, qv);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (j < 3) {
-          const uint32_t so = qslot(r, 4 * h + j + 1) * 4;
-#pragma unroll
-          for (int g = 0; g < RT; ++g) xa_n[g] = *reinterpret_cast<const f32x4 *>(xb + so + g * 32 * kQStride);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) qv_n[t] = *reinterpret_cast<const f32x4 *>(qb + so + t * 32 * kQStride);
+        if (kPipe) {
+          if (j < 3) read_frags(j + 1, xa_n, qv_n);
+        } else {
+          read_frags(j, xa, qv);
         }
         if (ahead) dma_step(j, c + (NS - 1), stage_a);
 #pragma unroll
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const Bat
             for (int t = 0; t < NT; ++t)
               acc[g][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[g][e], qv[t][e], acc[g][t], 0, 0, 0);
         }
-        if (j < 3) {
+        if (kPipe && j < 3) {
 #pragma unroll
           for (int g = 0; g < RT; ++g) xa[g] = xa_n[g];
 #pragma unroll
@@ -210,39 +217,41 @@ __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const Bat
       stage = stage == NS - 1 ? 0 : stage + 1;
     }
 
-    // epilogue: C layout of 32x32: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+    // epilogue, one 32x32 tile at a time (C layout: column = lane & 31,
+    // row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5))
 #pragma unroll
     for (int g = 0; g < RT; ++g) {
       const uint32_t grow0 = row0 + g * 32;
+      float xn[16];
       if (a.xnorm2) {
-        // L2 family: rank by s = 2 q.x - |x|^2 (larger s <=> smaller |q - x|^2)
-        float xn[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const uint32_t row = grow0 + (i & 3) + 8 * (i >> 2) + 4 * h;
           xn[i] = a.xnorm2[row < a.n_total ? row : a.n_total - 1];
         }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[g][t][i] = 2.0f * acc[g][t][i] - xn[i];
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const uint32_t qcol = t * 32 + r;
+        f32x16 v = acc[g][t];
+        if (a.xnorm2) {
+          // L2 family: rank by s = 2 q.x - |x|^2 (larger s <=> smaller |q - x|^2)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = 2.0f * v[i] - xn[i];
+        }
         if (DENSE) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const uint32_t off = (i & 3) + 8 * (i >> 2) + 4 * h;
             // dense sample matrix [query][sample row]
             const uint32_t srow = tile * kTileRowsB + wid * kWaveRows + g * 32 + off;
-            a.sample[(size_t)qcol * a.sample_rows + srow] = grow0 + off < a.n_total ? acc[g][t][i] : -INFINITY;
+            a.sample[(size_t)qcol * a.sample_rows + srow] = grow0 + off < a.n_total ? v[i] : -INFINITY;
           }
         } else {
-          float mx = acc[g][t][0];
+          float mx = v[0];
 #pragma unroll
-          for (int i = 1; i < 16; ++i) mx = fmaxf(mx, acc[g][t][i]);
-          if (mx >= tau[t]) append_candidates(a, acc[g][t], tau[t], qcol, grow0, h);
+          for (int i = 1; i < 16; ++i) mx = fmaxf(mx, v[i]);
+          if (mx >= tau[t]) append_candidates(a, v, tau[t], qcol, grow0, h);
         }
       }
     }
