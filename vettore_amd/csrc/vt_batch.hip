@@ -379,9 +379,12 @@ hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks
   return hipGetLastError();
 }
 
+// 32 rows per wave with three stages measured 118 TF against 106 TF for 64 rows
+// per wave with two (N=2M, B=256): the wide tile has no registers left to
+// pipeline its fragment reads.  VT_BATCH_WIDE=1 selects it for experiments.
 bool batch_wide() {
-  static const bool narrow = std::getenv("VT_BATCH_RT1") != nullptr;  // A/B switch: 32 rows per wave, 3 stages
-  return !narrow;
+  static const bool wide = std::getenv("VT_BATCH_WIDE") != nullptr;
+  return wide;
 }
 
 }  // namespace
