@@ -345,7 +345,7 @@ def test_random_parity_all_metrics(nifs, oracle_mod, d, order):
         oracle_mod.set_reduce_order(0)
 
 
-@pytest.mark.parametrize("d", [1024, 1536, 1540, 3072, 4100])
+@pytest.mark.parametrize("d", [1024, 1536, 1540, 3072, 4100, 8192])
 def test_wide_rows_use_column_panels(nifs, oracle_mod, d):
     """Rows wider than one LDS panel (96 chunks) are walked in column panels with
     the running sum carried across them; the tail chunk lands in the last one."""
@@ -357,7 +357,7 @@ def test_wide_rows_use_column_panels(nifs, oracle_mod, d):
     for order in ORDERS:
         oracle_mod.set_reduce_order(order)
         try:
-            for m in (0, 2, 3, 5, 6, 7):
+            for m in ((0, 2, 3, 5, 6, 7) if d < 8192 else (2, 0)):
                 g = GpuIndex(nifs, m, order)
                 unwrap(nifs.flat_load_matrix(g.ref, ids, x))
                 for k in (10, 100):

@@ -150,6 +150,7 @@ struct Ctx {
   int device = 0;
   int num_cus = 256;
   int blocks_per_cu = 2;
+  int hamming_blocks_per_cu = 2;
   hipStream_t stream = nullptr;
   DevBuf<float> dQ;
   DevBuf<uint64_t> dQbits;
@@ -197,6 +198,10 @@ struct Ctx {
     hipDeviceProp_t prop;
     VT_HIP(hipGetDeviceProperties(&prop, dev));
     num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = std::getenv("VT_HAMMING_BLOCKS_PER_CU")) {
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 8) hamming_blocks_per_cu = v;
+    }
     if (const char *e = std::getenv("VT_BLOCKS_PER_CU")) {
       const int v = std::atoi(e);
       if (v >= 1 && v <= 8) blocks_per_cu = v;
@@ -219,9 +224,9 @@ struct Ctx {
   }
   // Tiles are dealt to waves statically, so the grid must be fully resident:
   // blocks per CU = what LDS admits, capped (VT_BLOCKS_PER_CU overrides).
-  uint32_t grid_for(uint32_t units, size_t lds_bytes) const {
+  uint32_t grid_for(uint32_t units, size_t lds_bytes, int max_per_cu = 0) const {
     size_t per_cu = lds_bytes ? (160 * 1024) / lds_bytes : 8;
-    per_cu = std::max<size_t>(1, std::min<size_t>(per_cu, (size_t)blocks_per_cu));
+    per_cu = std::max<size_t>(1, std::min<size_t>(per_cu, (size_t)(max_per_cu > 0 ? max_per_cu : blocks_per_cu)));
     const uint32_t want = (units + vt::kWavesPerBlock - 1) / vt::kWavesPerBlock;
     return std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)(num_cus * per_cu)));
   }
@@ -378,7 +383,7 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
   const size_t total = std::min<size_t>(want, n);
   while (out.size() < total) {
     const uint32_t k = (uint32_t)std::min<size_t>((size_t)vt::kMaxFusedK, total - out.size());
-    const uint32_t blocks = c.grid_for(ntiles, vt::hamming_lds_bytes(k));
+    const uint32_t blocks = c.grid_for(ntiles, vt::hamming_lds_bytes(k), c.hamming_blocks_per_cu);
     const uint32_t waves = vt::scan_lists(blocks);
     VT_TRY(c.dPartKeys.ensure((size_t)waves * k));
     VT_TRY(c.dPartPay.ensure((size_t)waves * k));
@@ -1252,7 +1257,7 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
     // stage 1 stays on the device: hamming scan -> select into a device block
     // whose Entry.row column is the gather list of stage 2 (no host round trip)
     const uint32_t k1 = (uint32_t)ncand;
-    const uint32_t blocks = c.grid_for((ix->n + 63) / 64, vt::hamming_lds_bytes(k1));
+    const uint32_t blocks = c.grid_for((ix->n + 63) / 64, vt::hamming_lds_bytes(k1), c.hamming_blocks_per_cu);
     const uint32_t waves = vt::scan_lists(blocks);
     VT_TRY(c.dPartKeys.ensure((size_t)waves * k1));
     VT_TRY(c.dPartPay.ensure((size_t)waves * k1));
