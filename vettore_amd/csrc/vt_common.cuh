@@ -58,27 +58,6 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    uint64_t t = __shfl_xor(v, o, kWave);
-    v = t > v ? t : v;
-  }
-  return v;
-}
-
-__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
-  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-  uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
-  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src);
-  uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
-  return ((uint64_t)hi << 32) | lo;
-}
-
 // Wave-private candidate buffer in LDS holding (at least) the k smallest keys
 // seen so far: keys[CAP] + payload[CAP], k + 64 <= CAP.
 //  * `thr` (wave-uniform) is an upper bound: only keys < thr can still be among
