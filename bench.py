@@ -266,6 +266,9 @@ def main():
     del x
     torch.cuda.empty_cache()
     sharded = ShardedFlat(ref, dist if use_dist else None, device, force_exchange=a.force_exchange)
+    if use_dist and os.environ.get("VT_HOST_EXCHANGE") is None:
+        # one ordering of all ids -> shard keys compare on the device (see vettore_amd/sharded.py)
+        sharded.enable_device_exchange(ids, max_limit=max(a.limit, 16))
 
     qrng = np.random.default_rng(SEED_QUERY)
     nq = a.steps + a.warmup
@@ -334,7 +337,8 @@ def main():
                 "workload": "index: :flat, metric: :cosine, d=%d, N=%d, limit=%d, single query in flight" % (a.dim, a.rows, a.limit),
                 "rows_per_gpu": count,
                 "reduce_order": "pair",
-                "sharding": "row blocks, all_gather of per-shard top-k" if world > 1 else "none",
+                "sharding": ("row blocks, all_gather of per-shard top-k (%s merge)" % ("device" if sharded._dev else "host"))
+                if use_dist else "none",
                 "setup_s": round(t_build, 1),
             },
             "roofline": {

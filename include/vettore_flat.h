@@ -166,6 +166,28 @@ int vt_flat_funnel_search(vt_flat *index, const float *query, size_t n,
                           const size_t *stages, size_t nstages, size_t candidates,
                           size_t limit, vt_hits **out);
 
+/* ---- row-sharded search across GPUs, device-side exchange -----
+ * A shard's candidates are u64 keys (rank key << 32 | id_rank); they compare
+ * across shards iff every shard's id_rank column comes from ONE ordering of all
+ * ids.  vt_rank_ids computes that ordering (bytewise, like FlatHit::cmp,
+ * flat.rs:34-40) for the concatenated ids of all shards; each shard installs its
+ * slice with vt_flat_set_id_ranks (valid until its next mutation).
+ *
+ * Per query: vt_flat_search_begin enqueues upload + scan + select on the index's
+ * stream and returns WITHOUT waiting; the shard's result lands in `device_block`
+ * (device memory, >= 16 + limit * 16 bytes: {i32 status, u32 count, pad[2]} then
+ * `limit` entries {u64 key, u32 row, f32 raw}).  The caller gathers the blocks of
+ * all shards with one collective queued on vt_flat_stream(), then
+ * vt_flat_merge_gathered merges `world` blocks on the device and waits once. */
+int vt_rank_ids(const char *ids, const size_t *id_off, size_t count, uint32_t *out_rank);
+int vt_flat_set_id_ranks(vt_flat *index, const uint32_t *ranks, size_t count);
+void *vt_flat_stream(vt_flat *index); /* hipStream_t */
+int vt_flat_search_begin(vt_flat *index, const float *query, size_t n, size_t limit,
+                         void *device_block);
+int vt_flat_merge_gathered(vt_flat *index, const void *device_blocks, size_t world,
+                           size_t limit, size_t block_bytes, uint64_t *keys,
+                           uint32_t *rows, float *raw, uint32_t *shard, size_t *count);
+
 /* ------------------------------------------------- stateless NIF helpers
  * vector_top_k/5, nifs.rs:151-162 -> search.rs:38-73. */
 int vt_vector_top_k(int device, size_t count, const char *ids,

@@ -564,6 +564,49 @@ def test_batched_search_large_values_fall_back_safely(nifs, oracle_mod):
         assert bits(got[i]) == bits(oracle_mod.matrix_search(3, x, packed, qs[i], 5)), i
 
 
+@pytest.mark.parametrize("metric", [2, 0])
+def test_device_side_shard_merge_equals_single_index(nifs, oracle_mod, metric):
+    """The multi-GPU exchange path on one GPU: 4 row-block shards whose id_rank
+    columns are slices of ONE ordering of all ids (vt_rank_ids), per-shard
+    vt_flat_search_begin into a gathered device buffer, vt_flat_merge_gathered --
+    must equal the oracle over all rows, ties (identical rows across shards)
+    included."""
+    import torch
+    n, d, world = 40_000, 96, 4
+    x, ids = make_corpus(n, d, 900 + metric, metric == 2, oracle_mod, tie_block=0)
+    # identical rows living in different shards: only the global id order can rank them
+    for s in range(world):
+        x[s * (n // world) + 17] = x[5]
+    packed = oracle_mod.pack_ids(ids)
+    ranks = nifs.rank_ids(nifs.pack_ids(ids))
+    per = n // world
+    shards = []
+    for s in range(world):
+        g = GpuIndex(nifs, metric)
+        unwrap(nifs.flat_load_matrix(g.ref, ids[s * per:(s + 1) * per], x[s * per:(s + 1) * per]))
+        assert nifs.flat_set_id_ranks(g.ref, ranks[s * per:(s + 1) * per]) == "ok"
+        shards.append(g)
+    rng = np.random.default_rng(12)
+    bufs = nifs.MergeBuffers()
+    for limit in (10, 64):
+        block_bytes = 16 + limit * 16
+        gathered = torch.zeros(world * block_bytes, dtype=torch.uint8, device="cuda")
+        for qi in range(4):
+            q = x[5] if qi == 0 else rng.uniform(-1, 1, d).astype(np.float32)
+            if metric == 2 and qi:
+                q = oracle_mod.normalize_l2(q)
+            for s, g in enumerate(shards):
+                assert nifs.flat_search_begin(g.ref, q, limit, gathered.data_ptr() + s * block_bytes) == "ok"
+            torch.cuda.synchronize()
+            st, cnt = nifs.flat_merge_gathered(shards[0].ref, gathered.data_ptr(), world, limit, block_bytes, bufs)
+            assert st == "ok" and cnt == limit
+            got = [(ids[int(bufs.shard[i]) * per + int(bufs.rows[i])], float(bufs.raw[i])) for i in range(cnt)]
+            assert bits(got) == bits(oracle_mod.matrix_search(metric, x, packed, q, limit)), (metric, limit, qi)
+    # a mutation invalidates the external ranks; the shard re-ranks locally and still answers alone
+    shards[0].insert("zzz-new", x[0])
+    assert shards[0].search(x[0], 2)[0][1] == shards[0].search(x[0], 2)[1][1]
+
+
 # --------------------------------------------- full-size checks (BASELINE sizes)
 def test_config2_full_size_properties_and_spot_parity(nifs, oracle_mod):
     """BASELINE.json configs[1]: flat cosine, d=768, N=1M, single query.

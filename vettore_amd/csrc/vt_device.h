@@ -136,6 +136,13 @@ struct CosineRerankArgs {
 };
 hipError_t launch_cosine_rerank(const CosineRerankArgs &a, hipStream_t s);
 
+// Cross-shard merge on the device: `blocks` is `world` ResultBlock prefixes
+// (16-B header + k entries each, `block_bytes` apart) as gathered from the shards;
+// writes the k smallest keys overall, sorted, to out->e / out->count, the shard of
+// each winner to out_shard, and the OR of the shards' status words to out->status.
+hipError_t launch_merge_blocks(const void *blocks, uint32_t world, uint32_t k, uint32_t block_bytes, ResultBlock *out,
+                               uint32_t *out_shard, hipStream_t s);
+
 // ---- K2: query batches on the FP32 matrix cores (vt_batch.hip) ----------------
 struct BatchCand {
   float score;   // MFMA (approximate-order) dot product

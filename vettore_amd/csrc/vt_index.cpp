@@ -175,7 +175,10 @@ struct Ctx {
   PinnedBuf<float> hQ;
   PinnedBuf<ResultBlock> hRes;  // written by the select kernel through the host mapping
   ResultBlock *dResMapped = nullptr;
+  PinnedBuf<uint32_t> hShard;  // shard of each winner of a cross-shard merge (host mapped)
+  uint32_t *dShardMapped = nullptr;
   PinnedBuf<unsigned char> hStage;
+  uint32_t begin_rows = 0, begin_dim = 0;  // scan of the last vt_flat_search_begin (profiling)
   bool profiling = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   vt_profile prof{};
@@ -216,6 +219,8 @@ struct Ctx {
     VT_HIP(hipMemset(dStatus.p, 0, sizeof(int)));
     VT_TRY(hRes.ensure(1));
     VT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dResMapped), hRes.p, 0));
+    VT_TRY(hShard.ensure(vt::kMaxFusedK));
+    VT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dShardMapped), hShard.p, 0));
     return VT_OK;
   }
   int bind() {
@@ -260,6 +265,7 @@ struct vt_flat {
   std::unordered_map<std::string, uint32_t> row_of;
   std::vector<uint32_t> rank_host;  // by row
   bool ranks_clean = true;          // rank_host/dRank describe the current rows
+  bool external_ranks = false;      // rank column supplied by vt_flat_set_id_ranks (valid until the next mutation)
   std::string max_id;               // upper bound of all ids while ranks_clean
   uint32_t max_rank = 0;
 
@@ -484,6 +490,12 @@ uint32_t index_row_for(vt_flat *ix, const char *id, size_t len, bool *is_new) {
   }
   const uint32_t r = ix->n++;
   *is_new = true;
+  if (ix->external_ranks) {
+    // externally supplied ranks describe the old row set only: fall back to a local re-rank
+    ix->external_ranks = false;
+    ix->ranks_clean = false;
+    std::fill(ix->rank_host.begin(), ix->rank_host.end(), kUnranked);
+  }
   if (ix->ranks_clean) {
     // ids arriving in ascending order (snapshot rebuild sorts by id,
     // collection.ex:427-433) keep ranks valid without a re-sort
@@ -1203,6 +1215,120 @@ int vt_flat_search(vt_flat *ix, const float *query, size_t n, size_t limit, vt_h
   std::lock_guard<std::mutex> g(ix->mu);
   VT_TRY(ix->ctx.bind());
   return search_locked(ix, query, n, limit, out);
+  });
+}
+
+int vt_rank_ids(const char *ids, const size_t *id_off, size_t count, uint32_t *out_rank) {
+  return guarded([&]() -> int {
+  if (count && (!id_off || !out_rank)) return VT_ERR_ARGUMENT;
+  if (count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 ids");
+  std::vector<uint32_t> order(count);
+  for (size_t i = 0; i < count; ++i) order[i] = (uint32_t)i;
+  auto less = [&](uint32_t a, uint32_t b) {
+    const size_t la = id_off[a + 1] - id_off[a], lb = id_off[b + 1] - id_off[b];
+    const size_t m = std::min(la, lb);
+    const int c = m ? std::memcmp(ids + id_off[a], ids + id_off[b], m) : 0;
+    if (c) return c < 0;
+    if (la != lb) return la < lb;
+    return a < b;  // equal ids: input order
+  };
+  parallel_sort(order, less);
+  for (size_t i = 0; i < count; ++i) out_rank[order[i]] = (uint32_t)i;
+  return VT_OK;
+  });
+}
+
+int vt_flat_set_id_ranks(vt_flat *ix, const uint32_t *ranks, size_t count) {
+  return guarded([&]() -> int {
+  if (!ix || (count && !ranks)) return VT_ERR_ARGUMENT;
+  std::lock_guard<std::mutex> g(ix->mu);
+  VT_TRY(ix->ctx.bind());
+  if (count != ix->n) return VT_ERR_DIMENSION;
+  ix->rank_host.assign(ranks, ranks + count);
+  ix->ranks_clean = true;
+  ix->external_ranks = true;
+  ix->max_rank = kUnranked - 1;  // an appended id can no longer extend the ranks in place
+  return index_sync_ranks(ix, true);
+  });
+}
+
+void *vt_flat_stream(vt_flat *ix) { return ix ? static_cast<void *>(ix->ctx.stream) : nullptr; }
+
+int vt_flat_search_begin(vt_flat *ix, const float *query, size_t n, size_t limit, void *device_block) {
+  return guarded([&]() -> int {
+  if (!ix || !device_block || (!query && n)) return VT_ERR_ARGUMENT;
+  std::lock_guard<std::mutex> g(ix->mu);
+  Ctx &c = ix->ctx;
+  VT_TRY(c.bind());
+  if (limit == 0 || limit > (size_t)vt::kMaxFusedK) return fail(VT_ERR_UNSUPPORTED, "search_begin needs 1 <= limit <= 256");
+  VT_TRY(validate_vector(query, n, ix->dim));
+  if (ix->n == 0) {
+    VT_HIP(hipMemsetAsync(device_block, 0, 16, c.stream));  // count = 0
+    return VT_OK;
+  }
+  VT_TRY(index_sync_ranks(ix, false));
+  uint32_t qnz = 0;
+  VT_TRY(upload_query(c, query, n, &qnz));
+  const uint32_t d = (uint32_t)ix->dim, k = (uint32_t)limit;
+  if (vt::scan_lds_bytes(d, k) == 0) return fail(VT_ERR_UNSUPPORTED, "dimension/limit exceed the scan kernel's LDS");
+  const uint32_t blocks = c.grid_for((ix->n + vt::kTileRows - 1) / vt::kTileRows, vt::scan_lds_bytes(d, k));
+  VT_TRY(c.dPartKeys.ensure((size_t)blocks * k));
+  VT_TRY(c.dPartPay.ensure((size_t)blocks * k));
+  vt::ScanArgs a{};
+  a.X = ix->dX;
+  a.stride = ix->ld;
+  a.q = c.dQ.p;
+  a.id_rank = ix->dRank.p;
+  a.n = ix->n;
+  a.d = d;
+  a.metric = ix->metric;
+  a.order = ix->order;
+  a.k = k;
+  a.q_nonzero = qnz;
+  a.part_keys = c.dPartKeys.p;
+  a.part_pay = c.dPartPay.p;
+  a.status = c.dStatus.p;
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+  VT_HIP(vt::launch_scan(a, blocks, c.stream));
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+  c.begin_rows = ix->n;
+  c.begin_dim = d;
+  VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, blocks * k, k, 0, 0, c.dStatus.p,
+                           static_cast<ResultBlock *>(device_block), c.stream));
+  return VT_OK;  // nothing waited for: the caller's collective queues behind these kernels
+  });
+}
+
+int vt_flat_merge_gathered(vt_flat *ix, const void *device_blocks, size_t world, size_t limit, size_t block_bytes,
+                           uint64_t *keys, uint32_t *rows, float *raw, uint32_t *shard, size_t *count) {
+  return guarded([&]() -> int {
+  if (!ix || !device_blocks || !keys || !rows || !raw || !shard || !count) return VT_ERR_ARGUMENT;
+  std::lock_guard<std::mutex> g(ix->mu);
+  Ctx &c = ix->ctx;
+  VT_TRY(c.bind());
+  if (limit == 0 || limit > (size_t)vt::kMaxFusedK || world == 0) return VT_ERR_ARGUMENT;
+  VT_HIP(vt::launch_merge_blocks(device_blocks, (uint32_t)world, (uint32_t)limit, (uint32_t)block_bytes, c.dResMapped,
+                                 c.dShardMapped, c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  if (c.profiling && c.begin_rows) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    c.prof.scan_launches += 1;
+    c.prof.scan_ms += ms;
+    c.prof.scan_rows += c.begin_rows;
+    c.prof.scan_bytes += (uint64_t)c.begin_rows * c.begin_dim * 4;
+    c.begin_rows = 0;
+  }
+  if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
+  const uint32_t got = c.hRes.p->count;
+  for (uint32_t i = 0; i < got; ++i) {
+    keys[i] = c.hRes.p->e[i].key;
+    rows[i] = c.hRes.p->e[i].row;
+    raw[i] = c.hRes.p->e[i].raw;
+    shard[i] = c.hShard.p[i];
+  }
+  *count = got;
+  return VT_OK;
   });
 }
 

@@ -273,6 +273,55 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
   }
 }
 
+// Cross-shard merge: world * k candidate entries (already sorted per shard) ->
+// the k best overall by rank sort in LDS.  Keys are comparable across shards
+// because every shard's id_rank column was taken from ONE ordering of all ids.
+__global__ __launch_bounds__(256) void merge_blocks_kernel(const unsigned char *__restrict__ blocks, uint32_t world,
+                                                           uint32_t k, uint32_t block_bytes, ResultBlock *out,
+                                                           uint32_t *__restrict__ out_shard) {
+  extern __shared__ __align__(16) unsigned char mb_smem[];
+  uint64_t *keys = reinterpret_cast<uint64_t *>(mb_smem);  // [world * k]
+  const uint32_t m = world * k;
+  __shared__ uint32_t s_total;
+  __shared__ int s_status;
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    int status = 0;
+    for (uint32_t w = 0; w < world; ++w) {
+      const ResultBlock *b = reinterpret_cast<const ResultBlock *>(blocks + (size_t)w * block_bytes);
+      total += b->count < k ? b->count : k;
+      status = b->status > status ? b->status : status;
+    }
+    s_total = total;
+    s_status = status;
+  }
+  for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+    const uint32_t w = i / k, j = i - w * k;
+    const ResultBlock *b = reinterpret_cast<const ResultBlock *>(blocks + (size_t)w * block_bytes);
+    keys[i] = j < b->count ? b->e[j].key : kEmptyKey;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+    const uint64_t ki = keys[i];
+    if (ki == kEmptyKey) continue;
+    uint32_t pos = 0;
+    for (uint32_t x = 0; x < m; ++x) {
+      const uint64_t kx = keys[x];
+      pos += (kx < ki || (kx == ki && x < i)) ? 1u : 0u;
+    }
+    if (pos < k) {
+      const uint32_t w = i / k, j = i - w * k;
+      const ResultBlock *b = reinterpret_cast<const ResultBlock *>(blocks + (size_t)w * block_bytes);
+      out->e[pos] = b->e[j];
+      out_shard[pos] = w;
+    }
+  }
+  if (threadIdx.x == 0) {
+    out->count = s_total < k ? s_total : k;
+    out->status = s_status;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K4: packed sign-bit Hamming scan + fused top-k.  Replaces binary_top_k
 // (search.rs:76-92) + packed_hamming (distances.rs:426-437, word_mask :472-481).
@@ -563,6 +612,14 @@ size_t scan_lds_bytes(uint32_t d, uint32_t k) {
   if (!make_scan_shape(d, 1, &p)) return 0;
   const size_t bytes = scan_lds_for(p, k);
   return bytes <= kMaxLds ? bytes : 0;
+}
+
+hipError_t launch_merge_blocks(const void *blocks, uint32_t world, uint32_t k, uint32_t block_bytes, ResultBlock *out,
+                               uint32_t *out_shard, hipStream_t s) {
+  if (world == 0 || k == 0 || k > (uint32_t)kMaxFusedK || (size_t)world * k * 8 > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(merge_blocks_kernel, dim3(1), dim3(256), (size_t)world * k * 8, s,
+                     static_cast<const unsigned char *>(blocks), world, k, block_bytes, out, out_shard);
+  return hipGetLastError();
 }
 
 size_t hamming_lds_bytes(uint32_t k) {

@@ -334,6 +334,57 @@ def flat_funnel_search(index: FlatRef, query, stages: Sequence[int], candidates:
     return ("ok", _take_hits(h)) if rc == 0 else _err(rc)
 
 
+def rank_ids(ids_packed: Tuple[bytes, np.ndarray]) -> np.ndarray:
+    """Position of every id in the bytewise order of all of them (vt_rank_ids)."""
+    blob, off = ids_packed
+    n = len(off) - 1
+    out = np.empty(n, dtype=np.uint32)
+    st = _lib.load().vt_rank_ids(blob, _szp(off), n, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if st != 0:
+        raise RuntimeError("rank_ids: " + _lib.error_text(st))
+    return out
+
+
+def flat_set_id_ranks(index: FlatRef, ranks: np.ndarray):
+    r = np.ascontiguousarray(ranks, dtype=np.uint32)
+    st = _lib.load().vt_flat_set_id_ranks(index.handle, r.ctypes.data_as(C.POINTER(C.c_uint32)), r.size)
+    return "ok" if st == 0 else _err(st)
+
+
+def flat_stream(index: FlatRef) -> int:
+    """The hipStream_t (as an integer) the index enqueues its kernels on."""
+    return int(_lib.load().vt_flat_stream(index.handle) or 0)
+
+
+def flat_search_begin(index: FlatRef, query, limit: int, device_block_ptr: int):
+    """Enqueue one shard's search; the result block lands at `device_block_ptr`."""
+    q = _f32_list(query)
+    st = _lib.load().vt_flat_search_begin(index.handle, _fp(q), q.size, limit, C.c_void_p(device_block_ptr))
+    return "ok" if st == 0 else _err(st)
+
+
+class MergeBuffers:
+    """Reusable output arrays of flat_merge_gathered."""
+
+    def __init__(self, cap: int = 256):
+        self.keys = np.zeros(cap, dtype=np.uint64)
+        self.rows = np.zeros(cap, dtype=np.uint32)
+        self.raw = np.zeros(cap, dtype=np.float32)
+        self.shard = np.zeros(cap, dtype=np.uint32)
+        self.count = C.c_size_t()
+        self.ptrs = (self.keys.ctypes.data_as(C.POINTER(C.c_uint64)), self.rows.ctypes.data_as(C.POINTER(C.c_uint32)),
+                     self.raw.ctypes.data_as(C.POINTER(C.c_float)), self.shard.ctypes.data_as(C.POINTER(C.c_uint32)))
+
+
+def flat_merge_gathered(index: FlatRef, device_blocks_ptr: int, world: int, limit: int, block_bytes: int,
+                        bufs: MergeBuffers):
+    """Merge `world` gathered shard blocks on the device, wait, return the number of winners
+    (their keys / rows / raw / shard are in `bufs`)."""
+    st = _lib.load().vt_flat_merge_gathered(index.handle, C.c_void_p(device_blocks_ptr), world, limit, block_bytes,
+                                            *bufs.ptrs, C.byref(bufs.count))
+    return ("ok", int(bufs.count.value)) if st == 0 else _err(st)
+
+
 def flat_set_reduce_order(index: FlatRef, order: int):
     st = _lib.load().vt_flat_set_reduce_order(index.handle, order)
     return "ok" if st == 0 else _err(st)

@@ -1,5 +1,19 @@
 """Row-sharded flat search across the GPUs of one node.
 
+Two exchange paths, same result:
+
+* device path (`enable_device_exchange`, used on GPUs): every shard's id_rank
+  column is its slice of ONE ordering of all ids (computed once, after loading),
+  so the shards' u64 candidate keys compare directly.  Per query the library
+  enqueues scan + select into a device block without waiting, ONE all_gather
+  queued on the same HIP stream collects the blocks of all shards, a small merge
+  kernel picks the global top-k and the host waits once.  While the scan runs the
+  host is already enqueueing the collective, so the exchange adds only the
+  collective's own device time.
+* host path (always available; CPU/gloo tests): per-shard hits travel as 64-byte
+  records and are merged by (rank key, id bytes).
+
+
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).  Each
 rank owns a contiguous block of rows in its own flat index.  A query runs on
 every shard; the per-shard top-k lists -- already in the reference order
@@ -74,9 +88,63 @@ class ShardedFlat:
         self._local = local_search
         self._torch = None
         self._bufs = {}
+        self._dev = None  # state of the device exchange path
         if dist is not None:
             import torch
             self._torch = torch
+
+    # ---------------------------------------------------------- device exchange
+    def enable_device_exchange(self, local_ids_packed, max_limit: int = 64):
+        """Collective: gathers every shard's ids, ranks them once, installs this
+        shard's slice as its id_rank column.  `local_ids_packed` = (bytes, offsets)
+        of this rank's rows in row order.  Valid until the shard is mutated."""
+        from . import nifs
+        torch, dist = self._torch, self.dist
+        blob, off = local_ids_packed
+        parts = [None] * self.world
+        dist.all_gather_object(parts, (blob, np.asarray(off, dtype=np.uint64)))
+        counts = [len(p[1]) - 1 for p in parts]
+        bases = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        all_blob = b"".join(p[0] for p in parts)
+        all_off = np.zeros(int(bases[-1]) + 1, dtype=np.uintp)
+        pos, byte0 = 0, 0
+        for p in parts:
+            o = p[1].astype(np.uintp)
+            all_off[pos:pos + len(o)] = o + byte0
+            pos += len(o) - 1
+            byte0 += len(p[0])
+        ranks = nifs.rank_ids((all_blob, all_off))
+        mine = ranks[bases[self.rank]:bases[self.rank + 1]]
+        res = nifs.flat_set_id_ranks(self.ref, mine)
+        if res != "ok":
+            raise RuntimeError(res)
+        block_bytes = 16 + max_limit * 16
+        stream = torch.cuda.ExternalStream(nifs.flat_stream(self.ref), device=self.device)
+        self._dev = {
+            "blob": all_blob, "off": all_off, "bases": bases, "max_limit": max_limit, "block_bytes": block_bytes,
+            "stream": stream,
+            "local": torch.zeros(block_bytes, dtype=torch.uint8, device=self.device),
+            "gathered": torch.zeros(self.world * block_bytes, dtype=torch.uint8, device=self.device),
+            "bufs": nifs.MergeBuffers(),
+        }
+
+    def _search_device(self, query, limit):
+        from . import nifs
+        torch, d = self._torch, self._dev
+        res = nifs.flat_search_begin(self.ref, query, limit, d["local"].data_ptr())
+        if res != "ok":
+            raise RuntimeError(res[1])
+        with torch.cuda.stream(d["stream"]):  # the collective queues behind the shard's kernels
+            self.dist.all_gather_into_tensor(d["gathered"], d["local"])
+        res = nifs.flat_merge_gathered(self.ref, d["gathered"].data_ptr(), self.world, limit, d["block_bytes"], d["bufs"])
+        if res[0] != "ok":
+            raise RuntimeError(res[1])
+        b, off, blob, bases = d["bufs"], d["off"], d["blob"], d["bases"]
+        out = []
+        for i in range(res[1]):
+            g = int(bases[int(b.shard[i])]) + int(b.rows[i])
+            out.append((blob[int(off[g]):int(off[g + 1])], float(b.raw[i])))
+        return out
 
     def _local_search(self, query, limit):
         if self._local is not None:
@@ -104,6 +172,8 @@ class ShardedFlat:
     def search(self, query, limit: int) -> List[Tuple[bytes, float]]:
         if self.dist is None or (self.world == 1 and not self.force_exchange):
             return [(h[0], h[1]) for h in self._local_search(query, limit)]
+        if self._dev is not None and 0 < limit <= self._dev["max_limit"]:
+            return self._search_device(query, limit)
         send_host, send_np, send_dev, gathered, on_gpu = self._buffers(limit)
         long_ids = None
         if self._local is None:
