@@ -571,7 +571,8 @@ def test_device_side_shard_merge_equals_single_index(nifs, oracle_mod, metric):
     vt_flat_search_begin into a gathered device buffer, vt_flat_merge_gathered --
     must equal the oracle over all rows, ties (identical rows across shards)
     included."""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library already loaded (torch must not come second)
     n, d, world = 40_000, 96, 4
     x, ids = make_corpus(n, d, 900 + metric, metric == 2, oracle_mod, tie_block=0)
     # identical rows living in different shards: only the global id order can rank them
@@ -590,18 +591,21 @@ def test_device_side_shard_merge_equals_single_index(nifs, oracle_mod, metric):
     bufs = nifs.MergeBuffers()
     for limit in (10, 64):
         block_bytes = 16 + limit * 16
-        gathered = torch.zeros(world * block_bytes, dtype=torch.uint8, device="cuda")
+        gathered = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(gathered), world * block_bytes) == 0
+        assert hip.hipMemset(gathered, 0, world * block_bytes) == 0
         for qi in range(4):
             q = x[5] if qi == 0 else rng.uniform(-1, 1, d).astype(np.float32)
             if metric == 2 and qi:
                 q = oracle_mod.normalize_l2(q)
             for s, g in enumerate(shards):
-                assert nifs.flat_search_begin(g.ref, q, limit, gathered.data_ptr() + s * block_bytes) == "ok"
-            torch.cuda.synchronize()
-            st, cnt = nifs.flat_merge_gathered(shards[0].ref, gathered.data_ptr(), world, limit, block_bytes, bufs)
+                assert nifs.flat_search_begin(g.ref, q, limit, gathered.value + s * block_bytes) == "ok"
+            assert hip.hipDeviceSynchronize() == 0
+            st, cnt = nifs.flat_merge_gathered(shards[0].ref, gathered.value, world, limit, block_bytes, bufs)
             assert st == "ok" and cnt == limit
             got = [(ids[int(bufs.shard[i]) * per + int(bufs.rows[i])], float(bufs.raw[i])) for i in range(cnt)]
             assert bits(got) == bits(oracle_mod.matrix_search(metric, x, packed, q, limit)), (metric, limit, qi)
+        assert hip.hipFree(gathered) == 0
     # a mutation invalidates the external ranks; the shard re-ranks locally and still answers alone
     shards[0].insert("zzz-new", x[0])
     assert shards[0].search(x[0], 2)[0][1] == shards[0].search(x[0], 2)[1][1]
