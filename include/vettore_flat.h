@@ -166,6 +166,17 @@ int vt_flat_funnel_search(vt_flat *index, const float *query, size_t n,
                           const size_t *stages, size_t nstages, size_t candidates,
                           size_t limit, vt_hits **out);
 
+/* hybrid_search with rerank: :exact, lib/vettore/collection.ex:325-345, :515-592:
+ * the union (first occurrence wins) of the candidate sets of `ngen` generators,
+ * exact rerank on the full vectors, top `limit`.  Generator i is
+ *   VT_GEN_FUNNEL    stages[stage_off[i] .. stage_off[i+1]) prefix passes keeping candidates[i] rows
+ *   VT_GEN_QUANTIZED sign-bit Hamming top candidates[i]
+ *   VT_GEN_SEARCH    the index's own search with limit = candidates[i]            */
+enum { VT_GEN_FUNNEL = 0, VT_GEN_QUANTIZED = 1, VT_GEN_SEARCH = 2 };
+int vt_flat_hybrid_search(vt_flat *index, const float *query, size_t n, const int *kinds,
+                          const size_t *candidates, const size_t *stage_off,
+                          const size_t *stages, size_t ngen, size_t limit, vt_hits **out);
+
 /* ---- row-sharded search across GPUs, device-side exchange -----
  * A shard's candidates are u64 keys (rank key << 32 | id_rank); they compare
  * across shards iff every shard's id_rank column comes from ONE ordering of all

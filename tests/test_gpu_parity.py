@@ -496,6 +496,41 @@ def test_elixir_funnel_equals_flat_with_full_candidates(nifs):
     ok, funnel = col.funnel_search(c["query"], {"stages": [2, 4], "candidates": c["candidates"], "limit": c["limit"]})
     assert [r.id for r in funnel] == [r.id for r in exact]
     assert col.funnel_search(c["query"], {"stages": [5]}) == ("error", "invalid_stages")
+    ok, hybrid = col.hybrid_search(c["query"], {"generators": [("funnel", {"stages": [2, 4], "candidates": 64}),
+                                                                ("quantized", {"candidates": 64}),
+                                                                ("search", {"candidates": 64})], "limit": c["limit"]})
+    assert [r.id for r in hybrid] == [r.id for r in exact]
+
+
+@pytest.mark.parametrize("metric", [2, 0])
+def test_hybrid_search_matches_oracle_composition(nifs, oracle_mod, metric):
+    """collection.ex:325-345, :515-592: union of generator candidates (funnel stages,
+    sign-bit Hamming, the index's own search), exact rerank -- composed from oracle pieces."""
+    n, d = 5000, 96
+    x, ids = make_corpus(n, d, 410 + metric, metric == 2, oracle_mod, tie_block=25)
+    packed = oracle_mod.pack_ids(ids)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rows = [(ids[i], x[i]) for i in range(n)]
+    by_id = dict(rows)
+    obits = [(ids[i], oracle_mod.compress_sign_bits(x[i])) for i in range(n)]
+    rng = np.random.default_rng(6)
+    for _ in range(3):
+        q = rng.uniform(-1, 1, d).astype(np.float32)
+        if metric == 2:
+            q = oracle_mod.normalize_l2(q)
+        cur = rows
+        for st in (16, 48):
+            kept = oracle_mod.vector_top_k(cur, q, metric, st, 60)
+            cur = [(i, by_id[i]) for i, _ in kept]
+        union = [i for i, _ in cur]
+        union += [i for i, _ in oracle_mod.binary_top_k(obits, oracle_mod.compress_sign_bits(q), d, 80)]
+        union += [i for i, _ in oracle_mod.matrix_search(metric, x, packed, q, 30)]
+        uniq = list(dict.fromkeys(union))
+        want = oracle_mod.vector_top_k([(i, by_id[i]) for i in uniq], q, metric, d, 10)
+        got = unwrap(nifs.flat_hybrid_search(g.ref, q, [(nifs.GEN_FUNNEL, 60, [16, 48]), (nifs.GEN_QUANTIZED, 80, []),
+                                                         (nifs.GEN_SEARCH, 30, [])], 10))
+        assert bits(got) == bits(want), metric
 
 
 def test_binary_top_k_with_massive_ties(nifs, oracle_mod):

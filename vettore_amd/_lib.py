@@ -21,7 +21,7 @@ SYMBOLS = [
     "vt_flat_new", "vt_flat_free", "vt_flat_insert", "vt_flat_insert_many", "vt_flat_delete",
     "vt_flat_search", "vt_flat_search_batch", "vt_flat_len", "vt_flat_dimension", "vt_flat_metric",
     "vt_flat_set_reduce_order", "vt_set_default_reduce_order",
-    "vt_flat_load_matrix", "vt_flat_load_device_matrix", "vt_flat_quantized_search", "vt_flat_funnel_search",
+    "vt_flat_load_matrix", "vt_flat_load_device_matrix", "vt_flat_quantized_search", "vt_flat_funnel_search", "vt_flat_hybrid_search",
     "vt_rank_ids", "vt_flat_set_id_ranks", "vt_flat_stream", "vt_flat_search_begin", "vt_flat_merge_gathered",
     "vt_vector_top_k", "vt_binary_top_k", "vt_normalize_l2", "vt_compress_sign_bits",
     "vt_flat_set_profiling", "vt_flat_get_profile",
@@ -87,6 +87,8 @@ def load() -> C.CDLL:
     L.vt_flat_load_device_matrix.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_char_p, szp, vp]
     L.vt_flat_quantized_search.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.vt_flat_funnel_search.argtypes = [vp, f32p, C.c_size_t, szp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.vt_flat_hybrid_search.argtypes = [vp, f32p, C.c_size_t, C.POINTER(C.c_int), szp, szp, szp, C.c_size_t, C.c_size_t,
+                                        C.POINTER(vp)]
     u32p = C.POINTER(C.c_uint32)
     L.vt_rank_ids.argtypes = [C.c_char_p, szp, C.c_size_t, u32p]
     L.vt_flat_set_id_ranks.argtypes = [vp, u32p, C.c_size_t]

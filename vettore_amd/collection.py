@@ -224,6 +224,49 @@ class Collection:
             return res
         return ("ok", self._hydrate(res[1]))
 
+    # -- collection.ex:325-345, :515-592 ---------------------------------------
+    def hybrid_search(self, query, opts=None):
+        opts = {} if opts is None else opts
+        if not isinstance(opts, dict):
+            return ("error", "invalid_options")
+        bad = [k for k in opts if k not in ("limit", "generators", "rerank")]
+        if bad:
+            return ("error", ("unsupported_option", bad[0]))
+        limit = opts.get("limit", 10)
+        if not (isinstance(limit, int) and 0 < limit <= MAX_NIF_USIZE):
+            return ("error", "invalid_limit")
+        if opts.get("rerank", "exact") != "exact":
+            return ("error", ("invalid_rerank", opts.get("rerank")))   # multi-vector rerank: out of scope
+        generators = opts.get("generators", ["funnel", "quantized"])   # collection.ex:512-513
+        if not isinstance(generators, list) or not generators:
+            return ("error", "invalid_generators")
+        spec = []
+        for gen in generators:
+            name, gopts = (gen, {}) if isinstance(gen, str) else gen
+            if name not in ("funnel", "quantized", "search") or not isinstance(gopts, dict):
+                return ("error", ("invalid_generator", gen))
+            cand = gopts.get("candidates", max(limit * 10, limit))      # collection.ex:547
+            if not (isinstance(cand, int) and 0 < cand <= MAX_NIF_USIZE):
+                return ("error", "invalid_candidates")
+            if name == "funnel":
+                stages = gopts["stages"] if "stages" in gopts else (
+                    [gopts["dimensions"]] if "dimensions" in gopts else [min(self.dimensions, 128)])
+                if not (isinstance(stages, list) and stages and
+                        all(isinstance(s, int) and 0 < s <= self.dimensions for s in stages)):
+                    return ("error", "invalid_stages")
+                spec.append((nifs.GEN_FUNNEL, cand, stages))
+            elif name == "quantized":
+                spec.append((nifs.GEN_QUANTIZED, cand, []))
+            else:
+                spec.append((nifs.GEN_SEARCH, cand, []))
+        q = self.prepare_query(query)
+        if q[0] != "ok":
+            return q
+        res = nifs.flat_hybrid_search(self.index_state, q[1], spec, limit)
+        if res[0] != "ok":
+            return res
+        return ("ok", self._hydrate(res[1]))
+
     def _hydrate(self, hits):
         out: List[Result] = []
         for id_, raw in hits:

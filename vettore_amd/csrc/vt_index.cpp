@@ -758,6 +758,52 @@ int funnel_stage(vt_flat *ix, const float *query, uint32_t d, const std::vector<
   return run_scan(c, j, want, out, false);
 }
 
+// Candidate rows of one funnel pass (collection.ex:674-691) without the final rerank.
+int funnel_rows(vt_flat *ix, const float *query, const size_t *stages, size_t nstages, size_t candidates,
+                std::vector<uint32_t> &rows) {
+  rows.clear();
+  bool all_rows = true;
+  for (size_t i = 0; i < nstages; ++i) {
+    uint32_t nz = 0;
+    for (size_t j = 0; j < stages[i]; ++j) nz += query[j] != 0.0f ? 1u : 0u;
+    std::vector<vt::Entry> kept;
+    VT_TRY(funnel_stage(ix, query, (uint32_t)stages[i], rows, all_rows, candidates, nz, kept));
+    rows.resize(kept.size());
+    for (size_t r = 0; r < kept.size(); ++r) rows[r] = kept[r].row;
+    all_rows = false;
+    if (rows.empty()) break;
+  }
+  return VT_OK;
+}
+
+// Sign bits of every stored row in K4's layout, built on first use.
+int index_ensure_bits(vt_flat *ix) {
+  if (ix->bits_valid) return VT_OK;
+  Ctx &c = ix->ctx;
+  const uint32_t d = (uint32_t)ix->dim, words = (d + 63) / 64;
+  // compress_sign_bits of every stored row (collection.ex:926): kept in HBM
+  const size_t bwords = vt::hamming_matrix_words(std::max<uint32_t>(ix->cap, ix->n), words);
+  VT_TRY(ix->dBits.ensure(bwords));
+  VT_HIP(hipMemsetAsync(ix->dBits.p, 0, bwords * sizeof(uint64_t), c.stream));
+  VT_HIP(vt::launch_sign_pack(ix->dX, ix->ld, ix->n, d, ix->dBits.p, 1, c.stream));
+  ix->bits_valid = true;
+  return VT_OK;
+}
+
+// binary_top_k candidates (search.rs:76-92) of the query already in c.dQ.
+int quantized_rows(vt_flat *ix, size_t candidates, std::vector<uint32_t> &rows) {
+  Ctx &c = ix->ctx;
+  const uint32_t d = (uint32_t)ix->dim, words = (d + 63) / 64;
+  VT_TRY(index_ensure_bits(ix));
+  VT_TRY(c.dQbits.ensure(words));
+  VT_HIP(vt::launch_sign_pack(c.dQ.p, vt::padded_dim(d), 1, d, c.dQbits.p, 0, c.stream));
+  std::vector<vt::Entry> cand;
+  VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits.p, ix->dRank.p, ix->n, d, candidates, cand, false));
+  rows.resize(cand.size());
+  for (size_t i = 0; i < cand.size(); ++i) rows[i] = cand[i].row;
+  return VT_OK;
+}
+
 // ---------------------------------------------------------------- K2 host side
 // One group of <= 256 queries through the matrix cores.  `done[i]` is set for
 // every query whose exact top-k was proven complete; the others are left for
@@ -1362,14 +1408,7 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
   const uint32_t d = (uint32_t)ix->dim;
   const uint32_t words = (d + 63) / 64;
   VT_TRY(index_sync_ranks(ix, false));
-  if (!ix->bits_valid) {
-    // compress_sign_bits of every stored row (collection.ex:926): kept in HBM
-    const size_t bwords = vt::hamming_matrix_words(std::max<uint32_t>(ix->cap, ix->n), words);
-    VT_TRY(ix->dBits.ensure(bwords));
-    VT_HIP(hipMemsetAsync(ix->dBits.p, 0, bwords * sizeof(uint64_t), c.stream));
-    VT_HIP(vt::launch_sign_pack(ix->dX, ix->ld, ix->n, d, ix->dBits.p, 1, c.stream));
-    ix->bits_valid = true;
-  }
+  VT_TRY(index_ensure_bits(ix));
   uint32_t qnz = 0;
   VT_TRY(upload_query(c, query, n, &qnz));
   VT_TRY(c.dQbits.ensure(words));
@@ -1479,24 +1518,77 @@ int vt_flat_funnel_search(vt_flat *ix, const float *query, size_t n, const size_
   uint32_t qnz_full = 0;
   VT_TRY(upload_query(c, query, n, &qnz_full));
   std::vector<uint32_t> rows;
-  bool all_rows = true;
-  auto qnz_of = [&](size_t d) {
-    uint32_t nz = 0;
-    for (size_t j = 0; j < d; ++j) nz += query[j] != 0.0f ? 1u : 0u;
-    return nz;
-  };
-  // funnel_stage_embeddings (collection.ex:674-691): each stage keeps `candidates` rows
-  for (size_t i = 0; i < nstages; ++i) {
-    std::vector<vt::Entry> kept;
-    VT_TRY(funnel_stage(ix, query, (uint32_t)stages[i], rows, all_rows, candidates, qnz_of(stages[i]), kept));
-    rows.resize(kept.size());
-    for (size_t r = 0; r < kept.size(); ++r) rows[r] = kept[r].row;
-    all_rows = false;
-    if (rows.empty()) return empty_hits(out);
-  }
+  VT_TRY(funnel_rows(ix, query, stages, nstages, candidates, rows));
+  if (rows.empty()) return empty_hits(out);
   // exact_rerank on the full vectors (collection.ex:821-851)
   std::vector<vt::Entry> entries;
   VT_TRY(funnel_stage(ix, query, (uint32_t)ix->dim, rows, false, limit, qnz_full, entries));
+  return make_hits(ix, entries, out);
+  });
+}
+
+int vt_flat_hybrid_search(vt_flat *ix, const float *query, size_t n, const int *kinds, const size_t *candidates,
+                          const size_t *stage_off, const size_t *stages, size_t ngen, size_t limit, vt_hits **out) {
+  return guarded([&]() -> int {
+  if (!ix || !out || (!query && n) || (ngen && (!kinds || !candidates || !stage_off))) return VT_ERR_ARGUMENT;
+  *out = nullptr;
+  std::lock_guard<std::mutex> g(ix->mu);
+  Ctx &c = ix->ctx;
+  VT_TRY(c.bind());
+  VT_TRY(validate_vector(query, n, ix->dim));
+  if (ngen == 0) return VT_ERR_ARGUMENT;
+  for (size_t i = 0; i < ngen; ++i) {
+    if (kinds[i] < VT_GEN_FUNNEL || kinds[i] > VT_GEN_SEARCH || candidates[i] == 0) return VT_ERR_ARGUMENT;
+    if (kinds[i] == VT_GEN_FUNNEL) {
+      if (stage_off[i + 1] <= stage_off[i]) return VT_ERR_PREFIX;
+      for (size_t j = stage_off[i]; j < stage_off[i + 1]; ++j)
+        if (stages[j] == 0 || stages[j] > n) return VT_ERR_PREFIX;
+    }
+  }
+  if (ix->n == 0 || limit == 0) return empty_hits(out);
+  VT_TRY(index_sync_ranks(ix, false));
+  uint32_t qnz_full = 0;
+  VT_TRY(upload_query(c, query, n, &qnz_full));
+  // hybrid_candidates (collection.ex:515-532): every generator's candidates, first occurrence wins
+  std::vector<uint32_t> all, rows;
+  std::vector<char> seen(ix->n, 0);
+  for (size_t i = 0; i < ngen; ++i) {
+    if (kinds[i] == VT_GEN_FUNNEL) {
+      VT_TRY(funnel_rows(ix, query, stages + stage_off[i], stage_off[i + 1] - stage_off[i], candidates[i], rows));
+    } else if (kinds[i] == VT_GEN_QUANTIZED) {
+      VT_TRY(quantized_rows(ix, candidates[i], rows));
+    } else {  // the index's own search with limit = candidates (collection.ex:583-592)
+      std::vector<vt::Entry> kept;
+      VT_TRY(funnel_stage(ix, query, (uint32_t)ix->dim, rows, true, candidates[i], qnz_full, kept));
+      rows.resize(kept.size());
+      for (size_t r = 0; r < kept.size(); ++r) rows[r] = kept[r].row;
+      // flat search ranks cosine by the f32 dot of normalised vectors, not by the f64 cosine
+      if (ix->metric == VT_COSINE) {
+        ScanJob j{};
+        j.X = ix->dX;
+        j.stride = ix->ld;
+        j.id_rank = ix->dRank.p;
+        j.n = ix->n;
+        j.d = (uint32_t)ix->dim;
+        j.metric = ix->metric;
+        j.order = ix->order;
+        j.q_nonzero = qnz_full;
+        kept.clear();
+        VT_TRY(run_scan(c, j, candidates[i], kept, false));
+        rows.resize(kept.size());
+        for (size_t r = 0; r < kept.size(); ++r) rows[r] = kept[r].row;
+      }
+    }
+    for (uint32_t r : rows)
+      if (!seen[r]) {
+        seen[r] = 1;
+        all.push_back(r);
+      }
+  }
+  if (all.empty()) return empty_hits(out);
+  // hybrid_rerank :exact == exact_rerank (collection.ex:627-630, :821-851)
+  std::vector<vt::Entry> entries;
+  VT_TRY(funnel_stage(ix, query, (uint32_t)ix->dim, all, false, limit, qnz_full, entries));
   return make_hits(ix, entries, out);
   });
 }

@@ -334,6 +334,27 @@ def flat_funnel_search(index: FlatRef, query, stages: Sequence[int], candidates:
     return ("ok", _take_hits(h)) if rc == 0 else _err(rc)
 
 
+GEN_FUNNEL, GEN_QUANTIZED, GEN_SEARCH = 0, 1, 2
+
+
+def flat_hybrid_search(index: FlatRef, query, generators, limit: int):
+    """hybrid_search(rerank: :exact) on the resident corpus.  `generators` is a list of
+    (kind, candidates, stages) with kind in GEN_*; stages only for GEN_FUNNEL."""
+    q = _f32_list(query)
+    kinds = (C.c_int * len(generators))(*[g[0] for g in generators])
+    cands = np.ascontiguousarray([g[1] for g in generators], dtype=np.uintp)
+    flat_stages, off = [], [0]
+    for g in generators:
+        flat_stages.extend(g[2] if g[0] == GEN_FUNNEL else [])
+        off.append(len(flat_stages))
+    st = np.ascontiguousarray(flat_stages if flat_stages else [0], dtype=np.uintp)
+    so = np.ascontiguousarray(off, dtype=np.uintp)
+    h = C.c_void_p()
+    rc = _lib.load().vt_flat_hybrid_search(index.handle, _fp(q), q.size, kinds, _szp(cands), _szp(so), _szp(st),
+                                           len(generators), limit, C.byref(h))
+    return ("ok", _take_hits(h)) if rc == 0 else _err(rc)
+
+
 def rank_ids(ids_packed: Tuple[bytes, np.ndarray]) -> np.ndarray:
     """Position of every id in the bytewise order of all of them (vt_rank_ids)."""
     blob, off = ids_packed
