@@ -135,6 +135,16 @@ def cpu_baseline(dim, limit, budget_s):
             "queries_1": done, "queries_T": sum(counts), "seconds": dt1 + dtn}
 
 
+def measured_read_peak():
+    """GB/s of the plain read-only streaming kernel on this pool's MI355X
+    (tools/hbm_peak.hip, recorded in profiles/r01_hbm_peak.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_peak.json")) as f:
+            return float(json.load(f)["read_peak_GBps"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def pmc_traffic(rows, dim):
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes
     (profiles/pmc_latest.json: FETCH_SIZE and WRITE_SIZE collected in separate
@@ -351,6 +361,8 @@ def main():
                 "traffic": pmc_traffic(count, a.dim),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": scan_ms,
+                "measured_read_peak": measured_read_peak(),
+                "frac_of_measured_read_peak": (achieved / measured_read_peak()) if measured_read_peak() else None,
             },
         }
         if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
