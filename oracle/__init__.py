@@ -47,9 +47,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB_PATH):
+    # VT_ORACLE_LIB: another build of the same source (tools/cpu_variants.py times -O3 / -march=native builds)
+    path = os.environ.get("VT_ORACLE_LIB") or _LIB_PATH
+    if path == _LIB_PATH and not os.path.exists(_LIB_PATH):
         build()
-    L = C.CDLL(_LIB_PATH)
+    L = C.CDLL(path)
     f32p, u64p, szp = C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)
     vp = C.c_void_p
     L.vto_strerror.restype = C.c_char_p

@@ -81,8 +81,13 @@ hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hi
 // writes them sorted ascending with their payloads to out->e, out->count;
 // moves *dev_status into out->status and clears it for the next query.
 // Keys <= lo_key are ignored when has_lo (multi-pass selection of k > kMaxFusedK).
+// Lists of >= kSelTwoLevelMin keys are selected in two levels (kSelGroups blocks on
+// slices, then one block); scratch_keys/scratch_pay hold kSelGroups * k entries.
+constexpr uint32_t kSelGroups = 16;
+constexpr uint32_t kSelTwoLevelMin = 16384;
 hipError_t launch_select(const uint64_t *keys, const Payload *pay, uint32_t m, uint32_t k, uint64_t lo_key, int has_lo,
-                         int *dev_status, ResultBlock *out, hipStream_t s);
+                         int *dev_status, ResultBlock *out, uint64_t *scratch_keys, Payload *scratch_pay,
+                         hipStream_t s);
 
 // K4's bit-matrix layout: per tile of 64 rows, word pair j of all 64 rows is
 // contiguous -- [tile][pair][row % 64][2] u64 (an odd word count is padded with a

@@ -156,6 +156,8 @@ struct Ctx {
   DevBuf<uint64_t> dQbits;
   DevBuf<uint64_t> dPartKeys;
   DevBuf<vt::Payload> dPartPay;
+  DevBuf<uint64_t> dSelKeys;  // second level of the two-level select: kSelGroups * kMaxFusedK entries
+  DevBuf<vt::Payload> dSelPay;
   DevBuf<int> dStatus;  // "metric overflow" flag: set by scan kernels, moved out and cleared by the select kernel
   DevBuf<int> dFlag;    // scratch flag of the ingest kernels
   DevBuf<ResultBlock> dStage;  // stage-1 winners of quantized_search, consumed on the device
@@ -216,6 +218,8 @@ struct Ctx {
     VT_HIP(hipEventCreate(&ev3));
     VT_TRY(dStatus.ensure(1));
     VT_TRY(dFlag.ensure(1));
+    VT_TRY(dSelKeys.ensure((size_t)vt::kSelGroups * vt::kMaxFusedK));
+    VT_TRY(dSelPay.ensure((size_t)vt::kSelGroups * vt::kMaxFusedK));
     VT_HIP(hipMemset(dStatus.p, 0, sizeof(int)));
     VT_TRY(hRes.ensure(1));
     VT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dResMapped), hRes.p, 0));
@@ -281,7 +285,7 @@ namespace {
 // One select launch + stream sync; the k winners arrive in c.hRes (pinned,
 // written by the kernel through the host mapping).
 int select_pass(Ctx &c, const uint64_t *keys, const vt::Payload *pay, uint32_t m, uint32_t k, uint64_t lo, bool has_lo) {
-  VT_HIP(vt::launch_select(keys, pay, m, k, lo, has_lo ? 1 : 0, c.dStatus.p, c.dResMapped, c.stream));
+  VT_HIP(vt::launch_select(keys, pay, m, k, lo, has_lo ? 1 : 0, c.dStatus.p, c.dResMapped, c.dSelKeys.p, c.dSelPay.p, c.stream));
   VT_HIP(hipStreamSynchronize(c.stream));
   return VT_OK;
 }
@@ -1340,7 +1344,7 @@ int vt_flat_search_begin(vt_flat *ix, const float *query, size_t n, size_t limit
   c.begin_rows = ix->n;
   c.begin_dim = d;
   VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, blocks * k, k, 0, 0, c.dStatus.p,
-                           static_cast<ResultBlock *>(device_block), c.stream));
+                           static_cast<ResultBlock *>(device_block), c.dSelKeys.p, c.dSelPay.p, c.stream));
   return VT_OK;  // nothing waited for: the caller's collective queues behind these kernels
   });
 }
@@ -1442,7 +1446,7 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
     VT_HIP(vt::launch_hamming(h, blocks, c.stream));
     if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
     timed_hamming = c.profiling;
-    VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, waves * k1, k1, 0, 0, c.dStatus.p, c.dStage.p, c.stream));
+    VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, waves * k1, k1, 0, 0, c.dStatus.p, c.dStage.p, c.dSelKeys.p, c.dSelPay.p, c.stream));
     gather = &c.dStage.p->e[0].row;
     gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
   } else {

@@ -70,11 +70,23 @@ __device__ __forceinline__ void for_each_key(const uint64_t *__restrict__ keys, 
   for (; i < m; i += kStride) f(keys[i], i);
 }
 
+// With more than one block (first level of a two-level select over a long
+// list) block b works on its own slice of `slice` keys and leaves its winners,
+// unsorted and padded with kEmptyKey, at part_keys/part_pay[b * k ..).
 __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__restrict__ keys,
                                                            const Payload *__restrict__ pay, uint32_t m, uint32_t k,
                                                            uint64_t lo_key, int has_lo, int *dev_status,
-                                                           ResultBlock *out) {
+                                                           ResultBlock *out, uint32_t slice,
+                                                           uint64_t *__restrict__ part_keys,
+                                                           Payload *__restrict__ part_pay) {
   extern __shared__ __align__(16) unsigned char smem[];
+  const bool partial = gridDim.x > 1;
+  if (partial) {
+    const uint32_t lo = blockIdx.x * slice;
+    keys += lo;
+    pay += lo;
+    m = lo >= m ? 0u : (m - lo < slice ? m - lo : slice);
+  }
   uint64_t *sel_key = reinterpret_cast<uint64_t *>(smem);  // [k]
   uint64_t *cand_key = sel_key + k;                        // [kSelCand]
   uint32_t *sel_idx = reinterpret_cast<uint32_t *>(cand_key + kSelCand);  // [k]
@@ -90,21 +102,23 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
 
   auto live = [&](uint64_t key) { return key != kEmptyKey && (!has_lo || key > lo_key); };
 
-  // pass 1: range and count of the live keys
-  uint64_t mn = ~0ull, mx = 0;
+  // pass 1: count of the live keys and the bit positions in which they differ
+  // (OR ^ AND): digits are cut from those positions only, so the long constant
+  // runs of a key -- an id rank below 2^24 under a 32-bit score, the handful of
+  // distinct Hamming distances -- cost no rounds
+  uint64_t mn = ~0ull, mx = 0;  // AND, OR
   uint32_t cnt = 0;
   for_each_key(keys, m, tid, [&](uint64_t key, uint32_t) {
     if (live(key)) {
-      mn = key < mn ? key : mn;
-      mx = key > mx ? key : mx;
+      mn &= key;
+      mx |= key;
       cnt += 1;
     }
   });
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
-    const uint64_t a = __shfl_xor(mn, o, kWave), b = __shfl_xor(mx, o, kWave);
-    mn = a < mn ? a : mn;
-    mx = b > mx ? b : mx;
+    mn &= __shfl_xor(mn, o, kWave);
+    mx |= __shfl_xor(mx, o, kWave);
     cnt += __shfl_xor(cnt, o, kWave);
   }
   if (lane == 0) {
@@ -122,22 +136,28 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
   mx = 0;
   uint32_t nvalid = 0;
   for (int w = 0; w < 16; ++w) {
-    mn = red_min[w] < mn ? red_min[w] : mn;
-    mx = red_max[w] > mx ? red_max[w] : mx;
+    mn &= red_min[w];
+    mx |= red_max[w];
     nvalid += red_cnt[w];
   }
+  const uint64_t var = nvalid ? (mn ^ mx) : 0ull;  // bits that differ among the live keys
 
   uint64_t T = ~0ull - 1;  // threshold over the global keys: select every live key <= T
   bool from_cand = false;  // the remaining winners are cand keys <= Tc
   uint64_t Tc = 0;
-  if (nvalid > k && mn != mx) {
+  if (nvalid > k && var != 0) {
     uint32_t krem = k;
-    int hb = 63 - __clzll((long long)(mn ^ mx));
-    uint64_t mask = hb == 63 ? 0ull : (~0ull << (hb + 1));
+    int hb = 63 - __clzll((long long)var);
+    uint64_t mask = ~var;          // constant bits count as resolved
     uint64_t prefix = mx & mask;
     int width = hb + 1 < 8 ? hb + 1 : 8;
     int shift = hb + 1 - width;
     uint32_t dmask = (1u << width) - 1;
+    // highest varying bit below `shift`, or -1: the next digit starts there
+    auto next_hb = [&](int sh) -> int {
+      const uint64_t rem = sh > 0 ? (var & ((1ull << sh) - 1)) : 0ull;
+      return rem ? 63 - __clzll((long long)rem) : -1;
+    };
     // pass 2: first digit
     for_each_key(keys, m, tid, [&](uint64_t key, uint32_t) {
       if (live(key)) atomicAdd(&hist[(uint32_t)(key >> shift) & dmask], 1u);
@@ -149,7 +169,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
     krem -= sb.below;
     prefix |= (uint64_t)sb.bin << shift;
     mask |= (uint64_t)dmask << shift;
-    if (sb.count == krem || shift == 0) {
+    if (sb.count == krem || next_hb(shift) < 0) {
       T = prefix | (shift ? ((1ull << shift) - 1) : 0ull);  // the whole bin is selected
     } else if (sb.count <= kSelCand) {
       // pass 3: winners below the bin, the bin itself into LDS
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
       __syncthreads();
       const uint32_t ncand = s_ncand < kSelCand ? s_ncand : kSelCand;
       // remaining digits on the LDS list
-      hb = shift - 1;
+      hb = next_hb(shift);
       for (;;) {
         width = hb + 1 < 8 ? hb + 1 : 8;
         shift = hb + 1 - width;
@@ -191,11 +211,11 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
         krem -= sb.below;
         prefix |= (uint64_t)sb.bin << shift;
         mask |= (uint64_t)dmask << shift;
-        if (sb.count == krem || shift == 0) {
+        if (sb.count == krem || next_hb(shift) < 0) {
           Tc = prefix | (shift ? ((1ull << shift) - 1) : 0ull);
           break;
         }
-        hb = shift - 1;
+        hb = next_hb(shift);
       }
       from_cand = true;
       for (uint32_t i = tid; i < ncand; i += 1024) {
@@ -210,7 +230,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
       }
     } else {
       // crowded bin (more than kSelCand keys share the digit): keep resolving on the global keys
-      hb = shift - 1;
+      hb = next_hb(shift);
       for (;;) {
         width = hb + 1 < 8 ? hb + 1 : 8;
         shift = hb + 1 - width;
@@ -228,11 +248,11 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
         krem -= sb.below;
         prefix |= (uint64_t)sb.bin << shift;
         mask |= (uint64_t)dmask << shift;
-        if (sb.count == krem || shift == 0) {
+        if (sb.count == krem || next_hb(shift) < 0) {
           T = prefix | (shift ? ((1ull << shift) - 1) : 0ull);
           break;
         }
-        hb = shift - 1;
+        hb = next_hb(shift);
       }
     }
   }
@@ -251,6 +271,13 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
   }
   __syncthreads();
   const uint32_t nsel = s_sel < k ? s_sel : k;
+  if (partial) {
+    for (uint32_t j = tid; j < k; j += 1024) {
+      part_keys[(size_t)blockIdx.x * k + j] = j < nsel ? sel_key[j] : kEmptyKey;
+      if (j < nsel) part_pay[(size_t)blockIdx.x * k + j] = pay[sel_idx[j]];
+    }
+    return;
+  }
   // rank sort (keys distinct; ties only for caller-supplied duplicate ids)
   for (uint32_t j = tid; j < nsel; j += 1024) {
     const uint64_t kj = sel_key[j];
@@ -444,9 +471,33 @@ __global__ __launch_bounds__(64) void cosine_rerank_kernel(const CosineRerankArg
   const uint32_t ld4 = (a.d + 3) / 4 * 4;
   float *qs = crs, *xs = crs + ld4;
   const float *x = a.X + (size_t)src * a.stride;
-  for (uint32_t j = lane; j < a.d; j += kWave) {
-    qs[j] = a.q[j];
-    xs[j] = x[j];
+  if ((a.stride & 3u) == 0 && a.stride >= ld4) {  // (the query buffer is always padded to padded_dim)
+    // every 16-B load of the row and of the query goes out before the first LDS store
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
+    const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.q);
+    const uint32_t n4 = ld4 / 4;
+    for (uint32_t base = 0; base < n4; base += 4 * kWave) {
+      f32x4 xv[4], qv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t j = base + u * kWave + lane;
+        xv[u] = j < n4 ? x4[j] : f32x4{0, 0, 0, 0};
+        qv[u] = j < n4 ? q4[j] : f32x4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t j = base + u * kWave + lane;
+        if (j < n4) {
+          *reinterpret_cast<f32x4 *>(xs + 4 * j) = xv[u];
+          *reinterpret_cast<f32x4 *>(qs + 4 * j) = qv[u];
+        }
+      }
+    }
+  } else {
+    for (uint32_t j = lane; j < a.d; j += kWave) {
+      qs[j] = a.q[j];
+      xs[j] = x[j];
+    }
   }
   wave_lds_fence();
   double acc = 0.0;
@@ -653,10 +704,22 @@ hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hi
 }
 
 hipError_t launch_select(const uint64_t *keys, const Payload *pay, uint32_t m, uint32_t k, uint64_t lo_key, int has_lo,
-                         int *dev_status, ResultBlock *out, hipStream_t s) {
+                         int *dev_status, ResultBlock *out, uint64_t *scratch_keys, Payload *scratch_pay,
+                         hipStream_t s) {
   if (k == 0 || k > (uint32_t)kMaxFusedK) return hipErrorInvalidValue;
   const size_t lds = ((size_t)k + kSelCand) * 12;
-  hipLaunchKernelGGL(select_topk_kernel, dim3(1), dim3(1024), lds, s, keys, pay, m, k, lo_key, has_lo, dev_status, out);
+  if (m >= kSelTwoLevelMin && scratch_keys && scratch_pay) {
+    // long lists (k = 100 leaves 51 200 partial keys): kSelGroups blocks select in
+    // parallel on slices, one block finishes on kSelGroups * k keys
+    const uint32_t slice = (m + kSelGroups - 1) / kSelGroups;
+    hipLaunchKernelGGL(select_topk_kernel, dim3(kSelGroups), dim3(1024), lds, s, keys, pay, m, k, lo_key, has_lo,
+                       dev_status, out, slice, scratch_keys, scratch_pay);
+    hipLaunchKernelGGL(select_topk_kernel, dim3(1), dim3(1024), lds, s, scratch_keys, scratch_pay, kSelGroups * k, k,
+                       0ull, 0, dev_status, out, 0u, nullptr, nullptr);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(select_topk_kernel, dim3(1), dim3(1024), lds, s, keys, pay, m, k, lo_key, has_lo, dev_status, out,
+                     0u, nullptr, nullptr);
   return hipGetLastError();
 }
 
