@@ -43,11 +43,12 @@ def parse():
     ap.add_argument("--limit", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--mode", choices=["single", "batch", "quantized"], default="single",
+    ap.add_argument("--mode", choices=["single", "batch", "quantized", "funnel"], default="single",
                     help="single: BASELINE.json metric (default); batch: configs[2] (dot, 256-query batches, "
                          "FP32 MFMA); quantized: configs[4] (sign-bit Hamming pass + exact rerank)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the all_gather exchange even on one rank (prices the multi-GPU merge step)")
+    ap.add_argument("--stages", default="128", help="funnel mode: prefix lengths (collection.ex:660-672 default min(d,128))")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--candidates", type=int, default=100)
     return ap.parse_args()
@@ -183,6 +184,8 @@ def run_side_mode(a, torch, nifs, device):
     if not batch:
         qs /= np.linalg.norm(qs.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
     outs = (C.c_void_p * per)()
+    stage_list = [int(v) for v in a.stages.split(",")]
+    stages = (C.c_size_t * len(stage_list))(*stage_list)
 
     def step(i):
         q = qs[i * per:(i + 1) * per]
@@ -191,6 +194,11 @@ def run_side_mode(a, torch, nifs, device):
             assert L.vt_flat_search_batch(ref.handle, qp, per, a.dim, a.limit, outs) == 0
             for j in range(per):
                 L.vt_hits_free(C.c_void_p(outs[j]))
+        elif a.mode == "funnel":
+            h = C.c_void_p()
+            assert L.vt_flat_funnel_search(ref.handle, qp, a.dim, stages, len(stage_list), a.candidates, a.limit,
+                                           C.byref(h)) == 0
+            L.vt_hits_free(h)
         else:
             h = C.c_void_p()
             assert L.vt_flat_quantized_search(ref.handle, qp, a.dim, a.candidates, a.limit, C.byref(h)) == 0
@@ -221,6 +229,18 @@ def run_side_mode(a, torch, nifs, device):
         out["roofline"] = {"bound": "mfma", "kernel": "mfma_scores_kernel", "achieved": tf, "peak": 157.3,
                            "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None, "avg_launch_ms": ms,
                            "algorithmic_flops_per_launch": p["batch_flops"] / max(1, p["batch_launches"])}
+    elif a.mode == "funnel":
+        ms = p["prefix_ms"] / max(1, p["prefix_launches"])
+        gbs = p["prefix_bytes"] / max(1, p["prefix_launches"]) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out["dtype"] = "f64"
+        out["metric"] = "queries/sec, funnel_search (f64 cosine on prefix %s, keep %d, exact rerank top-%d), N=%d d=%d" % (
+            a.stages, a.candidates, a.limit, a.rows, a.dim)
+        out["config"] = {"workload": "funnel_search stages=[%s] candidates=%d limit=%d, d=%d, N=%d" % (
+            a.stages, a.candidates, a.limit, a.dim, a.rows)}
+        out["roofline"] = {"bound": "hbm", "kernel": "cosine_scan_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+                           "algorithmic_bytes_per_launch": p["prefix_bytes"] / max(1, p["prefix_launches"]),
+                           "note": "useful bytes = rows * prefix * 4; the prefix of a 3 KiB row is a strided read"}
     else:
         ms = p["hamming_ms"] / max(1, p["hamming_launches"])
         gbs = p["hamming_bytes"] / max(1, p["hamming_launches"]) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

@@ -238,6 +238,9 @@ typedef struct vt_profile {
   double batch_flops;       /* 2 * rows * padded queries * padded dims per pass */
   uint64_t batch_queries;
   uint64_t batch_fallbacks; /* queries the bound could not certify (re-run singly) */
+  uint64_t prefix_launches; /* f64 cosine prefix scans (funnel stage over all rows) */
+  double prefix_ms;
+  uint64_t prefix_bytes;    /* rows * prefix dimensions * 4 */
 } vt_profile;
 int vt_flat_set_profiling(vt_flat *index, int enabled);
 int vt_flat_get_profile(vt_flat *index, vt_profile *out, int reset);

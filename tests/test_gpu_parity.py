@@ -458,6 +458,33 @@ def test_quantized_search_matches_oracle_composition(nifs, oracle_mod, metric):
         assert bits(got) == bits(want), (metric, cand, limit)
 
 
+def test_funnel_overflow_in_any_stage_is_reported(nifs, oracle_mod):
+    """search.rs:38-73 returns Err("metric overflow") whichever stage meets the row; the
+    chained device path carries the flag from an intermediate stage to the final select."""
+    n, d = 300, 16
+    rng = np.random.default_rng(77)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    ids = [b"r%03d" % i for i in range(n)]
+    q = np.full(d, 2.0, np.float32)
+    early, late = x.copy(), x.copy()
+    early[7, :] = 3e38                 # overflows already on the 8-wide prefix
+    late[9, :8] = 100.0                # best prefix score, so it survives stage 1 ...
+    late[9, 8:] = 3e38                 # ... and overflows in the full-width rerank
+    for m in (early, late):
+        g = GpuIndex(nifs, 3)
+        unwrap(nifs.flat_load_matrix(g.ref, ids, m))
+        rows = [(ids[i], m[i]) for i in range(n)]
+        for cand in (50, 300):         # device chain / host-staged path
+            with pytest.raises(oracle_mod.OracleError, match="metric overflow"):
+                kept = oracle_mod.vector_top_k(rows, q, 3, 8, cand)
+                by_id = dict(rows)
+                oracle_mod.vector_top_k([(i, by_id[i]) for i, _ in kept], q, 3, d, 5)
+            assert nifs.flat_funnel_search(g.ref, q, [8], cand, 5) == ("error", "metric overflow")
+        # the flag does not leak into the next call
+        ok = nifs.flat_funnel_search(g.ref, np.zeros(d, np.float32), [8], 50, 5)
+        assert ok[0] == "ok"
+
+
 @pytest.mark.parametrize("metric", [2, 0, 3])
 def test_funnel_search_matches_oracle_composition(nifs, oracle_mod, metric):
     """collection.ex:245-260, :674-691: per stage vector_top_k on a prefix (f64

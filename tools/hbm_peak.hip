@@ -41,6 +41,29 @@ __global__ __launch_bounds__(256) void copy_kernel(const f32x4 *__restrict__ p, 
   for (; i < n16; i += stride) q[i] = p[i];
 }
 
+// prefix read: the first `pre16` 16-byte words of every row of `row16` words (the funnel
+// stage's access pattern: 512 B of each 3 KiB row); one wave-instruction covers 1 KiB.
+__global__ __launch_bounds__(256) void prefix_kernel(const f32x4 *__restrict__ p, size_t rows, uint32_t row16,
+                                                     uint32_t pre16, float *out) {
+  const size_t total = rows * pre16;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  f32x4 acc = {0, 0, 0, 0};
+  for (; i + 7 * stride < total; i += 8 * stride) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t j = i + u * stride;
+      const size_t r = j / pre16, c = j - r * pre16;
+      v[u] = __builtin_nontemporal_load(p + r * row16 + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  const float s = acc.x + acc.y + acc.z + acc.w;
+  if (s == 123456.789f) out[0] = s;
+}
+
 int main(int argc, char **argv) {
   const double gb = argc > 1 ? atof(argv[1]) : 30.72;  // bytes read per launch, GB (default: the 10M x 768 corpus)
   const size_t bytes = (size_t)(gb * 1e9) / 4096 * 4096;
@@ -92,6 +115,25 @@ int main(int argc, char **argv) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double r = 2.0 * bytes / (ms * 1e-3) / 1e9;
     if (rep && r > best_memcpy) best_memcpy = r;
+  }
+  if (argc > 2) {  // hbm_peak <GB> <prefix floats>: strided prefix read of 768-float rows
+    const uint32_t pre16 = (uint32_t)atoi(argv[2]) / 4, row16 = 768 / 4;
+    const size_t rows = bytes / 3072;
+    double best = 0;
+    int best_pc = 0;
+    for (int pc : per_cu) {
+      for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0, s));
+        prefix_kernel<<<cus * pc, 256, 0, s>>>((const f32x4 *)a, rows, row16, pre16, out);
+        CK(hipEventRecord(e1, s));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double r = (double)rows * pre16 * 16 / (ms * 1e-3) / 1e9;
+        if (rep && r > best) { best = r; best_pc = pc; }
+      }
+    }
+    printf("{\"rows\": %zu, \"prefix_floats\": %u, \"prefix_read_useful_GBps\": %.0f, \"blocks_per_cu\": %d}\n", rows,
+           pre16 * 4, best, best_pc);
   }
   printf("{\"device\": \"%s\", \"cus\": %d, \"buffer_GB\": %.2f, \"read_GBps\": %.0f, \"read_blocks_per_cu\": %d, "
          "\"copy_GBps\": %.0f, \"copy_blocks_per_cu\": %d, \"memcpy_d2d_GBps\": %.0f}\n",

@@ -35,6 +35,7 @@ class Profile(C.Structure):
         ("hamming_bytes", C.c_uint64), ("merge_launches", C.c_uint64), ("merge_ms", C.c_double),
         ("batch_launches", C.c_uint64), ("batch_ms", C.c_double), ("batch_flops", C.c_double),
         ("batch_queries", C.c_uint64), ("batch_fallbacks", C.c_uint64),
+        ("prefix_launches", C.c_uint64), ("prefix_ms", C.c_double), ("prefix_bytes", C.c_uint64),
     ]
 
 

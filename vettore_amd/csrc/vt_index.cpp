@@ -231,6 +231,17 @@ struct Ctx {
     VT_HIP(hipSetDevice(device));
     return VT_OK;
   }
+  // a prefix scan timed with ev0/ev1 but not yet read back (the chained funnel waits once, at its end)
+  uint32_t prefix_pending = 0;
+  int settle_prefix_profile() {
+    if (!prefix_pending) return VT_OK;
+    float ms = 0.0f;
+    VT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+    prof.prefix_launches += 1;
+    prof.prefix_ms += ms;
+    prefix_pending = 0;
+    return VT_OK;
+  }
   // Tiles are dealt to waves statically, so the grid must be fully resident:
   // blocks per CU = what LDS admits, capped (VT_BLOCKS_PER_CU overrides).
   uint32_t grid_for(uint32_t units, size_t lds_bytes, int max_per_cu = 0) const {
@@ -704,8 +715,17 @@ int run_cosine_scan(Ctx &c, vt_flat *ix, uint32_t d, double qq, size_t want, std
     a.part_keys = c.dPartKeys.p;
     a.part_pay = c.dPartPay.p;
     a.status = c.dStatus.p;
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
     VT_HIP(vt::launch_cosine_scan(a, blocks, c.stream));
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
     VT_TRY(select_pass(c, c.dPartKeys.p, c.dPartPay.p, blocks * k, k, 0, false));
+    if (c.profiling) {
+      float ms = 0.0f;
+      VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+      c.prof.prefix_launches += 1;
+      c.prof.prefix_ms += ms;
+      c.prof.prefix_bytes += (uint64_t)ix->n * d * 4;
+    }
     if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
     const uint32_t got = c.hRes.p->count;
     for (uint32_t i = 0; i < got; ++i) out.push_back(c.hRes.p->e[i]);
@@ -760,6 +780,106 @@ int funnel_stage(vt_flat *ix, const float *query, uint32_t d, const std::vector<
   j.order = ix->order;
   j.q_nonzero = qnz;
   return run_scan(c, j, want, out, false);
+}
+
+// One funnel / rerank stage that never leaves the device: scores `count` rows
+// (all rows, or the Entry.row column of the previous stage's block), keeps
+// `want` <= kMaxFusedK of them in `dst`.  Nothing is waited for; an overflow
+// flag raised by any stage stays in c.dStatus until a select with `last` moves
+// it into its block.
+int funnel_stage_dev(vt_flat *ix, const float *query, uint32_t d, const ResultBlock *src, uint32_t count,
+                     uint32_t want, uint32_t qnz, ResultBlock *dst, bool last) {
+  Ctx &c = ix->ctx;
+  const uint32_t *gather = src ? &src->e[0].row : nullptr;
+  const uint32_t gstride = sizeof(vt::Entry) / sizeof(uint32_t);
+  int *status = last ? c.dStatus.p : nullptr;
+  if (ix->metric == VT_COSINE) {
+    double qq = 0.0;  // f64_dot(q, q) over the prefix (distances.rs:179-185)
+    for (uint32_t j = 0; j < d; ++j) qq += (double)query[j] * (double)query[j];
+    if (!src) {
+      const uint32_t blocks = c.grid_for((ix->n + 63) / 64, vt::cosine_scan_lds_bytes(d, want));
+      VT_TRY(c.dPartKeys.ensure((size_t)blocks * want));
+      VT_TRY(c.dPartPay.ensure((size_t)blocks * want));
+      vt::CosineScanArgs a{};
+      a.X = ix->dX;
+      a.stride = ix->ld;
+      a.q = c.dQ.p;
+      a.qq = qq;
+      a.id_rank = ix->dRank.p;
+      a.n = ix->n;
+      a.d = d;
+      a.k = want;
+      a.part_keys = c.dPartKeys.p;
+      a.part_pay = c.dPartPay.p;
+      a.status = c.dStatus.p;
+      if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+      VT_HIP(vt::launch_cosine_scan(a, blocks, c.stream));
+      if (c.profiling) {
+        VT_HIP(hipEventRecord(c.ev1, c.stream));
+        c.prefix_pending += 1;
+        c.prof.prefix_bytes += (uint64_t)ix->n * d * 4;
+      }
+      VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, blocks * want, want, 0, 0, status, dst, c.dSelKeys.p,
+                               c.dSelPay.p, c.stream));
+      return VT_OK;
+    }
+    VT_TRY(c.dCandKeys.ensure(count));
+    VT_TRY(c.dCandPay.ensure(count));
+    vt::CosineRerankArgs a{};
+    a.X = ix->dX;
+    a.stride = ix->ld;
+    a.q = c.dQ.p;
+    a.id_rank = ix->dRank.p;
+    a.gather = gather;
+    a.gather_stride = gstride;
+    a.n = count;
+    a.d = d;
+    a.out_keys = c.dCandKeys.p;
+    a.out_pay = c.dCandPay.p;
+    a.status = c.dStatus.p;
+    VT_HIP(vt::launch_cosine_rerank(a, c.stream));
+    VT_HIP(vt::launch_select(c.dCandKeys.p, c.dCandPay.p, count, want, 0, 0, status, dst, c.dSelKeys.p, c.dSelPay.p,
+                             c.stream));
+    return VT_OK;
+  }
+  const uint32_t ntiles = (count + vt::kTileRows - 1) / vt::kTileRows;
+  const uint32_t blocks = c.grid_for(ntiles, vt::scan_lds_bytes(d, want));
+  const uint32_t lists = vt::scan_lists(blocks);
+  VT_TRY(c.dPartKeys.ensure((size_t)lists * want));
+  VT_TRY(c.dPartPay.ensure((size_t)lists * want));
+  vt::ScanArgs a{};
+  a.X = ix->dX;
+  a.stride = ix->ld;
+  a.q = c.dQ.p;
+  a.id_rank = ix->dRank.p;
+  a.gather = gather;
+  a.gather_stride = gather ? gstride : 0;
+  a.n = count;
+  a.d = d;
+  a.metric = ix->metric;
+  a.order = ix->order;
+  a.k = want;
+  a.q_nonzero = qnz;
+  a.part_keys = c.dPartKeys.p;
+  a.part_pay = c.dPartPay.p;
+  a.status = c.dStatus.p;
+  VT_HIP(vt::launch_scan(a, blocks, c.stream));
+  VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, lists * want, want, 0, 0, status, dst, c.dSelKeys.p, c.dSelPay.p,
+                           c.stream));
+  return VT_OK;
+}
+
+// True when every stage of a funnel fits one fused pass on the device.
+bool funnel_fits_device(const vt_flat *ix, const size_t *stages, size_t nstages, size_t candidates, size_t limit) {
+  if (candidates > (size_t)vt::kMaxFusedK || limit > (size_t)vt::kMaxFusedK) return false;
+  if (ix->metric == VT_JACCARD && ix->dim >= 4096) return false;
+  auto fits = [&](uint32_t d, uint32_t k, bool all_rows) {
+    if (ix->metric == VT_COSINE) return all_rows ? vt::cosine_scan_lds_bytes(d, k) != 0 : (size_t)2 * d * 4 + 64 <= 160 * 1024;
+    return vt::scan_lds_bytes(d, k) != 0;
+  };
+  for (size_t i = 0; i < nstages; ++i)
+    if (!fits((uint32_t)stages[i], (uint32_t)std::min<size_t>(candidates, ix->n), i == 0)) return false;
+  return fits((uint32_t)ix->dim, (uint32_t)std::min<size_t>(limit, ix->n), false);
 }
 
 // Candidate rows of one funnel pass (collection.ex:674-691) without the final rerank.
@@ -1521,11 +1641,35 @@ int vt_flat_funnel_search(vt_flat *ix, const float *query, size_t n, const size_
   VT_TRY(index_sync_ranks(ix, false));
   uint32_t qnz_full = 0;
   VT_TRY(upload_query(c, query, n, &qnz_full));
+  std::vector<vt::Entry> entries;
+  if (funnel_fits_device(ix, stages, nstages, candidates, limit)) {
+    // the whole funnel as one chain of kernels: each stage's winners stay in a
+    // device block whose row column is the next stage's gather list; one wait
+    VT_TRY(c.dStage.ensure(2));
+    const ResultBlock *src = nullptr;
+    uint32_t count = ix->n;
+    for (size_t i = 0; i < nstages; ++i) {
+      uint32_t nz = 0;
+      for (size_t j = 0; j < stages[i]; ++j) nz += query[j] != 0.0f ? 1u : 0u;
+      const uint32_t want = (uint32_t)std::min<size_t>(candidates, count);
+      ResultBlock *dst = c.dStage.p + (i & 1);
+      VT_TRY(funnel_stage_dev(ix, query, (uint32_t)stages[i], src, count, want, nz, dst, false));
+      src = dst;
+      count = want;
+    }
+    // exact_rerank on the full vectors (collection.ex:821-851)
+    const uint32_t want = (uint32_t)std::min<size_t>(limit, count);
+    VT_TRY(funnel_stage_dev(ix, query, (uint32_t)ix->dim, src, count, want, qnz_full, c.dResMapped, true));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    VT_TRY(c.settle_prefix_profile());
+    if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
+    entries.assign(c.hRes.p->e, c.hRes.p->e + c.hRes.p->count);
+    return make_hits(ix, entries, out);
+  }
   std::vector<uint32_t> rows;
   VT_TRY(funnel_rows(ix, query, stages, nstages, candidates, rows));
   if (rows.empty()) return empty_hits(out);
   // exact_rerank on the full vectors (collection.ex:821-851)
-  std::vector<vt::Entry> entries;
   VT_TRY(funnel_stage(ix, query, (uint32_t)ix->dim, rows, false, limit, qnz_full, entries));
   return make_hits(ix, entries, out);
   });

@@ -295,8 +295,10 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
   }
   if (tid == 0) {
     out->count = nsel;
-    out->status = *dev_status;
-    *dev_status = 0;
+    // dev_status == nullptr: an intermediate stage -- the flag stays where it is
+    // and reaches the host with the last select of the chain
+    out->status = dev_status ? *dev_status : 0;
+    if (dev_status) *dev_status = 0;
   }
 }
 
@@ -567,44 +569,54 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_kernel(cons
 
   WaveTopK<CAP> tk;
   tk.init(tkbuf, a.k);
+  // The panel after the one being summed is already on its way: its 16 loads are
+  // issued as soon as the current panel has been parked in LDS, so a wave keeps
+  // 16 KiB in flight through its f64 chain phase (without this the kernel sat at
+  // 4.3 TB/s of prefix bytes; a plain strided read of the same bytes does 6.5).
+  f32x4 v[16];
+  auto issue = [&](uint32_t t, uint32_t p) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      uint32_t r = t * kCsRows + 4 * s + (lane >> 4);
+      r = r < a.n ? r : a.n - 1;
+      v[s] = __builtin_nontemporal_load(
+          reinterpret_cast<const f32x4 *>(a.X + (size_t)r * a.stride + p * kCsPanel + (lane & 15) * 4));
+    }
+  };
+  if (wave_global < ntiles) issue(wave_global, 0);
   for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
     const uint32_t grow = t * kCsRows + lane;
     const bool valid_row = grow < a.n;
     const uint32_t my_rank = (valid_row && a.id_rank) ? a.id_rank[grow] : grow;
     double xx = 0.0, qx = 0.0;
     for (uint32_t p = 0; p < npanel; ++p) {
-      f32x4 v[16];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        uint32_t r = t * kCsRows + 4 * s + (lane >> 4);
-        r = r < a.n ? r : a.n - 1;
-        v[s] = __builtin_nontemporal_load(
-            reinterpret_cast<const f32x4 *>(a.X + (size_t)r * a.stride + p * kCsPanel + (lane & 15) * 4));
-      }
 #pragma unroll
       for (int s = 0; s < 16; ++s)
         *reinterpret_cast<f32x4 *>(S + (4 * s + (lane >> 4)) * kCsStride + (lane & 15) * 4) = v[s];
       wave_lds_fence();
+      if (p + 1 < npanel) issue(t, p + 1);
+      else if (t + total_waves < ntiles) issue(t + total_waves, 0);
       const uint32_t cnt = a.d - p * kCsPanel < (uint32_t)kCsPanel ? a.d - p * kCsPanel : (uint32_t)kCsPanel;
       const float *Sr = S + lane * kCsStride;
       const float *qp = qs + p * kCsPanel;
+      // fma(x, y, acc) == acc + x*y here: the product of two f32 is exact in f64
       uint32_t j = 0;
       for (; j + 4 <= cnt; j += 4) {
         const f32x4 xv = *reinterpret_cast<const f32x4 *>(Sr + j);
         const f32x4 qv = *reinterpret_cast<const f32x4 *>(qp + j);
-        xx += (double)xv.x * (double)xv.x;
-        qx += (double)qv.x * (double)xv.x;
-        xx += (double)xv.y * (double)xv.y;
-        qx += (double)qv.y * (double)xv.y;
-        xx += (double)xv.z * (double)xv.z;
-        qx += (double)qv.z * (double)xv.z;
-        xx += (double)xv.w * (double)xv.w;
-        qx += (double)qv.w * (double)xv.w;
+        xx = __builtin_fma((double)xv.x, (double)xv.x, xx);
+        qx = __builtin_fma((double)qv.x, (double)xv.x, qx);
+        xx = __builtin_fma((double)xv.y, (double)xv.y, xx);
+        qx = __builtin_fma((double)qv.y, (double)xv.y, qx);
+        xx = __builtin_fma((double)xv.z, (double)xv.z, xx);
+        qx = __builtin_fma((double)qv.z, (double)xv.z, qx);
+        xx = __builtin_fma((double)xv.w, (double)xv.w, xx);
+        qx = __builtin_fma((double)qv.w, (double)xv.w, qx);
       }
       for (; j < cnt; ++j) {
         const double xd = (double)Sr[j];
-        xx += xd * xd;
-        qx += (double)qp[j] * xd;
+        xx = __builtin_fma(xd, xd, xx);
+        qx = __builtin_fma((double)qp[j], xd, qx);
       }
       wave_lds_fence();
     }
