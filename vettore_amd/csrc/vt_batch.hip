@@ -61,20 +61,36 @@ __device__ __noinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v
   }
 }
 
-// NT: 32-query tiles in the batch (a wave covers them all); RT: 32-row groups per
-// wave (RT = 2: 64 rows x 256 queries = 256 accumulator registers, 256 MFMAs per
-// barrier); NS: LDS stages (the DMA runs NS - 1 chunks ahead of the MFMAs).
-template <int NT, int RT, int NS, bool DENSE>
+// NT: 32-query tiles in the batch (a wave covers them all: 32 rows x NT*32
+// queries, NT*16 accumulator registers).
+//
+// The block's work is ONE sequence of 32-k chunks running through all of its row
+// tiles, carried by a ring of three LDS stages:
+//   * the DMA of chunk m+2 is issued in quarters under the four MFMA steps of
+//     chunk m -- across tile boundaries too, so a new tile starts with its first
+//     two chunks already on their way (a first version drained the ring per tile:
+//     a full HBM latency without MFMAs every 24 chunks);
+//   * after step 2 of chunk m every wave waits for ITS pieces of chunk m+1
+//     (counted vmcnt: the three quarters of chunk m+2 just issued stay in flight)
+//     and for its own fragment reads, then one raw s_barrier: chunk m+1 is
+//     complete for everybody and nobody reads the stage of chunk m-1 any more;
+//   * under step 3 the fragments of chunk m+1's first step are read, so the MFMA
+//     stream does not stop at the chunk boundary either.
+// (64 rows per wave with two stages was measured 10 % slower: no registers left to
+// pipeline the fragment reads.)
+template <int NT, bool DENSE>
 __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const BatchScoreArgs a) {
-  extern __shared__ __align__(16) float qlds[];  // [NS][NT*32][32] queries, then [NS][4 waves][RT*32][32] rows
+  extern __shared__ __align__(16) float qlds[];  // [3][NT*32][32] queries, then [3][4 waves][32][32] rows
+  constexpr int NS = 3;
   constexpr int NQ = NT * 32;
-  constexpr int kWaveRows = RT * 32;
-  constexpr int kTileRowsB = kRowWaves * kWaveRows;
+  constexpr int kTileRowsB = kRowWaves * 32;
   const int lane = threadIdx.x & (kWave - 1);
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
   const uint32_t nchunk = a.ld / 32;
   const uint32_t ntiles = (a.n + kTileRowsB - 1) / kTileRowsB;
+  if (blockIdx.x >= ntiles) return;
+  const uint32_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
 
   // thresholds of the query columns this lane sees (column = 32*t + r)
   float tau[NT];
@@ -83,13 +99,14 @@ __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const Bat
 
   // Staging by LDS-DMA: one wave instruction fills 8 rows (1 KiB); lane L lands
   // in row L/8, physical slot L%8 and fetches logical slot (L%8) ^ ((row >> 1) & 7)
-  // of that row.  Per-lane source pointers are set up once and advanced by the
-  // chunk; the pieces are issued one at a time so they can be spread between
-  // the MFMAs of a chunk.
+  // of that row.  Per-lane source pointers are set up once per tile and advanced
+  // by the chunk.
   constexpr int kDmaQ = NQ / 8 / kRowWaves;  // Q pieces per wave per chunk
-  constexpr int kDmaX = RT * 4;              // X pieces per wave per chunk
+  constexpr int kDmaX = 4;                   // X pieces per wave per chunk (32 rows)
   static_assert(kDmaQ * 8 * kRowWaves == NQ, "query rows split evenly over the waves");
   constexpr int kDmaPerChunk = kDmaQ + kDmaX;
+  // pieces of a chunk issued with steps 0..2 (piece i goes with step i % 4)
+  constexpr int kDmaBy3 = (kDmaQ < 3 ? kDmaQ : (kDmaQ / 4) * 3 + (kDmaQ % 4 < 3 ? kDmaQ % 4 : 3)) + 3;
   // physical 16-B slot of logical slot s in row q
   auto qslot = [&](uint32_t q, uint32_t s) { return s ^ ((q >> 1) & 7); };
   const float *qsrc[kDmaQ];
@@ -103,156 +120,154 @@ __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const Bat
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qsrc[i] + c * 32),
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
   };
-  // this wave's RT*32 X rows: RT*4 pieces of 8 whole lines each
-  float *xlds = qlds + NS * (NQ * kQStride) + wid * (kWaveRows * kQStride);
-  const float *xsrc[kDmaX];
+  float *xlds = qlds + NS * (NQ * kQStride) + wid * (32 * kQStride);
+  const float *xsrc[kDmaX];  // of the tile the DMA cursor is in
   auto dma_x = [&](int i, uint32_t c, int stage) {
-    float *dst = xlds + stage * (kRowWaves * kWaveRows * kQStride) + i * 8 * kQStride;
+    float *dst = xlds + stage * (kRowWaves * 32 * kQStride) + i * 8 * kQStride;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xsrc[i] + c * 32),
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
   };
-  // all of a chunk's pieces, or the share that goes with step j of the MFMA loop
+  auto tile_row0 = [&](uint32_t k) {
+    const uint32_t tile = blockIdx.x + k * gridDim.x;
+    return (DENSE ? tile * a.sample_stride : tile) * kTileRowsB + wid * 32;  // DENSE: a strided sample of the tiles
+  };
+  auto set_xsrc = [&](uint32_t k) {
+    const uint32_t row0 = tile_row0(k);
+#pragma unroll
+    for (int i = 0; i < kDmaX; ++i) {
+      const uint32_t xr = (uint32_t)i * 8 + (lane >> 3);  // row within the wave's rows
+      uint32_t grow = row0 + xr;
+      grow = grow < a.n_total ? grow : a.n_total - 1;  // clamped for the load, masked in the epilogue
+      xsrc[i] = a.X + (size_t)grow * a.stride + qslot(xr, lane & 7) * 4;
+    }
+  };
   auto dma_chunk = [&](uint32_t c, int stage) {
 #pragma unroll
     for (int i = 0; i < kDmaX; ++i) dma_x(i, c, stage);
 #pragma unroll
     for (int i = 0; i < kDmaQ; ++i) dma_q(i, c, stage);
   };
-  // With two stages the chunk must land within the iteration that issues it, so
-  // its pieces go out with the first two steps; with three stages they spread
-  // over all four.
-  constexpr int kDmaSteps = NS == 2 ? 2 : 4;
-  auto dma_step = [&](int j, uint32_t c, int stage) {
-    if (j >= kDmaSteps) return;
-#pragma unroll
-    for (int i = 0; i < kDmaX; ++i)
-      if (i % kDmaSteps == j) dma_x(i, c, stage);
-#pragma unroll
-    for (int i = 0; i < kDmaQ; ++i)
-      if (i % kDmaSteps == j) dma_q(i, c, stage);
+  // DMA cursor: tile dk (of this block's), chunk dc
+  uint32_t dk = 0, dc = 0;
+  // past the end of the sequence the cursor stays on the last chunk: the steady
+  // state keeps issuing (into a stage nobody reads any more) so that the loop body
+  // has no branches and the vmcnt arithmetic never changes
+  auto dma_advance = [&]() {
+    if (dc + 1 == nchunk && dk + 1 == my_tiles) return;
+    dc += 1;
+    if (dc == nchunk) {
+      dc = 0;
+      dk += 1;
+      set_xsrc(dk);
+    }
   };
 
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // DENSE (pass 0) visits a strided sample of the tiles
-    const uint32_t rtile = DENSE ? tile * a.sample_stride : tile;
-    const uint32_t row0 = rtile * kTileRowsB + wid * kWaveRows;
-    // rows past the end are clamped for the load and masked in the epilogue
+  f32x4 xa, qv[NT], xa_n, qv_n[NT];
+  auto read_frags = [&](int stage, int j, f32x4 &xd, f32x4 *qd) {
+    // the swizzle depends only on r (tile bases are multiples of 32 rows)
+    const uint32_t so = qslot(r, 4 * h + j) * 4;
+    const float *xb = xlds + stage * (kRowWaves * 32 * kQStride) + r * kQStride;
+    const float *qb = qlds + stage * (NQ * kQStride) + r * kQStride;
+    xd = *reinterpret_cast<const f32x4 *>(xb + so);
 #pragma unroll
-    for (int i = 0; i < kDmaX; ++i) {
-      const uint32_t xr = (uint32_t)i * 8 + (lane >> 3);  // row within the wave's rows
-      uint32_t grow = row0 + xr;
-      grow = grow < a.n_total ? grow : a.n_total - 1;
-      xsrc[i] = a.X + (size_t)grow * a.stride + qslot(xr, lane & 7) * 4;
-    }
+    for (int t = 0; t < NT; ++t) qd[t] = *reinterpret_cast<const f32x4 *>(qb + so + t * 32 * kQStride);
+  };
 
-    f32x16 acc[RT][NT];
-#pragma unroll
-    for (int g = 0; g < RT; ++g)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[g][t][i] = 0.f;
+  // ring prologue: chunks 0 and 1 of the sequence, fragments of (chunk 0, step 0)
+  set_xsrc(0);
+  dma_chunk(0, 0);
+  dma_advance();
+  dma_chunk(dc, 1);
+  dma_advance();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerChunk) : "memory");
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, 0, xa, qv);
 
-    // NS LDS stages, DMA NS-1 chunks ahead of the MFMAs.  Raw s_barrier + counted
-    // vmcnt: a __syncthreads() would drain the DMA that is meant to stay in flight.
-    __builtin_amdgcn_s_barrier();  // every wave is done reading the previous tile's stages
-    dma_chunk(0, 0);
-    if (NS == 3 && nchunk > 1) {
-      dma_chunk(1, 1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerChunk) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
+  int stage = 0;
+  for (uint32_t k = 0; k < my_tiles; ++k) {
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    int stage = 0;
     for (uint32_t c = 0; c < nchunk; ++c) {
-      const int stage_a = (stage + NS - 1) % NS;  // stage of chunk c + NS - 1 == the one read in iteration c - 1
-      const bool ahead = c + (NS - 1) < nchunk;
-      const float *xb = xlds + stage * (kRowWaves * kWaveRows * kQStride) + r * kQStride;
-      // the swizzle depends only on r (tile bases are multiples of 32 rows), so the
-      // per-tile address is a constant offset from four per-lane bases
-      const float *qb = qlds + stage * (NQ * kQStride) + r * kQStride;
-      // software pipeline over the four 8-k steps (RT == 1): fragments of step j+1
-      // are read while step j's MFMAs run; with 64 rows per wave the accumulators
-      // already take half the register file, so the fragments are read per step
-      // (there are twice as many MFMAs per read to hide them behind).
-      constexpr bool kPipe = RT == 1;
-      f32x4 xa[RT], qv[NT], xa_n[kPipe ? RT : 1], qv_n[kPipe ? NT : 1];
-      auto read_frags = [&](int j, f32x4 *xd, f32x4 *qd) {
-        const uint32_t so = qslot(r, 4 * h + j) * 4;
-#pragma unroll
-        for (int g = 0; g < RT; ++g) xd[g] = *reinterpret_cast<const f32x4 *>(xb + so + g * 32 * kQStride);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) qd[t] = *reinterpret_cast<const f32x4 *>(qb + so + t * 32 * kQStride);
-      };
-      if (kPipe) read_frags(0, xa, qv);
+      const int stage_n = stage == NS - 1 ? 0 : stage + 1;      // chunk m + 1
+      const int stage_a = stage_n == NS - 1 ? 0 : stage_n + 1;  // chunk m + 2 == the stage chunk m - 1 was read from
+      const uint32_t cdma = dc;
+      // One step = 32-k quarter of the chunk: NT*4 MFMAs.  Everything else the step
+      // has to issue is pinned between them, one item per MFMA, so that nothing
+      // piles up in front of the matrix pipe: the NT+1 fragment reads of the next
+      // step (under the first NT MFMAs) and this step's share of chunk m+2's DMA
+      // (one piece under each of the three remaining groups).
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (kPipe) {
-          if (j < 3) read_frags(j + 1, xa_n, qv_n);
-        } else {
-          read_frags(j, xa, qv);
-        }
-        if (ahead) dma_step(j, c + (NS - 1), stage_a);
+        const int rs = j < 3 ? stage : stage_n;  // step 3 reads (chunk m+1, step 0)
+        const uint32_t so = qslot(r, 4 * h + (j < 3 ? j + 1 : 0)) * 4;
+        const float *xb = xlds + rs * (kRowWaves * 32 * kQStride) + r * kQStride + so;
+        const float *qb = qlds + rs * (NQ * kQStride) + r * kQStride + so;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
-          for (int g = 0; g < RT; ++g)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-              acc[g][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[g][e], qv[t][e], acc[g][t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], qv[t][e], acc[t], 0, 0, 0);
+            if (e == 0) {
+              if (t == 0) xa_n = *reinterpret_cast<const f32x4 *>(xb);
+              qv_n[t] = *reinterpret_cast<const f32x4 *>(qb + t * 32 * kQStride);
+            } else if (t == 0) {
+              if (e == 1) dma_x(j, cdma, stage_a);
+              if (e == 2 && j < kDmaQ) dma_q(j, cdma, stage_a);
+              if (e == 3 && j + 4 < kDmaQ) dma_q(j + 4, cdma, stage_a);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
-        if (kPipe && j < 3) {
-#pragma unroll
-          for (int g = 0; g < RT; ++g) xa[g] = xa_n[g];
-#pragma unroll
-          for (int t = 0; t < NT; ++t) qv[t] = qv_n[t];
+        if (j == 2) {
+          // my pieces of chunk m+1 have landed, my reads of chunk m are done
+          if (!(a.debug & 4u)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kDmaBy3) : "memory");
+          if (!(a.debug & 2u)) __builtin_amdgcn_s_barrier();
         }
+        xa = xa_n;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) qv[t] = qv_n[t];
       }
-      // chunk c + 1 must have landed for everyone before anyone reads it
-      if (NS == 3 && ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerChunk) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      stage = stage == NS - 1 ? 0 : stage + 1;
+      dma_advance();
+      stage = stage_n;
     }
 
     // epilogue, one 32x32 tile at a time (C layout: column = lane & 31,
     // row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5))
+    const uint32_t grow0 = tile_row0(k);
+    float xn[16];
+    if (a.xnorm2) {
 #pragma unroll
-    for (int g = 0; g < RT; ++g) {
-      const uint32_t grow0 = row0 + g * 32;
-      float xn[16];
+      for (int i = 0; i < 16; ++i) {
+        const uint32_t row = grow0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        xn[i] = a.xnorm2[row < a.n_total ? row : a.n_total - 1];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const uint32_t qcol = t * 32 + r;
+      f32x16 v = acc[t];
       if (a.xnorm2) {
+        // L2 family: rank by s = 2 q.x - |x|^2 (larger s <=> smaller |q - x|^2)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 2.0f * v[i] - xn[i];
+      }
+      if (DENSE) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const uint32_t row = grow0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          xn[i] = a.xnorm2[row < a.n_total ? row : a.n_total - 1];
+          const uint32_t off = (i & 3) + 8 * (i >> 2) + 4 * h;
+          // dense sample matrix [query][sample row]
+          const uint32_t srow = (blockIdx.x + k * gridDim.x) * kTileRowsB + wid * 32 + off;
+          a.sample[(size_t)qcol * a.sample_rows + srow] = grow0 + off < a.n_total ? v[i] : -INFINITY;
         }
-      }
+      } else {
+        float mx = v[0];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const uint32_t qcol = t * 32 + r;
-        f32x16 v = acc[g][t];
-        if (a.xnorm2) {
-          // L2 family: rank by s = 2 q.x - |x|^2 (larger s <=> smaller |q - x|^2)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = 2.0f * v[i] - xn[i];
-        }
-        if (DENSE) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const uint32_t off = (i & 3) + 8 * (i >> 2) + 4 * h;
-            // dense sample matrix [query][sample row]
-            const uint32_t srow = tile * kTileRowsB + wid * kWaveRows + g * 32 + off;
-            a.sample[(size_t)qcol * a.sample_rows + srow] = grow0 + off < a.n_total ? v[i] : -INFINITY;
-          }
-        } else {
-          float mx = v[0];
-#pragma unroll
-          for (int i = 1; i < 16; ++i) mx = fmaxf(mx, v[i]);
-          if (mx >= tau[t]) append_candidates(a, v, tau[t], qcol, grow0, h);
-        }
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, v[i]);
+        if (mx >= tau[t] && !(a.debug & 8u)) append_candidates(a, v, tau[t], qcol, grow0, h);
       }
     }
   }
@@ -280,13 +295,25 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
         bi = i;
       }
     }
-    s_best[threadIdx.x] = best;
-    s_idx[threadIdx.x] = bi;
+    // wave reduction by shuffles, then the four wave winners by thread 0
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float ob = __shfl_xor(best, o, kWave);
+      const uint32_t oi = __shfl_xor(bi, o, kWave);
+      if (ob > best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+      s_best[threadIdx.x >> 6] = best;
+      s_idx[threadIdx.x >> 6] = bi;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
       float b = -INFINITY;
       uint32_t ix = 0xFFFFFFFFu;
-      for (int t = 0; t < 256; ++t)
+      for (int t = 0; t < 4; ++t)
         if (s_best[t] > b || (s_best[t] == b && s_idx[t] < ix)) {
           b = s_best[t];
           ix = s_idx[t];
@@ -359,18 +386,18 @@ __global__ __launch_bounds__(256) void batch_select_kernel(const uint64_t *__res
   if (threadIdx.x == 0) out_count[blockIdx.x] = s_live < k ? s_live : k;
 }
 
-template <int NT, int RT, int NS>
+template <int NT>
 hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
-  const size_t lds = (size_t)NS * (NT * 32 + kRowWaves * RT * 32) * kQStride * sizeof(float);
+  const size_t lds = (size_t)3 * (NT * 32 + kRowWaves * 32) * kQStride * sizeof(float);
   const dim3 block(kRowWaves * kWave);
   if (dense) {
-    auto kern = mfma_scores_kernel<NT, RT, NS, true>;
+    auto kern = mfma_scores_kernel<NT, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
   } else {
-    auto kern = mfma_scores_kernel<NT, RT, NS, false>;
+    auto kern = mfma_scores_kernel<NT, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
@@ -379,26 +406,20 @@ hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks
   return hipGetLastError();
 }
 
-// 32 rows per wave with three stages measured 118 TF against 106 TF for 64 rows
-// per wave with two (N=2M, B=256): the wide tile has no registers left to
-// pipeline its fragment reads.  VT_BATCH_WIDE=1 selects it for experiments.
-bool batch_wide() {
-  static const bool wide = std::getenv("VT_BATCH_WIDE") != nullptr;
-  return wide;
-}
-
 }  // namespace
 
-uint32_t batch_rows_per_block() { return kRowWaves * 32 * (batch_wide() ? 2 : 1); }
+uint32_t batch_rows_per_block() { return kRowWaves * 32; }
 
-hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
+hipError_t launch_batch_scores(const BatchScoreArgs &a0, bool dense, uint32_t blocks, hipStream_t s) {
+  BatchScoreArgs a = a0;
+  static const uint32_t dbg = std::getenv("VT_BATCH_DEBUG") ? (uint32_t)std::atoi(std::getenv("VT_BATCH_DEBUG")) : 0u;
+  a.debug = dense ? 0u : dbg;
   if (a.ld % 32 != 0 || a.nq_pad % 32 != 0 || a.nq_pad == 0 || a.nq_pad > 256) return hipErrorInvalidValue;
-  const bool wide = batch_wide();
   switch (a.nq_pad / 32) {
-    case 1: return wide ? launch_scores_nt<1, 2, 2>(a, dense, blocks, s) : launch_scores_nt<1, 1, 3>(a, dense, blocks, s);
-    case 2: return wide ? launch_scores_nt<2, 2, 2>(a, dense, blocks, s) : launch_scores_nt<2, 1, 3>(a, dense, blocks, s);
-    case 4: return wide ? launch_scores_nt<4, 2, 2>(a, dense, blocks, s) : launch_scores_nt<4, 1, 3>(a, dense, blocks, s);
-    case 8: return wide ? launch_scores_nt<8, 2, 2>(a, dense, blocks, s) : launch_scores_nt<8, 1, 3>(a, dense, blocks, s);
+    case 1: return launch_scores_nt<1>(a, dense, blocks, s);
+    case 2: return launch_scores_nt<2>(a, dense, blocks, s);
+    case 4: return launch_scores_nt<4>(a, dense, blocks, s);
+    case 8: return launch_scores_nt<8>(a, dense, blocks, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -169,6 +169,7 @@ struct BatchScoreArgs {
   uint32_t *cand_count;   // pass 1: [nq_pad], may exceed cand_cap (overflow)
   uint32_t cand_cap;
   const float *xnorm2;    // null: score = q.x; else score = 2 q.x - xnorm2[row] (= |q|^2 - |q - x|^2)
+  uint32_t debug;         // VT_BATCH_DEBUG timing experiments (results invalid when non-zero)
 };
 uint32_t batch_rows_per_block();
 hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s);
