@@ -1,0 +1,73 @@
+#!/bin/bash
+# Regenerates the rocprofv3 evidence under profiles/ on a GPU box (run from the repo root):
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'
+# Kernel-trace/stats runs and PMC runs are separate passes, as the pool requires.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+stats() {  # name, bench args...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o p -- python3 $R/bench.py "$@" > $OUT/$name.log 2>&1
+  tail -1 $OUT/$name.log > $OUT/$name.json
+}
+pmc() {  # name, counter, bench args...
+  local name=$1 ctr=$2; shift 2
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$name -o p -- python3 $R/bench.py "$@" > $OUT/$name.log 2>&1
+}
+stats single
+pmc single_fetch FETCH_SIZE --steps 20 --warmup 2 --no-cpu
+pmc single_write WRITE_SIZE --steps 20 --warmup 2 --no-cpu
+stats batch --mode batch --steps 6 --warmup 1 --no-cpu
+stats quantized --mode quantized --steps 300 --warmup 20 --no-cpu
+pmc quantized_fetch FETCH_SIZE --mode quantized --steps 20 --warmup 2 --no-cpu
+stats funnel --mode funnel --steps 200 --warmup 5 --no-cpu
+cd $R
+python3 - <<'PY'
+import csv, glob, json, os
+out = 'gpurun_out/prof'
+def trim(src, dst):
+    rows = list(csv.reader(open(src)))
+    with open(dst, 'w', newline='') as f:
+        w = csv.writer(f)
+        for r in rows:
+            r[0] = r[0][:140]
+            w.writerow(r)
+for name in ('single', 'batch', 'quantized', 'funnel'):
+    trim('%s/%s/p_kernel_stats.csv' % (out, name), '%s/r01_%s_kernel_stats.csv' % (out, name))
+def per_launch(path, kernel_substr, counter):
+    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
+            if kernel_substr in r['Kernel_Name'] and r['Counter_Name'] == counter]
+    return sum(vals) / len(vals), len(vals)
+def keep(path, dst, kernel_substr):
+    rows = list(csv.DictReader(open(path)))
+    with open(dst, 'w', newline='') as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        for r in rows:
+            if kernel_substr in r['Kernel_Name']:
+                r['Kernel_Name'] = r['Kernel_Name'][:140]
+                w.writerow(r)
+keep(out + '/single_fetch/p_counter_collection.csv', out + '/r01_single_pmc_fetch.csv', 'scan_topk_kernel')
+keep(out + '/single_write/p_counter_collection.csv', out + '/r01_single_pmc_write.csv', 'scan_topk_kernel')
+keep(out + '/quantized_fetch/p_counter_collection.csv', out + '/r01_quantized_pmc_fetch.csv', 'hamming_topk_kernel')
+fetch, n1 = per_launch(out + '/single_fetch/p_counter_collection.csv', 'scan_topk_kernel', 'FETCH_SIZE')
+write, n2 = per_launch(out + '/single_write/p_counter_collection.csv', 'scan_topk_kernel', 'WRITE_SIZE')
+stat = [r for r in csv.DictReader(open(out + '/single/p_kernel_stats.csv')) if 'scan_topk_kernel' in r['Name']][0]
+json.dump({
+    "round": 1,
+    "command": "python3 bench.py  (N=10M, d=768, cosine, limit 10; PMC passes: --steps 20 --warmup 2 --no-cpu)",
+    "rows": 10000000, "dim": 768, "kernel": stat['Name'],
+    "rocprof_avg_ns": float(stat['AverageNs']), "rocprof_calls": int(stat['Calls']),
+    "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
+    "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2 for 16-B/lane streaming reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; unit KiB",
+    "hbm_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
+}, open(out + '/pmc_latest.json', 'w'), indent=1)
+hf, _ = per_launch(out + '/quantized_fetch/p_counter_collection.csv', 'hamming_topk_kernel', 'FETCH_SIZE')
+print("hamming FETCH_SIZE KiB per launch", hf, "x2 bytes", 2 * hf * 1024)
+for name in ('single', 'batch', 'quantized', 'funnel'):
+    print(open('%s/%s.json' % (out, name)).read().strip())
+    for r in csv.DictReader(open('%s/%s/p_kernel_stats.csv' % (out, name))):
+        if 'vt::' in r['Name']:
+            print('   ', r['Name'][:70], r['Calls'], r['AverageNs'])
+PY

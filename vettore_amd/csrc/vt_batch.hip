@@ -273,29 +273,50 @@ __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const Bat
   }
 }
 
-// tau_b = the `rank`-th largest of the query's sample scores (one block per query).
-__global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict__ sample, uint32_t sample_rows,
-                                                         uint32_t rank, float *__restrict__ tau) {
-  __shared__ float s_best[256];
-  __shared__ uint32_t s_idx[256];
+// tau_b = the `rank`-th largest of the query's sample scores (one block per query):
+// `rank` rounds of "largest value not yet taken" (ties by index).  1024 threads,
+// 16-B loads, four in flight per thread: the sample row (256 KiB at 512 tiles)
+// comes out of L2 once per round.
+constexpr int kTauThreads = 1024;
+__global__ __launch_bounds__(kTauThreads) void sample_tau_kernel(const float *__restrict__ sample, uint32_t sample_rows,
+                                                                 uint32_t rank, float *__restrict__ tau) {
+  __shared__ float s_best[kTauThreads / kWave];
+  __shared__ uint32_t s_idx[kTauThreads / kWave];
   __shared__ float s_cut;
   __shared__ uint32_t s_cutidx;
   const float *v = sample + (size_t)blockIdx.x * sample_rows;
-  float cut = INFINITY;      // values >= cut (ties by index) were already taken
+  const f32x4 *v4 = reinterpret_cast<const f32x4 *>(v);
+  const uint32_t n4 = sample_rows / 4;  // sample_rows is a multiple of 128
+  float cut = INFINITY;                 // values >= cut (ties by index) were already taken
   uint32_t cutidx = 0xFFFFFFFFu;
   float result = -INFINITY;
   for (uint32_t round = 0; round < rank; ++round) {
     float best = -INFINITY;
     uint32_t bi = 0xFFFFFFFFu;
-    for (uint32_t i = threadIdx.x; i < sample_rows; i += blockDim.x) {
-      const float x = v[i];
+    auto consider = [&](float x, uint32_t i) {
       const bool taken = x > cut || (x == cut && i <= cutidx);
       if (!taken && (x > best || (x == best && i < bi))) {
         best = x;
         bi = i;
       }
+    };
+    for (uint32_t i = threadIdx.x; i < n4; i += 4 * kTauThreads) {
+      f32x4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t j = i + u * kTauThreads;
+        x[u] = j < n4 ? v4[j] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t j = 4 * (i + u * kTauThreads);
+        consider(x[u].x, j);
+        consider(x[u].y, j + 1);
+        consider(x[u].z, j + 2);
+        consider(x[u].w, j + 3);
+      }
     }
-    // wave reduction by shuffles, then the four wave winners by thread 0
+    // wave reduction by shuffles, then the wave winners by thread 0
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
       const float ob = __shfl_xor(best, o, kWave);
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
     if (threadIdx.x == 0) {
       float b = -INFINITY;
       uint32_t ix = 0xFFFFFFFFu;
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < kTauThreads / kWave; ++t)
         if (s_best[t] > b || (s_best[t] == b && s_idx[t] < ix)) {
           b = s_best[t];
           ix = s_idx[t];
@@ -426,7 +447,7 @@ hipError_t launch_batch_scores(const BatchScoreArgs &a0, bool dense, uint32_t bl
 
 hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t rank, float *tau,
                              hipStream_t s) {
-  hipLaunchKernelGGL(sample_tau_kernel, dim3(nq), dim3(256), 0, s, sample, sample_rows, rank, tau);
+  hipLaunchKernelGGL(sample_tau_kernel, dim3(nq), dim3(kTauThreads), 0, s, sample, sample_rows, rank, tau);
   return hipGetLastError();
 }
 
