@@ -50,6 +50,18 @@ def _worker(rank, world, port, outq):
                 got = sf.search(q, 10)
                 whole = oracle.matrix_search(metric, x, oracle.pack_ids(ids), q, 10)
                 results.append(got == whole)
+        # the global id ranking behind the device-side exchange: uneven shards, ids that
+        # sort differently bytewise and numerically ("doc-10" < "doc-9")
+        from vettore_amd.sharded import gather_global_ranks
+        ids = [b"doc-%d" % (i + 1) for i in range(1000)]
+        cut = 617
+        mine = ids[:cut] if rank == 0 else ids[cut:]
+        blob, off, bases, ranks = gather_global_ranks(dist, world, oracle.pack_ids(mine))
+        order = sorted(range(len(ids)), key=lambda i: ids[i])
+        want = np.empty(len(ids), dtype=np.int64)
+        want[order] = np.arange(len(ids))
+        results.append(list(bases) == [0, cut, len(ids)] and np.array_equal(np.asarray(ranks, dtype=np.int64), want)
+                       and all(blob[int(off[i]):int(off[i + 1])] == ids[i] for i in (0, cut - 1, cut, len(ids) - 1)))
         outq.put((rank, all(results), len(results)))
     except Exception as e:  # surface the failure instead of letting the parent time out
         outq.put((rank, False, repr(e)))
@@ -71,7 +83,7 @@ def test_two_rank_sharded_search_equals_single_index():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(o[0] for o in outs) == [0, 1]
-    assert all(o[1] for o in outs) and all(o[2] == 12 for o in outs), outs
+    assert all(o[1] for o in outs) and all(o[2] == 13 for o in outs), outs
 
 
 def test_pack_unpack_roundtrip():

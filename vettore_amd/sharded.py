@@ -74,6 +74,28 @@ def merge_shards(per_rank: List[List[Tuple[bytes, float, int]]], limit: int) -> 
     return [(h[0], h[1]) for h in allhits[:limit]]
 
 
+def gather_global_ranks(dist, world: int, local_ids_packed):
+    """Collective: every rank contributes the ids of its rows (row order); returns
+    (all ids blob, offsets, first global row of each rank, rank of every global row
+    in bytewise id order -- FlatHit::cmp's tie-break, flat.rs:34-40)."""
+    from . import nifs
+    blob, off = local_ids_packed
+    parts = [None] * world
+    dist.all_gather_object(parts, (bytes(blob), np.asarray(off, dtype=np.uint64)))
+    counts = [len(p[1]) - 1 for p in parts]
+    bases = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    all_blob = b"".join(p[0] for p in parts)
+    all_off = np.zeros(int(bases[-1]) + 1, dtype=np.uintp)
+    pos, byte0 = 0, 0
+    for p in parts:
+        o = p[1].astype(np.uintp)
+        all_off[pos:pos + len(o)] = o + byte0
+        pos += len(o) - 1
+        byte0 += len(p[0])
+    ranks = nifs.rank_ids((all_blob, all_off))
+    return all_blob, all_off, bases, ranks
+
+
 class ShardedFlat:
     """`ref` is this rank's FlatRef; `dist` is torch.distributed (initialised)
     or None for a single shard.  `local_search(query, limit)` may be injected
@@ -99,21 +121,8 @@ class ShardedFlat:
         shard's slice as its id_rank column.  `local_ids_packed` = (bytes, offsets)
         of this rank's rows in row order.  Valid until the shard is mutated."""
         from . import nifs
-        torch, dist = self._torch, self.dist
-        blob, off = local_ids_packed
-        parts = [None] * self.world
-        dist.all_gather_object(parts, (blob, np.asarray(off, dtype=np.uint64)))
-        counts = [len(p[1]) - 1 for p in parts]
-        bases = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        all_blob = b"".join(p[0] for p in parts)
-        all_off = np.zeros(int(bases[-1]) + 1, dtype=np.uintp)
-        pos, byte0 = 0, 0
-        for p in parts:
-            o = p[1].astype(np.uintp)
-            all_off[pos:pos + len(o)] = o + byte0
-            pos += len(o) - 1
-            byte0 += len(p[0])
-        ranks = nifs.rank_ids((all_blob, all_off))
+        torch = self._torch
+        all_blob, all_off, bases, ranks = gather_global_ranks(self.dist, self.world, local_ids_packed)
         mine = ranks[bases[self.rank]:bases[self.rank + 1]]
         res = nifs.flat_set_id_ranks(self.ref, mine)
         if res != "ok":
