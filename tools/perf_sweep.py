@@ -115,6 +115,12 @@ if __name__ == "__main__":
         run_batch(2, 2_000_000, 768, 256, 10, True)
         run_batch(3, 2_000_000, 768, 64, 10, False)
         run_batch(3, 10_000_000, 768, 256, 10, False, steps=3)
+    if which in ("all", "configs"):   # BASELINE.json configs 1, 2, 4 (per-GPU shard) on one GPU
+        run(2, 10_000, 384, 10, steps=300)
+        run(2, 1_000_000, 768, 10, steps=100)
+        run(0, 5_000_000, 768, 10, steps=40)
+        run_batch(0, 5_000_000, 768, 256, 10, False, steps=3)
+        run_batch(2, 10_000_000, 768, 256, 10, True, steps=3)
     if which in ("all", "small"):
         for rows in (10_000, 100_000, 1_000_000):
             run(2, rows, 768, 10, steps=100)
