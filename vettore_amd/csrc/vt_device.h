@@ -65,7 +65,14 @@ struct ScanArgs {
   // min(batch_counts[b], batch_cap) rows and writes list (b * grid.x + blockIdx.x).
   const uint32_t *batch_counts;
   uint32_t batch_cap;
+  uint32_t tile_rows;      // 0 / 32 (default), 16 or 8: rows per wave tile, see scan_tile_rows()
 };
+
+// Rows per wave tile for a scan of n rows of dimension d on `resident_waves` waves:
+// 32 when there is plenty of work per wave; 16 or 8 when there are few tiles per
+// wave (a 32-row tile of 768 floats is ~25 us of one wave's load latency, so small
+// corpora spread over more waves).  ntiles = ceil(n / result).
+uint32_t scan_tile_rows(uint32_t n, uint32_t d, uint32_t resident_waves);
 
 // LDS bytes per block the scan kernel needs for dimension d and list size k (0 = unsupported).
 size_t scan_lds_bytes(uint32_t d, uint32_t k);

@@ -231,6 +231,7 @@ struct Ctx {
     VT_HIP(hipSetDevice(device));
     return VT_OK;
   }
+  uint32_t resident_waves() const { return (uint32_t)(num_cus * blocks_per_cu * vt::kWavesPerBlock); }
   // a prefix scan timed with ev0/ev1 but not yet read back (the chained funnel waits once, at its end)
   uint32_t prefix_pending = 0;
   int settle_prefix_profile() {
@@ -341,7 +342,8 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
     return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(j.d) + " exceeds what the scan kernel stages in LDS");
   if (j.metric == VT_JACCARD && j.d >= 4096)
     return fail(VT_ERR_UNSUPPORTED, "jaccard on device supports d < 4096");
-  const uint32_t ntiles = (j.n + vt::kTileRows - 1) / vt::kTileRows;
+  const uint32_t tile_rows = vt::scan_tile_rows(j.n, j.d, c.resident_waves());
+  const uint32_t ntiles = (j.n + tile_rows - 1) / tile_rows;
   // very wide rows leave no LDS for the large candidate buffer: smaller passes
   const size_t kmax = vt::scan_lds_bytes(j.d, vt::kMaxFusedK) ? (size_t)vt::kMaxFusedK : (size_t)vt::kSmallK;
   uint64_t lo = 0;
@@ -368,6 +370,7 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
     a.lo_key = lo;
     a.has_lo = has_lo ? 1 : 0;
     a.q_nonzero = j.q_nonzero;
+    a.tile_rows = tile_rows;
     a.part_keys = c.dPartKeys.p;
     a.part_pay = c.dPartPay.p;
     a.status = c.dStatus.p;
@@ -842,7 +845,8 @@ int funnel_stage_dev(vt_flat *ix, const float *query, uint32_t d, const ResultBl
                              c.stream));
     return VT_OK;
   }
-  const uint32_t ntiles = (count + vt::kTileRows - 1) / vt::kTileRows;
+  const uint32_t tile_rows = vt::scan_tile_rows(count, d, c.resident_waves());
+  const uint32_t ntiles = (count + tile_rows - 1) / tile_rows;
   const uint32_t blocks = c.grid_for(ntiles, vt::scan_lds_bytes(d, want));
   const uint32_t lists = vt::scan_lists(blocks);
   VT_TRY(c.dPartKeys.ensure((size_t)lists * want));
@@ -860,6 +864,7 @@ int funnel_stage_dev(vt_flat *ix, const float *query, uint32_t d, const ResultBl
   a.order = ix->order;
   a.k = want;
   a.q_nonzero = qnz;
+  a.tile_rows = tile_rows;
   a.part_keys = c.dPartKeys.p;
   a.part_pay = c.dPartPay.p;
   a.status = c.dStatus.p;
@@ -1445,7 +1450,8 @@ int vt_flat_search_begin(vt_flat *ix, const float *query, size_t n, size_t limit
   VT_TRY(upload_query(c, query, n, &qnz));
   const uint32_t d = (uint32_t)ix->dim, k = (uint32_t)limit;
   if (vt::scan_lds_bytes(d, k) == 0) return fail(VT_ERR_UNSUPPORTED, "dimension/limit exceed the scan kernel's LDS");
-  const uint32_t blocks = c.grid_for((ix->n + vt::kTileRows - 1) / vt::kTileRows, vt::scan_lds_bytes(d, k));
+  const uint32_t tile_rows = vt::scan_tile_rows(ix->n, d, c.resident_waves());
+  const uint32_t blocks = c.grid_for((ix->n + tile_rows - 1) / tile_rows, vt::scan_lds_bytes(d, k));
   VT_TRY(c.dPartKeys.ensure((size_t)blocks * k));
   VT_TRY(c.dPartPay.ensure((size_t)blocks * k));
   vt::ScanArgs a{};
@@ -1459,6 +1465,7 @@ int vt_flat_search_begin(vt_flat *ix, const float *query, size_t n, size_t limit
   a.order = ix->order;
   a.k = k;
   a.q_nonzero = qnz;
+  a.tile_rows = tile_rows;
   a.part_keys = c.dPartKeys.p;
   a.part_pay = c.dPartPay.p;
   a.status = c.dStatus.p;

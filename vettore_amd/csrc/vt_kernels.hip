@@ -689,10 +689,20 @@ size_t hamming_lds_bytes(uint32_t k) {
   return kWavesPerBlock * (k <= (uint32_t)kSmallK ? WaveTopK<kCapSmall>::lds_bytes() : WaveTopK<kCapLarge>::lds_bytes());
 }
 
+uint32_t scan_tile_rows(uint32_t n, uint32_t d, uint32_t resident_waves) {
+  uint32_t want = kTileRows;
+  if ((uint64_t)n <= (uint64_t)resident_waves * 8 * 8) want = 8;        // <= 8 tiles of 8 rows per wave
+  else if ((uint64_t)n <= (uint64_t)resident_waves * 8 * 16) want = 16;
+  ScanShape p;
+  if (!make_scan_shape(d, n, &p, want)) return kTileRows;
+  return p.tr;
+}
+
 hipError_t launch_scan(const ScanArgs &a, uint32_t blocks, hipStream_t s) {
   ScanDev sd;
   sd.a = a;
-  if (!make_scan_shape(a.d, a.n, &sd.p)) return hipErrorInvalidValue;
+  if (!make_scan_shape(a.d, a.n, &sd.p, a.tile_rows ? a.tile_rows : (uint32_t)kTileRows)) return hipErrorInvalidValue;
+  sd.p.tile_floats = sd.p.tr * (uint32_t)a.stride;
   const size_t lds = scan_lds_for(sd.p, a.k);
   if (lds > kMaxLds || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.stride < sd.p.ld || a.stride % 4 != 0)
     return hipErrorInvalidValue;
@@ -709,6 +719,7 @@ hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hi
   ScanDev sd;
   sd.a = a;
   if (!make_scan_shape(a.d, a.batch_cap, &sd.p)) return hipErrorInvalidValue;
+  sd.p.tile_floats = sd.p.tr * (uint32_t)a.stride;
   const size_t lds = scan_lds_for(sd.p, a.k);
   if (lds > kMaxLds || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.stride < sd.p.ld || !a.gather || !a.batch_counts)
     return hipErrorInvalidValue;

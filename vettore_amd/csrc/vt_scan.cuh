@@ -47,9 +47,15 @@ struct ScanShape {
   uint32_t ss;         // dwords per LDS panel row, 4 * odd
   uint32_t tail_base;  // dword offset of the 8 tail-product slots in a panel row
   uint32_t ntiles;
+  uint32_t tr;         // rows per tile: 32, or 16 / 8 for small row counts (more tiles than waves)
+  uint32_t segs;       // 1-KiB segments per panel of a tile = pc * tr / 32 (multiple of kU)
+  uint32_t segs_last;
+  uint32_t tile_floats;  // tr * row stride (contiguous scans)
 };
 
-inline bool make_scan_shape(uint32_t d, uint32_t n, ScanShape *out) {
+// `tile_rows`: 32, 16 or 8 requested by the caller; a height whose panels are not a
+// whole number of kU-segment groups falls back to the next larger one.
+inline bool make_scan_shape(uint32_t d, uint32_t n, ScanShape *out, uint32_t tile_rows = kTileRows) {
   if (d == 0) return false;
   ScanShape p;
   p.ld = padded_dim(d);
@@ -68,7 +74,15 @@ inline bool make_scan_shape(uint32_t d, uint32_t n, ScanShape *out) {
   p.pc_last = cpr - (np - 1) * pc;
   p.tail_base = pc;
   p.ss = pc + 12;  // pc % 8 == 0 -> (pc + 12) / 4 is odd
-  p.ntiles = (n + kTileRows - 1) / kTileRows;
+  uint32_t tr = tile_rows == 8 || tile_rows == 16 ? tile_rows : (uint32_t)kTileRows;
+  while (tr < (uint32_t)kTileRows && ((p.pc * tr / 32) % kU != 0 || (p.pc_last * tr / 32) % kU != 0 ||
+                                      (p.pc * tr) % 32 != 0 || (p.pc_last * tr) % 32 != 0))
+    tr *= 2;
+  p.tr = tr;
+  p.segs = p.pc * tr / 32;
+  p.segs_last = p.pc_last * tr / 32;
+  p.tile_floats = 0;  // set by the launcher (needs the row stride)
+  p.ntiles = (n + tr - 1) / tr;
   *out = p;
   return true;
 }
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
   const int op_rt = metric_op(a.metric);
   const uint32_t total_waves = gridDim.x * kWavesPerBlock;
   const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
-  const uint32_t ntiles = GENERAL ? (nrows + kTileRows - 1) / kTileRows : p.ntiles;
+  const uint32_t ntiles = GENERAL ? (nrows + p.tr - 1) / p.tr : p.ntiles;
 
   WaveTopK<CAP> tk;
   tk.init(tkbuf, a.k);
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       }
     };
     auto advance = [&](Cursor &c) {
-      const uint32_t nseg = c.p == lastp ? p.pc_last : p.pc;
+      const uint32_t nseg = c.p == lastp ? p.segs_last : p.segs;
       c.s += 1;
       if (c.s == nseg) {
         c.s = 0;
@@ -254,10 +268,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       const uint32_t t = c.t < last_tile ? c.t : last_tile;  // clamp at the end of the stream
       const uint32_t colf = c.p * pw0 + c.col;
       if (!GENERAL) {
-        const float *base = a.X + (size_t)t * (kTileRows * (size_t)a.stride);
+        const float *base = a.X + (size_t)t * p.tile_floats;
         return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (c.rowi * (uint32_t)a.stride + colf)));
       }
-      const uint32_t gi = t * kTileRows + c.rowi;
+      const uint32_t gi = t * p.tr + c.rowi;
       uint32_t src = 0;
       if (gi < nrows) src = gather ? gather[(size_t)gi * a.gather_stride] : gi;
       return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.X + (size_t)src * a.stride + colf));
@@ -276,8 +290,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
     }
 
     for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
-      const uint32_t grow = t * kTileRows + lane;  // lanes 0..31 own a row
-      const bool row_valid = lane < kTileRows && grow < nrows;
+      const uint32_t grow = t * p.tr + lane;  // lanes 0..tr-1 own a row
+      const bool row_valid = (uint32_t)lane < p.tr && grow < nrows;
       uint32_t src_row = grow;
       if (GENERAL && row_valid && gather) src_row = gather[(size_t)grow * a.gather_stride];
       uint32_t my_rank = src_row;
@@ -287,10 +301,11 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       Cursor cc;
       cc.t = t;
       for (cc.p = 0; cc.p < p.npanel; ++cc.p) {
-        const uint32_t nseg = cc.p == lastp ? p.pc_last : p.pc;
+        const uint32_t nseg = cc.p == lastp ? p.pc_last : p.pc;       // chunks per row in this panel
+        const uint32_t nload = cc.p == lastp ? p.segs_last : p.segs;  // 1-KiB segments of the tile's panel
         const uint32_t c0 = cc.p * p.pc;  // first chunk of the panel
         enter_panel(cc);
-        for (uint32_t s = 0; s < nseg; s += kU) {
+        for (uint32_t s = 0; s < nload; s += kU) {
 #pragma unroll
           for (int u = 0; u < kU; ++u) {
             const f32x4 x = buf[u];
@@ -317,7 +332,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
 
         // panel complete: lane r continues row r's sequential chain
         wave_lds_fence();
-        if (lane < kTileRows) {
+        if ((uint32_t)lane < p.tr) {
           const float *Sr = S + lane * p.ss;
           uint32_t nsum = nseg;
           if (PADDED) nsum = p.cfull > c0 ? (p.cfull - c0 < nseg ? p.cfull - c0 : nseg) : 0;
