@@ -52,11 +52,11 @@ __global__ __launch_bounds__(256) void k_lds(float *out, int iters, float a0) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, q[t][e], acc[t], 0, 0, 0);
-        if (e == 0 && t < READS) qn[t] = *reinterpret_cast<const f32x4 *>(base + t * 1024);
+        if (e == 0 && t < (READS < 8 ? READS : 8)) qn[t] = *reinterpret_cast<const f32x4 *>(base + t * 1024);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-    for (int t = 0; t < READS; ++t) q[t] = qn[t];
+    for (int t = 0; t < (READS < 8 ? READS : 8); ++t) q[t] = qn[t];
   }
   float s = 0.f;
 #pragma unroll
@@ -67,13 +67,13 @@ __global__ __launch_bounds__(256) void k_lds(float *out, int iters, float a0) {
 }
 
 template <int READS>
-int run_lds() {
+int run_lds(int waves_per_simd = 1) {
   float *out;
   CK(hipMalloc((void **)&out, 64));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const int iters = 20000, blocks = 256;
+  const int iters = 20000, blocks = 256 * waves_per_simd;
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipEventRecord(e0, 0));
     k_lds<READS><<<blocks, 256>>>(out, iters, 1.0f);
@@ -82,7 +82,7 @@ int run_lds() {
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double flops = (double)blocks * 4 * iters * 32 * 4096.0;
-    if (rep == 2) printf("{\"kernel\": \"32 MFMA + %d ds_read_b128 per iteration\", \"ms\": %.2f, \"TFLOPs\": %.1f}\n", READS, ms, flops / ms / 1e9);
+    if (rep == 2) printf("{\"kernel\": \"32 MFMA + %d ds_read_b128 per iteration\", \"waves_per_simd\": %d, \"ms\": %.2f, \"TFLOPs\": %.1f}\n", READS, waves_per_simd, ms, flops / ms / 1e9);
   }
   return 0;
 }
@@ -117,5 +117,8 @@ int main() {
   run_lds<0>();
   run_lds<4>();
   run_lds<8>();
+  run_lds<9>(1);
+  run_lds<0>(2);
+  run_lds<8>(2);
   return 0;
 }
