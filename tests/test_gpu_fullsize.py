@@ -92,3 +92,50 @@ def test_config4_shape_l2_shards_merge_to_the_single_index(corpus, oracle_mod):
                [(h[0], np.float32(h[1]).tobytes()) for h in want]
         keys = _rank_keys(0, got)
         assert keys == sorted(keys)
+
+
+def test_full_size_results_against_torch_brute_force(corpus, oracle_mod):
+    """An independent computation over all 10M rows (torch matmuls in HBM, different
+    summation order): the flat hits carry the right scores and are the true top 10 up to
+    near-ties; the sign-bit candidate set of quantized_search is the exact Hamming top 100
+    including the id tie-break (integer arithmetic: no tolerance)."""
+    torch, nifs, x, doc_ids, host = corpus
+    ref = _index(nifs, nifs.flat_new_cosine, x, doc_ids, 0, N)
+    blob, off = doc_ids(0, N)
+    ids = np.array([blob[int(off[i]):int(off[i + 1])] for i in range(N)], dtype="S12")
+    order = np.argsort(ids, kind="stable")          # bytewise id order (shorter prefix first)
+    id_rank = np.empty(N, dtype=np.int64)
+    id_rank[order] = np.arange(N)
+    rank_dev = torch.from_numpy(id_rank).to(x.device)
+    for seed in (1, 2):
+        q = oracle_mod.normalize_l2(np.random.default_rng(seed).uniform(-1, 1, D).astype(np.float32))
+        qd = torch.from_numpy(q).to(x.device)
+        # --- flat cosine
+        st, hits = nifs.flat_search(ref, q, 10)
+        assert st == "ok" and len(hits) == 10
+        approx = x @ qd
+        cand = torch.topk(approx, 2000).indices
+        exact = x[cand].double() @ qd.double()       # f64 scores of the best 2000 by the f32 pass
+        top = torch.topk(exact, 10)
+        true_rows = set(cand[top.indices].tolist())
+        kth = float(top.values[-1])
+        got_rows = []
+        for id_, raw in hits:
+            row = int(id_[4:]) - 1
+            got_rows.append(row)
+            assert support.close(raw, float(x[row].double() @ qd.double()), 1e-5)
+        for row in true_rows - set(got_rows):        # only near-ties of the 10th may differ
+            assert abs(float(x[row].double() @ qd.double()) - kth) <= 2e-6
+        # --- sign-bit Hamming candidates
+        st, qhits = nifs.flat_quantized_search(ref, q, 100, 100)
+        assert st == "ok" and len(qhits) == 100
+        sq = torch.where(qd >= 0, 1.0, -1.0).to(torch.float16)
+        keys = torch.empty(N, dtype=torch.int64, device=x.device)
+        step = 1_000_000
+        for lo in range(0, N, step):
+            s = torch.where(x[lo:lo + step] >= 0, 1.0, -1.0).to(torch.float16)
+            ham = ((D - (s @ sq).float()) / 2).round().to(torch.int64)   # exact: |sum| <= 768
+            keys[lo:lo + step] = ham * (1 << 32) + rank_dev[lo:lo + step]
+        want = set(torch.topk(keys, 100, largest=False).indices.tolist())
+        assert {int(i[4:]) - 1 for i, _ in qhits} == want
+    del ref
