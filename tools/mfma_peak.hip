@@ -87,6 +87,61 @@ int run_lds(int waves_per_simd = 1) {
   return 0;
 }
 
+// the bare stream again, but with operands that look like data (a different pseudo-random
+// value per lane and per MFMA, accumulators away from zero): power, not issue, may set the rate
+__global__ __launch_bounds__(256) void k_rand(float *out, int iters, unsigned seed) {
+  f32x16 acc[8];
+  unsigned x = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+  auto rnd = [&]() {
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    return (float)(int)(x & 0xFFFFFF) * (1.0f / 8388608.0f) - 1.0f;  // uniform(-1, 1)
+  };
+  float a[16], b[32];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = rnd();
+#pragma unroll
+  for (int i = 0; i < 32; ++i) b[i] = rnd();
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = rnd();
+  for (int it = 0; it < iters; it += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)  // all register indices are compile-time constants
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u * 4 + e], b[(e * 8 + t + u * 5) & 31], acc[t], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[t][i];
+  if (s == 12345.678f) out[0] = s;
+}
+
+int run_rand() {
+  float *out;
+  CK(hipMalloc((void **)&out, 64));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int iters = 40000, blocks = 256;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(e0, 0));
+    k_rand<<<blocks, 256>>>(out, iters, 12345u);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)blocks * 4 * iters * 32 * 4096.0;
+    if (rep == 2) printf("{\"kernel\": \"32 MFMA per iteration, pseudo-random operands\", \"ms\": %.2f, \"TFLOPs\": %.1f}\n", ms, flops / ms / 1e9);
+  }
+  return 0;
+}
+
 template <int NACC>
 int run(const char *name, int waves_per_simd) {
   float *out;
@@ -114,6 +169,7 @@ int main() {
   run<8>("mfma_f32_32x32x2_f32 x8 independent accumulators", 2);
   run<4>("mfma_f32_32x32x2_f32 x4 independent accumulators", 1);
   run<2>("mfma_f32_32x32x2_f32 x2 independent accumulators", 1);
+  run_rand();
   run_lds<0>();
   run_lds<4>();
   run_lds<8>();

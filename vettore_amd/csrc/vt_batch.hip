@@ -41,6 +41,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kRowWaves = 4;  // waves per block, each owning RT * 32 rows of the block's tile
 constexpr int kQStride = 32;        // LDS floats per query row of a 32-k chunk (linear, swizzled slots)
 
+// One LDS-DMA piece: 64 lanes x 16 B from (wave-uniform base + 32-bit lane offset) to
+// LDS at lds_addr + lane * 16.  Written out so that the address is the SGPR-base form
+// (no 64-bit VALU add per piece) and the m0 write sits right in front of the load.
+__device__ __forceinline__ void dma16(uint32_t lds_addr, const void *base, uint32_t lane_off) {
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(sl), "v"(lane_off), "s"(sb) : "m0");
+}
+
 // Cold path of the epilogue: some score of this lane's 16 (one query column, 16
 // rows) reaches the threshold.  Kept out of line so the hot loop stays lean.
 __device__ __noinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v, float tau, uint32_t qcol,
@@ -109,23 +120,29 @@ __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const Bat
   constexpr int kDmaBy3 = (kDmaQ < 3 ? kDmaQ : (kDmaQ / 4) * 3 + (kDmaQ % 4 < 3 ? kDmaQ % 4 : 3)) + 3;
   // physical 16-B slot of logical slot s in row q
   auto qslot = [&](uint32_t q, uint32_t s) { return s ^ ((q >> 1) & 7); };
-  const float *qsrc[kDmaQ];
+  // Addresses are (wave-uniform base) + (32-bit per-lane byte offset): the base moves
+  // by the chunk in SGPRs, the lane offsets are set once per tile, so a piece costs
+  // an m0 write and the load itself -- no per-piece VALU between the MFMAs.
+  uint32_t qoff[kDmaQ];
 #pragma unroll
   for (int i = 0; i < kDmaQ; ++i) {
     const uint32_t qrow = (uint32_t)(wid * kDmaQ + i) * 8 + (lane >> 3);
-    qsrc[i] = a.Q + (size_t)qrow * a.ld + qslot(qrow, lane & 7) * 4;
+    qoff[i] = (qrow * a.ld + qslot(qrow, lane & 7) * 4) * 4;
   }
+  const char *qbase = reinterpret_cast<const char *>(a.Q);
+  // LDS byte address of the staging area (one address-space cast, integer arithmetic after it)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)qlds;
   auto dma_q = [&](int i, uint32_t c, int stage) {
-    float *dst = qlds + stage * (NQ * kQStride) + (wid * kDmaQ + i) * 8 * kQStride;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qsrc[i] + c * 32),
-                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    const uint32_t dst = lds0 + (uint32_t)(stage * (NQ * kQStride) + (wid * kDmaQ + i) * 8 * kQStride) * 4u;
+    dma16(dst, qbase + (size_t)c * 128, qoff[i]);
   };
   float *xlds = qlds + NS * (NQ * kQStride) + wid * (32 * kQStride);
-  const float *xsrc[kDmaX];  // of the tile the DMA cursor is in
+  uint32_t xoff[kDmaX];      // of the tile the DMA cursor is in, relative to xbase
+  const char *xbase = nullptr;  // first row of that block tile (wave-uniform)
   auto dma_x = [&](int i, uint32_t c, int stage) {
-    float *dst = xlds + stage * (kRowWaves * 32 * kQStride) + i * 8 * kQStride;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xsrc[i] + c * 32),
-                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    const uint32_t dst = lds0 + (uint32_t)(NS * (NQ * kQStride) + wid * (32 * kQStride) +
+                                           stage * (kRowWaves * 32 * kQStride) + i * 8 * kQStride) * 4u;
+    dma16(dst, xbase + (size_t)c * 128, xoff[i]);
   };
   auto tile_row0 = [&](uint32_t k) {
     const uint32_t tile = blockIdx.x + k * gridDim.x;
@@ -133,12 +150,14 @@ __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const Bat
   };
   auto set_xsrc = [&](uint32_t k) {
     const uint32_t row0 = tile_row0(k);
+    const uint32_t block0 = row0 - wid * 32;  // first row of the block tile (< n_total for every tile visited)
+    xbase = reinterpret_cast<const char *>(a.X + (size_t)block0 * a.stride);
 #pragma unroll
     for (int i = 0; i < kDmaX; ++i) {
       const uint32_t xr = (uint32_t)i * 8 + (lane >> 3);  // row within the wave's rows
       uint32_t grow = row0 + xr;
       grow = grow < a.n_total ? grow : a.n_total - 1;  // clamped for the load, masked in the epilogue
-      xsrc[i] = a.X + (size_t)grow * a.stride + qslot(xr, lane & 7) * 4;
+      xoff[i] = ((grow - block0) * (uint32_t)a.stride + qslot(xr, lane & 7) * 4) * 4;
     }
   };
   auto dma_chunk = [&](uint32_t c, int stage) {
@@ -192,9 +211,10 @@ __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const Bat
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     for (uint32_t c = 0; c < nchunk; ++c) {
+      stage = __builtin_amdgcn_readfirstlane(stage);             // keep the ring index (and every LDS base) scalar
       const int stage_n = stage == NS - 1 ? 0 : stage + 1;      // chunk m + 1
       const int stage_a = stage_n == NS - 1 ? 0 : stage_n + 1;  // chunk m + 2 == the stage chunk m - 1 was read from
-      const uint32_t cdma = dc;
+      const uint32_t cdma = __builtin_amdgcn_readfirstlane(dc);
       // One step = 32-k quarter of the chunk: NT*4 MFMAs.  Everything else the step
       // has to issue is pinned between them, one item per MFMA, so that nothing
       // piles up in front of the matrix pipe: the NT+1 fragment reads of the next
