@@ -52,6 +52,16 @@ __device__ __forceinline__ void dma16(uint32_t lds_addr, const void *base, uint3
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(sl), "v"(lane_off), "s"(sb) : "m0");
 }
 
+// The same with a base that is already in SGPRs (made scalar once per chunk).
+__device__ __forceinline__ uint64_t scalar64(const void *p) {
+  const uint64_t b = reinterpret_cast<uint64_t>(p);
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+}
+__device__ __forceinline__ void dma16s(uint32_t lds_addr, uint64_t sbase, uint32_t lane_off) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(lane_off), "s"(sbase) : "m0");
+}
+
 // Cold path of the epilogue: some score of this lane's 16 (one query column, 16
 // rows) reaches the threshold.  Kept out of line so the hot loop stays lean.
 __device__ __noinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v, float tau, uint32_t qcol,
@@ -449,6 +459,205 @@ __global__ __launch_bounds__(kRowWaves2 *kWave, 1) void mfma_scores_kernel2(cons
   }
 }
 
+// ---------------------------------------------------------------------------
+// 256-query batches, 128 x 128 register tile per wave (VT_BATCH_KERNEL=3): the four
+// waves of a block sit 2 x 2 over a 256-row x 256-query block tile, each with
+// 4 x 4 accumulator tiles (256 registers, the whole AGPR file).  A quarter chunk is
+// then 64 MFMAs fed by 4 + 4 fragment reads (the 32 x 256 shape needs 1 + 8 per 32),
+// and a chunk's DMA is 16 pieces per 256 MFMAs instead of 12 per 128: half the
+// issue slots taken from the matrix pipe.  Two 64-KiB LDS stages; a chunk lasts
+// 16 384 MFMA cycles, so chunk m+1's DMA (issued under the first three quarters of
+// chunk m) has landed when the chunk ends.
+// ---------------------------------------------------------------------------
+template <bool DENSE>
+__global__ __launch_bounds__(kRowWaves *kWave, 1) void mfma_scores_kernel3(const BatchScoreArgs a) {
+  extern __shared__ __align__(16) float qlds[];  // [2][256][32] queries, then [2][256][32] rows
+  constexpr int NS = 2, NQ = 256, kTileRowsB = 256, G = 4, T = 4;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wid >> 1, wq = wid & 1;  // row half, query half
+  const int r = lane & 31, h = lane >> 5;
+  const uint32_t nchunk = a.ld / 32;
+  const uint32_t ntiles = (a.n + kTileRowsB - 1) / kTileRowsB;
+  if (blockIdx.x >= ntiles) return;
+  const uint32_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+
+  float tau[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) tau[t] = DENSE ? 0.f : a.tau[wq * 128 + t * 32 + r];
+
+  // DMA: 32 Q pieces + 32 X pieces of 8 rows per chunk; wave w issues pieces w*8 .. w*8+7 of
+  // each, addressed as (SGPR base of the chunk) + (32-bit lane offset), see dma16
+  constexpr int kDma = 8;
+  auto qslot = [&](uint32_t q, uint32_t s) { return s ^ ((q >> 1) & 7); };
+  uint32_t qoff[kDma], xoff[kDma];
+#pragma unroll
+  for (int i = 0; i < kDma; ++i) {
+    const uint32_t qrow = (uint32_t)(wid * kDma + i) * 8 + (lane >> 3);
+    qoff[i] = (qrow * a.ld + qslot(qrow, lane & 7) * 4) * 4;
+  }
+  float *xlds0 = qlds + NS * (NQ * kQStride);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)qlds;
+  const char *xbase = nullptr;  // first row of the DMA cursor's block tile
+  uint64_t qb_c = 0, xb_c = 0;  // scalar bases of the chunk being fetched
+  auto dma_q = [&](int i, int stage) {
+    dma16s(lds0 + (uint32_t)(stage * (NQ * kQStride) + (wid * kDma + i) * 8 * kQStride) * 4u, qb_c, qoff[i]);
+  };
+  auto dma_x = [&](int i, int stage) {
+    dma16s(lds0 + (uint32_t)(NS * (NQ * kQStride) + stage * (kTileRowsB * kQStride) + (wid * kDma + i) * 8 * kQStride) * 4u,
+           xb_c, xoff[i]);
+  };
+  auto tile_base = [&](uint32_t k) {
+    const uint32_t tile = blockIdx.x + k * gridDim.x;
+    return (DENSE ? tile * a.sample_stride : tile) * kTileRowsB;
+  };
+  auto set_xsrc = [&](uint32_t k) {
+    const uint32_t block0 = tile_base(k);
+    const uint32_t row0 = block0 + wid * (kDma * 8);
+    xbase = reinterpret_cast<const char *>(a.X + (size_t)block0 * a.stride);
+#pragma unroll
+    for (int i = 0; i < kDma; ++i) {
+      const uint32_t xr = (uint32_t)i * 8 + (lane >> 3);  // row within this wave's 64 DMA rows
+      uint32_t grow = row0 + xr;
+      grow = grow < a.n_total ? grow : a.n_total - 1;
+      xoff[i] = ((grow - block0) * (uint32_t)a.stride + qslot(xr, lane & 7) * 4) * 4;  // (wid * 64 is a multiple of 16: same swizzle)
+    }
+  };
+  auto set_chunk = [&](uint32_t c) {
+    qb_c = scalar64(reinterpret_cast<const char *>(a.Q) + (size_t)c * 128);
+    xb_c = scalar64(xbase + (size_t)c * 128);
+  };
+  uint32_t dk = 0, dc = 0;  // DMA cursor; stays on the last chunk past the end
+  auto dma_advance = [&]() {
+    if (dc + 1 == nchunk && dk + 1 == my_tiles) return;
+    dc += 1;
+    if (dc == nchunk) {
+      dc = 0;
+      dk += 1;
+      set_xsrc(dk);
+    }
+  };
+  // piece p (0..15) of a chunk: 0..7 X, 8..15 Q
+  auto dma_piece = [&](int p, int stage) {
+    if (p < kDma) dma_x(p, stage);
+    else dma_q(p - kDma, stage);
+  };
+
+  set_xsrc(0);
+  set_chunk(0);
+#pragma unroll
+  for (int p = 0; p < 2 * kDma; ++p) dma_piece(p, 0);
+  dma_advance();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  f32x4 xa[G], qv[T], xa_n[G], qv_n[T];
+  auto frag_x = [&](int stage, int j, int g) {
+    const uint32_t so = qslot(r, 4 * h + j) * 4;
+    return *reinterpret_cast<const f32x4 *>(xlds0 + stage * (kTileRowsB * kQStride) + (wr * 128 + g * 32 + r) * kQStride + so);
+  };
+  auto frag_q = [&](int stage, int j, int t) {
+    const uint32_t so = qslot(r, 4 * h + j) * 4;
+    return *reinterpret_cast<const f32x4 *>(qlds + stage * (NQ * kQStride) + (wq * 128 + t * 32 + r) * kQStride + so);
+  };
+
+  int stage = 0;
+  for (uint32_t k = 0; k < my_tiles; ++k) {
+    f32x16 acc[G][T];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[g][t][i] = 0.f;
+
+    for (uint32_t c = 0; c < nchunk; ++c) {
+      stage = __builtin_amdgcn_readfirstlane(stage);
+      const int stage_n = stage ^ 1;
+      set_chunk(dc);
+#pragma unroll
+      for (int g = 0; g < G; ++g) xa[g] = frag_x(stage, 0, g);
+#pragma unroll
+      for (int t = 0; t < T; ++t) qv[t] = frag_q(stage, 0, t);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // 64 MFMAs; under the first eight the fragments of the next quarter are read,
+        // then one DMA piece of chunk m+1 per eight MFMAs (quarters 0..2: 6 + 5 + 5)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              acc[g][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[g][e], qv[t][e], acc[g][t], 0, 0, 0);
+              const int m = (e * G + g) * T + t;  // 0..63 within the quarter
+              if (j < 3) {
+                if (m < G) xa_n[m] = frag_x(stage, j + 1, m);
+                else if (m < G + T) qv_n[m - G] = frag_q(stage, j + 1, m - G);
+                else if (m % 8 == 0) {
+                  const int slot = m / 8 - 1;                       // 0..6
+                  const int first = j == 0 ? 0 : (j == 1 ? 6 : 11);  // pieces 0-5, 6-10, 11-15
+                  const int count = j == 0 ? 6 : 5;
+                  if (slot < count) dma_piece(first + slot, stage_n);
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        if (j < 3) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) xa[g] = xa_n[g];
+#pragma unroll
+          for (int t = 0; t < T; ++t) qv[t] = qv_n[t];
+        }
+      }
+      // my pieces of chunk m+1 have landed and my reads of chunk m are done
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      dma_advance();
+      stage = stage_n;
+    }
+
+    // epilogue: 16 tiles of 32 x 32 (C layout: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5))
+    const uint32_t base = tile_base(k) + wr * 128;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const uint32_t grow0 = base + g * 32;
+      float xn[16];
+      if (a.xnorm2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const uint32_t row = grow0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          xn[i] = a.xnorm2[row < a.n_total ? row : a.n_total - 1];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const uint32_t qcol = wq * 128 + t * 32 + r;
+        f32x16 v = acc[g][t];
+        if (a.xnorm2) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = 2.0f * v[i] - xn[i];
+        }
+        if (DENSE) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const uint32_t off = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const uint32_t srow = (blockIdx.x + k * gridDim.x) * kTileRowsB + wr * 128 + g * 32 + off;
+            a.sample[(size_t)qcol * a.sample_rows + srow] = grow0 + off < a.n_total ? v[i] : -INFINITY;
+          }
+        } else {
+          float mx = v[0];
+#pragma unroll
+          for (int i = 1; i < 16; ++i) mx = fmaxf(mx, v[i]);
+          if (mx >= tau[t]) append_candidates(a, v, tau[t], qcol, grow0, h);
+        }
+      }
+    }
+  }
+}
+
 // tau_b = the `rank`-th largest of the query's sample scores (one block per query):
 // `rank` rounds of "largest value not yet taken" (ties by index).  1024 threads,
 // 16-B loads, four in flight per thread: the sample row (256 KiB at 512 tiles)
@@ -623,22 +832,43 @@ hipError_t launch_scores2_nt(const BatchScoreArgs &a, bool dense, uint32_t block
   return hipGetLastError();
 }
 
-// VT_BATCH_KERNEL=2 selects the two-waves-per-SIMD variant.
-bool batch_two_waves() {
-  static const bool v = std::getenv("VT_BATCH_KERNEL") && std::atoi(std::getenv("VT_BATCH_KERNEL")) == 2;
+hipError_t launch_scores3(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
+  const size_t lds = (size_t)2 * (256 + 256) * kQStride * sizeof(float);
+  const dim3 block(kRowWaves * kWave);
+  if (dense) {
+    auto kern = mfma_scores_kernel3<true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
+  } else {
+    auto kern = mfma_scores_kernel3<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
+  }
+  return hipGetLastError();
+}
+
+// VT_BATCH_KERNEL=2 selects the two-waves-per-SIMD variant, 3 the 128 x 128 register tile.
+int batch_variant() {
+  static const int v = std::getenv("VT_BATCH_KERNEL") ? std::atoi(std::getenv("VT_BATCH_KERNEL")) : 1;
   return v;
 }
+bool batch_two_waves() { return batch_variant() == 2; }
 
 }  // namespace
 
-uint32_t batch_rows_per_block() { return (batch_two_waves() ? kRowWaves2 : kRowWaves) * 32; }
+uint32_t batch_rows_per_block() { return batch_variant() == 1 ? kRowWaves * 32 : 256; }
 
 hipError_t launch_batch_scores(const BatchScoreArgs &a0, bool dense, uint32_t blocks, hipStream_t s) {
   BatchScoreArgs a = a0;
   static const uint32_t dbg = std::getenv("VT_BATCH_DEBUG") ? (uint32_t)std::atoi(std::getenv("VT_BATCH_DEBUG")) : 0u;
   a.debug = dense ? 0u : dbg;
   if (a.ld % 32 != 0 || a.nq_pad % 32 != 0 || a.nq_pad == 0 || a.nq_pad > 256) return hipErrorInvalidValue;
-  if (batch_two_waves()) {
+  if (batch_variant() == 3 && a.nq_pad == 256) return launch_scores3(a, dense, blocks, s);
+  if (batch_variant() != 1) {  // (variant 3 handles 256-query batches only; smaller ones share variant 2's 256-row tiles)
     switch (a.nq_pad / 32) {
       case 1: return launch_scores2_nt<1>(a, dense, blocks, s);
       case 2: return launch_scores2_nt<2>(a, dense, blocks, s);
