@@ -64,7 +64,7 @@ __device__ __forceinline__ void dma16s(uint32_t lds_addr, uint64_t sbase, uint32
 
 // Cold path of the epilogue: some score of this lane's 16 (one query column, 16
 // rows) reaches the threshold.  Kept out of line so the hot loop stays lean.
-__device__ __noinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v, float tau, uint32_t qcol,
+__device__ __forceinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v, float tau, uint32_t qcol,
                                                uint32_t row0, int h) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
