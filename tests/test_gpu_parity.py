@@ -705,3 +705,19 @@ def test_config2_full_size_properties_and_spot_parity(nifs, oracle_mod):
         assert keys == sorted(keys)
         # limit monotonicity: top-5 is a prefix of top-10
         assert bits(g.search(x[row], 5)) == bits(hits[:5])
+
+
+def test_batched_search_with_the_wide_register_tile_kernel():
+    """VT_BATCH_KERNEL=3 (128 x 128 register tile per wave for 256-query batches) is read once
+    per process, so the batched parity tests are re-run in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("VT_BATCH_KERNEL") == "3":
+        pytest.skip("already the child")
+    env = dict(os.environ, VT_BATCH_KERNEL="3")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x",
+                          "-m", "gpu", "-k", "batch and not wide_register", "-p", "no:cacheprovider"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]

@@ -304,165 +304,9 @@ __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const Bat
 }
 
 // ---------------------------------------------------------------------------
-// Variant with TWO waves per SIMD (8 waves per block, 256 rows x NT*32 queries per
-// block tile).  At one wave per SIMD nothing hides a wave's own LDS issue: the
-// matrix pipe loses ~18 cycles per ds_read_b128 (tools/mfma_peak.hip), 8 % of
-// the pass.  With a second wave on the SIMD, one wave's fragment reads, barrier
-// and append stalls sit under the other's MFMAs.  Each wave keeps 128 accumulators
-// and must stay within 256 registers (thresholds live in LDS).  Two LDS stages of
-// 64 KiB (NT = 8): the DMA of chunk m+1 is issued under chunk m, which now lasts
-// two waves' worth of MFMAs.  Selected with VT_BATCH_KERNEL=2.
-// ---------------------------------------------------------------------------
-constexpr int kRowWaves2 = 8;
-
-template <int NT, bool DENSE>
-__global__ __launch_bounds__(kRowWaves2 *kWave, 1) void mfma_scores_kernel2(const BatchScoreArgs a) {
-  extern __shared__ __align__(16) float qlds[];  // [2][NT*32][32] queries, [2][8 waves][32][32] rows, [NT*32] tau
-  constexpr int NS = 2;
-  constexpr int NQ = NT * 32;
-  constexpr int kTileRowsB = kRowWaves2 * 32;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const uint32_t nchunk = a.ld / 32;
-  const uint32_t ntiles = (a.n + kTileRowsB - 1) / kTileRowsB;
-  if (blockIdx.x >= ntiles) return;
-  const uint32_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
-
-  // thresholds live in LDS (registers are the scarce resource here), read in the epilogue
-  float *tau_lds = qlds + NS * (NQ + kRowWaves2 * 32) * kQStride;
-  if (!DENSE)
-    for (int i = threadIdx.x; i < NQ; i += kRowWaves2 * kWave) tau_lds[i] = a.tau[i];
-
-  // Q pieces (8 query rows each) are dealt round-robin to the 8 waves; NT*4 pieces per chunk
-  constexpr int kPiecesQ = NQ / 8;
-  constexpr int kDmaQ = (kPiecesQ + kRowWaves2 - 1) / kRowWaves2;  // per wave (NT = 1: only waves 0..3 have one)
-  constexpr int kDmaX = 4;
-  auto qslot = [&](uint32_t q, uint32_t s) { return s ^ ((q >> 1) & 7); };
-  auto dma_q = [&](int i, uint32_t c, int stage) {
-    const int piece = wid + i * kRowWaves2;
-    if (piece >= kPiecesQ) return;
-    const uint32_t qrow = (uint32_t)piece * 8 + (lane >> 3);
-    const float *src = a.Q + (size_t)qrow * a.ld + qslot(qrow, lane & 7) * 4 + c * 32;
-    float *dst = qlds + stage * (NQ * kQStride) + piece * 8 * kQStride;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-  };
-  float *xlds = qlds + NS * (NQ * kQStride) + wid * (32 * kQStride);
-  const float *xsrc[kDmaX];
-  auto dma_x = [&](int i, uint32_t c, int stage) {
-    float *dst = xlds + stage * (kRowWaves2 * 32 * kQStride) + i * 8 * kQStride;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xsrc[i] + c * 32),
-                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-  };
-  auto tile_row0 = [&](uint32_t k) {
-    const uint32_t tile = blockIdx.x + k * gridDim.x;
-    return (DENSE ? tile * a.sample_stride : tile) * kTileRowsB + wid * 32;
-  };
-  auto set_xsrc = [&](uint32_t k) {
-    const uint32_t row0 = tile_row0(k);
-#pragma unroll
-    for (int i = 0; i < kDmaX; ++i) {
-      const uint32_t xr = (uint32_t)i * 8 + (lane >> 3);
-      uint32_t grow = row0 + xr;
-      grow = grow < a.n_total ? grow : a.n_total - 1;
-      xsrc[i] = a.X + (size_t)grow * a.stride + qslot(xr, lane & 7) * 4;
-    }
-  };
-  uint32_t dk = 0, dc = 0;  // DMA cursor; stays on the last chunk past the end (see the one-wave kernel)
-  auto dma_advance = [&]() {
-    if (dc + 1 == nchunk && dk + 1 == my_tiles) return;
-    dc += 1;
-    if (dc == nchunk) {
-      dc = 0;
-      dk += 1;
-      set_xsrc(dk);
-    }
-  };
-
-  set_xsrc(0);
-#pragma unroll
-  for (int i = 0; i < kDmaX; ++i) dma_x(i, 0, 0);
-#pragma unroll
-  for (int i = 0; i < kDmaQ; ++i) dma_q(i, 0, 0);
-  dma_advance();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  int stage = 0;
-  for (uint32_t k = 0; k < my_tiles; ++k) {
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-    for (uint32_t c = 0; c < nchunk; ++c) {
-      const int stage_n = stage ^ 1;
-      const uint32_t cdma = dc;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t so = qslot(r, 4 * h + j) * 4;
-        const float *xb = xlds + stage * (kRowWaves2 * 32 * kQStride) + r * kQStride + so;
-        const float *qb = qlds + stage * (NQ * kQStride) + r * kQStride + so;
-        f32x4 xa = *reinterpret_cast<const f32x4 *>(xb);
-        f32x4 qv[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) qv[t] = *reinterpret_cast<const f32x4 *>(qb + t * 32 * kQStride);
-        // this step's share of chunk m+1's DMA: one X piece, one Q piece
-        dma_x(j, cdma, stage_n);
-        if (j < kDmaQ) dma_q(j, cdma, stage_n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], qv[t][e], acc[t], 0, 0, 0);
-      }
-      // my pieces of chunk m+1 have landed and my reads of chunk m are done
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      dma_advance();
-      stage = stage_n;
-    }
-
-    const uint32_t grow0 = tile_row0(k);
-    float xn[16];
-    if (a.xnorm2) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const uint32_t row = grow0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        xn[i] = a.xnorm2[row < a.n_total ? row : a.n_total - 1];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const uint32_t qcol = t * 32 + r;
-      f32x16 v = acc[t];
-      if (a.xnorm2) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = 2.0f * v[i] - xn[i];
-      }
-      if (DENSE) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const uint32_t off = (i & 3) + 8 * (i >> 2) + 4 * h;
-          const uint32_t srow = (blockIdx.x + k * gridDim.x) * kTileRowsB + wid * 32 + off;
-          a.sample[(size_t)qcol * a.sample_rows + srow] = grow0 + off < a.n_total ? v[i] : -INFINITY;
-        }
-      } else {
-        float mx = v[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, v[i]);
-        const float tq = tau_lds[qcol];
-        if (mx >= tq) append_candidates(a, v, tq, qcol, grow0, h);
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
 // 256-query batches, 128 x 128 register tile per wave (VT_BATCH_KERNEL=3): the four
 // waves of a block sit 2 x 2 over a 256-row x 256-query block tile, each with
-// 4 x 4 accumulator tiles (256 registers, the whole AGPR file).  A quarter chunk is
+// 4 x 4 accumulator tiles (256 registers, the whole AGPR file; the epilogue spills).  A quarter chunk is
 // then 64 MFMAs fed by 4 + 4 fragment reads (the 32 x 256 shape needs 1 + 8 per 32),
 // and a chunk's DMA is 16 pieces per 256 MFMAs instead of 12 per 128: half the
 // issue slots taken from the matrix pipe.  Two 64-KiB LDS stages; a chunk lasts
@@ -812,26 +656,6 @@ hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks
   return hipGetLastError();
 }
 
-template <int NT>
-hipError_t launch_scores2_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
-  const size_t lds = ((size_t)2 * (NT * 32 + kRowWaves2 * 32) * kQStride + NT * 32) * sizeof(float);
-  const dim3 block(kRowWaves2 * kWave);
-  if (dense) {
-    auto kern = mfma_scores_kernel2<NT, true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
-  } else {
-    auto kern = mfma_scores_kernel2<NT, false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
-  }
-  return hipGetLastError();
-}
-
 hipError_t launch_scores3(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
   const size_t lds = (size_t)2 * (256 + 256) * kQStride * sizeof(float);
   const dim3 block(kRowWaves * kWave);
@@ -851,32 +675,22 @@ hipError_t launch_scores3(const BatchScoreArgs &a, bool dense, uint32_t blocks, 
   return hipGetLastError();
 }
 
-// VT_BATCH_KERNEL=2 selects the two-waves-per-SIMD variant, 3 the 128 x 128 register tile.
-int batch_variant() {
-  static const int v = std::getenv("VT_BATCH_KERNEL") ? std::atoi(std::getenv("VT_BATCH_KERNEL")) : 1;
-  return v;
+// VT_BATCH_KERNEL=3 selects the 128 x 128 register tile for 256-query batches.
+bool batch_wide_tile(uint32_t nq_pad) {
+  static const bool v = std::getenv("VT_BATCH_KERNEL") && std::atoi(std::getenv("VT_BATCH_KERNEL")) == 3;
+  return v && nq_pad == 256;
 }
-bool batch_two_waves() { return batch_variant() == 2; }
 
 }  // namespace
 
-uint32_t batch_rows_per_block() { return batch_variant() == 1 ? kRowWaves * 32 : 256; }
+uint32_t batch_rows_per_block(uint32_t nq_pad) { return batch_wide_tile(nq_pad) ? 256 : kRowWaves * 32; }
 
 hipError_t launch_batch_scores(const BatchScoreArgs &a0, bool dense, uint32_t blocks, hipStream_t s) {
   BatchScoreArgs a = a0;
   static const uint32_t dbg = std::getenv("VT_BATCH_DEBUG") ? (uint32_t)std::atoi(std::getenv("VT_BATCH_DEBUG")) : 0u;
   a.debug = dense ? 0u : dbg;
   if (a.ld % 32 != 0 || a.nq_pad % 32 != 0 || a.nq_pad == 0 || a.nq_pad > 256) return hipErrorInvalidValue;
-  if (batch_variant() == 3 && a.nq_pad == 256) return launch_scores3(a, dense, blocks, s);
-  if (batch_variant() != 1) {  // (variant 3 handles 256-query batches only; smaller ones share variant 2's 256-row tiles)
-    switch (a.nq_pad / 32) {
-      case 1: return launch_scores2_nt<1>(a, dense, blocks, s);
-      case 2: return launch_scores2_nt<2>(a, dense, blocks, s);
-      case 4: return launch_scores2_nt<4>(a, dense, blocks, s);
-      case 8: return launch_scores2_nt<8>(a, dense, blocks, s);
-      default: return hipErrorInvalidValue;
-    }
-  }
+  if (batch_wide_tile(a.nq_pad)) return launch_scores3(a, dense, blocks, s);
   switch (a.nq_pad / 32) {
     case 1: return launch_scores_nt<1>(a, dense, blocks, s);
     case 2: return launch_scores_nt<2>(a, dense, blocks, s);

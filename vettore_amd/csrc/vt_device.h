@@ -178,7 +178,7 @@ struct BatchScoreArgs {
   const float *xnorm2;    // null: score = q.x; else score = 2 q.x - xnorm2[row] (= |q|^2 - |q - x|^2)
   uint32_t debug;         // VT_BATCH_DEBUG timing experiments (results invalid when non-zero)
 };
-uint32_t batch_rows_per_block();
+uint32_t batch_rows_per_block(uint32_t nq_pad);
 hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s);
 hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t rank, float *tau,
                              hipStream_t s);

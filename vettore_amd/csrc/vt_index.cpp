@@ -943,7 +943,7 @@ int batch_group(vt_flat *ix, const float *queries, size_t nq, size_t limit, vt_h
   const uint32_t k = (uint32_t)std::min<size_t>(limit, n);
   uint32_t nq_pad = 32;
   while (nq_pad < nq) nq_pad *= 2;
-  const uint32_t rows_per_block = vt::batch_rows_per_block();
+  const uint32_t rows_per_block = vt::batch_rows_per_block(nq_pad);
   const uint32_t ntiles_total = (n + rows_per_block - 1) / rows_per_block;
   // pass-0 sample: 1/64 of the row tiles, 128..512 of them, spread over the corpus.
   // A larger sample gives a tighter tau: fewer candidates to rescore and, above
