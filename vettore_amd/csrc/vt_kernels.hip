@@ -506,16 +506,19 @@ __global__ __launch_bounds__(64) void cosine_rerank_kernel(const CosineRerankArg
   if (lane < 3) {
     const float *A = lane == 1 ? xs : qs;  // lane 0: q.q   lane 1: x.x   lane 2: q.x
     const float *B = lane == 0 ? qs : xs;
+    // fma(x, y, acc) == acc + x*y here (the product of two f32 is exact in f64); the
+    // loop is unrolled so that the LDS reads of 8 steps are issued ahead of the chain
     uint32_t j = 0;
+#pragma unroll 8
     for (; j + 4 <= a.d; j += 4) {
       const f32x4 av = *reinterpret_cast<const f32x4 *>(A + j);
       const f32x4 bv = *reinterpret_cast<const f32x4 *>(B + j);
-      acc += (double)av.x * (double)bv.x;
-      acc += (double)av.y * (double)bv.y;
-      acc += (double)av.z * (double)bv.z;
-      acc += (double)av.w * (double)bv.w;
+      acc = __builtin_fma((double)av.x, (double)bv.x, acc);
+      acc = __builtin_fma((double)av.y, (double)bv.y, acc);
+      acc = __builtin_fma((double)av.z, (double)bv.z, acc);
+      acc = __builtin_fma((double)av.w, (double)bv.w, acc);
     }
-    for (; j < a.d; ++j) acc += (double)A[j] * (double)B[j];
+    for (; j < a.d; ++j) acc = __builtin_fma((double)A[j], (double)B[j], acc);
   }
   const double qq = __shfl(acc, 0, kWave), xx = __shfl(acc, 1, kWave), qx = __shfl(acc, 2, kWave);
   if (lane != 0) return;
