@@ -721,3 +721,69 @@ def test_batched_search_with_the_wide_register_tile_kernel():
                           "-m", "gpu", "-k", "batch and not wide_register", "-p", "no:cacheprovider"],
                          env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_concurrent_callers_on_shared_and_separate_handles(nifs, oracle_mod):
+    """nifs.rs:266-309: every NIF is a dirty-scheduler job, so several OS threads call into
+    the same and into different indexes at once (searches under the handle's lock, a writer
+    mutating a third index).  ctypes releases the GIL during the C call; every result must
+    still equal the oracle's."""
+    import threading
+    specs = [(2, 6000, 64, True), (0, 5000, 100, False)]
+    idx, want = [], []
+    for metric, n, d, norm in specs:
+        x, ids = make_corpus(n, d, 900 + metric, norm, oracle_mod, tie_block=20)
+        g = GpuIndex(nifs, metric)
+        unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+        packed = oracle_mod.pack_ids(ids)
+        rng = np.random.default_rng(31 + metric)
+        qs = [x[n // 2]] + [rng.uniform(-1, 1, d).astype(np.float32) for _ in range(5)]
+        if norm:
+            qs = [oracle_mod.normalize_l2(q) for q in qs]
+        idx.append(g)
+        want.append([(q, bits(oracle_mod.matrix_search(metric, x, packed, q, 10))) for q in qs])
+    # a third index that a writer thread keeps mutating
+    wx, wids = make_corpus(3000, 32, 977, False, oracle_mod)
+    writer = GpuIndex(nifs, 1)
+    unwrap(nifs.flat_load_matrix(writer.ref, wids[:2000], wx[:2000]))
+    errors = []
+
+    def reader(t):
+        try:
+            for i in range(150):
+                which = (t + i) % 2
+                q, expect = want[which][(t * 7 + i) % len(want[which])]
+                got = bits(unwrap(nifs.flat_search(idx[which].ref, q, 10)))
+                if got != expect:
+                    errors.append(("reader", t, i, which))
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append(("reader", t, repr(e)))
+
+    def mutate():
+        try:
+            for i in range(2000, 3000):
+                writer.insert(wids[i], wx[i])
+                if i % 3 == 0:
+                    writer.delete(wids[i - 1500])
+                if i % 50 == 0:
+                    writer.search(wx[i], 5)
+        except Exception as e:  # noqa: BLE001
+            errors.append(("writer", repr(e)))
+
+    threads = [threading.Thread(target=reader, args=(t,)) for t in range(6)] + [threading.Thread(target=mutate)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    # the mutated index still answers like the oracle index that saw the same operations
+    o = oracle_mod.FlatIndex(1)
+    o.insert_matrix(wids[:2000], wx[:2000])
+    for i in range(2000, 3000):
+        o.insert(wids[i], wx[i])
+        if i % 3 == 0:
+            o.delete(wids[i - 1500])
+    assert len(writer) == len(o)
+    for q in (wx[10], wx[2500], wx[2999]):
+        assert bits(writer.search(q, 10)) == bits(o.search(q, 10))
