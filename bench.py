@@ -247,7 +247,7 @@ def run_side_mode(a, torch, nifs, device):
         out["metric"] = "queries/sec, quantized_search (sign-bit Hamming top-%d + exact cosine rerank top-%d), N=%d d=%d" % (
             a.candidates, a.limit, a.rows, a.dim)
         out["config"] = {"workload": "quantized_search candidates=%d limit=%d, d=%d, N=%d" % (a.candidates, a.limit, a.dim, a.rows)}
-        out["roofline"] = {"bound": "hbm", "kernel": "hamming_topk_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
+        out["roofline"] = {"bound": "hbm", "kernel": "hamming_dist_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
                            "algorithmic_bytes_per_launch": p["hamming_bytes"] / max(1, p["hamming_launches"])}
     print(json.dumps(out))

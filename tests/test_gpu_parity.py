@@ -458,6 +458,44 @@ def test_quantized_search_matches_oracle_composition(nifs, oracle_mod, metric):
         assert bits(got) == bits(want), (metric, cand, limit)
 
 
+@pytest.mark.parametrize("shape", ["random", "two_patterns", "all_equal"])
+def test_quantized_search_histogram_pass(nifs, oracle_mod, shape):
+    """Above 16 384 rows the candidate pass is the histogram/threshold stream (K4h).  Random
+    rows; rows drawn from two sign patterns (thousands of ties at the k-th distance, broken by
+    id bytes); and 150 000 identical rows (more ties than the device list holds: the call must
+    fall back to the list-carrying scan and still agree with the oracle)."""
+    d = 64
+    rng = np.random.default_rng(515)
+    if shape == "random":
+        n = 40_000
+        x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    elif shape == "two_patterns":
+        n = 30_000
+        base = rng.uniform(-1, 1, (2, d)).astype(np.float32)
+        x = base[rng.integers(0, 2, n)] * rng.uniform(0.5, 1.5, (n, 1)).astype(np.float32)
+    else:
+        n = 150_000
+        x = np.tile(rng.uniform(-1, 1, (1, d)).astype(np.float32), (n, 1))
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    g = GpuIndex(nifs, 0)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    packed = oracle_mod.pack_ids(ids)
+    xbits = np.stack([oracle_mod.compress_sign_bits(r) for r in x[:2]]) if shape == "all_equal" else None
+    for cand, limit in ((100, 10), (256, 30), (7, 7)):
+        q = rng.uniform(-1, 1, d).astype(np.float32)
+        qb = oracle_mod.compress_sign_bits(q)
+        # oracle composition without materialising n Python tuples: distances via numpy popcount
+        sign = (x >= 0)
+        ham = (sign != (q >= 0)[None, :]).sum(axis=1)
+        order = sorted(range(n), key=lambda i: (int(ham[i]), ids[i]))[:cand] if n <= 40_000 else \
+            sorted(np.argsort(ham, kind="stable")[:max(cand * 50, 10_000)].tolist() if shape != "all_equal" else range(n),
+                   key=lambda i: (int(ham[i]), ids[i]))[:cand]
+        assert oracle_mod.packed_hamming(oracle_mod.compress_sign_bits(x[order[0]]), qb, d) == ham[order[0]]
+        want = oracle_mod.vector_top_k([(ids[i], x[i]) for i in order], q, 0, d, limit)
+        got = unwrap(nifs.flat_quantized_search(g.ref, q, cand, limit))
+        assert bits(got) == bits(want), (shape, cand, limit)
+
+
 def test_funnel_overflow_in_any_stage_is_reported(nifs, oracle_mod):
     """search.rs:38-73 returns Err("metric overflow") whichever stage meets the row; the
     chained device path carries the flag from an intermediate stage to the final select."""

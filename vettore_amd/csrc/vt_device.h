@@ -94,7 +94,7 @@ constexpr uint32_t kSelGroups = 16;
 constexpr uint32_t kSelTwoLevelMin = 16384;
 hipError_t launch_select(const uint64_t *keys, const Payload *pay, uint32_t m, uint32_t k, uint64_t lo_key, int has_lo,
                          int *dev_status, ResultBlock *out, uint64_t *scratch_keys, Payload *scratch_pay,
-                         hipStream_t s);
+                         hipStream_t s, const uint32_t *m_dev = nullptr);
 
 // K4's bit-matrix layout: per tile of 64 rows, word pair j of all 64 rows is
 // contiguous -- [tile][pair][row % 64][2] u64 (an odd word count is padded with a
@@ -118,6 +118,33 @@ struct HammingArgs {
   Payload *part_pay;
 };
 hipError_t launch_hamming(const HammingArgs &a, uint32_t blocks, hipStream_t s);
+
+// K4h (vt_kernels.hip): distance column + histogram, then threshold collect.
+constexpr uint32_t kHammingHistMaxDim = 8191;  // (d + 1) u32 bins must fit comfortably in LDS
+constexpr int kStatusRetry = 100;              // internal: the tie list overflowed, take the K4 path
+struct HammingHistArgs {
+  const uint64_t *bits;   // tiled layout, as for K4
+  const uint64_t *qbits;  // [words]
+  uint32_t n, words, pairs, d;
+  uint16_t *dist;         // [n] out
+  uint32_t *hist;         // [d + 1] this query's histogram (zero on entry)
+  uint32_t *list_count;   // cleared here for the collect pass
+};
+struct HammingCollectArgs {
+  const uint16_t *dist;
+  const uint32_t *id_rank;
+  uint32_t n, d, k;
+  const uint32_t *hist;
+  uint32_t *hist_next;    // the other histogram, cleared for the next query
+  uint32_t *list_count;
+  uint64_t *keys;         // [cap]
+  Payload *pay;           // [cap]
+  uint32_t cap;
+  int *status;
+};
+size_t hamming_hist_lds_bytes(uint32_t d);
+hipError_t launch_hamming_dist(const HammingHistArgs &a, uint32_t blocks, hipStream_t s);
+hipError_t launch_hamming_collect(const HammingCollectArgs &a, uint32_t blocks, hipStream_t s);
 
 // rows[n][stride] (first d columns) -> sign bits, bit j%64 of word j/64 set iff
 // v[j] >= 0.0 (distances.rs:413-423).  tiled: K4's layout, else plain [n][words].

@@ -161,6 +161,11 @@ struct Ctx {
   DevBuf<int> dStatus;  // "metric overflow" flag: set by scan kernels, moved out and cleared by the select kernel
   DevBuf<int> dFlag;    // scratch flag of the ingest kernels
   DevBuf<ResultBlock> dStage;  // stage-1 winners of quantized_search, consumed on the device
+  // K4h: distance column, two alternating histograms, list counter
+  DevBuf<uint16_t> dDist16;
+  DevBuf<uint32_t> dHamHist, dHamCount;
+  uint32_t ham_parity = 0;
+  bool ham_ready = false, ham_dirty = false;
   // batched search (K2)
   DevBuf<float> dBQ, dBTau, dBSample;
   DevBuf<vt::BatchCand> dBCand;
@@ -293,6 +298,9 @@ struct vt_flat {
 
 namespace {
 
+// Internal (never crosses the ABI): a device-side list overflowed, redo on the general path.
+constexpr int kRetryInternal = -100;
+
 // ------------------------------------------------------------------ selection
 // One select launch + stream sync; the k winners arrive in c.hRes (pinned,
 // written by the kernel through the host mapping).
@@ -312,6 +320,7 @@ int collect_from_keys(Ctx &c, const uint64_t *keys, const vt::Payload *pay, uint
   while (out.size() < goal) {
     const uint32_t k = (uint32_t)std::min<size_t>((size_t)vt::kMaxFusedK, goal - out.size());
     VT_TRY(select_pass(c, keys, pay, m, k, lo, has_lo));
+    if (c.hRes.p->status == vt::kStatusRetry) return kRetryInternal;
     if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
     const uint32_t got = c.hRes.p->count;
     for (uint32_t i = 0; i < got; ++i) out.push_back(c.hRes.p->e[i]);
@@ -388,6 +397,7 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
       c.prof.scan_bytes += (uint64_t)j.n * j.d * 4;
       c.prof.merge_launches += 1;
     }
+    if (c.hRes.p->status == vt::kStatusRetry) return kRetryInternal;
     if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
     const uint32_t got = c.hRes.p->count;
     for (uint32_t i = 0; i < got; ++i) out.push_back(c.hRes.p->e[i]);
@@ -1548,12 +1558,68 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
   VT_TRY(upload_query(c, query, n, &qnz));
   VT_TRY(c.dQbits.ensure(words));
   VT_HIP(vt::launch_sign_pack(c.dQ.p, vt::padded_dim(d), 1, d, c.dQbits.p, 0, c.stream));
-  std::vector<vt::Entry> entries;
   const size_t ncand = std::min<size_t>(candidates, ix->n);
+  // K4h needs integer bins in LDS, one fused select, and enough rows to be worth two passes
+  const bool hist_ok = ncand <= (size_t)vt::kMaxFusedK && d <= vt::kHammingHistMaxDim && ix->n >= 16384 &&
+                       !std::getenv("VT_HAMMING_LISTS");
+  auto run = [&](bool use_hist) -> int {
+  std::vector<vt::Entry> entries;
   const uint32_t *gather = nullptr;
   uint32_t gather_stride = 1;
   bool timed_hamming = false;
-  if (ncand <= (size_t)vt::kMaxFusedK) {
+  if (use_hist) {
+    // stage 1 as a pure stream (K4h): distance column + histogram, threshold collect,
+    // select into the device block whose Entry.row column is stage 2's gather list
+    const uint32_t k1 = (uint32_t)ncand;
+    constexpr uint32_t kListCap = 65536, kHistStride = 8192;
+    VT_TRY(c.dDist16.ensure(((size_t)std::max<uint32_t>(ix->cap, ix->n) + 7) / 8 * 8));
+    VT_TRY(c.dHamHist.ensure(2 * kHistStride));
+    VT_TRY(c.dHamCount.ensure(1));
+    VT_TRY(c.dPartKeys.ensure(kListCap));
+    VT_TRY(c.dPartPay.ensure(kListCap));
+    VT_TRY(c.dStage.ensure(1));
+    if (!c.ham_ready || c.ham_dirty) {
+      VT_HIP(hipMemsetAsync(c.dHamHist.p, 0, 2 * kHistStride * sizeof(uint32_t), c.stream));
+      c.ham_ready = true;
+    }
+    c.ham_dirty = true;  // until this query's collect pass has been queued
+    vt::HammingHistArgs h{};
+    h.bits = ix->dBits.p;
+    h.qbits = c.dQbits.p;
+    h.n = ix->n;
+    h.words = words;
+    h.pairs = (words + 1) / 2;
+    h.d = d;
+    h.dist = c.dDist16.p;
+    h.hist = c.dHamHist.p + c.ham_parity * kHistStride;
+    h.list_count = c.dHamCount.p;
+    const uint32_t blocks = c.grid_for((ix->n + 63) / 64, vt::hamming_hist_lds_bytes(d), c.hamming_blocks_per_cu);
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+    VT_HIP(vt::launch_hamming_dist(h, blocks, c.stream));
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+    timed_hamming = c.profiling;
+    vt::HammingCollectArgs g{};
+    g.dist = c.dDist16.p;
+    g.id_rank = ix->dRank.p;
+    g.n = ix->n;
+    g.d = d;
+    g.k = k1;
+    g.hist = h.hist;
+    g.hist_next = c.dHamHist.p + (c.ham_parity ^ 1u) * kHistStride;
+    g.list_count = c.dHamCount.p;
+    g.keys = c.dPartKeys.p;
+    g.pay = c.dPartPay.p;
+    g.cap = kListCap;
+    g.status = c.dStatus.p;
+    VT_HIP(vt::launch_hamming_collect(g, (uint32_t)c.num_cus * 4, c.stream));
+    c.ham_parity ^= 1u;
+    c.ham_dirty = false;
+    // (no status pointer: a raised flag stays in dStatus for the final select)
+    VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, kListCap, k1, 0, 0, nullptr, c.dStage.p, c.dSelKeys.p, c.dSelPay.p,
+                             c.stream, c.dHamCount.p));
+    gather = &c.dStage.p->e[0].row;
+    gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
+  } else if (ncand <= (size_t)vt::kMaxFusedK) {
     // stage 1 stays on the device: hamming scan -> select into a device block
     // whose Entry.row column is the gather list of stage 2 (no host round trip)
     const uint32_t k1 = (uint32_t)ncand;
@@ -1631,6 +1697,10 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
     c.prof.hamming_bytes += (uint64_t)ix->n * words * 8;
   }
   return make_hits(ix, entries, out);
+  };
+  int rc = run(hist_ok);
+  if (rc == kRetryInternal) rc = run(false);  // more ties at the k-th distance than the list holds
+  return rc;
   });
 }
 

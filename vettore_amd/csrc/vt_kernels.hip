@@ -78,8 +78,10 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
                                                            uint64_t lo_key, int has_lo, int *dev_status,
                                                            ResultBlock *out, uint32_t slice,
                                                            uint64_t *__restrict__ part_keys,
-                                                           Payload *__restrict__ part_pay) {
+                                                           Payload *__restrict__ part_pay,
+                                                           const uint32_t *__restrict__ m_dev) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (m_dev) m = *m_dev < m ? *m_dev : m;  // list length decided on the device (hamming_collect_kernel)
   const bool partial = gridDim.x > 1;
   if (partial) {
     const uint32_t lo = blockIdx.x * slice;
@@ -416,6 +418,139 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
 }
 
 // ---------------------------------------------------------------------------
+// K4h: the Hamming candidate pass as a pure stream (resident corpus, k <= 256).
+// Distances are integers 0..d, so the k-th smallest is found exactly from a
+// histogram instead of carrying k-entry lists through the scan:
+//   hamming_dist_kernel     popcounts as in K4; writes the 2-byte distance of every
+//                           row and accumulates a (d+1)-bin histogram (LDS, flushed
+//                           once per block);
+//   hamming_collect_kernel  every block finds D* = the k-th smallest distance from
+//                           the histogram, then the grid sweeps the distance column
+//                           (2 bytes per row) and appends the rows with distance <=
+//                           D* -- all winners plus the ties at D* -- to one list,
+//                           keyed (distance, id rank); K3 selects the k best.
+// The scan neither reads id ranks nor touches candidate buffers, so its time does
+// not depend on k (K4: 168 us at k = 10, 249 us at k = 256 for 10M rows).
+// Two histograms alternate between queries: the collect pass of one query clears
+// the histogram of the next, block 0 of the distance pass clears the list counter.
+// ---------------------------------------------------------------------------
+template <int PAIRS>
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_dist_kernel(const HammingHistArgs a) {
+  extern __shared__ uint32_t hh_lds[];  // [d + 1]
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t pairs = PAIRS > 0 ? (uint32_t)PAIRS : a.pairs;
+  const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+  const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
+  const uint32_t ntiles = (a.n + kWave - 1) / kWave;
+  const uint32_t last_word = a.words - 1;
+  const uint32_t rem = a.d % 64;
+  const uint64_t last_mask = rem ? ((1ull << rem) - 1) : ~0ull;  // distances.rs:472-481 word_mask
+  const u64x2 *bits = reinterpret_cast<const u64x2 *>(a.bits);
+  for (uint32_t i = threadIdx.x; i <= a.d; i += blockDim.x) hh_lds[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.list_count = 0;
+  __syncthreads();
+  for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
+    const u64x2 *base = bits + ((size_t)t * pairs * kWave + lane);
+    uint32_t ham = 0;
+    if (PAIRS > 0) {
+      u64x2 v[PAIRS > 0 ? PAIRS : 1];
+#pragma unroll
+      for (int j = 0; j < PAIRS; ++j) v[j] = __builtin_nontemporal_load(base + (size_t)j * kWave);
+#pragma unroll
+      for (int j = 0; j < PAIRS; ++j) {
+        const uint32_t w0 = 2 * j, w1 = 2 * j + 1;
+        const uint64_t q0 = a.qbits[w0], q1 = w1 < a.words ? a.qbits[w1] : 0ull;
+        const uint64_t m0 = w0 == last_word ? last_mask : ~0ull, m1 = w1 == last_word ? last_mask : ~0ull;
+        ham += __popcll((v[j].x ^ q0) & m0) + __popcll((v[j].y ^ q1) & m1);
+      }
+    } else {
+      for (uint32_t j = 0; j < pairs; ++j) {
+        const u64x2 v = __builtin_nontemporal_load(base + (size_t)j * kWave);
+        const uint32_t w0 = 2 * j, w1 = 2 * j + 1;
+        const uint64_t q0 = a.qbits[w0], q1 = w1 < a.words ? a.qbits[w1] : 0ull;
+        const uint64_t m0 = w0 == last_word ? last_mask : ~0ull, m1 = w1 == last_word ? last_mask : ~0ull;
+        ham += __popcll((v.x ^ q0) & m0) + __popcll((v.y ^ q1) & m1);
+      }
+    }
+    const uint32_t grow = t * kWave + lane;
+    if (grow < a.n) {
+      a.dist[grow] = (uint16_t)ham;
+      atomicAdd(&hh_lds[ham], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i <= a.d; i += blockDim.x) {
+    const uint32_t c = hh_lds[i];
+    if (c) atomicAdd(&a.hist[i], c);
+  }
+}
+
+__global__ __launch_bounds__(256) void hamming_collect_kernel(const HammingCollectArgs a) {
+  extern __shared__ uint32_t hc_lds[];  // [d + 1]
+  __shared__ uint32_t s_dstar;
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t bins = a.d + 1;
+  for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) hc_lds[i] = a.hist[i];
+  // clear the other histogram for the next query (grid-wide, bins are few)
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < bins; i += gridDim.x * blockDim.x) a.hist_next[i] = 0;
+  __syncthreads();
+  if (threadIdx.x < kWave) {
+    // D* = smallest D with count(distance <= D) >= k; lane l owns bins [l*B, (l+1)*B)
+    const uint32_t B = (bins + kWave - 1) / kWave;
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < B; ++j) {
+      const uint32_t b = lane * B + j;
+      mine += b < bins ? hc_lds[b] : 0u;
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += t;
+    }
+    const uint32_t excl = incl - mine;
+    const uint32_t total = __shfl(incl, kWave - 1, kWave);
+    if (lane == 0 && total < a.k) s_dstar = a.d;  // fewer rows than k: everything qualifies
+    if (excl < a.k && a.k <= incl) {
+      uint32_t cum = excl, b = lane * B;
+      for (;; ++b) {
+        cum += hc_lds[b];
+        if (cum >= a.k) break;
+      }
+      s_dstar = b;
+    }
+  }
+  __syncthreads();
+  const uint32_t dstar = s_dstar;
+  // sweep the distance column, 8 rows (16 bytes) per load
+  const uint32_t n8 = (a.n + 7) / 8;
+  const u64x2 *d8 = reinterpret_cast<const u64x2 *>(a.dist);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += gridDim.x * blockDim.x) {
+    const u64x2 v = d8[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t row = i * 8 + j;
+      const uint32_t dv = (uint32_t)(((j < 4 ? v.x : v.y) >> (16 * (j & 3))) & 0xFFFFu);
+      if (row < a.n && dv <= dstar) {
+        const uint32_t pos = atomicAdd(a.list_count, 1u);
+        if (pos < a.cap) {
+          const float raw = (float)dv;  // distance as f32 (distances.rs:436)
+          const uint32_t rk = a.id_rank ? a.id_rank[row] : row;
+          a.keys[pos] = ((uint64_t)orderable(raw) << 32) | rk;
+          Payload p;
+          p.row = row;
+          p.raw = raw;
+          a.pay[pos] = p;
+        } else {
+          atomicMax(a.status, kStatusRetry);  // more ties than the list holds: the caller takes the K4 path
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K5: sign packing (compress_sign_bits, distances.rs:413-423).  One wave per
 // 64 coordinates: lane j tests v[j] >= 0.0, the wave ballot IS the word.
 // tiled != 0 writes K4's [tile][pair][row][2] layout, else plain [row][word].
@@ -731,21 +866,21 @@ hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hi
 
 hipError_t launch_select(const uint64_t *keys, const Payload *pay, uint32_t m, uint32_t k, uint64_t lo_key, int has_lo,
                          int *dev_status, ResultBlock *out, uint64_t *scratch_keys, Payload *scratch_pay,
-                         hipStream_t s) {
+                         hipStream_t s, const uint32_t *m_dev) {
   if (k == 0 || k > (uint32_t)kMaxFusedK) return hipErrorInvalidValue;
   const size_t lds = ((size_t)k + kSelCand) * 12;
-  if (m >= kSelTwoLevelMin && scratch_keys && scratch_pay) {
+  if (m >= kSelTwoLevelMin && scratch_keys && scratch_pay && !m_dev) {
     // long lists (k = 100 leaves 51 200 partial keys): kSelGroups blocks select in
     // parallel on slices, one block finishes on kSelGroups * k keys
     const uint32_t slice = (m + kSelGroups - 1) / kSelGroups;
     hipLaunchKernelGGL(select_topk_kernel, dim3(kSelGroups), dim3(1024), lds, s, keys, pay, m, k, lo_key, has_lo,
-                       dev_status, out, slice, scratch_keys, scratch_pay);
+                       dev_status, out, slice, scratch_keys, scratch_pay, nullptr);
     hipLaunchKernelGGL(select_topk_kernel, dim3(1), dim3(1024), lds, s, scratch_keys, scratch_pay, kSelGroups * k, k,
-                       0ull, 0, dev_status, out, 0u, nullptr, nullptr);
+                       0ull, 0, dev_status, out, 0u, nullptr, nullptr, nullptr);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(select_topk_kernel, dim3(1), dim3(1024), lds, s, keys, pay, m, k, lo_key, has_lo, dev_status, out,
-                     0u, nullptr, nullptr);
+                     0u, nullptr, nullptr, m_dev);
   return hipGetLastError();
 }
 
@@ -775,6 +910,37 @@ hipError_t launch_hamming_r(const HammingArgs &a, uint32_t blocks, hipStream_t s
 hipError_t launch_hamming(const HammingArgs &a, uint32_t blocks, hipStream_t s) {
   if (a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.words == 0 || a.pairs != (a.words + 1) / 2) return hipErrorInvalidValue;
   return a.k <= (uint32_t)kSmallK ? launch_hamming_r<kCapSmall>(a, blocks, s) : launch_hamming_r<kCapLarge>(a, blocks, s);
+}
+
+size_t hamming_hist_lds_bytes(uint32_t d) { return ((size_t)d + 1) * sizeof(uint32_t); }
+
+hipError_t launch_hamming_dist(const HammingHistArgs &a, uint32_t blocks, hipStream_t s) {
+  if (a.words == 0 || a.pairs != (a.words + 1) / 2 || a.d > kHammingHistMaxDim) return hipErrorInvalidValue;
+  const size_t lds = hamming_hist_lds_bytes(a.d);
+#define VT_HAMH_CASE(P)                                                                                   \
+  case P:                                                                                                 \
+    hipLaunchKernelGGL((hamming_dist_kernel<P>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a); \
+    break;
+  switch (a.pairs) {
+    VT_HAMH_CASE(1)
+    VT_HAMH_CASE(2)
+    VT_HAMH_CASE(3)
+    VT_HAMH_CASE(4)
+    VT_HAMH_CASE(6)
+    VT_HAMH_CASE(8)
+    VT_HAMH_CASE(12)
+    VT_HAMH_CASE(16)
+    default:
+      hipLaunchKernelGGL((hamming_dist_kernel<0>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+  }
+#undef VT_HAMH_CASE
+  return hipGetLastError();
+}
+
+hipError_t launch_hamming_collect(const HammingCollectArgs &a, uint32_t blocks, hipStream_t s) {
+  if (a.d > kHammingHistMaxDim || a.k == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(hamming_collect_kernel, dim3(blocks), dim3(256), hamming_hist_lds_bytes(a.d), s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32_t d, uint64_t *bits, int tiled,
