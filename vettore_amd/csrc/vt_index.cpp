@@ -74,6 +74,47 @@ int validate_finite(const float *v, size_t n) {
   return VT_OK;
 }
 
+// Splits [0, n) over up to 16 host threads (bulk ingest: validation and staging copies
+// are plain memory passes).  `f(lo, hi)` must not throw.
+template <class F>
+void parallel_for(size_t n, size_t grain, F f) {
+  unsigned threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  if (grain == 0) grain = 1;
+  threads = (unsigned)std::min<size_t>(threads, n / grain);
+  if (threads <= 1) {
+    f((size_t)0, n);
+    return;
+  }
+  const size_t per = (n + threads - 1) / threads;
+  std::vector<std::thread> pool;
+  pool.reserve(threads);
+  for (unsigned t = 0; t < threads; ++t) {
+    const size_t lo = (size_t)t * per, hi = std::min(n, lo + per);
+    if (lo < hi) pool.emplace_back([lo, hi, &f] { f(lo, hi); });
+  }
+  for (auto &th : pool) th.join();
+}
+
+// validate_vector over the rows of a dense matrix; the error of the FIRST failing row
+// (flat.rs:69-85 checks the batch in order).
+int validate_matrix(const float *rows, size_t count, size_t d, long expected) {
+  if (count == 0) return VT_OK;
+  if (d == 0) return VT_ERR_EMPTY;
+  if (expected >= 0 && d != (size_t)expected) return VT_ERR_DIMENSION;
+  std::mutex mu;
+  size_t first_bad = count;
+  parallel_for(count, 4096, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+      if (validate_finite(rows + i * d, d) != VT_OK) {
+        std::lock_guard<std::mutex> g(mu);
+        first_bad = std::min(first_bad, i);
+        return;
+      }
+    }
+  });
+  return first_bad < count ? VT_ERR_NON_FINITE : VT_OK;
+}
+
 inline bool id_less(const std::string &a, const std::string &b) { return a < b; }  // bytewise, like Rust String::cmp
 
 // Sorts `idx` with `less` on several threads (chunk sort + pairwise merges).
@@ -597,6 +638,11 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
   const uint32_t n_before = ix->n;
   std::vector<uint32_t> target(count);
   bool all_appended_in_order = true;
+  if (count > 1024) {  // bulk load: no rehash / regrowth inside the id loop
+    ix->row_of.reserve((size_t)ix->n + count);
+    ix->ids.reserve((size_t)ix->n + count);
+    ix->rank_host.reserve((size_t)ix->n + count);
+  }
   for (size_t i = 0; i < count; ++i) {
     bool is_new = false;
     target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new);
@@ -619,20 +665,26 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
     }
     VT_HIP(hipStreamSynchronize(c.stream));
   } else {
-    // pinned staging, rows padded to ld; runs of consecutive target rows go in one copy
+    // two pinned staging halves: host threads fill one (rows padded to ld) while the DMA
+    // of the other is in flight; runs of consecutive target rows go in one copy
     const size_t row_bytes = (size_t)ld * sizeof(float);
-    const size_t stage_rows = std::max<size_t>(1, std::min<size_t>(count, (64u << 20) / row_bytes));
-    VT_TRY(c.hStage.ensure(stage_rows * row_bytes));
-    float *stage = reinterpret_cast<float *>(c.hStage.p);
+    const size_t stage_rows = std::max<size_t>(1, std::min<size_t>(count, (256u << 20) / row_bytes));
+    VT_TRY(c.hStage.ensure(2 * stage_rows * row_bytes));
+    hipEvent_t done[2] = {c.ev2, c.ev3};
+    bool used[2] = {false, false};
     size_t i = 0;
-    while (i < count) {
+    for (int half = 0; i < count; half ^= 1) {
+      float *stage = reinterpret_cast<float *>(c.hStage.p) + (size_t)half * stage_rows * ld;
       const size_t chunk = std::min(stage_rows, count - i);
-      for (size_t j = 0; j < chunk; ++j) {
-        const float *row = src.off ? src.host + src.off[i + j] : src.host + (i + j) * src.d;
-        float *dst = stage + j * ld;
-        std::memcpy(dst, row, d * sizeof(float));
-        for (size_t t = d; t < ld; ++t) dst[t] = 0.0f;
-      }
+      if (used[half]) VT_HIP(hipEventSynchronize(done[half]));  // its previous copies have left the buffer
+      parallel_for(chunk, 2048, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+          const float *row = src.off ? src.host + src.off[i + j] : src.host + (i + j) * src.d;
+          float *dst = stage + j * ld;
+          std::memcpy(dst, row, d * sizeof(float));
+          for (size_t t = d; t < ld; ++t) dst[t] = 0.0f;
+        }
+      });
       size_t j = 0;
       while (j < chunk) {
         size_t e = j + 1;
@@ -641,9 +693,11 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
                               hipMemcpyHostToDevice, c.stream));
         j = e;
       }
-      VT_HIP(hipStreamSynchronize(c.stream));
+      VT_HIP(hipEventRecord(done[half], c.stream));
+      used[half] = true;
       i += chunk;
     }
+    VT_HIP(hipStreamSynchronize(c.stream));
   }
   // keep device ranks current when they stayed valid (sorted appends)
   if (ix->ranks_clean && ix->n > n_before) {
@@ -1320,7 +1374,7 @@ int vt_flat_load_matrix(vt_flat *ix, size_t count, size_t d, const char *ids, co
   VT_TRY(ix->ctx.bind());
   long expected = ix->dim;
   if (expected < 0 && count > 0) expected = (long)d;
-  for (size_t i = 0; i < count; ++i) VT_TRY(validate_vector(rows + i * d, d, expected));
+  VT_TRY(validate_matrix(rows, count, d, expected));
   if (count == 0) return VT_OK;
   if (ix->dim < 0) VT_TRY(index_set_dim(ix, d));
   RowSource src;
