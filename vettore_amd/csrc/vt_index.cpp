@@ -539,6 +539,7 @@ int index_set_dim(vt_flat *ix, size_t d) {
   if (vt::scan_lds_bytes((uint32_t)d, 1) == 0)
     return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(d) + " exceeds what the scan kernel stages in LDS");
   const uint32_t ld = vt::padded_dim((uint32_t)d);
+  ix->ctx.ham_dirty = true;  // K4h's histograms are cleared for d + 1 bins only: a new dimension starts clean
   if (ld != ix->ld) {
     if (ix->dX) VT_HIP(hipFree(ix->dX));
     ix->dX = nullptr;
