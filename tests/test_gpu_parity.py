@@ -825,3 +825,24 @@ def test_concurrent_callers_on_shared_and_separate_handles(nifs, oracle_mod):
     assert len(writer) == len(o)
     for q in (wx[10], wx[2500], wx[2999]):
         assert bits(writer.search(q, 10)) == bits(o.search(q, 10))
+
+
+def test_quantized_histogram_pass_survives_dimension_changes(nifs, oracle_mod):
+    """An emptied index forgets its dimension (flat.rs:88-93); refilled with another one, the
+    histogram pass must not see counts left over from the wider rows."""
+    rng = np.random.default_rng(99)
+    g = GpuIndex(nifs, 0)
+    n = 17_000
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    for d in (128, 32, 128):
+        x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+        unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+        for _ in range(2):
+            q = rng.uniform(-1, 1, d).astype(np.float32)
+            ham = ((x >= 0) != (q >= 0)[None, :]).sum(axis=1)
+            order = sorted(range(n), key=lambda i: (int(ham[i]), ids[i]))[:50]
+            want = oracle_mod.vector_top_k([(ids[i], x[i]) for i in order], q, 0, d, 10)
+            assert bits(unwrap(nifs.flat_quantized_search(g.ref, q, 50, 10))) == bits(want), d
+        for i in ids:
+            g.delete(i)
+        assert len(g) == 0 and g.dimension is None
