@@ -96,6 +96,11 @@ uint32_t vt_hits_rank_key(const vt_hits *hits, size_t i);
 #define VT_HIT_RECORD_BYTES 64
 #define VT_HIT_RECORD_ID_BYTES 52
 size_t vt_hits_pack(const vt_hits *hits, void *records, size_t cap);
+/* All hits in one call (bindings that would otherwise cross the ABI three times per hit):
+ * vt_hits_id_bytes = total id bytes; vt_hits_export fills ids (concatenated), id_off
+ * (len + 1 offsets), raw and rank_key (each len entries; null pointers are skipped). */
+size_t vt_hits_id_bytes(const vt_hits *hits);
+void vt_hits_export(const vt_hits *hits, char *ids, size_t *id_off, float *raw, uint32_t *rank_key);
 void vt_hits_free(vt_hits *hits);
 
 /* ----------------------------------------------------------- flat index

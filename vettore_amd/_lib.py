@@ -17,7 +17,8 @@ ORDER_PAIR, ORDER_AVX, ORDER_SEQ = 0, 1, 2
 # every symbol include/vettore_flat.h declares
 SYMBOLS = [
     "vt_strerror", "vt_last_error", "vt_abi_version", "vt_device_count",
-    "vt_hits_len", "vt_hits_id", "vt_hits_raw", "vt_hits_rank_key", "vt_hits_pack", "vt_hits_free",
+    "vt_hits_len", "vt_hits_id", "vt_hits_raw", "vt_hits_rank_key", "vt_hits_pack", "vt_hits_id_bytes", "vt_hits_export",
+    "vt_hits_free",
     "vt_flat_new", "vt_flat_free", "vt_flat_insert", "vt_flat_insert_many", "vt_flat_delete",
     "vt_flat_search", "vt_flat_search_batch", "vt_flat_len", "vt_flat_dimension", "vt_flat_metric",
     "vt_flat_set_reduce_order", "vt_set_default_reduce_order",
@@ -67,6 +68,10 @@ def load() -> C.CDLL:
     L.vt_hits_rank_key.argtypes = [vp, C.c_size_t]
     L.vt_hits_pack.restype = C.c_size_t
     L.vt_hits_pack.argtypes = [vp, vp, C.c_size_t]
+    L.vt_hits_id_bytes.restype = C.c_size_t
+    L.vt_hits_id_bytes.argtypes = [vp]
+    L.vt_hits_export.restype = None
+    L.vt_hits_export.argtypes = [vp, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.vt_hits_free.restype = None
     L.vt_hits_free.argtypes = [vp]
     L.vt_flat_new.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]

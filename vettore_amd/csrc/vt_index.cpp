@@ -1294,6 +1294,26 @@ size_t vt_hits_pack(const vt_hits *h, void *records, size_t cap) {
   }
   return n;
 }
+size_t vt_hits_id_bytes(const vt_hits *h) {
+  size_t total = 0;
+  if (h)
+    for (const auto &id : h->ids) total += id.size();
+  return total;
+}
+
+void vt_hits_export(const vt_hits *h, char *ids, size_t *id_off, float *raw, uint32_t *rank_key) {
+  if (!h) return;
+  size_t pos = 0;
+  for (size_t i = 0; i < h->ids.size(); ++i) {
+    if (id_off) id_off[i] = pos;
+    if (ids) std::memcpy(ids + pos, h->ids[i].data(), h->ids[i].size());
+    pos += h->ids[i].size();
+    if (raw) raw[i] = h->raw[i];
+    if (rank_key) rank_key[i] = h->rank_key[i];
+  }
+  if (id_off) id_off[h->ids.size()] = pos;
+}
+
 void vt_hits_free(vt_hits *h) { delete h; }
 
 int vt_flat_new(int metric_code, int device, vt_flat **out) {

@@ -123,30 +123,32 @@ def _err(status: int):
     return ("error", _lib.error_text(status))
 
 
-def _take_hits(h) -> List[Tuple[bytes, float]]:
+def _export_hits(h, with_keys: bool):
+    """One bulk copy across the ABI, then Python slicing."""
     L = _lib.load()
-    out = []
     try:
-        ln = C.c_size_t()
-        for i in range(L.vt_hits_len(h)):
-            p = L.vt_hits_id(h, i, C.byref(ln))
-            out.append((C.string_at(p, ln.value), float(L.vt_hits_raw(h, i))))
+        n = L.vt_hits_len(h)
+        if n == 0:
+            return []
+        blob = C.create_string_buffer(max(1, L.vt_hits_id_bytes(h)))
+        off = (C.c_size_t * (n + 1))()
+        raw = (C.c_float * n)()
+        keys = (C.c_uint32 * n)() if with_keys else None
+        L.vt_hits_export(h, blob, off, raw, keys)
+        data = blob.raw
+        if with_keys:
+            return [(data[off[i]:off[i + 1]], float(raw[i]), int(keys[i])) for i in range(n)]
+        return [(data[off[i]:off[i + 1]], float(raw[i])) for i in range(n)]
     finally:
         L.vt_hits_free(h)
-    return out
+
+
+def _take_hits(h) -> List[Tuple[bytes, float]]:
+    return _export_hits(h, False)
 
 
 def _take_hits_with_keys(h):
-    L = _lib.load()
-    out = []
-    try:
-        ln = C.c_size_t()
-        for i in range(L.vt_hits_len(h)):
-            p = L.vt_hits_id(h, i, C.byref(ln))
-            out.append((C.string_at(p, ln.value), float(L.vt_hits_raw(h, i)), int(L.vt_hits_rank_key(h, i))))
-    finally:
-        L.vt_hits_free(h)
-    return out
+    return _export_hits(h, True)
 
 
 # ----------------------------------------------------------------- flat_new_*
