@@ -30,7 +30,13 @@ $(LIBDIR)/libvettore_hip.so: $(DEVOBJ) $(LIBDIR)/vt_index.o
 oracle:
 	$(MAKE) -C oracle -s
 
-clean:
-	rm -rf $(LIBDIR) oracle/libvt_oracle.so
+# stand-alone hardware probes quoted in DESIGN.md (not part of the library)
+PROBES := tools/hbm_peak tools/launch_probe tools/mfma_peak tools/mfma_agpr
+probes: $(PROBES)
+tools/%: tools/%.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@
 
-.PHONY: all oracle clean
+clean:
+	rm -rf $(LIBDIR) oracle/libvt_oracle.so $(PROBES)
+
+.PHONY: all oracle clean probes
