@@ -16,16 +16,16 @@
 //           (score, row) with score >= tau_b to the query's candidate list.
 //
 // Work split: a wave owns 32 rows x (NT*32) queries (NT*16 accumulator VGPRs).
-// Both operands of a 32-wide k chunk go through LDS, double buffered, filled by
+// Both operands of a 32-wide k chunk go through LDS (a ring of three stages), filled by
 // LDS-DMA (global_load_lds, 16 B/lane, whole 128-B lines, no staging
 // registers): the Q chunk (all queries) is shared by the block, each wave's 32
 // X rows are private to it.  The images are linear [row][8 slots of 16 B] and
 // the slot index is XOR-swizzled with (row >> 1) & 7 -- applied to the per-lane
 // SOURCE address on the way in and to the read address on the way out -- which
 // makes every ds_read_b128 conflict-free.  (Fragment-shaped X loads straight to
-// registers were measured 6-20 % slower: 32 B per row per instruction.)  k is permuted inside a chunk
-// (lane half h owns k = 16h..16h+15) -- harmless for a sum that only nominates
-// candidates.
+// registers were measured 6-20 % slower: 32 B per row per instruction.)  k is
+// permuted inside a chunk (lane half h owns k = 16h..16h+15) -- harmless for a sum
+// that only nominates candidates.
 #include "vt_common.cuh"
 
 #include <cstdlib>
@@ -52,18 +52,9 @@ __device__ __forceinline__ void dma16(uint32_t lds_addr, const void *base, uint3
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(sl), "v"(lane_off), "s"(sb) : "m0");
 }
 
-// The same with a base that is already in SGPRs (made scalar once per chunk).
-__device__ __forceinline__ uint64_t scalar64(const void *p) {
-  const uint64_t b = reinterpret_cast<uint64_t>(p);
-  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
-         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-}
-__device__ __forceinline__ void dma16s(uint32_t lds_addr, uint64_t sbase, uint32_t lane_off) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(lane_off), "s"(sbase) : "m0");
-}
-
 // Cold path of the epilogue: some score of this lane's 16 (one query column, 16
-// rows) reaches the threshold.  Kept out of line so the hot loop stays lean.
+// rows) reaches the threshold.  Inlined into its (rare) branch: as an out-of-line call
+// it made the wave save and restore its live registers, 4 % of the pass.
 __device__ __forceinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v, float tau, uint32_t qcol,
                                                uint32_t row0, int h) {
 #pragma unroll
@@ -343,13 +334,13 @@ __global__ __launch_bounds__(kRowWaves *kWave, 1) void mfma_scores_kernel3(const
   float *xlds0 = qlds + NS * (NQ * kQStride);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)qlds;
   const char *xbase = nullptr;  // first row of the DMA cursor's block tile
-  uint64_t qb_c = 0, xb_c = 0;  // scalar bases of the chunk being fetched
+  const char *qb_p = nullptr, *xb_p = nullptr;  // bases of the chunk being fetched
   auto dma_q = [&](int i, int stage) {
-    dma16s(lds0 + (uint32_t)(stage * (NQ * kQStride) + (wid * kDma + i) * 8 * kQStride) * 4u, qb_c, qoff[i]);
+    dma16(lds0 + (uint32_t)(stage * (NQ * kQStride) + (wid * kDma + i) * 8 * kQStride) * 4u, qb_p, qoff[i]);
   };
   auto dma_x = [&](int i, int stage) {
-    dma16s(lds0 + (uint32_t)(NS * (NQ * kQStride) + stage * (kTileRowsB * kQStride) + (wid * kDma + i) * 8 * kQStride) * 4u,
-           xb_c, xoff[i]);
+    dma16(lds0 + (uint32_t)(NS * (NQ * kQStride) + stage * (kTileRowsB * kQStride) + (wid * kDma + i) * 8 * kQStride) * 4u,
+          xb_p, xoff[i]);
   };
   auto tile_base = [&](uint32_t k) {
     const uint32_t tile = blockIdx.x + k * gridDim.x;
@@ -368,8 +359,8 @@ __global__ __launch_bounds__(kRowWaves *kWave, 1) void mfma_scores_kernel3(const
     }
   };
   auto set_chunk = [&](uint32_t c) {
-    qb_c = scalar64(reinterpret_cast<const char *>(a.Q) + (size_t)c * 128);
-    xb_c = scalar64(xbase + (size_t)c * 128);
+    qb_p = reinterpret_cast<const char *>(a.Q) + (size_t)c * 128;
+    xb_p = xbase + (size_t)c * 128;
   };
   uint32_t dk = 0, dc = 0;  // DMA cursor; stays on the last chunk past the end
   auto dma_advance = [&]() {
