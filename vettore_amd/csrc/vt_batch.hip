@@ -44,12 +44,14 @@ constexpr int kQStride = 32;        // LDS floats per query row of a 32-k chunk 
 // One LDS-DMA piece: 64 lanes x 16 B from (wave-uniform base + 32-bit lane offset) to
 // LDS at lds_addr + lane * 16.  Written out so that the address is the SGPR-base form
 // (no 64-bit VALU add per piece) and the m0 write sits right in front of the load.
+// m0 is not listed as clobbered (the compiler reserves it); nothing else in these kernels
+// uses it: gfx9+ LDS instructions do not, and there is no register-indexed access.
 __device__ __forceinline__ void dma16(uint32_t lds_addr, const void *base, uint32_t lane_off) {
   const uint64_t b = reinterpret_cast<uint64_t>(base);
   const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
   const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(sl), "v"(lane_off), "s"(sb) : "m0");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(sl), "v"(lane_off), "s"(sb));
 }
 
 // Cold path of the epilogue: some score of this lane's 16 (one query column, 16
