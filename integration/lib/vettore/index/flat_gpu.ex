@@ -13,7 +13,7 @@ defmodule Vettore.Index.FlatGpu do
   """
   @behaviour Vettore.Index
 
-  alias Vettore.{Collection, Embedding}
+  alias Vettore.{Collection, Distance, Embedding, Result}
   alias Vettore.Gpu.Nifs
 
   @max_nif_usize 4_294_967_295
@@ -114,9 +114,12 @@ defmodule Vettore.Index.FlatGpu do
     end
   end
 
-  defp to_result(%Collection{} = collection, {id, raw}) do
-    case Collection.fetch_embedding(collection, id) do
-      {:ok, embedding} -> [Collection.to_result(collection, embedding, raw)]
+  # a hit whose record has left ETS in the meantime is dropped, like flat.ex does
+  defp to_result(%Collection{metric: metric, score: mode} = collection, {id, raw}) do
+    with {:ok, %Embedding{value: value, metadata: metadata}} <- Collection.get(collection, id) do
+      {score, distance} = Distance.result_values(metric, raw, mode)
+      [%Result{id: id, value: value, score: score, distance: distance, metric: metric, metadata: metadata}]
+    else
       _ -> []
     end
   end
@@ -125,9 +128,8 @@ defmodule Vettore.Index.FlatGpu do
   defp unit({:error, _} = error), do: error
 
   defp validate_opts(opts) do
-    if Keyword.keyword?(opts) and Enum.all?(Keyword.keys(opts), &(&1 == :limit)),
-      do: :ok,
-      else: {:error, :invalid_options}
+    only_limit? = is_list(opts) and Keyword.keyword?(opts) and Keyword.keys(opts) -- [:limit] == []
+    if only_limit?, do: :ok, else: {:error, :invalid_search_options}
   end
 
   defp validate_limit(limit) when is_integer(limit) and limit > 0 and limit <= @max_nif_usize, do: :ok
