@@ -410,6 +410,104 @@ static ERL_NIF_TERM compress_sign_bits(ErlNifEnv *env, int argc, const ERL_NIF_T
   return res;
 }
 
+/* [{id, [element]}] -> ids + id_off + values + value_off, as the C ABI's ragged batches expect.
+ * `u64` selects [u64] rows (binary_top_k) instead of [float] rows (vector_top_k). */
+typedef struct { char *ids; size_t *id_off; void *vals; size_t *val_off; unsigned count; } ragged;
+
+static void ragged_free(ragged *g) { free(g->ids); free(g->id_off); free(g->vals); free(g->val_off); }
+
+static int get_u64_list(ErlNifEnv *env, ERL_NIF_TERM list, uint64_t **out, size_t *n) {
+  unsigned len;
+  if (!enif_get_list_length(env, list, &len)) return 0;
+  uint64_t *v = (uint64_t *)malloc((len ? len : 1) * sizeof(uint64_t));
+  if (!v) return 0;
+  ERL_NIF_TERM head, tail = list;
+  for (unsigned i = 0; i < len; ++i) {
+    ErlNifUInt64 w;
+    if (!enif_get_list_cell(env, tail, &head, &tail) || !enif_get_uint64(env, head, &w)) { free(v); return 0; }
+    v[i] = (uint64_t)w;
+  }
+  *out = v;
+  *n = len;
+  return 1;
+}
+
+static int get_ragged(ErlNifEnv *env, ERL_NIF_TERM list, int u64, ragged *g) {
+  memset(g, 0, sizeof *g);
+  if (!enif_get_list_length(env, list, &g->count)) return 0;
+  g->id_off = (size_t *)calloc(g->count + 1, sizeof(size_t));
+  g->val_off = (size_t *)calloc(g->count + 1, sizeof(size_t));
+  if (!g->id_off || !g->val_off) return 0;
+  const size_t esz = u64 ? sizeof(uint64_t) : sizeof(float);
+  size_t ids_cap = 0, vals_cap = 0;
+  ERL_NIF_TERM head, tail = list;
+  for (unsigned i = 0; i < g->count; ++i) {
+    const ERL_NIF_TERM *pair;
+    int arity;
+    ErlNifBinary id;
+    void *v = NULL;
+    size_t n = 0;
+    if (!enif_get_list_cell(env, tail, &head, &tail) || !enif_get_tuple(env, head, &arity, &pair) || arity != 2 ||
+        !enif_inspect_binary(env, pair[0], &id))
+      return 0;
+    if (!(u64 ? get_u64_list(env, pair[1], (uint64_t **)&v, &n) : get_f32_list(env, pair[1], (float **)&v, &n))) return 0;
+    if (g->id_off[i] + id.size > ids_cap) {
+      ids_cap = (g->id_off[i] + id.size) * 2 + 64;
+      g->ids = (char *)realloc(g->ids, ids_cap);
+    }
+    if (g->val_off[i] + n > vals_cap) {
+      vals_cap = (g->val_off[i] + n) * 2 + 64;
+      g->vals = realloc(g->vals, vals_cap * esz);
+    }
+    if (!g->ids || !g->vals) { free(v); return 0; }
+    memcpy(g->ids + g->id_off[i], id.data, id.size);
+    memcpy((char *)g->vals + g->val_off[i] * esz, v, n * esz);
+    g->id_off[i + 1] = g->id_off[i] + id.size;
+    g->val_off[i + 1] = g->val_off[i] + n;
+    free(v);
+  }
+  return 1;
+}
+
+/* vector_top_k([{id, [float]}], [float], metric_code, dims, limit)        nifs.rs:151-162 */
+static ERL_NIF_TERM vector_top_k(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  ragged g;
+  float *q = NULL;
+  size_t nq, dims, limit;
+  int code;
+  (void)argc;
+  if (!get_ragged(env, argv[0], 0, &g) || !get_f32_list(env, argv[1], &q, &nq) || !enif_get_int(env, argv[2], &code) ||
+      !get_size(env, argv[3], &dims) || !get_size(env, argv[4], &limit)) {
+    ragged_free(&g);
+    free(q);
+    return enif_make_badarg(env);
+  }
+  vt_hits *h;
+  int st = vt_vector_top_k(0, g.count, g.ids ? g.ids : "", g.id_off, (const float *)g.vals, g.val_off, q, nq, code, dims, limit, &h);
+  ragged_free(&g);
+  free(q);
+  return st == VT_OK ? ok_hits(env, h) : mk_error(env, st);
+}
+
+/* binary_top_k([{id, [u64]}], [u64], dims, limit)                         nifs.rs:164-175 */
+static ERL_NIF_TERM binary_top_k(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  ragged g;
+  uint64_t *q = NULL;
+  size_t nq, dims, limit;
+  (void)argc;
+  if (!get_ragged(env, argv[0], 1, &g) || !get_u64_list(env, argv[1], &q, &nq) || !get_size(env, argv[2], &dims) ||
+      !get_size(env, argv[3], &limit)) {
+    ragged_free(&g);
+    free(q);
+    return enif_make_badarg(env);
+  }
+  vt_hits *h;
+  int st = vt_binary_top_k(0, g.count, g.ids ? g.ids : "", g.id_off, (const uint64_t *)g.vals, g.val_off, q, nq, dims, limit, &h);
+  ragged_free(&g);
+  free(q);
+  return st == VT_OK ? ok_hits(env, h) : mk_error(env, st);
+}
+
 static int load(ErlNifEnv *env, void **priv, ERL_NIF_TERM info) {
   (void)priv; (void)info;
   FLAT = enif_open_resource_type(env, NULL, "vettore_gpu_flat", flat_dtor, ERL_NIF_RT_CREATE, NULL);
@@ -429,6 +527,8 @@ static ErlNifFunc funcs[] = {
   {"flat_hybrid_search", 4, flat_hybrid_search, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"normalize_l2", 1, normalize_l2, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"compress_sign_bits", 1, compress_sign_bits, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"vector_top_k", 5, vector_top_k, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"binary_top_k", 4, binary_top_k, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 
 ERL_NIF_INIT(Elixir.Vettore.Gpu.Nifs, funcs, load, NULL, NULL, NULL)

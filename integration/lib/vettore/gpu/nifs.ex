@@ -27,4 +27,6 @@ defmodule Vettore.Gpu.Nifs do
   def flat_hybrid_search(_ref, _query, _generators, _limit), do: :erlang.nif_error(:nif_not_loaded)
   def normalize_l2(_vector), do: :erlang.nif_error(:nif_not_loaded)
   def compress_sign_bits(_vector), do: :erlang.nif_error(:nif_not_loaded)
+  def vector_top_k(_vectors, _query, _metric_code, _dimensions, _limit), do: :erlang.nif_error(:nif_not_loaded)
+  def binary_top_k(_vectors, _query, _dimensions, _limit), do: :erlang.nif_error(:nif_not_loaded)
 end
