@@ -846,3 +846,30 @@ def test_quantized_histogram_pass_survives_dimension_changes(nifs, oracle_mod):
         for i in ids:
             g.delete(i)
         assert len(g) == 0 and g.dimension is None
+
+
+def test_padding_columns_of_a_small_batch_nominate_nothing(nifs, oracle_mod):
+    """A batch of 8 is padded to 32 query columns; the all-zero padding columns once passed
+    every row as a candidate (45x slower than a full 32-query batch).  Timing guard with a
+    wide margin, plus parity of the small batch itself."""
+    import time
+    n, d = 300_000, 128
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    g = GpuIndex(nifs, 3)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    qs = rng.uniform(-1, 1, (32, d)).astype(np.float32)
+
+    def timed(batch):
+        unwrap(nifs.flat_search_batch(g.ref, batch, 10))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            out = unwrap(nifs.flat_search_batch(g.ref, batch, 10))
+        return (time.perf_counter() - t0) / 3, out
+
+    t32, _ = timed(qs)
+    t8, out8 = timed(qs[:8])
+    assert t8 < 5 * t32 + 5e-3, (t8, t32)
+    for i in range(8):
+        assert bits(out8[i]) == bits(unwrap(nifs.flat_search(g.ref, qs[i], 10)))

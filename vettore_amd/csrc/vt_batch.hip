@@ -501,7 +501,12 @@ __global__ __launch_bounds__(kRowWaves *kWave, 1) void mfma_scores_kernel3(const
 // comes out of L2 once per round.
 constexpr int kTauThreads = 1024;
 __global__ __launch_bounds__(kTauThreads) void sample_tau_kernel(const float *__restrict__ sample, uint32_t sample_rows,
-                                                                 uint32_t rank, float *__restrict__ tau) {
+                                                                 uint32_t rank, float *__restrict__ tau, uint32_t nq_real) {
+  // padding columns of the batch (all-zero queries) must never nominate a row
+  if (blockIdx.x >= nq_real) {
+    if (threadIdx.x == 0) tau[blockIdx.x] = INFINITY;
+    return;
+  }
   __shared__ float s_best[kTauThreads / kWave];
   __shared__ uint32_t s_idx[kTauThreads / kWave];
   __shared__ float s_cut;
@@ -693,9 +698,9 @@ hipError_t launch_batch_scores(const BatchScoreArgs &a0, bool dense, uint32_t bl
   }
 }
 
-hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t rank, float *tau,
-                             hipStream_t s) {
-  hipLaunchKernelGGL(sample_tau_kernel, dim3(nq), dim3(kTauThreads), 0, s, sample, sample_rows, rank, tau);
+hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t nq_real, uint32_t rank,
+                             float *tau, hipStream_t s) {
+  hipLaunchKernelGGL(sample_tau_kernel, dim3(nq), dim3(kTauThreads), 0, s, sample, sample_rows, rank, tau, nq_real);
   return hipGetLastError();
 }
 

@@ -207,8 +207,9 @@ struct BatchScoreArgs {
 };
 uint32_t batch_rows_per_block(uint32_t nq_pad);
 hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s);
-hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t rank, float *tau,
-                             hipStream_t s);
+// tau[b] for the nq_real real queries; +inf for the padding columns b >= nq_real.
+hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t nq_real, uint32_t rank,
+                             float *tau, hipStream_t s);
 // xnorm2[i] = (f32) sum_j x_ij^2 (f64 accumulation); *out_bits = bit pattern of
 // the f64 maximum over the rows (zero it first).
 hipError_t launch_row_sqnorms(const float *X, size_t stride, uint32_t n, uint32_t d, float *xnorm2,

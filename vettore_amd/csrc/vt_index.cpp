@@ -1076,7 +1076,7 @@ int batch_group(vt_flat *ix, const float *queries, size_t nq, size_t limit, vt_h
   a.sample_rows = sample_rows;
   const uint32_t grid_cap = (uint32_t)c.num_cus;
   VT_HIP(vt::launch_batch_scores(a, true, std::min<uint32_t>(ntiles_sample, grid_cap), c.stream));
-  VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, nq_pad, rank, c.dBTau.p, c.stream));
+  VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, nq_pad, (uint32_t)nq, rank, c.dBTau.p, c.stream));
   // pass 1: all rows, candidates with score >= tau
   a.n = n;
   a.sample = nullptr;
