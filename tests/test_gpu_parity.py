@@ -481,7 +481,10 @@ def test_quantized_search_histogram_pass(nifs, oracle_mod, shape):
     unwrap(nifs.flat_load_matrix(g.ref, ids, x))
     packed = oracle_mod.pack_ids(ids)
     xbits = np.stack([oracle_mod.compress_sign_bits(r) for r in x[:2]]) if shape == "all_equal" else None
-    for cand, limit in ((100, 10), (256, 30), (7, 7)):
+    # 257..4096 candidates: the candidate set stays on the device as an unsorted list;
+    # above that the host-staged multi-pass path
+    cases = ((100, 10), (256, 30), (7, 7)) + (((300, 20), (1000, 100), (4096, 10), (5000, 10)) if shape != "all_equal" else ((1000, 10),))
+    for cand, limit in cases:
         q = rng.uniform(-1, 1, d).astype(np.float32)
         qb = oracle_mod.compress_sign_bits(q)
         # oracle composition without materialising n Python tuples: distances via numpy popcount

@@ -90,6 +90,11 @@ hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hi
 // Keys <= lo_key are ignored when has_lo (multi-pass selection of k > kMaxFusedK).
 // Lists of >= kSelTwoLevelMin keys are selected in two levels (kSelGroups blocks on
 // slices, then one block); scratch_keys/scratch_pay hold kSelGroups * k entries.
+// The k smallest of a key list as a device-resident, unsorted list (k <= kSelListMax): the
+// candidate set of a following stage whose own ordering does not depend on this one.
+constexpr uint32_t kSelListMax = 4096;
+hipError_t launch_select_list(const uint64_t *keys, const Payload *pay, uint32_t m, const uint32_t *m_dev, uint32_t k,
+                              uint64_t *out_keys, Payload *out_pay, hipStream_t s);
 constexpr uint32_t kSelGroups = 16;
 constexpr uint32_t kSelTwoLevelMin = 16384;
 hipError_t launch_select(const uint64_t *keys, const Payload *pay, uint32_t m, uint32_t k, uint64_t lo_key, int has_lo,

@@ -204,6 +204,8 @@ struct Ctx {
   DevBuf<ResultBlock> dStage;  // stage-1 winners of quantized_search, consumed on the device
   // K4h: distance column, two alternating histograms, list counter
   DevBuf<uint16_t> dDist16;
+  DevBuf<uint64_t> dListKeys;  // candidate set of > 256 rows kept on the device
+  DevBuf<vt::Payload> dListPay;
   DevBuf<uint32_t> dHamHist, dHamCount;
   uint32_t ham_parity = 0;
   bool ham_ready = false, ham_dirty = false;
@@ -1635,7 +1637,7 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
   VT_HIP(vt::launch_sign_pack(c.dQ.p, vt::padded_dim(d), 1, d, c.dQbits.p, 0, c.stream));
   const size_t ncand = std::min<size_t>(candidates, ix->n);
   // K4h needs integer bins in LDS, one fused select, and enough rows to be worth two passes
-  const bool hist_ok = ncand <= (size_t)vt::kMaxFusedK && d <= vt::kHammingHistMaxDim && ix->n >= 16384 &&
+  const bool hist_ok = ncand <= (size_t)vt::kSelListMax && d <= vt::kHammingHistMaxDim && ix->n >= 16384 &&
                        !std::getenv("VT_HAMMING_LISTS");
   auto run = [&](bool use_hist) -> int {
   std::vector<vt::Entry> entries;
@@ -1689,11 +1691,22 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
     VT_HIP(vt::launch_hamming_collect(g, (uint32_t)c.num_cus * 4, c.stream));
     c.ham_parity ^= 1u;
     c.ham_dirty = false;
-    // (no status pointer: a raised flag stays in dStatus for the final select)
-    VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, kListCap, k1, 0, 0, nullptr, c.dStage.p, c.dSelKeys.p, c.dSelPay.p,
-                             c.stream, c.dHamCount.p));
-    gather = &c.dStage.p->e[0].row;
-    gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
+    if (k1 <= (uint32_t)vt::kMaxFusedK) {
+      // (no status pointer: a raised flag stays in dStatus for the final select)
+      VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, kListCap, k1, 0, 0, nullptr, c.dStage.p, c.dSelKeys.p, c.dSelPay.p,
+                               c.stream, c.dHamCount.p));
+      gather = &c.dStage.p->e[0].row;
+      gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
+    } else {
+      // up to 4 096 candidates (limit * 10 for limit <= 409): the exact candidate SET as a
+      // device list -- stage 2 orders by its own keys, so this one need not be sorted
+      VT_TRY(c.dListKeys.ensure(k1));
+      VT_TRY(c.dListPay.ensure(k1));
+      VT_HIP(vt::launch_select_list(c.dPartKeys.p, c.dPartPay.p, kListCap, c.dHamCount.p, k1, c.dListKeys.p, c.dListPay.p,
+                                    c.stream));
+      gather = &c.dListPay.p->row;
+      gather_stride = sizeof(vt::Payload) / sizeof(uint32_t);
+    }
   } else if (ncand <= (size_t)vt::kMaxFusedK) {
     // stage 1 stays on the device: hamming scan -> select into a device block
     // whose Entry.row column is the gather list of stage 2 (no host round trip)

@@ -82,8 +82,12 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
                                                            const uint32_t *__restrict__ m_dev) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (m_dev) m = *m_dev < m ? *m_dev : m;  // list length decided on the device (hamming_collect_kernel)
-  const bool partial = gridDim.x > 1;
-  if (partial) {
+  // part_keys != nullptr: the winners go, unsorted and padded with kEmptyKey, to
+  // part_keys/part_pay[blockIdx.x * k ..) instead of a result block -- the first level of
+  // a two-level select (several blocks, one slice each) or a device-resident list of up to
+  // kSelListMax rows for a following stage (one block).
+  const bool partial = part_keys != nullptr;
+  if (gridDim.x > 1) {
     const uint32_t lo = blockIdx.x * slice;
     keys += lo;
     pay += lo;
@@ -862,6 +866,17 @@ hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hi
   if (lds > kMaxLds || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.stride < sd.p.ld || !a.gather || !a.batch_counts)
     return hipErrorInvalidValue;
   return launch_scan_general(sd, blocks, nq, lds, s);
+}
+
+hipError_t launch_select_list(const uint64_t *keys, const Payload *pay, uint32_t m, const uint32_t *m_dev, uint32_t k,
+                              uint64_t *out_keys, Payload *out_pay, hipStream_t s) {
+  if (k == 0 || k > kSelListMax || !out_keys || !out_pay) return hipErrorInvalidValue;
+  const size_t lds = ((size_t)k + kSelCand) * 12;
+  hipError_t e = allow_lds(select_topk_kernel, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(select_topk_kernel, dim3(1), dim3(1024), lds, s, keys, pay, m, k, 0ull, 0, nullptr, nullptr, 0u,
+                     out_keys, out_pay, m_dev);
+  return hipGetLastError();
 }
 
 hipError_t launch_select(const uint64_t *keys, const Payload *pay, uint32_t m, uint32_t k, uint64_t lo_key, int has_lo,
