@@ -1182,12 +1182,15 @@ int batch_locked(vt_flat *ix, const float *queries, size_t nq, size_t d, size_t 
   std::vector<char> done(nq, 0);
   const bool mfma_metric = ix->metric == VT_COSINE || ix->metric == VT_INNER_PRODUCT ||
                            ix->metric == VT_NEG_INNER_PRODUCT || ix->metric == VT_L2 || ix->metric == VT_L2_SQUARED;
-  const bool use_mfma = mfma_metric && nq >= 8 && limit <= (size_t)vt::kMaxFusedK && ix->n >= 4096 &&
+  // one shared pass over the corpus costs about 1.3 single scans (HBM-bound below 33 queries),
+  // so it pays from two queries on
+  const bool use_mfma = mfma_metric && nq >= 2 && limit <= (size_t)vt::kMaxFusedK && ix->n >= 4096 &&
                         std::getenv("VT_BATCH_NO_MFMA") == nullptr;
   if (use_mfma) {
     VT_TRY(index_sync_ranks(ix, false));
     for (size_t g0 = 0; g0 < nq; g0 += 256) {
       const size_t gn = std::min<size_t>(256, nq - g0);
+      if (gn < 2) continue;  // a lone trailing query takes the single-query path below
       std::vector<char> gdone(gn, 0);
       VT_TRY(batch_group(ix, queries + g0 * d, gn, limit, out + g0, gdone));
       for (size_t i = 0; i < gn; ++i) done[g0 + i] = gdone[i];
