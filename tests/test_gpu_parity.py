@@ -876,3 +876,60 @@ def test_padding_columns_of_a_small_batch_nominate_nothing(nifs, oracle_mod):
     assert t8 < 5 * t32 + 5e-3, (t8, t32)
     for i in range(8):
         assert bits(out8[i]) == bits(unwrap(nifs.flat_search(g.ref, qs[i], 10)))
+
+
+@pytest.mark.parametrize("metric", [2, 0, 5])
+def test_limits_above_256_in_one_scan(nifs, oracle_mod, metric):
+    """Above 65 536 rows a limit of 257..4096 is answered from a key column and a radix
+    threshold instead of one scan per 256 hits; 5 000 still takes the pass-per-256 loop.
+    Both must equal the oracle's full sort, ties by id bytes included."""
+    n, d = 70_000, 24
+    x, ids = make_corpus(n, d, 1200 + metric, metric == 2, oracle_mod, tie_block=600)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    packed = oracle_mod.pack_ids(ids)
+    rng = np.random.default_rng(8)
+    for limit in (300, 1000, 4096, 5000):
+        q = x[n // 2] if limit == 1000 else rng.uniform(-1, 1, d).astype(np.float32)   # 1000: inside the tie block
+        if metric == 2:
+            q = oracle_mod.normalize_l2(q)
+        want = oracle_mod.matrix_search(metric, x, packed, q, limit)
+        got = unwrap(nifs.flat_search(g.ref, q, limit))
+        assert bits(got) == bits(want), (metric, limit)
+
+
+def test_limit_above_256_with_more_ties_than_the_list_holds(nifs, oracle_mod):
+    """80 000 identical rows: every key shares its 33-bit prefix, the device list overflows and
+    the call must fall back to the pass-per-256 loop -- same answer as the oracle."""
+    n, d = 80_000, 16
+    x = np.tile(np.random.default_rng(3).uniform(-1, 1, (1, d)).astype(np.float32), (n, 1))
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    g = GpuIndex(nifs, 0)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    q = np.zeros(d, np.float32)
+    want = oracle_mod.matrix_search(0, x, oracle_mod.pack_ids(ids), q, 400)
+    assert bits(unwrap(nifs.flat_search(g.ref, q, 400))) == bits(want)
+
+
+@pytest.mark.parametrize("metric", [2, 0])
+def test_funnel_with_more_than_256_candidates(nifs, oracle_mod, metric):
+    """funnel_search(limit: 100) defaults to 1 000 candidates (collection.ex:547): the first stage
+    over all rows keeps them through the key-column threshold."""
+    n, d = 70_000, 48
+    x, ids = make_corpus(n, d, 1300 + metric, metric == 2, oracle_mod, tie_block=30)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rows = [(ids[i], x[i]) for i in range(n)]
+    by_id = dict(rows)
+    rng = np.random.default_rng(4)
+    for stages, cand, limit in (([16], 1000, 100), ([8, 24], 600, 20)):
+        q = rng.uniform(-1, 1, d).astype(np.float32)
+        if metric == 2:
+            q = oracle_mod.normalize_l2(q)
+        cur = rows
+        for st in stages:
+            kept = oracle_mod.vector_top_k(cur, q, metric, st, cand)
+            cur = [(i, by_id[i]) for i, _ in kept]
+        want = oracle_mod.vector_top_k(cur, q, metric, d, limit)
+        got = unwrap(nifs.flat_funnel_search(g.ref, q, stages, cand, limit))
+        assert bits(got) == bits(want), (metric, stages, cand, limit)

@@ -66,6 +66,10 @@ struct ScanArgs {
   const uint32_t *batch_counts;
   uint32_t batch_cap;
   uint32_t tile_rows;      // 0 / 32 (default), 16 or 8: rows per wave tile, see scan_tile_rows()
+  // Key-column mode (limits above kMaxFusedK): instead of keeping the k best, every scanned
+  // position i writes key_out[i] (kEmptyKey if the row is excluded) and, if given, pay_out[i].
+  uint64_t *key_out;
+  Payload *pay_out;
 };
 
 // Rows per wave tile for a scan of n rows of dimension d on `resident_waves` waves:
@@ -90,6 +94,27 @@ hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hi
 // Keys <= lo_key are ignored when has_lo (multi-pass selection of k > kMaxFusedK).
 // Lists of >= kSelTwoLevelMin keys are selected in two levels (kSelGroups blocks on
 // slices, then one block); scratch_keys/scratch_pay hold kSelGroups * k entries.
+// Exact k-th smallest of a key column by three 11-bit radix passes over the top 33 bits
+// (the whole rank key and the top id-rank bit), all decisions taken on the device:
+// launch_radix_pass for pass = 0, 1, 2 (hist zeroed beforehand), then launch_radix_collect
+// appends every key below the resolved 33-bit prefix, and the keys sharing it, to a list
+// (positions as payload rows); the caller selects the k best of that list.  A list overflow
+// raises kStatusRetry in *status.
+constexpr uint32_t kRadixBins = 2048;
+struct RadixArgs {
+  const uint64_t *keys;
+  uint32_t n;
+  uint32_t k;
+  uint32_t *hist;        // [3][kRadixBins]
+  uint32_t *list_count;  // cleared by pass 0
+  uint64_t *list_keys;   // [cap]
+  Payload *list_pay;     // [cap]: row = position in `keys`
+  uint32_t cap;
+  int *status;
+};
+hipError_t launch_radix_pass(const RadixArgs &a, int pass, uint32_t blocks, hipStream_t s);
+hipError_t launch_radix_collect(const RadixArgs &a, uint32_t blocks, hipStream_t s);
+
 // The k smallest of a key list as a device-resident, unsorted list (k <= kSelListMax): the
 // candidate set of a following stage whose own ordering does not depend on this one.
 constexpr uint32_t kSelListMax = 4096;
@@ -238,6 +263,7 @@ struct CosineScanArgs {
   uint64_t *part_keys;     // [grid_blocks][k]
   Payload *part_pay;
   int *status;
+  uint64_t *key_out;       // key-column mode, as in ScanArgs
 };
 size_t cosine_scan_lds_bytes(uint32_t d, uint32_t k);
 hipError_t launch_cosine_scan(const CosineScanArgs &a, uint32_t blocks, hipStream_t s);

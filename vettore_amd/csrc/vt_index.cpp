@@ -205,6 +205,8 @@ struct Ctx {
   // K4h: distance column, two alternating histograms, list counter
   DevBuf<uint16_t> dDist16;
   DevBuf<uint64_t> dListKeys;  // candidate set of > 256 rows kept on the device
+  DevBuf<uint64_t> dKeyCol;    // one key per row (limits above kMaxFusedK: radix threshold instead of wave buffers)
+  DevBuf<uint32_t> dRadixHist, dRadixCount;
   DevBuf<vt::Payload> dListPay;
   DevBuf<uint32_t> dHamHist, dHamCount;
   uint32_t ham_parity = 0;
@@ -387,6 +389,43 @@ struct ScanJob {
   uint32_t q_nonzero;
 };
 
+// Limits above kMaxFusedK in ONE scan: the scan has written a key per row into c.dKeyCol;
+// three radix passes + a collect pass + one list select leave the exact `k` best rows,
+// unsorted, in c.dListPay (Payload.row = position in the key column).
+constexpr size_t kThresholdMinRows = 65536;
+constexpr uint32_t kThresholdListCap = 65536;
+
+bool threshold_applies(size_t total, uint32_t n) {
+  return total > (size_t)vt::kMaxFusedK && total <= (size_t)vt::kSelListMax && n >= kThresholdMinRows &&
+         !std::getenv("VT_NO_THRESHOLD_SELECT");
+}
+
+int threshold_rows(Ctx &c, uint32_t n, uint32_t k) {
+  VT_TRY(c.dRadixHist.ensure(3 * vt::kRadixBins));
+  VT_TRY(c.dRadixCount.ensure(1));
+  VT_TRY(c.dPartKeys.ensure(kThresholdListCap));
+  VT_TRY(c.dPartPay.ensure(kThresholdListCap));
+  VT_TRY(c.dListKeys.ensure(k));
+  VT_TRY(c.dListPay.ensure(k));
+  VT_HIP(hipMemsetAsync(c.dRadixHist.p, 0, 3 * vt::kRadixBins * sizeof(uint32_t), c.stream));
+  vt::RadixArgs r{};
+  r.keys = c.dKeyCol.p;
+  r.n = n;
+  r.k = k;
+  r.hist = c.dRadixHist.p;
+  r.list_count = c.dRadixCount.p;
+  r.list_keys = c.dPartKeys.p;
+  r.list_pay = c.dPartPay.p;
+  r.cap = kThresholdListCap;
+  r.status = c.dStatus.p;
+  const uint32_t blocks = (uint32_t)c.num_cus * 8;
+  for (int pass = 0; pass < 3; ++pass) VT_HIP(vt::launch_radix_pass(r, pass, blocks, c.stream));
+  VT_HIP(vt::launch_radix_collect(r, blocks, c.stream));
+  VT_HIP(vt::launch_select_list(c.dPartKeys.p, c.dPartPay.p, kThresholdListCap, c.dRadixCount.p, k, c.dListKeys.p,
+                                c.dListPay.p, c.stream));
+  return VT_OK;
+}
+
 // Scan + select passes until `want` hits are collected (ascending by key).
 // The query must already be in c.dQ (padded to padded_dim(d)).
 int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out, bool count_profile) {
@@ -401,6 +440,56 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
   uint64_t lo = 0;
   bool has_lo = false;
   const size_t total = std::min<size_t>(want, j.n);
+  if (!j.gather && out.empty() && threshold_applies(total, j.n)) {
+    // one scan in key-column mode, exact threshold on the device, then the winners are
+    // re-scored through the gather list for their raw values and sorted
+    const uint32_t k = (uint32_t)total;
+    VT_TRY(c.dKeyCol.ensure(((size_t)j.n + 1) / 2 * 2));
+    VT_TRY(c.dPartKeys.ensure(kThresholdListCap));
+    VT_TRY(c.dPartPay.ensure(kThresholdListCap));
+    vt::ScanArgs a{};
+    a.X = j.X;
+    a.stride = j.stride;
+    a.q = c.dQ.p;
+    a.id_rank = j.id_rank;
+    a.n = j.n;
+    a.d = j.d;
+    a.metric = j.metric;
+    a.order = j.order;
+    a.k = 1;
+    a.q_nonzero = j.q_nonzero;
+    a.tile_rows = tile_rows;
+    a.part_keys = c.dPartKeys.p;
+    a.part_pay = c.dPartPay.p;
+    a.status = c.dStatus.p;
+    a.key_out = c.dKeyCol.p;
+    const bool timed = c.profiling && count_profile;
+    if (timed) VT_HIP(hipEventRecord(c.ev0, c.stream));
+    VT_HIP(vt::launch_scan(a, c.grid_for(ntiles, vt::scan_lds_bytes(j.d, 1)), c.stream));
+    if (timed) VT_HIP(hipEventRecord(c.ev1, c.stream));
+    VT_TRY(threshold_rows(c, j.n, k));
+    VT_TRY(c.dCandKeys.ensure(k));
+    VT_TRY(c.dCandPay.ensure(k));
+    vt::ScanArgs g = a;
+    g.gather = &c.dListPay.p->row;
+    g.gather_stride = sizeof(vt::Payload) / sizeof(uint32_t);
+    g.n = k;
+    g.tile_rows = 0;
+    g.key_out = c.dCandKeys.p;
+    g.pay_out = c.dCandPay.p;
+    VT_HIP(vt::launch_scan(g, c.grid_for((k + vt::kTileRows - 1) / vt::kTileRows, vt::scan_lds_bytes(j.d, 1)), c.stream));
+    const int rc = collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, k, k, out);
+    if (timed && rc != kRetryInternal) {
+      float ms = 0.f;
+      VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+      c.prof.scan_launches += 1;
+      c.prof.scan_ms += ms;
+      c.prof.scan_rows += j.n;
+      c.prof.scan_bytes += (uint64_t)j.n * j.d * 4;
+    }
+    if (rc != kRetryInternal) return rc;
+    out.clear();  // more equal keys at the threshold than the list holds: the pass-per-256 loop below
+  }
   while (out.size() < total) {
     const uint32_t k = (uint32_t)std::min<size_t>(kmax, total - out.size());
     const uint32_t blocks = c.grid_for(ntiles, vt::scan_lds_bytes(j.d, k));
@@ -766,6 +855,54 @@ int run_cosine_scan(Ctx &c, vt_flat *ix, uint32_t d, double qq, size_t want, std
   uint64_t lo = 0;
   bool has_lo = false;
   const size_t total = std::min<size_t>(want, ix->n);
+  if (out.empty() && threshold_applies(total, ix->n)) {
+    const uint32_t k = (uint32_t)total;
+    VT_TRY(c.dKeyCol.ensure(((size_t)ix->n + 1) / 2 * 2));
+    VT_TRY(c.dPartKeys.ensure(kThresholdListCap));
+    VT_TRY(c.dPartPay.ensure(kThresholdListCap));
+    vt::CosineScanArgs a{};
+    a.X = ix->dX;
+    a.stride = ix->ld;
+    a.q = c.dQ.p;
+    a.qq = qq;
+    a.id_rank = ix->dRank.p;
+    a.n = ix->n;
+    a.d = d;
+    a.k = 1;
+    a.part_keys = c.dPartKeys.p;
+    a.part_pay = c.dPartPay.p;
+    a.status = c.dStatus.p;
+    a.key_out = c.dKeyCol.p;
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+    VT_HIP(vt::launch_cosine_scan(a, c.grid_for((ix->n + 63) / 64, vt::cosine_scan_lds_bytes(d, 1)), c.stream));
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+    VT_TRY(threshold_rows(c, ix->n, k));
+    VT_TRY(c.dCandKeys.ensure(k));
+    VT_TRY(c.dCandPay.ensure(k));
+    vt::CosineRerankArgs g{};
+    g.X = ix->dX;
+    g.stride = ix->ld;
+    g.q = c.dQ.p;
+    g.id_rank = ix->dRank.p;
+    g.gather = &c.dListPay.p->row;
+    g.gather_stride = sizeof(vt::Payload) / sizeof(uint32_t);
+    g.n = k;
+    g.d = d;
+    g.out_keys = c.dCandKeys.p;
+    g.out_pay = c.dCandPay.p;
+    g.status = c.dStatus.p;
+    VT_HIP(vt::launch_cosine_rerank(g, c.stream));
+    const int rc = collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, k, k, out);
+    if (c.profiling && rc != kRetryInternal) {
+      float ms = 0.0f;
+      VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+      c.prof.prefix_launches += 1;
+      c.prof.prefix_ms += ms;
+      c.prof.prefix_bytes += (uint64_t)ix->n * d * 4;
+    }
+    if (rc != kRetryInternal) return rc;
+    out.clear();
+  }
   while (out.size() < total) {
     const uint32_t k = (uint32_t)std::min<size_t>(kmax, total - out.size());
     const uint32_t blocks = c.grid_for((ix->n + 63) / 64, vt::cosine_scan_lds_bytes(d, k));

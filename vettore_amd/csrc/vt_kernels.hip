@@ -778,11 +778,134 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_kernel(cons
     }
     const uint64_t key = ((uint64_t)orderable(1.0f - raw) << 32) | my_rank;
     if (a.has_lo) valid = valid && key > a.lo_key;
-    tk.offer(valid, key, grow, raw, lane);
+    if (a.key_out) {
+      if (valid_row) a.key_out[grow] = valid ? key : kEmptyKey;
+    } else {
+      tk.offer(valid, key, grow, raw, lane);
+    }
   }
+  if (a.key_out) return;
   __shared__ uint32_t s_counts[kWavesPerBlock];
   tk.merge_block(wib, kWavesPerBlock, s_counts, lane);
   if (wib == 0) tk.store(a.part_keys + (size_t)blockIdx.x * a.k, a.part_pay + (size_t)blockIdx.x * a.k, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Exact k-th smallest of a key column (limits above kMaxFusedK), no host decisions:
+// three passes histogram 11-bit digits of the top 33 key bits among the keys that
+// match the prefix resolved so far; every block re-derives that prefix from the
+// previous passes' histograms (2 048 bins each), so a pass is one launch.  The
+// collect pass appends the keys below the final prefix and those sharing it.
+// ---------------------------------------------------------------------------
+struct RadixPrefix {
+  uint64_t prefix, mask;
+  uint32_t krem;
+};
+
+// Bin of `hist` holding the krem-th smallest (1-based), by one wave; updates krem.
+__device__ __forceinline__ uint32_t radix_find_bin(const uint32_t *hist, uint32_t *krem, int lane) {
+  constexpr uint32_t B = kRadixBins / kWave;  // bins per lane
+  uint32_t mine = 0;
+  for (uint32_t j = 0; j < B; ++j) mine += hist[lane * B + j];
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += t;
+  }
+  const uint32_t excl = incl - mine;
+  const uint32_t k = *krem;
+  uint32_t bin = 0xFFFFFFFFu, below = 0;
+  if (excl < k && k <= incl) {
+    uint32_t cum = excl, b = lane * B;
+    for (;; ++b) {
+      if (cum + hist[b] >= k) break;
+      cum += hist[b];
+    }
+    bin = b;
+    below = cum;
+  }
+  // exactly one lane found it (or none when fewer than k keys exist: take the last bin)
+  const uint64_t m = __ballot(bin != 0xFFFFFFFFu);
+  const int src = m ? __ffsll((long long)m) - 1 : 0;
+  const uint32_t rbin = __shfl(bin, src, kWave), rbelow = __shfl(below, src, kWave);
+  if (!m) return kRadixBins - 1;
+  *krem = k - rbelow;
+  return rbin;
+}
+
+// Prefix after `passes` resolved digits (wave 0 computes, everyone reads from LDS).
+__device__ __forceinline__ RadixPrefix radix_prefix(const RadixArgs &a, int passes, uint32_t *lds_hist, RadixPrefix *s_out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  RadixPrefix p;
+  p.prefix = 0;
+  p.mask = 0;
+  p.krem = a.k;
+  for (int q = 0; q < passes; ++q) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kRadixBins; i += blockDim.x) lds_hist[i] = a.hist[q * kRadixBins + i];
+    __syncthreads();
+    if (threadIdx.x < kWave) {
+      uint32_t krem = p.krem;
+      const uint32_t bin = radix_find_bin(lds_hist, &krem, lane);
+      const int shift = 53 - 11 * q;
+      p.prefix |= (uint64_t)bin << shift;
+      p.mask |= (uint64_t)(kRadixBins - 1) << shift;
+      p.krem = krem;
+      if (threadIdx.x == 0) *s_out = p;
+    }
+    __syncthreads();
+    p = *s_out;
+  }
+  return p;
+}
+
+__global__ __launch_bounds__(256) void radix_pass_kernel(const RadixArgs a, int pass) {
+  __shared__ uint32_t lds_hist[kRadixBins];
+  __shared__ RadixPrefix s_p;
+  if (pass == 0 && blockIdx.x == 0 && threadIdx.x == 0) *a.list_count = 0;
+  const RadixPrefix p = radix_prefix(a, pass, lds_hist, &s_p);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < kRadixBins; i += blockDim.x) lds_hist[i] = 0;
+  __syncthreads();
+  const int shift = 53 - 11 * pass;
+  const u64x2 *k2 = reinterpret_cast<const u64x2 *>(a.keys);
+  const uint32_t n2 = a.n / 2;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += gridDim.x * blockDim.x) {
+    const u64x2 v = k2[i];
+    if ((v.x & p.mask) == p.prefix) atomicAdd(&lds_hist[(uint32_t)(v.x >> shift) & (kRadixBins - 1)], 1u);
+    if ((v.y & p.mask) == p.prefix) atomicAdd(&lds_hist[(uint32_t)(v.y >> shift) & (kRadixBins - 1)], 1u);
+  }
+  if ((a.n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint64_t v = a.keys[a.n - 1];
+    if ((v & p.mask) == p.prefix) atomicAdd(&lds_hist[(uint32_t)(v >> shift) & (kRadixBins - 1)], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < kRadixBins; i += blockDim.x) {
+    const uint32_t c = lds_hist[i];
+    if (c) atomicAdd(&a.hist[pass * kRadixBins + i], c);
+  }
+}
+
+__global__ __launch_bounds__(256) void radix_collect_kernel(const RadixArgs a) {
+  __shared__ uint32_t lds_hist[kRadixBins];
+  __shared__ RadixPrefix s_p;
+  const RadixPrefix p = radix_prefix(a, 3, lds_hist, &s_p);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+    const uint64_t v = a.keys[i];
+    if (v != kEmptyKey && (v & p.mask) <= p.prefix) {
+      const uint32_t pos = atomicAdd(a.list_count, 1u);
+      if (pos < a.cap) {
+        a.list_keys[pos] = v;
+        Payload pv;
+        pv.row = i;
+        pv.raw = 0.0f;
+        a.list_pay[pos] = pv;
+      } else {
+        atomicMax(a.status, kStatusRetry);
+      }
+    }
+  }
 }
 
 // K7: normalize_l2 (distances.rs:350-361), one row per lane.
@@ -866,6 +989,17 @@ hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hi
   if (lds > kMaxLds || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.stride < sd.p.ld || !a.gather || !a.batch_counts)
     return hipErrorInvalidValue;
   return launch_scan_general(sd, blocks, nq, lds, s);
+}
+
+hipError_t launch_radix_pass(const RadixArgs &a, int pass, uint32_t blocks, hipStream_t s) {
+  if (pass < 0 || pass > 2 || a.n == 0 || a.k == 0 || ((uintptr_t)a.keys & 15)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(radix_pass_kernel, dim3(blocks), dim3(256), 0, s, a, pass);
+  return hipGetLastError();
+}
+
+hipError_t launch_radix_collect(const RadixArgs &a, uint32_t blocks, hipStream_t s) {
+  hipLaunchKernelGGL(radix_collect_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_select_list(const uint64_t *keys, const Payload *pay, uint32_t m, const uint32_t *m_dev, uint32_t k,

@@ -381,10 +381,23 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       else if (metric == M_IP) rank = -raw;
       const uint64_t key = ((uint64_t)orderable(rank) << 32) | my_rank;
       if (a.has_lo) valid = valid && key > a.lo_key;
-      tk.offer(valid, key, src_row, raw, lane);
+      if (a.key_out) {  // key-column mode (wave-uniform)
+        if (row_valid) {
+          a.key_out[grow] = valid ? key : kEmptyKey;
+          if (a.pay_out) {
+            Payload pv;
+            pv.row = src_row;
+            pv.raw = raw;
+            a.pay_out[grow] = pv;
+          }
+        }
+      } else {
+        tk.offer(valid, key, src_row, raw, lane);
+      }
     }
   }
   // one list per block: wave 0 absorbs the other waves' buffers
+  if (a.key_out) return;
   __shared__ uint32_t s_counts[kWavesPerBlock];
   tk.merge_block(wib, kWavesPerBlock, s_counts, lane);
   if (wib == 0)
