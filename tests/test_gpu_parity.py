@@ -933,3 +933,17 @@ def test_funnel_with_more_than_256_candidates(nifs, oracle_mod, metric):
         want = oracle_mod.vector_top_k(cur, q, metric, d, limit)
         got = unwrap(nifs.flat_funnel_search(g.ref, q, stages, cand, limit))
         assert bits(got) == bits(want), (metric, stages, cand, limit)
+
+
+def test_limit_above_256_with_an_overflowing_row_reports_the_error(nifs, oracle_mod):
+    """A row whose score overflows leaves an excluded slot in the key column; the threshold path
+    must still end in "metric overflow" (distances.rs:67), not in a short or garbage list."""
+    n, d = 70_000, 16
+    x = np.random.default_rng(2).uniform(-1, 1, (n, d)).astype(np.float32)
+    x[12345, :] = 3e38
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    g = GpuIndex(nifs, 3)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    q = np.full(d, 2.0, np.float32)
+    assert nifs.flat_search(g.ref, q, 500) == ("error", "metric overflow")
+    assert nifs.flat_search(g.ref, np.zeros(d, np.float32), 500)[0] == "ok"   # and the flag does not stick

@@ -280,7 +280,10 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
   if (partial) {
     for (uint32_t j = tid; j < k; j += 1024) {
       part_keys[(size_t)blockIdx.x * k + j] = j < nsel ? sel_key[j] : kEmptyKey;
-      if (j < nsel) part_pay[(size_t)blockIdx.x * k + j] = pay[sel_idx[j]];
+      Payload pad;  // padding entries must still be safe to gather from: row 0
+      pad.row = 0;
+      pad.raw = 0.0f;
+      part_pay[(size_t)blockIdx.x * k + j] = j < nsel ? pay[sel_idx[j]] : pad;
     }
     return;
   }
