@@ -617,11 +617,12 @@ def test_binary_top_k_with_massive_ties(nifs, oracle_mod):
 
 
 @pytest.mark.parametrize("metric", [2, 3, 4, 0, 1, 5])
-def test_batched_search_equals_single_queries(nifs, oracle_mod, metric):
+def test_batched_search_equals_single_queries(nifs, oracle_mod, metric, monkeypatch):
     """vt_flat_search_batch: dot-family metrics go through the FP32-MFMA candidate
     pass + exact rescoring; every query must still equal the oracle bit for bit
     (BASELINE.json configs[2] shape, scaled down).  L2 / L2^2 nominate by
     2 q.x - |x|^2; manhattan has no GEMM form and takes the per-query path."""
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")   # the cost model would send these small corpora to single scans
     n, d = 20000, 192
     x, ids = make_corpus(n, d, 500 + metric, metric == 2, oracle_mod, tie_block=48)
     packed = oracle_mod.pack_ids(ids)
@@ -651,9 +652,10 @@ def test_batched_search_equals_single_queries(nifs, oracle_mod, metric):
     assert unwrap(nifs.flat_search_batch(g.ref, bad, 0)) == [[]] * 9
 
 
-def test_batched_search_large_values_fall_back_safely(nifs, oracle_mod):
+def test_batched_search_large_values_fall_back_safely(nifs, oracle_mod, monkeypatch):
     """Huge coordinates blow the error margin (or overflow the MFMA sum): the
     bound must refuse and the per-query path must still give the exact answer."""
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
     n, d = 6000, 64
     rng = np.random.default_rng(21)
     x = (rng.uniform(-1, 1, size=(n, d)) * 1e18).astype(np.float32)
@@ -851,10 +853,11 @@ def test_quantized_histogram_pass_survives_dimension_changes(nifs, oracle_mod):
         assert len(g) == 0 and g.dimension is None
 
 
-def test_padding_columns_of_a_small_batch_nominate_nothing(nifs, oracle_mod):
+def test_padding_columns_of_a_small_batch_nominate_nothing(nifs, oracle_mod, monkeypatch):
     """A batch of 8 is padded to 32 query columns; the all-zero padding columns once passed
     every row as a candidate (45x slower than a full 32-query batch).  Timing guard with a
     wide margin, plus parity of the small batch itself."""
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
     import time
     n, d = 300_000, 128
     rng = np.random.default_rng(5)
@@ -878,11 +881,21 @@ def test_padding_columns_of_a_small_batch_nominate_nothing(nifs, oracle_mod):
         assert bits(out8[i]) == bits(unwrap(nifs.flat_search(g.ref, qs[i], 10)))
 
 
+@pytest.fixture
+def force_threshold(monkeypatch):
+    """The library picks the threshold path by a cost model (large corpora); the parity tests
+    force it so that it runs at oracle-sized inputs too.  getenv is read per call."""
+    monkeypatch.setenv("VT_FORCE_THRESHOLD_SELECT", "1")
+
+
+@pytest.mark.parametrize("forced", [True, False])
 @pytest.mark.parametrize("metric", [2, 0, 5])
-def test_limits_above_256_in_one_scan(nifs, oracle_mod, metric):
+def test_limits_above_256_in_one_scan(nifs, oracle_mod, metric, forced, monkeypatch):
     """Above 65 536 rows a limit of 257..4096 is answered from a key column and a radix
     threshold instead of one scan per 256 hits; 5 000 still takes the pass-per-256 loop.
     Both must equal the oracle's full sort, ties by id bytes included."""
+    if forced:
+        monkeypatch.setenv("VT_FORCE_THRESHOLD_SELECT", "1")
     n, d = 70_000, 24
     x, ids = make_corpus(n, d, 1200 + metric, metric == 2, oracle_mod, tie_block=600)
     g = GpuIndex(nifs, metric)
@@ -898,7 +911,7 @@ def test_limits_above_256_in_one_scan(nifs, oracle_mod, metric):
         assert bits(got) == bits(want), (metric, limit)
 
 
-def test_limit_above_256_with_more_ties_than_the_list_holds(nifs, oracle_mod):
+def test_limit_above_256_with_more_ties_than_the_list_holds(nifs, oracle_mod, force_threshold):
     """80 000 identical rows: every key shares its 33-bit prefix, the device list overflows and
     the call must fall back to the pass-per-256 loop -- same answer as the oracle."""
     n, d = 80_000, 16
@@ -912,7 +925,7 @@ def test_limit_above_256_with_more_ties_than_the_list_holds(nifs, oracle_mod):
 
 
 @pytest.mark.parametrize("metric", [2, 0])
-def test_funnel_with_more_than_256_candidates(nifs, oracle_mod, metric):
+def test_funnel_with_more_than_256_candidates(nifs, oracle_mod, metric, force_threshold):
     """funnel_search(limit: 100) defaults to 1 000 candidates (collection.ex:547): the first stage
     over all rows keeps them through the key-column threshold."""
     n, d = 70_000, 48
@@ -935,7 +948,7 @@ def test_funnel_with_more_than_256_candidates(nifs, oracle_mod, metric):
         assert bits(got) == bits(want), (metric, stages, cand, limit)
 
 
-def test_limit_above_256_with_an_overflowing_row_reports_the_error(nifs, oracle_mod):
+def test_limit_above_256_with_an_overflowing_row_reports_the_error(nifs, oracle_mod, force_threshold):
     """A row whose score overflows leaves an excluded slot in the key column; the threshold path
     must still end in "metric overflow" (distances.rs:67), not in a short or garbage list."""
     n, d = 70_000, 16

@@ -346,6 +346,13 @@ namespace {
 // Internal (never crosses the ABI): a device-side list overflowed, redo on the general path.
 constexpr int kRetryInternal = -100;
 
+// Rough per-call times on MI355X (tools/size_probe.py, tools/latency_floor.py), used only
+// to choose between equivalent code paths: one fused scan of `bytes`, and the fixed cost
+// the multi-kernel paths add on top of their scans.
+constexpr double kScanFixedS = 35e-6, kScanBytesPerS = 6.5e12;
+constexpr double kThresholdFixedS = 140e-6, kBatchFixedS = 300e-6, kBatchFlopsPerS = 135e12;
+inline double scan_seconds(double bytes) { return kScanFixedS + bytes / kScanBytesPerS; }
+
 // ------------------------------------------------------------------ selection
 // One select launch + stream sync; the k winners arrive in c.hRes (pinned,
 // written by the kernel through the host mapping).
@@ -392,12 +399,20 @@ struct ScanJob {
 // Limits above kMaxFusedK in ONE scan: the scan has written a key per row into c.dKeyCol;
 // three radix passes + a collect pass + one list select leave the exact `k` best rows,
 // unsorted, in c.dListPay (Payload.row = position in the key column).
-constexpr size_t kThresholdMinRows = 65536;
+constexpr size_t kThresholdMinRows = 16384;
 constexpr uint32_t kThresholdListCap = 65536;
 
-bool threshold_applies(size_t total, uint32_t n) {
-  return total > (size_t)vt::kMaxFusedK && total <= (size_t)vt::kSelListMax && n >= kThresholdMinRows &&
-         !std::getenv("VT_NO_THRESHOLD_SELECT");
+// One scan + radix threshold, or one scan per 256 hits?  Whichever the model says is shorter.
+bool threshold_applies(size_t total, uint32_t n, double scan_bytes, double pass_fixed_s = kScanFixedS) {
+  if (total <= (size_t)vt::kMaxFusedK || total > (size_t)vt::kSelListMax || n < kThresholdMinRows ||
+      std::getenv("VT_NO_THRESHOLD_SELECT"))
+    return false;
+  if (std::getenv("VT_FORCE_THRESHOLD_SELECT")) return true;  // tests: exercise the path on small corpora
+  const double passes = std::ceil((double)total / vt::kMaxFusedK);
+  const double t_pass = pass_fixed_s + scan_bytes / kScanBytesPerS;
+  const double t_loop = passes * t_pass;
+  const double t_threshold = t_pass + kThresholdFixedS + passes * 25e-6;
+  return t_threshold < t_loop;
 }
 
 int threshold_rows(Ctx &c, uint32_t n, uint32_t k) {
@@ -440,7 +455,7 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
   uint64_t lo = 0;
   bool has_lo = false;
   const size_t total = std::min<size_t>(want, j.n);
-  if (!j.gather && out.empty() && threshold_applies(total, j.n)) {
+  if (!j.gather && out.empty() && threshold_applies(total, j.n, (double)j.n * vt::padded_dim(j.d) * 4.0)) {
     // one scan in key-column mode, exact threshold on the device, then the winners are
     // re-scored through the gather list for their raw values and sorted
     const uint32_t k = (uint32_t)total;
@@ -855,7 +870,8 @@ int run_cosine_scan(Ctx &c, vt_flat *ix, uint32_t d, double qq, size_t want, std
   uint64_t lo = 0;
   bool has_lo = false;
   const size_t total = std::min<size_t>(want, ix->n);
-  if (out.empty() && threshold_applies(total, ix->n)) {
+  // (a prefix-cosine pass costs ~90 us before its first byte: f64 sums, its own select and wait)
+  if (out.empty() && threshold_applies(total, ix->n, (double)ix->n * vt::padded_dim(d) * 4.0, 90e-6)) {
     const uint32_t k = (uint32_t)total;
     VT_TRY(c.dKeyCol.ensure(((size_t)ix->n + 1) / 2 * 2));
     VT_TRY(c.dPartKeys.ensure(kThresholdListCap));
@@ -1321,8 +1337,17 @@ int batch_locked(vt_flat *ix, const float *queries, size_t nq, size_t d, size_t 
                            ix->metric == VT_NEG_INNER_PRODUCT || ix->metric == VT_L2 || ix->metric == VT_L2_SQUARED;
   // one shared pass over the corpus costs about 1.3 single scans (HBM-bound below 33 queries),
   // so it pays from two queries on
-  const bool use_mfma = mfma_metric && nq >= 2 && limit <= (size_t)vt::kMaxFusedK && ix->n >= 4096 &&
-                        std::getenv("VT_BATCH_NO_MFMA") == nullptr;
+  bool use_mfma = mfma_metric && nq >= 2 && limit <= (size_t)vt::kMaxFusedK && ix->n >= 4096 &&
+                  std::getenv("VT_BATCH_NO_MFMA") == nullptr;
+  if (use_mfma && !std::getenv("VT_FORCE_BATCH_MFMA")) {  // (tests force the shared pass on small corpora)
+    // nq single scans against one shared pass (HBM-bound below ~33 queries, then MFMA-bound)
+    const double bytes = (double)ix->n * ix->ld * 4.0;
+    double nq_pad = 32;
+    while (nq_pad < (double)std::min<size_t>(nq, 256)) nq_pad *= 2;
+    const double groups = std::ceil((double)nq / 256.0);
+    const double t_pass = std::max(1.3 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kBatchFlopsPerS);
+    use_mfma = (double)nq * scan_seconds(bytes) > groups * (kBatchFixedS + t_pass);
+  }
   if (use_mfma) {
     VT_TRY(index_sync_ranks(ix, false));
     for (size_t g0 = 0; g0 < nq; g0 += 256) {
@@ -1777,7 +1802,8 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
   VT_HIP(vt::launch_sign_pack(c.dQ.p, vt::padded_dim(d), 1, d, c.dQbits.p, 0, c.stream));
   const size_t ncand = std::min<size_t>(candidates, ix->n);
   // K4h needs integer bins in LDS, one fused select, and enough rows to be worth two passes
-  const bool hist_ok = ncand <= (size_t)vt::kSelListMax && d <= vt::kHammingHistMaxDim && ix->n >= 16384 &&
+  const bool hist_ok = ncand <= (size_t)vt::kSelListMax && d <= vt::kHammingHistMaxDim &&
+                       (ix->n >= 16384 || ncand > (size_t)vt::kMaxFusedK) &&
                        !std::getenv("VT_HAMMING_LISTS");
   auto run = [&](bool use_hist) -> int {
   std::vector<vt::Entry> entries;
