@@ -960,3 +960,47 @@ def test_limit_above_256_with_an_overflowing_row_reports_the_error(nifs, oracle_
     q = np.full(d, 2.0, np.float32)
     assert nifs.flat_search(g.ref, q, 500) == ("error", "metric overflow")
     assert nifs.flat_search(g.ref, np.zeros(d, np.float32), 500)[0] == "ok"   # and the flag does not stick
+
+
+def test_searches_between_unsorted_inserts_stay_exact(nifs, oracle_mod):
+    """Ids arriving out of bytewise order leave their rows unranked until a search needs the true
+    id order: a search first tries with one extra hit and re-ranks only if the boundary ties.
+    Interleaved inserts (with verbatim copies of stored rows under smaller and larger ids, so that
+    ties fall inside the list and across its boundary), deletes and searches against the oracle."""
+    d = 12
+    rng = np.random.default_rng(77)
+    base = rng.uniform(-1, 1, (400, d)).astype(np.float32)
+    for metric in (0, 2, 3):
+        g = GpuIndex(nifs, metric)
+        o = oracle_mod.FlatIndex(metric)
+        rows = {}
+
+        def put(id_, v):
+            g.insert(id_, v)
+            o.insert(id_, v)
+            rows[id_] = v
+
+        for i in range(300):
+            put(b"m-%04d" % i, base[i])
+        step = 0
+        for i in range(300, 400):
+            # alternate: new vector under an id that sorts before / after everything; copies of stored rows
+            kind = i % 4
+            if kind == 0:
+                put(b"a-%d" % i, base[i])
+            elif kind == 1:
+                put(b"z-%d" % i, base[i])
+            elif kind == 2:
+                put(b"a-copy-%d" % i, base[i - 250])     # ties with m-(i-250), smaller id
+            else:
+                put(b"zz-copy-%d" % i, base[i - 250])    # ties, larger id
+            if i % 7 == 0:
+                victim = b"m-%04d" % (i - 290)
+                g.delete(victim)
+                o.delete(victim)
+                rows.pop(victim, None)
+            for q in (base[i - 250], base[(i * 3) % 300], rng.uniform(-1, 1, d).astype(np.float32)):
+                for k in (1, 2, 5, 255, 256):
+                    step += 1
+                    assert bits(g.search(q, k)) == bits(o.search(q, k)), (metric, i, k)
+        assert len(g) == len(o)

@@ -50,3 +50,33 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def big():
+    """unsorted inserts interleaved with searches on a 2M-row corpus (lazy rank path)"""
+    d, n = 768, 2_000_000
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    ref = nifs.flat_new_cosine()
+    assert nifs.flat_load_matrix(ref, ids, x) == ("ok", ())
+    h = C.c_void_p()
+    q = x[5].ctypes.data_as(C.POINTER(C.c_float))
+    assert L.vt_flat_search(ref.handle, q, d, 10, C.byref(h)) == 0
+    L.vt_hits_free(h)
+    for label, env in (("lazy", None), ("eager", "1")):
+        if env:
+            os.environ["VT_EAGER_RANKS"] = env
+        t0 = time.perf_counter()
+        for i in range(30):
+            id_ = b"new-%s-%d" % (label.encode(), i)
+            v = x[i + 100]
+            assert L.vt_flat_insert(ref.handle, id_, len(id_), v.ctypes.data_as(C.POINTER(C.c_float)), d) == 0
+            assert L.vt_flat_search(ref.handle, q, d, 10, C.byref(h)) == 0
+            L.vt_hits_free(h)
+        t1 = time.perf_counter()
+        print(json.dumps({"op": "2M rows: unsorted insert + search, " + label, "per_pair_ms": round((t1 - t0) / 30 * 1e3, 3)}), flush=True)
+
+
+if __name__ == "__main__" and os.environ.get("BIG"):
+    big()

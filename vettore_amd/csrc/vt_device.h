@@ -187,6 +187,9 @@ hipError_t launch_check_finite(const float *rows, size_t stride, uint32_t n, uin
 // dst[n][dst_stride] <- src[n][d], columns d..dst_stride-1 zero-filled.
 hipError_t launch_pad_rows(const float *src, uint32_t n, uint32_t d, float *dst, size_t dst_stride, hipStream_t s);
 
+// dst[pairs[2i]] = pairs[2i + 1] for i < n (pairs on the device).
+hipError_t launch_scatter_u32(const uint32_t *pairs, uint32_t n, uint32_t *dst, hipStream_t s);
+
 // Exact rerank for Metric::Cosine (search.rs:56-60 -> distances.rs:160-177):
 // raw = clamp(f64_dot(q,x) / (sqrt(f64_dot(q,q)) * sqrt(f64_dot(x,x)))) as f32,
 // one candidate per lane, sequential f64 sums.  Emits key/payload per candidate.

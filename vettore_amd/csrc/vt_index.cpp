@@ -57,6 +57,7 @@ int guarded(F &&f) noexcept {
   } while (0)
 
 inline uint32_t round_up_u32(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+constexpr size_t kMaxDirtyRanks = 16384;  // above this the whole rank column is re-uploaded
 constexpr uint32_t kUnranked = 0xFFFFFFFFu;  // id_rank of a row inserted out of id order, until the next re-rank
 
 // flat.rs:136-144 validate_vector: empty, then dimension, then finiteness.
@@ -205,6 +206,8 @@ struct Ctx {
   // K4h: distance column, two alternating histograms, list counter
   DevBuf<uint16_t> dDist16;
   DevBuf<uint64_t> dListKeys;  // candidate set of > 256 rows kept on the device
+  DevBuf<uint32_t> dRankPairs;  // (row, rank) updates of the lazy rank path
+  PinnedBuf<uint32_t> hRankPairs;
   DevBuf<uint64_t> dKeyCol;    // one key per row (limits above kMaxFusedK: radix threshold instead of wave buffers)
   DevBuf<uint32_t> dRadixHist, dRadixCount;
   DevBuf<vt::Payload> dListPay;
@@ -331,6 +334,10 @@ struct vt_flat {
   std::unordered_map<std::string, uint32_t> row_of;
   std::vector<uint32_t> rank_host;  // by row
   bool ranks_clean = true;          // rank_host/dRank describe the current rows
+  // While !ranks_clean: rows whose device rank differs from rank_host (newcomers carry
+  // kUnranked, a swap-delete moved a rank); rank_dirty_all = re-upload the whole column.
+  std::vector<uint32_t> rank_dirty;
+  bool rank_dirty_all = false;
   bool external_ranks = false;      // rank column supplied by vt_flat_set_id_ranks (valid until the next mutation)
   std::string max_id;               // upper bound of all ids while ranks_clean
   uint32_t max_rank = 0;
@@ -671,6 +678,7 @@ uint32_t index_row_for(vt_flat *ix, const char *id, size_t len, bool *is_new) {
     ix->external_ranks = false;
     ix->ranks_clean = false;
     std::fill(ix->rank_host.begin(), ix->rank_host.end(), kUnranked);
+    ix->rank_dirty_all = true;  // the whole device column is stale now
   }
   if (ix->ranks_clean) {
     // ids arriving in ascending order (snapshot rebuild sorts by id,
@@ -719,12 +727,52 @@ int index_sync_ranks(vt_flat *ix, bool force_upload) {
     ix->ranks_clean = true;
     force_upload = true;
   }
+  if (force_upload) {
+    ix->rank_dirty.clear();
+    ix->rank_dirty_all = false;
+  }
   if (force_upload && ix->n) {
     VT_TRY(ix->dRank.ensure(std::max<size_t>(ix->cap, ix->n)));
     VT_HIP(hipMemcpyAsync(ix->dRank.p, ix->rank_host.data(), (size_t)ix->n * sizeof(uint32_t), hipMemcpyHostToDevice,
                           ix->ctx.stream));
     VT_HIP(hipStreamSynchronize(ix->ctx.stream));
   }
+  return VT_OK;
+}
+
+// Brings the device rank column in line with rank_host WITHOUT re-ranking: newcomers keep
+// kUnranked (all equal), which is enough for a search whose k-th and (k+1)-th hits differ in
+// their f32 rank (search_locked checks exactly that and orders equal ranks by id bytes on
+// the host).  An unsorted insert therefore costs the next search a few bytes, not an O(n)
+// merge and a column upload.
+int index_lazy_ranks(vt_flat *ix) {
+  Ctx &c = ix->ctx;
+  if (ix->n == 0) return VT_OK;
+  if (ix->dRank.count < std::max<size_t>(ix->cap, ix->n)) {
+    VT_TRY(ix->dRank.ensure(std::max<size_t>(ix->cap, ix->n)));
+    ix->rank_dirty_all = true;
+  }
+  if (ix->rank_dirty_all) {
+    VT_HIP(hipMemcpyAsync(ix->dRank.p, ix->rank_host.data(), (size_t)ix->n * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+  } else if (!ix->rank_dirty.empty()) {
+    const size_t m = ix->rank_dirty.size();
+    VT_TRY(c.hRankPairs.ensure(2 * m));
+    VT_TRY(c.dRankPairs.ensure(2 * m));
+    size_t live = 0;
+    for (uint32_t r : ix->rank_dirty) {
+      if (r >= ix->n) continue;  // deleted since
+      c.hRankPairs.p[2 * live] = r;
+      c.hRankPairs.p[2 * live + 1] = ix->rank_host[r];
+      ++live;
+    }
+    if (live) {
+      VT_HIP(hipMemcpyAsync(c.dRankPairs.p, c.hRankPairs.p, 2 * live * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+      VT_HIP(vt::launch_scatter_u32(c.dRankPairs.p, (uint32_t)live, ix->dRank.p, c.stream));
+    }
+  }
+  ix->rank_dirty.clear();
+  ix->rank_dirty_all = false;
   return VT_OK;
 }
 
@@ -806,6 +854,11 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
     }
     VT_HIP(hipStreamSynchronize(c.stream));
   }
+  if (!ix->ranks_clean) {
+    // the device column is brought up to date lazily (index_lazy_ranks) or by the next re-rank
+    for (uint32_t r = n_before; r < ix->n; ++r) ix->rank_dirty.push_back(r);
+    if (ix->rank_dirty.size() > kMaxDirtyRanks) ix->rank_dirty_all = true;
+  }
   // keep device ranks current when they stayed valid (sorted appends)
   if (ix->ranks_clean && ix->n > n_before) {
     uint32_t from = n_before;
@@ -843,7 +896,12 @@ int search_locked(vt_flat *ix, const float *query, size_t n, size_t limit, vt_hi
   if (limit == 0) return empty_hits(out);
   VT_TRY(validate_vector(query, n, ix->dim));
   if (ix->n == 0) return empty_hits(out);
-  VT_TRY(index_sync_ranks(ix, false));
+  // Ids inserted out of order since the last ranking: try without re-ranking first.
+  const size_t lazy_want = std::min<size_t>(limit, ix->n) + (limit < ix->n ? 1 : 0);
+  const bool lazy = !ix->ranks_clean && !ix->external_ranks && lazy_want <= (size_t)vt::kMaxFusedK &&
+                    !std::getenv("VT_EAGER_RANKS");
+  if (lazy) VT_TRY(index_lazy_ranks(ix));
+  else VT_TRY(index_sync_ranks(ix, false));
   uint32_t qnz = 0;
   VT_TRY(upload_query(c, query, n, &qnz));
   ScanJob j{};
@@ -858,6 +916,29 @@ int search_locked(vt_flat *ix, const float *query, size_t n, size_t limit, vt_hi
   j.order = ix->order;
   j.q_nonzero = qnz;
   std::vector<vt::Entry> entries;
+  if (lazy) {
+    // one hit more than asked for: if it does not tie with the last wanted one, the set is
+    // exact whatever the unranked rows' id order is, and equal-rank runs are put in id order here
+    VT_TRY(run_scan(c, j, lazy_want, entries, true));
+    const bool ambiguous = limit < ix->n && entries.size() == lazy_want &&
+                           rank_key_of(entries[limit - 1].key) == rank_key_of(entries[limit].key);
+    if (!ambiguous) {
+      if (entries.size() > limit) entries.resize(limit);
+      for (size_t i = 0; i < entries.size();) {
+        size_t e = i + 1;
+        while (e < entries.size() && rank_key_of(entries[e].key) == rank_key_of(entries[i].key)) ++e;
+        if (e - i > 1)
+          std::sort(entries.begin() + i, entries.begin() + e,
+                    [&](const vt::Entry &a, const vt::Entry &b) { return ix->ids[a.row] < ix->ids[b.row]; });
+        i = e;
+      }
+      return make_hits(ix, entries, out);
+    }
+    // a tie across the boundary: only the true id order can cut it
+    entries.clear();
+    VT_TRY(index_sync_ranks(ix, false));
+    j.id_rank = ix->dRank.p;
+  }
   VT_TRY(run_scan(c, j, limit, entries, true));
   return make_hits(ix, entries, out);
 }
@@ -1620,6 +1701,10 @@ int vt_flat_delete(vt_flat *ix, const char *id, size_t id_len) {
       ix->rank_host[r] = ix->rank_host[last];
       if (ix->ranks_clean && ix->dRank.p)
         VT_HIP(hipMemcpyAsync(ix->dRank.p + r, ix->dRank.p + last, sizeof(uint32_t), hipMemcpyDeviceToDevice, c.stream));
+      if (!ix->ranks_clean) {
+        ix->rank_dirty.push_back(r);
+        if (ix->rank_dirty.size() > kMaxDirtyRanks) ix->rank_dirty_all = true;
+      }
     }
     VT_HIP(hipMemsetAsync(ix->dX + (size_t)last * ix->ld, 0, (size_t)ix->ld * sizeof(float), c.stream));
     VT_HIP(hipStreamSynchronize(c.stream));
@@ -1631,6 +1716,8 @@ int vt_flat_delete(vt_flat *ix, const char *id, size_t id_len) {
   }
   if (ix->n == 0) {
     ix->dim = -1;
+    ix->rank_dirty.clear();
+    ix->rank_dirty_all = false;
     ix->ranks_clean = true;
     ix->max_id.clear();
     ix->max_rank = 0;

@@ -593,6 +593,13 @@ __global__ __launch_bounds__(256) void check_finite_kernel(const float *__restri
   if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// dst[idx[i]] = val[i]: rank updates of a few rows without re-uploading the column.
+__global__ __launch_bounds__(256) void scatter_u32_kernel(const uint32_t *__restrict__ pairs, uint32_t n,
+                                                          uint32_t *__restrict__ dst) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[pairs[2 * i]] = pairs[2 * i + 1];
+}
+
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float *__restrict__ src, uint32_t n, uint32_t d,
                                                        float *__restrict__ dst, size_t dst_stride) {
   const uint64_t total = (uint64_t)n * dst_stride;
@@ -1105,6 +1112,12 @@ hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32
 hipError_t launch_check_finite(const float *rows, size_t stride, uint32_t n, uint32_t d, int *flag, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(check_finite_kernel, dim3(2048), dim3(256), 0, s, rows, stride, n, d, flag);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter_u32(const uint32_t *pairs, uint32_t n, uint32_t *dst, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(scatter_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pairs, n, dst);
   return hipGetLastError();
 }
 
