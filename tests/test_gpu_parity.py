@@ -1004,3 +1004,43 @@ def test_searches_between_unsorted_inserts_stay_exact(nifs, oracle_mod):
                     step += 1
                     assert bits(g.search(q, k)) == bits(o.search(q, k)), (metric, i, k)
         assert len(g) == len(o)
+
+
+def test_derived_data_is_patched_after_mutations(nifs, oracle_mod, monkeypatch):
+    """Sign bits (quantized_search) and row norms (batched L2) are kept per row and patched for the
+    rows an insert / upsert / delete touched instead of being rebuilt; every search in between
+    must still agree with the oracle."""
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    n, d = 20_000, 64
+    rng = np.random.default_rng(404)
+    x = rng.uniform(-1, 1, (n + 200, d)).astype(np.float32)
+    ids = [b"doc-%05d" % i for i in range(n + 200)]
+    g = GpuIndex(nifs, 0)
+    unwrap(nifs.flat_load_matrix(g.ref, ids[:n], x[:n]))
+    cur = {ids[i]: x[i] for i in range(n)}
+
+    def check():
+        keys = sorted(cur)
+        mat = np.stack([cur[k] for k in keys])
+        packed = oracle_mod.pack_ids(keys)
+        q = rng.uniform(-1, 1, d).astype(np.float32)
+        ham = ((mat >= 0) != (q >= 0)[None, :]).sum(axis=1)
+        order = sorted(range(len(keys)), key=lambda i: (int(ham[i]), keys[i]))[:40]
+        want = oracle_mod.vector_top_k([(keys[i], mat[i]) for i in order], q, 0, d, 10)
+        assert bits(unwrap(nifs.flat_quantized_search(g.ref, q, 40, 10))) == bits(want)
+        qs = rng.uniform(-1, 1, (4, d)).astype(np.float32)
+        got = unwrap(nifs.flat_search_batch(g.ref, qs, 5))
+        for i in range(4):
+            assert bits(got[i]) == bits(oracle_mod.matrix_search(0, mat, packed, qs[i], 5))
+
+    check()                                              # builds bits and norms
+    for step in range(6):
+        for j in range(20):                              # appends, upserts (one with a huge norm), deletes
+            i = n + step * 20 + j
+            g.insert(ids[i], x[i]); cur[ids[i]] = x[i]
+        up = ids[step * 37]
+        v = x[step * 37] * (50.0 if step == 3 else -1.0)
+        g.insert(up, v); cur[up] = v
+        for victim in (ids[1000 + step], ids[n - 1 - step]):
+            g.delete(victim); cur.pop(victim, None)
+        check()

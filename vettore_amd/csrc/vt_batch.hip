@@ -28,6 +28,7 @@
 // that only nominates candidates.
 #include "vt_common.cuh"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace vt {
@@ -599,6 +600,27 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict
   if (lane == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(best));  // s >= 0: bits are monotone
 }
 
+// The same for a list of rows (norms of mutated rows patched in place).
+__global__ __launch_bounds__(256) void row_sqnorm_rows_kernel(const float *__restrict__ X, size_t stride,
+                                                              const uint32_t *__restrict__ list, uint32_t count, uint32_t d,
+                                                              float *__restrict__ xnorm2, unsigned long long *out_bits) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  double best = 0.0;
+  for (uint32_t i = wave; i < count; i += nwaves) {
+    const uint32_t row = list[i];
+    const float *x = X + (size_t)row * stride;
+    double s = 0.0;
+    for (uint32_t j = lane; j < d; j += kWave) s += (double)x[j] * (double)x[j];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, kWave);
+    if (lane == 0) xnorm2[row] = (float)s;
+    best = s > best ? s : best;
+  }
+  if (lane == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(best));
+}
+
 // Batched K3: block b selects the k smallest of keys[b][0..m) (rank sort; m is small).
 __global__ __launch_bounds__(256) void batch_select_kernel(const uint64_t *__restrict__ keys,
                                                            const Payload *__restrict__ pay, uint32_t m, uint32_t k,
@@ -708,6 +730,14 @@ hipError_t launch_row_sqnorms(const float *X, size_t stride, uint32_t n, uint32_
                               unsigned long long *out_bits, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3(2048), dim3(256), 0, s, X, stride, n, d, xnorm2, out_bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_row_sqnorms_rows(const float *X, size_t stride, const uint32_t *list, uint32_t count, uint32_t d,
+                                   float *xnorm2, unsigned long long *out_bits, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  const uint32_t blocks = std::min<uint32_t>(2048, (count + 3) / 4);
+  hipLaunchKernelGGL(row_sqnorm_rows_kernel, dim3(blocks), dim3(256), 0, s, X, stride, list, count, d, xnorm2, out_bits);
   return hipGetLastError();
 }
 

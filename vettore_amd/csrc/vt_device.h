@@ -187,6 +187,12 @@ hipError_t launch_check_finite(const float *rows, size_t stride, uint32_t n, uin
 // dst[n][dst_stride] <- src[n][d], columns d..dst_stride-1 zero-filled.
 hipError_t launch_pad_rows(const float *src, uint32_t n, uint32_t d, float *dst, size_t dst_stride, hipStream_t s);
 
+// K5 / row norms for a device list of rows (derived data of mutated rows patched in place).
+hipError_t launch_sign_pack_rows(const float *rows, size_t stride, const uint32_t *list, uint32_t count, uint32_t d,
+                                 uint64_t *bits, hipStream_t s);
+hipError_t launch_row_sqnorms_rows(const float *X, size_t stride, const uint32_t *list, uint32_t count, uint32_t d,
+                                   float *xnorm2, unsigned long long *out_bits, hipStream_t s);
+
 // dst[pairs[2i]] = pairs[2i + 1] for i < n (pairs on the device).
 hipError_t launch_scatter_u32(const uint32_t *pairs, uint32_t n, uint32_t *dst, hipStream_t s);
 

@@ -327,6 +327,9 @@ struct vt_flat {
   DevBuf<uint32_t> dRank;
   DevBuf<uint64_t> dBits;
   bool bits_valid = false;
+  // Rows mutated since the bit matrix / the norms were last brought up to date; patched in
+  // place at the next use (a full rebuild is a pass over the whole corpus).
+  std::vector<uint32_t> bits_dirty, norm_dirty;
   double max_sqnorm = -1.0;  // max_i sum_j x_ij^2, < 0 = stale (error margin of the batched path)
   DevBuf<float> dXnorm2;     // per-row squared norms, valid with max_sqnorm
   // ids
@@ -653,6 +656,10 @@ int index_set_dim(vt_flat *ix, size_t d) {
     return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(d) + " exceeds what the scan kernel stages in LDS");
   const uint32_t ld = vt::padded_dim((uint32_t)d);
   ix->ctx.ham_dirty = true;  // K4h's histograms are cleared for d + 1 bins only: a new dimension starts clean
+  ix->bits_valid = false;    // derived per-row data belongs to the old rows
+  ix->max_sqnorm = -1.0;
+  ix->bits_dirty.clear();
+  ix->norm_dirty.clear();
   if (ld != ix->ld) {
     if (ix->dX) VT_HIP(hipFree(ix->dX));
     ix->dX = nullptr;
@@ -783,6 +790,41 @@ struct RowSource {
   size_t d = 0;
 };
 
+constexpr size_t kMaxDerivedDirty = 65536;  // more mutated rows than this: rebuild instead of patching
+
+// Row `r` changed: its sign bits and norm are stale.
+inline void index_touch_row(vt_flat *ix, uint32_t r) {
+  if (ix->bits_valid) {
+    ix->bits_dirty.push_back(r);
+    if (ix->bits_dirty.size() > kMaxDerivedDirty) {
+      ix->bits_valid = false;
+      ix->bits_dirty.clear();
+    }
+  }
+  if (ix->max_sqnorm >= 0.0) {
+    ix->norm_dirty.push_back(r);
+    if (ix->norm_dirty.size() > kMaxDerivedDirty) {
+      ix->max_sqnorm = -1.0;
+      ix->norm_dirty.clear();
+    }
+  }
+}
+
+// Uploads a row list (rows still < n) for the patch kernels; returns its length.
+int upload_row_list(vt_flat *ix, std::vector<uint32_t> &list, uint32_t *count) {
+  Ctx &c = ix->ctx;
+  std::sort(list.begin(), list.end());
+  list.erase(std::unique(list.begin(), list.end()), list.end());
+  while (!list.empty() && list.back() >= ix->n) list.pop_back();
+  *count = (uint32_t)list.size();
+  if (list.empty()) return VT_OK;
+  VT_TRY(c.hRankPairs.ensure(list.size()));
+  VT_TRY(c.dRankPairs.ensure(list.size()));
+  std::memcpy(c.hRankPairs.p, list.data(), list.size() * sizeof(uint32_t));
+  VT_HIP(hipMemcpyAsync(c.dRankPairs.p, c.hRankPairs.p, list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+  return VT_OK;
+}
+
 // Shared body of insert / insert_many / load_matrix: rows are already validated.
 int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *id_off, const RowSource &src) {
   if (count == 0) return VT_OK;
@@ -803,8 +845,14 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
     target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new);
     if (!is_new || target[i] != n_before + i) all_appended_in_order = false;
   }
-  ix->bits_valid = false;
-  ix->max_sqnorm = -1.0;
+  if (count > kMaxDerivedDirty) {
+    ix->bits_valid = false;
+    ix->max_sqnorm = -1.0;
+    ix->bits_dirty.clear();
+    ix->norm_dirty.clear();
+  } else {
+    for (size_t i = 0; i < count; ++i) index_touch_row(ix, target[i]);
+  }
   const uint32_t ld = ix->ld;
   if (src.device) {
     if (all_appended_in_order) {
@@ -1208,11 +1256,20 @@ int funnel_rows(vt_flat *ix, const float *query, const size_t *stages, size_t ns
 
 // Sign bits of every stored row in K4's layout, built on first use.
 int index_ensure_bits(vt_flat *ix) {
-  if (ix->bits_valid) return VT_OK;
   Ctx &c = ix->ctx;
   const uint32_t d = (uint32_t)ix->dim, words = (d + 63) / 64;
   // compress_sign_bits of every stored row (collection.ex:926): kept in HBM
   const size_t bwords = vt::hamming_matrix_words(std::max<uint32_t>(ix->cap, ix->n), words);
+  if (ix->bits_valid && ix->dBits.count >= bwords) {
+    // only the rows mutated since the last use
+    uint32_t count = 0;
+    VT_TRY(upload_row_list(ix, ix->bits_dirty, &count));
+    VT_HIP(vt::launch_sign_pack_rows(ix->dX, ix->ld, c.dRankPairs.p, count, d, ix->dBits.p, c.stream));
+    if (count) VT_HIP(hipStreamSynchronize(c.stream));  // the pinned list is reused by the next caller
+    ix->bits_dirty.clear();
+    return VT_OK;
+  }
+  ix->bits_dirty.clear();
   VT_TRY(ix->dBits.ensure(bwords));
   VT_HIP(hipMemsetAsync(ix->dBits.p, 0, bwords * sizeof(uint64_t), c.stream));
   VT_HIP(vt::launch_sign_pack(ix->dX, ix->ld, ix->n, d, ix->dBits.p, 1, c.stream));
@@ -1286,7 +1343,24 @@ int batch_group(vt_flat *ix, const float *queries, size_t nq, size_t limit, vt_h
     qnorm[i] = std::sqrt(s);
   }
   VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  if (ix->max_sqnorm >= 0.0 && ix->dXnorm2.count >= std::max<uint32_t>(ix->cap, n) && !ix->norm_dirty.empty()) {
+    // norms of the rows mutated since the last batch; the maximum can only be kept or raised
+    // (a stale larger bound only widens the acceptance margin)
+    uint32_t count = 0;
+    VT_TRY(upload_row_list(ix, ix->norm_dirty, &count));
+    unsigned long long bits = 0;
+    std::memcpy(&bits, &ix->max_sqnorm, sizeof(double));
+    VT_HIP(hipMemcpyAsync(c.dBNorm.p, &bits, sizeof(bits), hipMemcpyHostToDevice, c.stream));
+    VT_HIP(vt::launch_row_sqnorms_rows(ix->dX, ix->ld, c.dRankPairs.p, count, d, ix->dXnorm2.p, c.dBNorm.p, c.stream));
+    VT_HIP(hipMemcpyAsync(&bits, c.dBNorm.p, sizeof(bits), hipMemcpyDeviceToHost, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    std::memcpy(&ix->max_sqnorm, &bits, sizeof(double));
+    ix->norm_dirty.clear();
+  } else if (ix->max_sqnorm >= 0.0 && ix->dXnorm2.count < std::max<uint32_t>(ix->cap, n)) {
+    ix->max_sqnorm = -1.0;  // the slab grew past the norm column
+  }
   if (ix->max_sqnorm < 0.0) {
+    ix->norm_dirty.clear();
     unsigned long long bits = 0;
     VT_TRY(ix->dXnorm2.ensure(std::max<uint32_t>(ix->cap, n)));
     VT_HIP(hipMemsetAsync(c.dBNorm.p, 0, sizeof(unsigned long long), c.stream));
@@ -1711,8 +1785,7 @@ int vt_flat_delete(vt_flat *ix, const char *id, size_t id_len) {
     ix->ids.pop_back();
     ix->rank_host.pop_back();
     ix->n -= 1;
-    ix->bits_valid = false;
-    ix->max_sqnorm = -1.0;
+    if (r != last) index_touch_row(ix, r);  // row r now holds what was the last row
   }
   if (ix->n == 0) {
     ix->dim = -1;

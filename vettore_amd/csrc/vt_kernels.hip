@@ -593,6 +593,26 @@ __global__ __launch_bounds__(256) void check_finite_kernel(const float *__restri
   if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// K5 for a list of rows (bits of mutated rows patched in place, tiled layout).
+__global__ __launch_bounds__(256) void sign_pack_rows_kernel(const float *__restrict__ rows, size_t stride,
+                                                             const uint32_t *__restrict__ list, uint32_t count, uint32_t d,
+                                                             uint64_t *__restrict__ bits) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t W = (d + 63) / 64;
+  const uint32_t pairs = (W + 1) / 2;
+  const uint64_t total = (uint64_t)count * W;
+  const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / kWave);
+  for (uint64_t w = (uint64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6); w < total; w += nwaves) {
+    const uint32_t i = (uint32_t)(w / W), wi = (uint32_t)(w - (uint64_t)i * W);
+    const uint32_t r = list[i];
+    const uint32_t j = wi * 64 + lane;
+    bool bit = false;
+    if (j < d) bit = rows[(size_t)r * stride + j] >= 0.0f;
+    const uint64_t word = __ballot(bit);
+    if (lane == 0) bits[hamming_word_index(r, wi, pairs)] = word;
+  }
+}
+
 // dst[idx[i]] = val[i]: rank updates of a few rows without re-uploading the column.
 __global__ __launch_bounds__(256) void scatter_u32_kernel(const uint32_t *__restrict__ pairs, uint32_t n,
                                                           uint32_t *__restrict__ dst) {
@@ -1112,6 +1132,14 @@ hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32
 hipError_t launch_check_finite(const float *rows, size_t stride, uint32_t n, uint32_t d, int *flag, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(check_finite_kernel, dim3(2048), dim3(256), 0, s, rows, stride, n, d, flag);
+  return hipGetLastError();
+}
+
+hipError_t launch_sign_pack_rows(const float *rows, size_t stride, const uint32_t *list, uint32_t count, uint32_t d,
+                                 uint64_t *bits, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>(2048, ((uint64_t)count * ((d + 63) / 64) + 3) / 4);
+  hipLaunchKernelGGL(sign_pack_rows_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, rows, stride, list, count, d, bits);
   return hipGetLastError();
 }
 
