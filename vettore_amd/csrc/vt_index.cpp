@@ -716,15 +716,48 @@ int index_sync_ranks(vt_flat *ix, bool force_upload) {
     // (ranks only need to be order-isomorphic to the ids): sort them by rank
     // (integers), sort only the unranked newcomers by id (strings), and merge.
     const std::vector<std::string> &ids = ix->ids;
-    std::vector<uint32_t> ranked, fresh;
-    ranked.reserve(ix->n);
-    for (uint32_t i = 0; i < ix->n; ++i) (ix->rank_host[i] == kUnranked ? fresh : ranked).push_back(i);
     const std::vector<uint32_t> &rk = ix->rank_host;
-    parallel_sort(ranked, [&rk](uint32_t a, uint32_t b) { return rk[a] < rk[b]; });
+    std::vector<uint32_t> ranked, fresh;
+    uint32_t maxr = 0;
+    size_t nranked = 0;
+    for (uint32_t i = 0; i < ix->n; ++i)
+      if (rk[i] != kUnranked) {
+        maxr = std::max(maxr, rk[i]);
+        ++nranked;
+      }
+    if (nranked && (uint64_t)maxr < 4ull * ix->n + 1024) {
+      // ranks are unique: a bucket pass puts the ranked rows in rank (= id) order without sorting
+      std::vector<uint32_t> slot((size_t)maxr + 1, kUnranked);
+      for (uint32_t i = 0; i < ix->n; ++i)
+        if (rk[i] != kUnranked) slot[rk[i]] = i;
+      ranked.reserve(nranked);
+      for (uint32_t v : slot)
+        if (v != kUnranked) ranked.push_back(v);
+      for (uint32_t i = 0; i < ix->n; ++i)
+        if (rk[i] == kUnranked) fresh.push_back(i);
+    } else {
+      ranked.reserve(ix->n);
+      for (uint32_t i = 0; i < ix->n; ++i) (rk[i] == kUnranked ? fresh : ranked).push_back(i);
+      parallel_sort(ranked, [&rk](uint32_t a, uint32_t b) { return rk[a] < rk[b]; });
+    }
     parallel_sort(fresh, [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
     std::vector<uint32_t> order(ix->n);
-    std::merge(ranked.begin(), ranked.end(), fresh.begin(), fresh.end(), order.begin(),
-               [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+    if (fresh.size() < ranked.size() / 16) {
+      // few newcomers: each finds its place among the ranked rows by binary search (string
+      // compares only there), the merge itself moves integers
+      std::vector<uint32_t> pos(fresh.size());
+      for (size_t i = 0; i < fresh.size(); ++i)
+        pos[i] = (uint32_t)(std::lower_bound(ranked.begin(), ranked.end(), fresh[i],
+                                             [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; }) - ranked.begin());
+      size_t o = 0, f = 0;
+      for (size_t r = 0; r <= ranked.size(); ++r) {
+        while (f < fresh.size() && pos[f] == r) order[o++] = fresh[f++];
+        if (r < ranked.size()) order[o++] = ranked[r];
+      }
+    } else {
+      std::merge(ranked.begin(), ranked.end(), fresh.begin(), fresh.end(), order.begin(),
+                 [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+    }
     ix->rank_host.resize(ix->n);
     for (uint32_t i = 0; i < ix->n; ++i) ix->rank_host[order[i]] = i;
     if (ix->n) {
