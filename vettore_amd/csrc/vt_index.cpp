@@ -1340,8 +1340,10 @@ int batch_group(vt_flat *ix, const float *queries, size_t nq, size_t limit, vt_h
   // A larger sample gives a tighter tau: fewer candidates to rescore and, above
   // all, fewer trips through the epilogue's append path (a returning global
   // atomic, ~2 us with the matrix pipe idle: 5 % of the pass at 128 tiles).
-  const uint32_t want_tiles = std::min<uint32_t>(512, std::max<uint32_t>(128, ntiles_total / 64));
-  const uint32_t stride = std::max<uint32_t>(1, ntiles_total / want_tiles);
+  // (at most 65 536 sample rows: sample_tau_kernel holds a query's sample in registers)
+  const uint32_t want_tiles = std::min<uint32_t>(std::min<uint32_t>(512, 65536 / rows_per_block),
+                                                 std::max<uint32_t>(128, ntiles_total / 64));
+  const uint32_t stride = std::max<uint32_t>(1, (ntiles_total + want_tiles - 1) / want_tiles);
   const uint32_t ntiles_sample = (ntiles_total + stride - 1) / stride;
   const uint32_t sample_rows = ntiles_sample * rows_per_block;
   // tau = rank-th best sample score: about rank * n / sample_rows rows pass

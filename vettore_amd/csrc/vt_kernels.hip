@@ -1013,7 +1013,9 @@ hipError_t launch_scan(const ScanArgs &a, uint32_t blocks, hipStream_t s) {
 hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hipStream_t s) {
   ScanDev sd;
   sd.a = a;
-  if (!make_scan_shape(a.d, a.batch_cap, &sd.p)) return hipErrorInvalidValue;
+  // candidate lists are short (tens to hundreds of rows per query): 8-row tiles spread a
+  // list over more waves (a 32-row tile is ~25 us of one wave's load latency)
+  if (!make_scan_shape(a.d, a.batch_cap, &sd.p, 8)) return hipErrorInvalidValue;
   sd.p.tile_floats = sd.p.tr * (uint32_t)a.stride;
   const size_t lds = scan_lds_for(sd.p, a.k);
   if (lds > kMaxLds || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.stride < sd.p.ld || !a.gather || !a.batch_counts)
