@@ -57,6 +57,7 @@ int guarded(F &&f) noexcept {
   } while (0)
 
 inline uint32_t round_up_u32(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+constexpr size_t kBulkRankRows = 16384;   // an insert of at least this many rows re-ranks at once
 constexpr size_t kMaxDirtyRanks = 16384;  // above this the whole rank column is re-uploaded
 constexpr uint32_t kUnranked = 0xFFFFFFFFu;  // id_rank of a row inserted out of id order, until the next re-rank
 
@@ -951,6 +952,9 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
                           hipMemcpyHostToDevice, c.stream));
     VT_HIP(hipStreamSynchronize(c.stream));
   }
+  // A bulk load ranks its ids right away (the load itself takes far longer); only trickling
+  // inserts leave their rows unranked for the lazy search path.
+  if (!ix->ranks_clean && count >= kBulkRankRows) VT_TRY(index_sync_ranks(ix, false));
   return VT_OK;
 }
 
