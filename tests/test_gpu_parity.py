@@ -1044,3 +1044,31 @@ def test_derived_data_is_patched_after_mutations(nifs, oracle_mod, monkeypatch):
         for victim in (ids[1000 + step], ids[n - 1 - step]):
             g.delete(victim); cur.pop(victim, None)
         check()
+
+
+def test_no_hidden_rebuild_inside_a_query_stream(nifs):
+    """After a bulk load (ids in numeric, not bytewise, order; 1 % verbatim duplicate rows, as in
+    bench.py) every search of a stream of distinct queries costs about the same: a deferred
+    id-rank rebuild once landed in the middle of the stream (7 ms/query average instead of 4.6 at
+    N=10M).  Guard: no query takes more than 8x the median."""
+    import time
+    import torch
+    from bench import build_shard, doc_ids
+    rows, dim = 1_000_000, 256
+    x = build_shard(torch, torch.device("cuda", 0), rows, dim, 4242)
+    g = GpuIndex(nifs, 2)
+    assert nifs.flat_load_device_matrix(g.ref, doc_ids(0, rows), x.data_ptr(), rows, dim) == ("ok", ())
+    dup = x[torch.randint(0, rows, (64,), device=x.device)].cpu().numpy()     # queries that hit duplicated rows too
+    del x
+    rng = np.random.default_rng(9)
+    qs = rng.uniform(-1, 1, (136, dim)).astype(np.float32)
+    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    qs = np.concatenate([qs, dup])
+    unwrap(nifs.flat_search(g.ref, qs[0], 10))
+    times = []
+    for q in qs:
+        t0 = time.perf_counter()
+        unwrap(nifs.flat_search(g.ref, q, 10))
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    assert max(times) < 8 * med + 1e-3, (max(times), med)
