@@ -1056,9 +1056,10 @@ def test_no_hidden_rebuild_inside_a_query_stream(nifs):
     from bench import build_shard, doc_ids
     rows, dim = 1_000_000, 256
     x = build_shard(torch, torch.device("cuda", 0), rows, dim, 4242)
+    x[500_000:500_032] = x[:32]                       # planted verbatim copies: limit-1 queries tie across the boundary
     g = GpuIndex(nifs, 2)
     assert nifs.flat_load_device_matrix(g.ref, doc_ids(0, rows), x.data_ptr(), rows, dim) == ("ok", ())
-    dup = x[torch.randint(0, rows, (64,), device=x.device)].cpu().numpy()     # queries that hit duplicated rows too
+    dup = x[:32].cpu().numpy()
     del x
     rng = np.random.default_rng(9)
     qs = rng.uniform(-1, 1, (136, dim)).astype(np.float32)
@@ -1066,9 +1067,12 @@ def test_no_hidden_rebuild_inside_a_query_stream(nifs):
     qs = np.concatenate([qs, dup])
     unwrap(nifs.flat_search(g.ref, qs[0], 10))
     times = []
-    for q in qs:
+    for i, q in enumerate(qs):
         t0 = time.perf_counter()
-        unwrap(nifs.flat_search(g.ref, q, 10))
+        hits = unwrap(nifs.flat_search(g.ref, q, 1 if i >= 136 else 10))
         times.append(time.perf_counter() - t0)
+        if i >= 136:                                   # the copy with the bytewise smaller id wins the tie
+            a_, b_ = b"doc-%d" % (i - 136 + 1), b"doc-%d" % (500_000 + i - 136 + 1)
+            assert hits[0][0] == min(a_, b_)
     med = sorted(times)[len(times) // 2]
     assert max(times) < 8 * med + 1e-3, (max(times), med)
