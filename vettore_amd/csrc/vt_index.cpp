@@ -888,6 +888,7 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
     for (size_t i = 0; i < count; ++i) index_touch_row(ix, target[i]);
   }
   const uint32_t ld = ix->ld;
+  bool pending = false;
   if (src.device) {
     if (all_appended_in_order) {
       float *dst = ix->dX + (size_t)n_before * ld;
@@ -934,9 +935,9 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
       used[half] = true;
       i += chunk;
     }
-    VT_HIP(hipStreamSynchronize(c.stream));
+    pending = true;  // one wait at the end of the function covers the rows and their ranks
   }
-  if (!ix->ranks_clean) {
+  if (!ix->ranks_clean && count < kBulkRankRows) {
     // the device column is brought up to date lazily (index_lazy_ranks) or by the next re-rank
     for (uint32_t r = n_before; r < ix->n; ++r) ix->rank_dirty.push_back(r);
     if (ix->rank_dirty.size() > kMaxDirtyRanks) ix->rank_dirty_all = true;
@@ -950,8 +951,9 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
     }
     VT_HIP(hipMemcpyAsync(ix->dRank.p + from, ix->rank_host.data() + from, (size_t)(ix->n - from) * sizeof(uint32_t),
                           hipMemcpyHostToDevice, c.stream));
-    VT_HIP(hipStreamSynchronize(c.stream));
+    pending = true;
   }
+  if (pending) VT_HIP(hipStreamSynchronize(c.stream));
   // A bulk load ranks its ids right away (the load itself takes far longer); only trickling
   // inserts leave their rows unranked for the lazy search path.
   if (!ix->ranks_clean && count >= kBulkRankRows) VT_TRY(index_sync_ranks(ix, false));
