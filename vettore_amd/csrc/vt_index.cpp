@@ -342,6 +342,7 @@ struct vt_flat {
   // kUnranked, a swap-delete moved a rank); rank_dirty_all = re-upload the whole column.
   std::vector<uint32_t> rank_dirty;
   bool rank_dirty_all = false;
+  size_t unranked = 0;  // rows carrying kUnranked: past a bound the next search rebuilds instead of going lazy
   bool external_ranks = false;      // rank column supplied by vt_flat_set_id_ranks (valid until the next mutation)
   std::string max_id;               // upper bound of all ids while ranks_clean
   uint32_t max_rank = 0;
@@ -687,6 +688,7 @@ uint32_t index_row_for(vt_flat *ix, const char *id, size_t len, bool *is_new) {
     ix->ranks_clean = false;
     std::fill(ix->rank_host.begin(), ix->rank_host.end(), kUnranked);
     ix->rank_dirty_all = true;  // the whole device column is stale now
+    ix->unranked = ix->rank_host.size();
   }
   if (ix->ranks_clean) {
     // ids arriving in ascending order (snapshot rebuild sorts by id,
@@ -700,9 +702,11 @@ uint32_t index_row_for(vt_flat *ix, const char *id, size_t len, bool *is_new) {
     } else {
       ix->ranks_clean = false;
       ix->rank_host.push_back(kUnranked);
+      ix->unranked += 1;
     }
   } else {
     ix->rank_host.push_back(kUnranked);
+    ix->unranked += 1;
   }
   ix->row_of.emplace(key, r);
   ix->ids.push_back(std::move(key));
@@ -766,6 +770,7 @@ int index_sync_ranks(vt_flat *ix, bool force_upload) {
       ix->max_rank = ix->n - 1;
     }
     ix->ranks_clean = true;
+    ix->unranked = 0;
     force_upload = true;
   }
   if (force_upload) {
@@ -985,8 +990,10 @@ int search_locked(vt_flat *ix, const float *query, size_t n, size_t limit, vt_hi
   if (ix->n == 0) return empty_hits(out);
   // Ids inserted out of order since the last ranking: try without re-ranking first.
   const size_t lazy_want = std::min<size_t>(limit, ix->n) + (limit < ix->n ? 1 : 0);
+  // (past ~1/8 of the rows unranked the eventual rebuild would have to sort too many ids at once:
+  // rebuild now, while it is still cheap)
   const bool lazy = !ix->ranks_clean && !ix->external_ranks && lazy_want <= (size_t)vt::kMaxFusedK &&
-                    !std::getenv("VT_EAGER_RANKS");
+                    ix->unranked <= std::max<size_t>(65536, ix->n / 8) && !std::getenv("VT_EAGER_RANKS");
   if (lazy) VT_TRY(index_lazy_ranks(ix));
   else VT_TRY(index_sync_ranks(ix, false));
   uint32_t qnz = 0;
@@ -1806,6 +1813,7 @@ int vt_flat_delete(vt_flat *ix, const char *id, size_t id_len) {
   auto it = ix->row_of.find(std::string(id ? id : "", id_len));
   if (it != ix->row_of.end()) {
     const uint32_t r = it->second, last = ix->n - 1;
+    if (ix->rank_host[r] == kUnranked && ix->unranked) ix->unranked -= 1;
     ix->row_of.erase(it);
     if (r != last) {
       // swap-delete: the last row moves into the hole and keeps its rank
@@ -1832,6 +1840,7 @@ int vt_flat_delete(vt_flat *ix, const char *id, size_t id_len) {
     ix->dim = -1;
     ix->rank_dirty.clear();
     ix->rank_dirty_all = false;
+    ix->unranked = 0;
     ix->ranks_clean = true;
     ix->max_id.clear();
     ix->max_rank = 0;
@@ -1877,6 +1886,7 @@ int vt_flat_set_id_ranks(vt_flat *ix, const uint32_t *ranks, size_t count) {
   VT_TRY(ix->ctx.bind());
   if (count != ix->n) return VT_ERR_DIMENSION;
   ix->rank_host.assign(ranks, ranks + count);
+  ix->unranked = 0;
   ix->ranks_clean = true;
   ix->external_ranks = true;
   ix->max_rank = kUnranked - 1;  // an appended id can no longer extend the ranks in place
