@@ -115,6 +115,15 @@ struct RadixArgs {
 hipError_t launch_radix_pass(const RadixArgs &a, int pass, uint32_t blocks, hipStream_t s);
 hipError_t launch_radix_collect(const RadixArgs &a, uint32_t blocks, hipStream_t s);
 
+// A whole list of <= kSelListMax (key, payload) pairs in ascending key order into host-mapped
+// memory: `out` receives the live entries, `head` their count and the scan status word.
+struct BigResultHeader {
+  int status;
+  uint32_t count;
+};
+hipError_t launch_sort_list(const uint64_t *keys, const Payload *pay, uint32_t m, int *dev_status, BigResultHeader *head,
+                            Entry *out, hipStream_t s);
+
 // The k smallest of a key list as a device-resident, unsorted list (k <= kSelListMax): the
 // candidate set of a following stage whose own ordering does not depend on this one.
 constexpr uint32_t kSelListMax = 4096;

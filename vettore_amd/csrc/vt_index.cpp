@@ -230,6 +230,9 @@ struct Ctx {
   DevBuf<vt::Payload> dCandPay;
   PinnedBuf<float> hQ;
   PinnedBuf<ResultBlock> hRes;  // written by the select kernel through the host mapping
+  // limits above kMaxFusedK: up to kSelListMax sorted entries + header, host-mapped, allocated on first use
+  PinnedBuf<unsigned char> hBig;
+  unsigned char *dBigMapped = nullptr;
   ResultBlock *dResMapped = nullptr;
   PinnedBuf<uint32_t> hShard;  // shard of each winner of a cross-shard merge (host mapped)
   uint32_t *dShardMapped = nullptr;
@@ -395,6 +398,26 @@ int collect_from_keys(Ctx &c, const uint64_t *keys, const vt::Payload *pay, uint
   return VT_OK;
 }
 
+// All `m` <= kSelListMax candidates (keys/payload on the device) in ascending key order,
+// appended to `out`: one launch, one wait.
+int collect_sorted_list(Ctx &c, const uint64_t *keys, const vt::Payload *pay, uint32_t m, std::vector<vt::Entry> &out) {
+  const size_t bytes = 16 + (size_t)vt::kSelListMax * sizeof(vt::Entry);
+  if (!c.dBigMapped) {
+    VT_TRY(c.hBig.ensure(bytes));
+    VT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&c.dBigMapped), c.hBig.p, 0));
+  }
+  auto *head = reinterpret_cast<vt::BigResultHeader *>(c.dBigMapped);
+  auto *ents = reinterpret_cast<vt::Entry *>(c.dBigMapped + 16);
+  VT_HIP(vt::launch_sort_list(keys, pay, m, c.dStatus.p, head, ents, c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  const auto *hh = reinterpret_cast<const vt::BigResultHeader *>(c.hBig.p);
+  if (hh->status == vt::kStatusRetry) return kRetryInternal;
+  if (hh->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
+  const auto *he = reinterpret_cast<const vt::Entry *>(c.hBig.p + 16);
+  out.insert(out.end(), he, he + hh->count);
+  return VT_OK;
+}
+
 struct ScanJob {
   const float *X;
   size_t stride;
@@ -505,7 +528,7 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
     g.key_out = c.dCandKeys.p;
     g.pay_out = c.dCandPay.p;
     VT_HIP(vt::launch_scan(g, c.grid_for((k + vt::kTileRows - 1) / vt::kTileRows, vt::scan_lds_bytes(j.d, 1)), c.stream));
-    const int rc = collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, k, k, out);
+    const int rc = collect_sorted_list(c, c.dCandKeys.p, c.dCandPay.p, k, out);
     if (timed && rc != kRetryInternal) {
       float ms = 0.f;
       VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
@@ -1083,7 +1106,7 @@ int run_cosine_scan(Ctx &c, vt_flat *ix, uint32_t d, double qq, size_t want, std
     g.out_pay = c.dCandPay.p;
     g.status = c.dStatus.p;
     VT_HIP(vt::launch_cosine_rerank(g, c.stream));
-    const int rc = collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, k, k, out);
+    const int rc = collect_sorted_list(c, c.dCandKeys.p, c.dCandPay.p, k, out);
     if (c.profiling && rc != kRetryInternal) {
       float ms = 0.0f;
       VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));

@@ -311,6 +311,44 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
   }
 }
 
+// All of a short list (<= kSelListMax keys) in ascending key order, kEmptyKey entries dropped:
+// the winners of a limit above kMaxFusedK leave the device in one launch.  One block, keys in
+// LDS, rank sort (m^2 / 1024 compares per thread: ~55 us at m = 4096).
+__global__ __launch_bounds__(1024) void sort_list_kernel(const uint64_t *__restrict__ keys, const Payload *__restrict__ pay,
+                                                         uint32_t m, int *dev_status, BigResultHeader *head,
+                                                         Entry *__restrict__ out) {
+  extern __shared__ __align__(16) unsigned char sl_smem[];
+  uint64_t *sk = reinterpret_cast<uint64_t *>(sl_smem);
+  __shared__ uint32_t s_live;
+  if (threadIdx.x == 0) s_live = 0;
+  for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) sk[i] = keys[i];
+  __syncthreads();
+  uint32_t live = 0;
+  for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+    const uint64_t ki = sk[i];
+    if (ki == kEmptyKey) continue;
+    live += 1;
+    uint32_t pos = 0;
+    for (uint32_t x = 0; x < m; ++x) {
+      const uint64_t kx = sk[x];
+      pos += (kx < ki || (kx == ki && x < i)) ? 1u : 0u;
+    }
+    const Payload p = pay[i];
+    Entry e;
+    e.key = ki;
+    e.row = p.row;
+    e.raw = p.raw;
+    out[pos] = e;
+  }
+  atomicAdd(&s_live, live);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    head->count = s_live;
+    head->status = *dev_status;
+    *dev_status = 0;
+  }
+}
+
 // Cross-shard merge: world * k candidate entries (already sorted per shard) ->
 // the k best overall by rank sort in LDS.  Keys are comparable across shards
 // because every shard's id_rank column was taken from ONE ordering of all ids.
@@ -1031,6 +1069,13 @@ hipError_t launch_radix_pass(const RadixArgs &a, int pass, uint32_t blocks, hipS
 
 hipError_t launch_radix_collect(const RadixArgs &a, uint32_t blocks, hipStream_t s) {
   hipLaunchKernelGGL(radix_collect_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_sort_list(const uint64_t *keys, const Payload *pay, uint32_t m, int *dev_status, BigResultHeader *head,
+                            Entry *out, hipStream_t s) {
+  if (m == 0 || m > kSelListMax) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sort_list_kernel, dim3(1), dim3(1024), (size_t)m * 8, s, keys, pay, m, dev_status, head, out);
   return hipGetLastError();
 }
 
