@@ -25,7 +25,7 @@ $(LIBDIR)/vt_index.o: $(CSRC)/vt_index.cpp $(CSRC)/vt_device.h include/vettore_f
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 $(LIBDIR)/libvettore_hip.so: $(DEVOBJ) $(LIBDIR)/vt_index.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread -ldl
 
 oracle:
 	$(MAKE) -C oracle -s

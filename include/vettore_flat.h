@@ -18,8 +18,11 @@
  *    exactly like native/vettore/src/flat.rs:69-85 does;
  *  - all compute runs on the GPU; there is no CPU fallback.  Without a usable
  *    HIP device the calls fail with VT_ERR_DEVICE.
- *  - thread safety: one index handle serialises its calls internally (the
- *    reference's RwLock, nifs.rs:266-309); different handles are independent.
+ *  - thread safety: a handle is the reference's RwLock<FlatIndex> (nifs.rs:266-309):
+ *    searches of one handle run concurrently with each other (each on its own HIP
+ *    stream), mutations are exclusive; different handles are independent.  A
+ *    mutation that fails on the device after it began changing the index poisons
+ *    the handle (VT_ERR_POISONED from then on), like a panic under the write lock.
  */
 #ifndef VETTORE_FLAT_H
 #define VETTORE_FLAT_H
@@ -31,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 1
+#define VT_ABI_VERSION 2
 
 /* Metric codes == Metric::from_code, native/vettore/src/distances.rs:24-38,
  * mirrored by lib/vettore/collection.ex:1306-1315. */
@@ -57,6 +60,7 @@ enum {
   VT_ERR_UNKNOWN_METRIC = 5, /* "unknown metric"                      distances.rs:36 */
   VT_ERR_PREFIX = 6,         /* "invalid prefix dimensions"           search.rs:47 */
   VT_ERR_DIMS_POSITIVE = 7,  /* "dimensions must be positive"         distances.rs:463 */
+  VT_ERR_POISONED = 8,       /* "flat lock poisoned"                  nifs.rs:269: an earlier mutation died half-way */
   /* statuses the reference cannot produce */
   VT_ERR_NOMEM = 16,
   VT_ERR_DEVICE = 17,        /* HIP error / no gfx950 device; see vt_last_error() */
@@ -66,9 +70,17 @@ enum {
 
 /* Lane order of wide::f32x8::reduce_add used for every 8-float chunk
  * (distances.rs:197-308).  The reference does not pin it (third-party crate,
- * build-flag dependent); the device kernels reproduce whichever is selected
- * bit for bit.  Default VT_ORDER_PAIR.  See DESIGN.md "summation order". */
-enum { VT_ORDER_PAIR = 0, VT_ORDER_AVX = 1, VT_ORDER_SEQ = 2 };
+ * build-flag dependent); the device kernels reproduce whichever is selected bit
+ * for bit.  With l0..l7 the lanes of a chunk:
+ *   VT_ORDER_PAIR ((l0+l1)+(l2+l3)) + ((l4+l5)+(l6+l7))   two f32x4 halves, SSE3 haddps / NEON vaddvq
+ *   VT_ORDER_AVX  ((l0+l4)+(l2+l6)) + ((l1+l5)+(l3+l7))   one 256-bit register (target-cpu=native, Taskfile.yml:12)
+ *   VT_ORDER_SEQ  (((l0+l1)+l2)+l3) + (((l4+l5)+l6)+l7)   array fallback (no SIMD target feature)
+ *   VT_ORDER_SSE2 ((l0+l2)+(l1+l3)) + ((l4+l6)+(l5+l7))   two f32x4 halves, movehl + shuffle (baseline
+ *                                                          x86-64: what the precompiled release NIF is built for)
+ * Default VT_ORDER_SSE2 (override: VT_REDUCE_ORDER=pair|avx|seq|sse2, vt_set_default_reduce_order,
+ * vt_flat_set_reduce_order).  See DESIGN.md "summation order" and INTEGRATION.md section 4 for the
+ * one-line probe that tells which order a given libvettore build uses. */
+enum { VT_ORDER_PAIR = 0, VT_ORDER_AVX = 1, VT_ORDER_SEQ = 2, VT_ORDER_SSE2 = 3 };
 
 const char *vt_strerror(int status);
 /* Detail text of the calling thread's last VT_ERR_DEVICE / VT_ERR_UNSUPPORTED. */
@@ -109,6 +121,35 @@ typedef struct vt_flat vt_flat;
 
 /* flat_new_<metric>/0, nifs.rs:200-257.  `device` = HIP device ordinal. */
 int vt_flat_new(int metric_code, int device, vt_flat **out);
+/* The same resource spread over the GPUs of one node (SURVEY.md 8b "device_mask", 8e):
+ * ONE handle in ONE process, like the reference's FlatResource (nifs.rs:254-257); shard i
+ * lives on HIP device devices[i].  A row belongs to shard hash(id) % ndev, so every
+ * operation on an id goes to one shard and the shards never talk to each other except
+ * for the per-query exchange of their top-k lists.  Every entry point below accepts the
+ * handle; results equal those of a one-GPU index over all rows (ids, order, raw bits).
+ * ndev == 1 is vt_flat_new.  The same ordinal may be listed more than once (tests on a
+ * one-GPU box); the exchange then stays on the host path. */
+int vt_flat_new_sharded(int metric_code, const int *devices, size_t ndev, vt_flat **out);
+size_t vt_flat_shard_count(const vt_flat *index);
+int vt_flat_shard_device(const vt_flat *index, size_t shard);  /* -1: no such shard */
+size_t vt_flat_shard_len(const vt_flat *index, size_t shard);
+/* out_shard[i] = shard that owns (or would own) id i. */
+int vt_flat_route_ids(const vt_flat *index, size_t count, const char *ids, const size_t *id_off,
+                      uint32_t *out_shard);
+/* How the shards' top-k lists meet (multi-shard handles):
+ *   VT_EXCHANGE_RCCL  every shard's select kernel leaves its list in a device block; one
+ *                     ncclAllGather per shard communicator (RCCL over xGMI, queued behind the
+ *                     scan on the shard's stream) collects the blocks, shard 0 hands the
+ *                     gathered lists to the host, which merges by (rank key, id bytes).
+ *                     Default when the shards sit on distinct devices and limit <= 256.
+ *   VT_EXCHANGE_HOST  every shard's select kernel writes its list straight into pinned host
+ *                     memory; same merge.  Always available; used for limits above 256,
+ *                     batches, and when RCCL cannot serve the device list. */
+enum { VT_EXCHANGE_HOST = 0, VT_EXCHANGE_RCCL = 1 };
+int vt_flat_set_exchange(vt_flat *index, int mode);
+int vt_flat_exchange(const vt_flat *index);
+/* Ranks of the shard communicator (ncclCommCount), 0 while none exists. */
+int vt_flat_rccl_ranks(const vt_flat *index);
 /* ResourceArc drop: frees HBM, streams, pinned staging. */
 void vt_flat_free(vt_flat *index);
 

@@ -18,7 +18,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvt_oracle.so")
 
-ORDER_PAIR, ORDER_AVX, ORDER_SEQ = 0, 1, 2
+ORDER_PAIR, ORDER_AVX, ORDER_SEQ, ORDER_SSE2 = 0, 1, 2, 3
+ORDERS = (ORDER_PAIR, ORDER_AVX, ORDER_SEQ, ORDER_SSE2)
+DEFAULT_ORDER = ORDER_SSE2
 METRICS = [
     "l2", "l2_squared", "cosine", "inner_product", "negative_inner_product",
     "manhattan", "chebyshev", "hamming", "jaccard",

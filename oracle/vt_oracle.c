@@ -14,10 +14,10 @@
 #include <stdlib.h>
 #include <string.h>
 
-static int g_order = VTO_ORDER_PAIR;
+static int g_order = VTO_ORDER_SSE2;
 
 void vto_set_reduce_order(int order) {
-  if (order >= VTO_ORDER_PAIR && order <= VTO_ORDER_SEQ) g_order = order;
+  if (order >= VTO_ORDER_PAIR && order <= VTO_ORDER_SSE2) g_order = order;
 }
 int vto_get_reduce_order(void) { return g_order; }
 
@@ -36,13 +36,15 @@ const char *vto_strerror(int code) {
   }
 }
 
-/* ---- wide::f32x8::reduce_add, three possible lane orders (header) -------- */
+/* ---- wide::f32x8::reduce_add, four possible lane orders (header) --------- */
 static inline float reduce_add8(const float l[8]) {
   switch (g_order) {
     case VTO_ORDER_AVX:
       return ((l[0] + l[4]) + (l[2] + l[6])) + ((l[1] + l[5]) + (l[3] + l[7]));
     case VTO_ORDER_SEQ:
       return (((l[0] + l[1]) + l[2]) + l[3]) + (((l[4] + l[5]) + l[6]) + l[7]);
+    case VTO_ORDER_SSE2:
+      return ((l[0] + l[2]) + (l[1] + l[3])) + ((l[4] + l[6]) + (l[5] + l[7]));
     default:
       return ((l[0] + l[1]) + (l[2] + l[3])) + ((l[4] + l[5]) + (l[6] + l[7]));
   }

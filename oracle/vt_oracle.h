@@ -49,7 +49,7 @@ enum {
  *        (Taskfile.yml:12).
  *  SEQ : (((l0+l1)+l2)+l3) + (((l4+l5)+l6)+l7)  scalar-fallback f32x4.
  */
-enum { VTO_ORDER_PAIR = 0, VTO_ORDER_AVX = 1, VTO_ORDER_SEQ = 2 };
+enum { VTO_ORDER_PAIR = 0, VTO_ORDER_AVX = 1, VTO_ORDER_SEQ = 2, VTO_ORDER_SSE2 = 3 };
 
 /* Error codes; vto_strerror() gives the reference's exact error strings. */
 enum {

@@ -10,11 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    config.addinivalue_line("markers", "gpu_perf: timing guards and throughput floors on a real MI355X "
+                                       "(run with -m gpu_perf; kept out of -m gpu so a busy box cannot fail parity)")
     # torch bundles its own libamdhip64 (same soname as ROCm's): whichever copy is
     # loaded first serves the whole process, and torch does not survive coming
     # second.  GPU sessions use both, so torch goes first.
     markexpr = config.getoption("-m", default="") or ""
-    if "gpu" in markexpr and "not gpu" not in markexpr:
+    if "gpu" in markexpr and "not gpu" not in markexpr.replace("not gpu_perf", ""):
         try:
             import torch  # noqa: F401
         except ImportError:
@@ -26,3 +28,15 @@ def oracle_mod():
     import oracle
     oracle.build()
     return oracle
+
+
+def pytest_collection_modifyitems(config, items):
+    # gpu_perf tests run only when asked for by name (-m gpu_perf): `-m "not gpu"` on a CPU box
+    # and `-m gpu` on the driver's box both leave them out
+    markexpr = config.getoption("-m", default="") or ""
+    if "gpu_perf" in markexpr:
+        return
+    skip = pytest.mark.skip(reason="timing guard: run with -m gpu_perf on an MI355X")
+    for item in items:
+        if "gpu_perf" in item.keywords:
+            item.add_marker(skip)

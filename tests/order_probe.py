@@ -18,11 +18,12 @@ PROBE_B = [1.0] * 8
 def table():
     import oracle
     out = {}
-    for name, order in (("PAIR", oracle.ORDER_PAIR), ("AVX", oracle.ORDER_AVX), ("SEQ", oracle.ORDER_SEQ)):
+    for name, order in (("PAIR", oracle.ORDER_PAIR), ("AVX", oracle.ORDER_AVX), ("SEQ", oracle.ORDER_SEQ),
+                        ("SSE2", oracle.ORDER_SSE2)):
         oracle.set_reduce_order(order)
         v = oracle.compute(oracle.METRIC_CODE["inner_product"], PROBE_A, PROBE_B)
         out[name] = (int(np.float32(v).view(np.uint32)), float(v))
-    oracle.set_reduce_order(oracle.ORDER_PAIR)
+    oracle.set_reduce_order(oracle.DEFAULT_ORDER)
     return out
 
 

@@ -45,10 +45,11 @@ def test_error_strings_are_the_references(lib):
         5: "unknown metric",
         6: "invalid prefix dimensions",
         7: "dimensions must be positive",
+        8: "flat lock poisoned",            # nifs.rs:269
     }
     for code, text in want.items():
         assert lib.vt_strerror(code).decode() == text
-    assert lib.vt_abi_version() == 1
+    assert lib.vt_abi_version() == 2
 
 
 def test_header_cites_the_reference_interface():
@@ -64,6 +65,9 @@ def test_argument_validation_happens_before_the_device(lib):
     h = C.c_void_p()
     assert lib.vt_flat_new(9, 0, C.byref(h)) == 5          # unknown metric
     assert lib.vt_flat_new(-1, 0, C.byref(h)) == 5
+    devs = (C.c_int * 2)(0, 1)
+    assert lib.vt_flat_new_sharded(9, devs, 2, C.byref(h)) == 5
+    assert lib.vt_flat_new_sharded(2, devs, 0, C.byref(h)) == 19   # no devices: VT_ERR_ARGUMENT
     one = (C.c_float * 1)(1.0)
     off = (C.c_size_t * 1)(0)
     out = C.c_void_p()
@@ -87,6 +91,8 @@ def test_no_cpu_fallback_without_a_device(lib):
     h = C.c_void_p()
     assert lib.vt_flat_new(2, 0, C.byref(h)) == 17         # VT_ERR_DEVICE
     assert b"no CPU fallback" in lib.vt_last_error()
+    devs = (C.c_int * 2)(0, 1)
+    assert lib.vt_flat_new_sharded(2, devs, 2, C.byref(h)) == 17
     from vettore_amd import nifs
     with pytest.raises(RuntimeError, match="device error"):
         nifs.flat_new_cosine()

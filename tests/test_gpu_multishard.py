@@ -1,0 +1,280 @@
+"""One resource, several shards (vt_flat_new_sharded, SURVEY.md 8e / 8b "device_mask") and
+several readers on one handle (the reference's RwLock, nifs.rs:266-309) -- `-m gpu`.
+
+The box has one GPU, so the shards of these tests all sit on device 0: every piece of the
+multi-shard machinery runs (hash routing, one worker thread per shard, the per-shard
+searches, the merge by (rank key, id bytes)) except the wire between devices.  The RCCL
+exchange itself is exercised with a one-rank communicator (ncclCommInitAll over [0]).
+Every result is compared bit for bit with the CPU oracle over ALL rows.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from support import load, run_steps
+from test_gpu_parity import GpuError, GpuIndex, bits, make_corpus, nifs, unwrap  # noqa: F401  (nifs is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+class ShardedIndex(GpuIndex):
+    def __init__(self, nifs, metric_code, devices, order=3):
+        self.n = nifs
+        self.ref = nifs.flat_new_sharded(metric_code, devices)
+        nifs.flat_set_reduce_order(self.ref, order)
+
+
+def test_flat_rs_scripts_on_a_sharded_handle(nifs, oracle_mod):
+    """The reference's own flat.rs known-answer scripts (tie-break by id, upsert, delete,
+    atomic batch validation, dimension reset, limit edge cases) on a 3-shard resource."""
+    for case in load("flat_rs.json"):
+        if case.get("differential"):
+            continue
+        ix = ShardedIndex(nifs, oracle_mod.METRIC_CODE[case["metric"]], [0, 0, 0])
+        assert nifs.flat_shard_count(ix.ref) == 3
+        run_steps(ix, case["steps"], GpuError)
+
+
+@pytest.mark.parametrize("metric", [2, 0, 5])
+def test_sharded_handle_equals_the_oracle_over_all_rows(nifs, oracle_mod, metric):
+    n, d, S = 40_000, 96, 4
+    x, ids = make_corpus(n, d, 1200 + metric, metric == 2, oracle_mod, tie_block=40)
+    ref = ShardedIndex(nifs, metric, [0] * S)
+    route = nifs.flat_route_ids(ref.ref, nifs.pack_ids(ids))
+    assert set(route.tolist()) == set(range(S))
+    # identical rows that live in different shards: only the id bytes can order them
+    first = [int(np.flatnonzero(route == s)[0]) for s in range(S)]
+    for r in first[1:]:
+        x[r] = x[first[0]]
+    unwrap(nifs.flat_load_matrix(ref.ref, ids, x))
+    lens = nifs.flat_shard_lens(ref.ref)
+    assert sum(lens) == n == len(ref) and min(lens) > n // S * 0.9, lens   # the hash spreads the rows evenly
+    assert ref.dimension == d
+    packed = oracle_mod.pack_ids(ids)
+    rng = np.random.default_rng(3)
+    qs = [x[first[0]], x[n // 2]] + [rng.uniform(-1, 1, d).astype(np.float32) for _ in range(3)]
+    if metric == 2:
+        qs = [oracle_mod.normalize_l2(q) for q in qs]
+    for q in qs:
+        for limit in (1, 4, 10, 64, 300):
+            assert bits(ref.search(q, limit)) == bits(oracle_mod.matrix_search(metric, x, packed, q, limit)), (metric, limit)
+    # the first query's top hits are the planted copies, in id-byte order across the shards
+    top = ref.search(qs[0], S)
+    assert sorted(h[0] for h in top) == sorted(ids[r] for r in first) and [h[0] for h in top] == sorted(h[0] for h in top)
+    # limit beyond the row count, and the batch entry point
+    assert len(ref.search(qs[1], n + 5)) == n
+    batch = np.stack(qs)
+    outs = unwrap(nifs.flat_search_batch(ref.ref, batch, 10))
+    for q, got in zip(qs, outs):
+        assert bits(got) == bits(oracle_mod.matrix_search(metric, x, packed, q, 10))
+
+
+def test_sharded_mutations_follow_the_oracle(nifs, oracle_mod):
+    """Random insert / upsert / delete / search interleaving (flat.rs:59-93) on a 3-shard
+    resource: routing, per-shard swap-deletes and rank upkeep must stay invisible."""
+    rng = np.random.default_rng(15)
+    d = 16
+    for m in (0, 2):
+        g = ShardedIndex(nifs, m, [0, 0, 0])
+        o = oracle_mod.FlatIndex(m)
+        live = []
+        for step in range(250):
+            op = rng.integers(0, 10)
+            if op < 5 or not live:
+                cnt = int(rng.integers(1, 40))
+                items = [("id-%d" % rng.integers(0, 500), rng.uniform(-1, 1, d).astype(np.float32)) for _ in range(cnt)]
+                g.insert_many(items)
+                o.insert_many(items)
+                live = list({*live, *[i for i, _ in items]})
+            elif op < 8:
+                victim = live.pop(int(rng.integers(0, len(live))))
+                g.delete(victim)
+                o.delete(victim)
+            else:
+                g.delete("missing-%d" % step)
+                o.delete("missing-%d" % step)
+            assert len(g) == len(o) and g.dimension == o.dimension
+            if len(o) == 0:
+                continue
+            q = rng.uniform(-1, 1, d).astype(np.float32)
+            k = int(rng.integers(1, 30))
+            assert bits(g.search(q, k)) == bits(o.search(q, k)), (m, step)
+        # empty it: the resource forgets its dimension (flat.rs:90-92) and takes another one
+        for i in list(live):
+            g.delete(i)
+        assert len(g) == 0 and g.dimension is None
+        g.insert("a", [1.0, 2.0, 3.0])
+        assert g.dimension == 3
+        with pytest.raises(GpuError, match="dimension mismatch"):
+            g.insert("b", [1.0, 2.0])
+        with pytest.raises(GpuError, match="dimension mismatch"):       # atomic: nothing of the batch lands
+            g.insert_many([("c", [1.0, 2.0, 3.0]), ("d", [1.0])])
+        assert len(g) == 1
+
+
+def test_sharded_validation_and_unsupported_calls(nifs, oracle_mod):
+    g = ShardedIndex(nifs, 2, [0, 0])
+    assert g.search([1.0, 0.0], 0) == [] and g.search([1.0, 0.0], 3) == []
+    with pytest.raises(GpuError, match="vector must not be empty"):
+        g.search([], 3)
+    with pytest.raises(GpuError, match="non-finite"):
+        g.search([float("inf"), 0.0], 3)
+    g.insert_many([("a", [1.0, 0.0]), ("b", [0.0, 1.0]), ("c", [1.0, 0.0])])
+    assert [h[0] for h in g.search([1.0, 0.0], 2)] == [b"a", b"c"]     # vector_algorithms_hardening_test.exs:20-36
+    with pytest.raises(GpuError, match="dimension mismatch"):
+        g.search([1.0, 0.0, 0.0], 2)
+    res = nifs.flat_quantized_search(g.ref, [1.0, 0.0], 3, 2)
+    assert res[0] == "error" and "multi-shard" in res[1]
+
+
+def test_rccl_exchange_with_a_one_rank_communicator(nifs, oracle_mod, monkeypatch):
+    """The RCCL leg of the exchange (librccl loaded at run time, ncclCommInitAll, one ncclAllGather
+    per shard queued behind the scan, gathered lists copied out by shard 0) on the only GPU of
+    the box: a one-shard resource forced onto the worker path."""
+    monkeypatch.setenv("VT_SHARD_FORCE_WORKERS", "1")
+    monkeypatch.setenv("VT_SHARD_EXCHANGE", "rccl")
+    n, d = 30_000, 128
+    x, ids = make_corpus(n, d, 77, True, oracle_mod, tie_block=30)
+    g = ShardedIndex(nifs, 2, [0])
+    from vettore_amd import _lib
+    assert nifs.flat_exchange(g.ref) == _lib.EXCHANGE_RCCL and nifs.flat_rccl_ranks(g.ref) == 1
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    packed = oracle_mod.pack_ids(ids)
+    rng = np.random.default_rng(8)
+    for i in range(6):
+        q = x[n // 2] if i == 0 else oracle_mod.normalize_l2(rng.uniform(-1, 1, d).astype(np.float32))
+        for limit in (10, 200, 300):      # 300 > 256: served by the host exchange
+            assert bits(g.search(q, limit)) == bits(oracle_mod.matrix_search(2, x, packed, q, limit)), (i, limit)
+    # unsorted inserts, then the exchange path again (ranks are rebuilt strictly for it)
+    g.insert("aaa-first", x[3])
+    g.delete(ids[10])
+    keep = [i for i in range(n) if i != 10]
+    x2 = np.concatenate([x[keep], x[3:4]])
+    ids2 = [ids[i] for i in keep] + [b"aaa-first"]
+    assert bits(g.search(x[3], 5)) == bits(oracle_mod.matrix_search(2, x2, oracle_mod.pack_ids(ids2), x[3], 5))
+    # two shards on ONE device cannot form a communicator: the handle says so and stays on the host path
+    monkeypatch.delenv("VT_SHARD_EXCHANGE")
+    two = ShardedIndex(nifs, 2, [0, 0])
+    assert nifs.flat_exchange(two.ref) == _lib.EXCHANGE_HOST and nifs.flat_rccl_ranks(two.ref) == 0
+    res = nifs.flat_set_exchange(two.ref, _lib.EXCHANGE_RCCL)
+    assert res[0] == "error" and "own device" in res[1]
+
+
+def test_stale_external_ranks_are_reported_to_every_rank(nifs, oracle_mod):
+    """after vt_flat_set_id_ranks a delete moves rows under the caller's id table and
+    an insert drops the installed ranks.  vt_flat_search_begin then marks its block instead of
+    scanning, and vt_flat_merge_gathered -- which every rank runs on the same gathered blocks --
+    fails with 'stale id ranks', so all ranks fall back together."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n, d = 5000, 32
+    x, ids = make_corpus(n, d, 5, False, oracle_mod)
+    g = GpuIndex(nifs, 0)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    assert nifs.flat_set_id_ranks(g.ref, nifs.rank_ids(nifs.pack_ids(ids))) == "ok"
+    block = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(block), 16 + 16 * 10) == 0
+    bufs = nifs.MergeBuffers()
+    assert nifs.flat_search_begin(g.ref, x[0], 10, block.value) == "ok"
+    st, cnt = nifs.flat_merge_gathered(g.ref, block.value, 1, 10, 176, bufs)
+    assert st == "ok" and cnt == 10
+    g.insert(ids[7], x[8])                     # an upsert moves nothing: still valid
+    assert nifs.flat_search_begin(g.ref, x[0], 10, block.value) == "ok"
+    assert nifs.flat_merge_gathered(g.ref, block.value, 1, 10, 176, bufs)[0] == "ok"
+    g.delete(ids[3])                           # the last row moves into slot 3
+    assert nifs.flat_search_begin(g.ref, x[0], 10, block.value) == "ok"
+    res = nifs.flat_merge_gathered(g.ref, block.value, 1, 10, 176, bufs)
+    assert res[0] == "error" and "stale id ranks" in res[1]
+    # the plain search is unaffected
+    keep = [i for i in range(n) if i != 3]
+    x2 = x[keep].copy()
+    x2[keep.index(7)] = x[8]
+    assert bits(g.search(x[0], 10)) == bits(oracle_mod.matrix_search(0, x2, oracle_mod.pack_ids([ids[i] for i in keep]), x[0], 10))
+    assert hip.hipFree(block) == 0
+
+
+def test_many_readers_and_a_writer_on_one_handle(nifs, oracle_mod):
+    """nifs.rs:297-309 takes the read lock, :259-295 the write lock: eight reader threads search
+    ONE handle (each on its own stream and scratch) while a writer inserts, upserts and deletes
+    rows that can never reach a top-10 (far from every query); every answer equals the oracle's."""
+    n, d = 20_000, 64
+    x, ids = make_corpus(n, d, 321, False, oracle_mod, tie_block=16)
+    g = GpuIndex(nifs, 0)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    packed = oracle_mod.pack_ids(ids)
+    rng = np.random.default_rng(2)
+    qs = [x[n // 2]] + [rng.uniform(-1, 1, d).astype(np.float32) for _ in range(7)]
+    want = [bits(oracle_mod.matrix_search(0, x, packed, q, 10)) for q in qs]
+    far = (rng.uniform(-1, 1, (400, d)) + 50.0).astype(np.float32)
+    errors, stop = [], threading.Event()
+
+    def reader(t):
+        try:
+            for i in range(200):
+                j = (t + i) % len(qs)
+                mode = (t + i) % 3
+                if mode == 0:
+                    got = bits(unwrap(nifs.flat_search(g.ref, qs[j], 10)))
+                elif mode == 1:
+                    got = bits(unwrap(nifs.flat_search_batch(g.ref, np.stack([qs[j], qs[j]]), 10))[1])
+                else:
+                    got = bits(unwrap(nifs.flat_search(g.ref, qs[j], 300))[:10])
+                if got != want[j]:
+                    errors.append(("reader", t, i, mode))
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append(("reader", t, repr(e)))
+
+    def writer():
+        try:
+            i = 0
+            while not stop.is_set():
+                key = "zz-far-%d" % (i % 400)
+                g.insert(key, far[i % 400])
+                if i % 3 == 2:
+                    g.delete("zz-far-%d" % ((i - 2) % 400))
+                if i % 7 == 0:
+                    g.insert_many([("aa-far-%d" % (i % 50), far[(i * 3) % 400])])   # sorts in front of every "doc-"
+                i += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(("writer", repr(e)))
+
+    ths = [threading.Thread(target=reader, args=(t,)) for t in range(8)]
+    w = threading.Thread(target=writer)
+    w.start()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    stop.set()
+    w.join()
+    assert not errors, errors[:3]
+    # quantized / funnel readers next to each other on a second handle (cosine)
+    xc, idc = make_corpus(20_000, 64, 99, True, oracle_mod)
+    c = GpuIndex(nifs, 2)
+    unwrap(nifs.flat_load_matrix(c.ref, idc, xc))
+    qn = [oracle_mod.normalize_l2(q) for q in qs]
+    wq = [bits(unwrap(nifs.flat_quantized_search(c.ref, q, 100, 10))) for q in qn]
+    wf = [bits(unwrap(nifs.flat_funnel_search(c.ref, q, [32], 100, 10))) for q in qn]
+
+    def reader2(t):
+        try:
+            for i in range(60):
+                j = (t + i) % len(qn)
+                if (t + i) % 2:
+                    ok = bits(unwrap(nifs.flat_quantized_search(c.ref, qn[j], 100, 10))) == wq[j]
+                else:
+                    ok = bits(unwrap(nifs.flat_funnel_search(c.ref, qn[j], [32], 100, 10))) == wf[j]
+                if not ok:
+                    errors.append(("reader2", t, i))
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append(("reader2", t, repr(e)))
+
+    ths = [threading.Thread(target=reader2, args=(t,)) for t in range(6)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors[:3]

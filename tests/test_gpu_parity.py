@@ -17,7 +17,7 @@ from support import b, close, load, run_steps, same_f32
 
 pytestmark = pytest.mark.gpu
 
-ORDERS = [0, 1, 2]
+ORDERS = [0, 1, 2, 3]
 TOL = 1e-5  # BASELINE.json: f32 scores within 1e-5 (relative, distances.rs:485-491 convention)
 
 
@@ -44,7 +44,7 @@ def unwrap(res):
 class GpuIndex:
     """support.run_steps adapter over the Python mirror of Vettore.Nifs."""
 
-    def __init__(self, nifs, metric_code, order=0):
+    def __init__(self, nifs, metric_code, order=3):
         self.n = nifs
         self.ref = nifs._flat_new(metric_code)
         nifs.flat_set_reduce_order(self.ref, order)
@@ -97,7 +97,7 @@ def test_flat_rs_all_metrics_match_oracle_bitwise(nifs, oracle_mod, order):
             for limit in case["limits"]:
                 assert bits(g.search(case["query"], limit)) == bits(o.search(case["query"], limit)), (name, limit)
     finally:
-        oracle_mod.set_reduce_order(0)
+        oracle_mod.set_reduce_order(oracle_mod.DEFAULT_ORDER)
 
 
 def test_distances_tail_lengths_bitwise(nifs, oracle_mod):
@@ -126,7 +126,7 @@ def test_distances_tail_lengths_bitwise(nifs, oracle_mod):
                     exact = float(np.sum(np.abs(l64 - r64)))
                 if exact is not None:
                     assert close(got[0][1], exact, c["tolerance"])
-    oracle_mod.set_reduce_order(0)
+    oracle_mod.set_reduce_order(oracle_mod.DEFAULT_ORDER)
 
 
 def test_distances_overflow_recovery(nifs, oracle_mod):
@@ -342,7 +342,7 @@ def test_random_parity_all_metrics(nifs, oracle_mod, d, order):
                     want = oracle_mod.matrix_search(m, x, packed, q, k)
                     assert bits(got) == bits(want), (d, order, m, k)
     finally:
-        oracle_mod.set_reduce_order(0)
+        oracle_mod.set_reduce_order(oracle_mod.DEFAULT_ORDER)
 
 
 @pytest.mark.parametrize("d", [1024, 1536, 1540, 3072, 4100, 8192])
@@ -363,7 +363,7 @@ def test_wide_rows_use_column_panels(nifs, oracle_mod, d):
                 for k in (10, 100):
                     assert bits(g.search(q, k)) == bits(oracle_mod.matrix_search(m, x, packed, q, k)), (d, order, m, k)
         finally:
-            oracle_mod.set_reduce_order(0)
+            oracle_mod.set_reduce_order(oracle_mod.DEFAULT_ORDER)
 
 
 def test_cosine_config1_parity(nifs, oracle_mod):
@@ -855,10 +855,9 @@ def test_quantized_histogram_pass_survives_dimension_changes(nifs, oracle_mod):
 
 def test_padding_columns_of_a_small_batch_nominate_nothing(nifs, oracle_mod, monkeypatch):
     """A batch of 8 is padded to 32 query columns; the all-zero padding columns once passed
-    every row as a candidate (45x slower than a full 32-query batch).  Timing guard with a
-    wide margin, plus parity of the small batch itself."""
+    every row as a candidate.  Parity of the small batch here; the timing guard that caught
+    it lives in tests/test_gpu_perf.py (-m gpu_perf)."""
     monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
-    import time
     n, d = 300_000, 128
     rng = np.random.default_rng(5)
     x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
@@ -866,17 +865,7 @@ def test_padding_columns_of_a_small_batch_nominate_nothing(nifs, oracle_mod, mon
     g = GpuIndex(nifs, 3)
     unwrap(nifs.flat_load_matrix(g.ref, ids, x))
     qs = rng.uniform(-1, 1, (32, d)).astype(np.float32)
-
-    def timed(batch):
-        unwrap(nifs.flat_search_batch(g.ref, batch, 10))
-        t0 = time.perf_counter()
-        for _ in range(3):
-            out = unwrap(nifs.flat_search_batch(g.ref, batch, 10))
-        return (time.perf_counter() - t0) / 3, out
-
-    t32, _ = timed(qs)
-    t8, out8 = timed(qs[:8])
-    assert t8 < 5 * t32 + 5e-3, (t8, t32)
+    out8 = unwrap(nifs.flat_search_batch(g.ref, qs[:8], 10))
     for i in range(8):
         assert bits(out8[i]) == bits(unwrap(nifs.flat_search(g.ref, qs[i], 10)))
 
@@ -1046,33 +1035,19 @@ def test_derived_data_is_patched_after_mutations(nifs, oracle_mod, monkeypatch):
         check()
 
 
-def test_no_hidden_rebuild_inside_a_query_stream(nifs):
-    """After a bulk load (ids in numeric, not bytewise, order; 1 % verbatim duplicate rows, as in
-    bench.py) every search of a stream of distinct queries costs about the same: a deferred
-    id-rank rebuild once landed in the middle of the stream (7 ms/query average instead of 4.6 at
-    N=10M).  Guard: no query takes more than 8x the median."""
-    import time
+def test_boundary_ties_after_a_bulk_load(nifs):
+    """After a bulk load (ids in numeric, not bytewise, order; verbatim duplicate rows, as in
+    bench.py) limit-1 queries on planted copies tie across the boundary: the copy with the
+    bytewise smaller id wins.  (The per-query timing guard of this scenario: test_gpu_perf.py.)"""
     import torch
     from bench import build_shard, doc_ids
     rows, dim = 1_000_000, 256
     x = build_shard(torch, torch.device("cuda", 0), rows, dim, 4242)
-    x[500_000:500_032] = x[:32]                       # planted verbatim copies: limit-1 queries tie across the boundary
+    x[500_000:500_032] = x[:32]
     g = GpuIndex(nifs, 2)
     assert nifs.flat_load_device_matrix(g.ref, doc_ids(0, rows), x.data_ptr(), rows, dim) == ("ok", ())
     dup = x[:32].cpu().numpy()
     del x
-    rng = np.random.default_rng(9)
-    qs = rng.uniform(-1, 1, (136, dim)).astype(np.float32)
-    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
-    qs = np.concatenate([qs, dup])
-    unwrap(nifs.flat_search(g.ref, qs[0], 10))
-    times = []
-    for i, q in enumerate(qs):
-        t0 = time.perf_counter()
-        hits = unwrap(nifs.flat_search(g.ref, q, 1 if i >= 136 else 10))
-        times.append(time.perf_counter() - t0)
-        if i >= 136:                                   # the copy with the bytewise smaller id wins the tie
-            a_, b_ = b"doc-%d" % (i - 136 + 1), b"doc-%d" % (500_000 + i - 136 + 1)
-            assert hits[0][0] == min(a_, b_)
-    med = sorted(times)[len(times) // 2]
-    assert max(times) < 8 * med + 1e-3, (max(times), med)
+    for i, q in enumerate(dup):
+        hits = unwrap(nifs.flat_search(g.ref, q, 1))
+        assert hits[0][0] == min(b"doc-%d" % (i + 1), b"doc-%d" % (500_000 + i + 1))

@@ -1,0 +1,97 @@
+"""Timing guards and throughput checks (`-m gpu_perf`): kept out of `-m gpu` so that a busy
+box cannot fail a parity run.  Each asserts a wide margin around a
+regression that once happened, or a floor the design promises."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import GpuIndex, bits, make_corpus, nifs, unwrap  # noqa: F401  (nifs is a fixture)
+
+pytestmark = pytest.mark.gpu_perf
+
+
+def test_small_batch_costs_no_more_than_a_full_one(nifs, monkeypatch):
+    """A batch of 8 (padded to 32 columns) once cost 45x a batch of 32."""
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    n, d = 300_000, 128
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    g = GpuIndex(nifs, 3)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    qs = rng.uniform(-1, 1, (32, d)).astype(np.float32)
+
+    def timed(batch):
+        unwrap(nifs.flat_search_batch(g.ref, batch, 10))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            unwrap(nifs.flat_search_batch(g.ref, batch, 10))
+        return (time.perf_counter() - t0) / 3
+
+    t32, t8 = timed(qs), timed(qs[:8])
+    assert t8 < 5 * t32 + 5e-3, (t8, t32)
+
+
+def test_no_hidden_rebuild_inside_a_query_stream(nifs):
+    """A deferred id-rank rebuild once landed in the middle of a query stream (7 ms/query average
+    instead of 4.6 at N=10M).  Guard: no query takes more than 8x the median."""
+    import torch
+    from bench import build_shard, doc_ids
+    rows, dim = 1_000_000, 256
+    x = build_shard(torch, torch.device("cuda", 0), rows, dim, 4242)
+    g = GpuIndex(nifs, 2)
+    assert nifs.flat_load_device_matrix(g.ref, doc_ids(0, rows), x.data_ptr(), rows, dim) == ("ok", ())
+    del x
+    rng = np.random.default_rng(9)
+    qs = rng.uniform(-1, 1, (136, dim)).astype(np.float32)
+    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    unwrap(nifs.flat_search(g.ref, qs[0], 10))
+    times = []
+    for q in qs:
+        t0 = time.perf_counter()
+        unwrap(nifs.flat_search(g.ref, q, 10))
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    assert max(times) < 8 * med + 1e-3, (max(times), med)
+
+
+def _throughput(nifs, g, qs, threads, seconds=1.5):
+    stop = time.perf_counter() + seconds
+    counts = [0] * threads
+
+    def run(t):
+        i = t
+        while time.perf_counter() < stop:
+            unwrap(nifs.flat_search(g.ref, qs[i % len(qs)], 10))
+            counts[t] += 1
+            i += 1
+
+    ths = [threading.Thread(target=run, args=(t,)) for t in range(threads)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    return sum(counts) / (time.perf_counter() - t0)
+
+
+def test_readers_on_one_handle_overlap(nifs, oracle_mod):
+    """searches take the read lock (nifs.rs:304-308).  Eight readers on one
+    handle must not be slower than one (large corpus: the GPU is the bottleneck either way) and
+    must gain from overlap where a call is mostly launch latency (N = 10 000)."""
+    rng = np.random.default_rng(4)
+    out = {}
+    for n, d in ((10_000, 384), (2_000_000, 128)):
+        x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+        ids = [b"doc-%d" % (i + 1) for i in range(n)]
+        g = GpuIndex(nifs, 3)
+        unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+        qs = rng.uniform(-1, 1, (16, d)).astype(np.float32)
+        _throughput(nifs, g, qs, 8, 0.3)
+        out[n] = (_throughput(nifs, g, qs, 1), _throughput(nifs, g, qs, 8))
+    print("queries/s (1 reader, 8 readers):", out)
+    small, large = out[10_000], out[2_000_000]
+    assert small[1] > 1.5 * small[0], small
+    assert large[1] > 0.95 * large[0], large

@@ -1,7 +1,7 @@
 """Pins the CPU oracle against every known-answer test the reference holds for
 the flat-index hot path (fixtures in tests/golden/).
 
-Each test runs under all three candidate `wide::f32x8::reduce_add` lane orders:
+Each test runs under all four candidate `wide::f32x8::reduce_add` lane orders:
 the reference's known answers do not depend on that order, which is exactly
 why the order itself stays unpinned (see oracle/vt_oracle.h).
 """
@@ -13,15 +13,15 @@ import pytest
 import support
 from support import b, close, load, run_steps, same_f32, full_sort
 
-ORDERS = [0, 1, 2]
+ORDERS = [0, 1, 2, 3]
 F32_MAX = float(np.finfo(np.float32).max)
 
 
-@pytest.fixture(params=ORDERS, ids=["pair", "avx", "seq"])
+@pytest.fixture(params=ORDERS, ids=["pair", "avx", "seq", "sse2"])
 def orc(request, oracle_mod):
     oracle_mod.set_reduce_order(request.param)
     yield oracle_mod
-    oracle_mod.set_reduce_order(0)
+    oracle_mod.set_reduce_order(oracle_mod.DEFAULT_ORDER)
 
 
 def code(orc, name):
@@ -317,13 +317,14 @@ def test_reduce_orders_differ_only_in_last_bits(oracle_mod):
     for o in ORDERS:
         oracle_mod.set_reduce_order(o)
         vals.append(float(oracle_mod.compute(3, a, c)))
-    oracle_mod.set_reduce_order(0)
+    oracle_mod.set_reduce_order(oracle_mod.DEFAULT_ORDER)
     exact = float(np.dot(a.astype(np.float64), c.astype(np.float64)))
     assert all(close(v, exact, 2e-6) for v in vals)
 
 
-def test_order_probe_separates_the_three_orders(oracle_mod):
+def test_order_probe_separates_the_four_orders(oracle_mod):
     """the probe a maintainer runs on the reference build."""
     import order_probe
     t = order_probe.table()
-    assert {k: v[0] for k, v in t.items()} == {"PAIR": 0xbfefdf3c, "AVX": 0x40480000, "SEQ": 0x3f9020c4}
+    assert {k: v[0] for k, v in t.items()} == {"PAIR": 0xbfefdf3c, "AVX": 0x40480000, "SEQ": 0x3f9020c4,
+                                                "SSE2": 0x40081064}

@@ -12,14 +12,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvettore_hip.so")
 
 VT_OK = 0
-ORDER_PAIR, ORDER_AVX, ORDER_SEQ = 0, 1, 2
+ORDER_PAIR, ORDER_AVX, ORDER_SEQ, ORDER_SSE2 = 0, 1, 2, 3
+EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1
 
 # every symbol include/vettore_flat.h declares
 SYMBOLS = [
     "vt_strerror", "vt_last_error", "vt_abi_version", "vt_device_count",
     "vt_hits_len", "vt_hits_id", "vt_hits_raw", "vt_hits_rank_key", "vt_hits_pack", "vt_hits_id_bytes", "vt_hits_export",
     "vt_hits_free",
-    "vt_flat_new", "vt_flat_free", "vt_flat_insert", "vt_flat_insert_many", "vt_flat_delete",
+    "vt_flat_new", "vt_flat_new_sharded", "vt_flat_shard_count", "vt_flat_shard_device", "vt_flat_shard_len",
+    "vt_flat_route_ids", "vt_flat_set_exchange", "vt_flat_exchange", "vt_flat_rccl_ranks", "vt_flat_free", "vt_flat_insert", "vt_flat_insert_many", "vt_flat_delete",
     "vt_flat_search", "vt_flat_search_batch", "vt_flat_len", "vt_flat_dimension", "vt_flat_metric",
     "vt_flat_set_reduce_order", "vt_set_default_reduce_order",
     "vt_flat_load_matrix", "vt_flat_load_device_matrix", "vt_flat_quantized_search", "vt_flat_funnel_search", "vt_flat_hybrid_search",
@@ -75,6 +77,16 @@ def load() -> C.CDLL:
     L.vt_hits_free.restype = None
     L.vt_hits_free.argtypes = [vp]
     L.vt_flat_new.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.vt_flat_new_sharded.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_size_t, C.POINTER(vp)]
+    L.vt_flat_shard_count.restype = C.c_size_t
+    L.vt_flat_shard_count.argtypes = [vp]
+    L.vt_flat_shard_device.argtypes = [vp, C.c_size_t]
+    L.vt_flat_shard_len.restype = C.c_size_t
+    L.vt_flat_shard_len.argtypes = [vp, C.c_size_t]
+    L.vt_flat_route_ids.argtypes = [vp, C.c_size_t, C.c_char_p, szp, C.POINTER(C.c_uint32)]
+    L.vt_flat_set_exchange.argtypes = [vp, C.c_int]
+    L.vt_flat_exchange.argtypes = [vp]
+    L.vt_flat_rccl_ranks.argtypes = [vp]
     L.vt_flat_free.restype = None
     L.vt_flat_free.argtypes = [vp]
     L.vt_flat_insert.argtypes = [vp, C.c_char_p, C.c_size_t, f32p, C.c_size_t]

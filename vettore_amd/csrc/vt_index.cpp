@@ -8,20 +8,40 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 namespace {
 
 thread_local std::string g_last_error;
-int g_default_order = VT_ORDER_PAIR;
+// Lane order of wide::f32x8::reduce_add assumed for new indexes (include/vettore_flat.h;
+// DESIGN.md "summation order" says why SSE2 and how to pin it): VT_REDUCE_ORDER overrides.
+int initial_order() {
+  const char *e = std::getenv("VT_REDUCE_ORDER");
+  if (e) {
+    const std::string v(e);
+    if (v == "pair" || v == "0") return VT_ORDER_PAIR;
+    if (v == "avx" || v == "1") return VT_ORDER_AVX;
+    if (v == "seq" || v == "2") return VT_ORDER_SEQ;
+    if (v == "sse2" || v == "3") return VT_ORDER_SSE2;
+  }
+  return VT_ORDER_SSE2;
+}
+int g_default_order = initial_order();
 
 int fail(int status, const std::string &detail) {
   g_last_error = detail;
@@ -318,9 +338,18 @@ struct vt_hits {
   std::vector<uint32_t> rank_key;
 };
 
-struct vt_flat {
-  std::mutex mu;
-  Ctx ctx;
+// One shard = one GPU's share of the rows: the slab, its derived columns, the ids of
+// its rows.  A plain index has exactly one; vt_flat_new_sharded deals rows to several.
+struct Shard {
+  Ctx ctx;  // primary context: mutations and derived-data upkeep run here, under the exclusive lock
+  // Further contexts (own stream, scratch, result block) so that several readers can be
+  // in flight on one handle (the reference's RwLock readers, nifs.rs:304-308); created
+  // on demand, handed out by CtxLease.
+  std::mutex pool_mu;
+  std::condition_variable pool_cv;
+  std::vector<std::unique_ptr<Ctx>> extra;
+  std::vector<Ctx *> free_ctx;
+  bool ctx0_busy = false;
   int metric = 0;
   int order = g_default_order;
   // corpus
@@ -347,12 +376,212 @@ struct vt_flat {
   bool rank_dirty_all = false;
   size_t unranked = 0;  // rows carrying kUnranked: past a bound the next search rebuilds instead of going lazy
   bool external_ranks = false;      // rank column supplied by vt_flat_set_id_ranks (valid until the next mutation)
+  uint64_t epoch = 0;               // bumped by every mutation of the row set (insert of a new id, delete)
+  uint64_t external_epoch = 0;      // epoch at which the external ranks were installed
+  bool external_expected = false;   // vt_flat_set_id_ranks has been used on this shard: search_begin insists on current ranks
   std::string max_id;               // upper bound of all ids while ranks_clean
   uint32_t max_rank = 0;
 
-  ~vt_flat() {
+  ~Shard() {
     (void)hipSetDevice(ctx.device);
     if (dX) (void)hipFree(dX);
+  }
+
+  template <class F>
+  void for_each_ctx(F f) {
+    f(ctx);
+    for (auto &e : extra) f(*e);
+  }
+};
+
+namespace {
+
+constexpr size_t kMaxContexts = 8;  // readers in flight per shard
+
+// A context for one reader: the primary one if free, else a spare, else a new one (up to
+// kMaxContexts), else wait.  Held only under the handle's shared lock.
+struct CtxLease {
+  Shard *ix;
+  Ctx *c = nullptr;
+  int status = VT_OK;
+  explicit CtxLease(Shard *s) : ix(s) {
+    std::unique_lock<std::mutex> g(ix->pool_mu);
+    for (;;) {
+      if (!ix->ctx0_busy) {
+        ix->ctx0_busy = true;
+        c = &ix->ctx;
+        return;
+      }
+      if (!ix->free_ctx.empty()) {
+        c = ix->free_ctx.back();
+        ix->free_ctx.pop_back();
+        return;
+      }
+      if (ix->extra.size() + 1 < kMaxContexts) {
+        auto nc = std::make_unique<Ctx>();
+        status = nc->init(ix->ctx.device);
+        if (status != VT_OK) return;
+        nc->profiling = ix->ctx.profiling;
+        c = nc.get();
+        ix->extra.push_back(std::move(nc));
+        return;
+      }
+      ix->pool_cv.wait(g);
+    }
+  }
+  ~CtxLease() {
+    if (!c) return;
+    {
+      std::lock_guard<std::mutex> g(ix->pool_mu);
+      if (c == &ix->ctx) ix->ctx0_busy = false;
+      else ix->free_ctx.push_back(c);
+    }
+    ix->pool_cv.notify_one();
+  }
+  CtxLease(const CtxLease &) = delete;
+  CtxLease &operator=(const CtxLease &) = delete;
+};
+
+// ---- RCCL, loaded on first use (librccl is half a gigabyte: a single-GPU index never maps it)
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+  bool ok = false;
+};
+
+Rccl &rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+      r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) {
+      r.error = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?");
+      return;
+    }
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    r.ok = r.CommInitAll && r.CommDestroy && r.CommCount && r.AllGather && r.GetErrorString;
+    if (!r.ok) r.error = "librccl lacks an expected symbol";
+  });
+  return r;
+}
+
+// One thread per shard of a multi-shard index, bound to the shard's device: the caller
+// posts the same job to all of them, so the launch overheads of the shards overlap and
+// each shard's kernels are issued by a thread whose current device never changes.
+struct Worker {
+  struct Job {
+    std::function<int()> fn;
+    int status = VT_OK;
+    std::string error;
+    bool done = false;
+  };
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv, done_cv;
+  std::deque<Job *> queue;
+  bool stop = false;
+  int device = 0;
+
+  void start(int dev) {
+    device = dev;
+    th = std::thread([this] { loop(); });
+  }
+  void loop() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      Job *job = nullptr;
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [this] { return stop || !queue.empty(); });
+        if (queue.empty()) return;  // stop
+        job = queue.front();
+        queue.pop_front();
+      }
+      g_last_error.clear();
+      const int st = guarded(job->fn);
+      {
+        std::lock_guard<std::mutex> g(mu);
+        job->status = st;
+        if (st != VT_OK) job->error = g_last_error;
+        job->done = true;
+      }
+      done_cv.notify_all();
+    }
+  }
+  void post(Job *job) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      queue.push_back(job);
+    }
+    cv.notify_one();
+  }
+  void wait(Job *job) {
+    std::unique_lock<std::mutex> g(mu);
+    done_cv.wait(g, [job] { return job->done; });
+  }
+  ~Worker() {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      stop = true;
+    }
+    cv.notify_one();
+    if (th.joinable()) th.join();
+  }
+};
+
+}  // namespace
+
+// The handle behind the C ABI: FlatResource(RwLock<FlatIndex>) (flat.rs:13-17, nifs.rs:254-257).
+struct vt_flat {
+  // searches share, mutations exclude (nifs.rs:266-309)
+  mutable std::shared_mutex rw;
+  // A mutation that failed on the device after it had begun changing the index leaves it
+  // poisoned, like a panic under the reference's write lock: every later call fails with
+  // "flat lock poisoned" (nifs.rs:269).
+  bool poisoned = false;
+  int metric = 0;
+  long dim = -1;  // FlatIndex.dimension across all shards
+  std::vector<std::unique_ptr<Shard>> shards;
+  // multi-shard only
+  std::vector<std::unique_ptr<Worker>> workers;
+  std::mutex post_mu;  // jobs reach every worker's queue in one order (collectives must match up)
+  int exchange = VT_EXCHANGE_HOST;
+  bool exchange_forced = false;
+  std::vector<ncclComm_t> comms;
+  bool comms_tried = false;
+  size_t exch_limit = 0;  // entries the exchange blocks are sized for
+  std::vector<void *> dBlock, dGather;  // per shard: its own result block, the gathered blocks of all shards
+  PinnedBuf<unsigned char> hGather;     // shard 0's gathered copy, read by the merging host thread
+  vt_profile xprof{};                   // exchange timing (merge_launches / merge_ms)
+
+  bool multi() const { return shards.size() > 1 || !workers.empty(); }
+  size_t total() const {
+    size_t t = 0;
+    for (auto &s : shards) t += s->n;
+    return t;
+  }
+  ~vt_flat() {
+    workers.clear();  // joins the threads before their shards go away
+    for (size_t i = 0; i < comms.size(); ++i)
+      if (comms[i]) (void)rccl().CommDestroy(comms[i]);
+    for (size_t i = 0; i < dBlock.size(); ++i) {
+      (void)hipSetDevice(shards[i]->ctx.device);
+      if (dBlock[i]) (void)hipFree(dBlock[i]);
+      if (dGather[i]) (void)hipFree(dGather[i]);
+    }
   }
 };
 
@@ -655,7 +884,7 @@ int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero) {
 inline uint32_t rank_key_of(uint64_t key) { return (uint32_t)(key >> 32); }
 
 // ------------------------------------------------------------------ index ops
-int index_reserve(vt_flat *ix, uint32_t want_rows) {
+int index_reserve(Shard *ix, uint32_t want_rows) {
   if (want_rows <= ix->cap) return VT_OK;
   uint64_t nc = std::max<uint64_t>(want_rows, (uint64_t)ix->cap * 2);
   nc = std::max<uint64_t>(nc, 1024);
@@ -675,12 +904,12 @@ int index_reserve(vt_flat *ix, uint32_t want_rows) {
 }
 
 // Sets the dimension of an empty index (first insert after creation/emptying).
-int index_set_dim(vt_flat *ix, size_t d) {
+int index_set_dim(Shard *ix, size_t d) {
   if (d > 0x7fffffffu) return fail(VT_ERR_UNSUPPORTED, "dimension too large");
   if (vt::scan_lds_bytes((uint32_t)d, 1) == 0)
     return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(d) + " exceeds what the scan kernel stages in LDS");
   const uint32_t ld = vt::padded_dim((uint32_t)d);
-  ix->ctx.ham_dirty = true;  // K4h's histograms are cleared for d + 1 bins only: a new dimension starts clean
+  ix->for_each_ctx([](Ctx &c) { c.ham_dirty = true; });  // K4h's histograms are cleared for d + 1 bins only: a new dimension starts clean
   ix->bits_valid = false;    // derived per-row data belongs to the old rows
   ix->max_sqnorm = -1.0;
   ix->bits_dirty.clear();
@@ -696,7 +925,7 @@ int index_set_dim(vt_flat *ix, size_t d) {
 }
 
 // Row for `id`: existing row, or a fresh one appended (ids/rank bookkeeping).
-uint32_t index_row_for(vt_flat *ix, const char *id, size_t len, bool *is_new) {
+uint32_t index_row_for(Shard *ix, const char *id, size_t len, bool *is_new) {
   std::string key(id, len);
   auto it = ix->row_of.find(key);
   if (it != ix->row_of.end()) {
@@ -705,6 +934,7 @@ uint32_t index_row_for(vt_flat *ix, const char *id, size_t len, bool *is_new) {
   }
   const uint32_t r = ix->n++;
   *is_new = true;
+  ix->epoch += 1;
   if (ix->external_ranks) {
     // externally supplied ranks describe the old row set only: fall back to a local re-rank
     ix->external_ranks = false;
@@ -738,7 +968,7 @@ uint32_t index_row_for(vt_flat *ix, const char *id, size_t len, bool *is_new) {
 
 // Recomputes id_rank (position of each row's id in bytewise order) if stale
 // and makes the device copy current.
-int index_sync_ranks(vt_flat *ix, bool force_upload) {
+int index_sync_ranks(Shard *ix, bool force_upload) {
   if (!ix->ranks_clean) {
     // Rows that kept a rank from before are still in the right relative order
     // (ranks only need to be order-isomorphic to the ids): sort them by rank
@@ -814,7 +1044,7 @@ int index_sync_ranks(vt_flat *ix, bool force_upload) {
 // their f32 rank (search_locked checks exactly that and orders equal ranks by id bytes on
 // the host).  An unsorted insert therefore costs the next search a few bytes, not an O(n)
 // merge and a column upload.
-int index_lazy_ranks(vt_flat *ix) {
+int index_lazy_ranks(Shard *ix) {
   Ctx &c = ix->ctx;
   if (ix->n == 0) return VT_OK;
   if (ix->dRank.count < std::max<size_t>(ix->cap, ix->n)) {
@@ -850,12 +1080,13 @@ struct RowSource {
   const size_t *off = nullptr;    // ragged offsets; null => dense with `d`
   const float *device = nullptr;  // dense device matrix [count][d]
   size_t d = 0;
+  const uint32_t *pick = nullptr;  // optional: row i of this batch is row pick[i] of the source
 };
 
 constexpr size_t kMaxDerivedDirty = 65536;  // more mutated rows than this: rebuild instead of patching
 
 // Row `r` changed: its sign bits and norm are stale.
-inline void index_touch_row(vt_flat *ix, uint32_t r) {
+inline void index_touch_row(Shard *ix, uint32_t r) {
   if (ix->bits_valid) {
     ix->bits_dirty.push_back(r);
     if (ix->bits_dirty.size() > kMaxDerivedDirty) {
@@ -873,7 +1104,7 @@ inline void index_touch_row(vt_flat *ix, uint32_t r) {
 }
 
 // Uploads a row list (rows still < n) for the patch kernels; returns its length.
-int upload_row_list(vt_flat *ix, std::vector<uint32_t> &list, uint32_t *count) {
+int upload_row_list(Shard *ix, std::vector<uint32_t> &list, uint32_t *count) {
   Ctx &c = ix->ctx;
   std::sort(list.begin(), list.end());
   list.erase(std::unique(list.begin(), list.end()), list.end());
@@ -888,7 +1119,9 @@ int upload_row_list(vt_flat *ix, std::vector<uint32_t> &list, uint32_t *count) {
 }
 
 // Shared body of insert / insert_many / load_matrix: rows are already validated.
-int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *id_off, const RowSource &src) {
+// `*began` is set once the index has started to change: a failure after that point
+// leaves it inconsistent (the caller poisons the handle).
+int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_off, const RowSource &src, bool *began) {
   if (count == 0) return VT_OK;
   Ctx &c = ix->ctx;
   const size_t d = (size_t)ix->dim;
@@ -902,6 +1135,7 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
     ix->ids.reserve((size_t)ix->n + count);
     ix->rank_host.reserve((size_t)ix->n + count);
   }
+  *began = true;
   for (size_t i = 0; i < count; ++i) {
     bool is_new = false;
     target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new);
@@ -918,15 +1152,21 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
   const uint32_t ld = ix->ld;
   bool pending = false;
   if (src.device) {
-    if (all_appended_in_order) {
+    bool picks_dense = true;  // the batch is one contiguous block of the source
+    if (src.pick)
+      for (size_t i = 1; i < count && picks_dense; ++i) picks_dense = src.pick[i] == src.pick[0] + i;
+    const float *first = src.device + (src.pick ? (size_t)src.pick[0] * d : 0);
+    if (all_appended_in_order && picks_dense) {
+      // (hipMemcpyDefault: the source may live on another device of the node)
       float *dst = ix->dX + (size_t)n_before * ld;
-      if (ld == d) VT_HIP(hipMemcpyAsync(dst, src.device, count * d * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
-      else VT_HIP(vt::launch_pad_rows(src.device, (uint32_t)count, (uint32_t)d, dst, ld, c.stream));
+      if (ld == d) VT_HIP(hipMemcpyAsync(dst, first, count * d * sizeof(float), hipMemcpyDefault, c.stream));
+      else VT_HIP(vt::launch_pad_rows(first, (uint32_t)count, (uint32_t)d, dst, ld, c.stream));
     } else {
       for (size_t i = 0; i < count; ++i) {
         float *dst = ix->dX + (size_t)target[i] * ld;
+        const size_t p = src.pick ? src.pick[i] : i;
         VT_HIP(hipMemsetAsync(dst, 0, (size_t)ld * sizeof(float), c.stream));
-        VT_HIP(hipMemcpyAsync(dst, src.device + i * d, d * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+        VT_HIP(hipMemcpyAsync(dst, src.device + p * d, d * sizeof(float), hipMemcpyDefault, c.stream));
       }
     }
     VT_HIP(hipStreamSynchronize(c.stream));
@@ -945,7 +1185,8 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
       if (used[half]) VT_HIP(hipEventSynchronize(done[half]));  // its previous copies have left the buffer
       parallel_for(chunk, 2048, [&](size_t lo, size_t hi) {
         for (size_t j = lo; j < hi; ++j) {
-          const float *row = src.off ? src.host + src.off[i + j] : src.host + (i + j) * src.d;
+          const size_t p = src.pick ? src.pick[i + j] : i + j;
+          const float *row = src.off ? src.host + src.off[p] : src.host + p * src.d;
           float *dst = stage + j * ld;
           std::memcpy(dst, row, d * sizeof(float));
           for (size_t t = d; t < ld; ++t) dst[t] = 0.0f;
@@ -988,7 +1229,7 @@ int index_store_rows(vt_flat *ix, size_t count, const char *ids, const size_t *i
   return VT_OK;
 }
 
-int make_hits(const vt_flat *ix, const std::vector<vt::Entry> &entries, vt_hits **out) {
+int make_hits(const Shard *ix, const std::vector<vt::Entry> &entries, vt_hits **out) {
   auto h = std::make_unique<vt_hits>();
   h->ids.reserve(entries.size());
   for (const auto &e : entries) {
@@ -1005,20 +1246,61 @@ int empty_hits(vt_hits **out) {
   return VT_OK;
 }
 
-// flat.rs:96-124 with the handle's lock held.
-int search_locked(vt_flat *ix, const float *query, size_t n, size_t limit, vt_hits **out) {
-  Ctx &c = ix->ctx;
+// ---- what a reader needs up to date before it may run under the shared lock ----------
+enum : unsigned { NEED_RANKS = 1, NEED_STRICT_RANKS = 2, NEED_BITS = 4, NEED_NORMS = 8 };
+// Internal: only the true id order can decide (a tie at the boundary of a lazy search).
+constexpr int kEscalate = -101;
+
+// Ids inserted out of order since the last ranking keep one shared sentinel rank; a search
+// that wants `limit` hits may run on that column if it can ask for one hit more (see
+// search_ready).  Past ~1/8 of the rows unranked the eventual rebuild would have to sort
+// too many ids at once: rebuild now, while it is still cheap.
+bool lazy_ranks_ok(const Shard *ix, size_t limit) {
+  const size_t lazy_want = std::min<size_t>(limit, ix->n) + (limit < ix->n ? 1 : 0);
+  // (one select pass only: very wide rows leave LDS for the small candidate buffer alone)
+  const size_t kmax = vt::scan_lds_bytes((uint32_t)ix->dim, vt::kMaxFusedK) ? (size_t)vt::kMaxFusedK : (size_t)vt::kSmallK;
+  return !ix->ranks_clean && !ix->external_ranks && lazy_want <= kmax &&
+         ix->unranked <= std::max<size_t>(65536, ix->n / 8) && !std::getenv("VT_EAGER_RANKS");
+}
+
+bool shard_stale(const Shard *ix, unsigned need, size_t limit) {
+  if (ix->n == 0) return false;
+  const size_t rows = std::max<size_t>(ix->cap, ix->n);
+  if ((need & (NEED_RANKS | NEED_STRICT_RANKS)) && !ix->ranks_clean) {
+    if ((need & NEED_STRICT_RANKS) || !lazy_ranks_ok(ix, limit)) return true;
+    if (!ix->rank_dirty.empty() || ix->rank_dirty_all || ix->dRank.count < rows) return true;
+  }
+  if (need & NEED_BITS) {
+    const size_t bwords = vt::hamming_matrix_words((uint32_t)rows, ((uint32_t)ix->dim + 63) / 64);
+    if (!ix->bits_valid || !ix->bits_dirty.empty() || ix->dBits.count < bwords) return true;
+  }
+  if ((need & NEED_NORMS) && (ix->max_sqnorm < 0.0 || !ix->norm_dirty.empty() || ix->dXnorm2.count < rows)) return true;
+  return false;
+}
+
+int index_ensure_bits(Shard *ix);
+int index_ensure_norms(Shard *ix);
+
+// Brings the derived columns a reader needs up to date (exclusive access; primary context).
+int shard_prepare(Shard *ix, unsigned need, size_t limit) {
+  if (ix->n == 0) return VT_OK;
+  if (need & (NEED_RANKS | NEED_STRICT_RANKS)) {
+    if (!(need & NEED_STRICT_RANKS) && lazy_ranks_ok(ix, limit)) VT_TRY(index_lazy_ranks(ix));
+    else VT_TRY(index_sync_ranks(ix, false));
+  }
+  if (need & NEED_BITS) VT_TRY(index_ensure_bits(ix));
+  if (need & NEED_NORMS) VT_TRY(index_ensure_norms(ix));
+  return VT_OK;
+}
+
+// flat.rs:96-124 on a shard whose rank column shard_prepare has brought up to date --
+// strictly (ranks_clean) or lazily (newcomers share kUnranked).  Read-only on the shard.
+int search_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t limit, vt_hits **out) {
   if (limit == 0) return empty_hits(out);
   VT_TRY(validate_vector(query, n, ix->dim));
   if (ix->n == 0) return empty_hits(out);
-  // Ids inserted out of order since the last ranking: try without re-ranking first.
+  const bool lazy = !ix->ranks_clean;
   const size_t lazy_want = std::min<size_t>(limit, ix->n) + (limit < ix->n ? 1 : 0);
-  // (past ~1/8 of the rows unranked the eventual rebuild would have to sort too many ids at once:
-  // rebuild now, while it is still cheap)
-  const bool lazy = !ix->ranks_clean && !ix->external_ranks && lazy_want <= (size_t)vt::kMaxFusedK &&
-                    ix->unranked <= std::max<size_t>(65536, ix->n / 8) && !std::getenv("VT_EAGER_RANKS");
-  if (lazy) VT_TRY(index_lazy_ranks(ix));
-  else VT_TRY(index_sync_ranks(ix, false));
   uint32_t qnz = 0;
   VT_TRY(upload_query(c, query, n, &qnz));
   ScanJob j{};
@@ -1039,30 +1321,37 @@ int search_locked(vt_flat *ix, const float *query, size_t n, size_t limit, vt_hi
     VT_TRY(run_scan(c, j, lazy_want, entries, true));
     const bool ambiguous = limit < ix->n && entries.size() == lazy_want &&
                            rank_key_of(entries[limit - 1].key) == rank_key_of(entries[limit].key);
-    if (!ambiguous) {
-      if (entries.size() > limit) entries.resize(limit);
-      for (size_t i = 0; i < entries.size();) {
-        size_t e = i + 1;
-        while (e < entries.size() && rank_key_of(entries[e].key) == rank_key_of(entries[i].key)) ++e;
-        if (e - i > 1)
-          std::sort(entries.begin() + i, entries.begin() + e,
-                    [&](const vt::Entry &a, const vt::Entry &b) { return ix->ids[a.row] < ix->ids[b.row]; });
-        i = e;
-      }
-      return make_hits(ix, entries, out);
+    if (ambiguous) return kEscalate;  // a tie across the boundary: only the true id order can cut it
+    if (entries.size() > limit) entries.resize(limit);
+    for (size_t i = 0; i < entries.size();) {
+      size_t e = i + 1;
+      while (e < entries.size() && rank_key_of(entries[e].key) == rank_key_of(entries[i].key)) ++e;
+      if (e - i > 1)
+        std::sort(entries.begin() + i, entries.begin() + e,
+                  [&](const vt::Entry &a, const vt::Entry &b) { return ix->ids[a.row] < ix->ids[b.row]; });
+      i = e;
     }
-    // a tie across the boundary: only the true id order can cut it
-    entries.clear();
-    VT_TRY(index_sync_ranks(ix, false));
-    j.id_rank = ix->dRank.p;
+    return make_hits(ix, entries, out);
   }
   VT_TRY(run_scan(c, j, limit, entries, true));
   return make_hits(ix, entries, out);
 }
 
+// The same for a caller that owns the shard outright (a shard worker, or any caller under
+// the exclusive lock): prepare, run on the primary context, settle a boundary tie.
+int search_owner(Shard *ix, const float *query, size_t n, size_t limit, vt_hits **out) {
+  if (shard_stale(ix, NEED_RANKS, limit)) VT_TRY(shard_prepare(ix, NEED_RANKS, limit));
+  int st = search_ready(ix, ix->ctx, query, n, limit, out);
+  if (st == kEscalate) {
+    VT_TRY(shard_prepare(ix, NEED_STRICT_RANKS, limit));
+    st = search_ready(ix, ix->ctx, query, n, limit, out);
+  }
+  return st;
+}
+
 // Exact f64-cosine scan of the first `d` coordinates of every row (K6b), passes
 // of <= kMaxFusedK until `want` hits are collected.  Query already in c.dQ.
-int run_cosine_scan(Ctx &c, vt_flat *ix, uint32_t d, double qq, size_t want, std::vector<vt::Entry> &out) {
+int run_cosine_scan(Ctx &c, Shard *ix, uint32_t d, double qq, size_t want, std::vector<vt::Entry> &out) {
   const size_t kmax = vt::cosine_scan_lds_bytes(d, vt::kMaxFusedK) ? (size_t)vt::kMaxFusedK : (size_t)vt::kSmallK;
   if (vt::cosine_scan_lds_bytes(d, 1) == 0) return fail(VT_ERR_UNSUPPORTED, "prefix too long for the cosine scan kernel");
   uint64_t lo = 0;
@@ -1160,9 +1449,8 @@ int run_cosine_scan(Ctx &c, vt_flat *ix, uint32_t d, double qq, size_t want, std
 // One vector_top_k stage (search.rs:38-73) on the resident corpus: prefix length
 // `d`, over all rows (`rows` empty) or over the candidate rows of the previous
 // stage; keeps `want` hits.
-int funnel_stage(vt_flat *ix, const float *query, uint32_t d, const std::vector<uint32_t> &rows, bool all_rows,
+int funnel_stage(Shard *ix, Ctx &c, const float *query, uint32_t d, const std::vector<uint32_t> &rows, bool all_rows,
                  size_t want, uint32_t qnz, std::vector<vt::Entry> &out) {
-  Ctx &c = ix->ctx;
   if (!all_rows) {
     VT_TRY(c.dRows.ensure(rows.size()));
     VT_HIP(hipMemcpyAsync(c.dRows.p, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
@@ -1208,9 +1496,8 @@ int funnel_stage(vt_flat *ix, const float *query, uint32_t d, const std::vector<
 // `want` <= kMaxFusedK of them in `dst`.  Nothing is waited for; an overflow
 // flag raised by any stage stays in c.dStatus until a select with `last` moves
 // it into its block.
-int funnel_stage_dev(vt_flat *ix, const float *query, uint32_t d, const ResultBlock *src, uint32_t count,
+int funnel_stage_dev(Shard *ix, Ctx &c, const float *query, uint32_t d, const ResultBlock *src, uint32_t count,
                      uint32_t want, uint32_t qnz, ResultBlock *dst, bool last) {
-  Ctx &c = ix->ctx;
   const uint32_t *gather = src ? &src->e[0].row : nullptr;
   const uint32_t gstride = sizeof(vt::Entry) / sizeof(uint32_t);
   int *status = last ? c.dStatus.p : nullptr;
@@ -1293,7 +1580,7 @@ int funnel_stage_dev(vt_flat *ix, const float *query, uint32_t d, const ResultBl
 }
 
 // True when every stage of a funnel fits one fused pass on the device.
-bool funnel_fits_device(const vt_flat *ix, const size_t *stages, size_t nstages, size_t candidates, size_t limit) {
+bool funnel_fits_device(const Shard *ix, const size_t *stages, size_t nstages, size_t candidates, size_t limit) {
   if (candidates > (size_t)vt::kMaxFusedK || limit > (size_t)vt::kMaxFusedK) return false;
   if (ix->metric == VT_JACCARD && ix->dim >= 4096) return false;
   auto fits = [&](uint32_t d, uint32_t k, bool all_rows) {
@@ -1306,7 +1593,7 @@ bool funnel_fits_device(const vt_flat *ix, const size_t *stages, size_t nstages,
 }
 
 // Candidate rows of one funnel pass (collection.ex:674-691) without the final rerank.
-int funnel_rows(vt_flat *ix, const float *query, const size_t *stages, size_t nstages, size_t candidates,
+int funnel_rows(Shard *ix, Ctx &c, const float *query, const size_t *stages, size_t nstages, size_t candidates,
                 std::vector<uint32_t> &rows) {
   rows.clear();
   bool all_rows = true;
@@ -1314,7 +1601,7 @@ int funnel_rows(vt_flat *ix, const float *query, const size_t *stages, size_t ns
     uint32_t nz = 0;
     for (size_t j = 0; j < stages[i]; ++j) nz += query[j] != 0.0f ? 1u : 0u;
     std::vector<vt::Entry> kept;
-    VT_TRY(funnel_stage(ix, query, (uint32_t)stages[i], rows, all_rows, candidates, nz, kept));
+    VT_TRY(funnel_stage(ix, c, query, (uint32_t)stages[i], rows, all_rows, candidates, nz, kept));
     rows.resize(kept.size());
     for (size_t r = 0; r < kept.size(); ++r) rows[r] = kept[r].row;
     all_rows = false;
@@ -1324,7 +1611,7 @@ int funnel_rows(vt_flat *ix, const float *query, const size_t *stages, size_t ns
 }
 
 // Sign bits of every stored row in K4's layout, built on first use.
-int index_ensure_bits(vt_flat *ix) {
+int index_ensure_bits(Shard *ix) {
   Ctx &c = ix->ctx;
   const uint32_t d = (uint32_t)ix->dim, words = (d + 63) / 64;
   // compress_sign_bits of every stored row (collection.ex:926): kept in HBM
@@ -1347,10 +1634,8 @@ int index_ensure_bits(vt_flat *ix) {
 }
 
 // binary_top_k candidates (search.rs:76-92) of the query already in c.dQ.
-int quantized_rows(vt_flat *ix, size_t candidates, std::vector<uint32_t> &rows) {
-  Ctx &c = ix->ctx;
+int quantized_rows(Shard *ix, Ctx &c, size_t candidates, std::vector<uint32_t> &rows) {
   const uint32_t d = (uint32_t)ix->dim, words = (d + 63) / 64;
-  VT_TRY(index_ensure_bits(ix));
   VT_TRY(c.dQbits.ensure(words));
   VT_HIP(vt::launch_sign_pack(c.dQ.p, vt::padded_dim(d), 1, d, c.dQbits.p, 0, c.stream));
   std::vector<vt::Entry> cand;
@@ -1360,12 +1645,47 @@ int quantized_rows(vt_flat *ix, size_t candidates, std::vector<uint32_t> &rows) 
   return VT_OK;
 }
 
+// Per-row squared norms and their maximum (the error margin of the batched path), brought
+// up to date: all rows on first use, afterwards only the rows mutated since.
+int index_ensure_norms(Shard *ix) {
+  Ctx &c = ix->ctx;
+  const uint32_t d = (uint32_t)ix->dim, n = ix->n;
+  VT_TRY(c.dBNorm.ensure(1));
+  if (ix->max_sqnorm >= 0.0 && ix->dXnorm2.count >= std::max<uint32_t>(ix->cap, n) && !ix->norm_dirty.empty()) {
+    // norms of the rows mutated since the last batch; the maximum can only be kept or raised
+    // (a stale larger bound only widens the acceptance margin)
+    uint32_t count = 0;
+    VT_TRY(upload_row_list(ix, ix->norm_dirty, &count));
+    unsigned long long bits = 0;
+    std::memcpy(&bits, &ix->max_sqnorm, sizeof(double));
+    VT_HIP(hipMemcpyAsync(c.dBNorm.p, &bits, sizeof(bits), hipMemcpyHostToDevice, c.stream));
+    VT_HIP(vt::launch_row_sqnorms_rows(ix->dX, ix->ld, c.dRankPairs.p, count, d, ix->dXnorm2.p, c.dBNorm.p, c.stream));
+    VT_HIP(hipMemcpyAsync(&bits, c.dBNorm.p, sizeof(bits), hipMemcpyDeviceToHost, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    std::memcpy(&ix->max_sqnorm, &bits, sizeof(double));
+    ix->norm_dirty.clear();
+  } else if (ix->max_sqnorm >= 0.0 && ix->dXnorm2.count < std::max<uint32_t>(ix->cap, n)) {
+    ix->max_sqnorm = -1.0;  // the slab grew past the norm column
+  }
+  if (ix->max_sqnorm < 0.0) {
+    ix->norm_dirty.clear();
+    unsigned long long bits = 0;
+    VT_TRY(ix->dXnorm2.ensure(std::max<uint32_t>(ix->cap, n)));
+    VT_HIP(hipMemsetAsync(c.dBNorm.p, 0, sizeof(unsigned long long), c.stream));
+    VT_HIP(vt::launch_row_sqnorms(ix->dX, ix->ld, n, d, ix->dXnorm2.p, c.dBNorm.p, c.stream));
+    VT_HIP(hipMemcpyAsync(&bits, c.dBNorm.p, sizeof(bits), hipMemcpyDeviceToHost, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    std::memcpy(&ix->max_sqnorm, &bits, sizeof(double));
+  }
+
+  return VT_OK;
+}
+
 // ---------------------------------------------------------------- K2 host side
 // One group of <= 256 queries through the matrix cores.  `done[i]` is set for
 // every query whose exact top-k was proven complete; the others are left for
 // the single-query path.
-int batch_group(vt_flat *ix, const float *queries, size_t nq, size_t limit, vt_hits **out, std::vector<char> &done) {
-  Ctx &c = ix->ctx;
+int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit, vt_hits **out, std::vector<char> &done) {
   const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
   const uint32_t k = (uint32_t)std::min<size_t>(limit, n);
   uint32_t nq_pad = 32;
@@ -1401,7 +1721,6 @@ int batch_group(vt_flat *ix, const float *queries, size_t nq, size_t limit, vt_h
   VT_TRY(c.hBOut.ensure((size_t)nq_pad * k));
   VT_TRY(c.dBOutCount.ensure(nq_pad));
   VT_TRY(c.hBOutCount.ensure(nq_pad));
-  VT_TRY(c.dBNorm.ensure(1));
   VT_TRY(c.dPartKeys.ensure((size_t)nq_pad * kBlocksPerQuery * k));
   VT_TRY(c.dPartPay.ensure((size_t)nq_pad * kBlocksPerQuery * k));
 
@@ -1414,33 +1733,6 @@ int batch_group(vt_flat *ix, const float *queries, size_t nq, size_t limit, vt_h
     qnorm[i] = std::sqrt(s);
   }
   VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, c.stream));
-  if (ix->max_sqnorm >= 0.0 && ix->dXnorm2.count >= std::max<uint32_t>(ix->cap, n) && !ix->norm_dirty.empty()) {
-    // norms of the rows mutated since the last batch; the maximum can only be kept or raised
-    // (a stale larger bound only widens the acceptance margin)
-    uint32_t count = 0;
-    VT_TRY(upload_row_list(ix, ix->norm_dirty, &count));
-    unsigned long long bits = 0;
-    std::memcpy(&bits, &ix->max_sqnorm, sizeof(double));
-    VT_HIP(hipMemcpyAsync(c.dBNorm.p, &bits, sizeof(bits), hipMemcpyHostToDevice, c.stream));
-    VT_HIP(vt::launch_row_sqnorms_rows(ix->dX, ix->ld, c.dRankPairs.p, count, d, ix->dXnorm2.p, c.dBNorm.p, c.stream));
-    VT_HIP(hipMemcpyAsync(&bits, c.dBNorm.p, sizeof(bits), hipMemcpyDeviceToHost, c.stream));
-    VT_HIP(hipStreamSynchronize(c.stream));
-    std::memcpy(&ix->max_sqnorm, &bits, sizeof(double));
-    ix->norm_dirty.clear();
-  } else if (ix->max_sqnorm >= 0.0 && ix->dXnorm2.count < std::max<uint32_t>(ix->cap, n)) {
-    ix->max_sqnorm = -1.0;  // the slab grew past the norm column
-  }
-  if (ix->max_sqnorm < 0.0) {
-    ix->norm_dirty.clear();
-    unsigned long long bits = 0;
-    VT_TRY(ix->dXnorm2.ensure(std::max<uint32_t>(ix->cap, n)));
-    VT_HIP(hipMemsetAsync(c.dBNorm.p, 0, sizeof(unsigned long long), c.stream));
-    VT_HIP(vt::launch_row_sqnorms(ix->dX, ix->ld, n, d, ix->dXnorm2.p, c.dBNorm.p, c.stream));
-    VT_HIP(hipMemcpyAsync(&bits, c.dBNorm.p, sizeof(bits), hipMemcpyDeviceToHost, c.stream));
-    VT_HIP(hipStreamSynchronize(c.stream));
-    std::memcpy(&ix->max_sqnorm, &bits, sizeof(double));
-  }
-
   vt::BatchScoreArgs a{};
   a.X = ix->dX;
   a.stride = ix->ld;
@@ -1547,7 +1839,28 @@ int batch_group(vt_flat *ix, const float *queries, size_t nq, size_t limit, vt_h
   return VT_OK;
 }
 
-int batch_locked(vt_flat *ix, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
+// True when a batch of nq queries takes the shared MFMA pass (and so needs the row norms).
+bool batch_uses_mfma(const Shard *ix, size_t nq, size_t limit) {
+  const bool mfma_metric = ix->metric == VT_COSINE || ix->metric == VT_INNER_PRODUCT ||
+                           ix->metric == VT_NEG_INNER_PRODUCT || ix->metric == VT_L2 || ix->metric == VT_L2_SQUARED;
+  // one shared pass over the corpus costs about 1.3 single scans (HBM-bound below 33 queries),
+  // so it pays from two queries on
+  bool use_mfma = mfma_metric && nq >= 2 && limit <= (size_t)vt::kMaxFusedK && limit > 0 && ix->n >= 4096 &&
+                  std::getenv("VT_BATCH_NO_MFMA") == nullptr;
+  if (use_mfma && !std::getenv("VT_FORCE_BATCH_MFMA")) {  // (tests force the shared pass on small corpora)
+    // nq single scans against one shared pass (HBM-bound below ~33 queries, then MFMA-bound)
+    const double bytes = (double)ix->n * ix->ld * 4.0;
+    double nq_pad = 32;
+    while (nq_pad < (double)std::min<size_t>(nq, 256)) nq_pad *= 2;
+    const double groups = std::ceil((double)nq / 256.0);
+    const double t_pass = std::max(1.3 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kBatchFlopsPerS);
+    use_mfma = (double)nq * scan_seconds(bytes) > groups * (kBatchFixedS + t_pass);
+  }
+  return use_mfma;
+}
+
+// Rank column strictly current, norms current when batch_uses_mfma (shard_prepare).
+int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
   // every query is validated like flat_search would (flat.rs:97-101), in order
   if (limit == 0) {
     for (size_t i = 0; i < nq; ++i) VT_TRY(empty_hits(&out[i]));
@@ -1559,477 +1872,32 @@ int batch_locked(vt_flat *ix, const float *queries, size_t nq, size_t d, size_t 
     return VT_OK;
   }
   std::vector<char> done(nq, 0);
-  const bool mfma_metric = ix->metric == VT_COSINE || ix->metric == VT_INNER_PRODUCT ||
-                           ix->metric == VT_NEG_INNER_PRODUCT || ix->metric == VT_L2 || ix->metric == VT_L2_SQUARED;
-  // one shared pass over the corpus costs about 1.3 single scans (HBM-bound below 33 queries),
-  // so it pays from two queries on
-  bool use_mfma = mfma_metric && nq >= 2 && limit <= (size_t)vt::kMaxFusedK && ix->n >= 4096 &&
-                  std::getenv("VT_BATCH_NO_MFMA") == nullptr;
-  if (use_mfma && !std::getenv("VT_FORCE_BATCH_MFMA")) {  // (tests force the shared pass on small corpora)
-    // nq single scans against one shared pass (HBM-bound below ~33 queries, then MFMA-bound)
-    const double bytes = (double)ix->n * ix->ld * 4.0;
-    double nq_pad = 32;
-    while (nq_pad < (double)std::min<size_t>(nq, 256)) nq_pad *= 2;
-    const double groups = std::ceil((double)nq / 256.0);
-    const double t_pass = std::max(1.3 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kBatchFlopsPerS);
-    use_mfma = (double)nq * scan_seconds(bytes) > groups * (kBatchFixedS + t_pass);
-  }
+  const bool use_mfma = batch_uses_mfma(ix, nq, limit);
   if (use_mfma) {
-    VT_TRY(index_sync_ranks(ix, false));
     for (size_t g0 = 0; g0 < nq; g0 += 256) {
       const size_t gn = std::min<size_t>(256, nq - g0);
       if (gn < 2) continue;  // a lone trailing query takes the single-query path below
       std::vector<char> gdone(gn, 0);
-      VT_TRY(batch_group(ix, queries + g0 * d, gn, limit, out + g0, gdone));
+      VT_TRY(batch_group(ix, c, queries + g0 * d, gn, limit, out + g0, gdone));
       for (size_t i = 0; i < gn; ++i) done[g0 + i] = gdone[i];
     }
   }
   for (size_t i = 0; i < nq; ++i) {
     if (done[i]) continue;
-    ix->ctx.prof.batch_fallbacks += use_mfma ? 1 : 0;
-    VT_TRY(search_locked(ix, queries + i * d, d, limit, &out[i]));
+    c.prof.batch_fallbacks += use_mfma ? 1 : 0;
+    VT_TRY(search_ready(ix, c, queries + i * d, d, limit, &out[i]));
   }
   return VT_OK;
 }
 
-// Per-device context for the stateless helpers.
-std::mutex g_ctx_mu;
-std::unordered_map<int, std::unique_ptr<Ctx>> g_ctx;
-int stateless_ctx(int device, Ctx **out) {
-  std::lock_guard<std::mutex> g(g_ctx_mu);
-  auto it = g_ctx.find(device);
-  if (it == g_ctx.end()) {
-    auto c = std::make_unique<Ctx>();
-    VT_TRY(c->init(device));
-    it = g_ctx.emplace(device, std::move(c)).first;
-  }
-  *out = it->second.get();
-  return (*out)->bind();
-}
-
-// id_rank for an ad-hoc batch of ids (ties between equal ids: input order).
-void ranks_for_ids(const char *ids, const size_t *id_off, size_t count, std::vector<uint32_t> &rank) {
-  std::vector<uint32_t> order(count);
-  for (size_t i = 0; i < count; ++i) order[i] = (uint32_t)i;
-  auto view = [&](uint32_t i) { return std::pair<const char *, size_t>(ids + id_off[i], id_off[i + 1] - id_off[i]); };
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-    auto x = view(a), y = view(b);
-    const size_t m = std::min(x.second, y.second);
-    const int c = m ? std::memcmp(x.first, y.first, m) : 0;
-    if (c) return c < 0;
-    return x.second < y.second;
-  });
-  rank.resize(count);
-  for (size_t i = 0; i < count; ++i) rank[order[i]] = (uint32_t)i;
-}
-
-int hits_from_batch(const char *ids, const size_t *id_off, const std::vector<vt::Entry> &entries, vt_hits **out) {
-  auto h = std::make_unique<vt_hits>();
-  for (const auto &e : entries) {
-    h->ids.emplace_back(ids + id_off[e.row], id_off[e.row + 1] - id_off[e.row]);
-    h->raw.push_back(e.raw);
-    h->rank_key.push_back(rank_key_of(e.key));
-  }
-  *out = h.release();
-  return VT_OK;
-}
-
-}  // namespace
-
-// =============================================================== C ABI
-extern "C" {
-
-const char *vt_strerror(int status) {
-  switch (status) {
-    case VT_OK: return "ok";
-    case VT_ERR_EMPTY: return "vector must not be empty";
-    case VT_ERR_DIMENSION: return "dimension mismatch";
-    case VT_ERR_NON_FINITE: return "vector contains a non-finite value";
-    case VT_ERR_OVERFLOW: return "metric overflow";
-    case VT_ERR_UNKNOWN_METRIC: return "unknown metric";
-    case VT_ERR_PREFIX: return "invalid prefix dimensions";
-    case VT_ERR_DIMS_POSITIVE: return "dimensions must be positive";
-    case VT_ERR_NOMEM: return "out of memory";
-    case VT_ERR_DEVICE: return "device error";
-    case VT_ERR_UNSUPPORTED: return "unsupported on device";
-    case VT_ERR_ARGUMENT: return "bad argument";
-    default: return "unknown status";
-  }
-}
-
-const char *vt_last_error(void) { return g_last_error.c_str(); }
-int vt_abi_version(void) { return VT_ABI_VERSION; }
-
-int vt_device_count(void) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-  return n;
-}
-
-size_t vt_hits_len(const vt_hits *h) { return h ? h->ids.size() : 0; }
-const char *vt_hits_id(const vt_hits *h, size_t i, size_t *len) {
-  *len = h->ids[i].size();
-  return h->ids[i].data();
-}
-float vt_hits_raw(const vt_hits *h, size_t i) { return h->raw[i]; }
-uint32_t vt_hits_rank_key(const vt_hits *h, size_t i) { return h->rank_key[i]; }
-size_t vt_hits_pack(const vt_hits *h, void *records, size_t cap) {
-  if (!h || !records) return 0;
-  const size_t n = std::min(cap, h->ids.size());
-  unsigned char *out = static_cast<unsigned char *>(records);
-  for (size_t i = 0; i < n; ++i, out += VT_HIT_RECORD_BYTES) {
-    const uint32_t len = (uint32_t)h->ids[i].size();
-    std::memset(out, 0, VT_HIT_RECORD_BYTES);
-    std::memcpy(out, &h->rank_key[i], 4);
-    std::memcpy(out + 4, &h->raw[i], 4);
-    std::memcpy(out + 8, &len, 4);
-    std::memcpy(out + 12, h->ids[i].data(), std::min<size_t>(len, VT_HIT_RECORD_ID_BYTES));
-  }
-  return n;
-}
-size_t vt_hits_id_bytes(const vt_hits *h) {
-  size_t total = 0;
-  if (h)
-    for (const auto &id : h->ids) total += id.size();
-  return total;
-}
-
-void vt_hits_export(const vt_hits *h, char *ids, size_t *id_off, float *raw, uint32_t *rank_key) {
-  if (!h) return;
-  size_t pos = 0;
-  for (size_t i = 0; i < h->ids.size(); ++i) {
-    if (id_off) id_off[i] = pos;
-    if (ids) std::memcpy(ids + pos, h->ids[i].data(), h->ids[i].size());
-    pos += h->ids[i].size();
-    if (raw) raw[i] = h->raw[i];
-    if (rank_key) rank_key[i] = h->rank_key[i];
-  }
-  if (id_off) id_off[h->ids.size()] = pos;
-}
-
-void vt_hits_free(vt_hits *h) { delete h; }
-
-int vt_flat_new(int metric_code, int device, vt_flat **out) {
-  return guarded([&]() -> int {
-  if (!out) return VT_ERR_ARGUMENT;
-  *out = nullptr;
-  if (metric_code < VT_L2 || metric_code > VT_JACCARD) return VT_ERR_UNKNOWN_METRIC;
-  auto ix = std::make_unique<vt_flat>();
-  ix->metric = metric_code;
-  VT_TRY(ix->ctx.init(device));
-  *out = ix.release();
-  return VT_OK;
-  });
-}
-
-void vt_flat_free(vt_flat *ix) { delete ix; }
-
-size_t vt_flat_len(const vt_flat *ix) { return ix ? ix->n : 0; }
-long vt_flat_dimension(const vt_flat *ix) { return ix ? ix->dim : -1; }
-int vt_flat_metric(const vt_flat *ix) { return ix ? ix->metric : -1; }
-
-int vt_set_default_reduce_order(int order) {
-  if (order < VT_ORDER_PAIR || order > VT_ORDER_SEQ) return VT_ERR_ARGUMENT;
-  g_default_order = order;
-  return VT_OK;
-}
-
-int vt_flat_set_reduce_order(vt_flat *ix, int order) {
-  return guarded([&]() -> int {
-  if (!ix || order < VT_ORDER_PAIR || order > VT_ORDER_SEQ) return VT_ERR_ARGUMENT;
-  std::lock_guard<std::mutex> g(ix->mu);
-  ix->order = order;
-  return VT_OK;
-  });
-}
-
-int vt_flat_insert(vt_flat *ix, const char *id, size_t id_len, const float *vector, size_t n) {
-  return guarded([&]() -> int {
-  if (!ix || (!id && id_len) || (!vector && n)) return VT_ERR_ARGUMENT;
-  std::lock_guard<std::mutex> g(ix->mu);
-  VT_TRY(ix->ctx.bind());
-  // flat.rs:59-66
-  VT_TRY(validate_vector(vector, n, ix->dim));
-  if (ix->dim < 0) VT_TRY(index_set_dim(ix, n));
-  const size_t id_off[2] = {0, id_len};
-  const size_t val_off[2] = {0, n};
-  RowSource src;
-  src.host = vector;
-  src.off = val_off;
-  return index_store_rows(ix, 1, id ? id : "", id_off, src);
-  });
-}
-
-int vt_flat_insert_many(vt_flat *ix, size_t count, const char *ids, const size_t *id_off, const float *values,
-                        const size_t *value_off) {
-  return guarded([&]() -> int {
-  if (!ix || (count && (!id_off || !value_off))) return VT_ERR_ARGUMENT;
-  std::lock_guard<std::mutex> g(ix->mu);
-  VT_TRY(ix->ctx.bind());
-  // flat.rs:69-85: expected = own dimension, else the first row's length;
-  // every row is validated before anything is stored.
-  long expected = ix->dim;
-  if (expected < 0 && count > 0) expected = (long)(value_off[1] - value_off[0]);
-  for (size_t i = 0; i < count; ++i)
-    VT_TRY(validate_vector(values + value_off[i], value_off[i + 1] - value_off[i], expected));
-  if (count == 0) return VT_OK;
-  if (ix->dim < 0) VT_TRY(index_set_dim(ix, (size_t)expected));
-  RowSource src;
-  src.host = values;
-  src.off = value_off;
-  return index_store_rows(ix, count, ids, id_off, src);
-  });
-}
-
-int vt_flat_load_matrix(vt_flat *ix, size_t count, size_t d, const char *ids, const size_t *id_off, const float *rows) {
-  return guarded([&]() -> int {
-  if (!ix || (count && (!id_off || !rows))) return VT_ERR_ARGUMENT;
-  std::lock_guard<std::mutex> g(ix->mu);
-  VT_TRY(ix->ctx.bind());
-  long expected = ix->dim;
-  if (expected < 0 && count > 0) expected = (long)d;
-  VT_TRY(validate_matrix(rows, count, d, expected));
-  if (count == 0) return VT_OK;
-  if (ix->dim < 0) VT_TRY(index_set_dim(ix, d));
-  RowSource src;
-  src.host = rows;
-  src.d = d;
-  return index_store_rows(ix, count, ids, id_off, src);
-  });
-}
-
-int vt_flat_load_device_matrix(vt_flat *ix, size_t count, size_t d, const char *ids, const size_t *id_off,
-                               const void *device_rows) {
-  return guarded([&]() -> int {
-  if (!ix || (count && (!id_off || !device_rows))) return VT_ERR_ARGUMENT;
-  std::lock_guard<std::mutex> g(ix->mu);
-  Ctx &c = ix->ctx;
-  VT_TRY(c.bind());
-  if (count == 0) return VT_OK;
-  if (count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
-  long expected = ix->dim < 0 ? (long)d : ix->dim;
-  if (d == 0) return VT_ERR_EMPTY;
-  if ((long)d != expected) return VT_ERR_DIMENSION;
-  const float *rows = static_cast<const float *>(device_rows);
-  VT_HIP(hipDeviceSynchronize());  // the producer may have used another stream
-  int non_finite = 0;
-  VT_HIP(hipMemsetAsync(c.dFlag.p, 0, sizeof(int), c.stream));
-  VT_HIP(vt::launch_check_finite(rows, d, (uint32_t)count, (uint32_t)d, c.dFlag.p, c.stream));
-  VT_HIP(hipMemcpyAsync(&non_finite, c.dFlag.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-  VT_HIP(hipStreamSynchronize(c.stream));
-  if (non_finite != 0) return VT_ERR_NON_FINITE;
-  if (ix->dim < 0) VT_TRY(index_set_dim(ix, d));
-  RowSource src;
-  src.device = rows;
-  src.d = d;
-  return index_store_rows(ix, count, ids, id_off, src);
-  });
-}
-
-int vt_flat_delete(vt_flat *ix, const char *id, size_t id_len) {
-  return guarded([&]() -> int {
-  if (!ix || (!id && id_len)) return VT_ERR_ARGUMENT;
-  std::lock_guard<std::mutex> g(ix->mu);
-  Ctx &c = ix->ctx;
-  VT_TRY(c.bind());
-  // flat.rs:88-93
-  auto it = ix->row_of.find(std::string(id ? id : "", id_len));
-  if (it != ix->row_of.end()) {
-    const uint32_t r = it->second, last = ix->n - 1;
-    if (ix->rank_host[r] == kUnranked && ix->unranked) ix->unranked -= 1;
-    ix->row_of.erase(it);
-    if (r != last) {
-      // swap-delete: the last row moves into the hole and keeps its rank
-      VT_HIP(hipMemcpyAsync(ix->dX + (size_t)r * ix->ld, ix->dX + (size_t)last * ix->ld, (size_t)ix->ld * sizeof(float),
-                            hipMemcpyDeviceToDevice, c.stream));
-      ix->ids[r] = std::move(ix->ids[last]);
-      ix->row_of[ix->ids[r]] = r;
-      ix->rank_host[r] = ix->rank_host[last];
-      if (ix->ranks_clean && ix->dRank.p)
-        VT_HIP(hipMemcpyAsync(ix->dRank.p + r, ix->dRank.p + last, sizeof(uint32_t), hipMemcpyDeviceToDevice, c.stream));
-      if (!ix->ranks_clean) {
-        ix->rank_dirty.push_back(r);
-        if (ix->rank_dirty.size() > kMaxDirtyRanks) ix->rank_dirty_all = true;
-      }
-    }
-    VT_HIP(hipMemsetAsync(ix->dX + (size_t)last * ix->ld, 0, (size_t)ix->ld * sizeof(float), c.stream));
-    VT_HIP(hipStreamSynchronize(c.stream));
-    ix->ids.pop_back();
-    ix->rank_host.pop_back();
-    ix->n -= 1;
-    if (r != last) index_touch_row(ix, r);  // row r now holds what was the last row
-  }
-  if (ix->n == 0) {
-    ix->dim = -1;
-    ix->rank_dirty.clear();
-    ix->rank_dirty_all = false;
-    ix->unranked = 0;
-    ix->ranks_clean = true;
-    ix->max_id.clear();
-    ix->max_rank = 0;
-  }
-  return VT_OK;
-  });
-}
-
-int vt_flat_search(vt_flat *ix, const float *query, size_t n, size_t limit, vt_hits **out) {
-  return guarded([&]() -> int {
-  if (!ix || !out || (!query && n)) return VT_ERR_ARGUMENT;
-  *out = nullptr;
-  std::lock_guard<std::mutex> g(ix->mu);
-  VT_TRY(ix->ctx.bind());
-  return search_locked(ix, query, n, limit, out);
-  });
-}
-
-int vt_rank_ids(const char *ids, const size_t *id_off, size_t count, uint32_t *out_rank) {
-  return guarded([&]() -> int {
-  if (count && (!id_off || !out_rank)) return VT_ERR_ARGUMENT;
-  if (count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 ids");
-  std::vector<uint32_t> order(count);
-  for (size_t i = 0; i < count; ++i) order[i] = (uint32_t)i;
-  auto less = [&](uint32_t a, uint32_t b) {
-    const size_t la = id_off[a + 1] - id_off[a], lb = id_off[b + 1] - id_off[b];
-    const size_t m = std::min(la, lb);
-    const int c = m ? std::memcmp(ids + id_off[a], ids + id_off[b], m) : 0;
-    if (c) return c < 0;
-    if (la != lb) return la < lb;
-    return a < b;  // equal ids: input order
-  };
-  parallel_sort(order, less);
-  for (size_t i = 0; i < count; ++i) out_rank[order[i]] = (uint32_t)i;
-  return VT_OK;
-  });
-}
-
-int vt_flat_set_id_ranks(vt_flat *ix, const uint32_t *ranks, size_t count) {
-  return guarded([&]() -> int {
-  if (!ix || (count && !ranks)) return VT_ERR_ARGUMENT;
-  std::lock_guard<std::mutex> g(ix->mu);
-  VT_TRY(ix->ctx.bind());
-  if (count != ix->n) return VT_ERR_DIMENSION;
-  ix->rank_host.assign(ranks, ranks + count);
-  ix->unranked = 0;
-  ix->ranks_clean = true;
-  ix->external_ranks = true;
-  ix->max_rank = kUnranked - 1;  // an appended id can no longer extend the ranks in place
-  return index_sync_ranks(ix, true);
-  });
-}
-
-void *vt_flat_stream(vt_flat *ix) { return ix ? static_cast<void *>(ix->ctx.stream) : nullptr; }
-
-int vt_flat_search_begin(vt_flat *ix, const float *query, size_t n, size_t limit, void *device_block) {
-  return guarded([&]() -> int {
-  if (!ix || !device_block || (!query && n)) return VT_ERR_ARGUMENT;
-  std::lock_guard<std::mutex> g(ix->mu);
-  Ctx &c = ix->ctx;
-  VT_TRY(c.bind());
-  if (limit == 0 || limit > (size_t)vt::kMaxFusedK) return fail(VT_ERR_UNSUPPORTED, "search_begin needs 1 <= limit <= 256");
-  VT_TRY(validate_vector(query, n, ix->dim));
-  if (ix->n == 0) {
-    VT_HIP(hipMemsetAsync(device_block, 0, 16, c.stream));  // count = 0
-    return VT_OK;
-  }
-  VT_TRY(index_sync_ranks(ix, false));
-  uint32_t qnz = 0;
-  VT_TRY(upload_query(c, query, n, &qnz));
-  const uint32_t d = (uint32_t)ix->dim, k = (uint32_t)limit;
-  if (vt::scan_lds_bytes(d, k) == 0) return fail(VT_ERR_UNSUPPORTED, "dimension/limit exceed the scan kernel's LDS");
-  const uint32_t tile_rows = vt::scan_tile_rows(ix->n, d, c.resident_waves());
-  const uint32_t blocks = c.grid_for((ix->n + tile_rows - 1) / tile_rows, vt::scan_lds_bytes(d, k));
-  VT_TRY(c.dPartKeys.ensure((size_t)blocks * k));
-  VT_TRY(c.dPartPay.ensure((size_t)blocks * k));
-  vt::ScanArgs a{};
-  a.X = ix->dX;
-  a.stride = ix->ld;
-  a.q = c.dQ.p;
-  a.id_rank = ix->dRank.p;
-  a.n = ix->n;
-  a.d = d;
-  a.metric = ix->metric;
-  a.order = ix->order;
-  a.k = k;
-  a.q_nonzero = qnz;
-  a.tile_rows = tile_rows;
-  a.part_keys = c.dPartKeys.p;
-  a.part_pay = c.dPartPay.p;
-  a.status = c.dStatus.p;
-  if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
-  VT_HIP(vt::launch_scan(a, blocks, c.stream));
-  if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
-  c.begin_rows = ix->n;
-  c.begin_dim = d;
-  VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, blocks * k, k, 0, 0, c.dStatus.p,
-                           static_cast<ResultBlock *>(device_block), c.dSelKeys.p, c.dSelPay.p, c.stream));
-  return VT_OK;  // nothing waited for: the caller's collective queues behind these kernels
-  });
-}
-
-int vt_flat_merge_gathered(vt_flat *ix, const void *device_blocks, size_t world, size_t limit, size_t block_bytes,
-                           uint64_t *keys, uint32_t *rows, float *raw, uint32_t *shard, size_t *count) {
-  return guarded([&]() -> int {
-  if (!ix || !device_blocks || !keys || !rows || !raw || !shard || !count) return VT_ERR_ARGUMENT;
-  std::lock_guard<std::mutex> g(ix->mu);
-  Ctx &c = ix->ctx;
-  VT_TRY(c.bind());
-  if (limit == 0 || limit > (size_t)vt::kMaxFusedK || world == 0) return VT_ERR_ARGUMENT;
-  VT_HIP(vt::launch_merge_blocks(device_blocks, (uint32_t)world, (uint32_t)limit, (uint32_t)block_bytes, c.dResMapped,
-                                 c.dShardMapped, c.stream));
-  VT_HIP(hipStreamSynchronize(c.stream));
-  if (c.profiling && c.begin_rows) {
-    float ms = 0.f;
-    VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
-    c.prof.scan_launches += 1;
-    c.prof.scan_ms += ms;
-    c.prof.scan_rows += c.begin_rows;
-    c.prof.scan_bytes += (uint64_t)c.begin_rows * c.begin_dim * 4;
-    c.begin_rows = 0;
-  }
-  if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
-  const uint32_t got = c.hRes.p->count;
-  for (uint32_t i = 0; i < got; ++i) {
-    keys[i] = c.hRes.p->e[i].key;
-    rows[i] = c.hRes.p->e[i].row;
-    raw[i] = c.hRes.p->e[i].raw;
-    shard[i] = c.hShard.p[i];
-  }
-  *count = got;
-  return VT_OK;
-  });
-}
-
-int vt_flat_search_batch(vt_flat *ix, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
-  return guarded([&]() -> int {
-  if (!ix || !out || (nq && !queries && d)) return VT_ERR_ARGUMENT;
-  for (size_t i = 0; i < nq; ++i) out[i] = nullptr;
-  std::lock_guard<std::mutex> g(ix->mu);
-  VT_TRY(ix->ctx.bind());
-  int st = batch_locked(ix, queries, nq, d, limit, out);
-  if (st != VT_OK)
-    for (size_t i = 0; i < nq; ++i) {
-      delete out[i];
-      out[i] = nullptr;
-    }
-  return st;
-  });
-}
-
-int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out) {
-  return guarded([&]() -> int {
-  if (!ix || !out || (!query && n)) return VT_ERR_ARGUMENT;
-  *out = nullptr;
-  std::lock_guard<std::mutex> g(ix->mu);
-  Ctx &c = ix->ctx;
-  VT_TRY(c.bind());
+// collection.ex:276-295 on a shard whose ranks (strict) and sign bits are current.
+int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out) {
   // collection.ex:276-295: prepare_query validates the query against the
   // collection's dimension; an empty store yields no candidates.
   VT_TRY(validate_vector(query, n, ix->dim));
   if (ix->n == 0 || candidates == 0 || limit == 0) return empty_hits(out);
   const uint32_t d = (uint32_t)ix->dim;
   const uint32_t words = (d + 63) / 64;
-  VT_TRY(index_sync_ranks(ix, false));
-  VT_TRY(index_ensure_bits(ix));
   uint32_t qnz = 0;
   VT_TRY(upload_query(c, query, n, &qnz));
   VT_TRY(c.dQbits.ensure(words));
@@ -2189,17 +2057,12 @@ int vt_flat_quantized_search(vt_flat *ix, const float *query, size_t n, size_t c
   int rc = run(hist_ok);
   if (rc == kRetryInternal) rc = run(false);  // more ties at the k-th distance than the list holds
   return rc;
-  });
 }
 
-int vt_flat_funnel_search(vt_flat *ix, const float *query, size_t n, const size_t *stages, size_t nstages,
-                          size_t candidates, size_t limit, vt_hits **out) {
-  return guarded([&]() -> int {
-  if (!ix || !out || (!query && n) || (nstages && !stages)) return VT_ERR_ARGUMENT;
-  *out = nullptr;
-  std::lock_guard<std::mutex> g(ix->mu);
-  Ctx &c = ix->ctx;
-  VT_TRY(c.bind());
+
+// collection.ex:245-260 on a shard whose ranks are strictly current.
+int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *stages, size_t nstages,
+                 size_t candidates, size_t limit, vt_hits **out) {
   // collection.ex:245-260: prepare_query validates the query against the
   // collection; stages are prefix lengths 1..dimensions (collection.ex:905-913)
   VT_TRY(validate_vector(query, n, ix->dim));
@@ -2207,7 +2070,6 @@ int vt_flat_funnel_search(vt_flat *ix, const float *query, size_t n, const size_
   for (size_t i = 0; i < nstages; ++i)
     if (stages[i] == 0 || stages[i] > n) return VT_ERR_PREFIX;
   if (ix->n == 0 || candidates == 0 || limit == 0) return empty_hits(out);
-  VT_TRY(index_sync_ranks(ix, false));
   uint32_t qnz_full = 0;
   VT_TRY(upload_query(c, query, n, &qnz_full));
   std::vector<vt::Entry> entries;
@@ -2222,13 +2084,13 @@ int vt_flat_funnel_search(vt_flat *ix, const float *query, size_t n, const size_
       for (size_t j = 0; j < stages[i]; ++j) nz += query[j] != 0.0f ? 1u : 0u;
       const uint32_t want = (uint32_t)std::min<size_t>(candidates, count);
       ResultBlock *dst = c.dStage.p + (i & 1);
-      VT_TRY(funnel_stage_dev(ix, query, (uint32_t)stages[i], src, count, want, nz, dst, false));
+      VT_TRY(funnel_stage_dev(ix, c, query, (uint32_t)stages[i], src, count, want, nz, dst, false));
       src = dst;
       count = want;
     }
     // exact_rerank on the full vectors (collection.ex:821-851)
     const uint32_t want = (uint32_t)std::min<size_t>(limit, count);
-    VT_TRY(funnel_stage_dev(ix, query, (uint32_t)ix->dim, src, count, want, qnz_full, c.dResMapped, true));
+    VT_TRY(funnel_stage_dev(ix, c, query, (uint32_t)ix->dim, src, count, want, qnz_full, c.dResMapped, true));
     VT_HIP(hipStreamSynchronize(c.stream));
     VT_TRY(c.settle_prefix_profile());
     if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
@@ -2236,22 +2098,18 @@ int vt_flat_funnel_search(vt_flat *ix, const float *query, size_t n, const size_
     return make_hits(ix, entries, out);
   }
   std::vector<uint32_t> rows;
-  VT_TRY(funnel_rows(ix, query, stages, nstages, candidates, rows));
+  VT_TRY(funnel_rows(ix, c, query, stages, nstages, candidates, rows));
   if (rows.empty()) return empty_hits(out);
   // exact_rerank on the full vectors (collection.ex:821-851)
-  VT_TRY(funnel_stage(ix, query, (uint32_t)ix->dim, rows, false, limit, qnz_full, entries));
+  VT_TRY(funnel_stage(ix, c, query, (uint32_t)ix->dim, rows, false, limit, qnz_full, entries));
   return make_hits(ix, entries, out);
-  });
 }
 
-int vt_flat_hybrid_search(vt_flat *ix, const float *query, size_t n, const int *kinds, const size_t *candidates,
-                          const size_t *stage_off, const size_t *stages, size_t ngen, size_t limit, vt_hits **out) {
-  return guarded([&]() -> int {
-  if (!ix || !out || (!query && n) || (ngen && (!kinds || !candidates || !stage_off))) return VT_ERR_ARGUMENT;
-  *out = nullptr;
-  std::lock_guard<std::mutex> g(ix->mu);
-  Ctx &c = ix->ctx;
-  VT_TRY(c.bind());
+
+// collection.ex:325-345 on a shard whose ranks are strictly current (and whose sign bits
+// are, when a quantized generator takes part).
+int hybrid_ready(Shard *ix, Ctx &c, const float *query, size_t n, const int *kinds, const size_t *candidates,
+                 const size_t *stage_off, const size_t *stages, size_t ngen, size_t limit, vt_hits **out) {
   VT_TRY(validate_vector(query, n, ix->dim));
   if (ngen == 0) return VT_ERR_ARGUMENT;
   for (size_t i = 0; i < ngen; ++i) {
@@ -2263,7 +2121,6 @@ int vt_flat_hybrid_search(vt_flat *ix, const float *query, size_t n, const int *
     }
   }
   if (ix->n == 0 || limit == 0) return empty_hits(out);
-  VT_TRY(index_sync_ranks(ix, false));
   uint32_t qnz_full = 0;
   VT_TRY(upload_query(c, query, n, &qnz_full));
   // hybrid_candidates (collection.ex:515-532): every generator's candidates, first occurrence wins
@@ -2271,30 +2128,25 @@ int vt_flat_hybrid_search(vt_flat *ix, const float *query, size_t n, const int *
   std::vector<char> seen(ix->n, 0);
   for (size_t i = 0; i < ngen; ++i) {
     if (kinds[i] == VT_GEN_FUNNEL) {
-      VT_TRY(funnel_rows(ix, query, stages + stage_off[i], stage_off[i + 1] - stage_off[i], candidates[i], rows));
+      VT_TRY(funnel_rows(ix, c, query, stages + stage_off[i], stage_off[i + 1] - stage_off[i], candidates[i], rows));
     } else if (kinds[i] == VT_GEN_QUANTIZED) {
-      VT_TRY(quantized_rows(ix, candidates[i], rows));
+      VT_TRY(quantized_rows(ix, c, candidates[i], rows));
     } else {  // the index's own search with limit = candidates (collection.ex:583-592)
+      // (flat search ranks cosine by the f32 dot of normalised vectors, not by the f64 cosine
+      // a vector_top_k stage would use: the plain scan serves every metric here)
+      ScanJob j{};
+      j.X = ix->dX;
+      j.stride = ix->ld;
+      j.id_rank = ix->dRank.p;
+      j.n = ix->n;
+      j.d = (uint32_t)ix->dim;
+      j.metric = ix->metric;
+      j.order = ix->order;
+      j.q_nonzero = qnz_full;
       std::vector<vt::Entry> kept;
-      VT_TRY(funnel_stage(ix, query, (uint32_t)ix->dim, rows, true, candidates[i], qnz_full, kept));
+      VT_TRY(run_scan(c, j, candidates[i], kept, false));
       rows.resize(kept.size());
       for (size_t r = 0; r < kept.size(); ++r) rows[r] = kept[r].row;
-      // flat search ranks cosine by the f32 dot of normalised vectors, not by the f64 cosine
-      if (ix->metric == VT_COSINE) {
-        ScanJob j{};
-        j.X = ix->dX;
-        j.stride = ix->ld;
-        j.id_rank = ix->dRank.p;
-        j.n = ix->n;
-        j.d = (uint32_t)ix->dim;
-        j.metric = ix->metric;
-        j.order = ix->order;
-        j.q_nonzero = qnz_full;
-        kept.clear();
-        VT_TRY(run_scan(c, j, candidates[i], kept, false));
-        rows.resize(kept.size());
-        for (size_t r = 0; r < kept.size(); ++r) rows[r] = kept[r].row;
-      }
     }
     for (uint32_t r : rows)
       if (!seen[r]) {
@@ -2305,8 +2157,925 @@ int vt_flat_hybrid_search(vt_flat *ix, const float *query, size_t n, const int *
   if (all.empty()) return empty_hits(out);
   // hybrid_rerank :exact == exact_rerank (collection.ex:627-630, :821-851)
   std::vector<vt::Entry> entries;
-  VT_TRY(funnel_stage(ix, query, (uint32_t)ix->dim, all, false, limit, qnz_full, entries));
+  VT_TRY(funnel_stage(ix, c, query, (uint32_t)ix->dim, all, false, limit, qnz_full, entries));
   return make_hits(ix, entries, out);
+}
+
+
+// Per-device context for the stateless helpers.
+std::mutex g_ctx_mu;
+std::unordered_map<int, std::unique_ptr<Ctx>> g_ctx;
+int stateless_ctx(int device, Ctx **out) {
+  std::lock_guard<std::mutex> g(g_ctx_mu);
+  auto it = g_ctx.find(device);
+  if (it == g_ctx.end()) {
+    auto c = std::make_unique<Ctx>();
+    VT_TRY(c->init(device));
+    it = g_ctx.emplace(device, std::move(c)).first;
+  }
+  *out = it->second.get();
+  return (*out)->bind();
+}
+
+// id_rank for an ad-hoc batch of ids (ties between equal ids: input order).
+void ranks_for_ids(const char *ids, const size_t *id_off, size_t count, std::vector<uint32_t> &rank) {
+  std::vector<uint32_t> order(count);
+  for (size_t i = 0; i < count; ++i) order[i] = (uint32_t)i;
+  auto view = [&](uint32_t i) { return std::pair<const char *, size_t>(ids + id_off[i], id_off[i + 1] - id_off[i]); };
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    auto x = view(a), y = view(b);
+    const size_t m = std::min(x.second, y.second);
+    const int c = m ? std::memcmp(x.first, y.first, m) : 0;
+    if (c) return c < 0;
+    return x.second < y.second;
+  });
+  rank.resize(count);
+  for (size_t i = 0; i < count; ++i) rank[order[i]] = (uint32_t)i;
+}
+
+int hits_from_batch(const char *ids, const size_t *id_off, const std::vector<vt::Entry> &entries, vt_hits **out) {
+  auto h = std::make_unique<vt_hits>();
+  for (const auto &e : entries) {
+    h->ids.emplace_back(ids + id_off[e.row], id_off[e.row + 1] - id_off[e.row]);
+    h->raw.push_back(e.raw);
+    h->rank_key.push_back(rank_key_of(e.key));
+  }
+  *out = h.release();
+  return VT_OK;
+}
+
+// ======================================================= handle level (vt_flat)
+int poisoned_status() { return fail(VT_ERR_POISONED, "flat lock poisoned"); }
+
+constexpr int kStatusStaleRanks = 64;  // block status bit: the shard's externally installed id ranks no longer hold
+constexpr size_t kExchangeBlockBytes = 16 + (size_t)vt::kMaxFusedK * sizeof(vt::Entry);
+
+// Shard of an id: FNV-1a over the bytes, finished with a 64-bit mix (so that ids which
+// differ in their last digits only still spread evenly).
+inline uint32_t shard_of(const char *id, size_t len, size_t nshards) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < len; ++i) {
+    h ^= (unsigned char)id[i];
+    h *= 1099511628211ull;
+  }
+  h ^= h >> 33;
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 33;
+  h *= 0xc4ceb9fe1a85ec53ull;
+  h ^= h >> 33;
+  return (uint32_t)(h % nshards);
+}
+
+// Runs fn(s) for every shard s in `which` on that shard's worker thread, all at once;
+// the status of the lowest failing shard wins (its detail text becomes this thread's).
+template <class F>
+int on_shards(vt_flat *h, const std::vector<size_t> &which, F fn) {
+  std::vector<Worker::Job> jobs(which.size());
+  for (size_t i = 0; i < which.size(); ++i) {
+    const size_t s = which[i];
+    jobs[i].fn = [&fn, s]() -> int { return fn(s); };
+  }
+  {
+    std::lock_guard<std::mutex> g(h->post_mu);
+    for (size_t i = 0; i < which.size(); ++i) h->workers[which[i]]->post(&jobs[i]);
+  }
+  for (size_t i = 0; i < which.size(); ++i) h->workers[which[i]]->wait(&jobs[i]);
+  for (size_t i = 0; i < which.size(); ++i)
+    if (jobs[i].status != VT_OK) return fail(jobs[i].status, jobs[i].error);
+  return VT_OK;
+}
+template <class F>
+int on_all_shards(vt_flat *h, F fn) {
+  std::vector<size_t> all(h->shards.size());
+  for (size_t s = 0; s < all.size(); ++s) all[s] = s;
+  return on_shards(h, all, fn);
+}
+
+// A read on a one-shard handle: under the shared lock on a leased context when the derived
+// columns it needs are current; otherwise (or when a lazy search hit a tie only the true id
+// order can cut) under the exclusive lock, which first brings them up to date.
+template <class F>
+int read_single(vt_flat *h, unsigned need, size_t limit, F &&fn) {
+  Shard *ix = h->shards[0].get();
+  bool escalated = false;
+  {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    if (h->poisoned) return poisoned_status();
+    if (!shard_stale(ix, need, limit)) {
+      CtxLease lease(ix);
+      if (!lease.c) return lease.status;
+      VT_TRY(lease.c->bind());
+      const int st = fn(ix, *lease.c);
+      if (st != kEscalate) return st;
+      escalated = true;
+    }
+  }
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  if (h->poisoned) return poisoned_status();
+  VT_TRY(ix->ctx.bind());
+  if (escalated) need |= NEED_STRICT_RANKS;
+  VT_TRY(shard_prepare(ix, need, limit));
+  int st = fn(ix, ix->ctx);
+  if (st == kEscalate) {
+    VT_TRY(shard_prepare(ix, need | NEED_STRICT_RANKS, limit));
+    st = fn(ix, ix->ctx);
+  }
+  return st;
+}
+
+// flat.rs:88-93 on one shard.
+int shard_delete(Shard *ix, const char *id, size_t id_len, bool *began) {
+  Ctx &c = ix->ctx;
+  auto it = ix->row_of.find(std::string(id ? id : "", id_len));
+  if (it != ix->row_of.end()) {
+    *began = true;
+    ix->epoch += 1;
+    const uint32_t r = it->second, last = ix->n - 1;
+    if (ix->rank_host[r] == kUnranked && ix->unranked) ix->unranked -= 1;
+    ix->row_of.erase(it);
+    if (r != last) {
+      // swap-delete: the last row moves into the hole and keeps its rank
+      VT_HIP(hipMemcpyAsync(ix->dX + (size_t)r * ix->ld, ix->dX + (size_t)last * ix->ld, (size_t)ix->ld * sizeof(float),
+                            hipMemcpyDeviceToDevice, c.stream));
+      ix->ids[r] = std::move(ix->ids[last]);
+      ix->row_of[ix->ids[r]] = r;
+      ix->rank_host[r] = ix->rank_host[last];
+      if (ix->ranks_clean && ix->dRank.p)
+        VT_HIP(hipMemcpyAsync(ix->dRank.p + r, ix->dRank.p + last, sizeof(uint32_t), hipMemcpyDeviceToDevice, c.stream));
+      if (!ix->ranks_clean) {
+        ix->rank_dirty.push_back(r);
+        if (ix->rank_dirty.size() > kMaxDirtyRanks) ix->rank_dirty_all = true;
+      }
+    }
+    VT_HIP(hipMemsetAsync(ix->dX + (size_t)last * ix->ld, 0, (size_t)ix->ld * sizeof(float), c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    ix->ids.pop_back();
+    ix->rank_host.pop_back();
+    ix->n -= 1;
+    if (r != last) index_touch_row(ix, r);  // row r now holds what was the last row
+  }
+  if (ix->n == 0) {
+    ix->dim = -1;
+    ix->rank_dirty.clear();
+    ix->rank_dirty_all = false;
+    ix->unranked = 0;
+    ix->ranks_clean = true;
+    ix->max_id.clear();
+    ix->max_rank = 0;
+  }
+  return VT_OK;
+}
+
+// Upload + scan + select into `device_block` ({i32 status, u32 count, pad[2]} then `limit`
+// entries) on the context's stream, nothing waited for.  Ranks strictly current.
+int shard_begin(Shard *ix, Ctx &c, const float *query, size_t n, size_t limit, void *device_block) {
+  if (limit == 0 || limit > (size_t)vt::kMaxFusedK) return fail(VT_ERR_UNSUPPORTED, "search_begin needs 1 <= limit <= 256");
+  VT_TRY(validate_vector(query, n, ix->dim));
+  if (ix->n == 0) {
+    VT_HIP(hipMemsetAsync(device_block, 0, 16, c.stream));  // count = 0
+    return VT_OK;
+  }
+  uint32_t qnz = 0;
+  VT_TRY(upload_query(c, query, n, &qnz));
+  const uint32_t d = (uint32_t)ix->dim, k = (uint32_t)limit;
+  if (vt::scan_lds_bytes(d, k) == 0) return fail(VT_ERR_UNSUPPORTED, "dimension/limit exceed the scan kernel's LDS");
+  const uint32_t tile_rows = vt::scan_tile_rows(ix->n, d, c.resident_waves());
+  const uint32_t blocks = c.grid_for((ix->n + tile_rows - 1) / tile_rows, vt::scan_lds_bytes(d, k));
+  VT_TRY(c.dPartKeys.ensure((size_t)blocks * k));
+  VT_TRY(c.dPartPay.ensure((size_t)blocks * k));
+  vt::ScanArgs a{};
+  a.X = ix->dX;
+  a.stride = ix->ld;
+  a.q = c.dQ.p;
+  a.id_rank = ix->dRank.p;
+  a.n = ix->n;
+  a.d = d;
+  a.metric = ix->metric;
+  a.order = ix->order;
+  a.k = k;
+  a.q_nonzero = qnz;
+  a.tile_rows = tile_rows;
+  a.part_keys = c.dPartKeys.p;
+  a.part_pay = c.dPartPay.p;
+  a.status = c.dStatus.p;
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+  VT_HIP(vt::launch_scan(a, blocks, c.stream));
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+  c.begin_rows = ix->n;
+  c.begin_dim = d;
+  VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, blocks * k, k, 0, 0, c.dStatus.p,
+                           static_cast<ResultBlock *>(device_block), c.dSelKeys.p, c.dSelPay.p, c.stream));
+  return VT_OK;
+}
+
+int settle_begin_profile(Ctx &c) {
+  if (c.profiling && c.begin_rows) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    c.prof.scan_launches += 1;
+    c.prof.scan_ms += ms;
+    c.prof.scan_rows += c.begin_rows;
+    c.prof.scan_bytes += (uint64_t)c.begin_rows * c.begin_dim * 4;
+  }
+  c.begin_rows = 0;
+  return VT_OK;
+}
+
+// ---- the shards' lists meet: merge by (rank key, id bytes) == FlatHit::cmp (flat.rs:34-40).
+// Needs no global id ranks: within a shard the lists are already in that order, across
+// shards the id bytes themselves decide.
+struct MergeItem {
+  uint32_t rank_key;
+  float raw;
+  const std::string *id;
+};
+inline bool merge_less(const MergeItem &a, const MergeItem &b) {
+  if (a.rank_key != b.rank_key) return a.rank_key < b.rank_key;
+  return *a.id < *b.id;
+}
+int merged_hits(std::vector<MergeItem> &items, size_t limit, vt_hits **out) {
+  const size_t k = std::min(limit, items.size());
+  std::partial_sort(items.begin(), items.begin() + k, items.end(), merge_less);
+  auto h = std::make_unique<vt_hits>();
+  h->ids.reserve(k);
+  for (size_t i = 0; i < k; ++i) {
+    h->ids.push_back(*items[i].id);
+    h->raw.push_back(items[i].raw);
+    h->rank_key.push_back(items[i].rank_key);
+  }
+  *out = h.release();
+  return VT_OK;
+}
+int merge_hit_lists(const std::vector<vt_hits *> &lists, size_t limit, vt_hits **out) {
+  std::vector<MergeItem> items;
+  for (const vt_hits *l : lists)
+    if (l)
+      for (size_t i = 0; i < l->ids.size(); ++i) items.push_back(MergeItem{l->rank_key[i], l->raw[i], &l->ids[i]});
+  return merged_hits(items, limit, out);
+}
+
+// One communicator per shard (ncclCommInitAll: one process, all devices), the exchange
+// blocks, and shard 0's pinned copy of the gathered lists.
+int exchange_setup(vt_flat *h) {
+  if (!h->comms.empty()) return VT_OK;
+  const size_t S = h->shards.size();
+  std::vector<int> devs(S);
+  for (size_t s = 0; s < S; ++s) devs[s] = h->shards[s]->ctx.device;
+  for (size_t a = 0; a < S; ++a)
+    for (size_t b = a + 1; b < S; ++b)
+      if (devs[a] == devs[b]) return fail(VT_ERR_UNSUPPORTED, "RCCL needs every shard on its own device");
+  Rccl &r = rccl();
+  if (!r.ok) return fail(VT_ERR_DEVICE, r.error);
+  std::vector<ncclComm_t> comms(S, nullptr);
+  const ncclResult_t rc = r.CommInitAll(comms.data(), (int)S, devs.data());
+  if (rc != ncclSuccess) return fail(VT_ERR_DEVICE, std::string("ncclCommInitAll: ") + r.GetErrorString(rc));
+  h->comms = std::move(comms);
+  h->dBlock.assign(S, nullptr);
+  h->dGather.assign(S, nullptr);
+  for (size_t s = 0; s < S; ++s) {
+    VT_HIP(hipSetDevice(devs[s]));
+    VT_HIP(hipMalloc(&h->dBlock[s], kExchangeBlockBytes));
+    VT_HIP(hipMalloc(&h->dGather[s], S * kExchangeBlockBytes));
+  }
+  VT_HIP(hipSetDevice(devs[0]));
+  VT_TRY(h->hGather.ensure(S * kExchangeBlockBytes));
+  return VT_OK;
+}
+
+// flat_search on a multi-shard handle (shared lock held by the caller).
+int search_multi(vt_flat *h, const float *query, size_t n, size_t limit, vt_hits **out) {
+  if (limit == 0) return empty_hits(out);  // flat.rs:97-101: before the query is looked at
+  VT_TRY(validate_vector(query, n, h->dim));
+  if (h->total() == 0) return empty_hits(out);
+  const size_t S = h->shards.size();
+  const bool via_rccl = h->exchange == VT_EXCHANGE_RCCL && !h->comms.empty() && limit <= (size_t)vt::kMaxFusedK &&
+                        vt::scan_lds_bytes((uint32_t)h->dim, (uint32_t)limit) != 0;
+  if (via_rccl) {
+    // every shard: scan + select into its device block, one all-gather queued behind them on
+    // the shard's stream; shard 0 copies the gathered lists out; one wait per shard
+    const size_t bytes = 16 + limit * sizeof(vt::Entry);
+    Rccl &r = rccl();
+    VT_TRY(on_all_shards(h, [&](size_t s) -> int {
+      Shard *ix = h->shards[s].get();
+      Ctx &c = ix->ctx;
+      int st = VT_OK;
+      if (shard_stale(ix, NEED_STRICT_RANKS, limit)) st = shard_prepare(ix, NEED_STRICT_RANKS, limit);
+      if (st == VT_OK) st = shard_begin(ix, c, query, n, limit, h->dBlock[s]);
+      if (st != VT_OK) {
+        // the collective must still be entered by every shard: an empty block carrying the status
+        uint32_t head[4] = {(uint32_t)st, 0, 0, 0};
+        (void)hipMemcpyAsync(h->dBlock[s], head, sizeof head, hipMemcpyHostToDevice, c.stream);
+        (void)hipStreamSynchronize(c.stream);
+      }
+      const ncclResult_t rc = r.AllGather(h->dBlock[s], h->dGather[s], bytes, ncclChar, h->comms[s], c.stream);
+      if (rc != ncclSuccess) return fail(VT_ERR_DEVICE, std::string("ncclAllGather: ") + r.GetErrorString(rc));
+      if (s == 0)
+        VT_HIP(hipMemcpyAsync(h->hGather.p, h->dGather[0], S * bytes, hipMemcpyDeviceToHost, c.stream));
+      VT_HIP(hipStreamSynchronize(c.stream));
+      VT_TRY(settle_begin_profile(c));
+      return st;
+    }));
+    std::vector<MergeItem> items;
+    for (size_t s = 0; s < S; ++s) {
+      const unsigned char *blk = h->hGather.p + s * bytes;
+      int status;
+      uint32_t count;
+      std::memcpy(&status, blk, 4);
+      std::memcpy(&count, blk + 4, 4);
+      if (status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
+      if (status != VT_OK) return fail(VT_ERR_DEVICE, "a shard reported status " + std::to_string(status));
+      const vt::Entry *e = reinterpret_cast<const vt::Entry *>(blk + 16);
+      for (uint32_t i = 0; i < count && i < limit; ++i)
+        items.push_back(MergeItem{rank_key_of(e[i].key), e[i].raw, &h->shards[s]->ids[e[i].row]});
+    }
+    h->xprof.merge_launches += 1;
+    return merged_hits(items, limit, out);
+  }
+  // host exchange: every shard's select kernel writes its list through the host mapping
+  std::vector<vt_hits *> lists(S, nullptr);
+  const int st = on_all_shards(h, [&](size_t s) -> int { return search_owner(h->shards[s].get(), query, n, limit, &lists[s]); });
+  int rc = st;
+  if (rc == VT_OK) rc = merge_hit_lists(lists, limit, out);
+  for (vt_hits *l : lists) delete l;
+  return rc;
+}
+
+// flat_search_batch on a multi-shard handle.
+int batch_multi(vt_flat *h, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
+  if (limit == 0) {
+    for (size_t i = 0; i < nq; ++i) VT_TRY(empty_hits(&out[i]));
+    return VT_OK;
+  }
+  for (size_t i = 0; i < nq; ++i) VT_TRY(validate_vector(queries + i * d, d, h->dim));
+  if (h->total() == 0) {
+    for (size_t i = 0; i < nq; ++i) VT_TRY(empty_hits(&out[i]));
+    return VT_OK;
+  }
+  const size_t S = h->shards.size();
+  std::vector<std::vector<vt_hits *>> per(S, std::vector<vt_hits *>(nq, nullptr));
+  int rc = on_all_shards(h, [&](size_t s) -> int {
+    Shard *ix = h->shards[s].get();
+    const unsigned need = NEED_STRICT_RANKS | (batch_uses_mfma(ix, nq, limit) ? NEED_NORMS : 0u);
+    if (shard_stale(ix, need, limit)) VT_TRY(shard_prepare(ix, need, limit));
+    return batch_ready(ix, ix->ctx, queries, nq, d, limit, per[s].data());
+  });
+  std::vector<vt_hits *> lists(S);
+  for (size_t i = 0; i < nq && rc == VT_OK; ++i) {
+    for (size_t s = 0; s < S; ++s) lists[s] = per[s][i];
+    rc = merge_hit_lists(lists, limit, &out[i]);
+  }
+  for (auto &v : per)
+    for (vt_hits *l : v) delete l;
+  return rc;
+}
+
+// Device a pointer lives on (-1: not device memory we can tell).
+int device_of_pointer(const void *p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return attr.device;
+}
+
+// Shared body of insert_many / load_matrix / load_device_matrix once every row is validated:
+// one shard takes the batch as it is; several shards take their rows (hash of the id) at
+// the same time, each on its own worker.
+int store_validated(vt_flat *h, size_t count, const char *ids, const size_t *id_off, const RowSource &src, size_t d) {
+  if (count == 0) return VT_OK;
+  const size_t S = h->shards.size();
+  if (!h->multi()) {
+    Shard *ix = h->shards[0].get();
+    if (ix->dim < 0) VT_TRY(index_set_dim(ix, d));
+    bool began = false;
+    const int st = index_store_rows(ix, count, ids, id_off, src, &began);
+    if (st != VT_OK && began) h->poisoned = true;
+    return st;
+  }
+  if (count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows in one batch");
+  std::vector<std::vector<uint32_t>> pick(S);
+  for (size_t i = 0; i < count; ++i) pick[shard_of(ids + id_off[i], id_off[i + 1] - id_off[i], S)].push_back((uint32_t)i);
+  std::vector<size_t> which;
+  for (size_t s = 0; s < S; ++s)
+    if (!pick[s].empty()) which.push_back(s);
+  std::vector<char> began(S, 0);
+  const int st = on_shards(h, which, [&](size_t s) -> int {
+    Shard *ix = h->shards[s].get();
+    const std::vector<uint32_t> &mine = pick[s];
+    // this shard's ids, packed
+    std::vector<size_t> off(mine.size() + 1, 0);
+    for (size_t i = 0; i < mine.size(); ++i) off[i + 1] = off[i] + (id_off[mine[i] + 1] - id_off[mine[i]]);
+    std::string blob;
+    blob.resize(off.back());
+    for (size_t i = 0; i < mine.size(); ++i)
+      std::memcpy(&blob[off[i]], ids + id_off[mine[i]], off[i + 1] - off[i]);
+    if (ix->dim < 0) VT_TRY(index_set_dim(ix, d));
+    RowSource sub = src;
+    sub.pick = mine.data();
+    bool b = false;
+    const int r = index_store_rows(ix, mine.size(), blob.data(), off.data(), sub, &b);
+    began[s] = b ? 1 : 0;
+    return r;
+  });
+  if (st != VT_OK)
+    for (size_t s = 0; s < S; ++s)
+      if (began[s]) h->poisoned = true;
+  if (st == VT_OK) h->dim = (long)d;
+  return st;
+}
+
+long handle_dim(const vt_flat *h) { return h->multi() ? h->dim : h->shards[0]->dim; }
+
+}  // namespace
+
+// =============================================================== C ABI
+extern "C" {
+
+const char *vt_strerror(int status) {
+  switch (status) {
+    case VT_OK: return "ok";
+    case VT_ERR_EMPTY: return "vector must not be empty";
+    case VT_ERR_DIMENSION: return "dimension mismatch";
+    case VT_ERR_NON_FINITE: return "vector contains a non-finite value";
+    case VT_ERR_OVERFLOW: return "metric overflow";
+    case VT_ERR_UNKNOWN_METRIC: return "unknown metric";
+    case VT_ERR_PREFIX: return "invalid prefix dimensions";
+    case VT_ERR_DIMS_POSITIVE: return "dimensions must be positive";
+    case VT_ERR_POISONED: return "flat lock poisoned";
+    case VT_ERR_NOMEM: return "out of memory";
+    case VT_ERR_DEVICE: return "device error";
+    case VT_ERR_UNSUPPORTED: return "unsupported on device";
+    case VT_ERR_ARGUMENT: return "bad argument";
+    default: return "unknown status";
+  }
+}
+
+const char *vt_last_error(void) { return g_last_error.c_str(); }
+int vt_abi_version(void) { return VT_ABI_VERSION; }
+
+int vt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+size_t vt_hits_len(const vt_hits *h) { return h ? h->ids.size() : 0; }
+const char *vt_hits_id(const vt_hits *h, size_t i, size_t *len) {
+  *len = h->ids[i].size();
+  return h->ids[i].data();
+}
+float vt_hits_raw(const vt_hits *h, size_t i) { return h->raw[i]; }
+uint32_t vt_hits_rank_key(const vt_hits *h, size_t i) { return h->rank_key[i]; }
+size_t vt_hits_pack(const vt_hits *h, void *records, size_t cap) {
+  if (!h || !records) return 0;
+  const size_t n = std::min(cap, h->ids.size());
+  unsigned char *out = static_cast<unsigned char *>(records);
+  for (size_t i = 0; i < n; ++i, out += VT_HIT_RECORD_BYTES) {
+    const uint32_t len = (uint32_t)h->ids[i].size();
+    std::memset(out, 0, VT_HIT_RECORD_BYTES);
+    std::memcpy(out, &h->rank_key[i], 4);
+    std::memcpy(out + 4, &h->raw[i], 4);
+    std::memcpy(out + 8, &len, 4);
+    std::memcpy(out + 12, h->ids[i].data(), std::min<size_t>(len, VT_HIT_RECORD_ID_BYTES));
+  }
+  return n;
+}
+size_t vt_hits_id_bytes(const vt_hits *h) {
+  size_t total = 0;
+  if (h)
+    for (const auto &id : h->ids) total += id.size();
+  return total;
+}
+
+void vt_hits_export(const vt_hits *h, char *ids, size_t *id_off, float *raw, uint32_t *rank_key) {
+  if (!h) return;
+  size_t pos = 0;
+  for (size_t i = 0; i < h->ids.size(); ++i) {
+    if (id_off) id_off[i] = pos;
+    if (ids) std::memcpy(ids + pos, h->ids[i].data(), h->ids[i].size());
+    pos += h->ids[i].size();
+    if (raw) raw[i] = h->raw[i];
+    if (rank_key) rank_key[i] = h->rank_key[i];
+  }
+  if (id_off) id_off[h->ids.size()] = pos;
+}
+
+void vt_hits_free(vt_hits *h) { delete h; }
+
+int vt_flat_new_sharded(int metric_code, const int *devices, size_t ndev, vt_flat **out) {
+  return guarded([&]() -> int {
+  if (!out || !devices || ndev == 0 || ndev > 64) return VT_ERR_ARGUMENT;
+  *out = nullptr;
+  if (metric_code < VT_L2 || metric_code > VT_JACCARD) return VT_ERR_UNKNOWN_METRIC;
+  auto h = std::make_unique<vt_flat>();
+  h->metric = metric_code;
+  for (size_t s = 0; s < ndev; ++s) {
+    auto ix = std::make_unique<Shard>();
+    ix->metric = metric_code;
+    VT_TRY(ix->ctx.init(devices[s]));
+    h->shards.push_back(std::move(ix));
+  }
+  if (ndev > 1 || std::getenv("VT_SHARD_FORCE_WORKERS")) {
+    bool distinct = true;
+    for (size_t a = 0; a < ndev; ++a)
+      for (size_t b = a + 1; b < ndev; ++b) {
+        if (devices[a] == devices[b]) {
+          distinct = false;
+          continue;
+        }
+        // bulk loads may hand a shard rows that live on another shard's device
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+          (void)hipSetDevice(devices[a]);
+          if (hipDeviceEnablePeerAccess(devices[b], 0) != hipSuccess) (void)hipGetLastError();
+        }
+        if (hipDeviceCanAccessPeer(&can, devices[b], devices[a]) == hipSuccess && can) {
+          (void)hipSetDevice(devices[b]);
+          if (hipDeviceEnablePeerAccess(devices[a], 0) != hipSuccess) (void)hipGetLastError();
+        }
+      }
+    for (size_t s = 0; s < ndev; ++s) {
+      h->workers.push_back(std::make_unique<Worker>());
+      h->workers.back()->start(devices[s]);
+    }
+    // the shards' lists meet over RCCL when every shard has a device of its own
+    // (VT_SHARD_EXCHANGE=host|rccl overrides; vt_flat_set_exchange later)
+    const char *want = std::getenv("VT_SHARD_EXCHANGE");
+    const bool want_host = want && std::string(want) == "host";
+    const bool want_rccl = want && std::string(want) == "rccl";
+    if (!want_host && (distinct || want_rccl)) {
+      const int st = exchange_setup(h.get());
+      if (st == VT_OK) h->exchange = VT_EXCHANGE_RCCL;
+      else if (want_rccl) return st;
+    }
+  }
+  *out = h.release();
+  return VT_OK;
+  });
+}
+
+int vt_flat_new(int metric_code, int device, vt_flat **out) { return vt_flat_new_sharded(metric_code, &device, 1, out); }
+
+void vt_flat_free(vt_flat *h) { delete h; }
+
+size_t vt_flat_len(const vt_flat *h) {
+  if (!h) return 0;
+  std::shared_lock<std::shared_mutex> rl(h->rw);
+  return h->total();
+}
+long vt_flat_dimension(const vt_flat *h) {
+  if (!h) return -1;
+  std::shared_lock<std::shared_mutex> rl(h->rw);
+  return handle_dim(h);
+}
+int vt_flat_metric(const vt_flat *h) { return h ? h->metric : -1; }
+size_t vt_flat_shard_count(const vt_flat *h) { return h ? h->shards.size() : 0; }
+int vt_flat_shard_device(const vt_flat *h, size_t shard) {
+  return h && shard < h->shards.size() ? h->shards[shard]->ctx.device : -1;
+}
+size_t vt_flat_shard_len(const vt_flat *h, size_t shard) {
+  if (!h || shard >= h->shards.size()) return 0;
+  std::shared_lock<std::shared_mutex> rl(h->rw);
+  return h->shards[shard]->n;
+}
+int vt_flat_route_ids(const vt_flat *h, size_t count, const char *ids, const size_t *id_off, uint32_t *out_shard) {
+  if (!h || (count && (!id_off || !out_shard))) return VT_ERR_ARGUMENT;
+  const size_t S = h->shards.size();
+  for (size_t i = 0; i < count; ++i) out_shard[i] = S > 1 ? shard_of(ids + id_off[i], id_off[i + 1] - id_off[i], S) : 0u;
+  return VT_OK;
+}
+int vt_flat_set_exchange(vt_flat *h, int mode) {
+  return guarded([&]() -> int {
+  if (!h || (mode != VT_EXCHANGE_HOST && mode != VT_EXCHANGE_RCCL)) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  if (mode == VT_EXCHANGE_RCCL) {
+    if (!h->multi()) return fail(VT_ERR_UNSUPPORTED, "a one-shard index has nothing to exchange");
+    VT_TRY(exchange_setup(h));
+  }
+  h->exchange = mode;
+  return VT_OK;
+  });
+}
+int vt_flat_exchange(const vt_flat *h) { return h ? h->exchange : -1; }
+int vt_flat_rccl_ranks(const vt_flat *h) {
+  if (!h || h->comms.empty() || !h->comms[0]) return 0;
+  int n = 0;
+  if (rccl().CommCount(h->comms[0], &n) != ncclSuccess) return 0;
+  return n;
+}
+
+int vt_set_default_reduce_order(int order) {
+  if (order < VT_ORDER_PAIR || order > VT_ORDER_SSE2) return VT_ERR_ARGUMENT;
+  g_default_order = order;
+  return VT_OK;
+}
+
+int vt_flat_set_reduce_order(vt_flat *h, int order) {
+  return guarded([&]() -> int {
+  if (!h || order < VT_ORDER_PAIR || order > VT_ORDER_SSE2) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  for (auto &s : h->shards) s->order = order;
+  return VT_OK;
+  });
+}
+
+int vt_flat_insert(vt_flat *h, const char *id, size_t id_len, const float *vector, size_t n) {
+  return guarded([&]() -> int {
+  if (!h || (!id && id_len) || (!vector && n)) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  if (h->poisoned) return poisoned_status();
+  VT_TRY(h->shards[0]->ctx.bind());
+  // flat.rs:59-66
+  VT_TRY(validate_vector(vector, n, handle_dim(h)));
+  const size_t id_off[2] = {0, id_len};
+  const size_t val_off[2] = {0, n};
+  RowSource src;
+  src.host = vector;
+  src.off = val_off;
+  return store_validated(h, 1, id ? id : "", id_off, src, n);
+  });
+}
+
+int vt_flat_insert_many(vt_flat *h, size_t count, const char *ids, const size_t *id_off, const float *values,
+                        const size_t *value_off) {
+  return guarded([&]() -> int {
+  if (!h || (count && (!id_off || !value_off))) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  if (h->poisoned) return poisoned_status();
+  VT_TRY(h->shards[0]->ctx.bind());
+  // flat.rs:69-85: expected = own dimension, else the first row's length;
+  // every row is validated before anything is stored.
+  long expected = handle_dim(h);
+  if (expected < 0 && count > 0) expected = (long)(value_off[1] - value_off[0]);
+  for (size_t i = 0; i < count; ++i)
+    VT_TRY(validate_vector(values + value_off[i], value_off[i + 1] - value_off[i], expected));
+  if (count == 0) return VT_OK;
+  RowSource src;
+  src.host = values;
+  src.off = value_off;
+  return store_validated(h, count, ids, id_off, src, (size_t)expected);
+  });
+}
+
+int vt_flat_load_matrix(vt_flat *h, size_t count, size_t d, const char *ids, const size_t *id_off, const float *rows) {
+  return guarded([&]() -> int {
+  if (!h || (count && (!id_off || !rows))) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  if (h->poisoned) return poisoned_status();
+  VT_TRY(h->shards[0]->ctx.bind());
+  long expected = handle_dim(h);
+  if (expected < 0 && count > 0) expected = (long)d;
+  VT_TRY(validate_matrix(rows, count, d, expected));
+  if (count == 0) return VT_OK;
+  RowSource src;
+  src.host = rows;
+  src.d = d;
+  return store_validated(h, count, ids, id_off, src, d);
+  });
+}
+
+int vt_flat_load_device_matrix(vt_flat *h, size_t count, size_t d, const char *ids, const size_t *id_off,
+                               const void *device_rows) {
+  return guarded([&]() -> int {
+  if (!h || (count && (!id_off || !device_rows))) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  if (h->poisoned) return poisoned_status();
+  if (count == 0) return VT_OK;
+  if (count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
+  const long expected = handle_dim(h) < 0 ? (long)d : handle_dim(h);
+  if (d == 0) return VT_ERR_EMPTY;
+  if ((long)d != expected) return VT_ERR_DIMENSION;
+  const float *rows = static_cast<const float *>(device_rows);
+  // finiteness is checked where the rows live (a shard on that device, else shard 0 over the peer mapping)
+  const int home = device_of_pointer(device_rows);
+  Shard *checker = h->shards[0].get();
+  for (auto &s : h->shards)
+    if (s->ctx.device == home) {
+      checker = s.get();
+      break;
+    }
+  Ctx &c = checker->ctx;
+  VT_TRY(c.bind());
+  VT_HIP(hipDeviceSynchronize());  // the producer may have used another stream
+  int non_finite = 0;
+  VT_HIP(hipMemsetAsync(c.dFlag.p, 0, sizeof(int), c.stream));
+  VT_HIP(vt::launch_check_finite(rows, d, (uint32_t)count, (uint32_t)d, c.dFlag.p, c.stream));
+  VT_HIP(hipMemcpyAsync(&non_finite, c.dFlag.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  if (non_finite != 0) return VT_ERR_NON_FINITE;
+  VT_TRY(h->shards[0]->ctx.bind());
+  RowSource src;
+  src.device = rows;
+  src.d = d;
+  return store_validated(h, count, ids, id_off, src, d);
+  });
+}
+
+int vt_flat_delete(vt_flat *h, const char *id, size_t id_len) {
+  return guarded([&]() -> int {
+  if (!h || (!id && id_len)) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  if (h->poisoned) return poisoned_status();
+  bool began = false;
+  int st;
+  if (!h->multi()) {
+    Shard *ix = h->shards[0].get();
+    VT_TRY(ix->ctx.bind());
+    st = shard_delete(ix, id, id_len, &began);
+  } else {
+    const size_t s = shard_of(id ? id : "", id_len, h->shards.size());
+    st = on_shards(h, std::vector<size_t>{s}, [&](size_t t) -> int { return shard_delete(h->shards[t].get(), id, id_len, &began); });
+    if (h->total() == 0) h->dim = -1;  // flat.rs:90-92: an emptied index forgets its dimension
+  }
+  if (st != VT_OK && began) h->poisoned = true;
+  return st;
+  });
+}
+
+int vt_flat_search(vt_flat *h, const float *query, size_t n, size_t limit, vt_hits **out) {
+  return guarded([&]() -> int {
+  if (!h || !out || (!query && n)) return VT_ERR_ARGUMENT;
+  *out = nullptr;
+  if (h->multi()) {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    if (h->poisoned) return poisoned_status();
+    return search_multi(h, query, n, limit, out);
+  }
+  return read_single(h, NEED_RANKS, limit,
+                     [&](Shard *ix, Ctx &c) -> int { return search_ready(ix, c, query, n, limit, out); });
+  });
+}
+
+int vt_rank_ids(const char *ids, const size_t *id_off, size_t count, uint32_t *out_rank) {
+  return guarded([&]() -> int {
+  if (count && (!id_off || !out_rank)) return VT_ERR_ARGUMENT;
+  if (count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 ids");
+  std::vector<uint32_t> order(count);
+  for (size_t i = 0; i < count; ++i) order[i] = (uint32_t)i;
+  auto less = [&](uint32_t a, uint32_t b) {
+    const size_t la = id_off[a + 1] - id_off[a], lb = id_off[b + 1] - id_off[b];
+    const size_t m = std::min(la, lb);
+    const int c = m ? std::memcmp(ids + id_off[a], ids + id_off[b], m) : 0;
+    if (c) return c < 0;
+    if (la != lb) return la < lb;
+    return a < b;  // equal ids: input order
+  };
+  parallel_sort(order, less);
+  for (size_t i = 0; i < count; ++i) out_rank[order[i]] = (uint32_t)i;
+  return VT_OK;
+  });
+}
+
+// ---- process-per-GPU sharding (vettore_amd/sharded.py): the caller owns the collective.
+// One-shard handles only; these calls run on the primary context under the exclusive lock.
+#define VT_SINGLE_SHARD_ONLY(h)                                                                                     \
+  if ((h)->multi()) return fail(VT_ERR_UNSUPPORTED, "a multi-shard handle runs its own exchange (vt_flat_search)")
+
+int vt_flat_set_id_ranks(vt_flat *h, const uint32_t *ranks, size_t count) {
+  return guarded([&]() -> int {
+  if (!h || (count && !ranks)) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  if (h->poisoned) return poisoned_status();
+  VT_SINGLE_SHARD_ONLY(h);
+  Shard *ix = h->shards[0].get();
+  VT_TRY(ix->ctx.bind());
+  if (count != ix->n) return VT_ERR_DIMENSION;
+  ix->rank_host.assign(ranks, ranks + count);
+  ix->unranked = 0;
+  ix->ranks_clean = true;
+  ix->external_ranks = true;
+  ix->external_expected = true;
+  ix->external_epoch = ix->epoch;
+  ix->max_rank = kUnranked - 1;  // an appended id can no longer extend the ranks in place
+  return index_sync_ranks(ix, true);
+  });
+}
+
+void *vt_flat_stream(vt_flat *h) { return h && !h->multi() ? static_cast<void *>(h->shards[0]->ctx.stream) : nullptr; }
+
+int vt_flat_search_begin(vt_flat *h, const float *query, size_t n, size_t limit, void *device_block) {
+  return guarded([&]() -> int {
+  if (!h || !device_block || (!query && n)) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  if (h->poisoned) return poisoned_status();
+  VT_SINGLE_SHARD_ONLY(h);
+  Shard *ix = h->shards[0].get();
+  Ctx &c = ix->ctx;
+  VT_TRY(c.bind());
+  if (ix->external_expected && (!ix->external_ranks || ix->epoch != ix->external_epoch)) {
+    // The ranks installed by vt_flat_set_id_ranks described another row set: keys of this
+    // shard no longer compare with the other shards', and rows have moved under the caller's
+    // id table.  The block says so (the merge hands the bit to every rank), nothing is scanned.
+    if (limit == 0 || limit > (size_t)vt::kMaxFusedK) return fail(VT_ERR_UNSUPPORTED, "search_begin needs 1 <= limit <= 256");
+    VT_TRY(validate_vector(query, n, ix->dim));
+    VT_HIP(hipMemsetAsync(device_block, 0, 16, c.stream));
+    VT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(device_block), kStatusStaleRanks, 1, c.stream));
+    c.begin_rows = 0;
+    return VT_OK;
+  }
+  VT_TRY(shard_prepare(ix, NEED_STRICT_RANKS, limit));
+  return shard_begin(ix, c, query, n, limit, device_block);  // nothing waited for: the caller's collective queues behind
+  });
+}
+
+int vt_flat_merge_gathered(vt_flat *h, const void *device_blocks, size_t world, size_t limit, size_t block_bytes,
+                           uint64_t *keys, uint32_t *rows, float *raw, uint32_t *shard, size_t *count) {
+  return guarded([&]() -> int {
+  if (!h || !device_blocks || !keys || !rows || !raw || !shard || !count) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  if (h->poisoned) return poisoned_status();
+  VT_SINGLE_SHARD_ONLY(h);
+  Ctx &c = h->shards[0]->ctx;
+  VT_TRY(c.bind());
+  if (limit == 0 || limit > (size_t)vt::kMaxFusedK || world == 0) return VT_ERR_ARGUMENT;
+  VT_HIP(vt::launch_merge_blocks(device_blocks, (uint32_t)world, (uint32_t)limit, (uint32_t)block_bytes, c.dResMapped,
+                                 c.dShardMapped, c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  VT_TRY(settle_begin_profile(c));
+  if (c.hRes.p->status & kStatusStaleRanks)
+    return fail(VT_ERR_UNSUPPORTED, "stale id ranks: a shard was mutated after vt_flat_set_id_ranks");
+  if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
+  const uint32_t got = c.hRes.p->count;
+  for (uint32_t i = 0; i < got; ++i) {
+    keys[i] = c.hRes.p->e[i].key;
+    rows[i] = c.hRes.p->e[i].row;
+    raw[i] = c.hRes.p->e[i].raw;
+    shard[i] = c.hShard.p[i];
+  }
+  *count = got;
+  return VT_OK;
+  });
+}
+
+int vt_flat_search_batch(vt_flat *h, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
+  return guarded([&]() -> int {
+  if (!h || !out || (nq && !queries && d)) return VT_ERR_ARGUMENT;
+  for (size_t i = 0; i < nq; ++i) out[i] = nullptr;
+  int st;
+  if (h->multi()) {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    if (h->poisoned) return poisoned_status();
+    st = batch_multi(h, queries, nq, d, limit, out);
+  } else {
+    unsigned need = NEED_STRICT_RANKS;
+    {
+      std::shared_lock<std::shared_mutex> rl(h->rw);
+      if (batch_uses_mfma(h->shards[0].get(), nq, limit)) need |= NEED_NORMS;
+    }
+    st = read_single(h, need, limit, [&](Shard *ix, Ctx &c) -> int {
+      for (size_t i = 0; i < nq; ++i) {  // (a second run after an escalation starts clean)
+        delete out[i];
+        out[i] = nullptr;
+      }
+      if (ix->n && batch_uses_mfma(ix, nq, limit) && shard_stale(ix, NEED_NORMS, limit)) return kEscalate;
+      return batch_ready(ix, c, queries, nq, d, limit, out);
+    });
+  }
+  if (st != VT_OK)
+    for (size_t i = 0; i < nq; ++i) {
+      delete out[i];
+      out[i] = nullptr;
+    }
+  return st;
+  });
+}
+
+int vt_flat_quantized_search(vt_flat *h, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out) {
+  return guarded([&]() -> int {
+  if (!h || !out || (!query && n)) return VT_ERR_ARGUMENT;
+  *out = nullptr;
+  VT_SINGLE_SHARD_ONLY(h);
+  return read_single(h, NEED_STRICT_RANKS | NEED_BITS, limit, [&](Shard *ix, Ctx &c) -> int {
+    return quantized_ready(ix, c, query, n, candidates, limit, out);
+  });
+  });
+}
+
+int vt_flat_funnel_search(vt_flat *h, const float *query, size_t n, const size_t *stages, size_t nstages,
+                          size_t candidates, size_t limit, vt_hits **out) {
+  return guarded([&]() -> int {
+  if (!h || !out || (!query && n) || (nstages && !stages)) return VT_ERR_ARGUMENT;
+  *out = nullptr;
+  VT_SINGLE_SHARD_ONLY(h);
+  return read_single(h, NEED_STRICT_RANKS, limit, [&](Shard *ix, Ctx &c) -> int {
+    return funnel_ready(ix, c, query, n, stages, nstages, candidates, limit, out);
+  });
+  });
+}
+
+int vt_flat_hybrid_search(vt_flat *h, const float *query, size_t n, const int *kinds, const size_t *candidates,
+                          const size_t *stage_off, const size_t *stages, size_t ngen, size_t limit, vt_hits **out) {
+  return guarded([&]() -> int {
+  if (!h || !out || (!query && n) || (ngen && (!kinds || !candidates || !stage_off))) return VT_ERR_ARGUMENT;
+  *out = nullptr;
+  VT_SINGLE_SHARD_ONLY(h);
+  unsigned need = NEED_STRICT_RANKS;
+  for (size_t i = 0; i < ngen; ++i)
+    if (kinds[i] == VT_GEN_QUANTIZED) need |= NEED_BITS;
+  return read_single(h, need, limit, [&](Shard *ix, Ctx &c) -> int {
+    return hybrid_ready(ix, c, query, n, kinds, candidates, stage_off, stages, ngen, limit, out);
+  });
   });
 }
 
@@ -2483,21 +3252,45 @@ int vt_compress_sign_bits(int device, size_t count, size_t d, const float *in, u
   });
 }
 
-int vt_flat_set_profiling(vt_flat *ix, int enabled) {
+int vt_flat_set_profiling(vt_flat *h, int enabled) {
   return guarded([&]() -> int {
-  if (!ix) return VT_ERR_ARGUMENT;
-  std::lock_guard<std::mutex> g(ix->mu);
-  ix->ctx.profiling = enabled != 0;
+  if (!h) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  for (auto &s : h->shards) s->for_each_ctx([&](Ctx &c) { c.profiling = enabled != 0; });
   return VT_OK;
   });
 }
 
-int vt_flat_get_profile(vt_flat *ix, vt_profile *out, int reset) {
+// Sums over every shard and every reader context of the handle.
+int vt_flat_get_profile(vt_flat *h, vt_profile *out, int reset) {
   return guarded([&]() -> int {
-  if (!ix || !out) return VT_ERR_ARGUMENT;
-  std::lock_guard<std::mutex> g(ix->mu);
-  *out = ix->ctx.prof;
-  if (reset) ix->ctx.prof = vt_profile{};
+  if (!h || !out) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  vt_profile t = h->xprof;
+  for (auto &s : h->shards)
+    s->for_each_ctx([&](Ctx &c) {
+      const vt_profile &p = c.prof;
+      t.scan_launches += p.scan_launches;
+      t.scan_ms += p.scan_ms;
+      t.scan_rows += p.scan_rows;
+      t.scan_bytes += p.scan_bytes;
+      t.hamming_launches += p.hamming_launches;
+      t.hamming_ms += p.hamming_ms;
+      t.hamming_bytes += p.hamming_bytes;
+      t.merge_launches += p.merge_launches;
+      t.merge_ms += p.merge_ms;
+      t.batch_launches += p.batch_launches;
+      t.batch_ms += p.batch_ms;
+      t.batch_flops += p.batch_flops;
+      t.batch_queries += p.batch_queries;
+      t.batch_fallbacks += p.batch_fallbacks;
+      t.prefix_launches += p.prefix_launches;
+      t.prefix_ms += p.prefix_ms;
+      t.prefix_bytes += p.prefix_bytes;
+      if (reset) c.prof = vt_profile{};
+    });
+  if (reset) h->xprof = vt_profile{};
+  *out = t;
   return VT_OK;
   });
 }

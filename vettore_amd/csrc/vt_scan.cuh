@@ -132,6 +132,8 @@ __device__ __forceinline__ float chunk_sum(int op_rt, int order_rt, float p0, fl
   float e;
   if (order == 2)  // SEQ: (((l0+l1)+l2)+l3) + (((l4+l5)+l6)+l7)
     e = comb<OP>(op_rt, comb<OP>(op_rt, comb<OP>(op_rt, p0, p1), p2), p3);
+  else if (order == 3)  // SSE2: ((l0+l2)+(l1+l3)) + ((l4+l6)+(l5+l7))
+    e = comb<OP>(op_rt, comb<OP>(op_rt, p0, p2), comb<OP>(op_rt, p1, p3));
   else  // PAIR: ((l0+l1)+(l2+l3)) + ((l4+l5)+(l6+l7))
     e = comb<OP>(op_rt, comb<OP>(op_rt, p0, p1), comb<OP>(op_rt, p2, p3));
   return comb<OP>(op_rt, e, dpp_xor1(e));
@@ -429,29 +431,24 @@ hipError_t launch_scan_l2(const ScanDev &sd, uint32_t blocks, size_t lds, bool p
 hipError_t launch_scan_misc(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
 hipError_t launch_scan_general(const ScanDev &sd, uint32_t blocks, uint32_t nq, size_t lds, hipStream_t s);
 
-// order (0..2) x buffer registers (k <= kSmallK -> 1, else 4) x padded
-#define VT_SCAN_DISPATCH_ORDERED(OPV)                                                          \
-  do {                                                                                         \
-    const int order = sd.a.order;                                                              \
-    const bool big = sd.a.k > kSmallK;                                                              \
-    if (!padded) {                                                                             \
-      if (!big) {                                                                              \
-        if (order == 0) return launch_scan_t<OPV, 0, kCapSmall, false, false>(sd, blocks, lds, s);     \
-        if (order == 1) return launch_scan_t<OPV, 1, kCapSmall, false, false>(sd, blocks, lds, s);     \
-        return launch_scan_t<OPV, 2, kCapSmall, false, false>(sd, blocks, lds, s);                     \
-      }                                                                                        \
-      if (order == 0) return launch_scan_t<OPV, 0, kCapLarge, false, false>(sd, blocks, lds, s);       \
-      if (order == 1) return launch_scan_t<OPV, 1, kCapLarge, false, false>(sd, blocks, lds, s);       \
-      return launch_scan_t<OPV, 2, kCapLarge, false, false>(sd, blocks, lds, s);                       \
-    }                                                                                          \
-    if (!big) {                                                                                \
-      if (order == 0) return launch_scan_t<OPV, 0, kCapSmall, false, true>(sd, blocks, lds, s);        \
-      if (order == 1) return launch_scan_t<OPV, 1, kCapSmall, false, true>(sd, blocks, lds, s);        \
-      return launch_scan_t<OPV, 2, kCapSmall, false, true>(sd, blocks, lds, s);                        \
-    }                                                                                          \
-    if (order == 0) return launch_scan_t<OPV, 0, kCapLarge, false, true>(sd, blocks, lds, s);          \
-    if (order == 1) return launch_scan_t<OPV, 1, kCapLarge, false, true>(sd, blocks, lds, s);          \
-    return launch_scan_t<OPV, 2, kCapLarge, false, true>(sd, blocks, lds, s);                          \
+// order (0..3) x candidate buffer (k <= kSmallK -> small) x padded
+#define VT_SCAN_ORDERS(OPV, CAPV, PADV)                                                            \
+  do {                                                                                             \
+    if (order == 0) return launch_scan_t<OPV, 0, CAPV, false, PADV>(sd, blocks, lds, s);           \
+    if (order == 1) return launch_scan_t<OPV, 1, CAPV, false, PADV>(sd, blocks, lds, s);           \
+    if (order == 2) return launch_scan_t<OPV, 2, CAPV, false, PADV>(sd, blocks, lds, s);           \
+    return launch_scan_t<OPV, 3, CAPV, false, PADV>(sd, blocks, lds, s);                           \
+  } while (0)
+#define VT_SCAN_DISPATCH_ORDERED(OPV)                                                              \
+  do {                                                                                             \
+    const int order = sd.a.order;                                                                  \
+    const bool big = sd.a.k > kSmallK;                                                             \
+    if (!padded) {                                                                                 \
+      if (!big) VT_SCAN_ORDERS(OPV, kCapSmall, false);                                             \
+      VT_SCAN_ORDERS(OPV, kCapLarge, false);                                                       \
+    }                                                                                              \
+    if (!big) VT_SCAN_ORDERS(OPV, kCapSmall, true);                                                \
+    VT_SCAN_ORDERS(OPV, kCapLarge, true);                                                          \
   } while (0)
 
 }  // namespace dev

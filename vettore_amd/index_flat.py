@@ -76,13 +76,24 @@ class FlatGpu:
 
     @staticmethod
     def new(metric: str, opts=None):
-        opts = [] if opts is None else opts
-        if not isinstance(opts, (list, dict)) or len(opts) != 0:
+        """`index_options` reach new/2 verbatim (collection.ex:100-103).  The built-in flat index
+        insists on [] (flat.ex:19-25); this one also takes `device: n` or `devices: [n, ...]`
+        -- one resource spread over several GPUs of the node (vt_flat_new_sharded)."""
+        opts = {} if opts is None else (dict(opts) if isinstance(opts, (list, dict)) else None)
+        if opts is None or any(k not in ("device", "devices") for k in opts) or len(opts) > 1:
             return ("error", "invalid_flat_options")          # flat.ex:19-25
-        fn = _NEW.get(metric)
-        if fn is None:
+        code = nifs.METRIC_CODE.get(metric)
+        if code is None:
             return ("error", ("unsupported_flat_metric", metric))  # flat.ex:69
-        return ("ok", fn())
+        devices = opts.get("devices", [opts.get("device", nifs.DEVICE)])
+        ok = isinstance(devices, (list, tuple)) and len(devices) > 0 and \
+            all(isinstance(d, int) and not isinstance(d, bool) and d >= 0 for d in devices)
+        if not ok:
+            return ("error", "invalid_flat_options")
+        try:
+            return ("ok", nifs.flat_new_sharded(code, list(devices)))
+        except RuntimeError as e:  # no such device, out of memory: the NIF's {:error, msg}
+            return ("error", str(e))
 
     @staticmethod
     def put(collection, embedding):

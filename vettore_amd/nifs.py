@@ -160,6 +160,50 @@ def _flat_new(metric: int) -> FlatRef:
     return FlatRef(h, metric)
 
 
+def flat_new_sharded(metric: int, devices: Sequence[int]) -> FlatRef:
+    """One resource over several GPUs of the node (vt_flat_new_sharded): same handle, same
+    calls, rows dealt to the shards by a hash of their id."""
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    h = C.c_void_p()
+    st = _lib.load().vt_flat_new_sharded(metric, devs, len(devices), C.byref(h))
+    if st != 0:
+        raise RuntimeError("flat_new_sharded: " + _lib.error_text(st))
+    return FlatRef(h, metric)
+
+
+def flat_shard_count(index: FlatRef) -> int:
+    return int(_lib.load().vt_flat_shard_count(index.handle))
+
+
+def flat_shard_lens(index: FlatRef) -> List[int]:
+    L = _lib.load()
+    return [int(L.vt_flat_shard_len(index.handle, s)) for s in range(flat_shard_count(index))]
+
+
+def flat_route_ids(index: FlatRef, ids_packed: Tuple[bytes, np.ndarray]) -> np.ndarray:
+    """Shard of every id of a packed id batch."""
+    blob, off = ids_packed
+    off = np.ascontiguousarray(off, dtype=np.uintp)
+    out = np.zeros(len(off) - 1, dtype=np.uint32)
+    st = _lib.load().vt_flat_route_ids(index.handle, len(off) - 1, blob, _szp(off), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if st != 0:
+        raise RuntimeError(_lib.error_text(st))
+    return out
+
+
+def flat_set_exchange(index: FlatRef, mode: int):
+    st = _lib.load().vt_flat_set_exchange(index.handle, mode)
+    return "ok" if st == 0 else _err(st)
+
+
+def flat_exchange(index: FlatRef) -> int:
+    return int(_lib.load().vt_flat_exchange(index.handle))
+
+
+def flat_rccl_ranks(index: FlatRef) -> int:
+    return int(_lib.load().vt_flat_rccl_ranks(index.handle))
+
+
 def flat_new_l2(): return _flat_new(0)                       # nifs.rs:200-204
 def flat_new_l2_squared(): return _flat_new(1)               # nifs.rs:206-210
 def flat_new_cosine(): return _flat_new(2)                   # nifs.rs:212-216

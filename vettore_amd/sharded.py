@@ -119,7 +119,9 @@ class ShardedFlat:
     def enable_device_exchange(self, local_ids_packed, max_limit: int = 64):
         """Collective: gathers every shard's ids, ranks them once, installs this
         shard's slice as its id_rank column.  `local_ids_packed` = (bytes, offsets)
-        of this rank's rows in row order.  Valid until the shard is mutated."""
+        of this rank's rows in row order.  Valid until a shard inserts a new id or deletes a row:
+        the library then marks that shard's blocks stale and every rank falls back to the host
+        exchange together (see _search_device)."""
         from . import nifs
         torch = self._torch
         all_blob, all_off, bases, ranks = gather_global_ranks(self.dist, self.world, local_ids_packed)
@@ -147,6 +149,14 @@ class ShardedFlat:
             self.dist.all_gather_into_tensor(d["gathered"], d["local"])
         res = nifs.flat_merge_gathered(self.ref, d["gathered"].data_ptr(), self.world, limit, d["block_bytes"], d["bufs"])
         if res[0] != "ok":
+            if "stale id ranks" in res[1]:
+                # Some shard was mutated after enable_device_exchange: its keys no longer compare with
+                # the others' and rows moved under the gathered id table.  The stale shard marked its
+                # block, every rank merged the same blocks and lands here together: all of them drop
+                # the device path and answer this query (and the following ones) over the host path,
+                # which needs no global ranks.  enable_device_exchange may be called again later.
+                self._dev = None
+                return None
             raise RuntimeError(res[1])
         b, off, blob, bases = d["bufs"], d["off"], d["blob"], d["bases"]
         out = []
@@ -182,7 +192,9 @@ class ShardedFlat:
         if self.dist is None or (self.world == 1 and not self.force_exchange):
             return [(h[0], h[1]) for h in self._local_search(query, limit)]
         if self._dev is not None and 0 < limit <= self._dev["max_limit"]:
-            return self._search_device(query, limit)
+            out = self._search_device(query, limit)
+            if out is not None:
+                return out
         send_host, send_np, send_dev, gathered, on_gpu = self._buffers(limit)
         long_ids = None
         if self._local is None:
