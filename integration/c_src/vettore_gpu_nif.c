@@ -65,8 +65,9 @@ static ERL_NIF_TERM ok_hits(ErlNifEnv *env, vt_hits *h) {
   return enif_make_tuple2(env, mk_atom(env, "ok"), hits_to_list(env, h));
 }
 
-/* [float] -> malloc'ed f32 array.  A non-number element, or a double outside the f32 range,
- * is a decode failure = badarg, as with rustler's Vec<f32> (SURVEY 8b conventions). */
+/* [float] -> malloc'ed f32 array.  Anything but a float, or a double outside the f32 range,
+ * is a decode failure = badarg, as with rustler's Vec<f32> (SURVEY 8b conventions; the Elixir
+ * layer converts integers with `/ 1` before the call, vettore_distance.ex:659-660). */
 static int get_f32_list(ErlNifEnv *env, ERL_NIF_TERM list, float **out, size_t *n) {
   unsigned len;
   if (!enif_get_list_length(env, list, &len)) return 0;
@@ -75,14 +76,9 @@ static int get_f32_list(ErlNifEnv *env, ERL_NIF_TERM list, float **out, size_t *
   ERL_NIF_TERM head, tail = list;
   for (unsigned i = 0; i < len; ++i) {
     double d;
-    long l;
-    if (!enif_get_list_cell(env, tail, &head, &tail)) { free(v); return 0; }
-    if (enif_get_double(env, head, &d)) {
-      if (d > 3.4028234663852886e38 || d < -3.4028234663852886e38) { free(v); return 0; }
-      v[i] = (float)d;
-    } else if (enif_get_long(env, head, &l)) {
-      v[i] = (float)l;
-    } else { free(v); return 0; }
+    if (!enif_get_list_cell(env, tail, &head, &tail) || !enif_get_double(env, head, &d)) { free(v); return 0; }
+    if (d > 3.4028234663852886e38 || d < -3.4028234663852886e38) { free(v); return 0; }
+    v[i] = (float)d;
   }
   *out = v;
   *n = len;
@@ -116,13 +112,22 @@ static flat_res *get_flat(ErlNifEnv *env, ERL_NIF_TERM t) {
 }
 
 /* ------------------------------------------------------- index lifecycle */
-/* flat_new(metric_code, device) -> reference        nifs.rs:200-257 (one NIF per metric there) */
+/* flat_new(metric_code, [device]) -> reference | {:error, binary}
+ * nifs.rs:200-257 (one NIF per metric there).  One device: a plain index; several: ONE resource
+ * whose rows are spread over those GPUs (vt_flat_new_sharded) -- still one reference, one process. */
 static ERL_NIF_TERM flat_new(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
-  int code, dev;
+  int code;
+  unsigned ndev;
   (void)argc;
-  if (!enif_get_int(env, argv[0], &code) || !enif_get_int(env, argv[1], &dev)) return enif_make_badarg(env);
+  if (!enif_get_int(env, argv[0], &code) || !enif_get_list_length(env, argv[1], &ndev) || ndev == 0 || ndev > 64)
+    return enif_make_badarg(env);
+  int devs[64];
+  ERL_NIF_TERM head, tail = argv[1];
+  for (unsigned i = 0; i < ndev; ++i)
+    if (!enif_get_list_cell(env, tail, &head, &tail) || !enif_get_int(env, head, &devs[i]) || devs[i] < 0)
+      return enif_make_badarg(env);
   vt_flat *h;
-  int st = vt_flat_new(code, dev, &h);
+  int st = vt_flat_new_sharded(code, devs, ndev, &h);
   if (st != VT_OK) return mk_error(env, st);
   flat_res *r = (flat_res *)enif_alloc_resource(FLAT, sizeof *r);
   r->h = h;
@@ -153,10 +158,10 @@ static ERL_NIF_TERM flat_insert_many(ErlNifEnv *env, int argc, const ERL_NIF_TER
   if (!r || !enif_get_list_length(env, argv[1], &count)) return enif_make_badarg(env);
   size_t *id_off = (size_t *)calloc(count + 1, sizeof(size_t));
   size_t *val_off = (size_t *)calloc(count + 1, sizeof(size_t));
-  char *ids = NULL;
-  float *vals = NULL;
-  size_t ids_cap = 0, vals_cap = 0;
-  int ok = id_off && val_off;
+  size_t ids_cap = 64, vals_cap = 64;
+  char *ids = (char *)malloc(ids_cap);
+  float *vals = (float *)malloc(vals_cap * sizeof(float));
+  int ok = id_off && val_off && ids && vals;
   ERL_NIF_TERM head, tail = argv[1];
   for (unsigned i = 0; ok && i < count; ++i) {
     const ERL_NIF_TERM *pair;
@@ -188,7 +193,7 @@ static ERL_NIF_TERM flat_insert_many(ErlNifEnv *env, int argc, const ERL_NIF_TER
   if (!ok) {
     res = enif_make_badarg(env);
   } else {
-    int st = vt_flat_insert_many(r->h, count, ids ? ids : "", id_off, vals, val_off);
+    int st = vt_flat_insert_many(r->h, count, ids, id_off, vals, val_off);
     res = st == VT_OK ? mk_ok_unit(env) : mk_error(env, st);
   }
   free(ids); free(vals); free(id_off); free(val_off);
@@ -208,9 +213,9 @@ static ERL_NIF_TERM flat_load_binary(ErlNifEnv *env, int argc, const ERL_NIF_TER
       !get_size(env, argv[3], &d) || rows.size != (size_t)count * d * sizeof(float))
     return enif_make_badarg(env);
   size_t *id_off = (size_t *)calloc(count + 1, sizeof(size_t));
-  char *ids = NULL;
-  size_t ids_cap = 0;
-  int ok = id_off != NULL;
+  size_t ids_cap = 64;
+  char *ids = (char *)malloc(ids_cap);
+  int ok = id_off != NULL && ids != NULL;
   ERL_NIF_TERM head, tail = argv[1];
   for (unsigned i = 0; ok && i < count; ++i) {
     ErlNifBinary id;
@@ -229,7 +234,7 @@ static ERL_NIF_TERM flat_load_binary(ErlNifEnv *env, int argc, const ERL_NIF_TER
   if (!ok) {
     res = enif_make_badarg(env);
   } else {
-    int st = vt_flat_load_matrix(r->h, count, d, ids ? ids : "", id_off, (const float *)rows.data);
+    int st = vt_flat_load_matrix(r->h, count, d, ids, id_off, (const float *)rows.data);
     res = st == VT_OK ? mk_ok_unit(env) : mk_error(env, st);
   }
   free(ids); free(id_off);
@@ -439,7 +444,10 @@ static int get_ragged(ErlNifEnv *env, ERL_NIF_TERM list, int u64, ragged *g) {
   g->val_off = (size_t *)calloc(g->count + 1, sizeof(size_t));
   if (!g->id_off || !g->val_off) return 0;
   const size_t esz = u64 ? sizeof(uint64_t) : sizeof(float);
-  size_t ids_cap = 0, vals_cap = 0;
+  size_t ids_cap = 64, vals_cap = 64;
+  g->ids = (char *)malloc(ids_cap);
+  g->vals = malloc(vals_cap * esz);
+  if (!g->ids || !g->vals) return 0;
   ERL_NIF_TERM head, tail = list;
   for (unsigned i = 0; i < g->count; ++i) {
     const ERL_NIF_TERM *pair;
@@ -483,7 +491,7 @@ static ERL_NIF_TERM vector_top_k(ErlNifEnv *env, int argc, const ERL_NIF_TERM ar
     return enif_make_badarg(env);
   }
   vt_hits *h;
-  int st = vt_vector_top_k(0, g.count, g.ids ? g.ids : "", g.id_off, (const float *)g.vals, g.val_off, q, nq, code, dims, limit, &h);
+  int st = vt_vector_top_k(0, g.count, g.ids, g.id_off, (const float *)g.vals, g.val_off, q, nq, code, dims, limit, &h);
   ragged_free(&g);
   free(q);
   return st == VT_OK ? ok_hits(env, h) : mk_error(env, st);
@@ -502,7 +510,7 @@ static ERL_NIF_TERM binary_top_k(ErlNifEnv *env, int argc, const ERL_NIF_TERM ar
     return enif_make_badarg(env);
   }
   vt_hits *h;
-  int st = vt_binary_top_k(0, g.count, g.ids ? g.ids : "", g.id_off, (const uint64_t *)g.vals, g.val_off, q, nq, dims, limit, &h);
+  int st = vt_binary_top_k(0, g.count, g.ids, g.id_off, (const uint64_t *)g.vals, g.val_off, q, nq, dims, limit, &h);
   ragged_free(&g);
   free(q);
   return st == VT_OK ? ok_hits(env, h) : mk_error(env, st);

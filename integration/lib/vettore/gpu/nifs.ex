@@ -15,7 +15,7 @@ defmodule Vettore.Gpu.Nifs do
     :erlang.load_nif(path, 0)
   end
 
-  def flat_new(_metric_code, _device), do: :erlang.nif_error(:nif_not_loaded)
+  def flat_new(_metric_code, _devices), do: :erlang.nif_error(:nif_not_loaded)
   def flat_insert(_ref, _id, _vector), do: :erlang.nif_error(:nif_not_loaded)
   def flat_insert_many(_ref, _entries), do: :erlang.nif_error(:nif_not_loaded)
   def flat_load_binary(_ref, _ids, _rows_f32_native, _dimensions), do: :erlang.nif_error(:nif_not_loaded)

@@ -4,6 +4,9 @@ defmodule Vettore.Index.FlatGpu do
 
       Vettore.new(dimensions: 768, metric: :cosine, index: Vettore.Index.FlatGpu,
                   index_options: [device: 0])
+      # or the whole node behind one collection:
+      Vettore.new(dimensions: 768, metric: :l2, index: Vettore.Index.FlatGpu,
+                  index_options: [devices: Enum.to_list(0..7)])
 
   Same steps as `Vettore.Index.Flat` (lib/vettore/index/flat.ex:29-57, :72-112): the
   collection has already validated and normalised embeddings on `put*`
@@ -23,8 +26,13 @@ defmodule Vettore.Index.FlatGpu do
   @impl true
   def new(metric, options) when is_list(options) do
     with true <- Keyword.keyword?(options),
+         {:ok, devices} <- devices(options),
          {:ok, code} <- Map.fetch(@codes, metric) do
-      {:ok, Nifs.flat_new(code, Keyword.get(options, :device, 0))}
+      # the NIF hands back a bare reference, or {:error, message} (no such device, out of memory)
+      case Nifs.flat_new(code, devices) do
+        {:error, _} = error -> error
+        ref -> {:ok, ref}
+      end
     else
       :error -> {:error, {:unsupported_flat_metric, metric}}
       _ -> {:error, :invalid_flat_options}
@@ -97,6 +105,17 @@ defmodule Vettore.Index.FlatGpu do
          {:ok, prepared} <- Collection.prepare_query(collection, query),
          {:ok, hits} <- Nifs.flat_funnel_search(collection.index_state, prepared, stages, candidates, limit) do
       {:ok, Enum.flat_map(hits, &to_result(collection, &1))}
+    end
+  end
+
+  # `index_options: [device: 0]` (default) or `[devices: [0, 1, 2, 3, 4, 5, 6, 7]]`: one resource whose
+  # rows are spread over the GPUs of the node (collection.ex:100-103 hands the options over verbatim).
+  defp devices(options) do
+    case options do
+      [] -> {:ok, [0]}
+      [device: d] when is_integer(d) and d >= 0 -> {:ok, [d]}
+      [devices: [_ | _] = ds] -> if Enum.all?(ds, &(is_integer(&1) and &1 >= 0)), do: {:ok, ds}, else: :invalid
+      _ -> :invalid
     end
   end
 

@@ -416,7 +416,15 @@ def test_mutations_follow_the_oracle(nifs, oracle_mod):
             k = int(rng.integers(1, 30))
             if len(o) == 0:
                 continue
-            assert bits(g.search(q, k)) == bits(o.search(q, k)), (m, step)
+            got, want = g.search(q, k), o.search(q, k)
+            if bits(got) != bits(want):  # say what kind of difference it is before failing
+                full_g, full_o = g.search(q, len(o)), o.search(q, len(o))
+                gd, od = dict(full_g), dict(full_o)
+                first = next(i for i, (a_, b_) in enumerate(zip(got, want)) if bits([a_]) != bits([b_]))
+                detail = {"k": k, "n": len(o), "first_diff": first, "gpu": got[first], "oracle": want[first],
+                          "gpu_raw_of_wanted_id": gd.get(want[first][0]), "oracle_raw_of_gpu_id": od.get(got[first][0]),
+                          "full_lists_equal": bits(full_g) == bits(full_o), "second_try_equal": bits(g.search(q, k)) == bits(want)}
+                raise AssertionError((m, step, detail))
 
 
 def test_sorted_and_unsorted_id_arrival(nifs, oracle_mod):
