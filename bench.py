@@ -8,10 +8,22 @@ A step = one `flat_search` call (one query scanned against the whole corpus)
 through the C ABI of libvettore_hip.so: query H2D, scan + fused top-k kernel,
 merge kernel, result D2H.  The corpus is resident in HBM before timing starts.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the SAME
-10M-row corpus is row-sharded across the ranks (strong scaling); every query
-runs on every shard and the per-shard top-k lists are merged after one
-all_gather of fixed-size records (the path's only exchange step).
+N > 1: the SAME 10M-row corpus is sharded across N GPUs (strong scaling); every
+query runs on every shard and the per-shard top-k lists meet in one all-gather
+(the path's only exchange step), then merge by (rank key, id bytes).  Two ways
+to get there, same library underneath:
+  * `python bench.py --gpus N` (no launcher): ONE process, ONE index handle
+    over N devices (vt_flat_new_sharded) -- the shape of the reference's NIF
+    resource (nifs.rs:254-257); the library runs ncclAllGather itself
+    (`rccl_ranks` = ncclCommCount of its communicator);
+  * under torch.distributed.run (WORLD_SIZE set): one rank per GPU, each with
+    its own one-device index, torch.distributed (nccl = RCCL) carries the
+    all-gather (vettore_amd/sharded.py); `rccl_ranks` = dist.get_world_size().
+
+At N = 1 the JSON line also carries `side`: short legs of the other BASELINE
+configs on the same box (config 2: N=1M single query; config 3: dot, batches of
+256 on the FP32 matrix cores; config 5: quantized search; funnel search), each
+with its own roofline figure.  The headline fields are not affected.
 
 Synthetic data: iid uniform(-1,1) coordinates, rows
 L2-normalised, 1% verbatim duplicate rows, ids "doc-<i>", seeds 20260721/22.
@@ -51,12 +63,25 @@ def parse():
     ap.add_argument("--stages", default="128", help="funnel mode: prefix lengths (collection.ex:660-672 default min(d,128))")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--candidates", type=int, default=100)
+    ap.add_argument("--reduce-order", choices=["pair", "avx", "seq", "sse2"], default="sse2",
+                    help="lane order of wide::f32x8::reduce_add the kernels reproduce (include/vettore_flat.h)")
+    ap.add_argument("--no-side", action="store_true", help="skip the side legs (configs 2, 3, 5, funnel) at N=1")
+    ap.add_argument("--devices", default=None,
+                    help="one process, N devices: HIP ordinals of the shards (default 0..N-1); an ordinal may repeat, "
+                         "which puts several shards on one GPU (how a one-GPU box exercises --gpus 2)")
+    ap.add_argument("--exchange", choices=["auto", "rccl", "host"], default="auto",
+                    help="one process, N devices: how the shards' lists meet (auto = the library's default)")
     return ap.parse_args()
 
 
-def doc_ids(start, count):
-    """ids "doc-<i>" for i in [start+1, start+count] as (bytes, offsets)."""
-    idx = np.arange(start + 1, start + count + 1, dtype=np.int64)
+ORDER_CODE = {"pair": 0, "avx": 1, "seq": 2, "sse2": 3}
+
+
+def doc_ids(start, count, idx=None):
+    """ids "doc-<i>" for i in [start+1, start+count] (or for the given i's) as (bytes, offsets)."""
+    if idx is None:
+        idx = np.arange(start + 1, start + count + 1, dtype=np.int64)
+    count = len(idx)
     digits = np.floor(np.log10(idx)).astype(np.int64) + 1
     off = np.zeros(count + 1, dtype=np.uintp)
     off[1:] = np.cumsum(digits + 4)
@@ -162,9 +187,98 @@ def pmc_traffic(rows, dim):
     return None
 
 
+def hits_of(L, handle_ptr):
+    """[(id, raw bits)] of a vt_hits handle (freed)."""
+    from vettore_amd import nifs
+    return [(h[0], np.float32(h[1]).tobytes()) for h in nifs._take_hits(handle_ptr)]
+
+
+def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidates=100, limit=10):
+    """Times `steps` calls of one entry point on the resident index `ref` (after `warmup`
+    untimed ones) and returns {ms_per_step, value, roofline...} from the library's HIP-event
+    profile.  One result per leg is verified against the single-query path (batch) or
+    against a second run of itself (the other modes): a fast path that returns something
+    else cannot post a number."""
+    import torch
+    dim = qs.shape[1]
+    outs = (C.c_void_p * per)()
+    st_arr = (C.c_size_t * len(stages))(*stages)
+
+    def call(i, keep=False):
+        q = qs[i * per:(i + 1) * per]
+        qp = q.ctypes.data_as(C.POINTER(C.c_float))
+        if mode == "batch":
+            assert L.vt_flat_search_batch(ref.handle, qp, per, dim, limit, outs) == 0
+            res = [C.c_void_p(outs[j]) for j in range(per)]
+        else:
+            h = C.c_void_p()
+            if mode == "single":
+                st = L.vt_flat_search(ref.handle, qp, dim, limit, C.byref(h))
+            elif mode == "funnel":
+                st = L.vt_flat_funnel_search(ref.handle, qp, dim, st_arr, len(stages), candidates, limit, C.byref(h))
+            else:
+                st = L.vt_flat_quantized_search(ref.handle, qp, dim, candidates, limit, C.byref(h))
+            assert st == 0, st
+            res = [h]
+        if keep:
+            return [hits_of(L, r) for r in res]
+        for r in res:
+            L.vt_hits_free(r)
+        return None
+
+    for i in range(warmup):
+        call(i)
+    nifs.flat_set_profiling(ref, True)
+    nifs.flat_get_profile(ref, reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        call(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    p = nifs.flat_get_profile(ref, reset=True)
+    nifs.flat_set_profiling(ref, False)
+    # verification outside the timed region
+    last = call(warmup + steps - 1, keep=True)
+    if mode == "batch":
+        for j in (0, per - 1):
+            h = C.c_void_p()
+            q = qs[(warmup + steps - 1) * per + j]
+            assert L.vt_flat_search(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), dim, limit, C.byref(h)) == 0
+            assert hits_of(L, h) == last[j], "batched result differs from the single-query path"
+    else:
+        assert call(warmup + steps - 1, keep=True) == last and len(last[0]) == limit
+    out = {"ms_per_step": dt / steps * 1e3, "value": steps * per / dt, "unit": "queries/s", "steps": steps, "warmup": warmup,
+           "verified": True}
+    if mode == "batch":
+        ms = p["batch_ms"] / max(1, p["batch_launches"])
+        tf = p["batch_flops"] / max(1e-9, p["batch_ms"]) / 1e9
+        out["fallback_queries"] = p["batch_fallbacks"]
+        out["roofline"] = {"bound": "mfma", "kernel": "mfma_scores_kernel", "achieved": tf, "peak": 157.3,
+                           "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None, "avg_launch_ms": ms,
+                           "algorithmic_flops_per_launch": p["batch_flops"] / max(1, p["batch_launches"])}
+    else:
+        key = {"single": "scan", "funnel": "prefix", "quantized": "hamming"}[mode]
+        kern = {"single": "scan_topk_kernel", "funnel": "cosine_scan_kernel", "quantized": "hamming_dist_kernel"}[mode]
+        launches = max(1, p[key + "_launches"])
+        ms = p[key + "_ms"] / launches
+        gbs = p[key + "_bytes"] / launches / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": kern, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+                           "algorithmic_bytes_per_launch": p[key + "_bytes"] / launches}
+        # end to end against the same algorithmic bytes (launch chain + host waits included)
+        out["end_to_end_frac"] = p[key + "_bytes"] / launches / (dt / steps) / 1e9 / HBM_PEAK_GBS
+    return out
+
+
+def normalized_queries(n, dim, seed):
+    qs = np.random.default_rng(seed).uniform(-1, 1, size=(n, dim)).astype(np.float32)
+    qs /= np.linalg.norm(qs.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+    return qs
+
+
 def run_side_mode(a, torch, nifs, device):
-    """configs[2] / configs[4] on one GPU: same corpus generator, own JSON line."""
-    import ctypes as C
+    """`--mode batch|quantized|funnel`: that config alone, its own JSON line (profiling runs)."""
     from vettore_amd import _lib
     L = _lib.load()
     batch = a.mode == "batch"
@@ -174,83 +288,80 @@ def run_side_mode(a, torch, nifs, device):
         ref = nifs.flat_new_inner_product()
     else:
         ref = nifs.flat_new_cosine()
+    nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
     assert nifs.flat_load_device_matrix(ref, doc_ids(0, a.rows), x.data_ptr(), a.rows, a.dim) == ("ok", ())
     del x
     torch.cuda.empty_cache()
-    qrng = np.random.default_rng(SEED_QUERY)
     per = a.batch if batch else 1
     nq = (a.steps + a.warmup) * per
-    qs = qrng.uniform(-1, 1, size=(nq, a.dim)).astype(np.float32)
-    if not batch:
-        qs /= np.linalg.norm(qs.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
-    outs = (C.c_void_p * per)()
-    stage_list = [int(v) for v in a.stages.split(",")]
-    stages = (C.c_size_t * len(stage_list))(*stage_list)
-
-    def step(i):
-        q = qs[i * per:(i + 1) * per]
-        qp = q.ctypes.data_as(C.POINTER(C.c_float))
-        if batch:
-            assert L.vt_flat_search_batch(ref.handle, qp, per, a.dim, a.limit, outs) == 0
-            for j in range(per):
-                L.vt_hits_free(C.c_void_p(outs[j]))
-        elif a.mode == "funnel":
-            h = C.c_void_p()
-            assert L.vt_flat_funnel_search(ref.handle, qp, a.dim, stages, len(stage_list), a.candidates, a.limit,
-                                           C.byref(h)) == 0
-            L.vt_hits_free(h)
-        else:
-            h = C.c_void_p()
-            assert L.vt_flat_quantized_search(ref.handle, qp, a.dim, a.candidates, a.limit, C.byref(h)) == 0
-            L.vt_hits_free(h)
-
-    for i in range(a.warmup):
-        step(i)
-    nifs.flat_set_profiling(ref, True)
-    nifs.flat_get_profile(ref, reset=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.warmup, a.warmup + a.steps):
-        step(i)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    p = nifs.flat_get_profile(ref, reset=True)
-    out = {
-        "value": a.steps * per / dt, "unit": "queries/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32" if batch else "u64", "data": "synthetic",
-    }
     if batch:
-        ms = p["batch_ms"] / max(1, p["batch_launches"])
-        tf = p["batch_flops"] / max(1e-9, p["batch_ms"]) / 1e9
+        qs = np.random.default_rng(SEED_QUERY).uniform(-1, 1, size=(nq, a.dim)).astype(np.float32)
+    else:
+        qs = normalized_queries(nq, a.dim, SEED_QUERY)
+    stage_list = [int(v) for v in a.stages.split(",")]
+    r = leg(a, L, nifs, ref, a.mode, qs, a.steps, a.warmup, per=per, stages=stage_list, candidates=a.candidates, limit=a.limit)
+    out = {"value": r["value"], "unit": "queries/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": {"batch": "f32", "funnel": "f64", "quantized": "u64"}[a.mode], "data": "synthetic",
+           "roofline": r["roofline"]}
+    if batch:
         out["metric"] = "queries/sec, flat dot top-%d, N=%d d=%d, batch=%d" % (a.limit, a.rows, a.dim, per)
         out["config"] = {"workload": "index: :flat, metric: :dot, d=%d, N=%d, batch=%d queries (MFMA Q x D^T + exact rescoring)"
-                         % (a.dim, a.rows, per), "fallback_queries": p["batch_fallbacks"]}
-        out["roofline"] = {"bound": "mfma", "kernel": "mfma_scores_kernel", "achieved": tf, "peak": 157.3,
-                           "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None, "avg_launch_ms": ms,
-                           "algorithmic_flops_per_launch": p["batch_flops"] / max(1, p["batch_launches"])}
+                         % (a.dim, a.rows, per), "fallback_queries": r["fallback_queries"]}
     elif a.mode == "funnel":
-        ms = p["prefix_ms"] / max(1, p["prefix_launches"])
-        gbs = p["prefix_bytes"] / max(1, p["prefix_launches"]) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        out["dtype"] = "f64"
         out["metric"] = "queries/sec, funnel_search (f64 cosine on prefix %s, keep %d, exact rerank top-%d), N=%d d=%d" % (
             a.stages, a.candidates, a.limit, a.rows, a.dim)
         out["config"] = {"workload": "funnel_search stages=[%s] candidates=%d limit=%d, d=%d, N=%d" % (
             a.stages, a.candidates, a.limit, a.dim, a.rows)}
-        out["roofline"] = {"bound": "hbm", "kernel": "cosine_scan_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
-                           "algorithmic_bytes_per_launch": p["prefix_bytes"] / max(1, p["prefix_launches"]),
-                           "note": "useful bytes = rows * prefix * 4; the prefix of a 3 KiB row is a strided read"}
     else:
-        ms = p["hamming_ms"] / max(1, p["hamming_launches"])
-        gbs = p["hamming_bytes"] / max(1, p["hamming_launches"]) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out["metric"] = "queries/sec, quantized_search (sign-bit Hamming top-%d + exact cosine rerank top-%d), N=%d d=%d" % (
             a.candidates, a.limit, a.rows, a.dim)
         out["config"] = {"workload": "quantized_search candidates=%d limit=%d, d=%d, N=%d" % (a.candidates, a.limit, a.dim, a.rows)}
-        out["roofline"] = {"bound": "hbm", "kernel": "hamming_dist_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
-                           "algorithmic_bytes_per_launch": p["hamming_bytes"] / max(1, p["hamming_launches"])}
+    out["config"]["reduce_order"] = a.reduce_order
     print(json.dumps(out))
+
+
+def side_legs(a, torch, nifs, L, device, main_ref):
+    """The other BASELINE configs, briefly, on the same box.  `main_ref` is
+    the resident N-row cosine index of the headline leg."""
+    side = {}
+    t0 = time.perf_counter()
+    # config 5: quantized_search on the resident cosine corpus (sign bits are built by the first call)
+    qs = normalized_queries(330, a.dim, SEED_QUERY + 5)
+    side["config5"] = dict(leg(a, L, nifs, main_ref, "quantized", qs, 300, 30, candidates=100),
+                           workload="quantized_search candidates=100 limit=10, d=%d, N=%d" % (a.dim, a.rows), dtype="u64")
+    # funnel_search (SURVEY 8f-2), prefix 128
+    qs = normalized_queries(110, a.dim, SEED_QUERY + 6)
+    side["funnel"] = dict(leg(a, L, nifs, main_ref, "funnel", qs, 100, 10, stages=(min(a.dim, 128),), candidates=100),
+                          workload="funnel_search stages=[%d] candidates=100 limit=10, d=%d, N=%d" % (min(a.dim, 128), a.dim, a.rows),
+                          dtype="f64")
+    # config 2: flat cosine top-10, N = 1M, single query
+    rows2 = min(1_000_000, a.rows)
+    x = build_shard(torch, device, rows2, a.dim, SEED_CORPUS + 2)
+    ref2 = nifs.flat_new_cosine()
+    nifs.flat_set_reduce_order(ref2, ORDER_CODE[a.reduce_order])
+    assert nifs.flat_load_device_matrix(ref2, doc_ids(0, rows2), x.data_ptr(), rows2, a.dim) == ("ok", ())
+    del x
+    qs = normalized_queries(1100, a.dim, SEED_QUERY + 2)
+    side["config2"] = dict(leg(a, L, nifs, ref2, "single", qs, 1000, 100),
+                           workload="index: :flat, metric: :cosine, d=%d, N=%d, single query" % (a.dim, rows2), dtype="f32")
+    del ref2
+    # config 3: dot, N rows, batches of 256 (rows scaled x U(8,24): no normalisation, collection.ex:1302, :1319)
+    x = build_shard(torch, device, a.rows, a.dim, SEED_CORPUS + 3)
+    x.mul_(torch.empty((a.rows, 1), device=device).uniform_(8.0, 24.0))
+    ref3 = nifs.flat_new_inner_product()
+    nifs.flat_set_reduce_order(ref3, ORDER_CODE[a.reduce_order])
+    assert nifs.flat_load_device_matrix(ref3, doc_ids(0, a.rows), x.data_ptr(), a.rows, a.dim) == ("ok", ())
+    del x
+    torch.cuda.empty_cache()
+    qs = np.random.default_rng(SEED_QUERY + 3).uniform(-1, 1, size=(7 * 256, a.dim)).astype(np.float32)
+    side["config3"] = dict(leg(a, L, nifs, ref3, "batch", qs, 5, 2, per=256),
+                           workload="index: :flat, metric: :dot, d=%d, N=%d, batch=256 queries (MFMA Q x D^T + exact rescoring)"
+                           % (a.dim, a.rows), dtype="f32")
+    del ref3
+    torch.cuda.empty_cache()
+    side["seconds"] = round(time.perf_counter() - t0, 1)
+    return side
 
 
 def main():
@@ -258,93 +369,133 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
+    launched = "WORLD_SIZE" in os.environ and world > 1
+    if launched:
         a.gpus = world
+    shards_in_process = a.gpus if not launched else 1   # one process, one handle over a.gpus devices
 
     import torch  # first: its bundled libamdhip64 must be the one the process shares
     import torch.distributed as dist
     from vettore_amd import nifs, _lib
     from vettore_amd.sharded import ShardedFlat
+    L = _lib.load()
 
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    use_dist = world > 1 or a.force_exchange
+    use_dist = launched or a.force_exchange
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     nifs.set_device(local_rank)
     if a.mode != "single":
-        if world > 1:
+        if a.gpus > 1:
             sys.exit("--mode %s is a single-GPU measurement" % a.mode)
         if a.mode == "batch" and a.steps == 200:
             a.steps, a.warmup = 8, 2
         return run_side_mode(a, torch, nifs, device)
 
-    # ---- corpus: this rank's row block of the N-row corpus ------------------
-    per = a.rows // world
-    start = rank * per
-    count = per if rank < world - 1 else a.rows - start
     t_build = time.perf_counter()
-    x = build_shard(torch, device, count, a.dim, SEED_CORPUS + rank)
-    ids = doc_ids(start, count)
-    ref = nifs.flat_new_cosine()
-    res = nifs.flat_load_device_matrix(ref, ids, x.data_ptr(), count, a.dim)
-    assert res == ("ok", ()), res
-    del x
-    torch.cuda.empty_cache()
-    sharded = ShardedFlat(ref, dist if use_dist else None, device, force_exchange=a.force_exchange)
-    if use_dist and os.environ.get("VT_HOST_EXCHANGE") is None:
-        # one ordering of all ids -> shard keys compare on the device (see vettore_amd/sharded.py)
-        sharded.enable_device_exchange(ids, max_limit=max(a.limit, 16))
+    rccl_ranks = 0
+    devices = [local_rank]
+    if shards_in_process > 1:
+        # ---- one process, one handle, N devices: rows go where the hash of their id says -------
+        ndev = torch.cuda.device_count()
+        devices = [int(v) for v in a.devices.split(",")] if a.devices else list(range(shards_in_process))
+        if len(devices) != shards_in_process or max(devices) >= ndev:
+            sys.exit("--gpus %d needs %d visible devices (or --devices with %d ordinals < %d)" % (
+                shards_in_process, shards_in_process, shards_in_process, ndev))
+        if a.exchange != "auto":
+            os.environ["VT_SHARD_EXCHANGE"] = a.exchange
+        ref = nifs.flat_new_sharded(nifs.METRIC_CODE["cosine"], devices)
+        nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
+        all_idx = np.arange(1, a.rows + 1, dtype=np.int64)
+        route = nifs.flat_route_ids(ref, doc_ids(0, a.rows))
+        for s in range(shards_in_process):
+            idx = all_idx[route == s]
+            dev_s = torch.device("cuda", devices[s])
+            with torch.cuda.device(dev_s):
+                x = build_shard(torch, dev_s, len(idx), a.dim, SEED_CORPUS + s)
+                res = nifs.flat_load_device_matrix(ref, doc_ids(0, 0, idx), x.data_ptr(), len(idx), a.dim)
+                assert res == ("ok", ()), res
+                del x
+                torch.cuda.empty_cache()
+        count = max(nifs.flat_shard_lens(ref))
+        rccl_ranks = nifs.flat_rccl_ranks(ref)
+        exchange = "rccl" if nifs.flat_exchange(ref) == _lib.EXCHANGE_RCCL else "host"
+        sharding = "one handle over %d devices (hash of id), %s exchange of per-shard top-k, merge by (rank key, id bytes)" % (
+            shards_in_process, exchange)
+        sharded = None
+    else:
+        # ---- this rank's row block of the N-row corpus (one device per process) ----------------
+        per = a.rows // world
+        start = rank * per
+        count = per if rank < world - 1 else a.rows - start
+        x = build_shard(torch, device, count, a.dim, SEED_CORPUS + rank)
+        ids = doc_ids(start, count)
+        ref = nifs.flat_new_cosine()
+        nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
+        res = nifs.flat_load_device_matrix(ref, ids, x.data_ptr(), count, a.dim)
+        assert res == ("ok", ()), res
+        del x
+        torch.cuda.empty_cache()
+        sharded = ShardedFlat(ref, dist if use_dist else None, device, force_exchange=a.force_exchange)
+        if use_dist and os.environ.get("VT_HOST_EXCHANGE") is None:
+            # one ordering of all ids -> shard keys compare on the device (see vettore_amd/sharded.py)
+            sharded.enable_device_exchange(ids, max_limit=max(a.limit, 16))
+        if use_dist:
+            rccl_ranks = dist.get_world_size()
+        sharding = ("row blocks, one rank per GPU, all_gather of per-shard top-k (%s merge)" % ("device" if sharded._dev else "host")) \
+            if use_dist else "none"
 
-    qrng = np.random.default_rng(SEED_QUERY)
     nq = a.steps + a.warmup
-    qs = qrng.uniform(-1, 1, size=(nq, a.dim)).astype(np.float32)
-    qs /= np.linalg.norm(qs.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
-    # first search also sorts the ids (id-rank column) -- setup, not a step
-    sharded.search(qs[0], a.limit)
+    qs = normalized_queries(nq, a.dim, SEED_QUERY)
+    hp = C.c_void_p()
+
+    def search_c(q):
+        # the step is the C-ABI call itself (the hit list is freed, not unpacked into Python
+        # objects -- a NIF would build BEAM terms here)
+        st = L.vt_flat_search(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), a.dim, a.limit, C.byref(hp))
+        assert st == 0, st
+        n_hits = L.vt_hits_len(hp)
+        L.vt_hits_free(hp)
+        return range(n_hits)
+
+    search = (lambda q: sharded.search(q, a.limit)) if (sharded is not None and use_dist) else search_c  # noqa: E731
+    # first search also settles the id ranks -- setup, not a step
+    search(qs[0])
     t_build = time.perf_counter() - t_build
 
     def sync():
-        if world > 1:
+        if launched:
             dist.barrier()
+        for dv in (set(devices) if shards_in_process > 1 else ()):
+            torch.cuda.synchronize(dv)
         torch.cuda.synchronize()
 
-    if use_dist:
-        search = lambda q: sharded.search(q, a.limit)  # noqa: E731
-    else:
-        # one rank, no exchange: the step is the C-ABI call itself (the hit list is
-        # freed, not unpacked into Python objects -- a NIF would build BEAM terms here)
-        L = _lib.load()
-        hp = C.c_void_p()
+    def timed_run():
+        for i in range(a.warmup):
+            search(qs[i])
+        nifs.flat_set_profiling(ref, True)
+        nifs.flat_get_profile(ref, reset=True)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(a.warmup, nq):
+            hits = search(qs[i])
+        sync()
+        dt = time.perf_counter() - t0
+        prof = nifs.flat_get_profile(ref, reset=True)
+        nifs.flat_set_profiling(ref, False)
+        assert len(hits) == min(a.limit, a.rows)
+        return dt, prof
 
-        def search(q):
-            st = L.vt_flat_search(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), a.dim, a.limit, C.byref(hp))
-            assert st == 0, st
-            n_hits = L.vt_hits_len(hp)
-            L.vt_hits_free(hp)
-            return range(n_hits)
-
-    for i in range(a.warmup):
-        search(qs[i])
-    nifs.flat_set_profiling(ref, True)
-    nifs.flat_get_profile(ref, reset=True)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.warmup, nq):
-        hits = search(qs[i])
-    sync()
-    dt = time.perf_counter() - t0
-    prof = nifs.flat_get_profile(ref, reset=True)
-    if world > 1:
+    dt, prof = timed_run()
+    if launched:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert len(hits) == min(a.limit, a.rows)
 
+    out = None
     if rank == 0:
         qps = a.steps / dt
         scan_ms = prof["scan_ms"] / max(1, prof["scan_launches"])
@@ -354,7 +505,7 @@ def main():
             "metric": "queries/sec, flat cosine top-%d, N=%d d=%d (achieved HBM GB/s in roofline)" % (a.limit, a.rows, a.dim),
             "value": qps,
             "unit": "queries/s",
-            "n_gpus": world,
+            "n_gpus": a.gpus,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
@@ -363,12 +514,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "rccl_ranks": rccl_ranks,
             "config": {
                 "workload": "index: :flat, metric: :cosine, d=%d, N=%d, limit=%d, single query in flight" % (a.dim, a.rows, a.limit),
                 "rows_per_gpu": count,
-                "reduce_order": "pair",
-                "sharding": ("row blocks, all_gather of per-shard top-k (%s merge)" % ("device" if sharded._dev else "host"))
-                if use_dist else "none",
+                "reduce_order": a.reduce_order,
+                "sharding": sharding,
+                "processes": world,
                 "setup_s": round(t_build, 1),
             },
             "roofline": {
@@ -385,7 +537,15 @@ def main():
                 "frac_of_measured_read_peak": (achieved / measured_read_peak()) if measured_read_peak() else None,
             },
         }
-        if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
+        if shards_in_process > 1 and rccl_ranks:
+            # the same steps over the other exchange, for comparison (not the headline)
+            assert nifs.flat_set_exchange(ref, _lib.EXCHANGE_HOST) == "ok"
+            dt2, _ = timed_run()
+            out["config"]["host_exchange_ms_per_step"] = dt2 / a.steps * 1e3
+            assert nifs.flat_set_exchange(ref, _lib.EXCHANGE_RCCL) == "ok"
+        if a.gpus == 1 and not launched and not a.no_side:
+            out["side"] = side_legs(a, torch, nifs, L, device, ref)
+        if a.gpus == 1 and not launched and not a.no_cpu and a.cpu_seconds > 0:
             cb = cpu_baseline(a.dim, a.limit, a.cpu_seconds)
             out["cpu_baseline"] = {
                 "value": cb["rows_per_s_T"] / a.rows,

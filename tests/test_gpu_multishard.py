@@ -278,3 +278,24 @@ def test_many_readers_and_a_writer_on_one_handle(nifs, oracle_mod):
     for th in ths:
         th.join()
     assert not errors, errors[:3]
+
+
+def test_bench_runs_as_the_driver_invokes_it_for_two_gpus():
+    """`python bench.py --gpus 2` with no launcher: one process, one handle over
+    two shards -- both on device 0 here (--devices 0,0), the box has one GPU -- and ONE JSON line
+    last, n_gpus = 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--devices", "0,0", "--rows", "200000",
+                          "--dim", "64", "--steps", "20", "--warmup", "3", "--no-cpu"], capture_output=True, text=True,
+                         env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["value"] > 0
+    assert "one handle over 2 devices" in line["config"]["sharding"] and line["config"]["processes"] == 1
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == line["config"]["rows_per_gpu"] * 64 * 4 or \
+        abs(line["roofline"]["algorithmic_bytes_per_launch"] - 100000 * 64 * 4) < 0.05 * 100000 * 64 * 4
