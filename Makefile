@@ -10,7 +10,12 @@ LIBDIR  := vettore_amd/lib
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
             -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function
 
-DEVSRC  := vt_kernels vt_batch vt_scan_dot vt_scan_l2 vt_scan_misc vt_scan_general
+# make EXPERIMENTS=1: K2's timing switches (VT_BATCH_DEBUG, tools/batch_debug.sh) are compiled in
+ifdef EXPERIMENTS
+HIPFLAGS += -DVT_BATCH_TIMING_EXPERIMENTS
+endif
+
+DEVSRC  := vt_kernels vt_batch vt_scan_dot vt_scan_l2 vt_scan_misc vt_scan_general vt_scan_multi
 DEVOBJ  := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(DEVSRC)))
 DEVHDR  := $(CSRC)/vt_device.h $(CSRC)/vt_common.cuh $(CSRC)/vt_scan.cuh
 

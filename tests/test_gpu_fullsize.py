@@ -139,3 +139,48 @@ def test_full_size_results_against_torch_brute_force(corpus, oracle_mod):
         want = set(torch.topk(keys, 100, largest=False).indices.tolist())
         assert {int(i[4:]) - 1 for i, _ in qhits} == want
     del ref
+
+
+def test_config3_shape_dot_batch_equals_single_queries(corpus, oracle_mod):
+    """configs[2] at its own shape: metric :dot on UN-normalised rows
+    (the bench's `--mode batch` corpus: rows x U(8,24)), N=10M, d=768, ONE batch of 256 on the
+    `mfma_scores_kernel<8,...>` instance, where the acceptance bound eps ~ d |q| X actually
+    bites -- every query's hits equal its own flat_search bit for bit, the number of queries
+    the bound could not certify is reported, and a sample is checked against an f64 brute
+    force over all rows."""
+    torch, nifs, x, doc_ids, host = corpus
+    g = torch.Generator(device=x.device)
+    g.manual_seed(33)
+    scale = torch.empty((N, 1), device=x.device).uniform_(8.0, 24.0, generator=g)
+    x.mul_(scale)
+    try:
+        ref = _index(nifs, nifs.flat_new_inner_product, x, doc_ids, 0, N)
+        qs = np.random.default_rng(20260722).uniform(-1, 1, size=(256, D)).astype(np.float32)
+        nifs.flat_set_profiling(ref, True)
+        nifs.flat_get_profile(ref, reset=True)
+        st, batch = nifs.flat_search_batch(ref, qs, 10)
+        assert st == "ok" and len(batch) == 256
+        prof = nifs.flat_get_profile(ref, reset=True)
+        print("config3 shape: batch_queries=%d fallbacks=%d" % (prof["batch_queries"], prof["batch_fallbacks"]))
+        assert prof["batch_queries"] == 256 and prof["batch_launches"] == 1
+        assert prof["batch_fallbacks"] <= 8          # the bound certifies (nearly) every query of this workload
+        for i in range(256):
+            single = nifs.flat_search(ref, qs[i], 10)[1]
+            assert [(h[0], np.float32(h[1]).tobytes()) for h in batch[i]] == \
+                   [(h[0], np.float32(h[1]).tobytes()) for h in single], i
+        for i in (0, 100, 255):                       # independent f64 scores of the hits, true top-10 up to near-ties
+            qd = torch.from_numpy(qs[i]).to(x.device)
+            approx = x @ qd
+            cand = torch.topk(approx, 2000).indices
+            exact = x[cand].double() @ qd.double()
+            top = torch.topk(exact, 10)
+            true_rows = set(cand[top.indices].tolist())
+            kth = float(top.values[-1])
+            got_rows = [int(h[0][4:]) - 1 for h in batch[i]]
+            for (id_, raw), row in zip(batch[i], got_rows):
+                assert support.close(raw, float(x[row].double() @ qd.double()), 1e-5)
+            for row in true_rows - set(got_rows):
+                assert abs(float(x[row].double() @ qd.double()) - kth) <= 1e-5 * max(1.0, abs(kth))
+        del ref
+    finally:
+        x.div_(scale)   # the fixture is shared (module scope); later tests see (almost) the same rows again

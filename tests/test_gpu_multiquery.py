@@ -1,0 +1,106 @@
+"""K1m (vt_scan_multi.hip): several queries per sweep of the corpus, exact arithmetic, all nine
+metrics -- `-m gpu`.  Every query of a batch must get the hits its own flat_search gets, bit for
+bit (ids, order, raw), which the oracle pins in turn."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import GpuError, GpuIndex, bits, make_corpus, nifs, unwrap  # noqa: F401  (nifs is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def no_matrix_cores(monkeypatch):
+    # dot-family batches would otherwise take the shared MFMA pass: here K1m serves every metric
+    monkeypatch.setenv("VT_BATCH_NO_MFMA", "1")
+
+
+@pytest.mark.parametrize("metric", range(9))
+def test_multi_query_scan_equals_single_queries_all_metrics(nifs, oracle_mod, metric):
+    rng = np.random.default_rng(40 + metric)
+    for d in (7, 24, 100, 256, 384, 1000):
+        n = 6000 if d >= 384 else 12000
+        x, ids = make_corpus(n, d, 700 + metric + d, metric == 2, oracle_mod, tie_block=40)
+        if metric in (7, 8):                       # float hamming / jaccard: zeros must occur
+            x[rng.uniform(size=x.shape) < 0.3] = 0.0
+        packed = oracle_mod.pack_ids(ids)
+        for order in ((3,) if d != 100 else (0, 1, 2, 3)):
+            oracle_mod.set_reduce_order(order)
+            try:
+                g = GpuIndex(nifs, metric, order)
+                unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+                nifs.flat_set_profiling(g.ref, True)
+                for nq, k in ((2, 10), (3, 1), (5, 32), (8, 10), (9, 7), (17, 10)):
+                    qs = rng.uniform(-1, 1, size=(nq, d)).astype(np.float32)
+                    qs[0] = x[n // 2]                  # sits on the block of identical rows
+                    if metric in (7, 8):
+                        qs[rng.uniform(size=qs.shape) < 0.3] = 0.0
+                    if metric == 2:
+                        qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+                    nifs.flat_get_profile(g.ref, reset=True)
+                    got = unwrap(nifs.flat_search_batch(g.ref, qs, k))
+                    prof = nifs.flat_get_profile(g.ref, reset=True)
+                    assert prof["scan_launches"] == (nq + 7) // 8, (prof, nq)   # sweeps, not nq scans
+                    for i in range(nq):
+                        assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, x, packed, qs[i], k)), (metric, d, order, nq, k, i)
+                # a limit the small wave buffers cannot hold goes query by query, same answers
+                qs = rng.uniform(-1, 1, size=(3, d)).astype(np.float32)
+                if metric == 2:
+                    qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+                got = unwrap(nifs.flat_search_batch(g.ref, qs, 40))
+                for i in range(3):
+                    assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, x, packed, qs[i], 40))
+            finally:
+                oracle_mod.set_reduce_order(oracle_mod.DEFAULT_ORDER)
+
+
+def test_multi_query_scan_overflow_and_recovery(nifs, oracle_mod):
+    """distances.rs:59-67 inside a sweep: an f32 sum that overflows is recomputed in f64 for
+    that (query, row) pair alone; one that stays unrepresentable fails the call with 'metric
+    overflow', as the query's own flat_search would."""
+    n, d = 3000, 40
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    x[17] = 1e20                                       # L2 to an ordinary query: sum of squares overflows f32, sqrt does not
+    ids = [b"r%04d" % i for i in range(n)]
+    packed = oracle_mod.pack_ids(ids)
+    g = GpuIndex(nifs, 0)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    qs = rng.uniform(-1, 1, (6, d)).astype(np.float32)
+    got = unwrap(nifs.flat_search_batch(g.ref, qs, n)) if False else unwrap(nifs.flat_search_batch(g.ref, qs, 32))
+    for i in range(6):
+        assert bits(got[i]) == bits(oracle_mod.matrix_search(0, x, packed, qs[i], 32))
+    far = np.full(d, -1e20, np.float32)                # this query makes row 17's distance recoverable and LARGE: it is last
+    qs2 = np.stack([qs[0], far, qs[1]])
+    got = unwrap(nifs.flat_search_batch(g.ref, qs2, 5))
+    for i in range(3):
+        assert bits(got[i]) == bits(oracle_mod.matrix_search(0, x, packed, qs2[i], 5))
+    # squared L2 of the same pair is not representable: the batch reports it
+    g2 = GpuIndex(nifs, 1)
+    unwrap(nifs.flat_load_matrix(g2.ref, ids, x))
+    assert nifs.flat_search_batch(g2.ref, qs, 5) == ("error", "metric overflow")
+    with pytest.raises(oracle_mod.OracleError, match="metric overflow"):
+        oracle_mod.matrix_search(1, x, packed, qs[0], 5)
+
+
+def test_multi_query_scan_at_config_shape(nifs, oracle_mod):
+    """d = 768 (three panels per row), N = 1M, a batch of 16 under manhattan (no GEMM form): two
+    sweeps instead of sixteen scans, each query equal to its single search."""
+    import torch
+    from bench import build_shard, doc_ids
+    rows, dim = 1_000_000, 768
+    x = build_shard(torch, torch.device("cuda", 0), rows, dim, 77)
+    g = GpuIndex(nifs, 5)
+    assert nifs.flat_load_device_matrix(g.ref, doc_ids(0, rows), x.data_ptr(), rows, dim) == ("ok", ())
+    host = x[:4].cpu().numpy()
+    del x
+    qs = np.random.default_rng(1).uniform(-1, 1, (16, dim)).astype(np.float32)
+    qs[:4] = host
+    nifs.flat_set_profiling(g.ref, True)
+    nifs.flat_get_profile(g.ref, reset=True)
+    got = unwrap(nifs.flat_search_batch(g.ref, qs, 10))
+    assert nifs.flat_get_profile(g.ref, reset=True)["scan_launches"] == 2
+    for i in range(16):
+        assert bits(got[i]) == bits(unwrap(nifs.flat_search(g.ref, qs[i], 10))), i
+    for i in range(4):
+        assert got[i][0] == (b"doc-%d" % (i + 1), 0.0)

@@ -214,6 +214,55 @@ def test_search_rs_vector_top_k_full_grid_bitwise(nifs, oracle_mod):
                 assert bits(got) == bits(want), (name, dims, limit)
 
 
+def test_distances_rs_packed_word_boundaries_on_device(nifs):
+    """distances.rs:675-707 through binary_top_k on the GPU: dims {1,63,64,65,127,128,129}, the
+    tail word of one row filled with dirty padding bits -- the distance counts only the
+    flipped coordinates (word_mask, distances.rs:459-481)."""
+    c = load("distances_rs.json")["packed_distances_cover_word_boundaries_and_ignore_padding"]
+    full = (1 << 64) - 1
+    for dims in c["dimensions"]:
+        words = (dims + 63) // 64
+        left = [full] * words
+        right = list(left)
+        flipped = [0] + ([dims - 1] if dims > 1 else [])
+        for coord in flipped:
+            right[coord // 64] ^= 1 << (coord % 64)
+        if dims % 64:
+            used = (1 << (dims % 64)) - 1
+            right[words - 1] ^= (~used) & full           # dirty padding
+        got = unwrap(nifs.binary_top_k([("same", left), ("flipped", right)], left, dims, 2))
+        assert got == [(b"same", 0.0), (b"flipped", float(len(flipped)))], dims
+        # dirty padding in the QUERY must be ignored as well
+        got = unwrap(nifs.binary_top_k([("same", left), ("flipped", right)], right, dims, 2))
+        assert got == [(b"flipped", 0.0), (b"same", float(len(flipped)))], dims
+    res = nifs.binary_top_k([("a", [])], [], 1, 1)        # distances.rs:704-706: no words for 1 dimension
+    assert res == ("error", "dimension mismatch")
+
+
+def test_distances_rs_cosine_edge_cases_on_device(nifs, oracle_mod):
+    """distances.rs:637-673 (`cosine`: f64 dot / f64 norms, clamp, zero norm => 0.0) through
+    vector_top_k(metric = cosine) on the GPU, search.rs:56-60."""
+    c = load("distances_rs.json")["cosine_and_normalization_obey_numerical_invariants"]
+    for l, r, want, tol in c["cosine_close"]:
+        got = unwrap(nifs.vector_top_k([("x", r)], l, 2, len(l), 1))
+        assert got[0][0] == b"x" and close(got[0][1], want, tol)
+        assert same_f32(got[0][1], oracle_mod.cosine(l, r))
+    # zero norm on either side => 0.0 (distances.rs:168-170)
+    for l, r in (([0.0, 0.0], [1.0, 2.0]), ([1.0, 2.0], [0.0, 0.0]), ([0.0], [0.0])):
+        got = unwrap(nifs.vector_top_k([("z", r)], l, 2, len(l), 1))
+        assert same_f32(got[0][1], 0.0) and same_f32(got[0][1], oracle_mod.cosine(l, r))
+    # dimension mismatch: a row shorter than the prefix (search.rs:49-55)
+    l, r, msg = c["cosine_errors"][0]
+    assert nifs.vector_top_k([("short", l)], r, 2, len(r), 1) == ("error", msg)
+    for bad in c["non_finite"]:
+        assert nifs.vector_top_k([("x", [1.0])], [bad], 2, 1, 1) == ("error", "vector contains a non-finite value")
+        assert nifs.vector_top_k([("x", [bad])], [1.0], 2, 1, 1) == ("error", "vector contains a non-finite value")
+    # the clamp: parallel vectors whose f64 quotient lands a hair above 1.0
+    v = [0.1, 0.2, 0.3, 0.7]
+    got = unwrap(nifs.vector_top_k([("p", [3.0 * t for t in v])], v, 2, 4, 1))
+    assert got[0][1] <= 1.0 and same_f32(got[0][1], oracle_mod.cosine(v, [3.0 * t for t in v]))
+
+
 def test_search_rs_binary_top_k(nifs, oracle_mod):
     d = load("search_rs.json")
     c = d["binary_top_k_masks_padding_and_orders_ids"]

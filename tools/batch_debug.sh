@@ -1,6 +1,7 @@
 #!/bin/bash
 # K2 timing experiments: VT_BATCH_DEBUG bits -- 2: no per-chunk barrier, 4: no per-chunk waits,
 # 8: no candidate append (results are invalid with any bit set; only the kernel time is meaningful).
+# Needs a library built with `make clean && make EXPERIMENTS=1`: the product build ignores VT_BATCH_DEBUG.
 ROWS=${ROWS:-10000000}
 for d in ${DEBUGS:-0 8 6 14}; do
   echo "debug=$d"; VT_BATCH_DEBUG=$d timeout 300 python bench.py --mode batch --rows $ROWS --steps 3 --warmup 1 --no-cpu 2>&1 | tail -1 | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['roofline']['achieved'], j['roofline']['avg_launch_ms'])"

@@ -85,6 +85,31 @@ size_t hamming_lds_bytes(uint32_t k);
 // Partial lists a launch with `blocks` blocks produces (one per block).
 inline uint32_t scan_lists(uint32_t blocks) { return blocks; }
 hipError_t launch_scan(const ScanArgs &a, uint32_t blocks, hipStream_t s);
+
+// K1m (vt_scan_multi.hip): the same scan for up to kMultiMaxQueries queries in ONE sweep of
+// the corpus, exact arithmetic, any metric; contiguous rows only.  Block b leaves query q's
+// list at part_keys/part_pay[((first_query + q) * grid_blocks + b) * k ..) -- the layout
+// launch_batch_select reads.
+constexpr uint32_t kMultiMaxQueries = 8;
+struct MultiScanArgs {
+  const float *X;
+  size_t stride;
+  const float *Q;           // [nq][ld] queries, zero padded (device)
+  const uint32_t *id_rank;
+  uint32_t n, d, ld;        // ld = padded_dim(d)
+  int metric, order;
+  uint32_t k;               // <= scan_multi_max_k(nq)
+  uint32_t nq;              // queries of this launch, 1..kMultiMaxQueries
+  uint32_t first_query;     // index of Q[0] among the lists of the whole batch
+  uint32_t q_nonzero[kMultiMaxQueries];
+  uint64_t *part_keys;
+  Payload *part_pay;
+  int *status;
+};
+uint32_t scan_multi_max_k(uint32_t nq);       // 64 for up to 4 queries per sweep, 32 for up to 8
+uint32_t scan_multi_tile_rows(uint32_t nq);   // rows per wave tile (grid sizing)
+size_t scan_multi_lds_bytes(uint32_t nq);
+hipError_t launch_scan_multi(const MultiScanArgs &a, uint32_t blocks, hipStream_t s);
 // Batch mode: `blocks` per query x `nq` queries.
 hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hipStream_t s);
 
@@ -129,6 +154,11 @@ hipError_t launch_sort_list(const uint64_t *keys, const Payload *pay, uint32_t m
 constexpr uint32_t kSelListMax = 4096;
 hipError_t launch_select_list(const uint64_t *keys, const Payload *pay, uint32_t m, const uint32_t *m_dev, uint32_t k,
                               uint64_t *out_keys, Payload *out_pay, hipStream_t s);
+// One radix select per query in ONE launch (grid.y = queries): query y's list is keys/pay[y * m ..
+// (y + 1) * m), its winners land, sorted, in the block at out + y * out_stride bytes
+// ({i32 status = 0, u32 count, pad[2]} + k entries).
+hipError_t launch_select_queries(const uint64_t *keys, const Payload *pay, uint32_t nq, uint32_t m, uint32_t k, void *out,
+                                 uint32_t out_stride, hipStream_t s);
 constexpr uint32_t kSelGroups = 16;
 constexpr uint32_t kSelTwoLevelMin = 16384;
 hipError_t launch_select(const uint64_t *keys, const Payload *pay, uint32_t m, uint32_t k, uint64_t lo_key, int has_lo,

@@ -594,7 +594,10 @@ constexpr int kRetryInternal = -100;
 // to choose between equivalent code paths: one fused scan of `bytes`, and the fixed cost
 // the multi-kernel paths add on top of their scans.
 constexpr double kScanFixedS = 35e-6, kScanBytesPerS = 6.5e12;
-constexpr double kThresholdFixedS = 140e-6, kBatchFixedS = 300e-6, kBatchFlopsPerS = 135e12;
+constexpr double kThresholdFixedS = 140e-6, kBatchFixedS = 180e-6, kBatchFlopsPerS = 135e12;
+// K1m: one sweep carries up to 8 queries at about the byte rate of the single scan; a chain of
+// sweeps pays the call's fixed cost once
+constexpr double kMultiFixedS = 60e-6, kMultiSweepFixedS = 8e-6, kMultiBytesPerS = 4.2e12;
 inline double scan_seconds(double bytes) { return kScanFixedS + bytes / kScanBytesPerS; }
 
 // ------------------------------------------------------------------ selection
@@ -1839,6 +1842,94 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   return VT_OK;
 }
 
+// K1m serves a batch when every query's list fits its small wave buffers.
+bool multi_scan_applies(const Shard *ix, size_t limit) {
+  return limit >= 1 && std::min<size_t>(limit, ix->n) <= vt::scan_multi_max_k(vt::kMultiMaxQueries) &&
+         !(ix->metric == VT_JACCARD && ix->dim >= 4096) && std::getenv("VT_NO_MULTI_SCAN") == nullptr;
+}
+double multi_scan_seconds(size_t nq, double bytes) {
+  const double sweeps = std::ceil((double)nq / vt::kMultiMaxQueries);
+  return kMultiFixedS + sweeps * (kMultiSweepFixedS + bytes / kMultiBytesPerS);
+}
+
+// `count` queries (rows `which[i]` of `queries`) in ceil(count / 8) sweeps of the corpus (K1m),
+// every sweep and one batched select queued before the single wait.  Ranks strictly current.
+int multi_scan_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size_t> &which, size_t limit, vt_hits **out) {
+  const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
+  const uint32_t k = (uint32_t)std::min<size_t>(limit, n);
+  const size_t nq = which.size();
+  const size_t lds = vt::scan_multi_lds_bytes(vt::kMultiMaxQueries);
+  const uint32_t ntiles = (n + vt::scan_multi_tile_rows(vt::kMultiMaxQueries) - 1) / vt::scan_multi_tile_rows(vt::kMultiMaxQueries);
+  const uint32_t blocks = c.grid_for(ntiles, lds);
+  // (a sweep always reads a full group of query rows: the last group is padded with zero rows)
+  const size_t nq_pad = (nq + vt::kMultiMaxQueries - 1) / vt::kMultiMaxQueries * vt::kMultiMaxQueries;
+  VT_TRY(c.dBQ.ensure(nq_pad * ld));
+  VT_TRY(c.hBQ.ensure(nq_pad * ld));
+  VT_TRY(c.dPartKeys.ensure(nq * blocks * k));
+  VT_TRY(c.dPartPay.ensure(nq * blocks * k));
+  // per query a packed result block: 16-byte header + k entries (Entry is 16 bytes)
+  const uint32_t out_stride = 16 + k * (uint32_t)sizeof(vt::Entry);
+  VT_TRY(c.dBOut.ensure(nq * (k + 1)));
+  VT_TRY(c.hBOut.ensure(nq * (k + 1)));
+  std::memset(c.hBQ.p, 0, nq_pad * ld * sizeof(float));
+  std::vector<uint32_t> qnz(nq, 0);
+  for (size_t i = 0; i < nq; ++i) {
+    const float *q = queries + which[i] * d;
+    std::memcpy(c.hBQ.p + i * ld, q, (size_t)d * sizeof(float));
+    for (uint32_t j = 0; j < d; ++j) qnz[i] += q[j] != 0.0f ? 1u : 0u;
+  }
+  VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+  uint32_t sweeps = 0;
+  for (size_t g0 = 0; g0 < nq; g0 += vt::kMultiMaxQueries, ++sweeps) {
+    const uint32_t gn = (uint32_t)std::min<size_t>(vt::kMultiMaxQueries, nq - g0);
+    vt::MultiScanArgs a{};
+    a.X = ix->dX;
+    a.stride = ix->ld;
+    a.Q = c.dBQ.p + g0 * ld;
+    a.id_rank = ix->dRank.p;
+    a.n = n;
+    a.d = d;
+    a.ld = ld;
+    a.metric = ix->metric;
+    a.order = ix->order;
+    a.k = k;
+    a.nq = gn;
+    a.first_query = (uint32_t)g0;
+    for (uint32_t i = 0; i < gn; ++i) a.q_nonzero[i] = qnz[g0 + i];
+    a.part_keys = c.dPartKeys.p;
+    a.part_pay = c.dPartPay.p;
+    a.status = c.dStatus.p;
+    VT_HIP(vt::launch_scan_multi(a, blocks, c.stream));
+  }
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+  VT_HIP(vt::launch_select_queries(c.dPartKeys.p, c.dPartPay.p, (uint32_t)nq, blocks * k, k, c.dBOut.p, out_stride, c.stream));
+  int status = 0;
+  VT_HIP(hipMemcpyAsync(c.hBOut.p, c.dBOut.p, nq * out_stride, hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(&status, c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  if (c.profiling) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    c.prof.scan_launches += sweeps;
+    c.prof.scan_ms += ms;
+    c.prof.scan_rows += (uint64_t)sweeps * n;
+    c.prof.scan_bytes += (uint64_t)sweeps * n * d * 4;
+  }
+  // "metric overflow" belongs to one query (flat.rs:105): the single-query path finds out whose
+  if (status != 0) return kRetryInternal;
+  for (size_t i = 0; i < nq; ++i) {
+    const vt::Entry *blk = c.hBOut.p + i * (k + 1);  // [0] is the header
+    uint32_t got = 0;
+    std::memcpy(&got, reinterpret_cast<const unsigned char *>(blk) + 4, 4);
+    got = std::min<uint32_t>(got, k);
+    std::vector<vt::Entry> entries(blk + 1, blk + 1 + got);
+    VT_TRY(make_hits(ix, entries, &out[which[i]]));
+  }
+  return VT_OK;
+}
+
 // True when a batch of nq queries takes the shared MFMA pass (and so needs the row norms).
 bool batch_uses_mfma(const Shard *ix, size_t nq, size_t limit) {
   const bool mfma_metric = ix->metric == VT_COSINE || ix->metric == VT_INNER_PRODUCT ||
@@ -1854,7 +1945,9 @@ bool batch_uses_mfma(const Shard *ix, size_t nq, size_t limit) {
     while (nq_pad < (double)std::min<size_t>(nq, 256)) nq_pad *= 2;
     const double groups = std::ceil((double)nq / 256.0);
     const double t_pass = std::max(1.3 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kBatchFlopsPerS);
-    use_mfma = (double)nq * scan_seconds(bytes) > groups * (kBatchFixedS + t_pass);
+    double t_other = (double)nq * scan_seconds(bytes);
+    if (multi_scan_applies(ix, limit)) t_other = std::min(t_other, multi_scan_seconds(nq, bytes));
+    use_mfma = t_other > groups * (kBatchFixedS + t_pass);
   }
   return use_mfma;
 }
@@ -1882,11 +1975,24 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
       for (size_t i = 0; i < gn; ++i) done[g0 + i] = gdone[i];
     }
   }
-  for (size_t i = 0; i < nq; ++i) {
-    if (done[i]) continue;
-    c.prof.batch_fallbacks += use_mfma ? 1 : 0;
-    VT_TRY(search_ready(ix, c, queries + i * d, d, limit, &out[i]));
+  std::vector<size_t> left;
+  for (size_t i = 0; i < nq; ++i)
+    if (!done[i]) left.push_back(i);
+  c.prof.batch_fallbacks += use_mfma ? left.size() : 0;
+  // what the matrix cores did not take (no GEMM form for this metric, a small batch, a query
+  // the bound could not certify): several queries per sweep of the corpus when their lists
+  // fit, else one scan each
+  if (left.size() >= 2 && multi_scan_applies(ix, limit) &&
+      multi_scan_seconds(left.size(), (double)ix->n * ix->ld * 4.0) < (double)left.size() * scan_seconds((double)ix->n * ix->ld * 4.0)) {
+    const int st = multi_scan_group(ix, c, queries, left, limit, out);
+    if (st == VT_OK) return VT_OK;
+    if (st != kRetryInternal) return st;
+    for (size_t i : left) {  // an overflow somewhere: one by one, so that it is reported for its own query's position
+      delete out[i];
+      out[i] = nullptr;
+    }
   }
+  for (size_t i : left) VT_TRY(search_ready(ix, c, queries + i * d, d, limit, &out[i]));
   return VT_OK;
 }
 

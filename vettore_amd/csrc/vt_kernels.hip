@@ -79,9 +79,16 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
                                                            ResultBlock *out, uint32_t slice,
                                                            uint64_t *__restrict__ part_keys,
                                                            Payload *__restrict__ part_pay,
-                                                           const uint32_t *__restrict__ m_dev) {
+                                                           const uint32_t *__restrict__ m_dev, uint32_t out_stride) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (m_dev) m = *m_dev < m ? *m_dev : m;  // list length decided on the device (hamming_collect_kernel)
+  if (gridDim.y > 1) {
+    // one list of m keys per query (grid.y = queries): query y's winners go to the block
+    // `out_stride` bytes after query y - 1's (header + k entries when packed tightly)
+    keys += (size_t)blockIdx.y * m;
+    pay += (size_t)blockIdx.y * m;
+    out = reinterpret_cast<ResultBlock *>(reinterpret_cast<unsigned char *>(out) + (size_t)blockIdx.y * out_stride);
+  }
   // part_keys != nullptr: the winners go, unsorted and padded with kEmptyKey, to
   // part_keys/part_pay[blockIdx.x * k ..) instead of a result block -- the first level of
   // a two-level select (several blocks, one slice each) or a device-resident list of up to
@@ -1086,7 +1093,19 @@ hipError_t launch_select_list(const uint64_t *keys, const Payload *pay, uint32_t
   hipError_t e = allow_lds(select_topk_kernel, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(select_topk_kernel, dim3(1), dim3(1024), lds, s, keys, pay, m, k, 0ull, 0, nullptr, nullptr, 0u,
-                     out_keys, out_pay, m_dev);
+                     out_keys, out_pay, m_dev, 0u);
+  return hipGetLastError();
+}
+
+hipError_t launch_select_queries(const uint64_t *keys, const Payload *pay, uint32_t nq, uint32_t m, uint32_t k, void *out,
+                                 uint32_t out_stride, hipStream_t s) {
+  if (k == 0 || k > (uint32_t)kMaxFusedK || nq == 0 || nq > 65535 || out_stride < 16 + k * sizeof(Entry) || out_stride % 16)
+    return hipErrorInvalidValue;
+  const size_t lds = ((size_t)k + kSelCand) * 12;
+  hipError_t e = allow_lds(select_topk_kernel, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(select_topk_kernel, dim3(1, nq), dim3(1024), lds, s, keys, pay, m, k, 0ull, 0, nullptr,
+                     static_cast<ResultBlock *>(out), 0u, nullptr, nullptr, nullptr, out_stride);
   return hipGetLastError();
 }
 
@@ -1100,13 +1119,13 @@ hipError_t launch_select(const uint64_t *keys, const Payload *pay, uint32_t m, u
     // parallel on slices, one block finishes on kSelGroups * k keys
     const uint32_t slice = (m + kSelGroups - 1) / kSelGroups;
     hipLaunchKernelGGL(select_topk_kernel, dim3(kSelGroups), dim3(1024), lds, s, keys, pay, m, k, lo_key, has_lo,
-                       dev_status, out, slice, scratch_keys, scratch_pay, nullptr);
+                       dev_status, out, slice, scratch_keys, scratch_pay, nullptr, 0u);
     hipLaunchKernelGGL(select_topk_kernel, dim3(1), dim3(1024), lds, s, scratch_keys, scratch_pay, kSelGroups * k, k,
-                       0ull, 0, dev_status, out, 0u, nullptr, nullptr, nullptr);
+                       0ull, 0, dev_status, out, 0u, nullptr, nullptr, nullptr, 0u);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(select_topk_kernel, dim3(1), dim3(1024), lds, s, keys, pay, m, k, lo_key, has_lo, dev_status, out,
-                     0u, nullptr, nullptr, m_dev);
+                     0u, nullptr, nullptr, m_dev, 0u);
   return hipGetLastError();
 }
 

@@ -1,0 +1,404 @@
+// vt_scan_multi.hip -- K1m: the flat scan for SEVERAL queries in one sweep of the corpus,
+// exact reference arithmetic, any metric (gfx950).
+//
+// Replaces NQ runs of the loop of FlatIndex::search (native/vettore/src/flat.rs:104-118).
+// Every (query, row) value is computed exactly as K1 computes it (vt_scan.cuh): eight
+// separately rounded products per 8-float chunk, one horizontal add in the selected lane
+// order of wide::f32x8::reduce_add, `acc += chunk_sum` sequentially over the chunks, then
+// the scalar tail -- so the hits of query q are bit-identical to its own flat_search.
+//
+// What changes is the shape of the walk.  The scan uses a few per cent of the vector ALUs,
+// so one pass over HBM can carry several queries:
+//   * a wave owns a tile of TR rows and walks it in column panels of 256 floats: ONE 1-KiB
+//     wave load per row and panel (16 B per lane, nontemporal), kU loads in flight in a
+//     register ring that runs ahead across panel and tile boundaries;
+//   * within a panel a lane always sits on the same four columns, so its fragment of each
+//     query is loop-invariant: NQ x 4 registers, fetched (from L1/L2: every wave of the chip
+//     reads the same few KB) one panel ahead.  No query tile in LDS, no per-load LDS read;
+//   * each load is multiplied into NQ = 8 chunk sums (lane pair = one chunk, DPP add), filed
+//     in NQ small LDS panels S_q[TR = 8 rows][32 chunks] (the even lane of a pair stores the
+//     even queries' sums, the odd lane the odd ones': four stores per load);
+//   * after the 8 loads of a panel the wave re-reads the panels as 64 (query, row) pairs:
+//     lane (q, r) advances the sequential chain of row r under query q by 32 chunks -- all
+//     64 lanes busy, one chain each;
+//   * after the last panel every lane owns one finished (query, row) value: finiteness / f64
+//     recovery, rank key, then 8 offers into 8 wave-private top-k buffers (WaveTopK).
+// LDS per block: 4 waves x 8 queries x (1.4 KiB panel + 1 KiB candidates) = 77 KB: two
+// blocks per CU.  Two groups of 8 loads (16 KiB) are in flight per wave.
+//
+// Roofline: HBM-bound like K1 -- algorithmic bytes per launch = n * d * 4, whatever NQ is.
+#include "vt_scan.cuh"
+
+namespace vt {
+namespace dev {
+
+constexpr uint32_t kMqPanel = 256;  // floats per panel = one 1-KiB wave load per row
+constexpr uint32_t kMqSS = 44;      // dwords per LDS panel row: 32 chunk sums, 8 tail products, pad (4 * odd)
+constexpr uint32_t kMqTail = 32;    // dword offset of the tail products in a panel row
+constexpr int kMqNQ = (int)kMultiMaxQueries;  // queries per sweep
+constexpr int kMqTR = kWave / kMqNQ;          // rows per tile: (query, row) pairs fill the wave exactly
+constexpr int kMqCap = 64;                    // candidate slots per query and wave (k <= 32, 8 offers at a time)
+constexpr uint32_t kMqQS = kMqTR * kMqSS + 8; // dwords between two queries' panels (the + 8 staggers their banks)
+constexpr uint32_t kMqRedo = 64;              // overflowed (query, row) pairs a wave can set aside for the f64 replay
+
+// Per-element operation on PREPARED operands: for float hamming / jaccard the loaded row and
+// the query fragments are first turned into 0/1 indicators (x != 0), after which the element
+// is |q - x| like manhattan's (sums of small integers: exact in f32 in any order), jaccard
+// adding 4096 per non-zero row coordinate (exact for d < 4096), as K1 does.
+template <int OP>
+__device__ __forceinline__ float melem(float q, float x, float x4k) {
+  if (OP == OP_DOT) return q * x;
+  if (OP == OP_L2) {
+    const float t = q - x;
+    return t * t;
+  }
+  if (OP == OP_JAC) return fabsf(q - x) + x4k;
+  return fabsf(q - x);  // OP_L1, OP_LINF, OP_HAM (indicators)
+}
+template <int OP>
+__device__ __forceinline__ f32x4 indicator(f32x4 v) {
+  if (OP != OP_HAM && OP != OP_JAC) return v;
+  return f32x4{v.x != 0.0f ? 1.0f : 0.0f, v.y != 0.0f ? 1.0f : 0.0f, v.z != 0.0f ? 1.0f : 0.0f, v.w != 0.0f ? 1.0f : 0.0f};
+}
+
+// `b` in the odd lanes, `a` in the even ones.  Written as the instruction: left to the
+// compiler, a select between two elements of a register array becomes an indexed access to a
+// copy of the array in scratch memory -- vector-memory traffic whose waits also drain the
+// corpus loads that are in flight behind it.
+__device__ __forceinline__ float pick_odd(float a, float b) {
+  float r;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(0xAAAAAAAAAAAAAAAAull));
+  return r;
+}
+
+// ---- loads the compiler does not schedule (FAST path) --------------------------------------
+// Vector loads return in order and `s_waitcnt vmcnt(N)` waits for all but the N youngest, so a
+// stream of loads that is consumed in issue order never stalls on a younger load -- provided
+// every wait carries the exact count.  The compiler's own counting gives up at loop-carried
+// and conditional loads (it then waits for vmcnt(0), i.e. for the group that was just
+// requested: the pipeline drains once per step).  So the FAST path issues its loads as bare
+// instructions and places the counted waits itself; each wait names the registers it
+// releases, which is what keeps their uses behind it.  (The compiler's own vector-memory
+// instructions elsewhere in the kernel stay correct: more loads in flight than it knows of
+// can only make its waits longer.)
+__device__ __forceinline__ void issue_load_nt(f32x4 &dst, const float *p) {
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void issue_load(f32x4 &dst, const float *p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void issue_load_u32(uint32_t &dst, const uint32_t *p) {
+  asm volatile("global_load_dword %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_all_but(f32x4 &released) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(released) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_all_but(uint32_t &released) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(released) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void released_too(f32x4 &v) { asm volatile("" : "+v"(v)); }
+
+// FAST: d % 256 == 0 -- every panel is full, no padding, no scalar tail; ORDER is then a
+// compile-time constant.  Otherwise (ORDER = -1) bounds, tail and lane order are run-time.
+template <int OP, int ORDER, bool FAST>
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_multi_kernel(const MultiScanArgs a) {
+  constexpr int NQ = kMqNQ, TR = kMqTR, CAP = kMqCap;
+  constexpr int SUM_OP = (OP == OP_HAM || OP == OP_JAC) ? OP_L1 : OP;  // how chunk sums combine
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int odd = lane & 1;
+  // LDS: per wave NQ panels, then per query the four waves' candidate buffers side by side
+  // (merge_block expects wave w's buffer 2 * CAP u64 after wave 0's)
+  float *S = lds + wib * (NQ * kMqQS);
+  unsigned char *tkbase = reinterpret_cast<unsigned char *>(lds + kWavesPerBlock * (NQ * kMqQS));
+  __shared__ uint32_t s_counts[NQ][kWavesPerBlock];
+  // (query, row) pairs whose f32 value came out non-finite: re-evaluated in f64 after the sweep
+  // (distances.rs:59-67), so that the loop itself holds no vector-memory instruction of the
+  // compiler's (its waits would drain the load stream).  More of them than fit: the launch
+  // reports kStatusRetry and the host takes the queries one by one.
+  __shared__ uint32_t s_redo[kWavesPerBlock][kMqRedo], s_redo_q[kWavesPerBlock][kMqRedo];
+  uint32_t nredo = 0;  // wave-uniform
+
+  const uint32_t ld = a.ld;
+  const uint32_t cfull = a.d / 8, tail = FAST ? 0u : a.d % 8;
+  const uint32_t npanel = (ld + kMqPanel - 1) / kMqPanel;
+  const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+  const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
+  const uint32_t ntiles = (a.n + TR - 1) / TR;
+  const uint32_t lane_col = (uint32_t)lane * 4u;
+  // compute phase: a lane pair owns chunk (lane >> 1) of the loaded row; the even lane files
+  // the sums of the even queries, the odd lane those of the odd queries (one store per pair of queries)
+  float *Sstore = S + odd * kMqQS + (lane >> 1);
+  // chain phase: lane = (query, row) -- 64 sequential chains advance side by side
+  const int cq = lane / TR, cr = lane % TR;
+  const float *Schain = S + cq * kMqQS + cr * kMqSS;
+
+  WaveTopK<CAP> tk[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) tk[q].init(tkbase + (size_t)(q * kWavesPerBlock + wib) * WaveTopK<CAP>::lds_bytes(), a.k);
+
+  if (wave_global < ntiles) {
+    const uint32_t my_tiles = (ntiles - wave_global + total_waves - 1) / total_waves;
+    const uint32_t last_tile = wave_global + (my_tiles - 1) * total_waves;
+    const uint32_t total_steps = my_tiles * npanel;  // one step = one panel of one tile = TR loads
+    // the load stream runs one step ahead of the compute stream
+    uint32_t lt = wave_global, lp = 0;
+    auto load_group = [&](f32x4 *buf) {
+      const uint32_t t = lt < last_tile ? lt : last_tile;  // clamp at the end of the stream
+      const uint32_t colf = lp * kMqPanel + lane_col;
+      const float *base = a.X + (size_t)t * TR * a.stride + colf;
+#pragma unroll
+      for (int u = 0; u < TR; ++u) {
+        if constexpr (FAST) {
+          issue_load_nt(buf[u], base + (size_t)u * a.stride);
+        } else {
+          // (rows up to the slab's capacity exist and are zero; a panel's lanes beyond the row end do not load)
+          buf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (colf < ld) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (size_t)u * a.stride));
+        }
+      }
+      lp += 1;
+      if (lp == npanel) {
+        lp = 0;
+        lt += total_waves;
+      }
+    };
+    auto query_fragment = [&](uint32_t panel, f32x4 *qv) {
+      const uint32_t colf = panel * kMqPanel + lane_col;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if constexpr (FAST) {
+          issue_load(qv[q], a.Q + (size_t)q * ld + colf);
+        } else {
+          qv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (colf < ld) qv[q] = *reinterpret_cast<const f32x4 *>(a.Q + (size_t)q * ld + colf);
+        }
+      }
+    };
+
+    // Two register sets for the query fragments and two groups of TR corpus loads, swapping
+    // roles every step: the step loop is unrolled by two, so every register index is static
+    // and nothing is copied.  Every vector-memory instruction of the loop is unconditional and
+    // issued in the order its data is needed -- loads return in order, so a wait for the oldest
+    // never has to wait for a younger one.
+    f32x4 qa[NQ], qb[NQ];
+    query_fragment(0, qa);
+    f32x4 bufa[TR], bufb[TR];
+    load_group(bufa);
+
+    uint32_t t = wave_global, pc = 0;  // tile and panel of the step being consumed
+    float acc = 0.0f;
+    for (uint32_t step = 0; step < total_steps; step += 2) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (step + half >= total_steps) break;
+        f32x4 *cur = half ? bufb : bufa;
+        f32x4 *nxt = half ? bufa : bufb;
+        f32x4 *qcur = half ? qb : qa;
+        f32x4 *qnext = half ? qa : qb;
+        const uint32_t grow = t * TR + cr;  // the row of this lane's chain
+        const bool row_valid = grow < a.n;
+        // per step, in this order: the row's id rank (the column covers the slab's capacity), the
+        // next panel's query fragments, the next group of corpus loads -- 1 + NQ + TR loads
+        uint32_t my_rank = 0;
+        if constexpr (FAST) issue_load_u32(my_rank, a.id_rank + grow);
+        query_fragment(pc + 1 == npanel ? 0 : pc + 1, qnext);
+        load_group(nxt);
+        const uint32_t c = pc * (kMqPanel / 8) + ((uint32_t)lane >> 1);  // this lane pair's chunk of the row
+#pragma unroll
+        for (int u = 0; u < TR; ++u) {
+          if constexpr (FAST) {
+            // younger than cur[u]: the rest of its group and this step's 1 + NQ + TR loads
+            switch (u) {
+              case 0: wait_all_but<TR - 1 + 1 + NQ + TR>(cur[0]); break;
+              case 1: wait_all_but<TR - 2 + 1 + NQ + TR>(cur[1]); break;
+              case 2: wait_all_but<TR - 3 + 1 + NQ + TR>(cur[2]); break;
+              case 3: wait_all_but<TR - 4 + 1 + NQ + TR>(cur[3]); break;
+              case 4: wait_all_but<TR - 5 + 1 + NQ + TR>(cur[4]); break;
+              case 5: wait_all_but<TR - 6 + 1 + NQ + TR>(cur[5]); break;
+              case 6: wait_all_but<TR - 7 + 1 + NQ + TR>(cur[6]); break;
+              default: wait_all_but<1 + NQ + TR>(cur[7]); break;
+            }
+            if (u == 0) {  // (the fragments were requested before cur's group: they are in as well)
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) released_too(qcur[q]);
+            }
+          }
+          const f32x4 x = indicator<OP>(cur[u]);
+          f32x4 x4k = x;
+          if (OP == OP_JAC) x4k = f32x4{x.x * 4096.0f, x.y * 4096.0f, x.z * 4096.0f, x.w * 4096.0f};
+          float sum[NQ];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const f32x4 qv = indicator<OP>(qcur[q]);
+            const float p0 = melem<OP>(qv.x, x.x, x4k.x);
+            const float p1 = melem<OP>(qv.y, x.y, x4k.y);
+            const float p2 = melem<OP>(qv.z, x.z, x4k.z);
+            const float p3 = melem<OP>(qv.w, x.w, x4k.w);
+            sum[q] = chunk_sum<SUM_OP, ORDER>(SUM_OP, a.order, p0, p1, p2, p3, odd);
+            if (!FAST && tail && c == cfull)  // tail chunk: the reference adds these products one by one
+              *reinterpret_cast<f32x4 *>(S + q * kMqQS + u * kMqSS + kMqTail + odd * 4) = f32x4{p0, p1, p2, p3};
+          }
+          // (sums of padding chunks land in slots the chain never reads)
+#pragma unroll
+          for (int qq = 0; qq < NQ; qq += 2) Sstore[qq * kMqQS + u * kMqSS] = pick_odd(sum[qq], sum[qq + 1]);
+        }
+        // The rank was requested first in this step: it has long arrived.  The wait is placed in
+        // EVERY step, used or not -- a register whose load is still on its way must not look dead
+        // to the register allocator, or the late write lands in whatever was put there since.
+        if constexpr (FAST) wait_all_but<NQ + TR>(my_rank);
+        // panel complete: every (query, row) chain advances by the panel's chunks
+        wave_lds_fence();
+        {
+          const uint32_t c0 = pc * (kMqPanel / 8);
+          float v = pc == 0 ? 0.0f : acc;
+          if (FAST) {
+#pragma unroll
+            for (uint32_t i = 0; i < kMqPanel / 8; i += 4) {
+              const f32x4 w = *reinterpret_cast<const f32x4 *>(Schain + i);
+              v = comb<SUM_OP>(SUM_OP, v, w.x);
+              v = comb<SUM_OP>(SUM_OP, v, w.y);
+              v = comb<SUM_OP>(SUM_OP, v, w.z);
+              v = comb<SUM_OP>(SUM_OP, v, w.w);
+            }
+          } else {
+            const uint32_t nsum = cfull > c0 ? (cfull - c0 < kMqPanel / 8 ? cfull - c0 : kMqPanel / 8) : 0u;
+            uint32_t i = 0;
+            for (; i + 4 <= nsum; i += 4) {
+              const f32x4 w = *reinterpret_cast<const f32x4 *>(Schain + i);
+              v = comb<SUM_OP>(SUM_OP, v, w.x);
+              v = comb<SUM_OP>(SUM_OP, v, w.y);
+              v = comb<SUM_OP>(SUM_OP, v, w.z);
+              v = comb<SUM_OP>(SUM_OP, v, w.w);
+            }
+            for (; i < nsum; ++i) v = comb<SUM_OP>(SUM_OP, v, Schain[i]);
+            if (tail && cfull >= c0 && cfull < c0 + kMqPanel / 8)
+              for (uint32_t j = 0; j < tail; ++j) v = comb<SUM_OP>(SUM_OP, v, Schain[kMqTail + j]);
+          }
+          acc = v;
+        }
+        wave_lds_fence();
+        pc += 1;
+        if (pc == npanel) {
+          // the tile is done: distances.rs:42-68 compute() for this lane's (query, row) -- value,
+          // finiteness, f64 recovery -- then distances.rs:113-119 rank_value and the key (flat.rs:34-40)
+          const int metric = a.metric;
+          float raw = acc;
+          if (metric == M_NIP) raw = -acc;
+          else if (metric == M_L2) raw = finite_f32(acc) ? __builtin_sqrtf(acc) : acc;
+          else if (OP == OP_JAC) {
+            uint32_t qnz = a.q_nonzero[0];
+#pragma unroll
+            for (int q = 1; q < NQ; ++q) qnz = cq == q ? a.q_nonzero[q] : qnz;
+            const uint32_t tot = (uint32_t)acc;
+            const uint32_t xnz = tot >> 12, ham = tot & 4095u;
+            const uint32_t uni = (qnz + xnz + ham) >> 1;
+            const uint32_t inter = (qnz + xnz - ham) >> 1;
+            raw = uni == 0 ? 0.0f : 1.0f - (float)inter / (float)uni;
+          }
+          bool valid = row_valid && (uint32_t)cq < a.nq;  // (padding queries of a short group offer nothing)
+          const bool redo = valid && !finite_f32(raw);
+          const uint64_t redo_mask = __ballot(redo);
+          if (redo_mask) {
+            const uint32_t pos = nredo + __popcll(redo_mask & ((1ull << lane) - 1));
+            if (redo && pos < kMqRedo) s_redo[wib][pos] = grow;  // (the query is the lane's own: see the replay)
+            if (redo && pos < kMqRedo) s_redo_q[wib][pos] = (uint32_t)cq;
+            nredo += __popcll(redo_mask);
+            valid = valid && !redo;
+          }
+          float rank = raw;
+          if (metric == M_COS) rank = 1.0f - raw;
+          else if (metric == M_IP) rank = -raw;
+          if constexpr (!FAST) my_rank = row_valid ? a.id_rank[grow] : 0u;
+          const uint64_t key = ((uint64_t)orderable(rank) << 32) | my_rank;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) tk[q].offer(valid && cq == q, key, grow, raw, lane);
+          pc = 0;
+          t += total_waves;
+        }
+      }
+    }
+    // nothing of the load stream may still be on its way into registers that get new owners below
+    if constexpr (FAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the overflowed pairs, one per lane: f64 re-evaluation, then the same offer as everyone else
+    if (nredo) {
+      wave_lds_fence();
+      if (nredo > kMqRedo) {
+        if (lane == 0) atomicMax(a.status, kStatusRetry);
+      } else {
+        const bool mine = (uint32_t)lane < nredo;
+        const uint32_t row = mine ? s_redo[wib][lane] : 0u, rq = mine ? s_redo_q[wib][lane] : 0u;
+        float raw = 0.0f;
+        bool valid = mine;
+        if (mine && !recover_overflow(a.metric, a.Q + (size_t)rq * ld, a.X + (size_t)row * a.stride, a.d, &raw)) {
+          atomicMax(a.status, kErrOverflow);
+          valid = false;
+        }
+        float rank = raw;
+        if (a.metric == M_COS) rank = 1.0f - raw;
+        else if (a.metric == M_IP) rank = -raw;
+        const uint64_t key = ((uint64_t)orderable(rank) << 32) | (mine ? a.id_rank[row] : 0u);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) tk[q].offer(valid && rq == (uint32_t)q, key, row, raw, lane);
+      }
+    }
+  }
+  // one list per block and query: wave 0 absorbs the other waves' buffers
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if ((uint32_t)q >= a.nq) break;
+    tk[q].merge_block(wib, kWavesPerBlock, s_counts[q], lane);
+    if (wib == 0) {
+      const size_t list = (size_t)(a.first_query + q) * gridDim.x + blockIdx.x;
+      tk[q].store(a.part_keys + list * a.k, a.part_pay + list * a.k, lane);
+    }
+  }
+}
+
+constexpr size_t kMqLds = (size_t)kWavesPerBlock * kMqNQ * ((size_t)kMqQS * 4 + WaveTopK<kMqCap>::lds_bytes());
+
+template <int OP, int ORDER, bool FAST>
+static hipError_t launch_multi_t(const MultiScanArgs &a, uint32_t blocks, hipStream_t s) {
+  auto kern = scan_multi_kernel<OP, ORDER, FAST>;
+  hipError_t e = allow_lds(kern, kMqLds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), kMqLds, s, a);
+  return hipGetLastError();
+}
+
+// ORDERED: the metric's value depends on the lane order of reduce_add (sums); max and the
+// small-integer sums of float hamming / jaccard do not.
+template <int OP, bool ORDERED>
+static hipError_t launch_multi_op(const MultiScanArgs &a, uint32_t blocks, hipStream_t s) {
+  if (a.d % kMqPanel != 0) return launch_multi_t<OP, ORDERED ? -1 : 0, false>(a, blocks, s);
+  if (!ORDERED || a.order == 0) return launch_multi_t<OP, 0, true>(a, blocks, s);
+  if (a.order == 1) return launch_multi_t<OP, ORDERED ? 1 : 0, true>(a, blocks, s);
+  if (a.order == 2) return launch_multi_t<OP, ORDERED ? 2 : 0, true>(a, blocks, s);
+  return launch_multi_t<OP, ORDERED ? 3 : 0, true>(a, blocks, s);
+}
+
+}  // namespace dev
+
+uint32_t scan_multi_max_k(uint32_t) { return 32u; }
+uint32_t scan_multi_tile_rows(uint32_t) { return (uint32_t)dev::kMqTR; }
+size_t scan_multi_lds_bytes(uint32_t) { return dev::kMqLds; }
+
+hipError_t launch_scan_multi(const MultiScanArgs &a, uint32_t blocks, hipStream_t s) {
+  using namespace dev;
+  if (a.nq == 0 || a.nq > kMultiMaxQueries || a.k == 0 || a.k > scan_multi_max_k(a.nq) || a.ld % kRowAlign != 0 || !a.id_rank ||
+      a.ld < a.d || a.stride < a.ld || (a.metric == M_JAC && a.d >= 4096))
+    return hipErrorInvalidValue;
+  switch (metric_op(a.metric)) {
+    case OP_DOT: return launch_multi_op<OP_DOT, true>(a, blocks, s);
+    case OP_L2: return launch_multi_op<OP_L2, true>(a, blocks, s);
+    case OP_L1: return launch_multi_op<OP_L1, true>(a, blocks, s);
+    case OP_LINF: return launch_multi_op<OP_LINF, false>(a, blocks, s);
+    case OP_HAM: return launch_multi_op<OP_HAM, false>(a, blocks, s);
+    default: return launch_multi_op<OP_JAC, false>(a, blocks, s);
+  }
+}
+
+}  // namespace vt
