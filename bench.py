@@ -373,6 +373,11 @@ def main():
     if launched:
         a.gpus = world
     shards_in_process = a.gpus if not launched else 1   # one process, one handle over a.gpus devices
+    # `--gpus 1 --exchange rccl|host`: the one shard goes through the multi-shard machinery anyway
+    # (worker thread, exchange, host merge) -- prices that machinery on a one-GPU box
+    force_sharded = not launched and a.gpus == 1 and a.exchange != "auto"
+    if force_sharded:
+        os.environ["VT_SHARD_FORCE_WORKERS"] = "1"
 
     import torch  # first: its bundled libamdhip64 must be the one the process shares
     import torch.distributed as dist
@@ -398,7 +403,7 @@ def main():
     t_build = time.perf_counter()
     rccl_ranks = 0
     devices = [local_rank]
-    if shards_in_process > 1:
+    if shards_in_process > 1 or force_sharded:
         # ---- one process, one handle, N devices: rows go where the hash of their id says -------
         ndev = torch.cuda.device_count()
         devices = [int(v) for v in a.devices.split(",")] if a.devices else list(range(shards_in_process))
@@ -469,7 +474,7 @@ def main():
     def sync():
         if launched:
             dist.barrier()
-        for dv in (set(devices) if shards_in_process > 1 else ()):
+        for dv in (set(devices) if (shards_in_process > 1 or force_sharded) else ()):
             torch.cuda.synchronize(dv)
         torch.cuda.synchronize()
 
@@ -537,13 +542,13 @@ def main():
                 "frac_of_measured_read_peak": (achieved / measured_read_peak()) if measured_read_peak() else None,
             },
         }
-        if shards_in_process > 1 and rccl_ranks:
+        if (shards_in_process > 1 or force_sharded) and rccl_ranks:
             # the same steps over the other exchange, for comparison (not the headline)
             assert nifs.flat_set_exchange(ref, _lib.EXCHANGE_HOST) == "ok"
             dt2, _ = timed_run()
             out["config"]["host_exchange_ms_per_step"] = dt2 / a.steps * 1e3
             assert nifs.flat_set_exchange(ref, _lib.EXCHANGE_RCCL) == "ok"
-        if a.gpus == 1 and not launched and not a.no_side:
+        if a.gpus == 1 and not launched and not a.no_side and not force_sharded:
             out["side"] = side_legs(a, torch, nifs, L, device, ref)
         if a.gpus == 1 and not launched and not a.no_cpu and a.cpu_seconds > 0:
             cb = cpu_baseline(a.dim, a.limit, a.cpu_seconds)

@@ -957,6 +957,31 @@ def test_limits_above_256_in_one_scan(nifs, oracle_mod, metric, forced, monkeypa
         assert bits(got) == bits(want), (metric, limit)
 
 
+@pytest.mark.parametrize("metric", [2, 0])
+def test_limits_above_4096_in_one_scan(nifs, oracle_mod, metric):
+    """flat.ex:98-103 allows any limit below 2^32.  Above 4 096 hits the scan writes key and
+    payload columns, the radix threshold runs on the device and the host cuts and orders the
+    collected list: one scan, not one per 256 hits (the profile counts the launches).  70 000
+    hits exceed the device list: the pass-per-256 loop answers, same order."""
+    n, d = 90_000, 24
+    x, ids = make_corpus(n, d, 1500 + metric, metric == 2, oracle_mod, tie_block=700)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    packed = oracle_mod.pack_ids(ids)
+    rng = np.random.default_rng(18)
+    nifs.flat_set_profiling(g.ref, True)
+    for limit, scans in ((5000, 1), (20000, 1), (65536, 1), (70000, None)):
+        q = x[n // 2] if limit == 20000 else rng.uniform(-1, 1, d).astype(np.float32)
+        if metric == 2:
+            q = oracle_mod.normalize_l2(q)
+        nifs.flat_get_profile(g.ref, reset=True)
+        got = unwrap(nifs.flat_search(g.ref, q, limit))
+        prof = nifs.flat_get_profile(g.ref, reset=True)
+        assert bits(got) == bits(oracle_mod.matrix_search(metric, x, packed, q, limit)), (metric, limit)
+        if scans is not None:
+            assert prof["scan_launches"] == scans, (limit, prof["scan_launches"])
+
+
 def test_limit_above_256_with_more_ties_than_the_list_holds(nifs, oracle_mod, force_threshold):
     """80 000 identical rows: every key shares its 33-bit prefix, the device list overflows and
     the call must fall back to the pass-per-256 loop -- same answer as the oracle."""

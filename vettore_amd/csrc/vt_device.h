@@ -136,6 +136,7 @@ struct RadixArgs {
   Payload *list_pay;     // [cap]: row = position in `keys`
   uint32_t cap;
   int *status;
+  const Payload *pay_col;  // optional: per-position payload whose raw value travels with a collected key
 };
 hipError_t launch_radix_pass(const RadixArgs &a, int pass, uint32_t blocks, hipStream_t s);
 hipError_t launch_radix_collect(const RadixArgs &a, uint32_t blocks, hipStream_t s);

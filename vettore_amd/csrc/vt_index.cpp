@@ -230,6 +230,9 @@ struct Ctx {
   DevBuf<uint32_t> dRankPairs;  // (row, rank) updates of the lazy rank path
   PinnedBuf<uint32_t> hRankPairs;
   DevBuf<uint64_t> dKeyCol;    // one key per row (limits above kMaxFusedK: radix threshold instead of wave buffers)
+  DevBuf<vt::Payload> dPayCol; // (row, raw) per row beside the key column (limits above kSelListMax)
+  PinnedBuf<uint64_t> hListKeys;
+  PinnedBuf<vt::Payload> hListPay;
   DevBuf<uint32_t> dRadixHist, dRadixCount;
   DevBuf<vt::Payload> dListPay;
   DevBuf<uint32_t> dHamHist, dHamCount;
@@ -682,6 +685,76 @@ bool threshold_applies(size_t total, uint32_t n, double scan_bytes, double pass_
   return t_threshold < t_loop;
 }
 
+// Limits above kSelListMax (flat.ex:98-103 allows up to 2^32 - 1) in ONE scan: key and payload
+// columns, the device-side radix threshold, and the collected list -- every key up to the k-th
+// one's 33-bit prefix, a few more than k -- handed to the host as it is, which cuts and orders it
+// (nth_element + sort of ~k entries).  kRetryInternal: more ties at the threshold than the list
+// holds; the caller takes the pass-per-256 loop.
+int threshold_big(Ctx &c, const vt::ScanArgs &scan, uint32_t blocks, uint32_t n, uint32_t k, bool timed, uint32_t d,
+                  std::vector<vt::Entry> &out) {
+  VT_TRY(c.dKeyCol.ensure(((size_t)n + 1) / 2 * 2));
+  VT_TRY(c.dPayCol.ensure(n));
+  VT_TRY(c.dRadixHist.ensure(3 * vt::kRadixBins));
+  VT_TRY(c.dRadixCount.ensure(1));
+  VT_TRY(c.dPartKeys.ensure(kThresholdListCap));
+  VT_TRY(c.dPartPay.ensure(kThresholdListCap));
+  VT_TRY(c.hListKeys.ensure(kThresholdListCap));
+  VT_TRY(c.hListPay.ensure(kThresholdListCap));
+  vt::ScanArgs a = scan;
+  a.k = 1;
+  a.key_out = c.dKeyCol.p;
+  a.pay_out = c.dPayCol.p;
+  if (timed) VT_HIP(hipEventRecord(c.ev0, c.stream));
+  VT_HIP(vt::launch_scan(a, blocks, c.stream));
+  if (timed) VT_HIP(hipEventRecord(c.ev1, c.stream));
+  VT_HIP(hipMemsetAsync(c.dRadixHist.p, 0, 3 * vt::kRadixBins * sizeof(uint32_t), c.stream));
+  vt::RadixArgs r{};
+  r.keys = c.dKeyCol.p;
+  r.n = n;
+  r.k = k;
+  r.hist = c.dRadixHist.p;
+  r.list_count = c.dRadixCount.p;
+  r.list_keys = c.dPartKeys.p;
+  r.list_pay = c.dPartPay.p;
+  r.cap = kThresholdListCap;
+  r.status = c.dStatus.p;
+  r.pay_col = c.dPayCol.p;
+  const uint32_t rblocks = (uint32_t)c.num_cus * 8;
+  for (int pass = 0; pass < 3; ++pass) VT_HIP(vt::launch_radix_pass(r, pass, rblocks, c.stream));
+  VT_HIP(vt::launch_radix_collect(r, rblocks, c.stream));
+  uint32_t count = 0;
+  int status = 0;
+  VT_HIP(hipMemcpyAsync(&count, c.dRadixCount.p, sizeof(count), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(&status, c.dStatus.p, sizeof(status), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  if (timed) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    c.prof.scan_launches += 1;
+    c.prof.scan_ms += ms;
+    c.prof.scan_rows += n;
+    c.prof.scan_bytes += (uint64_t)n * d * 4;
+  }
+  if (status == vt::kStatusRetry || count > kThresholdListCap) return kRetryInternal;
+  if (status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
+  VT_HIP(hipMemcpyAsync(c.hListKeys.p, c.dPartKeys.p, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(c.hListPay.p, c.dPartPay.p, (size_t)count * sizeof(vt::Payload), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  std::vector<vt::Entry> list(count);
+  for (uint32_t i = 0; i < count; ++i) {
+    list[i].key = c.hListKeys.p[i];
+    list[i].row = c.hListPay.p[i].row;
+    list[i].raw = c.hListPay.p[i].raw;
+  }
+  const size_t take = std::min<size_t>(k, list.size());
+  auto by_key = [](const vt::Entry &x, const vt::Entry &y) { return x.key < y.key; };
+  std::nth_element(list.begin(), list.begin() + (take ? take - 1 : 0), list.end(), by_key);
+  std::sort(list.begin(), list.begin() + take, by_key);
+  out.assign(list.begin(), list.begin() + take);
+  return VT_OK;
+}
+
 int threshold_rows(Ctx &c, uint32_t n, uint32_t k) {
   VT_TRY(c.dRadixHist.ensure(3 * vt::kRadixBins));
   VT_TRY(c.dRadixCount.ensure(1));
@@ -722,6 +795,31 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
   uint64_t lo = 0;
   bool has_lo = false;
   const size_t total = std::min<size_t>(want, j.n);
+  if (!j.gather && out.empty() && total > (size_t)vt::kSelListMax && total <= (size_t)kThresholdListCap &&
+      j.n >= kThresholdMinRows && !std::getenv("VT_NO_THRESHOLD_SELECT")) {
+    vt::ScanArgs a{};
+    a.X = j.X;
+    a.stride = j.stride;
+    a.q = c.dQ.p;
+    a.id_rank = j.id_rank;
+    a.n = j.n;
+    a.d = j.d;
+    a.metric = j.metric;
+    a.order = j.order;
+    a.q_nonzero = j.q_nonzero;
+    a.tile_rows = tile_rows;
+    a.part_keys = c.dPartKeys.p;  // (unused in key-column mode)
+    a.part_pay = c.dPartPay.p;
+    a.status = c.dStatus.p;
+    VT_TRY(c.dPartKeys.ensure(kThresholdListCap));
+    VT_TRY(c.dPartPay.ensure(kThresholdListCap));
+    a.part_keys = c.dPartKeys.p;
+    a.part_pay = c.dPartPay.p;
+    const int rc = threshold_big(c, a, c.grid_for(ntiles, vt::scan_lds_bytes(j.d, 1)), j.n, (uint32_t)total,
+                                 c.profiling && count_profile, j.d, out);
+    if (rc != kRetryInternal) return rc;
+    out.clear();  // more equal keys at the threshold than the list holds: the pass-per-256 loop below
+  }
   if (!j.gather && out.empty() && threshold_applies(total, j.n, (double)j.n * vt::padded_dim(j.d) * 4.0)) {
     // one scan in key-column mode, exact threshold on the device, then the winners are
     // re-scored through the gather list for their raw values and sorted

@@ -974,7 +974,7 @@ __global__ __launch_bounds__(256) void radix_collect_kernel(const RadixArgs a) {
         a.list_keys[pos] = v;
         Payload pv;
         pv.row = i;
-        pv.raw = 0.0f;
+        pv.raw = a.pay_col ? a.pay_col[i].raw : 0.0f;  // (limits above kSelListMax: the list leaves the device as it is)
         a.list_pay[pos] = pv;
       } else {
         atomicMax(a.status, kStatusRetry);
