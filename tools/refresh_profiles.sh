@@ -15,17 +15,25 @@ pmc() {  # name, counter, bench args...
   local name=$1 ctr=$2; shift 2
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$name -o p -- python3 $R/bench.py "$@" > $OUT/$name.log 2>&1
 }
-stats single
-pmc single_fetch FETCH_SIZE --steps 20 --warmup 2 --no-cpu
-pmc single_write WRITE_SIZE --steps 20 --warmup 2 --no-cpu
+export RND=${RND:-r02}
+stats single --no-side          # the headline alone: the scan kernel's average is the bench line's avg_launch_ms
+stats default                   # the driver's command: headline + side legs (config 2 shares the scan kernel: 1 100 launches at N=1M)
+pmc single_fetch FETCH_SIZE --steps 20 --warmup 2 --no-cpu --no-side
+pmc single_write WRITE_SIZE --steps 20 --warmup 2 --no-cpu --no-side
 stats batch --mode batch --steps 6 --warmup 1 --no-cpu
 stats quantized --mode quantized --steps 300 --warmup 20 --no-cpu
 pmc quantized_fetch FETCH_SIZE --mode quantized --steps 20 --warmup 2 --no-cpu
 stats funnel --mode funnel --steps 200 --warmup 5 --no-cpu
+# K1m: 8 queries per sweep (manhattan, N=10M, d=768); the program after `--` is python3 itself
+export ROWS=10000000 NQS=8 METRICS=5
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/multi -o p -- python3 $R/tools/multi_probe.py > $OUT/multi.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/multi_fetch -o p -- python3 $R/tools/multi_probe.py > $OUT/multi_fetch.log 2>&1
+unset ROWS NQS METRICS
 cd $R
 python3 - <<'PY'
 import csv, glob, json, os
 out = 'gpurun_out/prof'
+RND = os.environ.get('RND', 'r02')
 def trim(src, dst):
     rows = list(csv.reader(open(src)))
     with open(dst, 'w', newline='') as f:
@@ -33,8 +41,8 @@ def trim(src, dst):
         for r in rows:
             r[0] = r[0][:140]
             w.writerow(r)
-for name in ('single', 'batch', 'quantized', 'funnel'):
-    trim('%s/%s/p_kernel_stats.csv' % (out, name), '%s/r01_%s_kernel_stats.csv' % (out, name))
+for name in ('single', 'default', 'batch', 'quantized', 'funnel', 'multi'):
+    trim('%s/%s/p_kernel_stats.csv' % (out, name), '%s/%s_%s_kernel_stats.csv' % (out, RND, name))
 def per_launch(path, kernel_substr, counter):
     vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
             if kernel_substr in r['Kernel_Name'] and r['Counter_Name'] == counter]
@@ -48,15 +56,18 @@ def keep(path, dst, kernel_substr):
             if kernel_substr in r['Kernel_Name']:
                 r['Kernel_Name'] = r['Kernel_Name'][:140]
                 w.writerow(r)
-keep(out + '/single_fetch/p_counter_collection.csv', out + '/r01_single_pmc_fetch.csv', 'scan_topk_kernel')
-keep(out + '/single_write/p_counter_collection.csv', out + '/r01_single_pmc_write.csv', 'scan_topk_kernel')
-keep(out + '/quantized_fetch/p_counter_collection.csv', out + '/r01_quantized_pmc_fetch.csv', 'hamming_dist_kernel')
+keep(out + '/single_fetch/p_counter_collection.csv', out + '/%s_single_pmc_fetch.csv' % RND, 'scan_topk_kernel')
+keep(out + '/single_write/p_counter_collection.csv', out + '/%s_single_pmc_write.csv' % RND, 'scan_topk_kernel')
+keep(out + '/quantized_fetch/p_counter_collection.csv', out + '/%s_quantized_pmc_fetch.csv' % RND, 'hamming_dist_kernel')
+keep(out + '/multi_fetch/p_counter_collection.csv', out + '/%s_multi_pmc_fetch.csv' % RND, 'scan_multi_kernel')
+mf, mn = per_launch(out + '/multi_fetch/p_counter_collection.csv', 'scan_multi_kernel', 'FETCH_SIZE')
+print("K1m FETCH_SIZE KiB per sweep", mf, "x2 bytes", 2 * mf * 1024, "launches", mn)
 fetch, n1 = per_launch(out + '/single_fetch/p_counter_collection.csv', 'scan_topk_kernel', 'FETCH_SIZE')
 write, n2 = per_launch(out + '/single_write/p_counter_collection.csv', 'scan_topk_kernel', 'WRITE_SIZE')
 stat = [r for r in csv.DictReader(open(out + '/single/p_kernel_stats.csv')) if 'scan_topk_kernel' in r['Name']][0]
 json.dump({
-    "round": 1,
-    "command": "python3 bench.py  (N=10M, d=768, cosine, limit 10; PMC passes: --steps 20 --warmup 2 --no-cpu)",
+    "round": int(RND[1:]),
+    "command": "python3 bench.py --no-side  (N=10M, d=768, cosine, limit 10; PMC passes: --steps 20 --warmup 2 --no-cpu --no-side)",
     "rows": 10000000, "dim": 768, "kernel": stat['Name'],
     "rocprof_avg_ns": float(stat['AverageNs']), "rocprof_calls": int(stat['Calls']),
     "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
