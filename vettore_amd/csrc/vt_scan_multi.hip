@@ -100,8 +100,10 @@ __device__ __forceinline__ void wait_all_but(uint32_t &released) {
 }
 __device__ __forceinline__ void released_too(f32x4 &v) { asm volatile("" : "+v"(v)); }
 
-// FAST: d % 256 == 0 -- every panel is full, no padding, no scalar tail; ORDER is then a
-// compile-time constant.  Otherwise (ORDER = -1) bounds, tail and lane order are run-time.
+// FAST: d % 64 == 0 -- rows carry no padding and no scalar tail, and ORDER is a compile-time
+// constant.  The last panel of a row may still be partial (d % 256 != 0): its surplus lanes
+// re-read columns of the same row (no extra HBM lines) and file sums the chain never reads.
+// Otherwise (ORDER = -1) bounds, tail and lane order are run-time and the loads the compiler's.
 template <int OP, int ORDER, bool FAST>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_multi_kernel(const MultiScanArgs a) {
   constexpr int NQ = kMqNQ, TR = kMqTR, CAP = kMqCap;
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_multi_kernel(const
     uint32_t lt = wave_global, lp = 0;
     auto load_group = [&](f32x4 *buf) {
       const uint32_t t = lt < last_tile ? lt : last_tile;  // clamp at the end of the stream
-      const uint32_t colf = lp * kMqPanel + lane_col;
+      uint32_t colf = lp * kMqPanel + lane_col;
+      if (FAST && colf >= ld) colf %= ld;  // surplus lane of a partial panel: any column of the row will do
       const float *base = a.X + (size_t)t * TR * a.stride + colf;
 #pragma unroll
       for (int u = 0; u < TR; ++u) {
@@ -167,7 +170,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_multi_kernel(const
       }
     };
     auto query_fragment = [&](uint32_t panel, f32x4 *qv) {
-      const uint32_t colf = panel * kMqPanel + lane_col;
+      uint32_t colf = panel * kMqPanel + lane_col;
+      if (FAST && colf >= ld) colf %= ld;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if constexpr (FAST) {
@@ -256,13 +260,25 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_multi_kernel(const
           const uint32_t c0 = pc * (kMqPanel / 8);
           float v = pc == 0 ? 0.0f : acc;
           if (FAST) {
+            // chunks of this panel: 32, or what is left of the row (a multiple of 8 chunks)
+            const uint32_t left = cfull - c0;
+            if (left >= kMqPanel / 8) {
 #pragma unroll
-            for (uint32_t i = 0; i < kMqPanel / 8; i += 4) {
-              const f32x4 w = *reinterpret_cast<const f32x4 *>(Schain + i);
-              v = comb<SUM_OP>(SUM_OP, v, w.x);
-              v = comb<SUM_OP>(SUM_OP, v, w.y);
-              v = comb<SUM_OP>(SUM_OP, v, w.z);
-              v = comb<SUM_OP>(SUM_OP, v, w.w);
+              for (uint32_t i = 0; i < kMqPanel / 8; i += 4) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(Schain + i);
+                v = comb<SUM_OP>(SUM_OP, v, w.x);
+                v = comb<SUM_OP>(SUM_OP, v, w.y);
+                v = comb<SUM_OP>(SUM_OP, v, w.z);
+                v = comb<SUM_OP>(SUM_OP, v, w.w);
+              }
+            } else {
+              for (uint32_t i = 0; i < left; i += 4) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(Schain + i);
+                v = comb<SUM_OP>(SUM_OP, v, w.x);
+                v = comb<SUM_OP>(SUM_OP, v, w.y);
+                v = comb<SUM_OP>(SUM_OP, v, w.z);
+                v = comb<SUM_OP>(SUM_OP, v, w.w);
+              }
             }
           } else {
             const uint32_t nsum = cfull > c0 ? (cfull - c0 < kMqPanel / 8 ? cfull - c0 : kMqPanel / 8) : 0u;
@@ -373,7 +389,7 @@ static hipError_t launch_multi_t(const MultiScanArgs &a, uint32_t blocks, hipStr
 // small-integer sums of float hamming / jaccard do not.
 template <int OP, bool ORDERED>
 static hipError_t launch_multi_op(const MultiScanArgs &a, uint32_t blocks, hipStream_t s) {
-  if (a.d % kMqPanel != 0) return launch_multi_t<OP, ORDERED ? -1 : 0, false>(a, blocks, s);
+  if (a.d % kRowAlign != 0) return launch_multi_t<OP, ORDERED ? -1 : 0, false>(a, blocks, s);
   if (!ORDERED || a.order == 0) return launch_multi_t<OP, 0, true>(a, blocks, s);
   if (a.order == 1) return launch_multi_t<OP, ORDERED ? 1 : 0, true>(a, blocks, s);
   if (a.order == 2) return launch_multi_t<OP, ORDERED ? 2 : 0, true>(a, blocks, s);
