@@ -124,8 +124,52 @@ def test_sharded_validation_and_unsupported_calls(nifs, oracle_mod):
     assert [h[0] for h in g.search([1.0, 0.0], 2)] == [b"a", b"c"]     # vector_algorithms_hardening_test.exs:20-36
     with pytest.raises(GpuError, match="dimension mismatch"):
         g.search([1.0, 0.0, 0.0], 2)
-    res = nifs.flat_quantized_search(g.ref, [1.0, 0.0], 3, 2)
-    assert res[0] == "error" and "multi-shard" in res[1]
+    # collection.ex:276-295 through a two-shard resource
+    assert [h[0] for h in unwrap(nifs.flat_quantized_search(g.ref, [1.0, 0.0], 3, 2))] == [b"a", b"c"]
+    assert nifs.flat_funnel_search(g.ref, [1.0, 0.0], [3], 3, 2) == ("error", "invalid prefix dimensions")
+    assert nifs.flat_funnel_search(g.ref, [1.0, 0.0], [], 3, 2) == ("error", "invalid prefix dimensions")
+    assert unwrap(nifs.flat_quantized_search(g.ref, [1.0, 0.0], 0, 2)) == []
+
+
+@pytest.mark.parametrize("metric", [2, 0, 3])
+def test_staged_searches_on_a_sharded_handle_equal_the_one_gpu_index(nifs, oracle_mod, metric):
+    """quantized_search, funnel_search and hybrid_search (collection.ex:276-295, :245-260,
+    :325-345) on a 3-shard resource: every step keeps the best rows of a row set, per shard and
+    then merged by (rank key, id bytes) -- the results must equal the one-GPU index's (which the
+    parity tests pin to the oracle's composition), and the quantized one the oracle's directly."""
+    n, d = 30_000, 96
+    x, ids = make_corpus(n, d, 2100 + metric, metric == 2, oracle_mod, tie_block=50)
+    one = GpuIndex(nifs, metric)
+    many = ShardedIndex(nifs, metric, [0, 0, 0])
+    unwrap(nifs.flat_load_matrix(one.ref, ids, x))
+    unwrap(nifs.flat_load_matrix(many.ref, ids, x))
+    rng = np.random.default_rng(6)
+    qs = [x[n // 2], x[7]] + [rng.uniform(-1, 1, d).astype(np.float32) for _ in range(3)]
+    if metric == 2:
+        qs = [oracle_mod.normalize_l2(q) for q in qs]
+    by_id = {ids[i]: x[i] for i in range(n)}
+    sign = [oracle_mod.compress_sign_bits(r) for r in x]
+    for qi, q in enumerate(qs):
+        for cand, limit in ((100, 10), (300, 40), (5, 10)):
+            got = unwrap(nifs.flat_quantized_search(many.ref, q, cand, limit))
+            assert bits(got) == bits(unwrap(nifs.flat_quantized_search(one.ref, q, cand, limit))), (metric, qi, cand)
+            if qi < 2 and cand == 100:      # the oracle's own composition: binary_top_k then vector_top_k
+                cands = oracle_mod.binary_top_k([(ids[i], sign[i]) for i in range(n)], oracle_mod.compress_sign_bits(q), d, cand)
+                want = oracle_mod.vector_top_k([(c, by_id[c]) for c, _ in cands], q, metric, d, limit)
+                assert bits(got) == bits(want)
+        for stages, cand, limit in (([32], 100, 10), ([16, 48], 64, 10), ([24], 300, 20)):
+            got = unwrap(nifs.flat_funnel_search(many.ref, q, stages, cand, limit))
+            assert bits(got) == bits(unwrap(nifs.flat_funnel_search(one.ref, q, stages, cand, limit))), (metric, qi, stages)
+        gens = [(nifs.GEN_FUNNEL, 50, [32]), (nifs.GEN_QUANTIZED, 60, []), (nifs.GEN_SEARCH, 40, [])]
+        got = unwrap(nifs.flat_hybrid_search(many.ref, q, gens, 15))
+        assert bits(got) == bits(unwrap(nifs.flat_hybrid_search(one.ref, q, gens, 15))), (metric, qi)
+    # after mutations on both (derived columns are patched per shard)
+    for target in (one, many):
+        target.insert("zz-new", x[7])
+        target.delete(ids[8])
+    q = qs[1]
+    assert bits(unwrap(nifs.flat_quantized_search(many.ref, q, 100, 10))) == bits(unwrap(nifs.flat_quantized_search(one.ref, q, 100, 10)))
+    assert bits(unwrap(nifs.flat_funnel_search(many.ref, q, [32], 100, 10))) == bits(unwrap(nifs.flat_funnel_search(one.ref, q, [32], 100, 10)))
 
 
 def test_rccl_exchange_with_a_one_rank_communicator(nifs, oracle_mod, monkeypatch):

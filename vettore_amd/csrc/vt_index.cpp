@@ -1735,11 +1735,13 @@ int index_ensure_bits(Shard *ix) {
 }
 
 // binary_top_k candidates (search.rs:76-92) of the query already in c.dQ.
-int quantized_rows(Shard *ix, Ctx &c, size_t candidates, std::vector<uint32_t> &rows) {
+int quantized_rows(Shard *ix, Ctx &c, size_t candidates, std::vector<uint32_t> &rows, std::vector<vt::Entry> *entries = nullptr) {
   const uint32_t d = (uint32_t)ix->dim, words = (d + 63) / 64;
   VT_TRY(c.dQbits.ensure(words));
   VT_HIP(vt::launch_sign_pack(c.dQ.p, vt::padded_dim(d), 1, d, c.dQbits.p, 0, c.stream));
-  std::vector<vt::Entry> cand;
+  std::vector<vt::Entry> local;
+  std::vector<vt::Entry> &cand = entries ? *entries : local;
+  cand.clear();
   VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits.p, ix->dRank.p, ix->n, d, candidates, cand, false));
   rows.resize(cand.size());
   for (size_t i = 0; i < cand.size(); ++i) rows[i] = cand[i].row;
@@ -2733,6 +2735,176 @@ int batch_multi(vt_flat *h, const float *queries, size_t nq, size_t d, size_t li
   return rc;
 }
 
+// ---- quantized / funnel / hybrid search on a multi-shard handle --------------------------
+// Every step of those searches is "the best `keep` rows of a row set under some score"
+// (binary_top_k, search.rs:76-92; vector_top_k on a prefix or on the full vectors,
+// search.rs:38-73; the index's own search).  Each shard finds the best `keep` of ITS part of the
+// row set, the handle merges the shards' lists by (rank key, id bytes) -- the order every one of
+// those functions sorts by -- and the survivors are dealt back to their shards for the next
+// step.  The global best `keep` are among the shards' best `keep`, so the result is the
+// reference's.
+enum StageKind { STAGE_HAMMING, STAGE_PREFIX, STAGE_SEARCH };
+struct StageItem {
+  uint32_t rank_key;
+  float raw;
+  uint32_t shard, row;
+  const std::string *id;
+};
+using ShardRows = std::vector<std::vector<uint32_t>>;  // per shard: rows of the current candidate set
+
+// `subset` == nullptr: all rows of every shard.  Keeps the best `keep`, ascending, in `out`.
+int multi_stage(vt_flat *h, StageKind kind, uint32_t d, const float *query, size_t n, const ShardRows *subset, size_t keep,
+                std::vector<StageItem> &out) {
+  const size_t S = h->shards.size();
+  std::vector<std::vector<vt::Entry>> per(S);
+  std::vector<size_t> which;
+  for (size_t s = 0; s < S; ++s)
+    if (h->shards[s]->n && (!subset || !(*subset)[s].empty())) which.push_back(s);
+  out.clear();
+  if (which.empty()) return VT_OK;
+  VT_TRY(on_shards(h, which, [&](size_t s) -> int {
+    Shard *ix = h->shards[s].get();
+    Ctx &c = ix->ctx;
+    const unsigned need = NEED_STRICT_RANKS | (kind == STAGE_HAMMING ? NEED_BITS : 0u);
+    if (shard_stale(ix, need, keep)) VT_TRY(shard_prepare(ix, need, keep));
+    uint32_t qnz_full = 0;
+    VT_TRY(upload_query(c, query, n, &qnz_full));
+    if (kind == STAGE_HAMMING) {
+      std::vector<uint32_t> rows;
+      return quantized_rows(ix, c, keep, rows, &per[s]);
+    }
+    if (kind == STAGE_SEARCH) {
+      ScanJob j{};
+      j.X = ix->dX;
+      j.stride = ix->ld;
+      j.id_rank = ix->dRank.p;
+      j.n = ix->n;
+      j.d = (uint32_t)ix->dim;
+      j.metric = ix->metric;
+      j.order = ix->order;
+      j.q_nonzero = qnz_full;
+      return run_scan(c, j, keep, per[s], false);
+    }
+    uint32_t nz = 0;
+    for (uint32_t i = 0; i < d; ++i) nz += query[i] != 0.0f ? 1u : 0u;
+    static const std::vector<uint32_t> none;
+    return funnel_stage(ix, c, query, d, subset ? (*subset)[s] : none, subset == nullptr, keep, nz, per[s]);
+  }));
+  for (size_t s : which)
+    for (const vt::Entry &e : per[s])
+      out.push_back(StageItem{rank_key_of(e.key), e.raw, (uint32_t)s, e.row, &h->shards[s]->ids[e.row]});
+  const size_t k = std::min(keep, out.size());
+  auto less = [](const StageItem &a, const StageItem &b) {
+    if (a.rank_key != b.rank_key) return a.rank_key < b.rank_key;
+    return *a.id < *b.id;
+  };
+  std::partial_sort(out.begin(), out.begin() + k, out.end(), less);
+  out.resize(k);
+  return VT_OK;
+}
+
+void deal_rows(const std::vector<StageItem> &items, size_t nshards, ShardRows &rows) {
+  rows.assign(nshards, {});
+  for (const StageItem &it : items) rows[it.shard].push_back(it.row);
+}
+
+int stage_hits(const std::vector<StageItem> &items, vt_hits **out) {
+  auto hh = std::make_unique<vt_hits>();
+  for (const StageItem &it : items) {
+    hh->ids.push_back(*it.id);
+    hh->raw.push_back(it.raw);
+    hh->rank_key.push_back(it.rank_key);
+  }
+  *out = hh.release();
+  return VT_OK;
+}
+
+// funnel passes (collection.ex:674-691) without the final rerank: the candidate set per shard
+int funnel_rows_multi(vt_flat *h, const float *query, size_t n, const size_t *stages, size_t nstages, size_t candidates,
+                      ShardRows &rows, bool *empty) {
+  std::vector<StageItem> kept;
+  const ShardRows *subset = nullptr;
+  for (size_t i = 0; i < nstages; ++i) {
+    VT_TRY(multi_stage(h, STAGE_PREFIX, (uint32_t)stages[i], query, n, subset, candidates, kept));
+    deal_rows(kept, h->shards.size(), rows);
+    subset = &rows;
+    if (kept.empty()) break;
+  }
+  *empty = kept.empty();
+  return VT_OK;
+}
+
+int quantized_multi(vt_flat *h, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out) {
+  VT_TRY(validate_vector(query, n, h->dim));  // collection.ex:276-295 via prepare_query
+  if (h->total() == 0 || candidates == 0 || limit == 0) return empty_hits(out);
+  std::vector<StageItem> kept;
+  VT_TRY(multi_stage(h, STAGE_HAMMING, 0, query, n, nullptr, candidates, kept));
+  if (kept.empty()) return empty_hits(out);
+  ShardRows rows;
+  deal_rows(kept, h->shards.size(), rows);
+  VT_TRY(multi_stage(h, STAGE_PREFIX, (uint32_t)h->dim, query, n, &rows, limit, kept));  // exact rerank, collection.ex:821-851
+  return stage_hits(kept, out);
+}
+
+int funnel_multi(vt_flat *h, const float *query, size_t n, const size_t *stages, size_t nstages, size_t candidates,
+                 size_t limit, vt_hits **out) {
+  VT_TRY(validate_vector(query, n, h->dim));
+  if (nstages == 0) return VT_ERR_PREFIX;
+  for (size_t i = 0; i < nstages; ++i)
+    if (stages[i] == 0 || stages[i] > n) return VT_ERR_PREFIX;
+  if (h->total() == 0 || candidates == 0 || limit == 0) return empty_hits(out);
+  ShardRows rows;
+  bool empty = false;
+  VT_TRY(funnel_rows_multi(h, query, n, stages, nstages, candidates, rows, &empty));
+  if (empty) return empty_hits(out);
+  std::vector<StageItem> kept;
+  VT_TRY(multi_stage(h, STAGE_PREFIX, (uint32_t)h->dim, query, n, &rows, limit, kept));
+  return stage_hits(kept, out);
+}
+
+int hybrid_multi(vt_flat *h, const float *query, size_t n, const int *kinds, const size_t *candidates,
+                 const size_t *stage_off, const size_t *stages, size_t ngen, size_t limit, vt_hits **out) {
+  VT_TRY(validate_vector(query, n, h->dim));
+  if (ngen == 0) return VT_ERR_ARGUMENT;
+  for (size_t i = 0; i < ngen; ++i) {
+    if (kinds[i] < VT_GEN_FUNNEL || kinds[i] > VT_GEN_SEARCH || candidates[i] == 0) return VT_ERR_ARGUMENT;
+    if (kinds[i] == VT_GEN_FUNNEL) {
+      if (stage_off[i + 1] <= stage_off[i]) return VT_ERR_PREFIX;
+      for (size_t j = stage_off[i]; j < stage_off[i + 1]; ++j)
+        if (stages[j] == 0 || stages[j] > n) return VT_ERR_PREFIX;
+    }
+  }
+  if (h->total() == 0 || limit == 0) return empty_hits(out);
+  // hybrid_candidates (collection.ex:515-532): the union of the generators' candidate sets
+  const size_t S = h->shards.size();
+  ShardRows all(S), rows;
+  std::vector<std::vector<char>> seen(S);
+  for (size_t s = 0; s < S; ++s) seen[s].assign(h->shards[s]->n, 0);
+  std::vector<StageItem> kept;
+  for (size_t i = 0; i < ngen; ++i) {
+    if (kinds[i] == VT_GEN_FUNNEL) {
+      bool empty = false;
+      VT_TRY(funnel_rows_multi(h, query, n, stages + stage_off[i], stage_off[i + 1] - stage_off[i], candidates[i], rows, &empty));
+      if (empty) rows.assign(S, {});
+    } else {
+      VT_TRY(multi_stage(h, kinds[i] == VT_GEN_QUANTIZED ? STAGE_HAMMING : STAGE_SEARCH, 0, query, n, nullptr, candidates[i], kept));
+      deal_rows(kept, S, rows);
+    }
+    for (size_t s = 0; s < S; ++s)
+      for (uint32_t r : rows[s])
+        if (!seen[s][r]) {
+          seen[s][r] = 1;
+          all[s].push_back(r);
+        }
+  }
+  bool any = false;
+  for (size_t s = 0; s < S; ++s) any = any || !all[s].empty();
+  if (!any) return empty_hits(out);
+  // hybrid_rerank :exact == exact_rerank (collection.ex:627-630, :821-851)
+  VT_TRY(multi_stage(h, STAGE_PREFIX, (uint32_t)h->dim, query, n, &all, limit, kept));
+  return stage_hits(kept, out);
+}
+
 // Device a pointer lives on (-1: not device memory we can tell).
 int device_of_pointer(const void *p) {
   hipPointerAttribute_t attr;
@@ -3249,7 +3421,11 @@ int vt_flat_quantized_search(vt_flat *h, const float *query, size_t n, size_t ca
   return guarded([&]() -> int {
   if (!h || !out || (!query && n)) return VT_ERR_ARGUMENT;
   *out = nullptr;
-  VT_SINGLE_SHARD_ONLY(h);
+  if (h->multi()) {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    if (h->poisoned) return poisoned_status();
+    return quantized_multi(h, query, n, candidates, limit, out);
+  }
   return read_single(h, NEED_STRICT_RANKS | NEED_BITS, limit, [&](Shard *ix, Ctx &c) -> int {
     return quantized_ready(ix, c, query, n, candidates, limit, out);
   });
@@ -3261,7 +3437,11 @@ int vt_flat_funnel_search(vt_flat *h, const float *query, size_t n, const size_t
   return guarded([&]() -> int {
   if (!h || !out || (!query && n) || (nstages && !stages)) return VT_ERR_ARGUMENT;
   *out = nullptr;
-  VT_SINGLE_SHARD_ONLY(h);
+  if (h->multi()) {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    if (h->poisoned) return poisoned_status();
+    return funnel_multi(h, query, n, stages, nstages, candidates, limit, out);
+  }
   return read_single(h, NEED_STRICT_RANKS, limit, [&](Shard *ix, Ctx &c) -> int {
     return funnel_ready(ix, c, query, n, stages, nstages, candidates, limit, out);
   });
@@ -3273,7 +3453,11 @@ int vt_flat_hybrid_search(vt_flat *h, const float *query, size_t n, const int *k
   return guarded([&]() -> int {
   if (!h || !out || (!query && n) || (ngen && (!kinds || !candidates || !stage_off))) return VT_ERR_ARGUMENT;
   *out = nullptr;
-  VT_SINGLE_SHARD_ONLY(h);
+  if (h->multi()) {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    if (h->poisoned) return poisoned_status();
+    return hybrid_multi(h, query, n, kinds, candidates, stage_off, stages, ngen, limit, out);
+  }
   unsigned need = NEED_STRICT_RANKS;
   for (size_t i = 0; i < ngen; ++i)
     if (kinds[i] == VT_GEN_QUANTIZED) need |= NEED_BITS;
