@@ -216,7 +216,7 @@ struct Ctx {
   int hamming_blocks_per_cu = 2;
   hipStream_t stream = nullptr;
   DevBuf<float> dQ;
-  DevBuf<uint64_t> dQbits;
+  uint64_t *dQbits = nullptr;  // the query's sign bits, behind the query in dQ (upload_query with_bits)
   DevBuf<uint64_t> dPartKeys;
   DevBuf<vt::Payload> dPartPay;
   DevBuf<uint64_t> dSelKeys;  // second level of the two-level select: kSelGroups * kMaxFusedK entries
@@ -967,10 +967,15 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
 }
 
 // Uploads a query of n floats into c.dQ padded with zeros to padded_dim(n).
-int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero) {
+// `with_bits`: the query's sign bits (compress_sign_bits, distances.rs:413-423: bit i % 64 of
+// word i / 64 set iff v[i] >= 0.0, padding bits zero) are packed on the host -- n compares --
+// and ride behind the floats in the same copy; c.dQbits points at them.
+int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero, bool with_bits = false) {
   const uint32_t ld = vt::padded_dim((uint32_t)n);
-  VT_TRY(c.dQ.ensure(ld));
-  VT_TRY(c.hQ.ensure(ld));
+  const size_t words = (n + 63) / 64;
+  const size_t total = (size_t)ld + (with_bits ? 2 * words : 0);  // in floats (ld is a multiple of 64: the words are 8-byte aligned)
+  VT_TRY(c.dQ.ensure(total));
+  VT_TRY(c.hQ.ensure(total));
   std::memcpy(c.hQ.p, q, n * sizeof(float));
   for (size_t i = n; i < ld; ++i) c.hQ.p[i] = 0.0f;
   if (q_nonzero) {
@@ -978,7 +983,14 @@ int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero) {
     for (size_t i = 0; i < n; ++i) nz += q[i] != 0.0f ? 1u : 0u;
     *q_nonzero = nz;
   }
-  VT_HIP(hipMemcpyAsync(c.dQ.p, c.hQ.p, (size_t)ld * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  if (with_bits) {
+    uint64_t *w = reinterpret_cast<uint64_t *>(c.hQ.p + ld);
+    for (size_t i = 0; i < words; ++i) w[i] = 0;
+    for (size_t i = 0; i < n; ++i)
+      if (q[i] >= 0.0f) w[i / 64] |= 1ull << (i % 64);
+    c.dQbits = reinterpret_cast<uint64_t *>(c.dQ.p + ld);
+  }
+  VT_HIP(hipMemcpyAsync(c.dQ.p, c.hQ.p, total * sizeof(float), hipMemcpyHostToDevice, c.stream));
   return VT_OK;
 }
 
@@ -1736,13 +1748,11 @@ int index_ensure_bits(Shard *ix) {
 
 // binary_top_k candidates (search.rs:76-92) of the query already in c.dQ.
 int quantized_rows(Shard *ix, Ctx &c, size_t candidates, std::vector<uint32_t> &rows, std::vector<vt::Entry> *entries = nullptr) {
-  const uint32_t d = (uint32_t)ix->dim, words = (d + 63) / 64;
-  VT_TRY(c.dQbits.ensure(words));
-  VT_HIP(vt::launch_sign_pack(c.dQ.p, vt::padded_dim(d), 1, d, c.dQbits.p, 0, c.stream));
+  const uint32_t d = (uint32_t)ix->dim;
   std::vector<vt::Entry> local;
   std::vector<vt::Entry> &cand = entries ? *entries : local;
   cand.clear();
-  VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits.p, ix->dRank.p, ix->n, d, candidates, cand, false));
+  VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits, ix->dRank.p, ix->n, d, candidates, cand, false));
   rows.resize(cand.size());
   for (size_t i = 0; i < cand.size(); ++i) rows[i] = cand[i].row;
   return VT_OK;
@@ -2105,9 +2115,7 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
   const uint32_t d = (uint32_t)ix->dim;
   const uint32_t words = (d + 63) / 64;
   uint32_t qnz = 0;
-  VT_TRY(upload_query(c, query, n, &qnz));
-  VT_TRY(c.dQbits.ensure(words));
-  VT_HIP(vt::launch_sign_pack(c.dQ.p, vt::padded_dim(d), 1, d, c.dQbits.p, 0, c.stream));
+  VT_TRY(upload_query(c, query, n, &qnz, true));
   const size_t ncand = std::min<size_t>(candidates, ix->n);
   // K4h needs integer bins in LDS, one fused select, and enough rows to be worth two passes
   const bool hist_ok = ncand <= (size_t)vt::kSelListMax && d <= vt::kHammingHistMaxDim &&
@@ -2136,7 +2144,7 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
     c.ham_dirty = true;  // until this query's collect pass has been queued
     vt::HammingHistArgs h{};
     h.bits = ix->dBits.p;
-    h.qbits = c.dQbits.p;
+    h.qbits = c.dQbits;
     h.n = ix->n;
     h.words = words;
     h.pairs = (words + 1) / 2;
@@ -2192,7 +2200,7 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
     VT_TRY(c.dStage.ensure(1));
     vt::HammingArgs h{};
     h.bits = ix->dBits.p;
-    h.qbits = c.dQbits.p;
+    h.qbits = c.dQbits;
     h.id_rank = ix->dRank.p;
     h.n = ix->n;
     h.words = words;
@@ -2211,7 +2219,7 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
   } else {
     // stage 1: binary_top_k (search.rs:76-92), candidate rows via the host
     std::vector<vt::Entry> cand;
-    VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits.p, ix->dRank.p, ix->n, d, candidates, cand, true));
+    VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits, ix->dRank.p, ix->n, d, candidates, cand, true));
     std::vector<uint32_t> rows(cand.size());
     for (size_t i = 0; i < cand.size(); ++i) rows[i] = cand[i].row;
     VT_TRY(c.dRows.ensure(rows.size()));
@@ -2328,7 +2336,7 @@ int hybrid_ready(Shard *ix, Ctx &c, const float *query, size_t n, const int *kin
   }
   if (ix->n == 0 || limit == 0) return empty_hits(out);
   uint32_t qnz_full = 0;
-  VT_TRY(upload_query(c, query, n, &qnz_full));
+  VT_TRY(upload_query(c, query, n, &qnz_full, true));
   // hybrid_candidates (collection.ex:515-532): every generator's candidates, first occurrence wins
   std::vector<uint32_t> all, rows;
   std::vector<char> seen(ix->n, 0);
@@ -2768,7 +2776,7 @@ int multi_stage(vt_flat *h, StageKind kind, uint32_t d, const float *query, size
     const unsigned need = NEED_STRICT_RANKS | (kind == STAGE_HAMMING ? NEED_BITS : 0u);
     if (shard_stale(ix, need, keep)) VT_TRY(shard_prepare(ix, need, keep));
     uint32_t qnz_full = 0;
-    VT_TRY(upload_query(c, query, n, &qnz_full));
+    VT_TRY(upload_query(c, query, n, &qnz_full, kind == STAGE_HAMMING));
     if (kind == STAGE_HAMMING) {
       std::vector<uint32_t> rows;
       return quantized_rows(ix, c, keep, rows, &per[s]);
