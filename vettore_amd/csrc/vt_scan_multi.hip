@@ -45,16 +45,65 @@ constexpr uint32_t kMqRedo = 64;              // overflowed (query, row) pairs a
 // the query fragments are first turned into 0/1 indicators (x != 0), after which the element
 // is |q - x| like manhattan's (sums of small integers: exact in f32 in any order), jaccard
 // adding 4096 per non-zero row coordinate (exact for d < 4096), as K1 does.
-template <int OP>
-__device__ __forceinline__ float melem(float q, float x, float x4k) {
-  if (OP == OP_DOT) return q * x;
-  if (OP == OP_L2) {
-    const float t = q - x;
-    return t * t;
-  }
-  if (OP == OP_JAC) return fabsf(q - x) + x4k;
-  return fabsf(q - x);  // OP_L1, OP_LINF, OP_HAM (indicators)
+// The four elements of a lane's half chunk as two packed pairs (a = elements 0,1; b = 2,3):
+// v_pk_mul_f32 / v_pk_add_f32 do two lanes' worth of f32 work per instruction, each half
+// rounded on its own exactly like the scalar instruction (-ffp-contract=off: no fusing).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (q - x on both halves of a pair in one instruction: the compiler packs products and sums but
+// turns every form of a packed difference back into two scalar subtractions)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 q, f32x2 x) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(q), "v"(x));
+  return r;
 }
+template <int OP>
+__device__ __forceinline__ void half_chunk(const f32x4 q, const f32x4 x, const f32x4 x4k, f32x2 &a, f32x2 &b) {
+  const f32x2 qa{q.x, q.y}, qb{q.z, q.w}, xa{x.x, x.y}, xb{x.z, x.w};
+  if (OP == OP_DOT) {
+    a = qa * xa;
+    b = qb * xb;
+  } else if (OP == OP_L2) {
+    const f32x2 ta = pk_sub(qa, xa), tb = pk_sub(qb, xb);
+    a = ta * ta;
+    b = tb * tb;
+  } else if (OP == OP_JAC) {
+    const f32x2 ta = pk_sub(qa, xa), tb = pk_sub(qb, xb);
+    a = f32x2{fabsf(ta.x), fabsf(ta.y)} + f32x2{x4k.x, x4k.y};
+    b = f32x2{fabsf(tb.x), fabsf(tb.y)} + f32x2{x4k.z, x4k.w};
+  } else {
+    // manhattan / chebyshev / (indicator) hamming: the signed differences; |.| is applied where
+    // they are summed (an operand modifier of the scalar add / max: free)
+    a = pk_sub(qa, xa);
+    b = pk_sub(qb, xb);
+  }
+}
+// wide::f32x8::reduce_add of the chunk held by a lane pair, from the packed halves (see
+// chunk_sum in vt_scan.cuh for the four orders); both lanes return the chunk sum.
+template <int SUM_OP, int ORDER, bool ABS>
+__device__ __forceinline__ float chunk_sum_packed(int order_rt, const f32x2 a, const f32x2 b, int odd) {
+  // ABS: the halves hold signed differences whose magnitudes are summed (half_chunk)
+  if (ORDER < 0 || ORDER == 1) {
+    if (ABS) return chunk_sum<SUM_OP, ORDER>(SUM_OP, order_rt, fabsf(a.x), fabsf(a.y), fabsf(b.x), fabsf(b.y), odd);
+    return chunk_sum<SUM_OP, ORDER>(SUM_OP, order_rt, a.x, a.y, b.x, b.y, odd);
+  }
+  float e;
+  if (SUM_OP == OP_LINF) {
+    e = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(b.x), fabsf(b.y)));
+  } else if (ABS) {
+    if (ORDER == 3) e = (fabsf(a.x) + fabsf(b.x)) + (fabsf(a.y) + fabsf(b.y));
+    else if (ORDER == 2) e = ((fabsf(a.x) + fabsf(a.y)) + fabsf(b.x)) + fabsf(b.y);
+    else e = (fabsf(a.x) + fabsf(a.y)) + (fabsf(b.x) + fabsf(b.y));
+  } else if (ORDER == 3) {  // SSE2: ((l0+l2)+(l1+l3)) + ((l4+l6)+(l5+l7)): one packed add, one add
+    const f32x2 t = a + b;
+    e = t.x + t.y;
+  } else if (ORDER == 2) {  // SEQ
+    e = ((a.x + a.y) + b.x) + b.y;
+  } else {  // PAIR
+    e = (a.x + a.y) + (b.x + b.y);
+  }
+  return comb<SUM_OP>(SUM_OP, e, dpp_xor1(e));
+}
+
 template <int OP>
 __device__ __forceinline__ f32x4 indicator(f32x4 v) {
   if (OP != OP_HAM && OP != OP_JAC) return v;
@@ -105,9 +154,10 @@ __device__ __forceinline__ void released_too(f32x4 &v) { asm volatile("" : "+v"(
 // re-read columns of the same row (no extra HBM lines) and file sums the chain never reads.
 // Otherwise (ORDER = -1) bounds, tail and lane order are run-time and the loads the compiler's.
 template <int OP, int ORDER, bool FAST>
-__global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_multi_kernel(const MultiScanArgs a) {
+__global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(const MultiScanArgs a) {
   constexpr int NQ = kMqNQ, TR = kMqTR, CAP = kMqCap;
   constexpr int SUM_OP = (OP == OP_HAM || OP == OP_JAC) ? OP_L1 : OP;  // how chunk sums combine
+  constexpr bool kAbs = OP == OP_L1 || OP == OP_LINF || OP == OP_HAM;     // half_chunk leaves signed differences
   extern __shared__ __align__(16) float lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -234,17 +284,21 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_multi_kernel(const
           const f32x4 x = indicator<OP>(cur[u]);
           f32x4 x4k = x;
           if (OP == OP_JAC) x4k = f32x4{x.x * 4096.0f, x.y * 4096.0f, x.z * 4096.0f, x.w * 4096.0f};
+          // the eight queries' chains are independent: written level by level (all products, then
+          // all sums) so that the instruction stream interleaves them instead of walking one
+          // dependent chain after the other
           float sum[NQ];
+          f32x2 pa[NQ], pb[NQ];
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const f32x4 qv = indicator<OP>(qcur[q]);
-            const float p0 = melem<OP>(qv.x, x.x, x4k.x);
-            const float p1 = melem<OP>(qv.y, x.y, x4k.y);
-            const float p2 = melem<OP>(qv.z, x.z, x4k.z);
-            const float p3 = melem<OP>(qv.w, x.w, x4k.w);
-            sum[q] = chunk_sum<SUM_OP, ORDER>(SUM_OP, a.order, p0, p1, p2, p3, odd);
-            if (!FAST && tail && c == cfull)  // tail chunk: the reference adds these products one by one
-              *reinterpret_cast<f32x4 *>(S + q * kMqQS + u * kMqSS + kMqTail + odd * 4) = f32x4{p0, p1, p2, p3};
+          for (int q = 0; q < NQ; ++q) half_chunk<OP>(indicator<OP>(qcur[q]), x, x4k, pa[q], pb[q]);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) sum[q] = chunk_sum_packed<SUM_OP, ORDER, kAbs>(a.order, pa[q], pb[q], odd);
+          if (!FAST && tail && c == cfull) {  // tail chunk: the reference adds these products one by one
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+              *reinterpret_cast<f32x4 *>(S + q * kMqQS + u * kMqSS + kMqTail + odd * 4) =
+                  kAbs ? f32x4{fabsf(pa[q].x), fabsf(pa[q].y), fabsf(pb[q].x), fabsf(pb[q].y)}
+                       : f32x4{pa[q].x, pa[q].y, pb[q].x, pb[q].y};
           }
           // (sums of padding chunks land in slots the chain never reads)
 #pragma unroll
