@@ -343,3 +343,29 @@ def test_bench_runs_as_the_driver_invokes_it_for_two_gpus():
     assert "one handle over 2 devices" in line["config"]["sharding"] and line["config"]["processes"] == 1
     assert line["roofline"]["algorithmic_bytes_per_launch"] == line["config"]["rows_per_gpu"] * 64 * 4 or \
         abs(line["roofline"]["algorithmic_bytes_per_launch"] - 100000 * 64 * 4) < 0.05 * 100000 * 64 * 4
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0]])
+def test_a_mutation_that_dies_half_way_poisons_the_handle(nifs, oracle_mod, devices, monkeypatch):
+    """nifs.rs:266-309: a panic under the write lock poisons the RwLock and every later NIF call
+    returns {:error, "flat lock poisoned"}.  Here: a device failure after a mutation began changing
+    the index (injected between the id table's update and the rows' arrival).  Validation errors
+    come before anything is stored (flat.rs:69-85) and poison nothing."""
+    g = ShardedIndex(nifs, 0, devices)
+    g.insert_many([("a", [0.0, 0.0]), ("b", [1.0, 0.0]), ("c", [2.0, 0.0])])
+    with pytest.raises(GpuError, match="dimension mismatch"):
+        g.insert("d", [1.0])
+    with pytest.raises(GpuError, match="non-finite"):
+        g.insert_many([("d", [1.0, 1.0]), ("e", [float("nan"), 0.0])])
+    assert [h[0] for h in g.search([0.9, 0.0], 2)] == [b"b", b"a"] and len(g) == 3      # still healthy
+    monkeypatch.setenv("VT_TEST_FAIL_AFTER_ID_UPDATE", "1")
+    res = nifs.flat_insert(g.ref, "d", [3.0, 0.0])
+    assert res[0] == "error" and "injected" in res[1]
+    monkeypatch.delenv("VT_TEST_FAIL_AFTER_ID_UPDATE")
+    for res in (nifs.flat_search(g.ref, [0.9, 0.0], 2), nifs.flat_insert(g.ref, "e", [4.0, 0.0]),
+                nifs.flat_delete(g.ref, "a"), nifs.flat_search_batch(g.ref, np.zeros((2, 2), np.float32), 1),
+                nifs.flat_quantized_search(g.ref, [0.9, 0.0], 3, 2)):
+        assert res == ("error", "flat lock poisoned"), res
+    fresh = ShardedIndex(nifs, 0, devices)       # other handles are unaffected
+    fresh.insert("x", [1.0, 1.0])
+    assert fresh.search([1.0, 1.0], 1) == [(b"x", 0.0)]

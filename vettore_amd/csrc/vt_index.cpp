@@ -1254,6 +1254,10 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new);
     if (!is_new || target[i] != n_before + i) all_appended_in_order = false;
   }
+  // (test hook: a device failure between the id table's change and the rows' arrival, the one
+  // window in which a mutation cannot be taken back -- tests/test_gpu_multishard.py checks that
+  // the handle is poisoned from then on)
+  if (std::getenv("VT_TEST_FAIL_AFTER_ID_UPDATE")) return fail(VT_ERR_DEVICE, "injected failure after the id table changed");
   if (count > kMaxDerivedDirty) {
     ix->bits_valid = false;
     ix->max_sqnorm = -1.0;
