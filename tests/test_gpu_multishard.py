@@ -369,3 +369,32 @@ def test_a_mutation_that_dies_half_way_poisons_the_handle(nifs, oracle_mod, devi
     fresh = ShardedIndex(nifs, 0, devices)       # other handles are unaffected
     fresh.insert("x", [1.0, 1.0])
     assert fresh.search([1.0, 1.0], 1) == [(b"x", 0.0)]
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_device_resident_batches_with_scattered_rows(nifs, oracle_mod, devices):
+    """vt_flat_load_device_matrix when the batch does not land as one block: a batch dealt to
+    shards by the hash of its ids, upserts of rows all over the slab, an id twice in one batch
+    (the last occurrence wins, flat.rs:270-281) -- one gather launch per shard, same index as
+    the oracle's."""
+    import torch
+    n, d = 20_000, 40
+    x, ids = make_corpus(n, d, 31, False, oracle_mod)
+    g = ShardedIndex(nifs, 0, devices)
+    o = oracle_mod.FlatIndex(0)
+    xd = torch.from_numpy(x).to("cuda:0")
+    assert nifs.flat_load_device_matrix(g.ref, nifs.pack_ids(ids), xd.data_ptr(), n, d) == ("ok", ())
+    o.insert_matrix(ids, x)
+    # upserts of every third row in shuffled order, one id twice, plus new ids, from device memory
+    rng = np.random.default_rng(5)
+    pick = rng.permutation(np.arange(0, n, 3))[:3000]
+    up_ids = [ids[i] for i in pick] + [ids[int(pick[0])]] + [b"new-%d" % i for i in range(200)]
+    up = rng.uniform(-1, 1, (len(up_ids), d)).astype(np.float32)
+    ud = torch.from_numpy(up).to("cuda:0")
+    assert nifs.flat_load_device_matrix(g.ref, nifs.pack_ids(up_ids), ud.data_ptr(), len(up_ids), d) == ("ok", ())
+    o.insert_many(list(zip(up_ids, up)))
+    assert len(g) == len(o) == n + 200
+    for q in (up[0], up[len(pick)], up[-1], x[1], rng.uniform(-1, 1, d).astype(np.float32)):
+        assert bits(g.search(q, 20)) == bits(o.search(q, 20))
+    # the row written twice holds its LAST value
+    assert g.search(up[len(pick)], 1)[0] == (ids[int(pick[0])], 0.0)

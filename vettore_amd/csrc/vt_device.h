@@ -227,6 +227,11 @@ hipError_t launch_check_finite(const float *rows, size_t stride, uint32_t n, uin
 // dst[n][dst_stride] <- src[n][d], columns d..dst_stride-1 zero-filled.
 hipError_t launch_pad_rows(const float *src, uint32_t n, uint32_t d, float *dst, size_t dst_stride, hipStream_t s);
 
+// dst row map[2i + 1] <- src row map[2i] for i < count (map on the device; src rows are d floats,
+// dst rows dst_stride floats, zero padded).
+hipError_t launch_gather_rows(const float *src, uint32_t d, const uint32_t *map, uint32_t count, float *dst,
+                              size_t dst_stride, hipStream_t s);
+
 // K5 / row norms for a device list of rows (derived data of mutated rows patched in place).
 hipError_t launch_sign_pack_rows(const float *rows, size_t stride, const uint32_t *list, uint32_t count, uint32_t d,
                                  uint64_t *bits, hipStream_t s);

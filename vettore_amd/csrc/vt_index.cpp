@@ -1188,6 +1188,16 @@ int index_lazy_ranks(Shard *ix) {
   return VT_OK;
 }
 
+// Device a pointer lives on (-1: not device memory we can tell).
+int device_of_pointer(const void *p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return attr.device;
+}
+
 struct RowSource {
   const float *host = nullptr;    // host rows (ragged or dense)
   const size_t *off = nullptr;    // ragged offsets; null => dense with `d`
@@ -1278,13 +1288,32 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
       float *dst = ix->dX + (size_t)n_before * ld;
       if (ld == d) VT_HIP(hipMemcpyAsync(dst, first, count * d * sizeof(float), hipMemcpyDefault, c.stream));
       else VT_HIP(vt::launch_pad_rows(first, (uint32_t)count, (uint32_t)d, dst, ld, c.stream));
-    } else {
+    } else if (count < 64 || device_of_pointer(src.device) != c.device) {
+      // (few rows, or rows that live on another device: plain copies, which need no peer mapping)
       for (size_t i = 0; i < count; ++i) {
         float *dst = ix->dX + (size_t)target[i] * ld;
         const size_t p = src.pick ? src.pick[i] : i;
         VT_HIP(hipMemsetAsync(dst, 0, (size_t)ld * sizeof(float), c.stream));
         VT_HIP(hipMemcpyAsync(dst, src.device + p * d, d * sizeof(float), hipMemcpyDefault, c.stream));
       }
+    } else {
+      // scattered rows (upserts, or a batch dealt to shards by the hash of its ids): one gather
+      // launch over a (source row, slab row) map instead of a copy per row.  Duplicate ids of a
+      // batch map to one slab row: only the LAST occurrence is kept in the map (flat.rs:270-281).
+      std::vector<uint32_t> map;
+      map.reserve(2 * count);
+      std::unordered_map<uint32_t, size_t> last;
+      for (size_t i = 0; i < count; ++i) last[target[i]] = i;
+      for (size_t i = 0; i < count; ++i) {
+        if (last[target[i]] != i) continue;
+        map.push_back((uint32_t)(src.pick ? src.pick[i] : i));
+        map.push_back(target[i]);
+      }
+      DevBuf<uint32_t> dMap;
+      VT_TRY(dMap.ensure(map.size()));
+      VT_HIP(hipMemcpyAsync(dMap.p, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+      VT_HIP(vt::launch_gather_rows(src.device, (uint32_t)d, dMap.p, (uint32_t)(map.size() / 2), ix->dX, ld, c.stream));
+      VT_HIP(hipStreamSynchronize(c.stream));  // (map and dMap die with this scope)
     }
     VT_HIP(hipStreamSynchronize(c.stream));
   } else {
@@ -2644,19 +2673,22 @@ int exchange_setup(vt_flat *h) {
       if (devs[a] == devs[b]) return fail(VT_ERR_UNSUPPORTED, "RCCL needs every shard on its own device");
   Rccl &r = rccl();
   if (!r.ok) return fail(VT_ERR_DEVICE, r.error);
+  // buffers first, communicators last: the handle either has a complete exchange or none
+  if (h->dBlock.empty()) {
+    h->dBlock.assign(S, nullptr);
+    h->dGather.assign(S, nullptr);
+  }
+  for (size_t s = 0; s < S; ++s) {
+    VT_HIP(hipSetDevice(devs[s]));
+    if (!h->dBlock[s]) VT_HIP(hipMalloc(&h->dBlock[s], kExchangeBlockBytes));
+    if (!h->dGather[s]) VT_HIP(hipMalloc(&h->dGather[s], S * kExchangeBlockBytes));
+  }
+  VT_HIP(hipSetDevice(devs[0]));
+  VT_TRY(h->hGather.ensure(S * kExchangeBlockBytes));
   std::vector<ncclComm_t> comms(S, nullptr);
   const ncclResult_t rc = r.CommInitAll(comms.data(), (int)S, devs.data());
   if (rc != ncclSuccess) return fail(VT_ERR_DEVICE, std::string("ncclCommInitAll: ") + r.GetErrorString(rc));
   h->comms = std::move(comms);
-  h->dBlock.assign(S, nullptr);
-  h->dGather.assign(S, nullptr);
-  for (size_t s = 0; s < S; ++s) {
-    VT_HIP(hipSetDevice(devs[s]));
-    VT_HIP(hipMalloc(&h->dBlock[s], kExchangeBlockBytes));
-    VT_HIP(hipMalloc(&h->dGather[s], S * kExchangeBlockBytes));
-  }
-  VT_HIP(hipSetDevice(devs[0]));
-  VT_TRY(h->hGather.ensure(S * kExchangeBlockBytes));
   return VT_OK;
 }
 
@@ -2706,7 +2738,6 @@ int search_multi(vt_flat *h, const float *query, size_t n, size_t limit, vt_hits
       for (uint32_t i = 0; i < count && i < limit; ++i)
         items.push_back(MergeItem{rank_key_of(e[i].key), e[i].raw, &h->shards[s]->ids[e[i].row]});
     }
-    h->xprof.merge_launches += 1;
     return merged_hits(items, limit, out);
   }
   // host exchange: every shard's select kernel writes its list through the host mapping
@@ -2915,16 +2946,6 @@ int hybrid_multi(vt_flat *h, const float *query, size_t n, const int *kinds, con
   // hybrid_rerank :exact == exact_rerank (collection.ex:627-630, :821-851)
   VT_TRY(multi_stage(h, STAGE_PREFIX, (uint32_t)h->dim, query, n, &all, limit, kept));
   return stage_hits(kept, out);
-}
-
-// Device a pointer lives on (-1: not device memory we can tell).
-int device_of_pointer(const void *p) {
-  hipPointerAttribute_t attr;
-  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
-    (void)hipGetLastError();
-    return -1;
-  }
-  return attr.device;
 }
 
 // Shared body of insert_many / load_matrix / load_device_matrix once every row is validated:

@@ -715,6 +715,18 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float *__restrict__
   }
 }
 
+// dst row map[2i + 1] <- src row map[2i] (first d columns; the rest of the dst row zeroed): rows
+// of a device-resident batch that land scattered in the slab (upserts; a batch dealt to shards).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, uint32_t d,
+                                                          const uint32_t *__restrict__ map, uint32_t count,
+                                                          float *__restrict__ dst, size_t dst_stride) {
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const float *from = src + (size_t)map[2 * i] * d;
+    float *to = dst + (size_t)map[2 * i + 1] * dst_stride;
+    for (uint32_t c = threadIdx.x; c < dst_stride; c += blockDim.x) to[c] = c < d ? from[c] : 0.0f;
+  }
+}
+
 // K6 (cosine part): exact rerank value of distances.rs:160-177.  One wave per
 // candidate: the wave stages the row and the query in LDS with coalesced loads,
 // then lanes 0..2 run the three sequential f64 sums |q|^2, |x|^2, q.x in index
@@ -1259,6 +1271,14 @@ hipError_t launch_scatter_u32(const uint32_t *pairs, uint32_t n, uint32_t *dst, 
 hipError_t launch_pad_rows(const float *src, uint32_t n, uint32_t d, float *dst, size_t dst_stride, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(pad_rows_kernel, dim3(2048), dim3(256), 0, s, src, n, d, dst, dst_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const float *src, uint32_t d, const uint32_t *map, uint32_t count, float *dst,
+                              size_t dst_stride, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(count < 4096 ? count : 4096), dim3(256), 0, s, src, d, map, count, dst,
+                     dst_stride);
   return hipGetLastError();
 }
 
