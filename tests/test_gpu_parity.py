@@ -1077,6 +1077,44 @@ def test_searches_between_unsorted_inserts_stay_exact(nifs, oracle_mod):
         assert len(g) == len(o)
 
 
+def test_equal_keys_among_unranked_rows(nifs, oracle_mod):
+    """Rows inserted out of id order share one sentinel rank until the next re-rank, so two of them
+    at the same f32 distance carry the SAME 64-bit key.  A top-k compaction that keeps "the first k
+    keys <= threshold" then drops a smaller key when the threshold has equals in front of it -- r01's
+    bug: `limit: 1` returned the second-best row (1 in ~1e6 searches on random data, found by a soak
+    test).  Here deterministically: the duplicates sit in lower lanes than the true best row."""
+    d = 8
+    far = np.full(d, 4.0, np.float32)
+    a = np.zeros(d, np.float32); a[0] = 2.0
+    q = np.zeros(d, np.float32)
+    rows = [("z9", far), ("y8", a), ("x7", a), ("w6", q)] + \
+           [("v%02d" % (40 - i), np.full(d, 3.0 + i / 64, np.float32)) for i in range(36)]
+    for metric in (0, 1, 5):
+        g = GpuIndex(nifs, metric)
+        o = oracle_mod.FlatIndex(metric)
+        for id_, v in rows:                     # one by one, ids descending: every row but the first is unranked
+            g.insert(id_, v)
+            o.insert(id_, v)
+        for k in (1, 2, 3, 4, 10):
+            assert bits(g.search(q, k)) == bits(o.search(q, k)), (metric, k)
+        assert g.search(q, 1)[0][0] == b"w6"
+    # the same at scale: coordinates from {-1, 0, 1} give thousands of exactly equal distances; ids in
+    # shuffled order (all unranked), limits on both sides of the buffer sizes (long lists go through
+    # the radix select, short ones through the counting one)
+    rng = np.random.default_rng(12)
+    n, d = 60_000, 12
+    x = rng.integers(-1, 2, (n, d)).astype(np.float32)
+    ids = [b"k%06d" % i for i in rng.permutation(n)]
+    g = GpuIndex(nifs, 0)
+    o = oracle_mod.FlatIndex(0)
+    for s0 in range(0, n, 4000):               # below the bulk-ranking size: rows stay unranked
+        g.insert_many([(ids[i], x[i]) for i in range(s0, s0 + 4000)])
+    o.insert_matrix(ids, x)
+    for k in (1, 2, 7, 30, 64, 65, 200, 255):
+        q = rng.integers(-1, 2, d).astype(np.float32)
+        assert bits(g.search(q, k)) == bits(o.search(q, k)), k
+
+
 def test_derived_data_is_patched_after_mutations(nifs, oracle_mod, monkeypatch):
     """Sign bits (quantized_search) and row norms (batched L2) are kept per row and patched for the
     rows an insert / upsert / delete touched instead of being rebuilt; every search in between

@@ -114,16 +114,23 @@ struct WaveTopK {
     wave_lds_fence();
     const uint64_t lt = (1ull << lane) - 1;
     uint32_t base = 0;
+    // Keys are NOT always distinct: rows inserted out of id order share one sentinel rank until
+    // the next re-rank (lazy mode), so two of them with the same f32 rank carry the same key, and
+    // callers may pass duplicate ids.  "<= T" can then hold more than k entries; the ones left
+    // out must be among the equals of T, never a smaller key: the smaller ones are filed first.
 #pragma unroll
-    for (int j = 0; j < kRegs; ++j) {
-      const bool has = key[j] != kEmptyKey && key[j] <= T;
-      const uint64_t m = __ballot(has);
-      const uint32_t pos = base + __popcll(m & lt);
-      if (has && pos < k) {
-        bk[pos] = key[j];
-        bp[pos] = pay[j];
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int j = 0; j < kRegs; ++j) {
+        const bool has = key[j] != kEmptyKey && (pass == 0 ? key[j] < T : key[j] == T);
+        const uint64_t m = __ballot(has);
+        const uint32_t pos = base + __popcll(m & lt);
+        if (has && pos < k) {
+          bk[pos] = key[j];
+          bp[pos] = pay[j];
+        }
+        base += __popcll(m);
       }
-      base += __popcll(m);
     }
     n = base < k ? base : k;
     wave_lds_fence();

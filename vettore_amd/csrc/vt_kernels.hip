@@ -18,9 +18,11 @@ namespace {
 //   pass 2  histogram of the first digit -> the bin holding the k-th key,
 //   pass 3  keys below that bin are winners; keys in it move to an LDS list,
 //   then the remaining digits are resolved on the LDS list only.
-// Keys are unique (id_rank is unique per row), so "<= threshold" selects
-// exactly k.  The winners are rank-sorted in LDS and written, with the status
-// word of the scan, straight into the host-mapped result block.
+// Keys are distinct when every row carries its own id rank; rows that share the lazy
+// mode's sentinel rank (and callers' duplicate ids) can carry EQUAL keys, so "<= threshold"
+// may hold more than k: everything below the threshold is filed first, then its equals, and
+// only equals are ever left out.  The winners are rank-sorted in LDS and written, with the
+// status word of the scan, straight into the host-mapped result block.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kSelCand = 4096;  // LDS candidate list capacity
 
@@ -272,15 +274,20 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
         hb = next_hb(shift);
       }
       from_cand = true;
-      for (uint32_t i = tid; i < ncand; i += 1024) {
-        const uint64_t key = cand_key[i];
-        if (key <= Tc) {
-          const uint32_t pos = atomicAdd(&s_sel, 1u);
-          if (pos < k) {
-            sel_key[pos] = key;
-            sel_idx[pos] = cand_idx[i];
+      // (equal keys exist -- see WaveTopK::compact: everything below the threshold is filed
+      // before its equals, so that only equals can be left out)
+      for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t i = tid; i < ncand; i += 1024) {
+          const uint64_t key = cand_key[i];
+          if (pass == 0 ? key < Tc : key == Tc) {
+            const uint32_t pos = atomicAdd(&s_sel, 1u);
+            if (pos < k) {
+              sel_key[pos] = key;
+              sel_idx[pos] = cand_idx[i];
+            }
           }
         }
+        __syncthreads();
       }
     } else {
       // crowded bin (more than kSelCand keys share the digit): keep resolving on the global keys
@@ -312,16 +319,20 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
   }
 
   if (!from_cand) {
-    // compaction of the winners straight from the global keys
-    for_each_key(keys, m, tid, [&](uint64_t key, uint32_t i) {
-      if (live(key) && key <= T) {
-        const uint32_t pos = atomicAdd(&s_sel, 1u);
-        if (pos < k) {
-          sel_key[pos] = key;
-          sel_idx[pos] = i;
+    // compaction of the winners straight from the global keys: below the threshold first, then
+    // its equals
+    for (int pass = 0; pass < 2; ++pass) {
+      for_each_key(keys, m, tid, [&](uint64_t key, uint32_t i) {
+        if (live(key) && (pass == 0 ? key < T : key == T)) {
+          const uint32_t pos = atomicAdd(&s_sel, 1u);
+          if (pos < k) {
+            sel_key[pos] = key;
+            sel_idx[pos] = i;
+          }
         }
-      }
-    });
+      });
+      __syncthreads();
+    }
   }
   __syncthreads();
   const uint32_t nsel = s_sel < k ? s_sel : k;
