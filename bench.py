@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--limit", type=int, default=10)
+    ap.add_argument("--metric", default="cosine",
+                    choices=["cosine", "l2", "l2_squared", "inner_product", "negative_inner_product", "manhattan", "chebyshev"],
+                    help="single mode: the index metric (default: the headline's cosine; BASELINE configs[3] is "
+                         "`--metric l2 --rows 40000000 --gpus 8`)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--mode", choices=["single", "batch", "quantized", "funnel"], default="single",
@@ -423,7 +427,7 @@ def main():
                 shards_in_process, shards_in_process, shards_in_process, ndev))
         if a.exchange != "auto":
             os.environ["VT_SHARD_EXCHANGE"] = a.exchange
-        ref = nifs.flat_new_sharded(nifs.METRIC_CODE["cosine"], devices)
+        ref = nifs.flat_new_sharded(nifs.METRIC_CODE[a.metric], devices)
         nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
         all_idx = np.arange(1, a.rows + 1, dtype=np.int64)
         route = nifs.flat_route_ids(ref, doc_ids(0, a.rows))
@@ -449,7 +453,7 @@ def main():
         count = per if rank < world - 1 else a.rows - start
         x = build_shard(torch, device, count, a.dim, SEED_CORPUS + rank)
         ids = doc_ids(start, count)
-        ref = nifs.flat_new_cosine()
+        ref = nifs._flat_new(nifs.METRIC_CODE[a.metric])
         nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
         res = nifs.flat_load_device_matrix(ref, ids, x.data_ptr(), count, a.dim)
         assert res == ("ok", ()), res
@@ -518,7 +522,7 @@ def main():
         bytes_per_launch = prof["scan_bytes"] / max(1, prof["scan_launches"])
         achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         out = {
-            "metric": "queries/sec, flat cosine top-%d, N=%d d=%d (achieved HBM GB/s in roofline)" % (a.limit, a.rows, a.dim),
+            "metric": "queries/sec, flat %s top-%d, N=%d d=%d (achieved HBM GB/s in roofline)" % (a.metric, a.limit, a.rows, a.dim),
             "value": qps,
             "unit": "queries/s",
             "n_gpus": a.gpus,
@@ -532,7 +536,7 @@ def main():
             "data": "synthetic",
             "rccl_ranks": rccl_ranks,
             "config": {
-                "workload": "index: :flat, metric: :cosine, d=%d, N=%d, limit=%d, single query in flight" % (a.dim, a.rows, a.limit),
+                "workload": "index: :flat, metric: :%s, d=%d, N=%d, limit=%d, single query in flight" % (a.metric, a.dim, a.rows, a.limit),
                 "rows_per_gpu": count,
                 "reduce_order": a.reduce_order,
                 "sharding": sharding,
@@ -553,13 +557,19 @@ def main():
                 "frac_of_measured_read_peak": (achieved / measured_read_peak()) if measured_read_peak() else None,
             },
         }
+        if shards_in_process > 1 or force_sharded:
+            out["config"]["devices"] = devices
+            if len(set(devices)) < len(devices):
+                # several shards on one GPU: their scans overlap, a launch sees a share of the card
+                out["roofline"]["note"] = "shards share a device: per-launch figures are one overlapping scan's share"
+                out["roofline"]["whole_job_GBps"] = a.rows * a.dim * 4 / (dt / a.steps) / 1e9 / len(set(devices))
         if (shards_in_process > 1 or force_sharded) and rccl_ranks:
             # the same steps over the other exchange, for comparison (not the headline)
             assert nifs.flat_set_exchange(ref, _lib.EXCHANGE_HOST) == "ok"
             dt2, _ = timed_run()
             out["config"]["host_exchange_ms_per_step"] = dt2 / a.steps * 1e3
             assert nifs.flat_set_exchange(ref, _lib.EXCHANGE_RCCL) == "ok"
-        if a.gpus == 1 and not launched and not a.no_side and not force_sharded:
+        if a.gpus == 1 and not launched and not a.no_side and not force_sharded and a.metric == "cosine":
             out["side"] = side_legs(a, torch, nifs, L, device, ref)
         if a.gpus == 1 and not launched and not a.no_cpu and a.cpu_seconds > 0:
             cb = cpu_baseline(a.dim, a.limit, a.cpu_seconds)
