@@ -132,12 +132,17 @@ def test_sharded_validation_and_unsupported_calls(nifs, oracle_mod):
 
 
 @pytest.mark.parametrize("metric", [2, 0, 3])
-def test_staged_searches_on_a_sharded_handle_equal_the_one_gpu_index(nifs, oracle_mod, metric):
+@pytest.mark.parametrize("rounds", ["one", "per-stage"])
+def test_staged_searches_on_a_sharded_handle_equal_the_one_gpu_index(nifs, oracle_mod, metric, rounds, monkeypatch):
     """quantized_search, funnel_search and hybrid_search (collection.ex:276-295, :245-260,
     :325-345) on a 3-shard resource: every step keeps the best rows of a row set, per shard and
     then merged by (rank key, id bytes) -- the results must equal the one-GPU index's (which the
-    parity tests pin to the oracle's composition), and the quantized one the oracle's directly."""
-    n, d = 30_000, 96
+    parity tests pin to the oracle's composition), and the quantized one the oracle's directly.
+    Both ways the handle can run them: one fan-out (every shard its whole chain, the handle
+    cuts afterwards) and one fan-out per stage (`VT_STAGED_ROUNDS`, also the fallback)."""
+    if rounds == "per-stage":
+        monkeypatch.setenv("VT_STAGED_ROUNDS", "1")
+    n, d = 60_000, 96     # 20 000 rows per shard: the histogram form of the Hamming pass (n >= 16 384) runs in each
     x, ids = make_corpus(n, d, 2100 + metric, metric == 2, oracle_mod, tie_block=50)
     one = GpuIndex(nifs, metric)
     many = ShardedIndex(nifs, metric, [0, 0, 0])
@@ -170,6 +175,39 @@ def test_staged_searches_on_a_sharded_handle_equal_the_one_gpu_index(nifs, oracl
     q = qs[1]
     assert bits(unwrap(nifs.flat_quantized_search(many.ref, q, 100, 10))) == bits(unwrap(nifs.flat_quantized_search(one.ref, q, 100, 10)))
     assert bits(unwrap(nifs.flat_funnel_search(many.ref, q, [32], 100, 10))) == bits(unwrap(nifs.flat_funnel_search(one.ref, q, [32], 100, 10)))
+
+
+def test_one_round_staged_search_ignores_an_overflow_outside_the_candidate_set(nifs, oracle_mod):
+    """The one-round form reranks every shard's OWN candidates; one of them may be a row the
+    handle-wide candidate set does not contain.  If that row's full-length distance overflows
+    (here: L2 over components of 3e38, beyond f32 even through the f64 recovery,
+    distances.rs:70-98), the reference -- which never looks at it -- answers normally, and so
+    must the handle (it redoes the call stage by stage).  A row inside the set still raises."""
+    n, d, S = 3000, 16, 3
+    rng = np.random.default_rng(12)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    ids = [b"doc-%04d" % i for i in range(n)]
+    many = ShardedIndex(nifs, 0, [0] * S)
+    one = GpuIndex(nifs, 0)
+    route = nifs.flat_route_ids(many.ref, nifs.pack_ids(ids))
+    q = rng.uniform(-1, 1, d).astype(np.float32)
+    on0 = np.flatnonzero(route == 0)
+    great = list(np.flatnonzero(route == 1)[:3]) + list(np.flatnonzero(route == 2)[:3])
+    for r in great:                       # six rows whose 8-float prefix IS the query's: the whole candidate set (5)
+        x[r, :8] = q[:8]
+    bad = int(on0[0])                     # shard 0's best row under the prefix, 7th overall
+    x[bad, :8] = q[:8] + np.float32(0.001)
+    x[bad, 8:] = np.float32(3e38)
+    for ix in (one, many):
+        unwrap(nifs.flat_load_matrix(ix.ref, ids, x))
+    want = unwrap(nifs.flat_funnel_search(one.ref, q, [8], 5, 3))
+    assert bits(unwrap(nifs.flat_funnel_search(many.ref, q, [8], 5, 3))) == bits(want)
+    assert {h[0] for h in want} <= {ids[r] for r in great}
+    gens = [(nifs.GEN_FUNNEL, 5, [8])]
+    assert bits(unwrap(nifs.flat_hybrid_search(many.ref, q, gens, 3))) == bits(unwrap(nifs.flat_hybrid_search(one.ref, q, gens, 3)))
+    # seven candidates: the row is in the set, the rerank meets the overflow in both
+    assert nifs.flat_funnel_search(one.ref, q, [8], 7, 3) == ("error", "metric overflow")
+    assert nifs.flat_funnel_search(many.ref, q, [8], 7, 3) == ("error", "metric overflow")
 
 
 def test_rccl_exchange_with_a_one_rank_communicator(nifs, oracle_mod, monkeypatch):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak test over every search entry point: random insert / upsert / delete steps on a small index
 (plain or multi-shard), and after every step a search -- plain (limits 1..300), batched, quantized,
-funnel -- compared bit for bit with the oracle (an oracle index for the flat searches, the
+funnel (one or two stages), hybrid -- compared bit for bit with the oracle (an oracle index for the flat searches, the
 reference's compositions binary_top_k -> vector_top_k / prefix vector_top_k -> rerank for the staged
 ones).  Fresh seeds until SECONDS are over.
     SECONDS=200 SHARDS=3 METRICS=0,2 DIM=64 python tools/soak_all.py
@@ -74,12 +74,27 @@ def run(seed, metric, d, shards, steps=300):
                 want = oracle.vector_top_k([(i, mirror[i]) for i, _ in c], q, metric, d, k)
                 assert bits(got) == bits(want), ("quantized", cand, k)
             elif what == 11:
-                cand = int(rng.integers(1, 60)); k = int(rng.integers(1, 20)); pre = int(rng.integers(1, d + 1))
-                got = ok(nifs.flat_funnel_search(ref, q, [pre], cand, k))
+                cand = int(rng.integers(1, 60)); k = int(rng.integers(1, 20))
+                pres = sorted(int(p) for p in rng.integers(1, d + 1, size=int(rng.integers(1, 3))))
+                got = ok(nifs.flat_funnel_search(ref, q, pres, cand, k))
+                c = list(mirror.items())
+                for pre in pres:
+                    c = [(i, mirror[i]) for i, _ in oracle.vector_top_k(c, q, metric, pre, cand)]
+                want = oracle.vector_top_k(c, q, metric, d, k)
+                assert bits(got) == bits(want), ("funnel", pres, cand, k)
+            elif what == 1:
+                # hybrid_search, rerank: :exact (collection.ex:325-345): the union of the generators' candidates
+                cf, cq, cs = (int(v) for v in rng.integers(1, 40, size=3)); k = int(rng.integers(1, 20))
+                pre = int(rng.integers(1, d + 1))
+                got = ok(nifs.flat_hybrid_search(ref, q, [(nifs.GEN_FUNNEL, cf, [pre]), (nifs.GEN_QUANTIZED, cq, []),
+                                                          (nifs.GEN_SEARCH, cs, [])], k))
                 rows = list(mirror.items())
-                c = oracle.vector_top_k(rows, q, metric, pre, cand)
-                want = oracle.vector_top_k([(i, mirror[i]) for i, _ in c], q, metric, d, k)
-                assert bits(got) == bits(want), ("funnel", pre, cand, k)
+                union = {i for i, _ in oracle.vector_top_k(rows, q, metric, pre, cf)}
+                union |= {i for i, _ in oracle.binary_top_k([(i, oracle.compress_sign_bits(v)) for i, v in rows],
+                                                            oracle.compress_sign_bits(q), d, cq)}
+                union |= {i for i, _ in o.search(q, cs)}
+                want = oracle.vector_top_k([(i, mirror[i]) for i in union], q, metric, d, k)
+                assert bits(got) == bits(want), ("hybrid", pre, cf, cq, cs, k)
             else:
                 k = int(rng.integers(1, 30)) if what != 7 else int(rng.integers(250, 320))
                 assert bits(ok(nifs.flat_search(ref, q, k))) == bits(o.search(q, k)), ("search", k)

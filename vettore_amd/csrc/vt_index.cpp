@@ -21,6 +21,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include <dlfcn.h>
@@ -254,6 +255,7 @@ struct Ctx {
   DevBuf<vt::Payload> dCandPay;
   PinnedBuf<float> hQ;
   PinnedBuf<ResultBlock> hRes;  // written by the select kernel through the host mapping
+  PinnedBuf<ResultBlock> hFirst;  // a staged search's first-stage block, copied out for a cross-shard merge
   // limits above kMaxFusedK: up to kSelListMax sorted entries + header, host-mapped, allocated on first use
   PinnedBuf<unsigned char> hBig;
   unsigned char *dBigMapped = nullptr;
@@ -1741,14 +1743,16 @@ bool funnel_fits_device(const Shard *ix, const size_t *stages, size_t nstages, s
 
 // Candidate rows of one funnel pass (collection.ex:674-691) without the final rerank.
 int funnel_rows(Shard *ix, Ctx &c, const float *query, const size_t *stages, size_t nstages, size_t candidates,
-                std::vector<uint32_t> &rows) {
+                std::vector<uint32_t> &rows, std::vector<vt::Entry> *first = nullptr) {
   rows.clear();
+  if (first) first->clear();
   bool all_rows = true;
   for (size_t i = 0; i < nstages; ++i) {
     uint32_t nz = 0;
     for (size_t j = 0; j < stages[i]; ++j) nz += query[j] != 0.0f ? 1u : 0u;
     std::vector<vt::Entry> kept;
     VT_TRY(funnel_stage(ix, c, query, (uint32_t)stages[i], rows, all_rows, candidates, nz, kept));
+    if (first && i == 0) *first = kept;  // the only stage that cuts: later ones re-score the same set
     rows.resize(kept.size());
     for (size_t r = 0; r < kept.size(); ++r) rows[r] = kept[r].row;
     all_rows = false;
@@ -2141,7 +2145,21 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
 }
 
 // collection.ex:276-295 on a shard whose ranks (strict) and sign bits are current.
-int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out) {
+// What one shard of a multi-shard handle contributes to a staged search in ONE round: its
+// own candidates under each generator's cutting keys (ascending) and the exact-rerank entries
+// of all of them -- uncut, because which of them belong to the handle-wide candidate set is
+// only known once the shards' lists meet (staged_merge).
+struct LocalStages {
+  std::vector<std::vector<vt::Entry>> gens;
+  std::vector<vt::Entry> final_;
+};
+
+void entries_of_block(const ResultBlock *b, std::vector<vt::Entry> &out) { out.assign(b->e, b->e + b->count); }
+
+// `local` (multi-shard handles; candidates <= kMaxFusedK): nothing is cut to `limit` and no
+// hit list is built -- the shard's candidate and rerank entries go to *local.
+int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out,
+                    LocalStages *local = nullptr) {
   // collection.ex:276-295: prepare_query validates the query against the
   // collection's dimension; an empty store yields no candidates.
   VT_TRY(validate_vector(query, n, ix->dim));
@@ -2151,15 +2169,24 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
   uint32_t qnz = 0;
   VT_TRY(upload_query(c, query, n, &qnz, true));
   const size_t ncand = std::min<size_t>(candidates, ix->n);
+  const size_t keep = local ? ncand : limit;
   // K4h needs integer bins in LDS, one fused select, and enough rows to be worth two passes
   const bool hist_ok = ncand <= (size_t)vt::kSelListMax && d <= vt::kHammingHistMaxDim &&
                        (ix->n >= 16384 || ncand > (size_t)vt::kMaxFusedK) &&
                        !std::getenv("VT_HAMMING_LISTS");
   auto run = [&](bool use_hist) -> int {
-  std::vector<vt::Entry> entries;
+  std::vector<vt::Entry> entries, first;
+  bool first_in_block = false;
   const uint32_t *gather = nullptr;
   uint32_t gather_stride = 1;
   bool timed_hamming = false;
+  auto copy_first_block = [&]() -> int {  // queued behind the select that fills c.dStage[0]
+    if (!local) return VT_OK;
+    VT_TRY(c.hFirst.ensure(1));
+    VT_HIP(hipMemcpyAsync(c.hFirst.p, c.dStage.p, sizeof(ResultBlock), hipMemcpyDeviceToHost, c.stream));
+    first_in_block = true;
+    return VT_OK;
+  };
   if (use_hist) {
     // stage 1 as a pure stream (K4h): distance column + histogram, threshold collect,
     // select into the device block whose Entry.row column is stage 2's gather list
@@ -2211,9 +2238,11 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
       // (no status pointer: a raised flag stays in dStatus for the final select)
       VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, kListCap, k1, 0, 0, nullptr, c.dStage.p, c.dSelKeys.p, c.dSelPay.p,
                                c.stream, c.dHamCount.p));
+      VT_TRY(copy_first_block());
       gather = &c.dStage.p->e[0].row;
       gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
     } else {
+      if (local) return VT_ERR_ARGUMENT;  // callers keep one-round searches to candidates <= kMaxFusedK
       // up to 4 096 candidates (limit * 10 for limit <= 409): the exact candidate SET as a
       // device list -- stage 2 orders by its own keys, so this one need not be sorted
       VT_TRY(c.dListKeys.ensure(k1));
@@ -2248,12 +2277,14 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
     if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
     timed_hamming = c.profiling;
     VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, waves * k1, k1, 0, 0, c.dStatus.p, c.dStage.p, c.dSelKeys.p, c.dSelPay.p, c.stream));
+    VT_TRY(copy_first_block());
     gather = &c.dStage.p->e[0].row;
     gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
   } else {
     // stage 1: binary_top_k (search.rs:76-92), candidate rows via the host
     std::vector<vt::Entry> cand;
     VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits, ix->dRank.p, ix->n, d, candidates, cand, true));
+    if (local) first = cand;
     std::vector<uint32_t> rows(cand.size());
     for (size_t i = 0; i < cand.size(); ++i) rows[i] = cand[i].row;
     VT_TRY(c.dRows.ensure(rows.size()));
@@ -2278,7 +2309,7 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
     a.out_pay = c.dCandPay.p;
     a.status = c.dStatus.p;
     VT_HIP(vt::launch_cosine_rerank(a, c.stream));
-    VT_TRY(collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, (uint32_t)ncand, limit, entries));
+    VT_TRY(collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, (uint32_t)ncand, keep, entries));
   } else {
     ScanJob j{};
     j.X = ix->dX;
@@ -2291,7 +2322,7 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
     j.metric = ix->metric;
     j.order = ix->order;
     j.q_nonzero = qnz;
-    VT_TRY(run_scan(c, j, limit, entries, false));
+    VT_TRY(run_scan(c, j, keep, entries, false));
   }
   if (timed_hamming) {
     float ms = 0.f;
@@ -2299,6 +2330,12 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
     c.prof.hamming_launches += 1;
     c.prof.hamming_ms += ms;
     c.prof.hamming_bytes += (uint64_t)ix->n * words * 8;
+  }
+  if (local) {
+    if (first_in_block) entries_of_block(c.hFirst.p, first);  // (every path above ends in a stream sync)
+    local->gens.assign(1, std::move(first));
+    local->final_ = std::move(entries);
+    return VT_OK;
   }
   return make_hits(ix, entries, out);
   };
@@ -2310,7 +2347,7 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
 
 // collection.ex:245-260 on a shard whose ranks are strictly current.
 int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *stages, size_t nstages,
-                 size_t candidates, size_t limit, vt_hits **out) {
+                 size_t candidates, size_t limit, vt_hits **out, LocalStages *local = nullptr) {
   // collection.ex:245-260: prepare_query validates the query against the
   // collection; stages are prefix lengths 1..dimensions (collection.ex:905-913)
   VT_TRY(validate_vector(query, n, ix->dim));
@@ -2321,7 +2358,8 @@ int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *
   uint32_t qnz_full = 0;
   VT_TRY(upload_query(c, query, n, &qnz_full));
   std::vector<vt::Entry> entries;
-  if (funnel_fits_device(ix, stages, nstages, candidates, limit)) {
+  // (`local`: the rerank keeps every candidate -- see LocalStages)
+  if (funnel_fits_device(ix, stages, nstages, candidates, local ? candidates : limit)) {
     // the whole funnel as one chain of kernels: each stage's winners stay in a
     // device block whose row column is the next stage's gather list; one wait
     VT_TRY(c.dStage.ensure(2));
@@ -2333,20 +2371,37 @@ int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *
       const uint32_t want = (uint32_t)std::min<size_t>(candidates, count);
       ResultBlock *dst = c.dStage.p + (i & 1);
       VT_TRY(funnel_stage_dev(ix, c, query, (uint32_t)stages[i], src, count, want, nz, dst, false));
+      if (local && i == 0) {
+        VT_TRY(c.hFirst.ensure(1));
+        VT_HIP(hipMemcpyAsync(c.hFirst.p, dst, sizeof(ResultBlock), hipMemcpyDeviceToHost, c.stream));
+      }
       src = dst;
       count = want;
     }
     // exact_rerank on the full vectors (collection.ex:821-851)
-    const uint32_t want = (uint32_t)std::min<size_t>(limit, count);
+    const uint32_t want = local ? count : (uint32_t)std::min<size_t>(limit, count);
     VT_TRY(funnel_stage_dev(ix, c, query, (uint32_t)ix->dim, src, count, want, qnz_full, c.dResMapped, true));
     VT_HIP(hipStreamSynchronize(c.stream));
     VT_TRY(c.settle_prefix_profile());
     if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
     entries.assign(c.hRes.p->e, c.hRes.p->e + c.hRes.p->count);
+    if (local) {
+      local->gens.resize(1);
+      entries_of_block(c.hFirst.p, local->gens[0]);
+      local->final_ = std::move(entries);
+      return VT_OK;
+    }
     return make_hits(ix, entries, out);
   }
   std::vector<uint32_t> rows;
-  VT_TRY(funnel_rows(ix, c, query, stages, nstages, candidates, rows));
+  std::vector<vt::Entry> first;
+  VT_TRY(funnel_rows(ix, c, query, stages, nstages, candidates, rows, local ? &first : nullptr));
+  if (local) {
+    if (!rows.empty()) VT_TRY(funnel_stage(ix, c, query, (uint32_t)ix->dim, rows, false, rows.size(), qnz_full, entries));
+    local->gens.assign(1, std::move(first));
+    local->final_ = std::move(entries);
+    return VT_OK;
+  }
   if (rows.empty()) return empty_hits(out);
   // exact_rerank on the full vectors (collection.ex:821-851)
   VT_TRY(funnel_stage(ix, c, query, (uint32_t)ix->dim, rows, false, limit, qnz_full, entries));
@@ -2357,7 +2412,8 @@ int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *
 // collection.ex:325-345 on a shard whose ranks are strictly current (and whose sign bits
 // are, when a quantized generator takes part).
 int hybrid_ready(Shard *ix, Ctx &c, const float *query, size_t n, const int *kinds, const size_t *candidates,
-                 const size_t *stage_off, const size_t *stages, size_t ngen, size_t limit, vt_hits **out) {
+                 const size_t *stage_off, const size_t *stages, size_t ngen, size_t limit, vt_hits **out,
+                 LocalStages *local = nullptr) {
   VT_TRY(validate_vector(query, n, ix->dim));
   if (ngen == 0) return VT_ERR_ARGUMENT;
   for (size_t i = 0; i < ngen; ++i) {
@@ -2373,12 +2429,16 @@ int hybrid_ready(Shard *ix, Ctx &c, const float *query, size_t n, const int *kin
   VT_TRY(upload_query(c, query, n, &qnz_full, true));
   // hybrid_candidates (collection.ex:515-532): every generator's candidates, first occurrence wins
   std::vector<uint32_t> all, rows;
-  std::vector<char> seen(ix->n, 0);
+  std::unordered_set<uint32_t> seen;  // (a few hundred rows: never a column over the corpus)
+  std::vector<vt::Entry> kept;
+  if (local) local->gens.assign(ngen, {});
   for (size_t i = 0; i < ngen; ++i) {
+    kept.clear();
     if (kinds[i] == VT_GEN_FUNNEL) {
-      VT_TRY(funnel_rows(ix, c, query, stages + stage_off[i], stage_off[i + 1] - stage_off[i], candidates[i], rows));
+      VT_TRY(funnel_rows(ix, c, query, stages + stage_off[i], stage_off[i + 1] - stage_off[i], candidates[i], rows,
+                         local ? &kept : nullptr));
     } else if (kinds[i] == VT_GEN_QUANTIZED) {
-      VT_TRY(quantized_rows(ix, c, candidates[i], rows));
+      VT_TRY(quantized_rows(ix, c, candidates[i], rows, local ? &kept : nullptr));
     } else {  // the index's own search with limit = candidates (collection.ex:583-592)
       // (flat search ranks cosine by the f32 dot of normalised vectors, not by the f64 cosine
       // a vector_top_k stage would use: the plain scan serves every metric here)
@@ -2391,20 +2451,22 @@ int hybrid_ready(Shard *ix, Ctx &c, const float *query, size_t n, const int *kin
       j.metric = ix->metric;
       j.order = ix->order;
       j.q_nonzero = qnz_full;
-      std::vector<vt::Entry> kept;
       VT_TRY(run_scan(c, j, candidates[i], kept, false));
       rows.resize(kept.size());
       for (size_t r = 0; r < kept.size(); ++r) rows[r] = kept[r].row;
     }
+    if (local) local->gens[i] = kept;
     for (uint32_t r : rows)
-      if (!seen[r]) {
-        seen[r] = 1;
-        all.push_back(r);
-      }
+      if (seen.insert(r).second) all.push_back(r);
+  }
+  std::vector<vt::Entry> entries;
+  if (local) {
+    if (!all.empty()) VT_TRY(funnel_stage(ix, c, query, (uint32_t)ix->dim, all, false, all.size(), qnz_full, entries));
+    local->final_ = std::move(entries);
+    return VT_OK;
   }
   if (all.empty()) return empty_hits(out);
   // hybrid_rerank :exact == exact_rerank (collection.ex:627-630, :821-851)
-  std::vector<vt::Entry> entries;
   VT_TRY(funnel_stage(ix, c, query, (uint32_t)ix->dim, all, false, limit, qnz_full, entries));
   return make_hits(ix, entries, out);
 }
@@ -2878,9 +2940,85 @@ int funnel_rows_multi(vt_flat *h, const float *query, size_t n, const size_t *st
   return VT_OK;
 }
 
+// ---- the same searches in ONE round ------------------------------------------------------
+// Only the first stage of a generator cuts the row set (every later funnel stage keeps the same
+// `candidates`, collection.ex:674-691), and the handle-wide best `candidates` of that stage are
+// among the shards' own best `candidates`.  So every shard runs its whole chain on its own
+// candidates without waiting for anybody -- the chain a one-shard handle runs, the rerank left
+// uncut -- and hands over (first-stage entries, rerank entries); the handle cuts the union of
+// the first-stage lists to `candidates` by (rank key, id bytes), keeps the rerank entries of
+// exactly those rows and orders them.  One fan-out instead of one per stage.  A shard that
+// reports a metric overflow may have met it on a row the handle-wide set does not contain
+// (the reference would not have looked at it): such a call is redone round by round, below.
+bool staged_one_round() { return std::getenv("VT_STAGED_ROUNDS") == nullptr; }  // (tests force the round-per-stage path)
+
+std::vector<size_t> shards_with_rows(const vt_flat *h) {
+  std::vector<size_t> which;
+  for (size_t s = 0; s < h->shards.size(); ++s)
+    if (h->shards[s]->n) which.push_back(s);
+  return which;
+}
+
+int staged_merge(vt_flat *h, const std::vector<size_t> &which, const std::vector<LocalStages> &loc,
+                 const std::vector<size_t> &gen_keep, size_t limit, vt_hits **out) {
+  auto less = [](const StageItem &a, const StageItem &b) {
+    if (a.rank_key != b.rank_key) return a.rank_key < b.rank_key;
+    return *a.id < *b.id;
+  };
+  std::unordered_set<uint64_t> chosen;
+  std::vector<StageItem> items;
+  for (size_t g = 0; g < gen_keep.size(); ++g) {
+    items.clear();
+    for (size_t s : which) {
+      if (g >= loc[s].gens.size()) continue;
+      for (const vt::Entry &e : loc[s].gens[g])
+        items.push_back(StageItem{rank_key_of(e.key), e.raw, (uint32_t)s, e.row, &h->shards[s]->ids[e.row]});
+    }
+    const size_t k = std::min(gen_keep[g], items.size());
+    std::partial_sort(items.begin(), items.begin() + k, items.end(), less);
+    for (size_t i = 0; i < k; ++i) chosen.insert((uint64_t)items[i].shard << 32 | items[i].row);
+  }
+  items.clear();
+  for (size_t s : which)
+    for (const vt::Entry &e : loc[s].final_)
+      if (chosen.count((uint64_t)s << 32 | e.row))
+        items.push_back(StageItem{rank_key_of(e.key), e.raw, (uint32_t)s, e.row, &h->shards[s]->ids[e.row]});
+  if (items.size() != chosen.size()) return kRetryInternal;  // a candidate without its rerank entry: not trusted
+  const size_t k = std::min(limit, items.size());
+  std::partial_sort(items.begin(), items.begin() + k, items.end(), less);
+  items.resize(k);
+  return stage_hits(items, out);
+}
+
+// fn(shard, context, &local) runs a shard's chain; returns true when *status is final.
+template <class F>
+bool staged_once(vt_flat *h, unsigned need, size_t prep_limit, const std::vector<size_t> &gen_keep, size_t limit,
+                 vt_hits **out, int *status, F fn) {
+  if (!staged_one_round()) return false;
+  const std::vector<size_t> which = shards_with_rows(h);
+  std::vector<LocalStages> loc(h->shards.size());
+  int rc = on_shards(h, which, [&](size_t s) -> int {
+    Shard *ix = h->shards[s].get();
+    if (shard_stale(ix, need, prep_limit)) VT_TRY(shard_prepare(ix, need, prep_limit));
+    return fn(ix, ix->ctx, &loc[s]);
+  });
+  if (rc == VT_OK) rc = staged_merge(h, which, loc, gen_keep, limit, out);
+  if (rc == VT_ERR_OVERFLOW || rc == kRetryInternal) return false;
+  *status = rc;
+  return true;
+}
+
 int quantized_multi(vt_flat *h, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out) {
   VT_TRY(validate_vector(query, n, h->dim));  // collection.ex:276-295 via prepare_query
   if (h->total() == 0 || candidates == 0 || limit == 0) return empty_hits(out);
+  int status = VT_OK;
+  if (candidates <= (size_t)vt::kMaxFusedK &&
+      staged_once(h, NEED_STRICT_RANKS | NEED_BITS, candidates, {candidates}, limit, out, &status,
+                  [&](Shard *ix, Ctx &c, LocalStages *local) -> int {
+                    vt_hits *none = nullptr;
+                    return quantized_ready(ix, c, query, n, candidates, limit, &none, local);
+                  }))
+    return status;
   std::vector<StageItem> kept;
   VT_TRY(multi_stage(h, STAGE_HAMMING, 0, query, n, nullptr, candidates, kept));
   if (kept.empty()) return empty_hits(out);
@@ -2897,6 +3035,13 @@ int funnel_multi(vt_flat *h, const float *query, size_t n, const size_t *stages,
   for (size_t i = 0; i < nstages; ++i)
     if (stages[i] == 0 || stages[i] > n) return VT_ERR_PREFIX;
   if (h->total() == 0 || candidates == 0 || limit == 0) return empty_hits(out);
+  int status = VT_OK;
+  if (staged_once(h, NEED_STRICT_RANKS, candidates, {candidates}, limit, out, &status,
+                  [&](Shard *ix, Ctx &c, LocalStages *local) -> int {
+                    vt_hits *none = nullptr;
+                    return funnel_ready(ix, c, query, n, stages, nstages, candidates, limit, &none, local);
+                  }))
+    return status;
   ShardRows rows;
   bool empty = false;
   VT_TRY(funnel_rows_multi(h, query, n, stages, nstages, candidates, rows, &empty));
@@ -2919,11 +3064,25 @@ int hybrid_multi(vt_flat *h, const float *query, size_t n, const int *kinds, con
     }
   }
   if (h->total() == 0 || limit == 0) return empty_hits(out);
+  {
+    unsigned need = NEED_STRICT_RANKS;
+    size_t most = limit;
+    for (size_t i = 0; i < ngen; ++i) {
+      if (kinds[i] == VT_GEN_QUANTIZED) need |= NEED_BITS;
+      most = std::max(most, candidates[i]);
+    }
+    int status = VT_OK;
+    if (staged_once(h, need, most, std::vector<size_t>(candidates, candidates + ngen), limit, out, &status,
+                    [&](Shard *ix, Ctx &c, LocalStages *local) -> int {
+                      vt_hits *none = nullptr;
+                      return hybrid_ready(ix, c, query, n, kinds, candidates, stage_off, stages, ngen, limit, &none, local);
+                    }))
+      return status;
+  }
   // hybrid_candidates (collection.ex:515-532): the union of the generators' candidate sets
   const size_t S = h->shards.size();
   ShardRows all(S), rows;
-  std::vector<std::vector<char>> seen(S);
-  for (size_t s = 0; s < S; ++s) seen[s].assign(h->shards[s]->n, 0);
+  std::vector<std::unordered_set<uint32_t>> seen(S);
   std::vector<StageItem> kept;
   for (size_t i = 0; i < ngen; ++i) {
     if (kinds[i] == VT_GEN_FUNNEL) {
@@ -2936,10 +3095,7 @@ int hybrid_multi(vt_flat *h, const float *query, size_t n, const int *kinds, con
     }
     for (size_t s = 0; s < S; ++s)
       for (uint32_t r : rows[s])
-        if (!seen[s][r]) {
-          seen[s][r] = 1;
-          all[s].push_back(r);
-        }
+        if (seen[s].insert(r).second) all[s].push_back(r);
   }
   bool any = false;
   for (size_t s = 0; s < S; ++s) any = any || !all[s].empty();
