@@ -48,8 +48,8 @@ SEED_CORPUS, SEED_QUERY = 20260721, 20260722
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 1000: 4.6 s of scans at the headline size)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps first (default 50)")
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--limit", type=int, default=10)
@@ -381,6 +381,9 @@ def side_legs(a, torch, nifs, L, device, main_ref):
 
 def main():
     a = parse()
+    steps_default = a.steps is None
+    a.steps = 1000 if a.steps is None else a.steps
+    a.warmup = 50 if a.warmup is None else a.warmup
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -411,7 +414,7 @@ def main():
     if a.mode != "single":
         if a.gpus > 1:
             sys.exit("--mode %s is a single-GPU measurement" % a.mode)
-        if a.mode == "batch" and a.steps == 200:
+        if a.mode == "batch" and steps_default:
             a.steps, a.warmup = 8, 2
         return run_side_mode(a, torch, nifs, device)
 

@@ -601,9 +601,11 @@ constexpr int kRetryInternal = -100;
 // the multi-kernel paths add on top of their scans.
 constexpr double kScanFixedS = 35e-6, kScanBytesPerS = 6.5e12;
 constexpr double kThresholdFixedS = 140e-6, kBatchFixedS = 180e-6, kBatchFlopsPerS = 135e12;
-// K1m: one sweep carries up to 8 queries at about the byte rate of the single scan; a chain of
-// sweeps pays the call's fixed cost once
-constexpr double kMultiFixedS = 60e-6, kMultiSweepFixedS = 8e-6, kMultiBytesPerS = 4.2e12;
+// K1m: one sweep carries up to 8 queries; a chain of sweeps pays the call's fixed cost once.  A
+// sweep is priced per (tile, 256-float panel) a resident wave works through -- 2.9 us each once
+// the chip streams, 4.5 us for a wave's first ones -- plus its prologue and list merges
+// (tools/batch_path_probe.py, tools/multi_probe.py: 68 us at 150 MB, 326 us at 1.5 GB, 5.46 ms at 30 GB of d=768 rows)
+constexpr double kMultiFixedS = 60e-6, kMultiSweepFixedS = 45e-6, kMultiPanelS = 2.9e-6, kMultiRampS = 1.6e-6;
 inline double scan_seconds(double bytes) { return kScanFixedS + bytes / kScanBytesPerS; }
 
 // ------------------------------------------------------------------ selection
@@ -1995,9 +1997,14 @@ bool multi_scan_applies(const Shard *ix, size_t limit) {
   return limit >= 1 && std::min<size_t>(limit, ix->n) <= vt::scan_multi_max_k(vt::kMultiMaxQueries) &&
          !(ix->metric == VT_JACCARD && ix->dim >= 4096) && std::getenv("VT_NO_MULTI_SCAN") == nullptr;
 }
-double multi_scan_seconds(size_t nq, double bytes) {
+double multi_scan_seconds(const Shard *ix, size_t nq) {
   const double sweeps = std::ceil((double)nq / vt::kMultiMaxQueries);
-  return kMultiFixedS + sweeps * (kMultiSweepFixedS + bytes / kMultiBytesPerS);
+  const double waves = (double)ix->ctx.num_cus * 2 * vt::kWavesPerBlock;  // two blocks per CU
+  const double tiles = std::ceil((double)ix->n / vt::scan_multi_tile_rows(vt::kMultiMaxQueries));
+  double steps = std::ceil(tiles / waves) * std::ceil((double)ix->ld / 256.0);  // (tile, panel) steps of one wave
+  double per_step = kMultiPanelS + 0.3e-6 / std::ceil((double)ix->ld / 256.0);
+  if (ix->dim % 64 != 0) per_step *= 2.3;  // run-time bounds and lane order, compiler-scheduled loads
+  return kMultiFixedS + sweeps * (kMultiSweepFixedS + steps * per_step + std::min(steps, 20.0) * kMultiRampS);
 }
 
 // `count` queries (rows `which[i]` of `queries`) in ceil(count / 8) sweeps of the corpus (K1m),
@@ -2094,7 +2101,7 @@ bool batch_uses_mfma(const Shard *ix, size_t nq, size_t limit) {
     const double groups = std::ceil((double)nq / 256.0);
     const double t_pass = std::max(1.3 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kBatchFlopsPerS);
     double t_other = (double)nq * scan_seconds(bytes);
-    if (multi_scan_applies(ix, limit)) t_other = std::min(t_other, multi_scan_seconds(nq, bytes));
+    if (multi_scan_applies(ix, limit)) t_other = std::min(t_other, multi_scan_seconds(ix, nq));
     use_mfma = t_other > groups * (kBatchFixedS + t_pass);
   }
   return use_mfma;
@@ -2131,7 +2138,7 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
   // the bound could not certify): several queries per sweep of the corpus when their lists
   // fit, else one scan each
   if (left.size() >= 2 && multi_scan_applies(ix, limit) &&
-      multi_scan_seconds(left.size(), (double)ix->n * ix->ld * 4.0) < (double)left.size() * scan_seconds((double)ix->n * ix->ld * 4.0)) {
+      multi_scan_seconds(ix, left.size()) < (double)left.size() * scan_seconds((double)ix->n * ix->ld * 4.0)) {
     const int st = multi_scan_group(ix, c, queries, left, limit, out);
     if (st == VT_OK) return VT_OK;
     if (st != kRetryInternal) return st;
@@ -2144,7 +2151,6 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
   return VT_OK;
 }
 
-// collection.ex:276-295 on a shard whose ranks (strict) and sign bits are current.
 // What one shard of a multi-shard handle contributes to a staged search in ONE round: its
 // own candidates under each generator's cutting keys (ascending) and the exact-rerank entries
 // of all of them -- uncut, because which of them belong to the handle-wide candidate set is
@@ -2156,6 +2162,7 @@ struct LocalStages {
 
 void entries_of_block(const ResultBlock *b, std::vector<vt::Entry> &out) { out.assign(b->e, b->e + b->count); }
 
+// collection.ex:276-295 on a shard whose ranks (strict) and sign bits are current.
 // `local` (multi-shard handles; candidates <= kMaxFusedK): nothing is cut to `limit` and no
 // hit list is built -- the shard's candidate and rerank entries go to *local.
 int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out,
