@@ -36,7 +36,7 @@ oracle:
 	$(MAKE) -C oracle -s
 
 # stand-alone hardware probes quoted in DESIGN.md (not part of the library)
-PROBES := tools/hbm_peak tools/launch_probe tools/mfma_peak tools/mfma_agpr
+PROBES := tools/hbm_peak tools/launch_probe tools/mfma_peak tools/mfma_agpr tools/vmm_probe
 probes: $(PROBES)
 tools/%: tools/%.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@

@@ -133,6 +133,13 @@ int vt_flat_new_sharded(int metric_code, const int *devices, size_t ndev, vt_fla
 size_t vt_flat_shard_count(const vt_flat *index);
 int vt_flat_shard_device(const vt_flat *index, size_t shard);  /* -1: no such shard */
 size_t vt_flat_shard_len(const vt_flat *index, size_t shard);
+/* Where a shard's rows live: rows the slab holds without growing, its bytes, and the number of
+ * physical chunks mapped into its reserved range (0: a plain allocation, the form below one
+ * chunk).  A slab of one chunk or more grows by mapping further 1-GiB chunks behind the rows --
+ * they never move and no second slab exists beside the first (the reference's per-row Vec
+ * allocations, flat.rs:13-17, have no such step at all).  Any out pointer may be NULL. */
+int vt_flat_shard_memory(const vt_flat *index, size_t shard, size_t *row_capacity, size_t *slab_bytes,
+                         size_t *slab_chunks);
 /* out_shard[i] = shard that owns (or would own) id i. */
 int vt_flat_route_ids(const vt_flat *index, size_t count, const char *ids, const size_t *id_off,
                       uint32_t *out_shard);

@@ -13,6 +13,8 @@ pytestmark = pytest.mark.gpu
 def no_matrix_cores(monkeypatch):
     # dot-family batches would otherwise take the shared MFMA pass: here K1m serves every metric
     monkeypatch.setenv("VT_BATCH_NO_MFMA", "1")
+    # ... and on corpora of a few thousand rows two or three single scans would be priced lower than a sweep
+    monkeypatch.setenv("VT_FORCE_MULTI_SCAN", "1")
 
 
 @pytest.mark.parametrize("metric", range(9))

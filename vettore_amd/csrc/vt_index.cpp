@@ -50,11 +50,15 @@ int fail(int status, const std::string &detail) {
   return status;
 }
 
+// (a failed call also stays behind as the thread's "last error", which the launch wrappers
+// read after their <<<>>>: it is cleared here, or the next launch would report it again)
 #define VT_HIP(expr)                                                                       \
   do {                                                                                     \
     hipError_t _e = (expr);                                                                \
-    if (_e != hipSuccess)                                                                  \
+    if (_e != hipSuccess) {                                                                \
+      (void)hipGetLastError();                                                             \
       return fail(VT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+    }                                                                                      \
   } while (0)
 
 // No exception may cross the C ABI: allocation failures and anything unexpected
@@ -62,6 +66,7 @@ int fail(int status, const std::string &detail) {
 template <typename F>
 int guarded(F &&f) noexcept {
   try {
+    (void)hipGetLastError();  // whatever another library left behind on this thread is not ours to report
     return f();
   } catch (const std::bad_alloc &) {
     return fail(VT_ERR_NOMEM, "out of host memory");
@@ -170,6 +175,47 @@ void parallel_sort(std::vector<uint32_t> &idx, Less less) {
   }
 }
 
+// fn(lo, hi) over [0, n) on several threads when n is large.
+template <typename F>
+void parallel_for(size_t n, F fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  const size_t parts = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 1, 32), n >> 16));
+  if (parts == 1) {
+    fn((size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < parts; ++i) th.emplace_back([&, i] { fn(n * i / parts, n * (i + 1) / parts); });
+  for (auto &t : th) t.join();
+}
+
+// std::merge of two sorted index lists (no equal elements across them) on several threads:
+// `a` is cut into equal runs, each run's first element finds its place in `b`, the pieces merge
+// independently.  The compares chase ids all over the heap, so this is latency-bound work that
+// scales with the cores.
+template <typename Less>
+void parallel_merge(const std::vector<uint32_t> &a, const std::vector<uint32_t> &b, std::vector<uint32_t> &out, Less less) {
+  out.resize(a.size() + b.size());
+  unsigned hw = std::thread::hardware_concurrency();
+  const size_t parts = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 1, 32), a.size() >> 16));
+  if (parts == 1) {
+    std::merge(a.begin(), a.end(), b.begin(), b.end(), out.begin(), less);
+    return;
+  }
+  std::vector<size_t> ca(parts + 1), cb(parts + 1);
+  for (size_t i = 0; i <= parts; ++i) ca[i] = a.size() * i / parts;
+  cb[0] = 0;
+  cb[parts] = b.size();
+  for (size_t i = 1; i < parts; ++i) cb[i] = (size_t)(std::lower_bound(b.begin(), b.end(), a[ca[i]], less) - b.begin());
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < parts; ++i)
+    th.emplace_back([&, i] {
+      std::merge(a.begin() + ca[i], a.begin() + ca[i + 1], b.begin() + cb[i], b.begin() + cb[i + 1],
+                 out.begin() + ca[i] + cb[i], less);
+    });
+  for (auto &t : th) t.join();
+}
+
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
@@ -205,6 +251,97 @@ struct PinnedBuf {
     VT_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(T), hipHostMallocMapped));
     count = want;
     return VT_OK;
+  }
+};
+
+// The row matrix of a shard.
+//  * small: one hipMalloc, regrown by allocate + copy (cheap below a chunk);
+//  * from one chunk on: ONE reserved virtual range as large as the card's memory, physical
+//    chunks of equal size (1 GiB) mapped behind each other as the rows arrive
+//    (hipMemAddressReserve / hipMemCreate / hipMemMap).  Growing maps more chunks: no copy, no
+//    second slab beside the first (regrowing a 100-GB slab by allocate + copy needs 300 GB for a
+//    moment -- more than the card has), the rows never move.  Streaming over a mapped range
+//    runs at the rate of a hipMalloc'ed one (tools/vmm_probe.hip: the +-2 % between two
+//    allocations of either kind is placement luck).  Chunks of one range must be equally
+//    large: hipMemSetAccess rejects most mixed sequences on ROCm 7.
+struct Slab {
+  float *p = nullptr;
+  size_t bytes = 0;     // usable bytes behind p
+  bool mapped = false;  // p is a reserved range with `chunks` mapped at its start
+  size_t reserved = 0, chunk = 0;
+  std::vector<hipMemGenericAllocationHandle_t> chunks;
+
+  ~Slab() { release(); }
+  void release() {
+    if (mapped) {
+      if (bytes) (void)hipMemUnmap(p, bytes);
+      for (auto h : chunks) (void)hipMemRelease(h);
+      if (p) (void)hipMemAddressFree(p, reserved);
+    } else if (p) {
+      (void)hipFree(p);
+    }
+    p = nullptr;
+    bytes = reserved = chunk = 0;
+    mapped = false;
+    chunks.clear();
+  }
+  static size_t chunk_bytes() {
+    const char *e = std::getenv("VT_SLAB_CHUNK_MB");  // (tests: small chunks, so that small corpora cross chunk borders)
+    const long mb = e ? std::atol(e) : 0;
+    return mb > 0 ? (size_t)mb << 20 : (size_t)1 << 30;
+  }
+  static bool mapping_allowed() {
+    const char *e = std::getenv("VT_SLAB");
+    return !(e && std::strcmp(e, "malloc") == 0);
+  }
+  // Maps chunks until `want` bytes are usable.  Failure leaves what was mapped before intact.
+  int map_up_to(size_t want, int device) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    while (bytes < want) {
+      if (bytes + chunk > reserved) return fail(VT_ERR_DEVICE, "row slab: the reserved range is exhausted");
+      hipMemGenericAllocationHandle_t h;
+      VT_HIP(hipMemCreate(&h, chunk, &prop, 0));
+      char *at = reinterpret_cast<char *>(p) + bytes;
+      hipError_t e = hipMemMap(at, chunk, 0, h, 0);
+      if (e == hipSuccess) {
+        e = hipMemSetAccess(at, chunk, &acc, 1);
+        if (e != hipSuccess) (void)hipMemUnmap(at, chunk);
+      }
+      if (e != hipSuccess) {
+        (void)hipMemRelease(h);
+        return fail(VT_ERR_DEVICE, std::string("row slab: ") + hipGetErrorString(e));
+      }
+      chunks.push_back(h);
+      bytes += chunk;
+    }
+    return VT_OK;
+  }
+  // A fresh mapped slab of at least `want` bytes (nothing copied).  VT_ERR_UNSUPPORTED when the
+  // runtime has no virtual memory management (the caller stays with hipMalloc).
+  int start_mapped(size_t want, int device) {
+    release();
+    size_t free_b = 0, total_b = 0;
+    VT_HIP(hipMemGetInfo(&free_b, &total_b));
+    chunk = chunk_bytes();
+    reserved = (std::max(total_b, want) + chunk - 1) / chunk * chunk;
+    void *base = nullptr;
+    if (hipMemAddressReserve(&base, reserved, 0, nullptr, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      reserved = chunk = 0;
+      return VT_ERR_UNSUPPORTED;
+    }
+    p = reinterpret_cast<float *>(base);
+    mapped = true;
+    const int st = map_up_to(want, device);
+    if (st != VT_OK) release();
+    return st;
   }
 };
 
@@ -362,7 +499,8 @@ struct Shard {
   uint32_t n = 0, cap = 0;
   long dim = -1;    // FlatIndex.dimension (None = -1)
   uint32_t ld = 0;  // row stride of the slab in floats = padded_dim(dim), multiple of 64
-  float *dX = nullptr;
+  Slab slab;
+  float *dX = nullptr;  // == slab.p
   DevBuf<uint32_t> dRank;
   DevBuf<uint64_t> dBits;
   bool bits_valid = false;
@@ -390,7 +528,7 @@ struct Shard {
 
   ~Shard() {
     (void)hipSetDevice(ctx.device);
-    if (dX) (void)hipFree(dX);
+    slab.release();
   }
 
   template <class F>
@@ -605,7 +743,7 @@ constexpr double kThresholdFixedS = 140e-6, kBatchFixedS = 180e-6, kBatchFlopsPe
 // sweep is priced per (tile, 256-float panel) a resident wave works through -- 2.9 us each once
 // the chip streams, 4.5 us for a wave's first ones -- plus its prologue and list merges
 // (tools/batch_path_probe.py, tools/multi_probe.py: 68 us at 150 MB, 326 us at 1.5 GB, 5.46 ms at 30 GB of d=768 rows)
-constexpr double kMultiFixedS = 60e-6, kMultiSweepFixedS = 45e-6, kMultiPanelS = 2.9e-6, kMultiRampS = 1.6e-6;
+constexpr double kMultiFixedS = 50e-6, kMultiSweepFixedS = 45e-6, kMultiPanelS = 2.9e-6, kMultiRampS = 1.6e-6;
 inline double scan_seconds(double bytes) { return kScanFixedS + bytes / kScanBytesPerS; }
 
 // ------------------------------------------------------------------ selection
@@ -1004,20 +1142,55 @@ inline uint32_t rank_key_of(uint64_t key) { return (uint32_t)(key >> 32); }
 // ------------------------------------------------------------------ index ops
 int index_reserve(Shard *ix, uint32_t want_rows) {
   if (want_rows <= ix->cap) return VT_OK;
-  uint64_t nc = std::max<uint64_t>(want_rows, (uint64_t)ix->cap * 2);
-  nc = std::max<uint64_t>(nc, 1024);
-  nc = (nc + vt::kTileRows - 1) / vt::kTileRows * vt::kTileRows;
-  if (nc > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
-  float *nx = nullptr;
-  VT_HIP(hipMalloc(reinterpret_cast<void **>(&nx), (size_t)nc * ix->ld * sizeof(float)));
-  if (ix->dX && ix->n)
-    VT_HIP(hipMemcpyAsync(nx, ix->dX, (size_t)ix->n * ix->ld * sizeof(float), hipMemcpyDeviceToDevice, ix->ctx.stream));
-  // rows n..cap are scanned by the last tile: keep them defined
-  VT_HIP(hipMemsetAsync(nx + (size_t)ix->n * ix->ld, 0, (size_t)(nc - ix->n) * ix->ld * sizeof(float), ix->ctx.stream));
-  VT_HIP(hipStreamSynchronize(ix->ctx.stream));
-  if (ix->dX) VT_HIP(hipFree(ix->dX));
-  ix->dX = nx;
-  ix->cap = (uint32_t)nc;
+  const size_t row_bytes = (size_t)ix->ld * sizeof(float);
+  auto tiles_up = [](uint64_t rows) { return (rows + vt::kTileRows - 1) / vt::kTileRows * vt::kTileRows; };
+  if (tiles_up(want_rows) > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
+  Slab &sl = ix->slab;
+  hipStream_t stream = ix->ctx.stream;
+  const size_t old_bytes = (size_t)ix->n * row_bytes;
+  const size_t need = (size_t)tiles_up(want_rows) * row_bytes;
+  if (sl.mapped) {
+    // more chunks behind the ones in use: the rows stay where they are
+    const size_t before = sl.bytes;
+    VT_TRY(sl.map_up_to(need, ix->ctx.device));
+    // rows n..cap are scanned by the last tile: keep them defined
+    VT_HIP(hipMemsetAsync(reinterpret_cast<char *>(sl.p) + before, 0, sl.bytes - before, stream));
+    VT_HIP(hipStreamSynchronize(stream));
+  } else {
+    Slab fresh;
+    bool have = false;
+    if (need >= Slab::chunk_bytes() && Slab::mapping_allowed()) {
+      const int st = fresh.start_mapped(need, ix->ctx.device);
+      if (st == VT_OK) have = true;
+      else if (st != VT_ERR_UNSUPPORTED) return st;
+    }
+    if (!have) {
+      uint64_t nc = std::max<uint64_t>(want_rows, (uint64_t)ix->cap * 2);
+      nc = tiles_up(std::max<uint64_t>(nc, 1024));
+      // (doubling stops at one chunk: the growth after that maps instead of copying)
+      if (Slab::mapping_allowed() && nc * row_bytes > Slab::chunk_bytes())
+        nc = std::max<uint64_t>(tiles_up(want_rows), Slab::chunk_bytes() / row_bytes / vt::kTileRows * vt::kTileRows);
+      if (nc > 0xFFFFFFF0ull) nc = tiles_up(want_rows);
+      VT_HIP(hipMalloc(reinterpret_cast<void **>(&fresh.p), (size_t)nc * row_bytes));
+      fresh.bytes = (size_t)nc * row_bytes;
+    }
+    if (sl.p && ix->n) VT_HIP(hipMemcpyAsync(fresh.p, sl.p, old_bytes, hipMemcpyDeviceToDevice, stream));
+    VT_HIP(hipMemsetAsync(reinterpret_cast<char *>(fresh.p) + old_bytes, 0, fresh.bytes - old_bytes, stream));
+    VT_HIP(hipStreamSynchronize(stream));
+    sl.release();
+    sl.p = fresh.p;
+    sl.bytes = fresh.bytes;
+    sl.mapped = fresh.mapped;
+    sl.reserved = fresh.reserved;
+    sl.chunk = fresh.chunk;
+    sl.chunks.swap(fresh.chunks);
+    fresh.p = nullptr;  // (ownership moved)
+    fresh.bytes = fresh.reserved = 0;
+    fresh.mapped = false;
+  }
+  ix->dX = sl.p;
+  const uint64_t rows = std::min<uint64_t>(sl.bytes / row_bytes / vt::kTileRows * vt::kTileRows, 0xFFFFFFE0ull);
+  ix->cap = (uint32_t)rows;
   return VT_OK;
 }
 
@@ -1033,7 +1206,8 @@ int index_set_dim(Shard *ix, size_t d) {
   ix->bits_dirty.clear();
   ix->norm_dirty.clear();
   if (ld != ix->ld) {
-    if (ix->dX) VT_HIP(hipFree(ix->dX));
+    VT_HIP(hipStreamSynchronize(ix->ctx.stream));
+    ix->slab.release();
     ix->dX = nullptr;
     ix->cap = 0;
     ix->ld = ld;
@@ -1122,20 +1296,23 @@ int index_sync_ranks(Shard *ix, bool force_upload) {
       // few newcomers: each finds its place among the ranked rows by binary search (string
       // compares only there), the merge itself moves integers
       std::vector<uint32_t> pos(fresh.size());
-      for (size_t i = 0; i < fresh.size(); ++i)
-        pos[i] = (uint32_t)(std::lower_bound(ranked.begin(), ranked.end(), fresh[i],
-                                             [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; }) - ranked.begin());
+      parallel_for(fresh.size(), [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i)
+          pos[i] = (uint32_t)(std::lower_bound(ranked.begin(), ranked.end(), fresh[i],
+                                               [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; }) - ranked.begin());
+      });
       size_t o = 0, f = 0;
       for (size_t r = 0; r <= ranked.size(); ++r) {
         while (f < fresh.size() && pos[f] == r) order[o++] = fresh[f++];
         if (r < ranked.size()) order[o++] = ranked[r];
       }
     } else {
-      std::merge(ranked.begin(), ranked.end(), fresh.begin(), fresh.end(), order.begin(),
-                 [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+      parallel_merge(ranked, fresh, order, [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
     }
     ix->rank_host.resize(ix->n);
-    for (uint32_t i = 0; i < ix->n; ++i) ix->rank_host[order[i]] = i;
+    parallel_for(ix->n, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) ix->rank_host[order[i]] = (uint32_t)i;
+    });
     if (ix->n) {
       ix->max_id = ids[order[ix->n - 1]];
       ix->max_rank = ix->n - 1;
@@ -1258,10 +1435,14 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
   const uint32_t n_before = ix->n;
   std::vector<uint32_t> target(count);
   bool all_appended_in_order = true;
-  if (count > 1024) {  // bulk load: no rehash / regrowth inside the id loop
-    ix->row_of.reserve((size_t)ix->n + count);
-    ix->ids.reserve((size_t)ix->n + count);
-    ix->rank_host.reserve((size_t)ix->n + count);
+  if (count > 1024) {
+    // bulk load: no rehash / regrowth inside the id loop -- but geometric, or a corpus that arrives
+    // in many appends re-hashes and re-copies its whole id table at every one of them (84 M ids: 15 s)
+    const size_t need = (size_t)ix->n + count;
+    if ((double)need > (double)ix->row_of.bucket_count() * ix->row_of.max_load_factor())
+      ix->row_of.reserve(std::max(need, 2 * ix->row_of.size()));
+    if (need > ix->ids.capacity()) ix->ids.reserve(std::max(need, 2 * ix->ids.capacity()));
+    if (need > ix->rank_host.capacity()) ix->rank_host.reserve(std::max(need, 2 * ix->rank_host.capacity()));
   }
   *began = true;
   for (size_t i = 0; i < count; ++i) {
@@ -1357,9 +1538,17 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     }
     pending = true;  // one wait at the end of the function covers the rows and their ranks
   }
-  if (!ix->ranks_clean && count < kBulkRankRows) {
+  // A bulk load ranks its ids right away (the load itself takes far longer) -- unless it is a
+  // small part of what is already there: re-ranking costs a pass over ALL ids, and a corpus that
+  // arrives in many appends would pay it every time (84 M rows in 21 appends: 14 s each); the
+  // next search does it once.  Trickling inserts leave their rows unranked for the lazy search path.
+  const bool rank_now = !ix->ranks_clean && count >= kBulkRankRows && count >= (size_t)n_before / 4;
+  if (!ix->ranks_clean && !rank_now) {
     // the device column is brought up to date lazily (index_lazy_ranks) or by the next re-rank
-    for (uint32_t r = n_before; r < ix->n; ++r) ix->rank_dirty.push_back(r);
+    if (count < kBulkRankRows)
+      for (uint32_t r = n_before; r < ix->n; ++r) ix->rank_dirty.push_back(r);
+    else
+      ix->rank_dirty_all = true;
     if (ix->rank_dirty.size() > kMaxDirtyRanks) ix->rank_dirty_all = true;
   }
   // keep device ranks current when they stayed valid (sorted appends)
@@ -1374,9 +1563,7 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     pending = true;
   }
   if (pending) VT_HIP(hipStreamSynchronize(c.stream));
-  // A bulk load ranks its ids right away (the load itself takes far longer); only trickling
-  // inserts leave their rows unranked for the lazy search path.
-  if (!ix->ranks_clean && count >= kBulkRankRows) VT_TRY(index_sync_ranks(ix, false));
+  if (rank_now) VT_TRY(index_sync_ranks(ix, false));
   return VT_OK;
 }
 
@@ -2138,7 +2325,8 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
   // the bound could not certify): several queries per sweep of the corpus when their lists
   // fit, else one scan each
   if (left.size() >= 2 && multi_scan_applies(ix, limit) &&
-      multi_scan_seconds(ix, left.size()) < (double)left.size() * scan_seconds((double)ix->n * ix->ld * 4.0)) {
+      (multi_scan_seconds(ix, left.size()) < (double)left.size() * scan_seconds((double)ix->n * ix->ld * 4.0) ||
+       std::getenv("VT_FORCE_MULTI_SCAN"))) {  // (tests force the sweep on corpora of a few thousand rows)
     const int st = multi_scan_group(ix, c, queries, left, limit, out);
     if (st == VT_OK) return VT_OK;
     if (st != kRetryInternal) return st;
@@ -3311,6 +3499,15 @@ size_t vt_flat_shard_len(const vt_flat *h, size_t shard) {
   if (!h || shard >= h->shards.size()) return 0;
   std::shared_lock<std::shared_mutex> rl(h->rw);
   return h->shards[shard]->n;
+}
+int vt_flat_shard_memory(const vt_flat *h, size_t shard, size_t *row_capacity, size_t *slab_bytes, size_t *slab_chunks) {
+  if (!h || shard >= h->shards.size()) return VT_ERR_ARGUMENT;
+  std::shared_lock<std::shared_mutex> rl(h->rw);
+  const Shard *ix = h->shards[shard].get();
+  if (row_capacity) *row_capacity = ix->cap;
+  if (slab_bytes) *slab_bytes = ix->slab.bytes;
+  if (slab_chunks) *slab_chunks = ix->slab.mapped ? ix->slab.chunks.size() : 0;
+  return VT_OK;
 }
 int vt_flat_route_ids(const vt_flat *h, size_t count, const char *ids, const size_t *id_off, uint32_t *out_shard) {
   if (!h || (count && (!id_off || !out_shard))) return VT_ERR_ARGUMENT;

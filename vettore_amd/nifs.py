@@ -180,6 +180,15 @@ def flat_shard_lens(index: FlatRef) -> List[int]:
     return [int(L.vt_flat_shard_len(index.handle, s)) for s in range(flat_shard_count(index))]
 
 
+def flat_shard_memory(index: FlatRef, shard: int = 0):
+    """(row capacity, slab bytes, mapped chunks) of a shard (vt_flat_shard_memory)."""
+    cap, nbytes, chunks = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    st = _lib.load().vt_flat_shard_memory(index.handle, shard, C.byref(cap), C.byref(nbytes), C.byref(chunks))
+    if st != 0:
+        raise RuntimeError("flat_shard_memory: " + _lib.error_text(st))
+    return int(cap.value), int(nbytes.value), int(chunks.value)
+
+
 def flat_route_ids(index: FlatRef, ids_packed: Tuple[bytes, np.ndarray]) -> np.ndarray:
     """Shard of every id of a packed id batch."""
     blob, off = ids_packed
