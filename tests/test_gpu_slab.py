@@ -158,3 +158,35 @@ def test_large_appends_leave_the_ranking_to_the_next_search(nifs, oracle_mod):
     assert len(rows) == 10
     assert bits(g.search(q, 300)) == bits(o.search(q, 300))
     del sign
+
+
+@pytest.mark.parametrize("d", [64, 40])
+def test_rows_from_another_device_reach_a_mapped_slab_through_a_staging_block(nifs, oracle_mod, monkeypatch, d):
+    """Only the owning device is given access to a mapped slab's chunks, so rows resident on
+    another GPU of the node are first copied into an ordinary buffer on this one and placed from
+    there (`VT_TEST_FOREIGN_ROWS` makes the one GPU of this box count as "another"): appends,
+    scattered upserts, an id twice in a batch (the last one wins, flat.rs:270-281); d = 40 also
+    pads the rows on the way."""
+    import torch
+    monkeypatch.setenv("VT_SLAB_CHUNK_MB", "2")
+    monkeypatch.setenv("VT_TEST_FOREIGN_ROWS", "1")
+    rng = np.random.default_rng(3)
+    n = 30_000
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    ids = [b"r-%05d" % i for i in range(n)]
+    g = GpuIndex(nifs, 0)
+    o = oracle_mod.FlatIndex(0)
+    xd = torch.from_numpy(x).to("cuda:0")
+    assert nifs.flat_load_device_matrix(g.ref, nifs.pack_ids(ids), xd.data_ptr(), n, d) == ("ok", ())
+    o.insert_matrix(ids, x)
+    assert nifs.flat_shard_memory(g.ref)[2] >= 3
+    pick = rng.permutation(n)[:4000]
+    up_ids = [ids[i] for i in pick] + [ids[int(pick[0])]] + [b"new-%d" % i for i in range(300)]
+    up = rng.uniform(-1, 1, (len(up_ids), d)).astype(np.float32)
+    ud = torch.from_numpy(up).to("cuda:0")
+    assert nifs.flat_load_device_matrix(g.ref, nifs.pack_ids(up_ids), ud.data_ptr(), len(up_ids), d) == ("ok", ())
+    o.insert_many(list(zip(up_ids, up)))
+    assert len(g) == len(o) == n + 300
+    for q in (up[0], up[len(pick)], up[-1], x[1], rng.uniform(-1, 1, d).astype(np.float32)):
+        assert bits(g.search(q, 20)) == bits(o.search(q, 20))
+    assert g.search(up[len(pick)], 1)[0] == (ids[int(pick[0])], 0.0)

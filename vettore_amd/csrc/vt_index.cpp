@@ -1469,12 +1469,40 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     if (src.pick)
       for (size_t i = 1; i < count && picks_dense; ++i) picks_dense = src.pick[i] == src.pick[0] + i;
     const float *first = src.device + (src.pick ? (size_t)src.pick[0] * d : 0);
-    if (all_appended_in_order && picks_dense) {
+    // (test hook: a one-GPU box has no other device to own the rows)
+    const bool foreign = device_of_pointer(src.device) != c.device || std::getenv("VT_TEST_FOREIGN_ROWS") != nullptr;
+    if (foreign && ix->slab.mapped) {
+      // Rows that live on another device of the node, bound for a mapped slab: only this device
+      // has been given access to the slab's chunks (hipMemSetAccess), so a peer copy must not
+      // target it.  The rows cross into an ordinary buffer here first (blocks of <= 256 MB), and
+      // are placed from there by local copies.
+      const size_t block_rows = std::max<size_t>(1, ((size_t)256 << 20) / (d * sizeof(float)));
+      DevBuf<float> stage;
+      VT_TRY(stage.ensure(std::min(count, block_rows) * d));
+      size_t i = 0;
+      while (i < count) {
+        // a run of consecutive source rows, at most one block long
+        size_t e = i + 1;
+        const size_t p0 = src.pick ? src.pick[i] : i;
+        while (e < count && e - i < block_rows && (src.pick ? src.pick[e] : e) == p0 + (e - i)) ++e;
+        VT_HIP(hipMemcpyAsync(stage.p, src.device + p0 * d, (e - i) * d * sizeof(float), hipMemcpyDefault, c.stream));
+        for (size_t j = i; j < e;) {  // ... placed in runs of consecutive slab rows
+          size_t r = j + 1;
+          while (r < e && target[r] == target[j] + (uint32_t)(r - j)) ++r;
+          float *dst = ix->dX + (size_t)target[j] * ld;
+          if (ld == d) VT_HIP(hipMemcpyAsync(dst, stage.p + (j - i) * d, (r - j) * d * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+          else VT_HIP(vt::launch_pad_rows(stage.p + (j - i) * d, (uint32_t)(r - j), (uint32_t)d, dst, ld, c.stream));
+          j = r;
+        }
+        VT_HIP(hipStreamSynchronize(c.stream));  // the block is reused
+        i = e;
+      }
+    } else if (all_appended_in_order && picks_dense) {
       // (hipMemcpyDefault: the source may live on another device of the node)
       float *dst = ix->dX + (size_t)n_before * ld;
       if (ld == d) VT_HIP(hipMemcpyAsync(dst, first, count * d * sizeof(float), hipMemcpyDefault, c.stream));
       else VT_HIP(vt::launch_pad_rows(first, (uint32_t)count, (uint32_t)d, dst, ld, c.stream));
-    } else if (count < 64 || device_of_pointer(src.device) != c.device) {
+    } else if (count < 64 || foreign) {
       // (few rows, or rows that live on another device: plain copies, which need no peer mapping)
       for (size_t i = 0; i < count; ++i) {
         float *dst = ix->dX + (size_t)target[i] * ld;
