@@ -267,6 +267,7 @@ struct PinnedBuf {
 struct Slab {
   float *p = nullptr;
   size_t bytes = 0;     // usable bytes behind p
+  size_t defined = 0;   // bytes that hold rows or zeros (chunks mapped by a growth that failed later are not, yet)
   bool mapped = false;  // p is a reserved range with `chunks` mapped at its start
   size_t reserved = 0, chunk = 0;
   std::vector<hipMemGenericAllocationHandle_t> chunks;
@@ -281,7 +282,7 @@ struct Slab {
       (void)hipFree(p);
     }
     p = nullptr;
-    bytes = reserved = chunk = 0;
+    bytes = defined = reserved = chunk = 0;
     mapped = false;
     chunks.clear();
   }
@@ -1151,11 +1152,11 @@ int index_reserve(Shard *ix, uint32_t want_rows) {
   const size_t need = (size_t)tiles_up(want_rows) * row_bytes;
   if (sl.mapped) {
     // more chunks behind the ones in use: the rows stay where they are
-    const size_t before = sl.bytes;
     VT_TRY(sl.map_up_to(need, ix->ctx.device));
     // rows n..cap are scanned by the last tile: keep them defined
-    VT_HIP(hipMemsetAsync(reinterpret_cast<char *>(sl.p) + before, 0, sl.bytes - before, stream));
+    VT_HIP(hipMemsetAsync(reinterpret_cast<char *>(sl.p) + sl.defined, 0, sl.bytes - sl.defined, stream));
     VT_HIP(hipStreamSynchronize(stream));
+    sl.defined = sl.bytes;
   } else {
     Slab fresh;
     bool have = false;
@@ -1179,7 +1180,7 @@ int index_reserve(Shard *ix, uint32_t want_rows) {
     VT_HIP(hipStreamSynchronize(stream));
     sl.release();
     sl.p = fresh.p;
-    sl.bytes = fresh.bytes;
+    sl.bytes = sl.defined = fresh.bytes;
     sl.mapped = fresh.mapped;
     sl.reserved = fresh.reserved;
     sl.chunk = fresh.chunk;
