@@ -23,7 +23,8 @@ to get there, same library underneath:
 At N = 1 the JSON line also carries `side`: short legs of the other BASELINE
 configs on the same box (config 2: N=1M single query; config 3: dot, batches of
 256 on the FP32 matrix cores; config 5: quantized search; funnel search), each
-with its own roofline figure.  The headline fields are not affected.
+with its own roofline figure, and `callers`: 8 and 64 threads searching the
+headline index at the same time.  The headline fields are not affected.
 
 Synthetic data: iid uniform(-1,1) coordinates, rows
 L2-normalised, 1% verbatim duplicate rows, ids "doc-<i>", seeds 20260721/22.
@@ -336,6 +337,50 @@ def run_side_mode(a, torch, nifs, device):
     print(json.dumps(out))
 
 
+def concurrent_callers(a, L, nifs, ref, threads, seconds):
+    """`threads` callers searching ONE handle at the same time (what BEAM dirty schedulers do under
+    the reference's read lock, nifs.rs:297-309): the library lets searches that meet travel as one
+    batch.  Every answer is compared with the one the same query gets alone."""
+    import threading
+    qs = normalized_queries(64, a.dim, SEED_QUERY + 9)
+    hp = C.c_void_p()
+    alone = []
+    for q in qs:
+        assert L.vt_flat_search(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), a.dim, a.limit, C.byref(hp)) == 0
+        alone.append(hits_of(L, hp))
+    stop, counts, wrong = threading.Event(), [0] * threads, []
+
+    def worker(t):
+        h = C.c_void_p()
+        i = t
+        while not stop.is_set():
+            j = i % len(qs)
+            assert L.vt_flat_search(ref.handle, qs[j].ctypes.data_as(C.POINTER(C.c_float)), a.dim, a.limit, C.byref(h)) == 0
+            if counts[t] % 8 == 0:
+                if hits_of(L, h) != alone[j]:
+                    wrong.append((t, j))
+            else:
+                L.vt_hits_free(h)
+            counts[t] += 1
+            i += threads
+
+    b0 = nifs.flat_coalesce_stats(ref)
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    time.sleep(seconds)
+    stop.set()
+    for th in ths:
+        th.join()
+    dt = time.perf_counter() - t0
+    b1 = nifs.flat_coalesce_stats(ref)
+    total = sum(counts)
+    return {"threads": threads, "value": total / dt, "unit": "queries/s", "seconds": round(dt, 2), "searches": total,
+            "batches": b1[0] - b0[0], "searches_in_batches": b1[1] - b0[1], "verified": not wrong,
+            "mean_latency_ms": dt * threads / max(1, total) * 1e3}
+
+
 def side_legs(a, torch, nifs, L, device, main_ref):
     """The other BASELINE configs, briefly, on the same box.  `main_ref` is
     the resident N-row cosine index of the headline leg."""
@@ -350,6 +395,10 @@ def side_legs(a, torch, nifs, L, device, main_ref):
     side["funnel"] = dict(leg(a, L, nifs, main_ref, "funnel", qs, 100, 10, stages=(min(a.dim, 128),), candidates=100),
                           workload="funnel_search stages=[%d] candidates=100 limit=10, d=%d, N=%d" % (min(a.dim, 128), a.dim, a.rows),
                           dtype="f64")
+    # many callers on the one handle (the headline has one query in flight)
+    side["callers"] = {"workload": "index: :flat, metric: :cosine, d=%d, N=%d, limit=%d, T threads calling flat_search on one handle"
+                                   % (a.dim, a.rows, a.limit),
+                       "runs": [concurrent_callers(a, L, nifs, main_ref, t, 1.5) for t in (8, 64)]}
     # config 2: flat cosine top-10, N = 1M, single query
     rows2 = min(1_000_000, a.rows)
     x = build_shard(torch, device, rows2, a.dim, SEED_CORPUS + 2)

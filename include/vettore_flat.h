@@ -140,6 +140,15 @@ size_t vt_flat_shard_len(const vt_flat *index, size_t shard);
  * allocations, flat.rs:13-17, have no such step at all).  Any out pointer may be NULL. */
 int vt_flat_shard_memory(const vt_flat *index, size_t shard, size_t *row_capacity, size_t *slab_bytes,
                          size_t *slab_chunks);
+/* Searches that meet on one handle go together.  The reference's readers share an RwLock and
+ * scale with the host's cores (nifs.rs:297-309); here every search is a pass over the corpus in
+ * HBM, so a vt_flat_search that finds another one running waits for it, and everything that has
+ * queued up by then (same limit, up to 256) runs as ONE batch -- one sweep of the corpus for up
+ * to eight queries, the matrix-core pass beyond -- each caller getting exactly the hits its own
+ * search would have produced (ids, order, raw bits).  An idle handle adds nothing: the first
+ * caller runs at once, alone.  VT_COALESCE=0 in the environment switches it off.  This returns
+ * how many such batches ran and how many searches they carried.  Out pointers may be NULL. */
+int vt_flat_coalesce_stats(vt_flat *index, uint64_t *batches, uint64_t *batched_queries);
 /* out_shard[i] = shard that owns (or would own) id i. */
 int vt_flat_route_ids(const vt_flat *index, size_t count, const char *ids, const size_t *id_off,
                       uint32_t *out_shard);

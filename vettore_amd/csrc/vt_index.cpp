@@ -7,6 +7,7 @@
 #include "vt_device.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -711,6 +712,31 @@ struct vt_flat {
   std::vector<void *> dBlock, dGather;  // per shard: its own result block, the gathered blocks of all shards
   PinnedBuf<unsigned char> hGather;     // shard 0's gathered copy, read by the merging host thread
   vt_profile xprof{};                   // exchange timing (merge_launches / merge_ms)
+
+  // Searches that arrive while another one is running wait for it and then go TOGETHER: one
+  // sweep of the corpus answers up to eight of them (K1m), the matrix-core pass up to 256 (K2),
+  // where the same callers on their own streams would read the whole corpus once each.  See
+  // coalesced_search.
+  struct Waiting {
+    const float *query;
+    size_t n, limit;
+    vt_hits **out;
+    int status = VT_OK;
+    std::string error;
+    enum { QUEUED, LEADS, ALONE, DONE } state = QUEUED;
+    std::condition_variable wake;  // its own: a finished batch wakes exactly its members and the next leader
+    Waiting(const float *q, size_t n_, size_t limit_, vt_hits **out_) : query(q), n(n_), limit(limit_), out(out_) {}
+  };
+  struct Coalescer {
+    std::mutex mu;
+    std::condition_variable gather;  // a leader waiting a moment for the callers it expects back
+    std::deque<Waiting *> waiting;
+    unsigned active = 0;        // searches / batches running
+    size_t last_batch = 1;      // members of the last batch that ran
+    double last_seconds = 0.0;  // what it took
+    uint64_t batches = 0, batched_queries = 0;
+  } co;
+  std::atomic<uint64_t> approx_bytes{0};  // rows x row stride, refreshed by mutations (the coalescer's only use of it is a size class)
 
   bool multi() const { return shards.size() > 1 || !workers.empty(); }
   size_t total() const {
@@ -3332,7 +3358,7 @@ int hybrid_multi(vt_flat *h, const float *query, size_t n, const int *kinds, con
 // Shared body of insert_many / load_matrix / load_device_matrix once every row is validated:
 // one shard takes the batch as it is; several shards take their rows (hash of the id) at
 // the same time, each on its own worker.
-int store_validated(vt_flat *h, size_t count, const char *ids, const size_t *id_off, const RowSource &src, size_t d) {
+int store_validated_rows(vt_flat *h, size_t count, const char *ids, const size_t *id_off, const RowSource &src, size_t d) {
   if (count == 0) return VT_OK;
   const size_t S = h->shards.size();
   if (!h->multi()) {
@@ -3376,6 +3402,226 @@ int store_validated(vt_flat *h, size_t count, const char *ids, const size_t *id_
 }
 
 long handle_dim(const vt_flat *h) { return h->multi() ? h->dim : h->shards[0]->dim; }
+
+void refresh_approx_bytes(vt_flat *h) {
+  uint64_t b = 0;
+  for (auto &sh : h->shards) b += (uint64_t)sh->n * sh->ld * sizeof(float);
+  h->approx_bytes.store(b, std::memory_order_relaxed);
+}
+
+int store_validated(vt_flat *h, size_t count, const char *ids, const size_t *id_off, const RowSource &src, size_t d) {
+  const int st = store_validated_rows(h, count, ids, id_off, src, d);
+  refresh_approx_bytes(h);
+  return st;
+}
+
+// flat_search as one caller runs it (nifs.rs:297-309).
+int search_direct(vt_flat *h, const float *query, size_t n, size_t limit, vt_hits **out) {
+  if (h->multi()) {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    if (h->poisoned) return poisoned_status();
+    return search_multi(h, query, n, limit, out);
+  }
+  return read_single(h, NEED_RANKS, limit,
+                     [&](Shard *ix, Ctx &c) -> int { return search_ready(ix, c, query, n, limit, out); });
+}
+
+// flat_search_batch: nq queries of d floats, one hit list each, or one status for all.
+int batch_direct(vt_flat *h, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
+  for (size_t i = 0; i < nq; ++i) out[i] = nullptr;
+  int st;
+  if (h->multi()) {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    if (h->poisoned) return poisoned_status();
+    st = batch_multi(h, queries, nq, d, limit, out);
+  } else {
+    unsigned need = NEED_STRICT_RANKS;
+    {
+      std::shared_lock<std::shared_mutex> rl(h->rw);
+      if (batch_uses_mfma(h->shards[0].get(), nq, limit)) need |= NEED_NORMS;
+    }
+    st = read_single(h, need, limit, [&](Shard *ix, Ctx &c) -> int {
+      for (size_t i = 0; i < nq; ++i) {  // (a second run after an escalation starts clean)
+        delete out[i];
+        out[i] = nullptr;
+      }
+      if (ix->n && batch_uses_mfma(ix, nq, limit) && shard_stale(ix, NEED_NORMS, limit)) return kEscalate;
+      return batch_ready(ix, c, queries, nq, d, limit, out);
+    });
+  }
+  if (st != VT_OK)
+    for (size_t i = 0; i < nq; ++i) {
+      delete out[i];
+      out[i] = nullptr;
+    }
+  return st;
+}
+
+// ---- searches that meet on one handle go together -----------------------------------------
+// The reference's readers share an RwLock and scale with the host's cores.  Here every search
+// is a pass over the corpus in HBM, and callers that run side by side on their own streams
+// each read all of it.  So a search that finds another one running waits for it; whoever waits
+// first then leads everything that has queued up with its limit as ONE batch -- the batch path
+// gives every query the hits its own search would get, bit for bit -- and the others wake up
+// with their lists.  An idle handle adds nothing: the first caller runs at once, alone.  Small
+// corpora (latency-bound, not bandwidth-bound) keep two operations in flight.  What would force
+// work a lone search avoids (a strict re-rank after unsorted inserts) is not batched: those
+// callers are released to search side by side as before.  `VT_COALESCE=0` switches it off.
+constexpr size_t kCoalesceMax = 256;
+// Operations in flight before callers start to queue: a pass over a large corpus owns the
+// memory system, two over a medium one still overlap their fixed costs, and searches of a
+// corpus of a few MB are all fixed cost -- there every reader context runs side by side and
+// only the callers beyond them travel together (tools/reader_probe.cpp).
+unsigned coalesce_slots(uint64_t corpus_bytes) {
+  if (const char *e = std::getenv("VT_COALESCE_SLOTS")) return (unsigned)std::max(1, std::atoi(e));
+  return corpus_bytes < (64ull << 20) ? (unsigned)kMaxContexts : corpus_bytes < (1ull << 30) ? 2u : 1u;
+}
+
+bool coalescing_enabled() {
+  const char *e = std::getenv("VT_COALESCE");
+  return !(e && e[0] == '0');
+}
+
+// Runs the members of one batch (all with the leader's limit and query length).
+void run_coalesced(vt_flat *h, std::vector<vt_flat::Waiting *> &members) {
+  const size_t limit = members[0]->limit, n = members[0]->n;
+  auto alone = [&](vt_flat::Waiting *w) {
+    w->status = search_direct(h, w->query, w->n, w->limit, w->out);
+    if (w->status != VT_OK) w->error = g_last_error;
+  };
+  if (members.size() == 1) {
+    alone(members[0]);
+    return;
+  }
+  // every query is judged on its own (flat.rs:97-101), as if it had come alone
+  std::vector<vt_flat::Waiting *> good;
+  {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    const long dim = handle_dim(h);
+    for (vt_flat::Waiting *w : members) {
+      const int st = h->poisoned ? poisoned_status() : validate_vector(w->query, w->n, dim);
+      if (st != VT_OK) {
+        w->status = st;
+        w->error = st == VT_ERR_POISONED ? g_last_error : std::string();
+      } else {
+        good.push_back(w);
+      }
+    }
+  }
+  if (good.size() < 2) {
+    for (vt_flat::Waiting *w : good) alone(w);
+    return;
+  }
+  std::vector<float> qs(good.size() * n);
+  for (size_t i = 0; i < good.size(); ++i) std::memcpy(&qs[i * n], good[i]->query, n * sizeof(float));
+  std::vector<vt_hits *> outs(good.size(), nullptr);
+  const int st = batch_direct(h, qs.data(), good.size(), n, limit, outs.data());
+  if (st == VT_OK) {
+    for (size_t i = 0; i < good.size(); ++i) *good[i]->out = outs[i];
+    return;
+  }
+  // one query's failure ("metric overflow", a dimension that changed under us) is that query's own
+  for (vt_flat::Waiting *w : good) alone(w);
+}
+
+int coalesced_search(vt_flat *h, const float *query, size_t n, size_t limit, vt_hits **out) {
+  if (limit == 0 || limit > (size_t)vt::kMaxFusedK || n == 0 || !coalescing_enabled()) return search_direct(h, query, n, limit, out);
+  vt_flat::Coalescer &co = h->co;
+  const unsigned max_active = coalesce_slots(h->approx_bytes.load(std::memory_order_relaxed));
+  vt_flat::Waiting me(query, n, limit, out);
+  std::vector<vt_flat::Waiting *> members;
+  {
+    std::unique_lock<std::mutex> lk(co.mu);
+    if (co.active < max_active && co.waiting.empty()) {
+      co.active += 1;  // nobody to wait for, nobody to take along
+    } else {
+      co.waiting.push_back(&me);
+      co.gather.notify_one();
+      me.wake.wait(lk, [&] { return me.state != vt_flat::Waiting::QUEUED; });
+      if (me.state == vt_flat::Waiting::DONE) {
+        if (me.status != VT_OK) g_last_error = me.error;
+        return me.status;
+      }
+      if (me.state == vt_flat::Waiting::ALONE) {
+        lk.unlock();
+        return search_direct(h, query, n, limit, out);
+      }
+      // LEADS (the operation that just finished passed its slot on: `active` already counts this one).
+      // Callers that have just been answered are about to come back -- give them a moment (a few
+      // % of a pass) before the next pass over the corpus starts without them
+      if (co.last_batch > 1 && co.waiting.size() + 1 < co.last_batch) {
+        const double window = std::min(300e-6, 0.03 * co.last_seconds);
+        const size_t want = co.last_batch - 1;
+        co.gather.wait_for(lk, std::chrono::duration<double>(window), [&] { return co.waiting.size() >= want; });
+      }
+      for (auto it = co.waiting.begin(); it != co.waiting.end() && members.size() + 1 < kCoalesceMax;) {
+        if ((*it)->limit == limit && (*it)->n == n) {
+          members.push_back(*it);
+          it = co.waiting.erase(it);
+        } else {
+          ++it;
+        }
+      }
+    }
+    members.insert(members.begin(), &me);
+  }
+  // a batch needs strictly current id ranks; a lone search after unsorted inserts does not
+  // (lazy ranks): then nobody is made to wait for a re-rank -- everyone searches alone
+  bool disband = false;
+  if (members.size() > 1 && !h->multi()) {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    disband = shard_stale(h->shards[0].get(), NEED_STRICT_RANKS, limit);
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  if (disband) {
+    {
+      std::lock_guard<std::mutex> g(co.mu);
+      for (size_t i = 1; i < members.size(); ++i) {
+        members[i]->state = vt_flat::Waiting::ALONE;
+        members[i]->wake.notify_one();
+      }
+    }
+    members.resize(1);
+  }
+  try {
+    run_coalesced(h, members);
+  } catch (...) {  // (host memory, most likely) -- nobody may be left waiting
+    for (vt_flat::Waiting *w : members) {
+      if (w->out && *w->out) {
+        delete *w->out;
+        *w->out = nullptr;
+      }
+      w->status = VT_ERR_NOMEM;
+      w->error = "out of host memory";
+    }
+  }
+  const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  {
+    std::lock_guard<std::mutex> g(co.mu);
+    // (notified under the lock: a member may return -- and its Waiting leave the stack -- the
+    // moment it can take the lock and see DONE)
+    for (size_t i = 1; i < members.size(); ++i) {
+      members[i]->state = vt_flat::Waiting::DONE;
+      members[i]->wake.notify_one();
+    }
+    co.last_batch = members.size();
+    co.last_seconds = seconds;
+    if (members.size() > 1) {
+      co.batches += 1;
+      co.batched_queries += members.size();
+    }
+    // the longest-waiting caller leads next, in this operation's slot (it takes the others along)
+    if (!co.waiting.empty()) {
+      co.waiting.front()->state = vt_flat::Waiting::LEADS;
+      co.waiting.front()->wake.notify_one();
+      co.waiting.pop_front();
+    } else {
+      co.active -= 1;
+    }
+  }
+  if (me.status != VT_OK) g_last_error = me.error;
+  return me.status;
+}
 
 }  // namespace
 
@@ -3538,6 +3784,13 @@ int vt_flat_shard_memory(const vt_flat *h, size_t shard, size_t *row_capacity, s
   if (slab_chunks) *slab_chunks = ix->slab.mapped ? ix->slab.chunks.size() : 0;
   return VT_OK;
 }
+int vt_flat_coalesce_stats(vt_flat *h, uint64_t *batches, uint64_t *batched_queries) {
+  if (!h) return VT_ERR_ARGUMENT;
+  std::lock_guard<std::mutex> g(h->co.mu);
+  if (batches) *batches = h->co.batches;
+  if (batched_queries) *batched_queries = h->co.batched_queries;
+  return VT_OK;
+}
 int vt_flat_route_ids(const vt_flat *h, size_t count, const char *ids, const size_t *id_off, uint32_t *out_shard) {
   if (!h || (count && (!id_off || !out_shard))) return VT_ERR_ARGUMENT;
   const size_t S = h->shards.size();
@@ -3688,6 +3941,7 @@ int vt_flat_delete(vt_flat *h, const char *id, size_t id_len) {
     if (h->total() == 0) h->dim = -1;  // flat.rs:90-92: an emptied index forgets its dimension
   }
   if (st != VT_OK && began) h->poisoned = true;
+  refresh_approx_bytes(h);
   return st;
   });
 }
@@ -3696,13 +3950,7 @@ int vt_flat_search(vt_flat *h, const float *query, size_t n, size_t limit, vt_hi
   return guarded([&]() -> int {
   if (!h || !out || (!query && n)) return VT_ERR_ARGUMENT;
   *out = nullptr;
-  if (h->multi()) {
-    std::shared_lock<std::shared_mutex> rl(h->rw);
-    if (h->poisoned) return poisoned_status();
-    return search_multi(h, query, n, limit, out);
-  }
-  return read_single(h, NEED_RANKS, limit,
-                     [&](Shard *ix, Ctx &c) -> int { return search_ready(ix, c, query, n, limit, out); });
+  return coalesced_search(h, query, n, limit, out);
   });
 }
 
@@ -3810,33 +4058,7 @@ int vt_flat_merge_gathered(vt_flat *h, const void *device_blocks, size_t world, 
 int vt_flat_search_batch(vt_flat *h, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
   return guarded([&]() -> int {
   if (!h || !out || (nq && !queries && d)) return VT_ERR_ARGUMENT;
-  for (size_t i = 0; i < nq; ++i) out[i] = nullptr;
-  int st;
-  if (h->multi()) {
-    std::shared_lock<std::shared_mutex> rl(h->rw);
-    if (h->poisoned) return poisoned_status();
-    st = batch_multi(h, queries, nq, d, limit, out);
-  } else {
-    unsigned need = NEED_STRICT_RANKS;
-    {
-      std::shared_lock<std::shared_mutex> rl(h->rw);
-      if (batch_uses_mfma(h->shards[0].get(), nq, limit)) need |= NEED_NORMS;
-    }
-    st = read_single(h, need, limit, [&](Shard *ix, Ctx &c) -> int {
-      for (size_t i = 0; i < nq; ++i) {  // (a second run after an escalation starts clean)
-        delete out[i];
-        out[i] = nullptr;
-      }
-      if (ix->n && batch_uses_mfma(ix, nq, limit) && shard_stale(ix, NEED_NORMS, limit)) return kEscalate;
-      return batch_ready(ix, c, queries, nq, d, limit, out);
-    });
-  }
-  if (st != VT_OK)
-    for (size_t i = 0; i < nq; ++i) {
-      delete out[i];
-      out[i] = nullptr;
-    }
-  return st;
+  return batch_direct(h, queries, nq, d, limit, out);
   });
 }
 

@@ -180,6 +180,15 @@ def flat_shard_lens(index: FlatRef) -> List[int]:
     return [int(L.vt_flat_shard_len(index.handle, s)) for s in range(flat_shard_count(index))]
 
 
+def flat_coalesce_stats(index: FlatRef):
+    """(batches, searches they carried) of the searches that met on this handle (vt_flat_coalesce_stats)."""
+    a, b = C.c_uint64(), C.c_uint64()
+    st = _lib.load().vt_flat_coalesce_stats(index.handle, C.byref(a), C.byref(b))
+    if st != 0:
+        raise RuntimeError("flat_coalesce_stats: " + _lib.error_text(st))
+    return int(a.value), int(b.value)
+
+
 def flat_shard_memory(index: FlatRef, shard: int = 0):
     """(row capacity, slab bytes, mapped chunks) of a shard (vt_flat_shard_memory)."""
     cap, nbytes, chunks = C.c_size_t(), C.c_size_t(), C.c_size_t()
