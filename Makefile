@@ -25,7 +25,8 @@ $(LIBDIR)/%.o: $(CSRC)/%.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/vt_index.o: $(CSRC)/vt_index.cpp $(CSRC)/vt_device.h include/vettore_flat.h
+HOSTHDR := $(wildcard $(CSRC)/host/*.h)
+$(LIBDIR)/vt_index.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h include/vettore_flat.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 

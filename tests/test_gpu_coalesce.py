@@ -1,4 +1,4 @@
-"""Searches that meet on one handle go together (coalesced_search, vt_index.cpp): a search that
+"""Searches that meet on one handle go together (coalesced_search, csrc/host/vt_coalesce.h): a search that
 finds another one running waits, and what has queued up runs as one batch.  Every caller must
 get exactly what its own search returns alone -- hits, order, raw bits, and its own error.
 `VT_COALESCE_SLOTS=1` makes even a small corpus queue its callers."""

@@ -1,4 +1,4 @@
-"""Where the rows live (`Slab`, vt_index.cpp): below one chunk a plain allocation regrown by
+"""Where the rows live (`Slab`, csrc/host/vt_base.h): below one chunk a plain allocation regrown by
 copy, from one chunk on a reserved virtual range into which equal physical chunks are mapped as
 the rows arrive -- the rows never move, nothing is copied, and the slab is never larger than
 the rows plus one chunk.  The tests shrink the chunk to 2 MiB (`VT_SLAB_CHUNK_MB`) so that a

@@ -1,0 +1,696 @@
+// vt_batch_staged.h -- query batches (K2 / K1m host side) and the staged searches (quantized, funnel, hybrid) on one shard.
+// Part of vt_index.cpp's translation unit (included there, in this order, exactly once): the host
+// side is one TU on purpose -- everything below the C ABI lives in an anonymous namespace.
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------- K2 host side
+// One group of <= 256 queries through the matrix cores.  `done[i]` is set for
+// every query whose exact top-k was proven complete; the others are left for
+// the single-query path.
+int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit, vt_hits **out, std::vector<char> &done) {
+  const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
+  const uint32_t k = (uint32_t)std::min<size_t>(limit, n);
+  uint32_t nq_pad = 32;
+  while (nq_pad < nq) nq_pad *= 2;
+  const uint32_t rows_per_block = vt::batch_rows_per_block(nq_pad);
+  const uint32_t ntiles_total = (n + rows_per_block - 1) / rows_per_block;
+  // pass-0 sample: 1/64 of the row tiles, 128..512 of them, spread over the corpus.
+  // A larger sample gives a tighter tau: fewer candidates to rescore and, above
+  // all, fewer trips through the epilogue's append path (a returning global
+  // atomic, ~2 us with the matrix pipe idle: 5 % of the pass at 128 tiles).
+  // (at most 65 536 sample rows: sample_tau_kernel holds a query's sample in registers)
+  const uint32_t want_tiles = std::min<uint32_t>(std::min<uint32_t>(512, 65536 / rows_per_block),
+                                                 std::max<uint32_t>(128, ntiles_total / 64));
+  const uint32_t stride = std::max<uint32_t>(1, (ntiles_total + want_tiles - 1) / want_tiles);
+  const uint32_t ntiles_sample = (ntiles_total + stride - 1) / stride;
+  const uint32_t sample_rows = ntiles_sample * rows_per_block;
+  // tau = rank-th best sample score: about rank * n / sample_rows rows pass
+  const double ratio = (double)sample_rows / (double)n;
+  uint32_t rank = (uint32_t)std::ceil(8.0 * k * std::min(1.0, ratio));
+  rank = std::max<uint32_t>(3, std::min<uint32_t>(rank, std::min<uint32_t>(sample_rows, n)));
+  const uint32_t cand_cap = 8192;
+  constexpr uint32_t kBlocksPerQuery = 4;
+
+  VT_TRY(c.dBQ.ensure((size_t)nq_pad * ld));
+  VT_TRY(c.hBQ.ensure((size_t)nq_pad * ld));
+  VT_TRY(c.dBTau.ensure(nq_pad));
+  VT_TRY(c.hBTau.ensure(nq_pad));
+  VT_TRY(c.dBSample.ensure((size_t)nq_pad * sample_rows));
+  VT_TRY(c.dBCand.ensure((size_t)nq_pad * cand_cap));
+  VT_TRY(c.dBCount.ensure(nq_pad));
+  VT_TRY(c.hBCount.ensure(nq_pad));
+  VT_TRY(c.dBOut.ensure((size_t)nq_pad * k));
+  VT_TRY(c.hBOut.ensure((size_t)nq_pad * k));
+  VT_TRY(c.dBOutCount.ensure(nq_pad));
+  VT_TRY(c.hBOutCount.ensure(nq_pad));
+  VT_TRY(c.dPartKeys.ensure((size_t)nq_pad * kBlocksPerQuery * k));
+  VT_TRY(c.dPartPay.ensure((size_t)nq_pad * kBlocksPerQuery * k));
+
+  std::vector<double> qnorm(nq);
+  std::memset(c.hBQ.p, 0, (size_t)nq_pad * ld * sizeof(float));
+  for (size_t i = 0; i < nq; ++i) {
+    std::memcpy(c.hBQ.p + i * ld, queries + i * d, (size_t)d * sizeof(float));
+    double s = 0.0;
+    for (uint32_t j = 0; j < d; ++j) s += (double)queries[i * d + j] * (double)queries[i * d + j];
+    qnorm[i] = std::sqrt(s);
+  }
+  VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  vt::BatchScoreArgs a{};
+  a.X = ix->dX;
+  a.stride = ix->ld;
+  a.Q = c.dBQ.p;
+  a.ld = ld;
+  a.nq_pad = nq_pad;
+  a.n_total = n;
+  const bool l2_family = ix->metric == VT_L2 || ix->metric == VT_L2_SQUARED;
+  a.xnorm2 = l2_family ? ix->dXnorm2.p : nullptr;
+  // pass 0: dense scores of the sample -> tau
+  a.n = sample_rows;
+  a.sample_stride = stride;
+  a.sample = c.dBSample.p;
+  a.sample_rows = sample_rows;
+  const uint32_t grid_cap = (uint32_t)c.num_cus;
+  VT_HIP(vt::launch_batch_scores(a, true, std::min<uint32_t>(ntiles_sample, grid_cap), c.stream));
+  VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, nq_pad, (uint32_t)nq, rank, c.dBTau.p, c.stream));
+  // pass 1: all rows, candidates with score >= tau
+  a.n = n;
+  a.sample = nullptr;
+  a.tau = c.dBTau.p;
+  a.cand = c.dBCand.p;
+  a.cand_count = c.dBCount.p;
+  a.cand_cap = cand_cap;
+  VT_HIP(hipMemsetAsync(c.dBCount.p, 0, (size_t)nq_pad * sizeof(uint32_t), c.stream));
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev2, c.stream));
+  VT_HIP(vt::launch_batch_scores(a, false, std::min<uint32_t>(ntiles_total, grid_cap), c.stream));
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev3, c.stream));
+  // exact rescoring of every query's candidates with the K1 arithmetic
+  vt::ScanArgs sa{};
+  sa.X = ix->dX;
+  sa.stride = ix->ld;
+  sa.q = c.dBQ.p;
+  sa.id_rank = ix->dRank.p;
+  sa.gather = &c.dBCand.p->row;
+  sa.gather_stride = sizeof(vt::BatchCand) / sizeof(uint32_t);
+  sa.n = cand_cap;
+  sa.d = d;
+  sa.metric = ix->metric;
+  sa.order = ix->order;
+  sa.k = k;
+  sa.part_keys = c.dPartKeys.p;
+  sa.part_pay = c.dPartPay.p;
+  sa.status = c.dStatus.p;
+  sa.batch_counts = c.dBCount.p;
+  sa.batch_cap = cand_cap;
+  VT_HIP(vt::launch_scan_batch(sa, kBlocksPerQuery, nq_pad, c.stream));
+  VT_HIP(vt::launch_batch_select(c.dPartKeys.p, c.dPartPay.p, nq_pad, kBlocksPerQuery * k, k, c.dBOut.p, c.dBOutCount.p,
+                                 c.stream));
+  int status = 0;
+  VT_HIP(hipMemcpyAsync(c.hBOut.p, c.dBOut.p, (size_t)nq_pad * k * sizeof(vt::Entry), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(c.hBOutCount.p, c.dBOutCount.p, (size_t)nq_pad * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(c.hBCount.p, c.dBCount.p, (size_t)nq_pad * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(c.hBTau.p, c.dBTau.p, (size_t)nq_pad * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(&status, c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  if (c.profiling) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev2, c.ev3));
+    c.prof.batch_launches += 1;
+    c.prof.batch_ms += ms;
+    c.prof.batch_flops += 2.0 * (double)n * (double)nq_pad * (double)ld;
+    c.prof.batch_queries += nq;
+  }
+  if (status != 0) return VT_OK;  // an exact rescoring overflowed somewhere: let the single-query path decide
+
+  // A query is accepted when no row outside its candidate set can reach the
+  // top k.  Every such row y has score_mfma(y) < tau.  With u = 2^-24 and X the
+  // largest row norm, both the MFMA sum and the reference's chunked sum are
+  // d-term f32 sums of the same products, so
+  //   dot family:  |dot_mfma - dot_ref| <= 2 gamma_d |q| X            =: eps
+  //                => dot_ref(y) < tau + eps; accepted if tau + eps (+ slack) <= dot_k;
+  //   L2 family:   score = 2 q.x - |x|^2 = |q|^2 - |q - x|^2, so
+  //                l2sq_ref(y) > |q|^2 - tau - eps with eps = 3.5 d u (|q| + X)^2;
+  //                accepted if l2sq_k (+ slack) <= |q|^2 - tau - eps.
+  // The slack keeps y strictly behind the k-th hit even after the f32 rank
+  // (1 - raw for cosine, sqrt for L2) collapses nearby values onto equal keys,
+  // where the id tie-break could otherwise let y in.
+  const double u = std::ldexp(1.0, -24);
+  const double xnorm = std::sqrt(ix->max_sqnorm);
+  for (size_t i = 0; i < nq; ++i) {
+    const uint32_t cnt = c.hBCount.p[i];
+    if (cnt > cand_cap || c.hBOutCount.p[i] < k) continue;
+    const vt::Entry *e = c.hBOut.p + i * k;
+    const double tau = (double)c.hBTau.p[i];
+    const double raw_k = (double)e[k - 1].raw;
+    bool accept = false;
+    if (l2_family) {
+      const double eps = 3.5 * (double)d * u * (qnorm[i] + xnorm) * (qnorm[i] + xnorm);
+      const double l2sq_k = (ix->metric == VT_L2 ? raw_k * raw_k : raw_k) * (1.0 + 16.0 * u);
+      accept = l2sq_k <= qnorm[i] * qnorm[i] * (1.0 - 4.0 * u) - tau - eps;
+    } else {
+      const double eps = 2.5 * (double)d * u * qnorm[i] * xnorm;
+      const double dot_k = ix->metric == VT_NEG_INNER_PRODUCT ? -raw_k : raw_k;
+      const double slack = ix->metric == VT_COSINE ? 4.0 * u * std::max(1.0, std::fabs(1.0 - dot_k)) : 0.0;
+      accept = tau + eps + slack <= dot_k;
+    }
+    if (!accept) continue;  // also taken when anything above is NaN
+    std::vector<vt::Entry> entries(e, e + k);
+    VT_TRY(make_hits(ix, entries, &out[i]));
+    done[i] = 1;
+  }
+  return VT_OK;
+}
+
+// K1m serves a batch when every query's list fits its small wave buffers.
+bool multi_scan_applies(const Shard *ix, size_t limit) {
+  return limit >= 1 && std::min<size_t>(limit, ix->n) <= vt::scan_multi_max_k(vt::kMultiMaxQueries) &&
+         !(ix->metric == VT_JACCARD && ix->dim >= 4096) && std::getenv("VT_NO_MULTI_SCAN") == nullptr;
+}
+double multi_scan_seconds(const Shard *ix, size_t nq) {
+  const double sweeps = std::ceil((double)nq / vt::kMultiMaxQueries);
+  const double waves = (double)ix->ctx.num_cus * 2 * vt::kWavesPerBlock;  // two blocks per CU
+  const double tiles = std::ceil((double)ix->n / vt::scan_multi_tile_rows(vt::kMultiMaxQueries));
+  double steps = std::ceil(tiles / waves) * std::ceil((double)ix->ld / 256.0);  // (tile, panel) steps of one wave
+  double per_step = kMultiPanelS + 0.3e-6 / std::ceil((double)ix->ld / 256.0);
+  if (ix->dim % 64 != 0) per_step *= 2.3;  // run-time bounds and lane order, compiler-scheduled loads
+  return kMultiFixedS + sweeps * (kMultiSweepFixedS + steps * per_step + std::min(steps, 20.0) * kMultiRampS);
+}
+
+// `count` queries (rows `which[i]` of `queries`) in ceil(count / 8) sweeps of the corpus (K1m),
+// every sweep and one batched select queued before the single wait.  Ranks strictly current.
+int multi_scan_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size_t> &which, size_t limit, vt_hits **out) {
+  const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
+  const uint32_t k = (uint32_t)std::min<size_t>(limit, n);
+  const size_t nq = which.size();
+  const size_t lds = vt::scan_multi_lds_bytes(vt::kMultiMaxQueries);
+  const uint32_t ntiles = (n + vt::scan_multi_tile_rows(vt::kMultiMaxQueries) - 1) / vt::scan_multi_tile_rows(vt::kMultiMaxQueries);
+  const uint32_t blocks = c.grid_for(ntiles, lds);
+  // (a sweep always reads a full group of query rows: the last group is padded with zero rows)
+  const size_t nq_pad = (nq + vt::kMultiMaxQueries - 1) / vt::kMultiMaxQueries * vt::kMultiMaxQueries;
+  VT_TRY(c.dBQ.ensure(nq_pad * ld));
+  VT_TRY(c.hBQ.ensure(nq_pad * ld));
+  VT_TRY(c.dPartKeys.ensure(nq * blocks * k));
+  VT_TRY(c.dPartPay.ensure(nq * blocks * k));
+  // per query a packed result block: 16-byte header + k entries (Entry is 16 bytes)
+  const uint32_t out_stride = 16 + k * (uint32_t)sizeof(vt::Entry);
+  VT_TRY(c.dBOut.ensure(nq * (k + 1)));
+  VT_TRY(c.hBOut.ensure(nq * (k + 1)));
+  std::memset(c.hBQ.p, 0, nq_pad * ld * sizeof(float));
+  std::vector<uint32_t> qnz(nq, 0);
+  for (size_t i = 0; i < nq; ++i) {
+    const float *q = queries + which[i] * d;
+    std::memcpy(c.hBQ.p + i * ld, q, (size_t)d * sizeof(float));
+    for (uint32_t j = 0; j < d; ++j) qnz[i] += q[j] != 0.0f ? 1u : 0u;
+  }
+  VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+  uint32_t sweeps = 0;
+  for (size_t g0 = 0; g0 < nq; g0 += vt::kMultiMaxQueries, ++sweeps) {
+    const uint32_t gn = (uint32_t)std::min<size_t>(vt::kMultiMaxQueries, nq - g0);
+    vt::MultiScanArgs a{};
+    a.X = ix->dX;
+    a.stride = ix->ld;
+    a.Q = c.dBQ.p + g0 * ld;
+    a.id_rank = ix->dRank.p;
+    a.n = n;
+    a.d = d;
+    a.ld = ld;
+    a.metric = ix->metric;
+    a.order = ix->order;
+    a.k = k;
+    a.nq = gn;
+    a.first_query = (uint32_t)g0;
+    for (uint32_t i = 0; i < gn; ++i) a.q_nonzero[i] = qnz[g0 + i];
+    a.part_keys = c.dPartKeys.p;
+    a.part_pay = c.dPartPay.p;
+    a.status = c.dStatus.p;
+    VT_HIP(vt::launch_scan_multi(a, blocks, c.stream));
+  }
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+  VT_HIP(vt::launch_select_queries(c.dPartKeys.p, c.dPartPay.p, (uint32_t)nq, blocks * k, k, c.dBOut.p, out_stride, c.stream));
+  int status = 0;
+  VT_HIP(hipMemcpyAsync(c.hBOut.p, c.dBOut.p, nq * out_stride, hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(&status, c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  if (c.profiling) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    c.prof.scan_launches += sweeps;
+    c.prof.scan_ms += ms;
+    c.prof.scan_rows += (uint64_t)sweeps * n;
+    c.prof.scan_bytes += (uint64_t)sweeps * n * d * 4;
+  }
+  // "metric overflow" belongs to one query (flat.rs:105): the single-query path finds out whose
+  if (status != 0) return kRetryInternal;
+  for (size_t i = 0; i < nq; ++i) {
+    const vt::Entry *blk = c.hBOut.p + i * (k + 1);  // [0] is the header
+    uint32_t got = 0;
+    std::memcpy(&got, reinterpret_cast<const unsigned char *>(blk) + 4, 4);
+    got = std::min<uint32_t>(got, k);
+    std::vector<vt::Entry> entries(blk + 1, blk + 1 + got);
+    VT_TRY(make_hits(ix, entries, &out[which[i]]));
+  }
+  return VT_OK;
+}
+
+// True when a batch of nq queries takes the shared MFMA pass (and so needs the row norms).
+bool batch_uses_mfma(const Shard *ix, size_t nq, size_t limit) {
+  const bool mfma_metric = ix->metric == VT_COSINE || ix->metric == VT_INNER_PRODUCT ||
+                           ix->metric == VT_NEG_INNER_PRODUCT || ix->metric == VT_L2 || ix->metric == VT_L2_SQUARED;
+  // one shared pass over the corpus costs about 1.3 single scans (HBM-bound below 33 queries),
+  // so it pays from two queries on
+  bool use_mfma = mfma_metric && nq >= 2 && limit <= (size_t)vt::kMaxFusedK && limit > 0 && ix->n >= 4096 &&
+                  std::getenv("VT_BATCH_NO_MFMA") == nullptr;
+  if (use_mfma && !std::getenv("VT_FORCE_BATCH_MFMA")) {  // (tests force the shared pass on small corpora)
+    // nq single scans against one shared pass (HBM-bound below ~33 queries, then MFMA-bound)
+    const double bytes = (double)ix->n * ix->ld * 4.0;
+    double nq_pad = 32;
+    while (nq_pad < (double)std::min<size_t>(nq, 256)) nq_pad *= 2;
+    const double groups = std::ceil((double)nq / 256.0);
+    const double t_pass = std::max(1.3 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kBatchFlopsPerS);
+    double t_other = (double)nq * scan_seconds(bytes);
+    if (multi_scan_applies(ix, limit)) t_other = std::min(t_other, multi_scan_seconds(ix, nq));
+    use_mfma = t_other > groups * (kBatchFixedS + t_pass);
+  }
+  return use_mfma;
+}
+
+// Rank column strictly current, norms current when batch_uses_mfma (shard_prepare).
+int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
+  // every query is validated like flat_search would (flat.rs:97-101), in order
+  if (limit == 0) {
+    for (size_t i = 0; i < nq; ++i) VT_TRY(empty_hits(&out[i]));
+    return VT_OK;
+  }
+  for (size_t i = 0; i < nq; ++i) VT_TRY(validate_vector(queries + i * d, d, ix->dim));
+  if (ix->n == 0) {
+    for (size_t i = 0; i < nq; ++i) VT_TRY(empty_hits(&out[i]));
+    return VT_OK;
+  }
+  std::vector<char> done(nq, 0);
+  const bool use_mfma = batch_uses_mfma(ix, nq, limit);
+  if (use_mfma) {
+    for (size_t g0 = 0; g0 < nq; g0 += 256) {
+      const size_t gn = std::min<size_t>(256, nq - g0);
+      if (gn < 2) continue;  // a lone trailing query takes the single-query path below
+      std::vector<char> gdone(gn, 0);
+      VT_TRY(batch_group(ix, c, queries + g0 * d, gn, limit, out + g0, gdone));
+      for (size_t i = 0; i < gn; ++i) done[g0 + i] = gdone[i];
+    }
+  }
+  std::vector<size_t> left;
+  for (size_t i = 0; i < nq; ++i)
+    if (!done[i]) left.push_back(i);
+  c.prof.batch_fallbacks += use_mfma ? left.size() : 0;
+  // what the matrix cores did not take (no GEMM form for this metric, a small batch, a query
+  // the bound could not certify): several queries per sweep of the corpus when their lists
+  // fit, else one scan each
+  if (left.size() >= 2 && multi_scan_applies(ix, limit) &&
+      (multi_scan_seconds(ix, left.size()) < (double)left.size() * scan_seconds((double)ix->n * ix->ld * 4.0) ||
+       std::getenv("VT_FORCE_MULTI_SCAN"))) {  // (tests force the sweep on corpora of a few thousand rows)
+    const int st = multi_scan_group(ix, c, queries, left, limit, out);
+    if (st == VT_OK) return VT_OK;
+    if (st != kRetryInternal) return st;
+    for (size_t i : left) {  // an overflow somewhere: one by one, so that it is reported for its own query's position
+      delete out[i];
+      out[i] = nullptr;
+    }
+  }
+  for (size_t i : left) VT_TRY(search_ready(ix, c, queries + i * d, d, limit, &out[i]));
+  return VT_OK;
+}
+
+// What one shard of a multi-shard handle contributes to a staged search in ONE round: its
+// own candidates under each generator's cutting keys (ascending) and the exact-rerank entries
+// of all of them -- uncut, because which of them belong to the handle-wide candidate set is
+// only known once the shards' lists meet (staged_merge).
+struct LocalStages {
+  std::vector<std::vector<vt::Entry>> gens;
+  std::vector<vt::Entry> final_;
+};
+
+void entries_of_block(const ResultBlock *b, std::vector<vt::Entry> &out) { out.assign(b->e, b->e + b->count); }
+
+// collection.ex:276-295 on a shard whose ranks (strict) and sign bits are current.
+// `local` (multi-shard handles; candidates <= kMaxFusedK): nothing is cut to `limit` and no
+// hit list is built -- the shard's candidate and rerank entries go to *local.
+int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out,
+                    LocalStages *local = nullptr) {
+  // collection.ex:276-295: prepare_query validates the query against the
+  // collection's dimension; an empty store yields no candidates.
+  VT_TRY(validate_vector(query, n, ix->dim));
+  if (ix->n == 0 || candidates == 0 || limit == 0) return empty_hits(out);
+  const uint32_t d = (uint32_t)ix->dim;
+  const uint32_t words = (d + 63) / 64;
+  uint32_t qnz = 0;
+  VT_TRY(upload_query(c, query, n, &qnz, true));
+  const size_t ncand = std::min<size_t>(candidates, ix->n);
+  const size_t keep = local ? ncand : limit;
+  // K4h needs integer bins in LDS, one fused select, and enough rows to be worth two passes
+  const bool hist_ok = ncand <= (size_t)vt::kSelListMax && d <= vt::kHammingHistMaxDim &&
+                       (ix->n >= 16384 || ncand > (size_t)vt::kMaxFusedK) &&
+                       !std::getenv("VT_HAMMING_LISTS");
+  auto run = [&](bool use_hist) -> int {
+  std::vector<vt::Entry> entries, first;
+  bool first_in_block = false;
+  const uint32_t *gather = nullptr;
+  uint32_t gather_stride = 1;
+  bool timed_hamming = false;
+  auto copy_first_block = [&]() -> int {  // queued behind the select that fills c.dStage[0]
+    if (!local) return VT_OK;
+    VT_TRY(c.hFirst.ensure(1));
+    VT_HIP(hipMemcpyAsync(c.hFirst.p, c.dStage.p, sizeof(ResultBlock), hipMemcpyDeviceToHost, c.stream));
+    first_in_block = true;
+    return VT_OK;
+  };
+  if (use_hist) {
+    // stage 1 as a pure stream (K4h): distance column + histogram, threshold collect,
+    // select into the device block whose Entry.row column is stage 2's gather list
+    const uint32_t k1 = (uint32_t)ncand;
+    constexpr uint32_t kListCap = 65536, kHistStride = 8192;
+    VT_TRY(c.dDist16.ensure(((size_t)std::max<uint32_t>(ix->cap, ix->n) + 7) / 8 * 8));
+    VT_TRY(c.dHamHist.ensure(2 * kHistStride));
+    VT_TRY(c.dHamCount.ensure(1));
+    VT_TRY(c.dPartKeys.ensure(kListCap));
+    VT_TRY(c.dPartPay.ensure(kListCap));
+    VT_TRY(c.dStage.ensure(1));
+    if (!c.ham_ready || c.ham_dirty) {
+      VT_HIP(hipMemsetAsync(c.dHamHist.p, 0, 2 * kHistStride * sizeof(uint32_t), c.stream));
+      c.ham_ready = true;
+    }
+    c.ham_dirty = true;  // until this query's collect pass has been queued
+    vt::HammingHistArgs h{};
+    h.bits = ix->dBits.p;
+    h.qbits = c.dQbits;
+    h.n = ix->n;
+    h.words = words;
+    h.pairs = (words + 1) / 2;
+    h.d = d;
+    h.dist = c.dDist16.p;
+    h.hist = c.dHamHist.p + c.ham_parity * kHistStride;
+    h.list_count = c.dHamCount.p;
+    const uint32_t blocks = c.grid_for((ix->n + 63) / 64, vt::hamming_hist_lds_bytes(d), c.hamming_blocks_per_cu);
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+    VT_HIP(vt::launch_hamming_dist(h, blocks, c.stream));
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+    timed_hamming = c.profiling;
+    vt::HammingCollectArgs g{};
+    g.dist = c.dDist16.p;
+    g.id_rank = ix->dRank.p;
+    g.n = ix->n;
+    g.d = d;
+    g.k = k1;
+    g.hist = h.hist;
+    g.hist_next = c.dHamHist.p + (c.ham_parity ^ 1u) * kHistStride;
+    g.list_count = c.dHamCount.p;
+    g.keys = c.dPartKeys.p;
+    g.pay = c.dPartPay.p;
+    g.cap = kListCap;
+    g.status = c.dStatus.p;
+    VT_HIP(vt::launch_hamming_collect(g, (uint32_t)c.num_cus * 4, c.stream));
+    c.ham_parity ^= 1u;
+    c.ham_dirty = false;
+    if (k1 <= (uint32_t)vt::kMaxFusedK) {
+      // (no status pointer: a raised flag stays in dStatus for the final select)
+      VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, kListCap, k1, 0, 0, nullptr, c.dStage.p, c.dSelKeys.p, c.dSelPay.p,
+                               c.stream, c.dHamCount.p));
+      VT_TRY(copy_first_block());
+      gather = &c.dStage.p->e[0].row;
+      gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
+    } else {
+      if (local) return VT_ERR_ARGUMENT;  // callers keep one-round searches to candidates <= kMaxFusedK
+      // up to 4 096 candidates (limit * 10 for limit <= 409): the exact candidate SET as a
+      // device list -- stage 2 orders by its own keys, so this one need not be sorted
+      VT_TRY(c.dListKeys.ensure(k1));
+      VT_TRY(c.dListPay.ensure(k1));
+      VT_HIP(vt::launch_select_list(c.dPartKeys.p, c.dPartPay.p, kListCap, c.dHamCount.p, k1, c.dListKeys.p, c.dListPay.p,
+                                    c.stream));
+      gather = &c.dListPay.p->row;
+      gather_stride = sizeof(vt::Payload) / sizeof(uint32_t);
+    }
+  } else if (ncand <= (size_t)vt::kMaxFusedK) {
+    // stage 1 stays on the device: hamming scan -> select into a device block
+    // whose Entry.row column is the gather list of stage 2 (no host round trip)
+    const uint32_t k1 = (uint32_t)ncand;
+    const uint32_t blocks = c.grid_for((ix->n + 63) / 64, vt::hamming_lds_bytes(k1), c.hamming_blocks_per_cu);
+    const uint32_t waves = vt::scan_lists(blocks);
+    VT_TRY(c.dPartKeys.ensure((size_t)waves * k1));
+    VT_TRY(c.dPartPay.ensure((size_t)waves * k1));
+    VT_TRY(c.dStage.ensure(1));
+    vt::HammingArgs h{};
+    h.bits = ix->dBits.p;
+    h.qbits = c.dQbits;
+    h.id_rank = ix->dRank.p;
+    h.n = ix->n;
+    h.words = words;
+    h.pairs = (words + 1) / 2;
+    h.d = d;
+    h.k = k1;
+    h.part_keys = c.dPartKeys.p;
+    h.part_pay = c.dPartPay.p;
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+    VT_HIP(vt::launch_hamming(h, blocks, c.stream));
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+    timed_hamming = c.profiling;
+    VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, waves * k1, k1, 0, 0, c.dStatus.p, c.dStage.p, c.dSelKeys.p, c.dSelPay.p, c.stream));
+    VT_TRY(copy_first_block());
+    gather = &c.dStage.p->e[0].row;
+    gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
+  } else {
+    // stage 1: binary_top_k (search.rs:76-92), candidate rows via the host
+    std::vector<vt::Entry> cand;
+    VT_TRY(run_hamming(c, ix->dBits.p, c.dQbits, ix->dRank.p, ix->n, d, candidates, cand, true));
+    if (local) first = cand;
+    std::vector<uint32_t> rows(cand.size());
+    for (size_t i = 0; i < cand.size(); ++i) rows[i] = cand[i].row;
+    VT_TRY(c.dRows.ensure(rows.size()));
+    VT_HIP(hipMemcpyAsync(c.dRows.p, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));  // `rows` is pageable and dies with this scope
+    gather = c.dRows.p;
+  }
+  // stage 2: vector_top_k over the candidates (search.rs:38-73)
+  if (ix->metric == VT_COSINE) {
+    VT_TRY(c.dCandKeys.ensure(ncand));
+    VT_TRY(c.dCandPay.ensure(ncand));
+    vt::CosineRerankArgs a{};
+    a.X = ix->dX;
+    a.stride = ix->ld;
+    a.q = c.dQ.p;
+    a.id_rank = ix->dRank.p;
+    a.gather = gather;
+    a.gather_stride = gather_stride;
+    a.n = (uint32_t)ncand;
+    a.d = d;
+    a.out_keys = c.dCandKeys.p;
+    a.out_pay = c.dCandPay.p;
+    a.status = c.dStatus.p;
+    VT_HIP(vt::launch_cosine_rerank(a, c.stream));
+    VT_TRY(collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, (uint32_t)ncand, keep, entries));
+  } else {
+    ScanJob j{};
+    j.X = ix->dX;
+    j.stride = ix->ld;
+    j.id_rank = ix->dRank.p;
+    j.gather = gather;
+    j.gather_stride = gather_stride;
+    j.n = (uint32_t)ncand;
+    j.d = d;
+    j.metric = ix->metric;
+    j.order = ix->order;
+    j.q_nonzero = qnz;
+    VT_TRY(run_scan(c, j, keep, entries, false));
+  }
+  if (timed_hamming) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    c.prof.hamming_launches += 1;
+    c.prof.hamming_ms += ms;
+    c.prof.hamming_bytes += (uint64_t)ix->n * words * 8;
+  }
+  if (local) {
+    if (first_in_block) entries_of_block(c.hFirst.p, first);  // (every path above ends in a stream sync)
+    local->gens.assign(1, std::move(first));
+    local->final_ = std::move(entries);
+    return VT_OK;
+  }
+  return make_hits(ix, entries, out);
+  };
+  int rc = run(hist_ok);
+  if (rc == kRetryInternal) rc = run(false);  // more ties at the k-th distance than the list holds
+  return rc;
+}
+
+
+// collection.ex:245-260 on a shard whose ranks are strictly current.
+int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *stages, size_t nstages,
+                 size_t candidates, size_t limit, vt_hits **out, LocalStages *local = nullptr) {
+  // collection.ex:245-260: prepare_query validates the query against the
+  // collection; stages are prefix lengths 1..dimensions (collection.ex:905-913)
+  VT_TRY(validate_vector(query, n, ix->dim));
+  if (nstages == 0) return VT_ERR_PREFIX;
+  for (size_t i = 0; i < nstages; ++i)
+    if (stages[i] == 0 || stages[i] > n) return VT_ERR_PREFIX;
+  if (ix->n == 0 || candidates == 0 || limit == 0) return empty_hits(out);
+  uint32_t qnz_full = 0;
+  VT_TRY(upload_query(c, query, n, &qnz_full));
+  std::vector<vt::Entry> entries;
+  // (`local`: the rerank keeps every candidate -- see LocalStages)
+  if (funnel_fits_device(ix, stages, nstages, candidates, local ? candidates : limit)) {
+    // the whole funnel as one chain of kernels: each stage's winners stay in a
+    // device block whose row column is the next stage's gather list; one wait
+    VT_TRY(c.dStage.ensure(2));
+    const ResultBlock *src = nullptr;
+    uint32_t count = ix->n;
+    for (size_t i = 0; i < nstages; ++i) {
+      uint32_t nz = 0;
+      for (size_t j = 0; j < stages[i]; ++j) nz += query[j] != 0.0f ? 1u : 0u;
+      const uint32_t want = (uint32_t)std::min<size_t>(candidates, count);
+      ResultBlock *dst = c.dStage.p + (i & 1);
+      VT_TRY(funnel_stage_dev(ix, c, query, (uint32_t)stages[i], src, count, want, nz, dst, false));
+      if (local && i == 0) {
+        VT_TRY(c.hFirst.ensure(1));
+        VT_HIP(hipMemcpyAsync(c.hFirst.p, dst, sizeof(ResultBlock), hipMemcpyDeviceToHost, c.stream));
+      }
+      src = dst;
+      count = want;
+    }
+    // exact_rerank on the full vectors (collection.ex:821-851)
+    const uint32_t want = local ? count : (uint32_t)std::min<size_t>(limit, count);
+    VT_TRY(funnel_stage_dev(ix, c, query, (uint32_t)ix->dim, src, count, want, qnz_full, c.dResMapped, true));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    VT_TRY(c.settle_prefix_profile());
+    if (c.hRes.p->status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
+    entries.assign(c.hRes.p->e, c.hRes.p->e + c.hRes.p->count);
+    if (local) {
+      local->gens.resize(1);
+      entries_of_block(c.hFirst.p, local->gens[0]);
+      local->final_ = std::move(entries);
+      return VT_OK;
+    }
+    return make_hits(ix, entries, out);
+  }
+  std::vector<uint32_t> rows;
+  std::vector<vt::Entry> first;
+  VT_TRY(funnel_rows(ix, c, query, stages, nstages, candidates, rows, local ? &first : nullptr));
+  if (local) {
+    if (!rows.empty()) VT_TRY(funnel_stage(ix, c, query, (uint32_t)ix->dim, rows, false, rows.size(), qnz_full, entries));
+    local->gens.assign(1, std::move(first));
+    local->final_ = std::move(entries);
+    return VT_OK;
+  }
+  if (rows.empty()) return empty_hits(out);
+  // exact_rerank on the full vectors (collection.ex:821-851)
+  VT_TRY(funnel_stage(ix, c, query, (uint32_t)ix->dim, rows, false, limit, qnz_full, entries));
+  return make_hits(ix, entries, out);
+}
+
+
+// collection.ex:325-345 on a shard whose ranks are strictly current (and whose sign bits
+// are, when a quantized generator takes part).
+int hybrid_ready(Shard *ix, Ctx &c, const float *query, size_t n, const int *kinds, const size_t *candidates,
+                 const size_t *stage_off, const size_t *stages, size_t ngen, size_t limit, vt_hits **out,
+                 LocalStages *local = nullptr) {
+  VT_TRY(validate_vector(query, n, ix->dim));
+  if (ngen == 0) return VT_ERR_ARGUMENT;
+  for (size_t i = 0; i < ngen; ++i) {
+    if (kinds[i] < VT_GEN_FUNNEL || kinds[i] > VT_GEN_SEARCH || candidates[i] == 0) return VT_ERR_ARGUMENT;
+    if (kinds[i] == VT_GEN_FUNNEL) {
+      if (stage_off[i + 1] <= stage_off[i]) return VT_ERR_PREFIX;
+      for (size_t j = stage_off[i]; j < stage_off[i + 1]; ++j)
+        if (stages[j] == 0 || stages[j] > n) return VT_ERR_PREFIX;
+    }
+  }
+  if (ix->n == 0 || limit == 0) return empty_hits(out);
+  uint32_t qnz_full = 0;
+  VT_TRY(upload_query(c, query, n, &qnz_full, true));
+  // hybrid_candidates (collection.ex:515-532): every generator's candidates, first occurrence wins
+  std::vector<uint32_t> all, rows;
+  std::unordered_set<uint32_t> seen;  // (a few hundred rows: never a column over the corpus)
+  std::vector<vt::Entry> kept;
+  if (local) local->gens.assign(ngen, {});
+  for (size_t i = 0; i < ngen; ++i) {
+    kept.clear();
+    if (kinds[i] == VT_GEN_FUNNEL) {
+      VT_TRY(funnel_rows(ix, c, query, stages + stage_off[i], stage_off[i + 1] - stage_off[i], candidates[i], rows,
+                         local ? &kept : nullptr));
+    } else if (kinds[i] == VT_GEN_QUANTIZED) {
+      VT_TRY(quantized_rows(ix, c, candidates[i], rows, local ? &kept : nullptr));
+    } else {  // the index's own search with limit = candidates (collection.ex:583-592)
+      // (flat search ranks cosine by the f32 dot of normalised vectors, not by the f64 cosine
+      // a vector_top_k stage would use: the plain scan serves every metric here)
+      ScanJob j{};
+      j.X = ix->dX;
+      j.stride = ix->ld;
+      j.id_rank = ix->dRank.p;
+      j.n = ix->n;
+      j.d = (uint32_t)ix->dim;
+      j.metric = ix->metric;
+      j.order = ix->order;
+      j.q_nonzero = qnz_full;
+      VT_TRY(run_scan(c, j, candidates[i], kept, false));
+      rows.resize(kept.size());
+      for (size_t r = 0; r < kept.size(); ++r) rows[r] = kept[r].row;
+    }
+    if (local) local->gens[i] = kept;
+    for (uint32_t r : rows)
+      if (seen.insert(r).second) all.push_back(r);
+  }
+  std::vector<vt::Entry> entries;
+  if (local) {
+    if (!all.empty()) VT_TRY(funnel_stage(ix, c, query, (uint32_t)ix->dim, all, false, all.size(), qnz_full, entries));
+    local->final_ = std::move(entries);
+    return VT_OK;
+  }
+  if (all.empty()) return empty_hits(out);
+  // hybrid_rerank :exact == exact_rerank (collection.ex:627-630, :821-851)
+  VT_TRY(funnel_stage(ix, c, query, (uint32_t)ix->dim, all, false, limit, qnz_full, entries));
+  return make_hits(ix, entries, out);
+}
+
+
+// Per-device context for the stateless helpers.
+std::mutex g_ctx_mu;
+std::unordered_map<int, std::unique_ptr<Ctx>> g_ctx;
+int stateless_ctx(int device, Ctx **out) {
+  std::lock_guard<std::mutex> g(g_ctx_mu);
+  auto it = g_ctx.find(device);
+  if (it == g_ctx.end()) {
+    auto c = std::make_unique<Ctx>();
+    VT_TRY(c->init(device));
+    it = g_ctx.emplace(device, std::move(c)).first;
+  }
+  *out = it->second.get();
+  return (*out)->bind();
+}
+
+// id_rank for an ad-hoc batch of ids (ties between equal ids: input order).
+void ranks_for_ids(const char *ids, const size_t *id_off, size_t count, std::vector<uint32_t> &rank) {
+  std::vector<uint32_t> order(count);
+  for (size_t i = 0; i < count; ++i) order[i] = (uint32_t)i;
+  auto view = [&](uint32_t i) { return std::pair<const char *, size_t>(ids + id_off[i], id_off[i + 1] - id_off[i]); };
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    auto x = view(a), y = view(b);
+    const size_t m = std::min(x.second, y.second);
+    const int c = m ? std::memcmp(x.first, y.first, m) : 0;
+    if (c) return c < 0;
+    return x.second < y.second;
+  });
+  rank.resize(count);
+  for (size_t i = 0; i < count; ++i) rank[order[i]] = (uint32_t)i;
+}
+
+int hits_from_batch(const char *ids, const size_t *id_off, const std::vector<vt::Entry> &entries, vt_hits **out) {
+  auto h = std::make_unique<vt_hits>();
+  for (const auto &e : entries) {
+    h->ids.emplace_back(ids + id_off[e.row], id_off[e.row + 1] - id_off[e.row]);
+    h->raw.push_back(e.raw);
+    h->rank_key.push_back(rank_key_of(e.key));
+  }
+  *out = h.release();
+  return VT_OK;
+}
+
+}  // namespace

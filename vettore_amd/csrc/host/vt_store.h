@@ -1,0 +1,481 @@
+// vt_store.h -- index ops on one shard: growing the slab, the id table and its ranks, storing rows.
+// Part of vt_index.cpp's translation unit (included there, in this order, exactly once): the host
+// side is one TU on purpose -- everything below the C ABI lives in an anonymous namespace.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------ index ops
+int index_reserve(Shard *ix, uint32_t want_rows) {
+  if (want_rows <= ix->cap) return VT_OK;
+  const size_t row_bytes = (size_t)ix->ld * sizeof(float);
+  auto tiles_up = [](uint64_t rows) { return (rows + vt::kTileRows - 1) / vt::kTileRows * vt::kTileRows; };
+  if (tiles_up(want_rows) > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
+  Slab &sl = ix->slab;
+  hipStream_t stream = ix->ctx.stream;
+  const size_t old_bytes = (size_t)ix->n * row_bytes;
+  const size_t need = (size_t)tiles_up(want_rows) * row_bytes;
+  if (sl.mapped) {
+    // more chunks behind the ones in use: the rows stay where they are
+    VT_TRY(sl.map_up_to(need, ix->ctx.device));
+    // rows n..cap are scanned by the last tile: keep them defined
+    VT_HIP(hipMemsetAsync(reinterpret_cast<char *>(sl.p) + sl.defined, 0, sl.bytes - sl.defined, stream));
+    VT_HIP(hipStreamSynchronize(stream));
+    sl.defined = sl.bytes;
+  } else {
+    Slab fresh;
+    bool have = false;
+    if (need >= Slab::chunk_bytes() && Slab::mapping_allowed()) {
+      const int st = fresh.start_mapped(need, ix->ctx.device);
+      if (st == VT_OK) have = true;
+      else if (st != VT_ERR_UNSUPPORTED) return st;
+    }
+    if (!have) {
+      uint64_t nc = std::max<uint64_t>(want_rows, (uint64_t)ix->cap * 2);
+      nc = tiles_up(std::max<uint64_t>(nc, 1024));
+      // (doubling stops at one chunk: the growth after that maps instead of copying)
+      if (Slab::mapping_allowed() && nc * row_bytes > Slab::chunk_bytes())
+        nc = std::max<uint64_t>(tiles_up(want_rows), Slab::chunk_bytes() / row_bytes / vt::kTileRows * vt::kTileRows);
+      if (nc > 0xFFFFFFF0ull) nc = tiles_up(want_rows);
+      VT_HIP(hipMalloc(reinterpret_cast<void **>(&fresh.p), (size_t)nc * row_bytes));
+      fresh.bytes = (size_t)nc * row_bytes;
+    }
+    if (sl.p && ix->n) VT_HIP(hipMemcpyAsync(fresh.p, sl.p, old_bytes, hipMemcpyDeviceToDevice, stream));
+    VT_HIP(hipMemsetAsync(reinterpret_cast<char *>(fresh.p) + old_bytes, 0, fresh.bytes - old_bytes, stream));
+    VT_HIP(hipStreamSynchronize(stream));
+    sl.release();
+    sl.p = fresh.p;
+    sl.bytes = sl.defined = fresh.bytes;
+    sl.mapped = fresh.mapped;
+    sl.reserved = fresh.reserved;
+    sl.chunk = fresh.chunk;
+    sl.chunks.swap(fresh.chunks);
+    fresh.p = nullptr;  // (ownership moved)
+    fresh.bytes = fresh.reserved = 0;
+    fresh.mapped = false;
+  }
+  ix->dX = sl.p;
+  const uint64_t rows = std::min<uint64_t>(sl.bytes / row_bytes / vt::kTileRows * vt::kTileRows, 0xFFFFFFE0ull);
+  ix->cap = (uint32_t)rows;
+  return VT_OK;
+}
+
+// Sets the dimension of an empty index (first insert after creation/emptying).
+int index_set_dim(Shard *ix, size_t d) {
+  if (d > 0x7fffffffu) return fail(VT_ERR_UNSUPPORTED, "dimension too large");
+  if (vt::scan_lds_bytes((uint32_t)d, 1) == 0)
+    return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(d) + " exceeds what the scan kernel stages in LDS");
+  const uint32_t ld = vt::padded_dim((uint32_t)d);
+  ix->for_each_ctx([](Ctx &c) { c.ham_dirty = true; });  // K4h's histograms are cleared for d + 1 bins only: a new dimension starts clean
+  ix->bits_valid = false;    // derived per-row data belongs to the old rows
+  ix->max_sqnorm = -1.0;
+  ix->bits_dirty.clear();
+  ix->norm_dirty.clear();
+  if (ld != ix->ld) {
+    VT_HIP(hipStreamSynchronize(ix->ctx.stream));
+    ix->slab.release();
+    ix->dX = nullptr;
+    ix->cap = 0;
+    ix->ld = ld;
+  }
+  ix->dim = (long)d;
+  return VT_OK;
+}
+
+// Row for `id`: existing row, or a fresh one appended (ids/rank bookkeeping).
+uint32_t index_row_for(Shard *ix, const char *id, size_t len, bool *is_new) {
+  std::string key(id, len);
+  auto it = ix->row_of.find(key);
+  if (it != ix->row_of.end()) {
+    *is_new = false;
+    return it->second;
+  }
+  const uint32_t r = ix->n++;
+  *is_new = true;
+  ix->epoch += 1;
+  if (ix->external_ranks) {
+    // externally supplied ranks describe the old row set only: fall back to a local re-rank
+    ix->external_ranks = false;
+    ix->ranks_clean = false;
+    std::fill(ix->rank_host.begin(), ix->rank_host.end(), kUnranked);
+    ix->rank_dirty_all = true;  // the whole device column is stale now
+    ix->unranked = ix->rank_host.size();
+  }
+  if (ix->ranks_clean) {
+    // ids arriving in ascending order (snapshot rebuild sorts by id,
+    // collection.ex:427-433) keep ranks valid without a re-sort
+    if (r == 0 || id_less(ix->max_id, key)) {
+      const uint32_t rk = r == 0 ? 0 : ix->max_rank + 1;
+      if (r != 0 && ix->max_rank >= kUnranked - 1) ix->ranks_clean = false;
+      ix->rank_host.push_back(rk);
+      ix->max_rank = rk;
+      ix->max_id = key;
+    } else {
+      ix->ranks_clean = false;
+      ix->rank_host.push_back(kUnranked);
+      ix->unranked += 1;
+    }
+  } else {
+    ix->rank_host.push_back(kUnranked);
+    ix->unranked += 1;
+  }
+  ix->row_of.emplace(key, r);
+  ix->ids.push_back(std::move(key));
+  return r;
+}
+
+// Recomputes id_rank (position of each row's id in bytewise order) if stale
+// and makes the device copy current.
+int index_sync_ranks(Shard *ix, bool force_upload) {
+  if (!ix->ranks_clean) {
+    // Rows that kept a rank from before are still in the right relative order
+    // (ranks only need to be order-isomorphic to the ids): sort them by rank
+    // (integers), sort only the unranked newcomers by id (strings), and merge.
+    const std::vector<std::string> &ids = ix->ids;
+    const std::vector<uint32_t> &rk = ix->rank_host;
+    std::vector<uint32_t> ranked, fresh;
+    uint32_t maxr = 0;
+    size_t nranked = 0;
+    for (uint32_t i = 0; i < ix->n; ++i)
+      if (rk[i] != kUnranked) {
+        maxr = std::max(maxr, rk[i]);
+        ++nranked;
+      }
+    if (nranked && (uint64_t)maxr < 4ull * ix->n + 1024) {
+      // ranks are unique: a bucket pass puts the ranked rows in rank (= id) order without sorting
+      std::vector<uint32_t> slot((size_t)maxr + 1, kUnranked);
+      for (uint32_t i = 0; i < ix->n; ++i)
+        if (rk[i] != kUnranked) slot[rk[i]] = i;
+      ranked.reserve(nranked);
+      for (uint32_t v : slot)
+        if (v != kUnranked) ranked.push_back(v);
+      for (uint32_t i = 0; i < ix->n; ++i)
+        if (rk[i] == kUnranked) fresh.push_back(i);
+    } else {
+      ranked.reserve(ix->n);
+      for (uint32_t i = 0; i < ix->n; ++i) (rk[i] == kUnranked ? fresh : ranked).push_back(i);
+      parallel_sort(ranked, [&rk](uint32_t a, uint32_t b) { return rk[a] < rk[b]; });
+    }
+    parallel_sort(fresh, [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+    std::vector<uint32_t> order(ix->n);
+    if (fresh.size() < ranked.size() / 16) {
+      // few newcomers: each finds its place among the ranked rows by binary search (string
+      // compares only there), the merge itself moves integers
+      std::vector<uint32_t> pos(fresh.size());
+      parallel_for(fresh.size(), [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i)
+          pos[i] = (uint32_t)(std::lower_bound(ranked.begin(), ranked.end(), fresh[i],
+                                               [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; }) - ranked.begin());
+      });
+      size_t o = 0, f = 0;
+      for (size_t r = 0; r <= ranked.size(); ++r) {
+        while (f < fresh.size() && pos[f] == r) order[o++] = fresh[f++];
+        if (r < ranked.size()) order[o++] = ranked[r];
+      }
+    } else {
+      parallel_merge(ranked, fresh, order, [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+    }
+    ix->rank_host.resize(ix->n);
+    parallel_for(ix->n, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) ix->rank_host[order[i]] = (uint32_t)i;
+    });
+    if (ix->n) {
+      ix->max_id = ids[order[ix->n - 1]];
+      ix->max_rank = ix->n - 1;
+    }
+    ix->ranks_clean = true;
+    ix->unranked = 0;
+    force_upload = true;
+  }
+  if (force_upload) {
+    ix->rank_dirty.clear();
+    ix->rank_dirty_all = false;
+  }
+  if (force_upload && ix->n) {
+    VT_TRY(ix->dRank.ensure(std::max<size_t>(ix->cap, ix->n)));
+    VT_HIP(hipMemcpyAsync(ix->dRank.p, ix->rank_host.data(), (size_t)ix->n * sizeof(uint32_t), hipMemcpyHostToDevice,
+                          ix->ctx.stream));
+    VT_HIP(hipStreamSynchronize(ix->ctx.stream));
+  }
+  return VT_OK;
+}
+
+// Brings the device rank column in line with rank_host WITHOUT re-ranking: newcomers keep
+// kUnranked (all equal), which is enough for a search whose k-th and (k+1)-th hits differ in
+// their f32 rank (search_locked checks exactly that and orders equal ranks by id bytes on
+// the host).  An unsorted insert therefore costs the next search a few bytes, not an O(n)
+// merge and a column upload.
+int index_lazy_ranks(Shard *ix) {
+  Ctx &c = ix->ctx;
+  if (ix->n == 0) return VT_OK;
+  if (ix->dRank.count < std::max<size_t>(ix->cap, ix->n)) {
+    VT_TRY(ix->dRank.ensure(std::max<size_t>(ix->cap, ix->n)));
+    ix->rank_dirty_all = true;
+  }
+  if (ix->rank_dirty_all) {
+    VT_HIP(hipMemcpyAsync(ix->dRank.p, ix->rank_host.data(), (size_t)ix->n * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+  } else if (!ix->rank_dirty.empty()) {
+    const size_t m = ix->rank_dirty.size();
+    VT_TRY(c.hRankPairs.ensure(2 * m));
+    VT_TRY(c.dRankPairs.ensure(2 * m));
+    size_t live = 0;
+    for (uint32_t r : ix->rank_dirty) {
+      if (r >= ix->n) continue;  // deleted since
+      c.hRankPairs.p[2 * live] = r;
+      c.hRankPairs.p[2 * live + 1] = ix->rank_host[r];
+      ++live;
+    }
+    if (live) {
+      VT_HIP(hipMemcpyAsync(c.dRankPairs.p, c.hRankPairs.p, 2 * live * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+      VT_HIP(vt::launch_scatter_u32(c.dRankPairs.p, (uint32_t)live, ix->dRank.p, c.stream));
+    }
+  }
+  ix->rank_dirty.clear();
+  ix->rank_dirty_all = false;
+  return VT_OK;
+}
+
+// Device a pointer lives on (-1: not device memory we can tell).
+int device_of_pointer(const void *p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return attr.device;
+}
+
+struct RowSource {
+  const float *host = nullptr;    // host rows (ragged or dense)
+  const size_t *off = nullptr;    // ragged offsets; null => dense with `d`
+  const float *device = nullptr;  // dense device matrix [count][d]
+  size_t d = 0;
+  const uint32_t *pick = nullptr;  // optional: row i of this batch is row pick[i] of the source
+};
+
+constexpr size_t kMaxDerivedDirty = 65536;  // more mutated rows than this: rebuild instead of patching
+
+// Row `r` changed: its sign bits and norm are stale.
+inline void index_touch_row(Shard *ix, uint32_t r) {
+  if (ix->bits_valid) {
+    ix->bits_dirty.push_back(r);
+    if (ix->bits_dirty.size() > kMaxDerivedDirty) {
+      ix->bits_valid = false;
+      ix->bits_dirty.clear();
+    }
+  }
+  if (ix->max_sqnorm >= 0.0) {
+    ix->norm_dirty.push_back(r);
+    if (ix->norm_dirty.size() > kMaxDerivedDirty) {
+      ix->max_sqnorm = -1.0;
+      ix->norm_dirty.clear();
+    }
+  }
+}
+
+// Uploads a row list (rows still < n) for the patch kernels; returns its length.
+int upload_row_list(Shard *ix, std::vector<uint32_t> &list, uint32_t *count) {
+  Ctx &c = ix->ctx;
+  std::sort(list.begin(), list.end());
+  list.erase(std::unique(list.begin(), list.end()), list.end());
+  while (!list.empty() && list.back() >= ix->n) list.pop_back();
+  *count = (uint32_t)list.size();
+  if (list.empty()) return VT_OK;
+  VT_TRY(c.hRankPairs.ensure(list.size()));
+  VT_TRY(c.dRankPairs.ensure(list.size()));
+  std::memcpy(c.hRankPairs.p, list.data(), list.size() * sizeof(uint32_t));
+  VT_HIP(hipMemcpyAsync(c.dRankPairs.p, c.hRankPairs.p, list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+  return VT_OK;
+}
+
+// Shared body of insert / insert_many / load_matrix: rows are already validated.
+// `*began` is set once the index has started to change: a failure after that point
+// leaves it inconsistent (the caller poisons the handle).
+int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_off, const RowSource &src, bool *began) {
+  if (count == 0) return VT_OK;
+  Ctx &c = ix->ctx;
+  const size_t d = (size_t)ix->dim;
+  if ((uint64_t)ix->n + count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
+  VT_TRY(index_reserve(ix, ix->n + (uint32_t)count));
+  const uint32_t n_before = ix->n;
+  std::vector<uint32_t> target(count);
+  bool all_appended_in_order = true;
+  if (count > 1024) {
+    // bulk load: no rehash / regrowth inside the id loop -- but geometric, or a corpus that arrives
+    // in many appends re-hashes and re-copies its whole id table at every one of them (84 M ids: 15 s)
+    const size_t need = (size_t)ix->n + count;
+    if ((double)need > (double)ix->row_of.bucket_count() * ix->row_of.max_load_factor())
+      ix->row_of.reserve(std::max(need, 2 * ix->row_of.size()));
+    if (need > ix->ids.capacity()) ix->ids.reserve(std::max(need, 2 * ix->ids.capacity()));
+    if (need > ix->rank_host.capacity()) ix->rank_host.reserve(std::max(need, 2 * ix->rank_host.capacity()));
+  }
+  *began = true;
+  for (size_t i = 0; i < count; ++i) {
+    bool is_new = false;
+    target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new);
+    if (!is_new || target[i] != n_before + i) all_appended_in_order = false;
+  }
+  // (test hook: a device failure between the id table's change and the rows' arrival, the one
+  // window in which a mutation cannot be taken back -- tests/test_gpu_multishard.py checks that
+  // the handle is poisoned from then on)
+  if (std::getenv("VT_TEST_FAIL_AFTER_ID_UPDATE")) return fail(VT_ERR_DEVICE, "injected failure after the id table changed");
+  if (count > kMaxDerivedDirty) {
+    ix->bits_valid = false;
+    ix->max_sqnorm = -1.0;
+    ix->bits_dirty.clear();
+    ix->norm_dirty.clear();
+  } else {
+    for (size_t i = 0; i < count; ++i) index_touch_row(ix, target[i]);
+  }
+  const uint32_t ld = ix->ld;
+  bool pending = false;
+  if (src.device) {
+    bool picks_dense = true;  // the batch is one contiguous block of the source
+    if (src.pick)
+      for (size_t i = 1; i < count && picks_dense; ++i) picks_dense = src.pick[i] == src.pick[0] + i;
+    const float *first = src.device + (src.pick ? (size_t)src.pick[0] * d : 0);
+    // (test hook: a one-GPU box has no other device to own the rows)
+    const bool foreign = device_of_pointer(src.device) != c.device || std::getenv("VT_TEST_FOREIGN_ROWS") != nullptr;
+    if (foreign && ix->slab.mapped) {
+      // Rows that live on another device of the node, bound for a mapped slab: only this device
+      // has been given access to the slab's chunks (hipMemSetAccess), so a peer copy must not
+      // target it.  The rows cross into an ordinary buffer here first (blocks of <= 256 MB), and
+      // are placed from there by local copies.
+      const size_t block_rows = std::max<size_t>(1, ((size_t)256 << 20) / (d * sizeof(float)));
+      DevBuf<float> stage;
+      VT_TRY(stage.ensure(std::min(count, block_rows) * d));
+      size_t i = 0;
+      while (i < count) {
+        // a run of consecutive source rows, at most one block long
+        size_t e = i + 1;
+        const size_t p0 = src.pick ? src.pick[i] : i;
+        while (e < count && e - i < block_rows && (src.pick ? src.pick[e] : e) == p0 + (e - i)) ++e;
+        VT_HIP(hipMemcpyAsync(stage.p, src.device + p0 * d, (e - i) * d * sizeof(float), hipMemcpyDefault, c.stream));
+        for (size_t j = i; j < e;) {  // ... placed in runs of consecutive slab rows
+          size_t r = j + 1;
+          while (r < e && target[r] == target[j] + (uint32_t)(r - j)) ++r;
+          float *dst = ix->dX + (size_t)target[j] * ld;
+          if (ld == d) VT_HIP(hipMemcpyAsync(dst, stage.p + (j - i) * d, (r - j) * d * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+          else VT_HIP(vt::launch_pad_rows(stage.p + (j - i) * d, (uint32_t)(r - j), (uint32_t)d, dst, ld, c.stream));
+          j = r;
+        }
+        VT_HIP(hipStreamSynchronize(c.stream));  // the block is reused
+        i = e;
+      }
+    } else if (all_appended_in_order && picks_dense) {
+      // (hipMemcpyDefault: the source may live on another device of the node)
+      float *dst = ix->dX + (size_t)n_before * ld;
+      if (ld == d) VT_HIP(hipMemcpyAsync(dst, first, count * d * sizeof(float), hipMemcpyDefault, c.stream));
+      else VT_HIP(vt::launch_pad_rows(first, (uint32_t)count, (uint32_t)d, dst, ld, c.stream));
+    } else if (count < 64 || foreign) {
+      // (few rows, or rows that live on another device: plain copies, which need no peer mapping)
+      for (size_t i = 0; i < count; ++i) {
+        float *dst = ix->dX + (size_t)target[i] * ld;
+        const size_t p = src.pick ? src.pick[i] : i;
+        VT_HIP(hipMemsetAsync(dst, 0, (size_t)ld * sizeof(float), c.stream));
+        VT_HIP(hipMemcpyAsync(dst, src.device + p * d, d * sizeof(float), hipMemcpyDefault, c.stream));
+      }
+    } else {
+      // scattered rows (upserts, or a batch dealt to shards by the hash of its ids): one gather
+      // launch over a (source row, slab row) map instead of a copy per row.  Duplicate ids of a
+      // batch map to one slab row: only the LAST occurrence is kept in the map (flat.rs:270-281).
+      std::vector<uint32_t> map;
+      map.reserve(2 * count);
+      std::unordered_map<uint32_t, size_t> last;
+      for (size_t i = 0; i < count; ++i) last[target[i]] = i;
+      for (size_t i = 0; i < count; ++i) {
+        if (last[target[i]] != i) continue;
+        map.push_back((uint32_t)(src.pick ? src.pick[i] : i));
+        map.push_back(target[i]);
+      }
+      DevBuf<uint32_t> dMap;
+      VT_TRY(dMap.ensure(map.size()));
+      VT_HIP(hipMemcpyAsync(dMap.p, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+      VT_HIP(vt::launch_gather_rows(src.device, (uint32_t)d, dMap.p, (uint32_t)(map.size() / 2), ix->dX, ld, c.stream));
+      VT_HIP(hipStreamSynchronize(c.stream));  // (map and dMap die with this scope)
+    }
+    VT_HIP(hipStreamSynchronize(c.stream));
+  } else {
+    // two pinned staging halves: host threads fill one (rows padded to ld) while the DMA
+    // of the other is in flight; runs of consecutive target rows go in one copy
+    const size_t row_bytes = (size_t)ld * sizeof(float);
+    const size_t stage_rows = std::max<size_t>(1, std::min<size_t>(count, (256u << 20) / row_bytes));
+    VT_TRY(c.hStage.ensure(2 * stage_rows * row_bytes));
+    hipEvent_t done[2] = {c.ev2, c.ev3};
+    bool used[2] = {false, false};
+    size_t i = 0;
+    for (int half = 0; i < count; half ^= 1) {
+      float *stage = reinterpret_cast<float *>(c.hStage.p) + (size_t)half * stage_rows * ld;
+      const size_t chunk = std::min(stage_rows, count - i);
+      if (used[half]) VT_HIP(hipEventSynchronize(done[half]));  // its previous copies have left the buffer
+      parallel_for(chunk, 2048, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+          const size_t p = src.pick ? src.pick[i + j] : i + j;
+          const float *row = src.off ? src.host + src.off[p] : src.host + p * src.d;
+          float *dst = stage + j * ld;
+          std::memcpy(dst, row, d * sizeof(float));
+          for (size_t t = d; t < ld; ++t) dst[t] = 0.0f;
+        }
+      });
+      size_t j = 0;
+      while (j < chunk) {
+        size_t e = j + 1;
+        while (e < chunk && target[i + e] == target[i + e - 1] + 1) ++e;
+        VT_HIP(hipMemcpyAsync(ix->dX + (size_t)target[i + j] * ld, stage + j * ld, (e - j) * row_bytes,
+                              hipMemcpyHostToDevice, c.stream));
+        j = e;
+      }
+      VT_HIP(hipEventRecord(done[half], c.stream));
+      used[half] = true;
+      i += chunk;
+    }
+    pending = true;  // one wait at the end of the function covers the rows and their ranks
+  }
+  // A bulk load ranks its ids right away (the load itself takes far longer) -- unless it is a
+  // small part of what is already there: re-ranking costs a pass over ALL ids, and a corpus that
+  // arrives in many appends would pay it every time (84 M rows in 21 appends: 14 s each); the
+  // next search does it once.  Trickling inserts leave their rows unranked for the lazy search path.
+  const bool rank_now = !ix->ranks_clean && count >= kBulkRankRows && count >= (size_t)n_before / 4;
+  if (!ix->ranks_clean && !rank_now) {
+    // the device column is brought up to date lazily (index_lazy_ranks) or by the next re-rank
+    if (count < kBulkRankRows)
+      for (uint32_t r = n_before; r < ix->n; ++r) ix->rank_dirty.push_back(r);
+    else
+      ix->rank_dirty_all = true;
+    if (ix->rank_dirty.size() > kMaxDirtyRanks) ix->rank_dirty_all = true;
+  }
+  // keep device ranks current when they stayed valid (sorted appends)
+  if (ix->ranks_clean && ix->n > n_before) {
+    uint32_t from = n_before;
+    if (ix->dRank.count < ix->cap) {
+      VT_TRY(ix->dRank.ensure(ix->cap));
+      from = 0;
+    }
+    VT_HIP(hipMemcpyAsync(ix->dRank.p + from, ix->rank_host.data() + from, (size_t)(ix->n - from) * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, c.stream));
+    pending = true;
+  }
+  if (pending) VT_HIP(hipStreamSynchronize(c.stream));
+  if (rank_now) VT_TRY(index_sync_ranks(ix, false));
+  return VT_OK;
+}
+
+int make_hits(const Shard *ix, const std::vector<vt::Entry> &entries, vt_hits **out) {
+  auto h = std::make_unique<vt_hits>();
+  h->ids.reserve(entries.size());
+  for (const auto &e : entries) {
+    h->ids.push_back(ix->ids[e.row]);
+    h->raw.push_back(e.raw);
+    h->rank_key.push_back(rank_key_of(e.key));
+  }
+  *out = h.release();
+  return VT_OK;
+}
+
+int empty_hits(vt_hits **out) {
+  *out = new vt_hits();
+  return VT_OK;
+}
+
+}  // namespace

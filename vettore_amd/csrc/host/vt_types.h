@@ -1,0 +1,413 @@
+// vt_types.h -- per-reader context (Ctx), a shard, its worker thread, the RCCL entry points and the handle (vt_flat).
+// Part of vt_index.cpp's translation unit (included there, in this order, exactly once): the host
+// side is one TU on purpose -- everything below the C ABI lives in an anonymous namespace.
+#pragma once
+
+namespace {
+
+// Per-device execution context: stream, scratch, profiling.
+struct Ctx {
+  int device = 0;
+  int num_cus = 256;
+  int blocks_per_cu = 2;
+  int hamming_blocks_per_cu = 2;
+  hipStream_t stream = nullptr;
+  DevBuf<float> dQ;
+  uint64_t *dQbits = nullptr;  // the query's sign bits, behind the query in dQ (upload_query with_bits)
+  DevBuf<uint64_t> dPartKeys;
+  DevBuf<vt::Payload> dPartPay;
+  DevBuf<uint64_t> dSelKeys;  // second level of the two-level select: kSelGroups * kMaxFusedK entries
+  DevBuf<vt::Payload> dSelPay;
+  DevBuf<int> dStatus;  // "metric overflow" flag: set by scan kernels, moved out and cleared by the select kernel
+  DevBuf<int> dFlag;    // scratch flag of the ingest kernels
+  DevBuf<ResultBlock> dStage;  // stage-1 winners of quantized_search, consumed on the device
+  // K4h: distance column, two alternating histograms, list counter
+  DevBuf<uint16_t> dDist16;
+  DevBuf<uint64_t> dListKeys;  // candidate set of > 256 rows kept on the device
+  DevBuf<uint32_t> dRankPairs;  // (row, rank) updates of the lazy rank path
+  PinnedBuf<uint32_t> hRankPairs;
+  DevBuf<uint64_t> dKeyCol;    // one key per row (limits above kMaxFusedK: radix threshold instead of wave buffers)
+  DevBuf<vt::Payload> dPayCol; // (row, raw) per row beside the key column (limits above kSelListMax)
+  PinnedBuf<uint64_t> hListKeys;
+  PinnedBuf<vt::Payload> hListPay;
+  DevBuf<uint32_t> dRadixHist, dRadixCount;
+  DevBuf<vt::Payload> dListPay;
+  DevBuf<uint32_t> dHamHist, dHamCount;
+  uint32_t ham_parity = 0;
+  bool ham_ready = false, ham_dirty = false;
+  // batched search (K2)
+  DevBuf<float> dBQ, dBTau, dBSample;
+  DevBuf<vt::BatchCand> dBCand;
+  DevBuf<uint32_t> dBCount, dBOutCount;
+  DevBuf<vt::Entry> dBOut;
+  DevBuf<unsigned long long> dBNorm;
+  PinnedBuf<float> hBQ, hBTau;
+  PinnedBuf<uint32_t> hBCount, hBOutCount;
+  PinnedBuf<vt::Entry> hBOut;
+  hipEvent_t ev2 = nullptr, ev3 = nullptr;
+  DevBuf<uint32_t> dRows;
+  DevBuf<uint64_t> dCandKeys;
+  DevBuf<vt::Payload> dCandPay;
+  PinnedBuf<float> hQ;
+  PinnedBuf<ResultBlock> hRes;  // written by the select kernel through the host mapping
+  PinnedBuf<ResultBlock> hFirst;  // a staged search's first-stage block, copied out for a cross-shard merge
+  // limits above kMaxFusedK: up to kSelListMax sorted entries + header, host-mapped, allocated on first use
+  PinnedBuf<unsigned char> hBig;
+  unsigned char *dBigMapped = nullptr;
+  ResultBlock *dResMapped = nullptr;
+  PinnedBuf<uint32_t> hShard;  // shard of each winner of a cross-shard merge (host mapped)
+  uint32_t *dShardMapped = nullptr;
+  PinnedBuf<unsigned char> hStage;
+  uint32_t begin_rows = 0, begin_dim = 0;  // scan of the last vt_flat_search_begin (profiling)
+  bool profiling = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  vt_profile prof{};
+
+  ~Ctx() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (ev2) (void)hipEventDestroy(ev2);
+    if (ev3) (void)hipEventDestroy(ev3);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  int init(int dev) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      return fail(VT_ERR_DEVICE, "no HIP device visible: libvettore_hip has no CPU fallback");
+    if (dev < 0 || dev >= ndev) return fail(VT_ERR_DEVICE, "device ordinal out of range");
+    device = dev;
+    VT_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    VT_HIP(hipGetDeviceProperties(&prop, dev));
+    num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = std::getenv("VT_HAMMING_BLOCKS_PER_CU")) {
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 8) hamming_blocks_per_cu = v;
+    }
+    if (const char *e = std::getenv("VT_BLOCKS_PER_CU")) {
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 8) blocks_per_cu = v;
+    }
+    VT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    VT_HIP(hipEventCreate(&ev0));
+    VT_HIP(hipEventCreate(&ev1));
+    VT_HIP(hipEventCreate(&ev2));
+    VT_HIP(hipEventCreate(&ev3));
+    VT_TRY(dStatus.ensure(1));
+    VT_TRY(dFlag.ensure(1));
+    VT_TRY(dSelKeys.ensure((size_t)vt::kSelGroups * vt::kMaxFusedK));
+    VT_TRY(dSelPay.ensure((size_t)vt::kSelGroups * vt::kMaxFusedK));
+    VT_HIP(hipMemset(dStatus.p, 0, sizeof(int)));
+    VT_TRY(hRes.ensure(1));
+    VT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dResMapped), hRes.p, 0));
+    VT_TRY(hShard.ensure(vt::kMaxFusedK));
+    VT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dShardMapped), hShard.p, 0));
+    return VT_OK;
+  }
+  int bind() {
+    VT_HIP(hipSetDevice(device));
+    return VT_OK;
+  }
+  uint32_t resident_waves() const { return (uint32_t)(num_cus * blocks_per_cu * vt::kWavesPerBlock); }
+  // a prefix scan timed with ev0/ev1 but not yet read back (the chained funnel waits once, at its end)
+  uint32_t prefix_pending = 0;
+  int settle_prefix_profile() {
+    if (!prefix_pending) return VT_OK;
+    float ms = 0.0f;
+    VT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+    prof.prefix_launches += 1;
+    prof.prefix_ms += ms;
+    prefix_pending = 0;
+    return VT_OK;
+  }
+  // Tiles are dealt to waves statically, so the grid must be fully resident:
+  // blocks per CU = what LDS admits, capped (VT_BLOCKS_PER_CU overrides).
+  uint32_t grid_for(uint32_t units, size_t lds_bytes, int max_per_cu = 0) const {
+    size_t per_cu = lds_bytes ? (160 * 1024) / lds_bytes : 8;
+    per_cu = std::max<size_t>(1, std::min<size_t>(per_cu, (size_t)(max_per_cu > 0 ? max_per_cu : blocks_per_cu)));
+    const uint32_t want = (units + vt::kWavesPerBlock - 1) / vt::kWavesPerBlock;
+    return std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)(num_cus * per_cu)));
+  }
+};
+
+}  // namespace
+
+struct vt_hits {
+  std::vector<std::string> ids;
+  std::vector<float> raw;
+  std::vector<uint32_t> rank_key;
+};
+
+// One shard = one GPU's share of the rows: the slab, its derived columns, the ids of
+// its rows.  A plain index has exactly one; vt_flat_new_sharded deals rows to several.
+struct Shard {
+  Ctx ctx;  // primary context: mutations and derived-data upkeep run here, under the exclusive lock
+  // Further contexts (own stream, scratch, result block) so that several readers can be
+  // in flight on one handle (the reference's RwLock readers, nifs.rs:304-308); created
+  // on demand, handed out by CtxLease.
+  std::mutex pool_mu;
+  std::condition_variable pool_cv;
+  std::vector<std::unique_ptr<Ctx>> extra;
+  std::vector<Ctx *> free_ctx;
+  bool ctx0_busy = false;
+  int metric = 0;
+  int order = g_default_order;
+  // corpus
+  uint32_t n = 0, cap = 0;
+  long dim = -1;    // FlatIndex.dimension (None = -1)
+  uint32_t ld = 0;  // row stride of the slab in floats = padded_dim(dim), multiple of 64
+  Slab slab;
+  float *dX = nullptr;  // == slab.p
+  DevBuf<uint32_t> dRank;
+  DevBuf<uint64_t> dBits;
+  bool bits_valid = false;
+  // Rows mutated since the bit matrix / the norms were last brought up to date; patched in
+  // place at the next use (a full rebuild is a pass over the whole corpus).
+  std::vector<uint32_t> bits_dirty, norm_dirty;
+  double max_sqnorm = -1.0;  // max_i sum_j x_ij^2, < 0 = stale (error margin of the batched path)
+  DevBuf<float> dXnorm2;     // per-row squared norms, valid with max_sqnorm
+  // ids
+  std::vector<std::string> ids;  // by row
+  std::unordered_map<std::string, uint32_t> row_of;
+  std::vector<uint32_t> rank_host;  // by row
+  bool ranks_clean = true;          // rank_host/dRank describe the current rows
+  // While !ranks_clean: rows whose device rank differs from rank_host (newcomers carry
+  // kUnranked, a swap-delete moved a rank); rank_dirty_all = re-upload the whole column.
+  std::vector<uint32_t> rank_dirty;
+  bool rank_dirty_all = false;
+  size_t unranked = 0;  // rows carrying kUnranked: past a bound the next search rebuilds instead of going lazy
+  bool external_ranks = false;      // rank column supplied by vt_flat_set_id_ranks (valid until the next mutation)
+  uint64_t epoch = 0;               // bumped by every mutation of the row set (insert of a new id, delete)
+  uint64_t external_epoch = 0;      // epoch at which the external ranks were installed
+  bool external_expected = false;   // vt_flat_set_id_ranks has been used on this shard: search_begin insists on current ranks
+  std::string max_id;               // upper bound of all ids while ranks_clean
+  uint32_t max_rank = 0;
+
+  ~Shard() {
+    (void)hipSetDevice(ctx.device);
+    slab.release();
+  }
+
+  template <class F>
+  void for_each_ctx(F f) {
+    f(ctx);
+    for (auto &e : extra) f(*e);
+  }
+};
+
+namespace {
+
+constexpr size_t kMaxContexts = 8;  // readers in flight per shard
+
+// A context for one reader: the primary one if free, else a spare, else a new one (up to
+// kMaxContexts), else wait.  Held only under the handle's shared lock.
+struct CtxLease {
+  Shard *ix;
+  Ctx *c = nullptr;
+  int status = VT_OK;
+  explicit CtxLease(Shard *s) : ix(s) {
+    std::unique_lock<std::mutex> g(ix->pool_mu);
+    for (;;) {
+      if (!ix->ctx0_busy) {
+        ix->ctx0_busy = true;
+        c = &ix->ctx;
+        return;
+      }
+      if (!ix->free_ctx.empty()) {
+        c = ix->free_ctx.back();
+        ix->free_ctx.pop_back();
+        return;
+      }
+      if (ix->extra.size() + 1 < kMaxContexts) {
+        auto nc = std::make_unique<Ctx>();
+        status = nc->init(ix->ctx.device);
+        if (status != VT_OK) return;
+        nc->profiling = ix->ctx.profiling;
+        c = nc.get();
+        ix->extra.push_back(std::move(nc));
+        return;
+      }
+      ix->pool_cv.wait(g);
+    }
+  }
+  ~CtxLease() {
+    if (!c) return;
+    {
+      std::lock_guard<std::mutex> g(ix->pool_mu);
+      if (c == &ix->ctx) ix->ctx0_busy = false;
+      else ix->free_ctx.push_back(c);
+    }
+    ix->pool_cv.notify_one();
+  }
+  CtxLease(const CtxLease &) = delete;
+  CtxLease &operator=(const CtxLease &) = delete;
+};
+
+// ---- RCCL, loaded on first use (librccl is half a gigabyte: a single-GPU index never maps it)
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+  bool ok = false;
+};
+
+Rccl &rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+      r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) {
+      r.error = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?");
+      return;
+    }
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    r.ok = r.CommInitAll && r.CommDestroy && r.CommCount && r.AllGather && r.GetErrorString;
+    if (!r.ok) r.error = "librccl lacks an expected symbol";
+  });
+  return r;
+}
+
+// One thread per shard of a multi-shard index, bound to the shard's device: the caller
+// posts the same job to all of them, so the launch overheads of the shards overlap and
+// each shard's kernels are issued by a thread whose current device never changes.
+struct Worker {
+  struct Job {
+    std::function<int()> fn;
+    int status = VT_OK;
+    std::string error;
+    bool done = false;
+  };
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv, done_cv;
+  std::deque<Job *> queue;
+  bool stop = false;
+  int device = 0;
+
+  void start(int dev) {
+    device = dev;
+    th = std::thread([this] { loop(); });
+  }
+  void loop() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      Job *job = nullptr;
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [this] { return stop || !queue.empty(); });
+        if (queue.empty()) return;  // stop
+        job = queue.front();
+        queue.pop_front();
+      }
+      g_last_error.clear();
+      const int st = guarded(job->fn);
+      {
+        std::lock_guard<std::mutex> g(mu);
+        job->status = st;
+        if (st != VT_OK) job->error = g_last_error;
+        job->done = true;
+      }
+      done_cv.notify_all();
+    }
+  }
+  void post(Job *job) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      queue.push_back(job);
+    }
+    cv.notify_one();
+  }
+  void wait(Job *job) {
+    std::unique_lock<std::mutex> g(mu);
+    done_cv.wait(g, [job] { return job->done; });
+  }
+  ~Worker() {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      stop = true;
+    }
+    cv.notify_one();
+    if (th.joinable()) th.join();
+  }
+};
+
+}  // namespace
+
+// The handle behind the C ABI: FlatResource(RwLock<FlatIndex>) (flat.rs:13-17, nifs.rs:254-257).
+struct vt_flat {
+  // searches share, mutations exclude (nifs.rs:266-309)
+  mutable std::shared_mutex rw;
+  // A mutation that failed on the device after it had begun changing the index leaves it
+  // poisoned, like a panic under the reference's write lock: every later call fails with
+  // "flat lock poisoned" (nifs.rs:269).
+  bool poisoned = false;
+  int metric = 0;
+  long dim = -1;  // FlatIndex.dimension across all shards
+  std::vector<std::unique_ptr<Shard>> shards;
+  // multi-shard only
+  std::vector<std::unique_ptr<Worker>> workers;
+  std::mutex post_mu;  // jobs reach every worker's queue in one order (collectives must match up)
+  int exchange = VT_EXCHANGE_HOST;
+  bool exchange_forced = false;
+  std::vector<ncclComm_t> comms;
+  bool comms_tried = false;
+  size_t exch_limit = 0;  // entries the exchange blocks are sized for
+  std::vector<void *> dBlock, dGather;  // per shard: its own result block, the gathered blocks of all shards
+  PinnedBuf<unsigned char> hGather;     // shard 0's gathered copy, read by the merging host thread
+  vt_profile xprof{};                   // exchange timing (merge_launches / merge_ms)
+
+  // Searches that arrive while another one is running wait for it and then go TOGETHER: one
+  // sweep of the corpus answers up to eight of them (K1m), the matrix-core pass up to 256 (K2),
+  // where the same callers on their own streams would read the whole corpus once each.  See
+  // coalesced_search.
+  struct Waiting {
+    const float *query;
+    size_t n, limit;
+    vt_hits **out;
+    int status = VT_OK;
+    std::string error;
+    enum { QUEUED, LEADS, ALONE, DONE } state = QUEUED;
+    std::condition_variable wake;  // its own: a finished batch wakes exactly its members and the next leader
+    Waiting(const float *q, size_t n_, size_t limit_, vt_hits **out_) : query(q), n(n_), limit(limit_), out(out_) {}
+  };
+  struct Coalescer {
+    std::mutex mu;
+    std::condition_variable gather;  // a leader waiting a moment for the callers it expects back
+    std::deque<Waiting *> waiting;
+    unsigned active = 0;        // searches / batches running
+    size_t last_batch = 1;      // members of the last batch that ran
+    double last_seconds = 0.0;  // what it took
+    uint64_t batches = 0, batched_queries = 0;
+  } co;
+  std::atomic<uint64_t> approx_bytes{0};  // rows x row stride, refreshed by mutations (the coalescer's only use of it is a size class)
+
+  bool multi() const { return shards.size() > 1 || !workers.empty(); }
+  size_t total() const {
+    size_t t = 0;
+    for (auto &s : shards) t += s->n;
+    return t;
+  }
+  ~vt_flat() {
+    workers.clear();  // joins the threads before their shards go away
+    for (size_t i = 0; i < comms.size(); ++i)
+      if (comms[i]) (void)rccl().CommDestroy(comms[i]);
+    for (size_t i = 0; i < dBlock.size(); ++i) {
+      (void)hipSetDevice(shards[i]->ctx.device);
+      if (dBlock[i]) (void)hipFree(dBlock[i]);
+      if (dGather[i]) (void)hipFree(dGather[i]);
+    }
+  }
+};

@@ -47,7 +47,7 @@ class FlatRef:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _lib is not None:   # (module globals are None while the interpreter shuts down)
             _lib.load().vt_flat_free(h)
 
     @property
