@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 stats() {  # name, bench args...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o p -- python3 $R/bench.py "$@" > $OUT/$name.log 2>&1
-  tail -1 $OUT/$name.log > $OUT/$name.json
+  grep -a "^{\"" $OUT/$name.log | tail -1 > $OUT/$name.json   # (rocprofv3 prints its own lines after the program's last)
 }
 pmc() {  # name, counter, bench args...
   local name=$1 ctr=$2; shift 2

@@ -12,8 +12,8 @@ namespace {
 // first then leads everything that has queued up with its limit as ONE batch -- the batch path
 // gives every query the hits its own search would get, bit for bit -- and the others wake up
 // with their lists.  An idle handle adds nothing: the first caller runs at once, alone.  Small
-// corpora (latency-bound, not bandwidth-bound) keep two operations in flight.  What would force
-// work a lone search avoids (a strict re-rank after unsorted inserts) is not batched: those
+// corpora (latency-bound, not bandwidth-bound) keep more than one operation in flight
+// (coalesce_slots).  What would force work a lone search avoids (a strict re-rank after unsorted inserts) is not batched: those
 // callers are released to search side by side as before.  `VT_COALESCE=0` switches it off.
 constexpr size_t kCoalesceMax = 256;
 // Operations in flight before callers start to queue: a pass over a large corpus owns the
