@@ -155,6 +155,18 @@ struct WaveTopK {
     n += __popcll(m);
   }
 
+  // Offers the `cnt` entries of another wave's (compacted) buffer: keys at `ok`, payload at ok + CAP.
+  __device__ __forceinline__ void absorb(const uint64_t *ok, uint32_t cnt, int lane) {
+    const uint64_t *op = ok + CAP;
+    for (uint32_t base = 0; base < cnt; base += kWave) {
+      const uint32_t i = base + lane;
+      const bool valid = i < cnt;
+      const uint64_t ck = valid ? ok[i] : kEmptyKey;
+      const uint64_t cp = valid ? op[i] : 0ull;
+      offer(valid, ck, (uint32_t)cp, __uint_as_float((uint32_t)(cp >> 32)), lane);
+    }
+  }
+
   // Block-level merge at the end of a kernel: every wave compacts, wave 0 then
   // absorbs the other waves' buffers (`wave_bytes` apart in LDS) and is the only
   // one left holding a list.  Must be called by all waves of the block.
@@ -162,20 +174,8 @@ struct WaveTopK {
     compact(lane);
     if (lane == 0) s_counts[wib] = n;
     __syncthreads();
-    if (wib == 0) {
-      for (int w = 1; w < nwaves; ++w) {
-        const uint64_t *ok = bk + (size_t)w * 2 * CAP;  // wave w's keys (its payload follows at + CAP)
-        const uint64_t *op = ok + CAP;
-        const uint32_t cnt = s_counts[w];
-        for (uint32_t base = 0; base < cnt; base += kWave) {
-          const uint32_t i = base + lane;
-          const bool valid = i < cnt;
-          const uint64_t ck = valid ? ok[i] : kEmptyKey;
-          const uint64_t cp = valid ? op[i] : 0ull;
-          offer(valid, ck, (uint32_t)cp, __uint_as_float((uint32_t)(cp >> 32)), lane);
-        }
-      }
-    }
+    if (wib == 0)
+      for (int w = 1; w < nwaves; ++w) absorb(bk + (size_t)w * 2 * CAP, s_counts[w], lane);  // wave w's keys (its payload follows at + CAP)
   }
 
   // Writes the k best (unsorted) to keys/pay[0..k), padding with kEmptyKey.
