@@ -784,17 +784,58 @@ __global__ __launch_bounds__(64) void cosine_rerank_kernel(const CosineRerankArg
   if (lane < 3) {
     const float *A = lane == 1 ? xs : qs;  // lane 0: q.q   lane 1: x.x   lane 2: q.x
     const float *B = lane == 0 ? qs : xs;
-    // fma(x, y, acc) == acc + x*y here (the product of two f32 is exact in f64); the
-    // loop is unrolled so that the LDS reads of 8 steps are issued ahead of the chain
+    // fma(x, y, acc) == acc + x*y here (the product of two f32 is exact in f64).  The chain is
+    // one dependent f64 FMA per element; what it must never wait for is LDS: blocks of 16
+    // elements, the NEXT block's eight ds_read_b128 issued before the current block's 16 FMAs
+    // (one basic block: a plain `#pragma unroll` left an exit test between the steps and a
+    // `s_waitcnt lgkmcnt(0)` in front of every four FMAs -- 30 cycles per element instead of 10).
     uint32_t j = 0;
-#pragma unroll 8
-    for (; j + 4 <= a.d; j += 4) {
-      const f32x4 av = *reinterpret_cast<const f32x4 *>(A + j);
-      const f32x4 bv = *reinterpret_cast<const f32x4 *>(B + j);
-      acc = __builtin_fma((double)av.x, (double)bv.x, acc);
-      acc = __builtin_fma((double)av.y, (double)bv.y, acc);
-      acc = __builtin_fma((double)av.z, (double)bv.z, acc);
-      acc = __builtin_fma((double)av.w, (double)bv.w, acc);
+    const uint32_t nblk = a.d / 16;
+    if (nblk) {
+      f32x4 a0[4], b0[4], a1[4], b1[4];  // two blocks in registers, filled and consumed in turn
+      auto fetch = [&](f32x4(&ra)[4], f32x4(&rb)[4], uint32_t blk) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ra[u] = *reinterpret_cast<const f32x4 *>(A + 16 * blk + 4 * u);
+          rb[u] = *reinterpret_cast<const f32x4 *>(B + 16 * blk + 4 * u);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the reads stay in front of the chain that hides them
+      };
+      // (the chain's first step is split off: the compiler waits for EVERY outstanding LDS read
+      // before the first use of a block fetched an iteration ago, so the next fetch goes out
+      // right after that step, not before it)
+      auto head = [&](const f32x4(&ra)[4], const f32x4(&rb)[4]) {
+        acc = __builtin_fma((double)ra[0].x, (double)rb[0].x, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto rest = [&](const f32x4(&ra)[4], const f32x4(&rb)[4]) {
+        acc = __builtin_fma((double)ra[0].y, (double)rb[0].y, acc);
+        acc = __builtin_fma((double)ra[0].z, (double)rb[0].z, acc);
+        acc = __builtin_fma((double)ra[0].w, (double)rb[0].w, acc);
+#pragma unroll
+        for (int u = 1; u < 4; ++u) {
+          acc = __builtin_fma((double)ra[u].x, (double)rb[u].x, acc);
+          acc = __builtin_fma((double)ra[u].y, (double)rb[u].y, acc);
+          acc = __builtin_fma((double)ra[u].z, (double)rb[u].z, acc);
+          acc = __builtin_fma((double)ra[u].w, (double)rb[u].w, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      fetch(a0, b0, 0);
+      uint32_t blk = 0;
+      for (; blk + 2 <= nblk; blk += 2) {
+        head(a0, b0);
+        fetch(a1, b1, blk + 1);
+        rest(a0, b0);
+        head(a1, b1);
+        fetch(a0, b0, blk + 2 < nblk ? blk + 2 : nblk - 1);  // (no next block: the last one again, unused)
+        rest(a1, b1);
+      }
+      if (blk < nblk) {
+        head(a0, b0);
+        rest(a0, b0);
+      }
+      j = nblk * 16;
     }
     for (; j < a.d; ++j) acc = __builtin_fma((double)A[j], (double)B[j], acc);
   }
