@@ -259,6 +259,9 @@ int search_multi(vt_flat *h, const float *query, size_t n, size_t limit, vt_hits
     // the shard's stream; shard 0 copies the gathered lists out; one wait per shard
     const size_t bytes = 16 + limit * sizeof(vt::Entry);
     Rccl &r = rccl();
+    // (this call's copy of the gathered lists: hGather belongs to shard 0's worker, whose next job
+    // -- another caller's search -- may refill it while this thread is still merging)
+    std::vector<unsigned char> gathered;
     VT_TRY(on_all_shards(h, [&](size_t s) -> int {
       Shard *ix = h->shards[s].get();
       Ctx &c = ix->ctx;
@@ -276,12 +279,13 @@ int search_multi(vt_flat *h, const float *query, size_t n, size_t limit, vt_hits
       if (s == 0)
         VT_HIP(hipMemcpyAsync(h->hGather.p, h->dGather[0], S * bytes, hipMemcpyDeviceToHost, c.stream));
       VT_HIP(hipStreamSynchronize(c.stream));
+      if (s == 0) gathered.assign(h->hGather.p, h->hGather.p + S * bytes);
       VT_TRY(settle_begin_profile(c));
       return st;
     }));
     std::vector<MergeItem> items;
     for (size_t s = 0; s < S; ++s) {
-      const unsigned char *blk = h->hGather.p + s * bytes;
+      const unsigned char *blk = gathered.data() + s * bytes;
       int status;
       uint32_t count;
       std::memcpy(&status, blk, 4);
