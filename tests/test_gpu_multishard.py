@@ -243,6 +243,38 @@ def test_rccl_exchange_with_a_one_rank_communicator(nifs, oracle_mod, monkeypatc
     assert res[0] == "error" and "own device" in res[1]
 
 
+def test_concurrent_searches_over_the_rccl_exchange_keep_their_own_lists(nifs, oracle_mod, monkeypatch):
+    """Searches run under the shared lock, so two callers can be in the RCCL leg at once: their jobs
+    pass through every shard's worker in one order, but each caller merges on its own thread --
+    from its own copy of the gathered lists (shard 0's pinned buffer is refilled by the next job).
+    Eight threads, distinct queries, every answer checked."""
+    monkeypatch.setenv("VT_SHARD_FORCE_WORKERS", "1")
+    monkeypatch.setenv("VT_SHARD_EXCHANGE", "rccl")
+    monkeypatch.setenv("VT_COALESCE", "0")          # every caller runs its own search_multi
+    n, d = 20_000, 64
+    x, ids = make_corpus(n, d, 78, True, oracle_mod, tie_block=30)
+    g = ShardedIndex(nifs, 2, [0])
+    assert nifs.flat_rccl_ranks(g.ref) == 1
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(3)
+    qs = [x[n // 2]] + [oracle_mod.normalize_l2(rng.uniform(-1, 1, d).astype(np.float32)) for _ in range(23)]
+    want = [bits(g.search(q, 10)) for q in qs]
+    bad = []
+
+    def worker(t):
+        for r in range(150):
+            j = (t * 5 + r) % len(qs)
+            if bits(g.search(qs[j], 10)) != want[j]:
+                bad.append((t, r, j))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not bad, bad[:3]
+
+
 def test_stale_external_ranks_are_reported_to_every_rank(nifs, oracle_mod):
     """after vt_flat_set_id_ranks a delete moves rows under the caller's id table and
     an insert drops the installed ranks.  vt_flat_search_begin then marks its block instead of
