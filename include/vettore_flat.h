@@ -20,7 +20,9 @@
  *    HIP device the calls fail with VT_ERR_DEVICE.
  *  - thread safety: a handle is the reference's RwLock<FlatIndex> (nifs.rs:266-309):
  *    searches of one handle run concurrently with each other (each on its own HIP
- *    stream), mutations are exclusive; different handles are independent.  A
+ *    stream; vt_flat_search calls that meet on a busy handle are answered together
+ *    in one pass over the corpus, see vt_flat_coalesce_stats), mutations are
+ *    exclusive; different handles are independent.  A
  *    mutation that fails on the device after it began changing the index poisons
  *    the handle (VT_ERR_POISONED from then on), like a panic under the write lock.
  */
