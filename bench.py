@@ -192,6 +192,20 @@ def pmc_traffic(rows, dim):
     return None
 
 
+def pmc_side_traffic(kernel, nbytes_or_flops_rows, dim):
+    """HBM bytes per launch of a side leg's dominant kernel from the committed PMC passes
+    (profiles/pmc_side.json, written by tools/refresh_profiles.sh: FETCH_SIZE x 2 + WRITE_SIZE,
+    as for the headline), when they were taken on the same shape; else None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_side.json")) as f:
+            p = json.load(f).get(kernel)
+        if p and p.get("rows") == nbytes_or_flops_rows and p.get("dim") == dim:
+            return p["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def hits_of(L, handle_ptr):
     """[(id, raw bits)] of a vt_hits handle (freed)."""
     from vettore_amd import nifs
@@ -271,7 +285,8 @@ def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidat
         tf = p["batch_flops"] / max(1e-9, p["batch_ms"]) / 1e9
         out["fallback_queries"] = p["batch_fallbacks"]
         out["roofline"] = {"bound": "mfma", "kernel": "mfma_scores_kernel", "achieved": tf, "peak": 157.3,
-                           "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None, "avg_launch_ms": ms,
+                           "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": pmc_side_traffic("mfma_scores_kernel", len(ref), dim),
+                           "avg_launch_ms": ms,
                            "algorithmic_flops_per_launch": p["batch_flops"] / max(1, p["batch_launches"])}
     else:
         key = {"single": "scan", "funnel": "prefix", "quantized": "hamming"}[mode]
@@ -280,7 +295,8 @@ def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidat
         ms = p[key + "_ms"] / launches
         gbs = p[key + "_bytes"] / launches / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out["roofline"] = {"bound": "hbm", "kernel": kern, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+                           "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_side_traffic(kern, len(ref), dim) if mode != "single" else None,
+                           "avg_launch_ms": ms,
                            "algorithmic_bytes_per_launch": p[key + "_bytes"] / launches}
         # end to end against the same algorithmic bytes (launch chain + host waits included)
         out["end_to_end_frac"] = p[key + "_bytes"] / launches / (dt / steps) / 1e9 / HBM_PEAK_GBS

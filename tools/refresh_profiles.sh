@@ -24,6 +24,8 @@ stats batch --mode batch --steps 6 --warmup 1 --no-cpu
 stats quantized --mode quantized --steps 300 --warmup 20 --no-cpu
 pmc quantized_fetch FETCH_SIZE --mode quantized --steps 20 --warmup 2 --no-cpu
 stats funnel --mode funnel --steps 200 --warmup 5 --no-cpu
+pmc funnel_fetch FETCH_SIZE --mode funnel --steps 20 --warmup 2 --no-cpu
+pmc batch_fetch FETCH_SIZE --mode batch --steps 2 --warmup 1 --no-cpu
 # K1m: 8 queries per sweep (manhattan, N=10M, d=768); the program after `--` is python3 itself
 export ROWS=10000000 NQS=8 METRICS=5
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/multi -o p -- python3 $R/tools/multi_probe.py > $OUT/multi.log 2>&1
@@ -76,6 +78,16 @@ json.dump({
 }, open(out + '/pmc_latest.json', 'w'), indent=1)
 hf, _ = per_launch(out + '/quantized_fetch/p_counter_collection.csv', 'hamming_dist_kernel', 'FETCH_SIZE')
 print("hamming FETCH_SIZE KiB per launch", hf, "x2 bytes", 2 * hf * 1024)
+ff, _ = per_launch(out + '/funnel_fetch/p_counter_collection.csv', 'cosine_scan_kernel', 'FETCH_SIZE')
+bf, _ = per_launch(out + '/batch_fetch/p_counter_collection.csv', 'mfma_scores_kernel<8, false>', 'FETCH_SIZE')
+keep(out + '/funnel_fetch/p_counter_collection.csv', out + '/%s_funnel_pmc_fetch.csv' % RND, 'cosine_scan_kernel')
+keep(out + '/batch_fetch/p_counter_collection.csv', out + '/%s_batch_pmc_fetch.csv' % RND, 'mfma_scores_kernel<8, false>')
+print("cosine_scan FETCH_SIZE x2 bytes", 2 * ff * 1024, "mfma_scores<8> FETCH_SIZE x2 bytes", 2 * bf * 1024)
+# what the side legs of bench.py report as `traffic` (reads only: these kernels write a few KB of lists)
+json.dump({k: {"rows": 10000000, "dim": 768, "hbm_bytes_per_launch": 2 * v * 1024,
+               "source": "FETCH_SIZE x 2 (gfx950 correction as in pmc_latest.json), %s pass of tools/refresh_profiles.sh" % k}
+           for k, v in (("hamming_dist_kernel", hf), ("cosine_scan_kernel", ff), ("mfma_scores_kernel", bf), ("scan_multi_kernel", mf))},
+          open(out + '/pmc_side.json', 'w'), indent=1)
 for name in ('single', 'batch', 'quantized', 'funnel'):
     print(open('%s/%s.json' % (out, name)).read().strip())
     for r in csv.DictReader(open('%s/%s/p_kernel_stats.csv' % (out, name))):
