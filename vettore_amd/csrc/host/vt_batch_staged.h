@@ -174,7 +174,7 @@ double multi_scan_seconds(const Shard *ix, size_t nq) {
   const double tiles = std::ceil((double)ix->n / vt::scan_multi_tile_rows(vt::kMultiMaxQueries));
   double steps = std::ceil(tiles / waves) * std::ceil((double)ix->ld / 256.0);  // (tile, panel) steps of one wave
   double per_step = kMultiPanelS + 0.3e-6 / std::ceil((double)ix->ld / 256.0);
-  if (ix->dim % 64 != 0) per_step *= 2.3;  // run-time bounds and lane order, compiler-scheduled loads
+  if (ix->dim % 64 != 0) per_step *= 1.1;  // the variants that carry the tail handling
   return kMultiFixedS + sweeps * (kMultiSweepFixedS + steps * per_step + std::min(steps, 20.0) * kMultiRampS);
 }
 

@@ -29,6 +29,8 @@
 // Roofline: HBM-bound like K1 -- algorithmic bytes per launch = n * d * 4, whatever NQ is.
 #include "vt_scan.cuh"
 
+#include <cstdlib>
+
 namespace vt {
 namespace dev {
 
@@ -153,8 +155,9 @@ __device__ __forceinline__ void released_too(f32x4 &v) { asm volatile("" : "+v"(
 // constant.  The last panel of a row may still be partial (d % 256 != 0): its surplus lanes
 // re-read columns of the same row (no extra HBM lines) and file sums the chain never reads.
 // Otherwise (ORDER = -1) bounds, tail and lane order are run-time and the loads the compiler's.
-template <int OP, int ORDER, bool FAST>
+template <int OP, int ORDER, bool FAST, bool TAILED>
 __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(const MultiScanArgs a) {
+  constexpr bool kTail = TAILED || !FAST;  // rows may end in chunks short of a group of four and in a scalar tail
   constexpr int NQ = kMqNQ, TR = kMqTR, CAP = kMqCap;
   constexpr int SUM_OP = (OP == OP_HAM || OP == OP_JAC) ? OP_L1 : OP;  // how chunk sums combine
   constexpr bool kAbs = OP == OP_L1 || OP == OP_LINF || OP == OP_HAM;     // half_chunk leaves signed differences
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(co
   uint32_t nredo = 0;  // wave-uniform
 
   const uint32_t ld = a.ld;
-  const uint32_t cfull = a.d / 8, tail = FAST ? 0u : a.d % 8;
+  const uint32_t cfull = a.d / 8, tail = kTail ? a.d % 8 : 0u;
   const uint32_t npanel = (ld + kMqPanel - 1) / kMqPanel;
   const uint32_t total_waves = gridDim.x * kWavesPerBlock;
   const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(co
           for (int q = 0; q < NQ; ++q) half_chunk<OP>(indicator<OP>(qcur[q]), x, x4k, pa[q], pb[q]);
 #pragma unroll
           for (int q = 0; q < NQ; ++q) sum[q] = chunk_sum_packed<SUM_OP, ORDER, kAbs>(a.order, pa[q], pb[q], odd);
-          if (!FAST && tail && c == cfull) {  // tail chunk: the reference adds these products one by one
+          if (kTail && tail && c == cfull) {  // tail chunk: the reference adds these products one by one
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
               *reinterpret_cast<f32x4 *>(S + q * kMqQS + u * kMqSS + kMqTail + odd * 4) =
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(co
         {
           const uint32_t c0 = pc * (kMqPanel / 8);
           float v = pc == 0 ? 0.0f : acc;
-          if (FAST) {
+          if (FAST && !TAILED) {
             // chunks of this panel: 32, or what is left of the row (a multiple of 8 chunks)
             const uint32_t left = cfull - c0;
             if (left >= kMqPanel / 8) {
@@ -334,6 +337,32 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(co
                 v = comb<SUM_OP>(SUM_OP, v, w.w);
               }
             }
+          } else if (FAST) {
+            // chunks of this panel: 32, or what is left of the row (its full chunks, then the
+            // scalar tail's products one by one: distances.rs:236-270)
+            const uint32_t left = cfull > c0 ? cfull - c0 : 0u;
+            if (left >= kMqPanel / 8) {
+#pragma unroll
+              for (uint32_t i = 0; i < kMqPanel / 8; i += 4) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(Schain + i);
+                v = comb<SUM_OP>(SUM_OP, v, w.x);
+                v = comb<SUM_OP>(SUM_OP, v, w.y);
+                v = comb<SUM_OP>(SUM_OP, v, w.z);
+                v = comb<SUM_OP>(SUM_OP, v, w.w);
+              }
+            } else {
+              uint32_t i = 0;
+              for (; i + 4 <= left; i += 4) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(Schain + i);
+                v = comb<SUM_OP>(SUM_OP, v, w.x);
+                v = comb<SUM_OP>(SUM_OP, v, w.y);
+                v = comb<SUM_OP>(SUM_OP, v, w.z);
+                v = comb<SUM_OP>(SUM_OP, v, w.w);
+              }
+              for (; i < left; ++i) v = comb<SUM_OP>(SUM_OP, v, Schain[i]);
+            }
+            if (tail && cfull >= c0 && cfull < c0 + kMqPanel / 8)
+              for (uint32_t j = 0; j < tail; ++j) v = comb<SUM_OP>(SUM_OP, v, Schain[kMqTail + j]);
           } else {
             const uint32_t nsum = cfull > c0 ? (cfull - c0 < kMqPanel / 8 ? cfull - c0 : kMqPanel / 8) : 0u;
             uint32_t i = 0;
@@ -443,9 +472,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(co
 
 constexpr size_t kMqLds = (size_t)kWavesPerBlock * kMqNQ * ((size_t)kMqQS * 4 + WaveTopK<kMqCap>::lds_bytes());
 
-template <int OP, int ORDER, bool FAST>
+template <int OP, int ORDER, bool FAST, bool TAILED = false>
 static hipError_t launch_multi_t(const MultiScanArgs &a, uint32_t blocks, hipStream_t s) {
-  auto kern = scan_multi_kernel<OP, ORDER, FAST>;
+  auto kern = scan_multi_kernel<OP, ORDER, FAST, TAILED>;
   hipError_t e = allow_lds(kern, kMqLds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), kMqLds, s, a);
@@ -456,7 +485,20 @@ static hipError_t launch_multi_t(const MultiScanArgs &a, uint32_t blocks, hipStr
 // small-integer sums of float hamming / jaccard do not.
 template <int OP, bool ORDERED>
 static hipError_t launch_multi_op(const MultiScanArgs &a, uint32_t blocks, hipStream_t s) {
-  if (a.d % kRowAlign != 0) return launch_multi_t<OP, ORDERED ? -1 : 0, false>(a, blocks, s);
+  // Rows whose length is a multiple of 64 floats: no padding, no scalar tail, chunk counts in
+  // groups of four -- the variants measured in DESIGN 4.4.  Other lengths (d = 100, 300, 1000 ...)
+  // take the same scheduled-load kernels compiled with the tail handling in (it costs the
+  // aligned shapes 9 %, so they do not carry it): padding is zero in rows and queries alike,
+  // the scalar tail's products are filed beside the chunk sums.  The variant with run-time lane
+  // order and compiler-scheduled loads stays as an A/B switch (VT_MULTI_GENERAL).
+  static const bool general = std::getenv("VT_MULTI_GENERAL") != nullptr;
+  if (a.d % kRowAlign != 0) {
+    if (general) return launch_multi_t<OP, ORDERED ? -1 : 0, false>(a, blocks, s);
+    if (!ORDERED || a.order == 0) return launch_multi_t<OP, 0, true, true>(a, blocks, s);
+    if (a.order == 1) return launch_multi_t<OP, ORDERED ? 1 : 0, true, true>(a, blocks, s);
+    if (a.order == 2) return launch_multi_t<OP, ORDERED ? 2 : 0, true, true>(a, blocks, s);
+    return launch_multi_t<OP, ORDERED ? 3 : 0, true, true>(a, blocks, s);
+  }
   if (!ORDERED || a.order == 0) return launch_multi_t<OP, 0, true>(a, blocks, s);
   if (a.order == 1) return launch_multi_t<OP, ORDERED ? 1 : 0, true>(a, blocks, s);
   if (a.order == 2) return launch_multi_t<OP, ORDERED ? 2 : 0, true>(a, blocks, s);
