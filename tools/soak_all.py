@@ -5,6 +5,7 @@ funnel (one or two stages), hybrid -- compared bit for bit with the oracle (an o
 reference's compositions binary_top_k -> vector_top_k / prefix vector_top_k -> rerank for the staged
 ones).  Fresh seeds until SECONDS are over.
     SECONDS=200 SHARDS=3 METRICS=0,2 DIM=64 python tools/soak_all.py
+    VT_SLAB_CHUNK_MB=1 IDS=9000 BATCH=600 DIM=100 ...   (rows cross the mapped slab's chunk borders)
 """
 import os
 import sys
@@ -29,6 +30,10 @@ def ok(res):
     return res[1]
 
 
+IDS = int(os.environ.get("IDS", 700))        # id space: the index holds up to this many rows
+BATCH = int(os.environ.get("BATCH", 40))     # rows per insert_many, at most
+
+
 def run(seed, metric, d, shards, steps=300):
     rng = np.random.default_rng(seed)
     ref = nifs.flat_new_sharded(metric, [0] * shards) if shards else nifs._flat_new(metric)
@@ -44,7 +49,7 @@ def run(seed, metric, d, shards, steps=300):
     for step in range(steps):
         op = rng.integers(0, 10)
         if op < 5 or not mirror:
-            items = [(b"id-%d" % rng.integers(0, 700), vec()) for _ in range(int(rng.integers(1, 40)))]
+            items = [(b"id-%d" % rng.integers(0, IDS), vec()) for _ in range(int(rng.integers(1, BATCH)))]
             ok(nifs.flat_insert_many(ref, items))
             o.insert_many(items)
             mirror.update(items)
