@@ -85,10 +85,11 @@ int index_set_dim(Shard *ix, size_t d) {
 // Row for `id`: existing row, or a fresh one appended (ids/rank bookkeeping).
 uint32_t index_row_for(Shard *ix, const char *id, size_t len, bool *is_new) {
   std::string key(id, len);
-  auto it = ix->row_of.find(key);
-  if (it != ix->row_of.end()) {
+  // (one walk of the table for a new id -- the bulk-load case -- instead of a find and an insert)
+  const auto slot = ix->row_of.try_emplace(key, ix->n);
+  if (!slot.second) {
     *is_new = false;
-    return it->second;
+    return slot.first->second;
   }
   const uint32_t r = ix->n++;
   *is_new = true;
@@ -119,7 +120,6 @@ uint32_t index_row_for(Shard *ix, const char *id, size_t len, bool *is_new) {
     ix->rank_host.push_back(kUnranked);
     ix->unranked += 1;
   }
-  ix->row_of.emplace(key, r);
   ix->ids.push_back(std::move(key));
   return r;
 }
@@ -311,11 +311,14 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     if (need > ix->rank_host.capacity()) ix->rank_host.reserve(std::max(need, 2 * ix->rank_host.capacity()));
   }
   *began = true;
+  const bool trace = count > 100000 && std::getenv("VT_TRACE_INGEST") != nullptr;  // phase timings on stderr (tools/ingest_probe.py)
+  const auto t_ids = std::chrono::steady_clock::now();
   for (size_t i = 0; i < count; ++i) {
     bool is_new = false;
     target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new);
     if (!is_new || target[i] != n_before + i) all_appended_in_order = false;
   }
+  const auto t_rows = std::chrono::steady_clock::now();
   // (test hook: a device failure between the id table's change and the rows' arrival, the one
   // window in which a mutation cannot be taken back -- tests/test_gpu_multishard.py checks that
   // the handle is poisoned from then on)
@@ -457,7 +460,13 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     pending = true;
   }
   if (pending) VT_HIP(hipStreamSynchronize(c.stream));
+  const auto t_rank = std::chrono::steady_clock::now();
   if (rank_now) VT_TRY(index_sync_ranks(ix, false));
+  if (trace) {
+    auto s_of = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+    std::fprintf(stderr, "[vt ingest] %zu rows: id table %.3f s, rows to the device %.3f s, id ranks %.3f s\n", count,
+                 s_of(t_ids, t_rows), s_of(t_rows, t_rank), s_of(t_rank, std::chrono::steady_clock::now()));
+  }
   return VT_OK;
 }
 
