@@ -87,19 +87,22 @@ int read_single(vt_flat *h, unsigned need, size_t limit, F &&fn) {
 // flat.rs:88-93 on one shard.
 int shard_delete(Shard *ix, const char *id, size_t id_len, bool *began) {
   Ctx &c = ix->ctx;
-  auto it = ix->row_of.find(std::string(id ? id : "", id_len));
-  if (it != ix->row_of.end()) {
+  const char *idp = id ? id : "";
+  const uint64_t hash = vt_host::hash_id(idp, id_len);
+  const uint32_t found = ix->row_of.find(idp, id_len, hash);
+  if (found != vt_host::IdTable::kNone) {
     *began = true;
     ix->epoch += 1;
-    const uint32_t r = it->second, last = ix->n - 1;
+    const uint32_t r = found, last = ix->n - 1;
     if (ix->rank_host[r] == kUnranked && ix->unranked) ix->unranked -= 1;
-    ix->row_of.erase(it);
+    ix->row_of.erase(idp, id_len, hash);
     if (r != last) {
+      // (the table learns the last row's new place while ids[last] still holds its bytes)
+      ix->row_of.move_row(ix->ids[last].data(), ix->ids[last].size(), vt_host::hash_id(ix->ids[last].data(), ix->ids[last].size()), r);
       // swap-delete: the last row moves into the hole and keeps its rank
       VT_HIP(hipMemcpyAsync(ix->dX + (size_t)r * ix->ld, ix->dX + (size_t)last * ix->ld, (size_t)ix->ld * sizeof(float),
                             hipMemcpyDeviceToDevice, c.stream));
       ix->ids[r] = std::move(ix->ids[last]);
-      ix->row_of[ix->ids[r]] = r;
       ix->rank_host[r] = ix->rank_host[last];
       if (ix->ranks_clean && ix->dRank.p)
         VT_HIP(hipMemcpyAsync(ix->dRank.p + r, ix->dRank.p + last, sizeof(uint32_t), hipMemcpyDeviceToDevice, c.stream));

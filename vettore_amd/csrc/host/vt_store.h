@@ -83,14 +83,14 @@ int index_set_dim(Shard *ix, size_t d) {
 }
 
 // Row for `id`: existing row, or a fresh one appended (ids/rank bookkeeping).
-uint32_t index_row_for(Shard *ix, const char *id, size_t len, bool *is_new) {
-  std::string key(id, len);
-  // (one walk of the table for a new id -- the bulk-load case -- instead of a find and an insert)
-  const auto slot = ix->row_of.try_emplace(key, ix->n);
-  if (!slot.second) {
+uint32_t index_row_for(Shard *ix, const char *id, size_t len, bool *is_new, uint64_t hash) {
+  const uint32_t have = ix->row_of.find(id, len, hash);
+  if (have != vt_host::IdTable::kNone) {
     *is_new = false;
-    return slot.first->second;
+    return have;
   }
+  std::string key(id, len);
+  ix->row_of.insert(hash, ix->n);  // (its bytes arrive in ids[n] at the end of this function)
   const uint32_t r = ix->n++;
   *is_new = true;
   ix->epoch += 1;
@@ -305,18 +305,32 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     // bulk load: no rehash / regrowth inside the id loop -- but geometric, or a corpus that arrives
     // in many appends re-hashes and re-copies its whole id table at every one of them (84 M ids: 15 s)
     const size_t need = (size_t)ix->n + count;
-    if ((double)need > (double)ix->row_of.bucket_count() * ix->row_of.max_load_factor())
-      ix->row_of.reserve(std::max(need, 2 * ix->row_of.size()));
+    if (need * 10 > ix->row_of.slots() * 7) ix->row_of.reserve(std::max(need, 2 * ix->row_of.size()));
     if (need > ix->ids.capacity()) ix->ids.reserve(std::max(need, 2 * ix->ids.capacity()));
     if (need > ix->rank_host.capacity()) ix->rank_host.reserve(std::max(need, 2 * ix->rank_host.capacity()));
   }
   *began = true;
   const bool trace = count > 100000 && std::getenv("VT_TRACE_INGEST") != nullptr;  // phase timings on stderr (tools/ingest_probe.py)
   const auto t_ids = std::chrono::steady_clock::now();
-  for (size_t i = 0; i < count; ++i) {
-    bool is_new = false;
-    target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new);
-    if (!is_new || target[i] != n_before + i) all_appended_in_order = false;
+  {
+    // the table's slots are fetched a few ids ahead of their use: a bulk load walks a table far
+    // larger than the caches, one miss per id
+    constexpr size_t kAhead = 8;
+    uint64_t ring[kAhead];
+    for (size_t i = 0; i < std::min(count, kAhead); ++i) {
+      ring[i] = vt_host::hash_id(ids + id_off[i], id_off[i + 1] - id_off[i]);
+      ix->row_of.prefetch(ring[i]);
+    }
+    for (size_t i = 0; i < count; ++i) {
+      const uint64_t hash = ring[i % kAhead];
+      if (i + kAhead < count) {
+        ring[i % kAhead] = vt_host::hash_id(ids + id_off[i + kAhead], id_off[i + kAhead + 1] - id_off[i + kAhead]);
+        ix->row_of.prefetch(ring[i % kAhead]);
+      }
+      bool is_new = false;
+      target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new, hash);
+      if (!is_new || target[i] != n_before + i) all_appended_in_order = false;
+    }
   }
   const auto t_rows = std::chrono::steady_clock::now();
   // (test hook: a device failure between the id table's change and the rows' arrival, the one

@@ -169,7 +169,7 @@ struct Shard {
   DevBuf<float> dXnorm2;     // per-row squared norms, valid with max_sqnorm
   // ids
   std::vector<std::string> ids;  // by row
-  std::unordered_map<std::string, uint32_t> row_of;
+  vt_host::IdTable row_of{&ids};  // id bytes -> row (the bytes themselves stay in `ids`)
   std::vector<uint32_t> rank_host;  // by row
   bool ranks_clean = true;          // rank_host/dRank describe the current rows
   // While !ranks_clean: rows whose device rank differs from rank_host (newcomers carry

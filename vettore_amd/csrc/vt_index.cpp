@@ -30,6 +30,7 @@
 #include <rccl/rccl.h>
 
 // The host side in reading order (one translation unit; see the note at the top of each part):
+#include "host/vt_idtable.h"
 #include "host/vt_base.h"
 #include "host/vt_types.h"
 #include "host/vt_select.h"
