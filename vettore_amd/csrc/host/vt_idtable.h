@@ -12,13 +12,24 @@
 
 #include <cstdint>
 #include <cstring>
+#include <random>
 #include <string>
 #include <vector>
 
 namespace vt_host {
 
+// (seeded once per process, like the random keys of Rust's HashMap: ids come from callers, and a
+// fixed function would let them be chosen to pile up in one probe run)
+inline uint64_t hash_seed() {
+  static const uint64_t seed = [] {
+    std::random_device rd;
+    return ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ 0x9E3779B97F4A7C15ull;
+  }();
+  return seed;
+}
+
 inline uint64_t hash_id(const char *p, size_t n) {
-  uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
+  uint64_t h = hash_seed() ^ (n * 0xff51afd7ed558ccdull);
   while (n >= 8) {
     uint64_t w;
     std::memcpy(&w, p, 8);
