@@ -133,18 +133,19 @@ class IdTable {
     const std::string &s = (*ids_)[row];
     return s.size() == len && (len == 0 || std::memcmp(s.data(), id, len) == 0);
   }
-  void place(uint64_t hash, uint32_t row1) {
-    size_t i = hash & mask_;
-    while (slots_[i].row1 != 0) i = (i + 1) & mask_;
-    slots_[i] = Slot{hash, row1, 0};
+  static void place_in(std::vector<Slot> &slots, size_t mask, uint64_t hash, uint32_t row1) {
+    size_t i = hash & mask;
+    while (slots[i].row1 != 0) i = (i + 1) & mask;
+    slots[i] = Slot{hash, row1, 0};
   }
+  void place(uint64_t hash, uint32_t row1) { place_in(slots_, mask_, hash, row1); }
+  // (the new slots exist before the old ones go: an allocation that fails leaves the table as it was)
   void rebuild(size_t want) {
-    std::vector<Slot> old;
-    old.swap(slots_);
-    slots_.assign(want, Slot{0, 0, 0});
+    std::vector<Slot> fresh(want, Slot{0, 0, 0});
+    for (const Slot &s : slots_)
+      if (s.row1) place_in(fresh, want - 1, s.hash, s.row1);
+    slots_.swap(fresh);
     mask_ = want - 1;
-    for (const Slot &s : old)
-      if (s.row1) place(s.hash, s.row1);
   }
 
   const std::vector<std::string> *ids_;
