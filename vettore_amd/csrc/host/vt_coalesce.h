@@ -78,6 +78,7 @@ int coalesced_search(vt_flat *h, const float *query, size_t n, size_t limit, vt_
   const unsigned max_active = coalesce_slots(h->approx_bytes.load(std::memory_order_relaxed));
   vt_flat::Waiting me(query, n, limit, out);
   std::vector<vt_flat::Waiting *> members;
+  members.reserve(kCoalesceMax);  // (no allocation once others depend on this caller)
   {
     std::unique_lock<std::mutex> lk(co.mu);
     if (co.active < max_active && co.waiting.empty()) {
