@@ -201,6 +201,15 @@ size_t vt_flat_len(const vt_flat *index);
 long vt_flat_dimension(const vt_flat *index);
 int vt_flat_metric(const vt_flat *index);
 int vt_flat_set_reduce_order(vt_flat *index, int order);
+/* Which matrix-core pass nominates the candidates of vt_flat_search_batch (and of coalesced
+ * vt_flat_search calls): VT_NOMINATE_BF16 (default; operands rounded to bf16, the pass is
+ * HBM-bound) or VT_NOMINATE_F32 (FP32 matrix cores).  Hits are identical bit for bit under
+ * both: candidates are re-scored with the exact arithmetic and completeness is certified by
+ * an error bound that knows the rounding.  Override for new indexes: VT_BATCH_NOMINATE=f32. */
+#define VT_NOMINATE_F32 1
+#define VT_NOMINATE_BF16 2
+int vt_flat_set_batch_nominate(vt_flat *index, int mode);
+int vt_flat_batch_nominate(const vt_flat *index);
 /* Order used by indexes created afterwards and by the stateless helpers. */
 int vt_set_default_reduce_order(int order);
 
@@ -305,6 +314,14 @@ typedef struct vt_profile {
   uint64_t prefix_launches; /* f64 cosine prefix scans (funnel stage over all rows) */
   double prefix_ms;
   uint64_t prefix_bytes;    /* rows * prefix dimensions * 4 */
+  /* K2b: candidate passes with bf16 operands (HBM-bound; batch_* above count the FP32 passes) */
+  uint64_t nominate_launches;
+  double nominate_ms;
+  uint64_t nominate_bytes;        /* algorithmic bytes: rows * d * 4 per pass */
+  double nominate_flops;          /* 2 * rows * 256 * padded dims per pass */
+  uint64_t nominate_queries;
+  uint64_t nominate_second_passes; /* passes re-run with thresholds from a first pass's exact hits */
+  uint64_t nominate_candidates;   /* rows handed to the exact rescoring, summed over queries */
 } vt_profile;
 int vt_flat_set_profiling(vt_flat *index, int enabled);
 int vt_flat_get_profile(vt_flat *index, vt_profile *out, int reset);

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvettore_hip.so")
 
 VT_OK = 0
 ORDER_PAIR, ORDER_AVX, ORDER_SEQ, ORDER_SSE2 = 0, 1, 2, 3
+NOMINATE_F32, NOMINATE_BF16 = 1, 2
 EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1
 
 # every symbol include/vettore_flat.h declares
@@ -23,7 +24,7 @@ SYMBOLS = [
     "vt_flat_new", "vt_flat_new_sharded", "vt_flat_shard_count", "vt_flat_shard_device", "vt_flat_shard_len", "vt_flat_shard_memory", "vt_flat_coalesce_stats",
     "vt_flat_route_ids", "vt_flat_set_exchange", "vt_flat_exchange", "vt_flat_rccl_ranks", "vt_flat_free", "vt_flat_insert", "vt_flat_insert_many", "vt_flat_delete",
     "vt_flat_search", "vt_flat_search_batch", "vt_flat_len", "vt_flat_dimension", "vt_flat_metric",
-    "vt_flat_set_reduce_order", "vt_set_default_reduce_order",
+    "vt_flat_set_reduce_order", "vt_set_default_reduce_order", "vt_flat_set_batch_nominate", "vt_flat_batch_nominate",
     "vt_flat_load_matrix", "vt_flat_load_device_matrix", "vt_flat_quantized_search", "vt_flat_funnel_search", "vt_flat_hybrid_search",
     "vt_rank_ids", "vt_flat_set_id_ranks", "vt_flat_stream", "vt_flat_search_begin", "vt_flat_merge_gathered",
     "vt_vector_top_k", "vt_binary_top_k", "vt_normalize_l2", "vt_compress_sign_bits",
@@ -39,6 +40,9 @@ class Profile(C.Structure):
         ("batch_launches", C.c_uint64), ("batch_ms", C.c_double), ("batch_flops", C.c_double),
         ("batch_queries", C.c_uint64), ("batch_fallbacks", C.c_uint64),
         ("prefix_launches", C.c_uint64), ("prefix_ms", C.c_double), ("prefix_bytes", C.c_uint64),
+        ("nominate_launches", C.c_uint64), ("nominate_ms", C.c_double), ("nominate_bytes", C.c_uint64),
+        ("nominate_flops", C.c_double), ("nominate_queries", C.c_uint64),
+        ("nominate_second_passes", C.c_uint64), ("nominate_candidates", C.c_uint64),
     ]
 
 
@@ -105,6 +109,8 @@ def load() -> C.CDLL:
     L.vt_flat_metric.argtypes = [vp]
     L.vt_flat_set_reduce_order.argtypes = [vp, C.c_int]
     L.vt_set_default_reduce_order.argtypes = [C.c_int]
+    L.vt_flat_set_batch_nominate.argtypes = [vp, C.c_int]
+    L.vt_flat_batch_nominate.argtypes = [vp]
     L.vt_flat_load_matrix.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_char_p, szp, f32p]
     L.vt_flat_load_device_matrix.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_char_p, szp, vp]
     L.vt_flat_quantized_search.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]

@@ -21,6 +21,23 @@ int initial_order() {
 }
 int g_default_order = initial_order();
 
+// Which matrix-core pass nominates a batch's candidates: K2b (operands
+// rounded to bf16, HBM-bound) unless VT_BATCH_NOMINATE=f32 asks for K2.  Results are the same
+// bit for bit either way -- the exact kernel decides.
+int initial_nominate() {
+  const char *e = std::getenv("VT_BATCH_NOMINATE");
+  if (e && (std::string(e) == "f32" || std::string(e) == "1")) return VT_NOMINATE_F32;
+  return VT_NOMINATE_BF16;
+}
+int g_default_nominate = initial_nominate();
+// smallest sample rank K2b's threshold is taken from (VT_BF16_MIN_RANK: tools/nominate_probe.py sweeps it)
+uint32_t initial_bf16_min_rank() {
+  const char *e = std::getenv("VT_BF16_MIN_RANK");
+  const int v = e ? std::atoi(e) : 0;
+  return v >= 1 && v <= 4096 ? (uint32_t)v : 4u;
+}
+uint32_t g_bf16_min_rank = initial_bf16_min_rank();
+
 int fail(int status, const std::string &detail) {
   g_last_error = detail;
   return status;

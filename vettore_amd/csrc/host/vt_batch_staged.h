@@ -5,16 +5,25 @@
 
 namespace {
 
-// ---------------------------------------------------------------- K2 host side
+// ---------------------------------------------------------------- K2 / K2b host side
 // One group of <= 256 queries through the matrix cores.  `done[i]` is set for
 // every query whose exact top-k was proven complete; the others are left for
 // the single-query path.
-int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit, vt_hits **out, std::vector<char> &done) {
+//
+// bf16 = false: K2, operands in f32 on v_mfma_f32_32x32x2_f32 (MFMA-bound).
+// bf16 = true:  K2b, operands rounded to bf16 on v_mfma_f32_32x32x16_bf16 (HBM-bound); the
+//               acceptance margin grows by the operand rounding, nothing else changes.
+// tau_given (K2b's second pass): thresholds known from a first pass's exact results instead of
+// a sample.  retry_tau (first pass only): for every query the bound could not certify but whose
+// k exact hits exist, the threshold with which a second pass is certain to certify it (NaN
+// where there is none).
+int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit, vt_hits **out, std::vector<char> &done,
+                bool bf16, const float *tau_given = nullptr, std::vector<float> *retry_tau = nullptr) {
   const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
   const uint32_t k = (uint32_t)std::min<size_t>(limit, n);
-  uint32_t nq_pad = 32;
+  uint32_t nq_pad = bf16 ? 256 : 32;
   while (nq_pad < nq) nq_pad *= 2;
-  const uint32_t rows_per_block = vt::batch_rows_per_block(nq_pad);
+  const uint32_t rows_per_block = bf16 ? vt::batch_bf16_rows_per_block() : vt::batch_rows_per_block(nq_pad);
   const uint32_t ntiles_total = (n + rows_per_block - 1) / rows_per_block;
   // pass-0 sample: 1/64 of the row tiles, 128..512 of them, spread over the corpus.
   // A larger sample gives a tighter tau: fewer candidates to rescore and, above
@@ -26,10 +35,13 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   const uint32_t stride = std::max<uint32_t>(1, (ntiles_total + want_tiles - 1) / want_tiles);
   const uint32_t ntiles_sample = (ntiles_total + stride - 1) / stride;
   const uint32_t sample_rows = ntiles_sample * rows_per_block;
-  // tau = rank-th best sample score: about rank * n / sample_rows rows pass
+  // tau = rank-th best sample score: about rank * n / sample_rows rows pass.  K2b's margin is
+  // ~0.2 sigma of a score distribution where K2's is ~1e-4, so its tau sits lower: the k-th hit
+  // must clear it by that margin or the query costs a second pass.
   const double ratio = (double)sample_rows / (double)n;
-  uint32_t rank = (uint32_t)std::ceil(8.0 * k * std::min(1.0, ratio));
-  rank = std::max<uint32_t>(3, std::min<uint32_t>(rank, std::min<uint32_t>(sample_rows, n)));
+  const double want_cand = bf16 ? std::min(32.0 * k, std::max(8.0 * k, 4096.0)) : 8.0 * k;
+  uint32_t rank = (uint32_t)std::ceil(want_cand * std::min(1.0, ratio));
+  rank = std::max<uint32_t>(bf16 ? g_bf16_min_rank : 3, std::min<uint32_t>(rank, std::min<uint32_t>(sample_rows, n)));
   const uint32_t cand_cap = 8192;
   constexpr uint32_t kBlocksPerQuery = 4;
 
@@ -37,7 +49,7 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   VT_TRY(c.hBQ.ensure((size_t)nq_pad * ld));
   VT_TRY(c.dBTau.ensure(nq_pad));
   VT_TRY(c.hBTau.ensure(nq_pad));
-  VT_TRY(c.dBSample.ensure((size_t)nq_pad * sample_rows));
+  if (!tau_given) VT_TRY(c.dBSample.ensure((size_t)nq_pad * sample_rows));
   VT_TRY(c.dBCand.ensure((size_t)nq_pad * cand_cap));
   VT_TRY(c.dBCount.ensure(nq_pad));
   VT_TRY(c.hBCount.ensure(nq_pad));
@@ -47,6 +59,7 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   VT_TRY(c.hBOutCount.ensure(nq_pad));
   VT_TRY(c.dPartKeys.ensure((size_t)nq_pad * kBlocksPerQuery * k));
   VT_TRY(c.dPartPay.ensure((size_t)nq_pad * kBlocksPerQuery * k));
+  if (bf16) VT_TRY(c.dBQimage.ensure(vt::batch_bf16_image_bytes(ld)));
 
   std::vector<double> qnorm(nq);
   std::memset(c.hBQ.p, 0, (size_t)nq_pad * ld * sizeof(float));
@@ -66,14 +79,26 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   a.n_total = n;
   const bool l2_family = ix->metric == VT_L2 || ix->metric == VT_L2_SQUARED;
   a.xnorm2 = l2_family ? ix->dXnorm2.p : nullptr;
-  // pass 0: dense scores of the sample -> tau
-  a.n = sample_rows;
-  a.sample_stride = stride;
-  a.sample = c.dBSample.p;
-  a.sample_rows = sample_rows;
+  if (bf16) {
+    a.Qimage = c.dBQimage.p;
+    VT_HIP(vt::launch_batch_q_image(c.dBQ.p, ld, c.dBQimage.p, c.stream));
+  }
+  auto scores = [&](bool dense, uint32_t blocks) {
+    return bf16 ? vt::launch_batch_scores_bf16(a, dense, blocks, c.stream) : vt::launch_batch_scores(a, dense, blocks, c.stream);
+  };
   const uint32_t grid_cap = (uint32_t)c.num_cus;
-  VT_HIP(vt::launch_batch_scores(a, true, std::min<uint32_t>(ntiles_sample, grid_cap), c.stream));
-  VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, nq_pad, (uint32_t)nq, rank, c.dBTau.p, c.stream));
+  if (tau_given) {
+    for (uint32_t i = 0; i < nq_pad; ++i) c.hBTau.p[i] = i < nq ? tau_given[i] : INFINITY;
+    VT_HIP(hipMemcpyAsync(c.dBTau.p, c.hBTau.p, (size_t)nq_pad * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  } else {
+    // pass 0: dense scores of the sample -> tau
+    a.n = sample_rows;
+    a.sample_stride = stride;
+    a.sample = c.dBSample.p;
+    a.sample_rows = sample_rows;
+    VT_HIP(scores(true, std::min<uint32_t>(ntiles_sample, grid_cap)));
+    VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, nq_pad, (uint32_t)nq, rank, c.dBTau.p, c.stream));
+  }
   // pass 1: all rows, candidates with score >= tau
   a.n = n;
   a.sample = nullptr;
@@ -83,7 +108,7 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   a.cand_cap = cand_cap;
   VT_HIP(hipMemsetAsync(c.dBCount.p, 0, (size_t)nq_pad * sizeof(uint32_t), c.stream));
   if (c.profiling) VT_HIP(hipEventRecord(c.ev2, c.stream));
-  VT_HIP(vt::launch_batch_scores(a, false, std::min<uint32_t>(ntiles_total, grid_cap), c.stream));
+  VT_HIP(scores(false, std::min<uint32_t>(ntiles_total, grid_cap)));
   if (c.profiling) VT_HIP(hipEventRecord(c.ev3, c.stream));
   // exact rescoring of every query's candidates with the K1 arithmetic
   vt::ScanArgs sa{};
@@ -110,17 +135,29 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   VT_HIP(hipMemcpyAsync(c.hBOut.p, c.dBOut.p, (size_t)nq_pad * k * sizeof(vt::Entry), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(hipMemcpyAsync(c.hBOutCount.p, c.dBOutCount.p, (size_t)nq_pad * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(hipMemcpyAsync(c.hBCount.p, c.dBCount.p, (size_t)nq_pad * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
-  VT_HIP(hipMemcpyAsync(c.hBTau.p, c.dBTau.p, (size_t)nq_pad * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+  if (!tau_given) VT_HIP(hipMemcpyAsync(c.hBTau.p, c.dBTau.p, (size_t)nq_pad * sizeof(float), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(hipMemcpyAsync(&status, c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
   VT_HIP(hipStreamSynchronize(c.stream));
   if (c.profiling) {
     float ms = 0.f;
     VT_HIP(hipEventElapsedTime(&ms, c.ev2, c.ev3));
-    c.prof.batch_launches += 1;
-    c.prof.batch_ms += ms;
-    c.prof.batch_flops += 2.0 * (double)n * (double)nq_pad * (double)ld;
-    c.prof.batch_queries += nq;
+    if (bf16) {
+      c.prof.nominate_launches += 1;
+      c.prof.nominate_ms += ms;
+      c.prof.nominate_bytes += (uint64_t)n * d * 4;
+      c.prof.nominate_flops += 2.0 * (double)n * (double)nq_pad * (double)ld;
+      c.prof.nominate_queries += nq;
+      c.prof.nominate_second_passes += tau_given ? 1 : 0;
+      uint64_t cands = 0;
+      for (size_t i = 0; i < nq; ++i) cands += std::min<uint32_t>(c.hBCount.p[i], cand_cap);
+      c.prof.nominate_candidates += cands;
+    } else {
+      c.prof.batch_launches += 1;
+      c.prof.batch_ms += ms;
+      c.prof.batch_flops += 2.0 * (double)n * (double)nq_pad * (double)ld;
+      c.prof.batch_queries += nq;
+    }
   }
   if (status != 0) return VT_OK;  // an exact rescoring overflowed somewhere: let the single-query path decide
 
@@ -136,26 +173,58 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   // The slack keeps y strictly behind the k-th hit even after the f32 rank
   // (1 - raw for cosine, sqrt for L2) collapses nearby values onto equal keys,
   // where the id tie-break could otherwise let y in.
-  const double u = std::ldexp(1.0, -24);
+  //
+  // K2b: each operand is first rounded to bf16 (8 significant bits, round to nearest even:
+  // relative error <= ub = 2^-8 each), so every product carries a relative error of at most
+  // 2 ub + ub^2 and, by Cauchy-Schwarz, the sum an absolute one of at most (2 ub + ub^2) |q| X;
+  // the bf16 products are exact in f32 and the matrix core's f32 accumulation of them is priced
+  // generously (8 d u |q| X, together with the reference's own summation error: whatever the
+  // order and the rounding of its partial sums).  Subnormal operands may be flushed: at most
+  // 2^-126 per element times the other operand, sqrt(d) 2^-126 (|q| + X) over a row.  Rounding
+  // to bf16 can overflow only near f32's largest values: such queries are never certified here
+  // (the guard below), nor is any whose margin is not finite.
+  const double u = std::ldexp(1.0, -24), ub = std::ldexp(1.0, -8);
   const double xnorm = std::sqrt(ix->max_sqnorm);
+  if (retry_tau) retry_tau->assign(nq, std::numeric_limits<float>::quiet_NaN());
   for (size_t i = 0; i < nq; ++i) {
     const uint32_t cnt = c.hBCount.p[i];
-    if (cnt > cand_cap || c.hBOutCount.p[i] < k) continue;
+    if (c.hBOutCount.p[i] < k) continue;
     const vt::Entry *e = c.hBOut.p + i * k;
     const double tau = (double)c.hBTau.p[i];
     const double raw_k = (double)e[k - 1].raw;
+    const bool magnitudes_ok = !bf16 || (qnorm[i] < 1e18 && xnorm < 1e18);
     bool accept = false;
+    double tau2 = std::numeric_limits<double>::quiet_NaN();  // threshold that certifies given these k exact hits
     if (l2_family) {
-      const double eps = 3.5 * (double)d * u * (qnorm[i] + xnorm) * (qnorm[i] + xnorm);
+      double eps = 3.5 * (double)d * u * (qnorm[i] + xnorm) * (qnorm[i] + xnorm);
+      if (bf16)
+        eps = 2.0 * (2.0 * ub + ub * ub) * qnorm[i] * xnorm + 8.0 * (double)d * u * (qnorm[i] + xnorm) * (qnorm[i] + xnorm) +
+              std::ldexp(1.0, -120) * std::sqrt((double)d) * (qnorm[i] + xnorm);
       const double l2sq_k = (ix->metric == VT_L2 ? raw_k * raw_k : raw_k) * (1.0 + 16.0 * u);
-      accept = l2sq_k <= qnorm[i] * qnorm[i] * (1.0 - 4.0 * u) - tau - eps;
+      const double bound = qnorm[i] * qnorm[i] * (1.0 - 4.0 * u) - eps;
+      accept = l2sq_k <= bound - tau;
+      tau2 = bound - l2sq_k * (1.0 + 16.0 * u);
     } else {
-      const double eps = 2.5 * (double)d * u * qnorm[i] * xnorm;
+      double eps = 2.5 * (double)d * u * qnorm[i] * xnorm;
+      if (bf16)
+        eps = (2.0 * ub + ub * ub + 8.0 * (double)d * u) * qnorm[i] * xnorm +
+              std::ldexp(1.0, -120) * std::sqrt((double)d) * (qnorm[i] + xnorm);
       const double dot_k = ix->metric == VT_NEG_INNER_PRODUCT ? -raw_k : raw_k;
       const double slack = ix->metric == VT_COSINE ? 4.0 * u * std::max(1.0, std::fabs(1.0 - dot_k)) : 0.0;
       accept = tau + eps + slack <= dot_k;
+      tau2 = dot_k - eps - 2.0 * slack - 16.0 * u * std::fabs(dot_k);
     }
-    if (!accept) continue;  // also taken when anything above is NaN
+    accept = accept && magnitudes_ok && cnt <= cand_cap;
+    if (!accept) {  // also taken when anything above is NaN
+      if (retry_tau && magnitudes_ok && std::isfinite(tau2)) {
+        // rounded DOWN to f32: the second pass nominates at least what tau2 asks for
+        float t = (float)tau2;
+        if ((double)t > tau2) t = std::nextafterf(t, -INFINITY);
+        // (only a lower bar than the one that failed can help, and only a list that did not overflow)
+        if (tau_given == nullptr && (double)t < tau && cnt <= cand_cap) (*retry_tau)[i] = t;
+      }
+      continue;
+    }
     std::vector<vt::Entry> entries(e, e + k);
     VT_TRY(make_hits(ix, entries, &out[i]));
     done[i] = 1;
@@ -256,6 +325,10 @@ int multi_scan_group(Shard *ix, Ctx &c, const float *queries, const std::vector<
   return VT_OK;
 }
 
+// K2b applies wherever K2 does; which of the two nominates is the shard's setting
+// (vt_flat_set_batch_nominate / VT_BATCH_NOMINATE, default bf16).
+bool batch_nominates_bf16(const Shard *ix) { return ix->nominate == VT_NOMINATE_BF16; }
+
 // True when a batch of nq queries takes the shared MFMA pass (and so needs the row norms).
 bool batch_uses_mfma(const Shard *ix, size_t nq, size_t limit) {
   const bool mfma_metric = ix->metric == VT_COSINE || ix->metric == VT_INNER_PRODUCT ||
@@ -265,12 +338,15 @@ bool batch_uses_mfma(const Shard *ix, size_t nq, size_t limit) {
   bool use_mfma = mfma_metric && nq >= 2 && limit <= (size_t)vt::kMaxFusedK && limit > 0 && ix->n >= 4096 &&
                   std::getenv("VT_BATCH_NO_MFMA") == nullptr;
   if (use_mfma && !std::getenv("VT_FORCE_BATCH_MFMA")) {  // (tests force the shared pass on small corpora)
-    // nq single scans against one shared pass (HBM-bound below ~33 queries, then MFMA-bound)
+    // nq single scans against one shared pass (K2: HBM-bound below ~33 queries, then MFMA-bound;
+    // K2b: HBM-bound at every batch size)
     const double bytes = (double)ix->n * ix->ld * 4.0;
-    double nq_pad = 32;
+    const bool bf16 = batch_nominates_bf16(ix);
+    double nq_pad = bf16 ? 256 : 32;
     while (nq_pad < (double)std::min<size_t>(nq, 256)) nq_pad *= 2;
     const double groups = std::ceil((double)nq / 256.0);
-    const double t_pass = std::max(1.3 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kBatchFlopsPerS);
+    const double t_pass = bf16 ? std::max(1.1 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kNominateFlopsPerS)
+                               : std::max(1.3 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kBatchFlopsPerS);
     double t_other = (double)nq * scan_seconds(bytes);
     if (multi_scan_applies(ix, limit)) t_other = std::min(t_other, multi_scan_seconds(ix, nq));
     use_mfma = t_other > groups * (kBatchFixedS + t_pass);
@@ -292,13 +368,41 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
   }
   std::vector<char> done(nq, 0);
   const bool use_mfma = batch_uses_mfma(ix, nq, limit);
+  const bool bf16 = batch_nominates_bf16(ix);
   if (use_mfma) {
+    std::vector<float> tau2(nq, std::numeric_limits<float>::quiet_NaN());
     for (size_t g0 = 0; g0 < nq; g0 += 256) {
       const size_t gn = std::min<size_t>(256, nq - g0);
       if (gn < 2) continue;  // a lone trailing query takes the single-query path below
       std::vector<char> gdone(gn, 0);
-      VT_TRY(batch_group(ix, c, queries + g0 * d, gn, limit, out + g0, gdone));
+      std::vector<float> gtau;
+      VT_TRY(batch_group(ix, c, queries + g0 * d, gn, limit, out + g0, gdone, bf16, nullptr, bf16 ? &gtau : nullptr));
       for (size_t i = 0; i < gn; ++i) done[g0 + i] = gdone[i];
+      for (size_t i = 0; i < gtau.size(); ++i) tau2[g0 + i] = gtau[i];
+    }
+    // K2b's second pass: a query whose k exact hits did not clear tau by the margin names the
+    // threshold that its k-th hit does clear; one more pass over the rows with those thresholds
+    // certifies all such queries at once (K1m would need a sweep per eight of them).
+    std::vector<size_t> again;
+    for (size_t i = 0; i < nq; ++i)
+      if (!done[i] && !std::isnan(tau2[i])) again.push_back(i);
+    if (bf16 && again.size() >= 2) {
+      for (size_t g0 = 0; g0 < again.size(); g0 += 256) {
+        const size_t gn = std::min<size_t>(256, again.size() - g0);
+        std::vector<float> qs(gn * d), taus(gn);
+        std::vector<vt_hits *> outs(gn, nullptr);
+        for (size_t i = 0; i < gn; ++i) {
+          std::memcpy(qs.data() + i * d, queries + again[g0 + i] * d, d * sizeof(float));
+          taus[i] = tau2[again[g0 + i]];
+        }
+        std::vector<char> gdone(gn, 0);
+        VT_TRY(batch_group(ix, c, qs.data(), gn, limit, outs.data(), gdone, true, taus.data(), nullptr));
+        for (size_t i = 0; i < gn; ++i)
+          if (gdone[i]) {
+            out[again[g0 + i]] = outs[i];
+            done[again[g0 + i]] = 1;
+          }
+      }
     }
   }
   std::vector<size_t> left;

@@ -13,6 +13,7 @@ constexpr int kRetryInternal = -100;
 // the multi-kernel paths add on top of their scans.
 constexpr double kScanFixedS = 35e-6, kScanBytesPerS = 6.5e12;
 constexpr double kThresholdFixedS = 140e-6, kBatchFixedS = 180e-6, kBatchFlopsPerS = 135e12;
+constexpr double kNominateFlopsPerS = 1.0e15;  // K2b's bf16 pass when it is not HBM-bound (it is, at every shape measured)
 // K1m: one sweep carries up to 8 queries; a chain of sweeps pays the call's fixed cost once.  A
 // sweep is priced per (tile, 256-float panel) a resident wave works through -- 2.9 us each once
 // the chip streams, 4.5 us for a wave's first ones -- plus its prologue and list merges

@@ -41,6 +41,7 @@ struct Ctx {
   DevBuf<uint32_t> dBCount, dBOutCount;
   DevBuf<vt::Entry> dBOut;
   DevBuf<unsigned long long> dBNorm;
+  DevBuf<unsigned char> dBQimage;  // K2b: the batch's queries in bf16, fragment order
   PinnedBuf<float> hBQ, hBTau;
   PinnedBuf<uint32_t> hBCount, hBOutCount;
   PinnedBuf<vt::Entry> hBOut;
@@ -153,6 +154,7 @@ struct Shard {
   bool ctx0_busy = false;
   int metric = 0;
   int order = g_default_order;
+  int nominate = g_default_nominate;  // VT_NOMINATE_*
   // corpus
   uint32_t n = 0, cap = 0;
   long dim = -1;    // FlatIndex.dimension (None = -1)

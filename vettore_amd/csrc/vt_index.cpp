@@ -247,6 +247,16 @@ int vt_flat_set_reduce_order(vt_flat *h, int order) {
   });
 }
 
+int vt_flat_set_batch_nominate(vt_flat *h, int mode) {
+  return guarded([&]() -> int {
+  if (!h || (mode != VT_NOMINATE_F32 && mode != VT_NOMINATE_BF16)) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  for (auto &s : h->shards) s->nominate = mode;
+  return VT_OK;
+  });
+}
+int vt_flat_batch_nominate(const vt_flat *h) { return h && !h->shards.empty() ? h->shards[0]->nominate : -1; }
+
 int vt_flat_insert(vt_flat *h, const char *id, size_t id_len, const float *vector, size_t n) {
   return guarded([&]() -> int {
   if (!h || (!id && id_len) || (!vector && n)) return VT_ERR_ARGUMENT;
@@ -735,6 +745,13 @@ int vt_flat_get_profile(vt_flat *h, vt_profile *out, int reset) {
       t.prefix_launches += p.prefix_launches;
       t.prefix_ms += p.prefix_ms;
       t.prefix_bytes += p.prefix_bytes;
+      t.nominate_launches += p.nominate_launches;
+      t.nominate_ms += p.nominate_ms;
+      t.nominate_bytes += p.nominate_bytes;
+      t.nominate_flops += p.nominate_flops;
+      t.nominate_queries += p.nominate_queries;
+      t.nominate_second_passes += p.nominate_second_passes;
+      t.nominate_candidates += p.nominate_candidates;
       if (reset) c.prof = vt_profile{};
     });
   if (reset) h->xprof = vt_profile{};

@@ -475,6 +475,16 @@ def flat_set_reduce_order(index: FlatRef, order: int):
     return "ok" if st == 0 else _err(st)
 
 
+def flat_set_batch_nominate(index: FlatRef, mode: int):
+    """Which matrix-core pass nominates batch candidates: _lib.NOMINATE_BF16 (default) or NOMINATE_F32."""
+    st = _lib.load().vt_flat_set_batch_nominate(index.handle, mode)
+    return "ok" if st == 0 else _err(st)
+
+
+def flat_batch_nominate(index: FlatRef) -> int:
+    return int(_lib.load().vt_flat_batch_nominate(index.handle))
+
+
 def set_default_reduce_order(order: int):
     st = _lib.load().vt_set_default_reduce_order(order)
     return "ok" if st == 0 else _err(st)
