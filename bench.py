@@ -67,6 +67,8 @@ def parse():
                     help="run the all_gather exchange even on one rank (prices the multi-GPU merge step)")
     ap.add_argument("--stages", default="128", help="funnel mode: prefix lengths (collection.ex:660-672 default min(d,128))")
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--nominate", choices=["bf16", "f32"], default="bf16",
+                    help="batch mode: which matrix-core pass names the candidates (K2b bf16, HBM-bound / K2 FP32 MFMA)")
     ap.add_argument("--candidates", type=int, default=100)
     ap.add_argument("--reduce-order", choices=["pair", "avx", "seq", "sse2"], default="sse2",
                     help="lane order of wide::f32x8::reduce_add the kernels reproduce (include/vettore_flat.h)")
@@ -280,7 +282,22 @@ def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidat
         assert call(warmup + steps - 1, keep=True) == last and len(last[0]) == limit
     out = {"ms_per_step": dt / steps * 1e3, "value": steps * per / dt, "unit": "queries/s", "steps": steps, "warmup": warmup,
            "ms_per_step_with_event_timing": dt_profiled / steps * 1e3, "verified": True}
-    if mode == "batch":
+    if mode == "batch" and p["nominate_launches"]:
+        # K2b: candidates nominated with bf16 operands -- the pass is priced against HBM (one
+        # launch reads every row once for all 256 queries); hits are exact all the same
+        assert p["batch_launches"] == 0
+        launches = p["nominate_launches"]
+        ms = p["nominate_ms"] / launches
+        gbs = p["nominate_bytes"] / launches / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out["fallback_queries"] = p["batch_fallbacks"]
+        out["second_passes"] = p["nominate_second_passes"]
+        out["candidates_per_query"] = p["nominate_candidates"] / max(1, p["nominate_queries"])
+        out["roofline"] = {"bound": "hbm", "kernel": "bf16_scores_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_side_traffic("bf16_scores_kernel", len(ref), dim),
+                           "avg_launch_ms": ms, "algorithmic_bytes_per_launch": p["nominate_bytes"] / launches,
+                           "bf16_mfma_TFLOPs": p["nominate_flops"] / launches / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+        out["end_to_end_frac"] = p["nominate_bytes"] / launches / (dt / steps) / 1e9 / HBM_PEAK_GBS
+    elif mode == "batch":
         ms = p["batch_ms"] / max(1, p["batch_launches"])
         tf = p["batch_flops"] / max(1e-9, p["batch_ms"]) / 1e9
         out["fallback_queries"] = p["batch_fallbacks"]
@@ -303,6 +320,11 @@ def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidat
     return out
 
 
+def _lib_consts():
+    from vettore_amd import _lib
+    return _lib
+
+
 def normalized_queries(n, dim, seed):
     qs = np.random.default_rng(seed).uniform(-1, 1, size=(n, dim)).astype(np.float32)
     qs /= np.linalg.norm(qs.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
@@ -321,6 +343,7 @@ def run_side_mode(a, torch, nifs, device):
     else:
         ref = nifs.flat_new_cosine()
     nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
+    assert nifs.flat_set_batch_nominate(ref, _lib.NOMINATE_BF16 if a.nominate == "bf16" else _lib.NOMINATE_F32) == "ok"
     assert nifs.flat_load_device_matrix(ref, doc_ids(0, a.rows), x.data_ptr(), a.rows, a.dim) == ("ok", ())
     del x
     torch.cuda.empty_cache()
@@ -334,12 +357,13 @@ def run_side_mode(a, torch, nifs, device):
     r = leg(a, L, nifs, ref, a.mode, qs, a.steps, a.warmup, per=per, stages=stage_list, candidates=a.candidates, limit=a.limit)
     out = {"value": r["value"], "unit": "queries/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": {"batch": "f32", "funnel": "f64", "quantized": "u64"}[a.mode], "data": "synthetic",
+           "dtype": {"batch": "f32" if a.nominate == "f32" else "f32 (exact rescoring; bf16 nomination)", "funnel": "f64",
+                     "quantized": "u64"}[a.mode], "data": "synthetic",
            "roofline": r["roofline"]}
     if batch:
         out["metric"] = "queries/sec, flat dot top-%d, N=%d d=%d, batch=%d" % (a.limit, a.rows, a.dim, per)
-        out["config"] = {"workload": "index: :flat, metric: :dot, d=%d, N=%d, batch=%d queries (MFMA Q x D^T + exact rescoring)"
-                         % (a.dim, a.rows, per), "fallback_queries": r["fallback_queries"]}
+        out["config"] = {"workload": "index: :flat, metric: :dot, d=%d, N=%d, batch=%d queries (%s MFMA Q x D^T + exact rescoring)"
+                         % (a.dim, a.rows, per, a.nominate), "fallback_queries": r["fallback_queries"]}
     elif a.mode == "funnel":
         out["metric"] = "queries/sec, funnel_search (f64 cosine on prefix %s, keep %d, exact rerank top-%d), N=%d d=%d" % (
             a.stages, a.candidates, a.limit, a.rows, a.dim)
@@ -435,9 +459,18 @@ def side_legs(a, torch, nifs, L, device, main_ref):
     del x
     torch.cuda.empty_cache()
     qs = np.random.default_rng(SEED_QUERY + 3).uniform(-1, 1, size=(7 * 256, a.dim)).astype(np.float32)
+    # ... candidates nominated on the FP32 matrix cores (K2, the r01/r02 path, unchanged) ...
+    assert nifs.flat_set_batch_nominate(ref3, _lib_consts().NOMINATE_F32) == "ok"
     side["config3"] = dict(leg(a, L, nifs, ref3, "batch", qs, 5, 2, per=256),
-                           workload="index: :flat, metric: :dot, d=%d, N=%d, batch=256 queries (MFMA Q x D^T + exact rescoring)"
+                           workload="index: :flat, metric: :dot, d=%d, N=%d, batch=256 queries (FP32 MFMA Q x D^T + exact rescoring)"
                            % (a.dim, a.rows), dtype="f32")
+    # ... and on the bf16 matrix cores (K2b, the library's default since r03): same hits bit for bit
+    assert nifs.flat_set_batch_nominate(ref3, _lib_consts().NOMINATE_BF16) == "ok"
+    qs = np.random.default_rng(SEED_QUERY + 4).uniform(-1, 1, size=(24 * 256, a.dim)).astype(np.float32)
+    side["config3_bf16_nominate"] = dict(
+        leg(a, L, nifs, ref3, "batch", qs, 20, 4, per=256),
+        workload="index: :flat, metric: :dot, d=%d, N=%d, batch=256 queries (bf16 MFMA nomination, HBM-bound, + exact f32 rescoring)"
+        % (a.dim, a.rows), dtype="f32 (exact rescoring; bf16 nomination)")
     del ref3
     torch.cuda.empty_cache()
     side["seconds"] = round(time.perf_counter() - t0, 1)

@@ -141,13 +141,15 @@ def test_full_size_results_against_torch_brute_force(corpus, oracle_mod):
     del ref
 
 
-def test_config3_shape_dot_batch_equals_single_queries(corpus, oracle_mod):
+@pytest.mark.parametrize("nominate", ["bf16", "f32"])
+def test_config3_shape_dot_batch_equals_single_queries(corpus, oracle_mod, nominate):
     """configs[2] at its own shape: metric :dot on UN-normalised rows
     (the bench's `--mode batch` corpus: rows x U(8,24)), N=10M, d=768, ONE batch of 256 on the
-    `mfma_scores_kernel<8,...>` instance, where the acceptance bound eps ~ d |q| X actually
-    bites -- every query's hits equal its own flat_search bit for bit, the number of queries
-    the bound could not certify is reported, and a sample is checked against an f64 brute
-    force over all rows."""
+    `mfma_scores_kernel<8,...>` instance (nominate = f32: K2) and on `bf16_scores_kernel` (K2b,
+    the default: operands rounded to bf16, margin 2^-7 |q| X), where the acceptance bound
+    actually bites -- every query's hits equal its own flat_search bit for bit, the number of
+    queries the bound could not certify is reported, and a sample is checked against an f64
+    brute force over all rows."""
     torch, nifs, x, doc_ids, host = corpus
     g = torch.Generator(device=x.device)
     g.manual_seed(33)
@@ -155,14 +157,18 @@ def test_config3_shape_dot_batch_equals_single_queries(corpus, oracle_mod):
     x.mul_(scale)
     try:
         ref = _index(nifs, nifs.flat_new_inner_product, x, doc_ids, 0, N)
+        assert nifs.flat_set_batch_nominate(ref, {"f32": 1, "bf16": 2}[nominate]) == "ok"
         qs = np.random.default_rng(20260722).uniform(-1, 1, size=(256, D)).astype(np.float32)
         nifs.flat_set_profiling(ref, True)
         nifs.flat_get_profile(ref, reset=True)
         st, batch = nifs.flat_search_batch(ref, qs, 10)
         assert st == "ok" and len(batch) == 256
         prof = nifs.flat_get_profile(ref, reset=True)
-        print("config3 shape: batch_queries=%d fallbacks=%d" % (prof["batch_queries"], prof["batch_fallbacks"]))
-        assert prof["batch_queries"] == 256 and prof["batch_launches"] == 1
+        key = "nominate" if nominate == "bf16" else "batch"
+        print("config3 shape (%s): queries=%d fallbacks=%d second passes=%d candidates/query=%.0f" % (
+            nominate, prof[key + "_queries"], prof["batch_fallbacks"], prof["nominate_second_passes"],
+            prof["nominate_candidates"] / 256))
+        assert prof[key + "_queries"] == 256 and prof[key + "_launches"] == 1
         assert prof["batch_fallbacks"] <= 8          # the bound certifies (nearly) every query of this workload
         for i in range(256):
             single = nifs.flat_search(ref, qs[i], 10)[1]

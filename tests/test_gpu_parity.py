@@ -673,17 +673,24 @@ def test_binary_top_k_with_massive_ties(nifs, oracle_mod):
         assert got == want, limit
 
 
+NOMINATE = {"f32": 1, "bf16": 2}   # VT_NOMINATE_*: which matrix-core pass names the candidates
+
+
+@pytest.mark.parametrize("nominate", ["bf16", "f32"])
 @pytest.mark.parametrize("metric", [2, 3, 4, 0, 1, 5])
-def test_batched_search_equals_single_queries(nifs, oracle_mod, metric, monkeypatch):
-    """vt_flat_search_batch: dot-family metrics go through the FP32-MFMA candidate
-    pass + exact rescoring; every query must still equal the oracle bit for bit
-    (BASELINE.json configs[2] shape, scaled down).  L2 / L2^2 nominate by
-    2 q.x - |x|^2; manhattan has no GEMM form and takes the per-query path."""
+def test_batched_search_equals_single_queries(nifs, oracle_mod, metric, nominate, monkeypatch):
+    """vt_flat_search_batch: dot-family metrics go through a matrix-core candidate pass (K2b:
+    operands rounded to bf16, the default; K2: FP32 matrix cores) + exact rescoring; every query
+    must still equal the oracle bit for bit under both (BASELINE.json configs[2] shape, scaled
+    down).  L2 / L2^2 nominate by 2 q.x - |x|^2; manhattan has no GEMM form and takes the
+    per-query path."""
     monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")   # the cost model would send these small corpora to single scans
     n, d = 20000, 192
     x, ids = make_corpus(n, d, 500 + metric, metric == 2, oracle_mod, tie_block=48)
     packed = oracle_mod.pack_ids(ids)
     g = GpuIndex(nifs, metric)
+    assert nifs.flat_set_batch_nominate(g.ref, NOMINATE[nominate]) == "ok"
+    assert nifs.flat_batch_nominate(g.ref) == NOMINATE[nominate]
     unwrap(nifs.flat_load_matrix(g.ref, ids, x))
     rng = np.random.default_rng(8)
     nifs.flat_set_profiling(g.ref, True)
@@ -697,10 +704,13 @@ def test_batched_search_equals_single_queries(nifs, oracle_mod, metric, monkeypa
         for i in range(nq):
             assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, x, packed, qs[i], k)), (metric, nq, k, i)
     prof = nifs.flat_get_profile(g.ref)
+    key = "nominate" if nominate == "bf16" else "batch"
+    other = "batch" if nominate == "bf16" else "nominate"
+    assert prof[other + "_launches"] == 0, prof
     if metric != 5:
-        assert prof["batch_launches"] >= 5 and prof["batch_fallbacks"] <= prof["batch_queries"] // 10, prof
+        assert prof[key + "_launches"] >= 5 and prof["batch_fallbacks"] <= prof[key + "_queries"] // 10, prof
     else:
-        assert prof["batch_launches"] == 0
+        assert prof[key + "_launches"] == 0
     # validation order and empty cases follow flat_search
     assert nifs.flat_search_batch(g.ref, np.zeros((3, d + 1), np.float32), 5) == ("error", "dimension mismatch")
     bad = np.zeros((9, d), np.float32)
@@ -709,21 +719,79 @@ def test_batched_search_equals_single_queries(nifs, oracle_mod, metric, monkeypa
     assert unwrap(nifs.flat_search_batch(g.ref, bad, 0)) == [[]] * 9
 
 
-def test_batched_search_large_values_fall_back_safely(nifs, oracle_mod, monkeypatch):
+@pytest.mark.parametrize("nominate", ["bf16", "f32"])
+def test_batched_search_large_values_fall_back_safely(nifs, oracle_mod, nominate, monkeypatch):
     """Huge coordinates blow the error margin (or overflow the MFMA sum): the
     bound must refuse and the per-query path must still give the exact answer."""
     monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    scale = 1e18
     n, d = 6000, 64
     rng = np.random.default_rng(21)
-    x = (rng.uniform(-1, 1, size=(n, d)) * 1e18).astype(np.float32)
+    x = (rng.uniform(-1, 1, size=(n, d)) * scale).astype(np.float32)
     ids = [b"r%d" % i for i in range(n)]
     g = GpuIndex(nifs, 3)
+    assert nifs.flat_set_batch_nominate(g.ref, NOMINATE[nominate]) == "ok"
     unwrap(nifs.flat_load_matrix(g.ref, ids, x))
-    qs = (rng.uniform(-1, 1, size=(16, d)) * 1e18).astype(np.float32)
+    qs = (rng.uniform(-1, 1, size=(16, d)) * scale).astype(np.float32)
     got = unwrap(nifs.flat_search_batch(g.ref, qs, 5))
     packed = oracle_mod.pack_ids(ids)
     for i in range(16):
         assert bits(got[i]) == bits(oracle_mod.matrix_search(3, x, packed, qs[i], 5)), i
+
+
+@pytest.mark.parametrize("nominate", ["bf16", "f32"])
+def test_rows_that_round_to_infinity_in_bf16_are_not_lost(nifs, oracle_mod, nominate, monkeypatch):
+    """A coordinate at f32's largest value rounds to +inf in bf16; against a query that is zero
+    there the exact dot product is finite (and these rows are the best hits), the bf16 one is
+    inf * 0 = NaN and nominates nothing.  The handle knows its largest row norm: such a corpus
+    is never certified by K2b, the exact paths answer."""
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    n, d = 6000, 64
+    rng = np.random.default_rng(22)
+    x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    big = rng.choice(n, 12, replace=False)
+    x[big, 5] = np.float32(3.4028235e38)
+    x[big, 6] = 50.0                      # what makes them the best hits
+    ids = [b"r%d" % i for i in range(n)]
+    g = GpuIndex(nifs, 3)
+    assert nifs.flat_set_batch_nominate(g.ref, NOMINATE[nominate]) == "ok"
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    qs = rng.uniform(-1, 1, size=(16, d)).astype(np.float32)
+    qs[:, 5] = 0.0
+    qs[:, 6] = 1.0
+    got = unwrap(nifs.flat_search_batch(g.ref, qs, 5))
+    packed = oracle_mod.pack_ids(ids)
+    for i in range(16):
+        want = oracle_mod.matrix_search(3, x, packed, qs[i], 5)
+        assert bits(got[i]) == bits(want), i
+        assert {h[0] for h in got[i]} <= {ids[j] for j in big}
+
+
+@pytest.mark.parametrize("metric", [2, 3, 0])
+def test_bf16_nomination_second_pass(nifs, oracle_mod, metric, monkeypatch):
+    """K2b with a threshold that leaves no margin (VT_BF16_RANK = limit: tau is the k-th best
+    bf16 score itself): the bound cannot certify anything in the first pass, every query names
+    the threshold its k exact hits DO clear, and one more pass with those certifies them all --
+    same hits as the oracle, no query left to the single-query path."""
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    monkeypatch.setenv("VT_BF16_RANK", "10")
+    n, d = 30000, 256
+    x, ids = make_corpus(n, d, 900 + metric, metric == 2, oracle_mod, tie_block=0)
+    packed = oracle_mod.pack_ids(ids)
+    g = GpuIndex(nifs, metric)
+    assert nifs.flat_set_batch_nominate(g.ref, NOMINATE["bf16"]) == "ok"
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(77)
+    qs = rng.uniform(-1, 1, size=(40, d)).astype(np.float32)
+    if metric == 2:
+        qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+    nifs.flat_set_profiling(g.ref, True)
+    got = unwrap(nifs.flat_search_batch(g.ref, qs, 10))
+    for i in range(40):
+        assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, x, packed, qs[i], 10)), (metric, i)
+    prof = nifs.flat_get_profile(g.ref)
+    assert prof["nominate_launches"] == 2 and prof["nominate_second_passes"] == 1, prof
+    assert prof["batch_fallbacks"] == 0, prof
 
 
 @pytest.mark.parametrize("metric", [2, 0])
@@ -920,8 +988,13 @@ def test_padding_columns_of_a_small_batch_nominate_nothing(nifs, oracle_mod, mon
     x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
     ids = [b"doc-%d" % (i + 1) for i in range(n)]
     g = GpuIndex(nifs, 3)
+    assert nifs.flat_set_batch_nominate(g.ref, NOMINATE["f32"]) == "ok"   # (K2b always carries 256 columns: 248 padding ones)
     unwrap(nifs.flat_load_matrix(g.ref, ids, x))
     qs = rng.uniform(-1, 1, (32, d)).astype(np.float32)
+    out8 = unwrap(nifs.flat_search_batch(g.ref, qs[:8], 10))
+    for i in range(8):
+        assert bits(out8[i]) == bits(unwrap(nifs.flat_search(g.ref, qs[i], 10)))
+    assert nifs.flat_set_batch_nominate(g.ref, NOMINATE["bf16"]) == "ok"
     out8 = unwrap(nifs.flat_search_batch(g.ref, qs[:8], 10))
     for i in range(8):
         assert bits(out8[i]) == bits(unwrap(nifs.flat_search(g.ref, qs[i], 10)))

@@ -86,14 +86,14 @@ def main():
                 assert L.vt_flat_search(ref.handle, qs[j].ctypes.data_as(C.POINTER(C.c_float)), a.dim, a.limit, C.byref(h)) == 0
                 singles.append(bench.hits_of(L, h))
         wrong = sum(1 for j, s in enumerate(singles) if first[j] != s)
-        key = "nominate" if mode == "bf16" else "batch"
+        key = "nominate" if mode.startswith("bf16") else "batch"
         launches = max(1, p[key + "_launches"])
         ms = p[key + "_ms"] / launches
         out = {"mode": mode, "metric": a.metric, "rows": a.rows, "dim": a.dim, "batch": a.batch, "batches": a.batches,
                "ms_per_batch": dt / a.batches * 1e3, "queries_per_s": a.batch * a.batches / dt,
                "kernel_ms": ms, "launches": p[key + "_launches"], "fallbacks": p["batch_fallbacks"],
                "wrong_of_verified": [wrong, len(singles)]}
-        if mode == "bf16":
+        if mode.startswith("bf16"):
             out["GBps"] = p["nominate_bytes"] / launches / (ms * 1e-3) / 1e9 if ms else 0.0
             out["TFLOPs"] = p["nominate_flops"] / launches / (ms * 1e-3) / 1e12 if ms else 0.0
             out["second_passes"] = p["nominate_second_passes"]

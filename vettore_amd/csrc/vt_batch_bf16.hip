@@ -19,9 +19,29 @@
 // vmcnt + one raw s_barrier per chunk; 20 ds_read_b128, 8 conversions and 16 MFMAs per wave
 // and chunk.  k is permuted inside a chunk (lane half h owns k = 16h..16h+15, MFMA step s the
 // 8 of them at 8s) -- identically for both operands, so every product still meets its partner.
+//
+// What bounds it (tools/k2b_probe.hip, 6 M rows x 768): the DMA ring alone streams 6.7 TB/s,
+// the MFMA work alone (rows never fetched) takes 1.85-2.0 ms = 1.2-1.3 PFLOP/s -- what an
+// LDS-fed bf16 MFMA loop sustains on random data on this part, whose clock drops to ~1.6 GHz
+// under it -- and together 3.1 ms = 5.9-6.0 TB/s: the pass is co-limited, memory at ~0.73 of
+// the 8 TB/s peak with the matrix pipe busy ~60 % of the time.  Tried and dropped, each
+// measured in the same run: the rows staged through registers four chunks ahead instead of
+// LDS-DMA (128 KiB in flight per CU, hand-counted vmcnt like K1m: 3.19 ms against 3.08 -- depth
+// of the ring is not the limit); fragment reads issued one MFMA step ahead of their use,
+// across the barrier too (compute alone 2.06 ms against 2.07: not the fragment traffic either).
 #include "vt_common.cuh"
 
 #include <algorithm>
+#include <cstdlib>
+
+// Timing experiments (tools/k2b_probe.hip): only in builds made with -DVT_BATCH_TIMING_EXPERIMENTS;
+// results are garbage with any bit set.  1: no fragment reads / MFMAs, 2: no barrier, 4: no query
+// DMA, 8: no candidate append, 16: no row DMA.
+#ifdef VT_BATCH_TIMING_EXPERIMENTS
+#define VT_DBG(a, bit) ((a).debug & (bit))
+#else
+#define VT_DBG(a, bit) false
+#endif
 
 namespace vt {
 
@@ -82,6 +102,9 @@ __global__ __launch_bounds__(256) void q_image_kernel(const float *__restrict__ 
 // Cold path of the epilogue (as in vt_batch.hip): a score of this lane's 16 reaches tau.
 __device__ __forceinline__ void append_candidates(const BatchScoreArgs &a, f32x16 v, float tau, uint32_t qcol,
                                                   uint32_t row0, int h) {
+  // (the list addresses are loop-invariant; hoisted out of the tile loop they cost 16 registers
+  // this kernel does not have -- the compiler may not know where qcol comes from)
+  asm volatile("" : "+v"(qcol));
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const uint32_t row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -94,6 +117,62 @@ __device__ __forceinline__ void append_candidates(const BatchScoreArgs &a, f32x1
         cnd.row = row;
         a.cand[(size_t)qcol * a.cand_cap + pos] = cnd;
       }
+    }
+  }
+}
+
+// What a wave does with a finished 32-row x 256-query tile (C layout: column = lane & 31 =
+// query, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)): pass 0 writes the dense sample
+// matrix, pass 1 appends the scores that reach the query's threshold.
+template <bool DENSE>
+__device__ __forceinline__ void tile_epilogue(const BatchScoreArgs &a, f32x16 (&acc)[kNT], const float (&tau)[kNT],
+                                              uint32_t grow0, uint32_t srow0, int r, int h) {
+  // L2 family: the 32 row norms of this wave's tile.  The address is wave-uniform, so they come
+  // through the scalar cache (constant address space => s_load): a vector load here would sit in
+  // the same in-order queue as the row DMA, and the wait for it would drain the ring once per tile.
+  // (the norm column is as long as the slab's row capacity, a multiple of 32: a tile that starts
+  // below n_total ends inside it)
+  float xn[16];
+  if (a.xnorm2) {
+    typedef const __attribute__((address_space(4))) float *cfloat_p;
+    const uint32_t g0 = __builtin_amdgcn_readfirstlane(grow0);
+    if (g0 < a.n_total) {
+      cfloat_p xc = (cfloat_p)(uintptr_t)(a.xnorm2 + g0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int off = (i & 3) + 8 * (i >> 2);
+        const float lo = xc[off], hi = xc[off + 4];
+        xn[i] = h ? hi : lo;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xn[i] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) {
+    const uint32_t qcol = t * 32 + r;
+    f32x16 v = acc[t];
+    if (a.xnorm2) {
+      // L2 family: rank by s = 2 q.x - |x|^2 (larger s <=> smaller |q - x|^2)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = 2.0f * v[i] - xn[i];
+    }
+    if (DENSE) {
+      uint32_t qc2 = qcol;
+      asm volatile("" : "+v"(qc2));  // (as in append_candidates: no hoisted address arithmetic)
+      const uint32_t qcol = qc2;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const uint32_t off = (i & 3) + 8 * (i >> 2) + 4 * h;
+        // dense sample matrix [query][sample row]
+        a.sample[(size_t)qcol * a.sample_rows + srow0 + off] = grow0 + off < a.n_total ? v[i] : -INFINITY;
+      }
+    } else {
+      float mx = v[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, v[i]);
+      if (mx >= tau[t] && !VT_DBG(a, 8u)) append_candidates(a, v, tau[t], qcol, grow0, h);
     }
   }
 }
@@ -140,11 +219,15 @@ __global__ __launch_bounds__(kWavesB *kWave, 1) void bf16_scores_kernel(const Ba
     }
   };
   auto dma_chunk = [&](uint32_t c, int stage) {
+    if (!VT_DBG(a, 16u)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma16<true>(xlds0 + stage * kXStageBytes + i * 1024, xbase + (size_t)c * 128, xoff[i]);
+      for (int i = 0; i < 4; ++i) dma16<true>(xlds0 + stage * kXStageBytes + i * 1024, xbase + (size_t)c * 128, xoff[i]);
+    }
+    if (!VT_DBG(a, 4u)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      dma16<false>(lds0 + stage * kQStageBytes + (wid * 2 + i) * 1024, qimg + (size_t)c * kQStageBytes + i * 1024, qoff);
+      for (int i = 0; i < 2; ++i)
+        dma16<false>(lds0 + stage * kQStageBytes + (wid * 2 + i) * 1024, qimg + (size_t)c * kQStageBytes + i * 1024, qoff);
+    }
   };
   // DMA cursor; past the end of this block's sequence it stays on the last chunk, so the loop
   // body has no branches and the vmcnt arithmetic never changes
@@ -185,65 +268,44 @@ __global__ __launch_bounds__(kWavesB *kWave, 1) void bf16_scores_kernel(const Ba
       // my pieces of chunk m have landed (chunk m + 1's stay in flight), my reads of chunk m - 1
       // are done; behind the barrier that holds for every wave of the block
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kPiecesPerChunk) : "memory");
-      __builtin_amdgcn_s_barrier();
+      if (!VT_DBG(a, 2u)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       dma_chunk(__builtin_amdgcn_readfirstlane(dc), stage_a);
       dma_advance();
-
+      if (VT_DBG(a, 1u)) {
+        stage = stage == kStages - 1 ? 0 : stage + 1;
+        continue;
+      }
+      // All 20 fragment reads of the chunk go out before its first MFMA.  (Measured, compute
+      // alone on 6 M rows: reads a step or two ahead of their MFMAs 2.04 ms, all up front 2.07,
+      // reads of the next step under the MFMAs of this one, across the barrier too, 2.06 -- the
+      // fragment traffic is not what the time goes to: 1.3 PFLOP/s is what an LDS-fed bf16 MFMA
+      // loop on random data sustains on this part, the clock drops to ~1.6 GHz under it.)
       const unsigned char *xs = lds + stage * kXStageBytes;
       const unsigned char *qs = lds + stage * kQStageBytes + qfrag;
-      f32x4 x0 = *reinterpret_cast<const f32x4 *>(xs + xfrag[0]);
-      f32x4 x1 = *reinterpret_cast<const f32x4 *>(xs + xfrag[1]);
-      f32x4 x2 = *reinterpret_cast<const f32x4 *>(xs + xfrag[2]);
-      f32x4 x3 = *reinterpret_cast<const f32x4 *>(xs + xfrag[3]);
-      bf16x8 xb[2];
-      xb[0] = pack8(x0, x1);
-      xb[1] = pack8(x2, x3);
+      bf16x8 qv[2][kNT];
+      const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xs + xfrag[0]);
+      const f32x4 x1 = *reinterpret_cast<const f32x4 *>(xs + xfrag[1]);
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int t = 0; t < kNT; ++t) qv[0][t] = *reinterpret_cast<const bf16x8 *>(qs + (t * 2) * 1024);
+      const f32x4 x2 = *reinterpret_cast<const f32x4 *>(xs + xfrag[2]);
+      const f32x4 x3 = *reinterpret_cast<const f32x4 *>(xs + xfrag[3]);
 #pragma unroll
-        for (int t = 0; t < kNT; ++t) {
-          const bf16x8 qv = *reinterpret_cast<const bf16x8 *>(qs + (t * 2 + s) * 1024);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[s], qv, acc[t], 0, 0, 0);
-        }
+      for (int t = 0; t < kNT; ++t) qv[1][t] = *reinterpret_cast<const bf16x8 *>(qs + (t * 2 + 1) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8 xb0 = pack8(x0, x1), xb1 = pack8(x2, x3);
+#pragma unroll
+      for (int t = 0; t < kNT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb0, qv[0][t], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < kNT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb1, qv[1][t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       stage = stage == kStages - 1 ? 0 : stage + 1;
     }
 
-    // epilogue (C layout: column = lane & 31 = query, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5))
-    const uint32_t grow0 = tile_row0(k);
-    float xn[16];
-    if (a.xnorm2) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const uint32_t row = grow0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        xn[i] = a.xnorm2[row < a.n_total ? row : a.n_total - 1];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < kNT; ++t) {
-      const uint32_t qcol = t * 32 + r;
-      f32x16 v = acc[t];
-      if (a.xnorm2) {
-        // L2 family: rank by s = 2 q.x - |x|^2 (larger s <=> smaller |q - x|^2)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = 2.0f * v[i] - xn[i];
-      }
-      if (DENSE) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const uint32_t off = (i & 3) + 8 * (i >> 2) + 4 * h;
-          const uint32_t srow = (blockIdx.x + k * gridDim.x) * kRowsB + wid * 32 + off;
-          a.sample[(size_t)qcol * a.sample_rows + srow] = grow0 + off < a.n_total ? v[i] : -INFINITY;
-        }
-      } else {
-        float mx = v[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, v[i]);
-        if (mx >= tau[t]) append_candidates(a, v, tau[t], qcol, grow0, h);
-      }
-    }
+    tile_epilogue<DENSE>(a, acc, tau, tile_row0(k), (blockIdx.x + k * gridDim.x) * kRowsB + wid * 32, r, h);
   }
 }
+
 
 }  // namespace
 
@@ -258,26 +320,24 @@ hipError_t launch_batch_q_image(const float *Q, uint32_t ld, void *image, hipStr
   return hipGetLastError();
 }
 
+template <class K>
+hipError_t launch_one(K kern, size_t lds_bytes, const BatchScoreArgs &a, uint32_t blocks, hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesB * kWave), lds_bytes, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_batch_scores_bf16(const BatchScoreArgs &a0, bool dense, uint32_t blocks, hipStream_t s) {
   BatchScoreArgs a = a0;
+#ifndef VT_BATCH_TIMING_EXPERIMENTS
   a.debug = 0u;
+#endif
   if (a.ld % 32 != 0 || a.nq_pad != 256 || a.Qimage == nullptr) return hipErrorInvalidValue;
   const size_t lds_bytes = (size_t)kStages * (kQStageBytes + kXStageBytes);
-  const dim3 block(kWavesB * kWave);
-  if (dense) {
-    auto kern = bf16_scores_kernel<true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), block, lds_bytes, s, a);
-  } else {
-    auto kern = bf16_scores_kernel<false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), block, lds_bytes, s, a);
-  }
-  return hipGetLastError();
+  return dense ? launch_one(bf16_scores_kernel<true>, lds_bytes, a, blocks, s)
+               : launch_one(bf16_scores_kernel<false>, lds_bytes, a, blocks, s);
 }
 
 }  // namespace vt
