@@ -369,7 +369,11 @@ bool batch_uses_mfma(const Shard *ix, size_t nq, size_t limit) {
     double nq_pad = bf16 ? 256 : 32;
     while (nq_pad < (double)std::min<size_t>(nq, 256)) nq_pad *= 2;
     const double groups = std::ceil((double)nq / 256.0);
-    const double t_pass = bf16 ? std::max(1.1 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kNominateFlopsPerS)
+    // (K2b: the pass streams at ~0.85 of a plain scan's rate -- the matrix pipe is busy 60 % of
+    // the time beside it -- and every query adds a few hundred candidates to re-score: 6.5-6.9 ms
+    // per 256 queries at 30 GB where K1m's sweep of eight takes 5.5)
+    const double t_pass = bf16 ? std::max(1.2 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kNominateFlopsPerS) +
+                                     (double)std::min<size_t>(nq, 256) * 2.5e-6
                                : std::max(1.3 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kBatchFlopsPerS);
     double t_other = (double)nq * scan_seconds(bytes);
     if (multi_scan_applies(ix, limit)) t_other = std::min(t_other, multi_scan_seconds(ix, nq));
