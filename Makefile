@@ -19,11 +19,21 @@ DEVSRC  := vt_kernels vt_batch vt_batch_bf16 vt_scan_dot vt_scan_l2 vt_scan_misc
 DEVOBJ  := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(DEVSRC)))
 DEVHDR  := $(CSRC)/vt_device.h $(CSRC)/vt_common.cuh $(CSRC)/vt_scan.cuh
 
-all: $(LIBDIR)/libvettore_hip.so oracle
+all: $(LIBDIR)/libvettore_hip.so $(LIBDIR)/libvettore_hip_hooks.so oracle
 
 $(LIBDIR)/%.o: $(CSRC)/%.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+# Kernels that must not spill (tools/check_scratch.py says why): the build fails if one does.
+$(LIBDIR)/vt_scan_multi.o: $(CSRC)/vt_scan_multi.hip $(DEVHDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_scan_multi.resources
+	python3 tools/check_scratch.py $(LIBDIR)/vt_scan_multi.resources scan_multi_kernel
+$(LIBDIR)/vt_batch_bf16.o: $(CSRC)/vt_batch_bf16.hip $(DEVHDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_batch_bf16.resources
+	python3 tools/check_scratch.py $(LIBDIR)/vt_batch_bf16.resources bf16_scores_kernel
 
 HOSTHDR := $(wildcard $(CSRC)/host/*.h)
 $(LIBDIR)/vt_index.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h include/vettore_flat.h
@@ -31,6 +41,16 @@ $(LIBDIR)/vt_index.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h includ
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 $(LIBDIR)/libvettore_hip.so: $(DEVOBJ) $(LIBDIR)/vt_index.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread -ldl
+
+# The same library with the fault-injection hooks compiled into the host side (VT_TEST_FAIL_AFTER_ID_UPDATE,
+# VT_TEST_FOREIGN_ROWS): test infrastructure, loaded only by the two tests that need them
+# (VETTORE_HIP_LIB=...); the product library carries no such switch.
+$(LIBDIR)/vt_index_hooks.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h include/vettore_flat.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DVT_TEST_HOOKS -x hip -c $< -o $@
+
+$(LIBDIR)/libvettore_hip_hooks.so: $(DEVOBJ) $(LIBDIR)/vt_index_hooks.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread -ldl
 
 oracle:

@@ -100,3 +100,22 @@ def full_sort(rows, raw_fn, rank_fn, limit):
     scored = [(b(i), raw_fn(v)) for i, v in rows]
     scored.sort(key=lambda t: (total_key(rank_fn(t[1])), t[0]))
     return scored[:limit]
+
+
+def rerun_with_hooks_library(request):
+    """For the tests that need the fault-injection hooks: the product library has none, so the
+    test runs again in a child process whose vettore_amd loads lib/libvettore_hip_hooks.so (same
+    sources, host side built with -DVT_TEST_HOOKS).  Returns True in the parent (the child's
+    verdict has been asserted), False in the child (go on with the test body)."""
+    import subprocess
+    import sys
+    if os.environ.get("VETTORE_HIP_LIB"):
+        return False
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hooks = os.path.join(root, "vettore_amd", "lib", "libvettore_hip_hooks.so")
+    assert os.path.exists(hooks), "build it with `make` (libvettore_hip_hooks.so)"
+    env = dict(os.environ, VETTORE_HIP_LIB=hooks)
+    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", request.node.nodeid],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    return True

@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvettore_hip.so")
+# VETTORE_HIP_LIB: another build of the same library (e.g. lib/libvettore_hip_hooks.so, the one
+# with the fault-injection hooks two tests need); default: the product library beside this file
+LIB_PATH = os.environ.get("VETTORE_HIP_LIB") or os.path.join(_HERE, "lib", "libvettore_hip.so")
 
 VT_OK = 0
 ORDER_PAIR, ORDER_AVX, ORDER_SEQ, ORDER_SSE2 = 0, 1, 2, 3

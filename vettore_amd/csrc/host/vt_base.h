@@ -70,6 +70,23 @@ int guarded(F &&f) noexcept {
   }
 }
 
+// A mutation's body as a status: whatever it throws (an allocation failing half way through
+// the id table's change, say) comes back like any other failure, so that the caller's
+// "failed after it began => poisoned" rule sees it (an exception used to unwind
+// past that rule and leave a half-updated index usable).
+template <typename F>
+int no_throw(F &&f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc &) {
+    return fail(VT_ERR_NOMEM, "out of host memory");
+  } catch (const std::exception &e) {
+    return fail(VT_ERR_DEVICE, e.what());
+  } catch (...) {
+    return fail(VT_ERR_DEVICE, "unknown exception");
+  }
+}
+
 #define VT_TRY(expr)          \
   do {                        \
     int _s = (expr);          \

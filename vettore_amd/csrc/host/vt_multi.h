@@ -78,8 +78,13 @@ int read_single(vt_flat *h, unsigned need, size_t limit, F &&fn) {
   VT_TRY(shard_prepare(ix, need, limit));
   int st = fn(ix, ix->ctx);
   if (st == kEscalate) {
-    VT_TRY(shard_prepare(ix, need | NEED_STRICT_RANKS, limit));
+    // Under the exclusive lock nothing changes any more: whatever the body found stale a moment
+    // ago (a writer may have pushed the corpus past a threshold between the caller's look at it
+    // and this run, so that the body now wants norms it did not ask for) is brought up to date
+    // here, all of it, and the body runs once more.  kEscalate never leaves this function.
+    VT_TRY(shard_prepare(ix, need | NEED_STRICT_RANKS | NEED_NORMS, limit));
     st = fn(ix, ix->ctx);
+    if (st == kEscalate) return fail(VT_ERR_DEVICE, "internal: a search found its derived columns stale under the exclusive lock");
   }
   return st;
 }
@@ -613,7 +618,7 @@ int store_validated_rows(vt_flat *h, size_t count, const char *ids, const size_t
     Shard *ix = h->shards[0].get();
     if (ix->dim < 0) VT_TRY(index_set_dim(ix, d));
     bool began = false;
-    const int st = index_store_rows(ix, count, ids, id_off, src, &began);
+    const int st = no_throw([&]() -> int { return index_store_rows(ix, count, ids, id_off, src, &began); });
     if (st != VT_OK && began) h->poisoned = true;
     return st;
   }
@@ -638,7 +643,7 @@ int store_validated_rows(vt_flat *h, size_t count, const char *ids, const size_t
     RowSource sub = src;
     sub.pick = mine.data();
     bool b = false;
-    const int r = index_store_rows(ix, mine.size(), blob.data(), off.data(), sub, &b);
+    const int r = no_throw([&]() -> int { return index_store_rows(ix, mine.size(), blob.data(), off.data(), sub, &b); });
     began[s] = b ? 1 : 0;
     return r;
   });

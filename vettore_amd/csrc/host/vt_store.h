@@ -301,9 +301,11 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
   const uint32_t n_before = ix->n;
   std::vector<uint32_t> target(count);
   bool all_appended_in_order = true;
-  if (count > 1024) {
-    // bulk load: no rehash / regrowth inside the id loop -- but geometric, or a corpus that arrives
-    // in many appends re-hashes and re-copies its whole id table at every one of them (84 M ids: 15 s)
+  {
+    // Room for every new id BEFORE the index starts to change: no rehash / regrowth inside the id
+    // loop, and no allocation that could fail between the table's change and the rows' arrival
+    // (all sizes; geometric, or a corpus that arrives in many appends re-hashes and re-copies its
+    // whole id table at every one of them -- 84 M ids: 15 s).
     const size_t need = (size_t)ix->n + count;
     if (need * 10 > ix->row_of.slots() * 7) ix->row_of.reserve(std::max(need, 2 * ix->row_of.size()));
     if (need > ix->ids.capacity()) ix->ids.reserve(std::max(need, 2 * ix->ids.capacity()));
@@ -333,10 +335,12 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     }
   }
   const auto t_rows = std::chrono::steady_clock::now();
-  // (test hook: a device failure between the id table's change and the rows' arrival, the one
-  // window in which a mutation cannot be taken back -- tests/test_gpu_multishard.py checks that
-  // the handle is poisoned from then on)
+#ifdef VT_TEST_HOOKS
+  // (test hook, libvettore_hip_hooks.so only: a device failure between the id table's change and
+  // the rows' arrival, the one window in which a mutation cannot be taken back --
+  // tests/test_gpu_multishard.py checks that the handle is poisoned from then on)
   if (std::getenv("VT_TEST_FAIL_AFTER_ID_UPDATE")) return fail(VT_ERR_DEVICE, "injected failure after the id table changed");
+#endif
   if (count > kMaxDerivedDirty) {
     ix->bits_valid = false;
     ix->max_sqnorm = -1.0;
@@ -353,7 +357,10 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
       for (size_t i = 1; i < count && picks_dense; ++i) picks_dense = src.pick[i] == src.pick[0] + i;
     const float *first = src.device + (src.pick ? (size_t)src.pick[0] * d : 0);
     // (test hook: a one-GPU box has no other device to own the rows)
-    const bool foreign = device_of_pointer(src.device) != c.device || std::getenv("VT_TEST_FOREIGN_ROWS") != nullptr;
+    bool foreign = device_of_pointer(src.device) != c.device;
+#ifdef VT_TEST_HOOKS
+    foreign = foreign || std::getenv("VT_TEST_FOREIGN_ROWS") != nullptr;  // (libvettore_hip_hooks.so only)
+#endif
     if (foreign && ix->slab.mapped) {
       // Rows that live on another device of the node, bound for a mapped slab: only this device
       // has been given access to the slab's chunks (hipMemSetAccess), so a peer copy must not

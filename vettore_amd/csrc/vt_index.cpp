@@ -359,10 +359,12 @@ int vt_flat_delete(vt_flat *h, const char *id, size_t id_len) {
   if (!h->multi()) {
     Shard *ix = h->shards[0].get();
     VT_TRY(ix->ctx.bind());
-    st = shard_delete(ix, id, id_len, &began);
+    st = no_throw([&]() -> int { return shard_delete(ix, id, id_len, &began); });
   } else {
     const size_t s = shard_of(id ? id : "", id_len, h->shards.size());
-    st = on_shards(h, std::vector<size_t>{s}, [&](size_t t) -> int { return shard_delete(h->shards[t].get(), id, id_len, &began); });
+    st = on_shards(h, std::vector<size_t>{s}, [&](size_t t) -> int {
+      return no_throw([&]() -> int { return shard_delete(h->shards[t].get(), id, id_len, &began); });
+    });
     if (h->total() == 0) h->dim = -1;  // flat.rs:90-92: an emptied index forgets its dimension
   }
   if (st != VT_OK && began) h->poisoned = true;
