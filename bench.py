@@ -168,14 +168,18 @@ def cpu_baseline(dim, limit, budget_s):
             "queries_1": done, "queries_T": sum(counts), "seconds": dt1 + dtn}
 
 
-def measured_read_peak():
-    """GB/s of the plain read-only streaming kernel on this pool's MI355X
-    (tools/hbm_peak.hip, recorded in profiles/r01_hbm_peak.json), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_peak.json")) as f:
-            return float(json.load(f)["read_peak_GBps"])
-    except (OSError, ValueError, KeyError):
-        return None
+_READ_PEAK = {}
+
+
+def measured_read_peak(device=0):
+    """GB/s of the plainest read-only streaming kernel, measured HERE, in this run, on this box
+    (vt_device_read_peak: 8 GiB scratch buffer, best of 5 passes; VERDICT r2 weak #9 -- it used to
+    be quoted from a round-1 file).  None if the measurement fails."""
+    if device not in _READ_PEAK:
+        from vettore_amd import nifs
+        res = nifs.device_read_peak(device, 8 << 30, 5)
+        _READ_PEAK[device] = res[1] if res[0] == "ok" else None
+    return _READ_PEAK[device]
 
 
 def pmc_traffic(rows, dim):
@@ -208,6 +212,64 @@ def pmc_side_traffic(kernel, nbytes_or_flops_rows, dim):
     return None
 
 
+def verify_against_oracle(nifs, dim, order_code, limit=10):
+    """The checker of the side legs (they used to compare a call with a repeat of
+    itself).  A small resident side index -- 20 000 x dim cosine rows, enough for every leg to take
+    the kernels it takes at full size (K1, the Hamming histogram pass, the f64 prefix scan, K2b) --
+    answers one query per entry point, and each answer must equal the CPU oracle's composition of
+    the reference's functions bit for bit.  The oracle is test infrastructure: it checks, outside
+    every timed region; nothing measured runs through it."""
+    import oracle
+    oracle.build()
+    oracle.set_reduce_order(order_code)
+    try:
+        rng = np.random.default_rng(SEED_CORPUS + 77)
+        n = 20_000
+        x = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+        x[500:540] = x[500]                                     # a block of identical rows: the id bytes decide
+        x = np.stack([oracle.normalize_l2(r) for r in x])
+        ids = [b"doc-%d" % (i + 1) for i in range(n)]
+        ref = nifs.flat_new_cosine()
+        nifs.flat_set_reduce_order(ref, order_code)
+        assert nifs.flat_load_matrix(ref, ids, x) == ("ok", ())
+        packed = oracle.pack_ids(ids)
+        q = oracle.normalize_l2(rng.uniform(-1, 1, dim).astype(np.float32))
+        bits = lambda hits: [(h[0], np.float32(h[1]).tobytes()) for h in hits]  # noqa: E731
+        rows = [(ids[i], x[i]) for i in range(n)]
+        by_id = dict(rows)
+        out = {}
+        # flat_search (flat.rs:96-124)
+        out["single"] = bits(nifs.flat_search(ref, q, limit)[1]) == bits(oracle.matrix_search(2, x, packed, q, limit))
+        out["single_on_a_tie_block"] = bits(nifs.flat_search(ref, x[500], limit)[1]) == bits(oracle.matrix_search(2, x, packed, x[500], limit))
+        # quantized_search (collection.ex:276-295): binary_top_k over sign bits, then vector_top_k
+        words = (dim + 63) // 64
+        signs = np.zeros((n, words * 64), dtype=np.uint8)
+        signs[:, :dim] = x >= 0
+        packed_bits = np.packbits(signs, axis=1, bitorder="little").view(np.uint64)
+        cands = oracle.binary_top_k([(ids[i], packed_bits[i]) for i in range(n)], oracle.compress_sign_bits(q), dim, 100)
+        want = oracle.vector_top_k([(c, by_id[c]) for c, _ in cands], q, 2, dim, limit)
+        out["quantized"] = bits(nifs.flat_quantized_search(ref, q, 100, limit)[1]) == bits(want)
+        # funnel_search (collection.ex:245-260, :674-691): vector_top_k on the prefix, then on the full rows
+        stage = min(dim, 128)
+        kept = oracle.vector_top_k(rows, q, 2, stage, 100)
+        want = oracle.vector_top_k([(i, by_id[i]) for i, _ in kept], q, 2, dim, limit)
+        out["funnel"] = bits(nifs.flat_funnel_search(ref, q, [stage], 100, limit)[1]) == bits(want)
+        # a query batch through the matrix cores (both nominations) == the oracle's single searches
+        qs = np.stack([oracle.normalize_l2(v) for v in rng.uniform(-1, 1, (16, dim)).astype(np.float32)])
+        os.environ["VT_FORCE_BATCH_MFMA"] = "1"
+        try:
+            for name, mode in (("batch_bf16", 2), ("batch_f32", 1)):
+                nifs.flat_set_batch_nominate(ref, mode)
+                got = nifs.flat_search_batch(ref, qs, limit)[1]
+                out[name] = all(bits(got[i]) == bits(oracle.matrix_search(2, x, packed, qs[i], limit)) for i in range(16))
+        finally:
+            del os.environ["VT_FORCE_BATCH_MFMA"]
+        assert all(out.values()), out
+        return {"checker": "oracle/ (CPU restatement of flat.rs / search.rs / distances.rs)", "side_index_rows": n, "equal_bit_for_bit": out}
+    finally:
+        oracle.set_reduce_order(oracle.DEFAULT_ORDER)
+
+
 def hits_of(L, handle_ptr):
     """[(id, raw bits)] of a vt_hits handle (freed)."""
     from vettore_amd import nifs
@@ -217,9 +279,9 @@ def hits_of(L, handle_ptr):
 def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidates=100, limit=10):
     """Times `steps` calls of one entry point on the resident index `ref` (after `warmup`
     untimed ones) and returns {ms_per_step, value, roofline...} from the library's HIP-event
-    profile.  One result per leg is verified against the single-query path (batch) or
-    against a second run of itself (the other modes): a fast path that returns something
-    else cannot post a number."""
+    profile.  At full size a result per leg is compared with the single-query path (batch) or
+    with a second run of itself (the other modes); the entry point itself is checked against the
+    CPU oracle on a small side index by verify_against_oracle(), once per run."""
     import torch
     dim = qs.shape[1]
     outs = (C.c_void_p * per)()
@@ -426,6 +488,8 @@ def side_legs(a, torch, nifs, L, device, main_ref):
     the resident N-row cosine index of the headline leg."""
     side = {}
     t0 = time.perf_counter()
+    # every leg's entry point, once, against the oracle (a deterministic wrong answer cannot post a number)
+    side["verified_against_oracle"] = verify_against_oracle(nifs, a.dim, ORDER_CODE[a.reduce_order], a.limit)
     # config 5: quantized_search on the resident cosine corpus (sign bits are built by the first call)
     qs = normalized_queries(330, a.dim, SEED_QUERY + 5)
     side["config5"] = dict(leg(a, L, nifs, main_ref, "quantized", qs, 300, 30, candidates=100),
@@ -654,8 +718,8 @@ def main():
                 "traffic": pmc_traffic(count, a.dim),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": scan_ms,
-                "measured_read_peak": measured_read_peak(),
-                "frac_of_measured_read_peak": (achieved / measured_read_peak()) if measured_read_peak() else None,
+                "measured_read_peak": measured_read_peak(devices[0]),
+                "frac_of_measured_read_peak": (achieved / measured_read_peak(devices[0])) if measured_read_peak(devices[0]) else None,
             },
         }
         if shards_in_process > 1 or force_sharded:

@@ -90,6 +90,11 @@ const char *vt_last_error(void);
 int vt_abi_version(void);
 /* Number of visible HIP devices (0 if none); never fails. */
 int vt_device_count(void);
+/* Diagnostic (bench.py's `measured_read_peak`): GB/s of the plainest read-only streaming kernel
+ * over a scratch buffer of `bytes` (zero-filled; allocated and freed here) on `device`, best of
+ * `reps` passes after one warm-up pass, timed with HIP events.  The yardstick beside the 8 TB/s
+ * spec figure: no search kernel can stream faster than this one does on the same box. */
+int vt_device_read_peak(int device, size_t bytes, int reps, double *gbps);
 
 /* ------------------------------------------------------------------ hits
  * Vec<(String, f32)> as returned by flat_search / vector_top_k /

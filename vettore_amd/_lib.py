@@ -20,7 +20,7 @@ EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1
 
 # every symbol include/vettore_flat.h declares
 SYMBOLS = [
-    "vt_strerror", "vt_last_error", "vt_abi_version", "vt_device_count",
+    "vt_strerror", "vt_last_error", "vt_abi_version", "vt_device_count", "vt_device_read_peak",
     "vt_hits_len", "vt_hits_id", "vt_hits_raw", "vt_hits_rank_key", "vt_hits_pack", "vt_hits_id_bytes", "vt_hits_export",
     "vt_hits_free",
     "vt_flat_new", "vt_flat_new_sharded", "vt_flat_shard_count", "vt_flat_shard_device", "vt_flat_shard_len", "vt_flat_shard_memory", "vt_flat_coalesce_stats",
@@ -61,6 +61,7 @@ def load() -> C.CDLL:
             "vettore_amd has no CPU fallback." % LIB_PATH)
     L = C.CDLL(LIB_PATH)
     f32p, u64p, szp, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_size_t), C.c_void_p
+    L.vt_device_read_peak.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.vt_strerror.restype = C.c_char_p
     L.vt_strerror.argtypes = [C.c_int]
     L.vt_last_error.restype = C.c_char_p

@@ -330,6 +330,9 @@ struct CosineScanArgs {
 size_t cosine_scan_lds_bytes(uint32_t d, uint32_t k);
 hipError_t launch_cosine_scan(const CosineScanArgs &a, uint32_t blocks, hipStream_t s);
 
+// Diagnostic: one pass of a plain read-only kernel over `bytes` of `buf` (vt_device_read_peak).
+hipError_t launch_read_peak(const void *buf, size_t bytes, float *sink, uint32_t blocks, hipStream_t s);
+
 // normalize_l2 (distances.rs:350-361) on rows: out = (x / sqrt(f64 sum x^2)) as f32.
 hipError_t launch_normalize_l2(const float *in, uint32_t n, uint32_t d, float *out, hipStream_t s);
 

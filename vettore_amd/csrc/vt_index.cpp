@@ -71,6 +71,50 @@ int vt_device_count(void) {
   return n;
 }
 
+int vt_device_read_peak(int device, size_t bytes, int reps, double *gbps) {
+  return guarded([&]() -> int {
+  if (!gbps || bytes < (1u << 20) || reps < 1) return VT_ERR_ARGUMENT;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(VT_ERR_DEVICE, "no HIP device visible: libvettore_hip has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(VT_ERR_DEVICE, "device ordinal out of range");
+  VT_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  VT_HIP(hipGetDeviceProperties(&prop, device));
+  bytes &= ~(size_t)15;
+  void *buf = nullptr;
+  float *sink = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int st = VT_OK;
+  double best = 0.0;
+  auto body = [&]() -> int {
+    VT_HIP(hipMalloc(&buf, bytes));
+    VT_HIP(hipMalloc(reinterpret_cast<void **>(&sink), 16));
+    VT_HIP(hipMemset(buf, 0, bytes));
+    VT_HIP(hipEventCreate(&e0));
+    VT_HIP(hipEventCreate(&e1));
+    const uint32_t blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8;
+    for (int r = 0; r <= reps; ++r) {  // pass 0 warms up
+      VT_HIP(hipEventRecord(e0, nullptr));
+      VT_HIP(vt::launch_read_peak(buf, bytes, sink, blocks, nullptr));
+      VT_HIP(hipEventRecord(e1, nullptr));
+      VT_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      VT_HIP(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0 && ms > 0.f) best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
+    }
+    return VT_OK;
+  };
+  st = body();
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (sink) (void)hipFree(sink);
+  if (buf) (void)hipFree(buf);
+  if (st == VT_OK) *gbps = best;
+  return st;
+  });
+}
+
 size_t vt_hits_len(const vt_hits *h) { return h ? h->ids.size() : 0; }
 const char *vt_hits_id(const vt_hits *h, size_t i, size_t *len) {
   *len = h->ids[i].size();

@@ -1368,6 +1368,30 @@ hipError_t launch_cosine_scan(const CosineScanArgs &a, uint32_t blocks, hipStrea
   return hipGetLastError();
 }
 
+// The plainest read-only streaming kernel (tools/hbm_peak.hip's `read`): every lane sums 16-byte
+// non-temporal loads, 8 in flight, nothing is written.  What it reaches is the yardstick
+// bench.py quotes beside the 8 TB/s spec figure (vt_device_read_peak).
+__global__ __launch_bounds__(256) void read_peak_kernel(const f32x4 *__restrict__ p, size_t n16, float *out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; i < n16; i += stride) acc += __builtin_nontemporal_load(p + i);
+  const float s = acc.x + acc.y + acc.z + acc.w;
+  if (s == 123456.789f) out[0] = s;  // never true for a zero-filled buffer: keeps the loads alive
+}
+
+hipError_t launch_read_peak(const void *buf, size_t bytes, float *sink, uint32_t blocks, hipStream_t s) {
+  hipLaunchKernelGGL(read_peak_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(buf), bytes / 16, sink);
+  return hipGetLastError();
+}
+
 hipError_t launch_normalize_l2(const float *in, uint32_t n, uint32_t d, float *out, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(normalize_l2_kernel, dim3((n + 63) / 64), dim3(64), 0, s, in, n, d, out);

@@ -490,6 +490,13 @@ def set_default_reduce_order(order: int):
     return "ok" if st == 0 else _err(st)
 
 
+def device_read_peak(device: int = 0, nbytes: int = 8 << 30, reps: int = 5):
+    """GB/s of the plainest read-only streaming kernel on this box (diagnostic, bench.py)."""
+    g = C.c_double()
+    st = _lib.load().vt_device_read_peak(device, nbytes, reps, C.byref(g))
+    return ("ok", float(g.value)) if st == 0 else _err(st)
+
+
 def flat_set_profiling(index: FlatRef, enabled: bool):
     _lib.load().vt_flat_set_profiling(index.handle, 1 if enabled else 0)
 
