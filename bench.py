@@ -571,7 +571,9 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        import datetime
+        # (a collective that does not complete fails the run after two minutes instead of torch's ten)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=120))
     nifs.set_device(local_rank)
     if a.mode != "single":
         if a.gpus > 1:
@@ -641,7 +643,10 @@ def main():
         # the step is the C-ABI call itself (the hit list is freed, not unpacked into Python
         # objects -- a NIF would build BEAM terms here)
         st = L.vt_flat_search(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), a.dim, a.limit, C.byref(hp))
-        assert st == 0, st
+        if st != 0:
+            # (a wedged exchange arrives here as "RCCL exchange timed out on shard s ...": say so and
+            # leave with a non-zero status -- a fresh process is the only retry)
+            sys.exit("bench.py: flat_search failed with status %d: %s" % (st, (L.vt_last_error() or b"").decode()))
         n_hits = L.vt_hits_len(hp)
         L.vt_hits_free(hp)
         return range(n_hits)
@@ -722,7 +727,14 @@ def main():
                 "frac_of_measured_read_peak": (achieved / measured_read_peak(devices[0])) if measured_read_peak(devices[0]) else None,
             },
         }
+        if shards_in_process > 1 or force_sharded or launched:
+            # one line must be enough to read a bad scaling curve: the scan a shard does per query
+            # (HIP events, averaged over shards and steps) and everything else of a step -- query
+            # upload, select, worker hand-off, the exchange itself, D2H, host merge
+            out["config"]["per_shard_scan_ms"] = scan_ms
+            out["config"]["exchange_ms"] = dt / a.steps * 1e3 - scan_ms
         if shards_in_process > 1 or force_sharded:
+            out["config"]["exchange_note"] = nifs.flat_exchange_note(ref)
             out["config"]["devices"] = devices
             if len(set(devices)) < len(devices):
                 # several shards on one GPU: their scans overlap, a launch sees a share of the card

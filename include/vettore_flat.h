@@ -171,6 +171,11 @@ int vt_flat_route_ids(const vt_flat *index, size_t count, const char *ids, const
 enum { VT_EXCHANGE_HOST = 0, VT_EXCHANGE_RCCL = 1 };
 int vt_flat_set_exchange(vt_flat *index, int mode);
 int vt_flat_exchange(const vt_flat *index);
+/* Which exchange a multi-shard handle chose when it was created and, if RCCL was refused, why
+ * (one line, also printed on stderr at creation when VT_LOG is set).  Empty for a plain index.
+ * A search whose all-gather does not complete within VT_EXCHANGE_TIMEOUT_MS (default 20 000)
+ * fails with VT_ERR_DEVICE "RCCL exchange timed out on shard s ..." and poisons the handle. */
+const char *vt_flat_exchange_note(const vt_flat *index);
 /* Ranks of the shard communicator (ncclCommCount), 0 while none exists. */
 int vt_flat_rccl_ranks(const vt_flat *index);
 /* ResourceArc drop: frees HBM, streams, pinned staging. */

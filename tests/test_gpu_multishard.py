@@ -242,6 +242,39 @@ def test_rccl_exchange_with_a_one_rank_communicator(nifs, oracle_mod, monkeypatc
     assert nifs.flat_exchange(two.ref) == _lib.EXCHANGE_HOST and nifs.flat_rccl_ranks(two.ref) == 0
     res = nifs.flat_set_exchange(two.ref, _lib.EXCHANGE_RCCL)
     assert res[0] == "error" and "own device" in res[1]
+    # ... and each handle remembers what it chose and why (vt_flat_exchange_note)
+    assert "RCCL all-gather" in nifs.flat_exchange_note(g.ref) and "1 ranks" in nifs.flat_exchange_note(g.ref)
+    assert "share a device" in nifs.flat_exchange_note(two.ref)
+
+
+def test_a_wedged_exchange_times_out_with_a_message(nifs, oracle_mod, monkeypatch, request):
+    """The first 8-GPU run must not hang without a word if a collective never completes (VERDICT r2
+    next #7a): the wait behind a shard's all-gather has a deadline (VT_EXCHANGE_TIMEOUT_MS); past it
+    the search fails with "RCCL exchange timed out on shard s ...", the handle is poisoned (its
+    stream still holds the stuck collective).  The stall is injected in front of the all-gather
+    (VT_TEST_EXCHANGE_STALL_MS, libvettore_hip_hooks.so only: the test re-runs itself there)."""
+    if support.rerun_with_hooks_library(request):
+        return
+    import time
+    monkeypatch.setenv("VT_SHARD_FORCE_WORKERS", "1")
+    monkeypatch.setenv("VT_SHARD_EXCHANGE", "rccl")
+    monkeypatch.setenv("VT_EXCHANGE_TIMEOUT_MS", "250")     # (read once per process: before the first exchange)
+    g = ShardedIndex(nifs, 0, [0])
+    g.insert_many([("a", [0.0, 0.0]), ("b", [1.0, 0.0]), ("c", [2.0, 0.0])])
+    assert [h[0] for h in g.search([0.9, 0.0], 2)] == [b"b", b"a"]
+    monkeypatch.setenv("VT_TEST_EXCHANGE_STALL_MS", "1500")
+    t0 = time.perf_counter()
+    res = nifs.flat_search(g.ref, [0.9, 0.0], 2)
+    waited = time.perf_counter() - t0
+    assert res[0] == "error" and "RCCL exchange timed out on shard 0" in res[1], res
+    assert 0.2 < waited < 1.2, waited
+    monkeypatch.delenv("VT_TEST_EXCHANGE_STALL_MS")
+    assert nifs.flat_search(g.ref, [0.9, 0.0], 2) == ("error", "flat lock poisoned")
+    assert nifs.flat_insert(g.ref, "d", [3.0, 0.0]) == ("error", "flat lock poisoned")
+    time.sleep(1.6)                                         # the injected stall ends; the stream drains before the handle goes
+    fresh = ShardedIndex(nifs, 0, [0])                      # other handles (and their communicators) are unaffected
+    fresh.insert("x", [1.0, 1.0])
+    assert fresh.search([1.0, 1.0], 1) == [(b"x", 0.0)]
 
 
 def test_concurrent_searches_over_the_rccl_exchange_keep_their_own_lists(nifs, oracle_mod, monkeypatch):

@@ -24,7 +24,7 @@ SYMBOLS = [
     "vt_hits_len", "vt_hits_id", "vt_hits_raw", "vt_hits_rank_key", "vt_hits_pack", "vt_hits_id_bytes", "vt_hits_export",
     "vt_hits_free",
     "vt_flat_new", "vt_flat_new_sharded", "vt_flat_shard_count", "vt_flat_shard_device", "vt_flat_shard_len", "vt_flat_shard_memory", "vt_flat_coalesce_stats",
-    "vt_flat_route_ids", "vt_flat_set_exchange", "vt_flat_exchange", "vt_flat_rccl_ranks", "vt_flat_free", "vt_flat_insert", "vt_flat_insert_many", "vt_flat_delete",
+    "vt_flat_route_ids", "vt_flat_set_exchange", "vt_flat_exchange", "vt_flat_exchange_note", "vt_flat_rccl_ranks", "vt_flat_free", "vt_flat_insert", "vt_flat_insert_many", "vt_flat_delete",
     "vt_flat_search", "vt_flat_search_batch", "vt_flat_len", "vt_flat_dimension", "vt_flat_metric",
     "vt_flat_set_reduce_order", "vt_set_default_reduce_order", "vt_flat_set_batch_nominate", "vt_flat_batch_nominate",
     "vt_flat_load_matrix", "vt_flat_load_device_matrix", "vt_flat_quantized_search", "vt_flat_funnel_search", "vt_flat_hybrid_search",
@@ -97,6 +97,8 @@ def load() -> C.CDLL:
     L.vt_flat_route_ids.argtypes = [vp, C.c_size_t, C.c_char_p, szp, C.POINTER(C.c_uint32)]
     L.vt_flat_set_exchange.argtypes = [vp, C.c_int]
     L.vt_flat_exchange.argtypes = [vp]
+    L.vt_flat_exchange_note.argtypes = [vp]
+    L.vt_flat_exchange_note.restype = C.c_char_p
     L.vt_flat_rccl_ranks.argtypes = [vp]
     L.vt_flat_free.restype = None
     L.vt_flat_free.argtypes = [vp]

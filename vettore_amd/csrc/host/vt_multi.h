@@ -254,6 +254,59 @@ int exchange_setup(vt_flat *h) {
   return VT_OK;
 }
 
+// The wait behind a shard's all-gather, with a deadline.  A collective whose peers never arrive
+// (a rank that died, a link that wedged) would otherwise block this worker -- and with it the
+// caller, the handle and whoever drives the process -- until some outer timeout kills everything
+// without a word.  VT_EXCHANGE_TIMEOUT_MS (default 20 000; a scan of a full 288-GB card takes 45 ms).
+// On expiry the handle is poisoned: its streams still hold the stuck collective, nothing queued
+// behind it will ever run.  A fresh process is the only retry.
+int wait_exchange(vt_flat *h, Ctx &c, size_t shard) {
+  static const long timeout_ms = [] {
+    const char *e = std::getenv("VT_EXCHANGE_TIMEOUT_MS");
+    const long v = e ? std::atol(e) : 0;
+    return v > 0 ? v : 20000L;
+  }();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    const hipError_t e = hipStreamQuery(c.stream);
+    if (e == hipSuccess) return VT_OK;
+    if (e != hipErrorNotReady) {
+      (void)hipGetLastError();
+      return fail(VT_ERR_DEVICE, std::string("hipStreamQuery behind the exchange: ") + hipGetErrorString(e));
+    }
+    if ((spins & 63u) == 63u) {
+      const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (waited >= timeout_ms) {
+        h->poisoned = true;
+        return fail(VT_ERR_DEVICE, "RCCL exchange timed out on shard " + std::to_string(shard) + " (device " +
+                                       std::to_string(c.device) + ") after " + std::to_string(waited) +
+                                       " ms: the all-gather of the shards' top-k lists did not complete; the handle is unusable");
+      }
+    }
+    std::this_thread::yield();
+  }
+}
+
+#ifdef VT_TEST_HOOKS
+// (libvettore_hip_hooks.so only) VT_TEST_EXCHANGE_STALL_MS=<ms>: the shard's stream waits that long
+// on a flag before its all-gather -- what a peer that never arrives looks like from here
+int test_stall_exchange(Ctx &c) {
+  const char *e = std::getenv("VT_TEST_EXCHANGE_STALL_MS");
+  const long ms = e ? std::atol(e) : 0;
+  if (ms <= 0) return VT_OK;
+  uint32_t *flag = nullptr, *dflag = nullptr;
+  VT_HIP(hipHostMalloc(reinterpret_cast<void **>(&flag), sizeof(uint32_t), hipHostMallocMapped));
+  *flag = 0;
+  VT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dflag), flag, 0));
+  VT_HIP(hipStreamWaitValue32(c.stream, dflag, 1, hipStreamWaitValueGte, 0xFFFFFFFFu));
+  std::thread([flag, ms] {
+    std::this_thread::sleep_for(std::chrono::milliseconds(ms));
+    __atomic_store_n(flag, 1u, __ATOMIC_RELEASE);  // (leaked on purpose: the stream may look at it any time after)
+  }).detach();
+  return VT_OK;
+}
+#endif
+
 // flat_search on a multi-shard handle (shared lock held by the caller).
 int search_multi(vt_flat *h, const float *query, size_t n, size_t limit, vt_hits **out) {
   if (limit == 0) return empty_hits(out);  // flat.rs:97-101: before the query is looked at
@@ -282,11 +335,14 @@ int search_multi(vt_flat *h, const float *query, size_t n, size_t limit, vt_hits
         (void)hipMemcpyAsync(h->dBlock[s], head, sizeof head, hipMemcpyHostToDevice, c.stream);
         (void)hipStreamSynchronize(c.stream);
       }
+#ifdef VT_TEST_HOOKS
+      VT_TRY(test_stall_exchange(c));
+#endif
       const ncclResult_t rc = r.AllGather(h->dBlock[s], h->dGather[s], bytes, ncclChar, h->comms[s], c.stream);
       if (rc != ncclSuccess) return fail(VT_ERR_DEVICE, std::string("ncclAllGather: ") + r.GetErrorString(rc));
       if (s == 0)
         VT_HIP(hipMemcpyAsync(h->hGather.p, h->dGather[0], S * bytes, hipMemcpyDeviceToHost, c.stream));
-      VT_HIP(hipStreamSynchronize(c.stream));
+      VT_TRY(wait_exchange(h, c, s));
       if (s == 0) gathered.assign(h->hGather.p, h->hGather.p + S * bytes);
       VT_TRY(settle_begin_profile(c));
       return st;

@@ -355,7 +355,8 @@ struct vt_flat {
   // A mutation that failed on the device after it had begun changing the index leaves it
   // poisoned, like a panic under the reference's write lock: every later call fails with
   // "flat lock poisoned" (nifs.rs:269).
-  bool poisoned = false;
+  // (atomic: a reader that finds the exchange wedged sets it under the shared lock)
+  std::atomic<bool> poisoned{false};
   int metric = 0;
   long dim = -1;  // FlatIndex.dimension across all shards
   std::vector<std::unique_ptr<Shard>> shards;
@@ -364,6 +365,7 @@ struct vt_flat {
   std::mutex post_mu;  // jobs reach every worker's queue in one order (collectives must match up)
   int exchange = VT_EXCHANGE_HOST;
   bool exchange_forced = false;
+  std::string exchange_note;  // which exchange the handle chose when it was made, and why (vt_flat_exchange_note)
   std::vector<ncclComm_t> comms;
   bool comms_tried = false;
   size_t exch_limit = 0;  // entries the exchange blocks are sized for

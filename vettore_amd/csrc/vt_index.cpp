@@ -199,11 +199,25 @@ int vt_flat_new_sharded(int metric_code, const int *devices, size_t ndev, vt_fla
     const char *want = std::getenv("VT_SHARD_EXCHANGE");
     const bool want_host = want && std::string(want) == "host";
     const bool want_rccl = want && std::string(want) == "rccl";
-    if (!want_host && (distinct || want_rccl)) {
+    std::string note = std::to_string(ndev) + " shards: ";
+    if (want_host) {
+      note += "host exchange (VT_SHARD_EXCHANGE=host)";
+    } else if (!distinct && !want_rccl) {
+      note += "host exchange (several shards share a device: RCCL wants one rank per device)";
+    } else {
       const int st = exchange_setup(h.get());
-      if (st == VT_OK) h->exchange = VT_EXCHANGE_RCCL;
-      else if (want_rccl) return st;
+      if (st == VT_OK) {
+        h->exchange = VT_EXCHANGE_RCCL;
+        note += "RCCL all-gather of the per-shard top-k lists, " + std::to_string(vt_flat_rccl_ranks(h.get())) +
+                " ranks (ncclCommInitAll in this process); limits above 256, batches and staged searches take host-mapped lists";
+      } else if (want_rccl) {
+        return st;
+      } else {
+        note += "host exchange (RCCL refused: " + g_last_error + ")";
+      }
     }
+    h->exchange_note = note;
+    if (std::getenv("VT_LOG")) std::fprintf(stderr, "[vt] %s\n", note.c_str());
   }
   *out = h.release();
   return VT_OK;
@@ -269,6 +283,7 @@ int vt_flat_set_exchange(vt_flat *h, int mode) {
   });
 }
 int vt_flat_exchange(const vt_flat *h) { return h ? h->exchange : -1; }
+const char *vt_flat_exchange_note(const vt_flat *h) { return h ? h->exchange_note.c_str() : ""; }
 int vt_flat_rccl_ranks(const vt_flat *h) {
   if (!h || h->comms.empty() || !h->comms[0]) return 0;
   int n = 0;

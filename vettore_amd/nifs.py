@@ -218,6 +218,11 @@ def flat_exchange(index: FlatRef) -> int:
     return int(_lib.load().vt_flat_exchange(index.handle))
 
 
+def flat_exchange_note(index: FlatRef) -> str:
+    """Which exchange a multi-shard handle chose at creation, and why RCCL was refused if it was."""
+    return (_lib.load().vt_flat_exchange_note(index.handle) or b"").decode()
+
+
 def flat_rccl_ranks(index: FlatRef) -> int:
     return int(_lib.load().vt_flat_rccl_ranks(index.handle))
 
