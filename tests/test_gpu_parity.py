@@ -1033,9 +1033,9 @@ def test_limits_above_256_in_one_scan(nifs, oracle_mod, metric, forced, monkeypa
 @pytest.mark.parametrize("metric", [2, 0])
 def test_limits_above_4096_in_one_scan(nifs, oracle_mod, metric):
     """flat.ex:98-103 allows any limit below 2^32.  Above 4 096 hits the scan writes key and
-    payload columns, the radix threshold runs on the device and the host cuts and orders the
-    collected list: one scan, not one per 256 hits (the profile counts the launches).  70 000
-    hits exceed the device list: the pass-per-256 loop answers, same order."""
+    payload columns, an exact radix threshold (all 64 key bits) runs on the device and the host
+    orders the k collected entries: ONE scan whatever the limit (the profile counts the
+    launches) -- 70 000 of 90 000 rows, all of them, more than there are, usize::MAX."""
     n, d = 90_000, 24
     x, ids = make_corpus(n, d, 1500 + metric, metric == 2, oracle_mod, tie_block=700)
     g = GpuIndex(nifs, metric)
@@ -1043,7 +1043,7 @@ def test_limits_above_4096_in_one_scan(nifs, oracle_mod, metric):
     packed = oracle_mod.pack_ids(ids)
     rng = np.random.default_rng(18)
     nifs.flat_set_profiling(g.ref, True)
-    for limit, scans in ((5000, 1), (20000, 1), (65536, 1), (70000, None)):
+    for limit, scans in ((5000, 1), (20000, 1), (65536, 1), (70000, 1), (89_999, 1), (n, 1), (n + 5, 1), (2 ** 64 - 1, 1)):
         q = x[n // 2] if limit == 20000 else rng.uniform(-1, 1, d).astype(np.float32)
         if metric == 2:
             q = oracle_mod.normalize_l2(q)
@@ -1055,17 +1055,40 @@ def test_limits_above_4096_in_one_scan(nifs, oracle_mod, metric):
             assert prof["scan_launches"] == scans, (limit, prof["scan_launches"])
 
 
-def test_limit_above_256_with_more_ties_than_the_list_holds(nifs, oracle_mod, force_threshold):
-    """80 000 identical rows: every key shares its 33-bit prefix, the device list overflows and
-    the call must fall back to the pass-per-256 loop -- same answer as the oracle."""
+def test_limit_above_256_with_massive_ties(nifs, oracle_mod, force_threshold):
+    """80 000 identical rows: every key shares its rank (r02: the 33-bit threshold collected them
+    all, the device list overflowed, the call fell back to one scan per 256 hits).  The threshold
+    now resolves all 64 bits -- the id ranks cut the tie -- and the answer comes from one scan."""
     n, d = 80_000, 16
     x = np.tile(np.random.default_rng(3).uniform(-1, 1, (1, d)).astype(np.float32), (n, 1))
     ids = [b"doc-%d" % (i + 1) for i in range(n)]
     g = GpuIndex(nifs, 0)
     unwrap(nifs.flat_load_matrix(g.ref, ids, x))
     q = np.zeros(d, np.float32)
-    want = oracle_mod.matrix_search(0, x, oracle_mod.pack_ids(ids), q, 400)
-    assert bits(unwrap(nifs.flat_search(g.ref, q, 400))) == bits(want)
+    nifs.flat_set_profiling(g.ref, True)
+    for limit in (400, 4096, 30_000):
+        nifs.flat_get_profile(g.ref, reset=True)
+        want = oracle_mod.matrix_search(0, x, oracle_mod.pack_ids(ids), q, limit)
+        assert bits(unwrap(nifs.flat_search(g.ref, q, limit))) == bits(want)
+        assert nifs.flat_get_profile(g.ref, reset=True)["scan_launches"] <= 2, limit   # (+1: the winners' raw values re-scored)
+
+
+@pytest.mark.parametrize("metric", [7, 8])
+def test_few_distinct_values_at_limit_1000(nifs, oracle_mod, metric, force_threshold):
+    """Float hamming / jaccard take a handful of distinct values (limit 1000
+    cost 1.15 ms where the other metrics took 0.28 -- the tie list overflowed): one scan now."""
+    n, d = 70_000, 24
+    rng = np.random.default_rng(40 + metric)
+    x = (rng.uniform(-1, 1, (n, d)) * (rng.uniform(0, 1, (n, d)) < 0.5)).astype(np.float32)
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    q = x[7]
+    nifs.flat_set_profiling(g.ref, True)
+    nifs.flat_get_profile(g.ref, reset=True)
+    got = unwrap(nifs.flat_search(g.ref, q, 1000))
+    assert nifs.flat_get_profile(g.ref, reset=True)["scan_launches"] <= 2
+    assert bits(got) == bits(oracle_mod.matrix_search(metric, x, oracle_mod.pack_ids(ids), q, 1000))
 
 
 @pytest.mark.parametrize("metric", [2, 0])
@@ -1244,3 +1267,48 @@ def test_boundary_ties_after_a_bulk_load(nifs):
     for i, q in enumerate(dup):
         hits = unwrap(nifs.flat_search(g.ref, q, 1))
         assert hits[0][0] == min(b"doc-%d" % (i + 1), b"doc-%d" % (500_000 + i + 1))
+
+
+# ------------------------------------------------- the surface at the reference's limits
+@pytest.mark.parametrize("d", [4096, 5000, 9001])
+def test_jaccard_beyond_4095_dimensions(nifs, oracle_mod, d):
+    """distances.rs:327-347 has no bound on d.  The device packs (hamming count, non-zero count)
+    into one f32 per panel and carries them as integers across panels (r02: d >= 4096 was
+    VT_ERR_UNSUPPORTED)."""
+    n = 600
+    rng = np.random.default_rng(d)
+    x = (rng.uniform(-1, 1, (n, d)) * (rng.uniform(0, 1, (n, d)) < 0.3)).astype(np.float32)
+    x[5] = 0.0                                                       # an all-zero row: union with a zero query is empty
+    ids = [b"j-%d" % i for i in range(n)]
+    packed = oracle_mod.pack_ids(ids)
+    for metric in (8, 7):
+        g = GpuIndex(nifs, metric)
+        unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+        for q in (x[17], np.zeros(d, np.float32), (rng.uniform(-1, 1, d) * (rng.uniform(0, 1, d) < 0.5)).astype(np.float32)):
+            for limit in (1, 10, 300):
+                assert bits(g.search(q, limit)) == bits(oracle_mod.matrix_search(metric, x, packed, q, limit)), (metric, d, limit)
+        vecs = [(ids[i], x[i]) for i in range(50)]
+        assert bits(unwrap(nifs.vector_top_k(vecs, x[3], metric, d, 7))) == bits(oracle_mod.vector_top_k(vecs, x[3], metric, d, 7))
+
+
+@pytest.mark.parametrize("d", [24_000, 40_000])
+def test_rows_too_long_for_the_query_to_sit_in_lds(nifs, oracle_mod, d):
+    """flat.rs has no bound on the dimension.  Beyond ~24 000 floats the query no longer fits in
+    LDS beside the scan's panels: the run-time-op kernel then reads its query fragments from
+    global memory (r02: VT_ERR_UNSUPPORTED).  Every metric, bit for bit, plus batch and big limits."""
+    n = 400
+    rng = np.random.default_rng(d)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    x[9] = x[3]
+    ids = [b"w-%d" % i for i in range(n)]
+    packed = oracle_mod.pack_ids(ids)
+    q = rng.uniform(-1, 1, d).astype(np.float32)
+    for metric in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+        g = GpuIndex(nifs, metric)
+        unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+        for query, limit in ((q, 10), (x[3], 2), (q, n)):
+            assert bits(g.search(query, limit)) == bits(oracle_mod.matrix_search(metric, x, packed, query, limit)), (metric, d, limit)
+        if metric in (3, 5):
+            got = unwrap(nifs.flat_search_batch(g.ref, np.stack([q, x[3], x[100]]), 5))
+            for i, query in enumerate((q, x[3], x[100])):
+                assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, x, packed, query, 5))

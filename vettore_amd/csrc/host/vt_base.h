@@ -157,8 +157,8 @@ int validate_matrix(const float *rows, size_t count, size_t d, long expected) {
 inline bool id_less(const std::string &a, const std::string &b) { return a < b; }  // bytewise, like Rust String::cmp
 
 // Sorts `idx` with `less` on several threads (chunk sort + pairwise merges).
-template <typename Less>
-void parallel_sort(std::vector<uint32_t> &idx, Less less) {
+template <typename T, typename Less>
+void parallel_sort(std::vector<T> &idx, Less less) {
   const size_t n = idx.size();
   unsigned hw = std::thread::hardware_concurrency();
   size_t parts = 1;

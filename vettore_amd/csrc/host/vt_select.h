@@ -103,21 +103,29 @@ bool threshold_applies(size_t total, uint32_t n, double scan_bytes, double pass_
   return t_threshold < t_loop;
 }
 
-// Limits above kSelListMax (flat.ex:98-103 allows up to 2^32 - 1) in ONE scan: key and payload
-// columns, the device-side radix threshold, and the collected list -- every key up to the k-th
-// one's 33-bit prefix, a few more than k -- handed to the host as it is, which cuts and orders it
-// (nth_element + sort of ~k entries).  kRetryInternal: more ties at the threshold than the list
-// holds; the caller takes the pass-per-256 loop.
+// Limits above kSelListMax (flat.ex:98-103 allows any limit below 2^32) in ONE scan: key and
+// payload columns, an EXACT threshold on the device -- six radix passes resolve all 64 bits of
+// the k-th smallest key, so with the unique keys of a strictly ranked index the collect pass
+// leaves exactly the k winners however many rows tie in their rank (three passes, r02's rule,
+// left every key sharing the k-th one's 33-bit prefix: float hamming at limit 1000 overflowed the
+// list and fell to one scan per 256 hits) --, the list handed to the host as it is and ordered
+// there on several threads.  limit >= rows: there is nothing to cut, the two columns leave the
+// device whole.  kRetryInternal: more entries than asked for (equal keys: unranked rows) -- the
+// caller takes the pass-per-256 loop.
 int threshold_big(Ctx &c, const vt::ScanArgs &scan, uint32_t blocks, uint32_t n, uint32_t k, bool timed, uint32_t d,
                   std::vector<vt::Entry> &out) {
+  const bool all_rows = k >= n;
+  const size_t cap = all_rows ? (size_t)n : (size_t)k + 4096;  // (slack: equal keys are reported, not silently cut)
   VT_TRY(c.dKeyCol.ensure(((size_t)n + 1) / 2 * 2));
   VT_TRY(c.dPayCol.ensure(n));
-  VT_TRY(c.dRadixHist.ensure(3 * vt::kRadixBins));
+  VT_TRY(c.dRadixHist.ensure(6 * vt::kRadixBins));
   VT_TRY(c.dRadixCount.ensure(1));
-  VT_TRY(c.dPartKeys.ensure(kThresholdListCap));
-  VT_TRY(c.dPartPay.ensure(kThresholdListCap));
-  VT_TRY(c.hListKeys.ensure(kThresholdListCap));
-  VT_TRY(c.hListPay.ensure(kThresholdListCap));
+  if (!all_rows) {
+    VT_TRY(c.dPartKeys.ensure(cap));
+    VT_TRY(c.dPartPay.ensure(cap));
+  }
+  VT_TRY(c.hListKeys.ensure(cap));
+  VT_TRY(c.hListPay.ensure(cap));
   vt::ScanArgs a = scan;
   a.k = 1;
   a.key_out = c.dKeyCol.p;
@@ -125,24 +133,27 @@ int threshold_big(Ctx &c, const vt::ScanArgs &scan, uint32_t blocks, uint32_t n,
   if (timed) VT_HIP(hipEventRecord(c.ev0, c.stream));
   VT_HIP(vt::launch_scan(a, blocks, c.stream));
   if (timed) VT_HIP(hipEventRecord(c.ev1, c.stream));
-  VT_HIP(hipMemsetAsync(c.dRadixHist.p, 0, 3 * vt::kRadixBins * sizeof(uint32_t), c.stream));
-  vt::RadixArgs r{};
-  r.keys = c.dKeyCol.p;
-  r.n = n;
-  r.k = k;
-  r.hist = c.dRadixHist.p;
-  r.list_count = c.dRadixCount.p;
-  r.list_keys = c.dPartKeys.p;
-  r.list_pay = c.dPartPay.p;
-  r.cap = kThresholdListCap;
-  r.status = c.dStatus.p;
-  r.pay_col = c.dPayCol.p;
-  const uint32_t rblocks = (uint32_t)c.num_cus * 8;
-  for (int pass = 0; pass < 3; ++pass) VT_HIP(vt::launch_radix_pass(r, pass, rblocks, c.stream));
-  VT_HIP(vt::launch_radix_collect(r, rblocks, c.stream));
   uint32_t count = 0;
   int status = 0;
-  VT_HIP(hipMemcpyAsync(&count, c.dRadixCount.p, sizeof(count), hipMemcpyDeviceToHost, c.stream));
+  if (!all_rows) {
+    VT_HIP(hipMemsetAsync(c.dRadixHist.p, 0, 6 * vt::kRadixBins * sizeof(uint32_t), c.stream));
+    vt::RadixArgs r{};
+    r.keys = c.dKeyCol.p;
+    r.n = n;
+    r.k = k;
+    r.hist = c.dRadixHist.p;
+    r.list_count = c.dRadixCount.p;
+    r.list_keys = c.dPartKeys.p;
+    r.list_pay = c.dPartPay.p;
+    r.cap = (uint32_t)cap;
+    r.status = c.dStatus.p;
+    r.pay_col = c.dPayCol.p;
+    r.passes = 6;
+    const uint32_t rblocks = (uint32_t)c.num_cus * 8;
+    for (int pass = 0; pass < 6; ++pass) VT_HIP(vt::launch_radix_pass(r, pass, rblocks, c.stream));
+    VT_HIP(vt::launch_radix_collect(r, rblocks, c.stream));
+    VT_HIP(hipMemcpyAsync(&count, c.dRadixCount.p, sizeof(count), hipMemcpyDeviceToHost, c.stream));
+  }
   VT_HIP(hipMemcpyAsync(&status, c.dStatus.p, sizeof(status), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
   VT_HIP(hipStreamSynchronize(c.stream));
@@ -154,33 +165,39 @@ int threshold_big(Ctx &c, const vt::ScanArgs &scan, uint32_t blocks, uint32_t n,
     c.prof.scan_rows += n;
     c.prof.scan_bytes += (uint64_t)n * d * 4;
   }
-  if (status == vt::kStatusRetry || count > kThresholdListCap) return kRetryInternal;
   if (status == VT_ERR_OVERFLOW) return VT_ERR_OVERFLOW;
-  VT_HIP(hipMemcpyAsync(c.hListKeys.p, c.dPartKeys.p, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
-  VT_HIP(hipMemcpyAsync(c.hListPay.p, c.dPartPay.p, (size_t)count * sizeof(vt::Payload), hipMemcpyDeviceToHost, c.stream));
+  if (all_rows) count = n;
+  else if (status == vt::kStatusRetry || count > cap) return kRetryInternal;
+  const uint64_t *src_keys = all_rows ? c.dKeyCol.p : c.dPartKeys.p;
+  const vt::Payload *src_pay = all_rows ? c.dPayCol.p : c.dPartPay.p;
+  VT_HIP(hipMemcpyAsync(c.hListKeys.p, src_keys, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(c.hListPay.p, src_pay, (size_t)count * sizeof(vt::Payload), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(hipStreamSynchronize(c.stream));
-  std::vector<vt::Entry> list(count);
+  std::vector<vt::Entry> list;
+  list.reserve(count);
   for (uint32_t i = 0; i < count; ++i) {
-    list[i].key = c.hListKeys.p[i];
-    list[i].row = c.hListPay.p[i].row;
-    list[i].raw = c.hListPay.p[i].raw;
+    if (c.hListKeys.p[i] == vt::kEmptyKey) continue;
+    vt::Entry e;
+    e.key = c.hListKeys.p[i];
+    e.row = c.hListPay.p[i].row;
+    e.raw = c.hListPay.p[i].raw;
+    list.push_back(e);
   }
   const size_t take = std::min<size_t>(k, list.size());
-  auto by_key = [](const vt::Entry &x, const vt::Entry &y) { return x.key < y.key; };
-  std::nth_element(list.begin(), list.begin() + (take ? take - 1 : 0), list.end(), by_key);
-  std::sort(list.begin(), list.begin() + take, by_key);
-  out.assign(list.begin(), list.begin() + take);
+  parallel_sort(list, [](const vt::Entry &x, const vt::Entry &y) { return x.key < y.key; });
+  list.resize(take);
+  out = std::move(list);
   return VT_OK;
 }
 
 int threshold_rows(Ctx &c, uint32_t n, uint32_t k) {
-  VT_TRY(c.dRadixHist.ensure(3 * vt::kRadixBins));
+  VT_TRY(c.dRadixHist.ensure(6 * vt::kRadixBins));
   VT_TRY(c.dRadixCount.ensure(1));
   VT_TRY(c.dPartKeys.ensure(kThresholdListCap));
   VT_TRY(c.dPartPay.ensure(kThresholdListCap));
   VT_TRY(c.dListKeys.ensure(k));
   VT_TRY(c.dListPay.ensure(k));
-  VT_HIP(hipMemsetAsync(c.dRadixHist.p, 0, 3 * vt::kRadixBins * sizeof(uint32_t), c.stream));
+  VT_HIP(hipMemsetAsync(c.dRadixHist.p, 0, 6 * vt::kRadixBins * sizeof(uint32_t), c.stream));
   vt::RadixArgs r{};
   r.keys = c.dKeyCol.p;
   r.n = n;
@@ -191,8 +208,13 @@ int threshold_rows(Ctx &c, uint32_t n, uint32_t k) {
   r.list_pay = c.dPartPay.p;
   r.cap = kThresholdListCap;
   r.status = c.dStatus.p;
+  // all 64 bits: exactly the k smallest keys reach the list, whatever the number of rows that tie
+  // in their rank (float hamming / jaccard take a handful of distinct values: with the 33-bit
+  // threshold of r02 a limit of 1000 collected every row of the k-th value, overflowed the list and
+  // cost one scan per 256 hits -- 1.15 ms where the other metrics took 0.28)
+  r.passes = 6;
   const uint32_t blocks = (uint32_t)c.num_cus * 8;
-  for (int pass = 0; pass < 3; ++pass) VT_HIP(vt::launch_radix_pass(r, pass, blocks, c.stream));
+  for (int pass = 0; pass < 6; ++pass) VT_HIP(vt::launch_radix_pass(r, pass, blocks, c.stream));
   VT_HIP(vt::launch_radix_collect(r, blocks, c.stream));
   VT_HIP(vt::launch_select_list(c.dPartKeys.p, c.dPartPay.p, kThresholdListCap, c.dRadixCount.p, k, c.dListKeys.p,
                                 c.dListPay.p, c.stream));
@@ -204,8 +226,6 @@ int threshold_rows(Ctx &c, uint32_t n, uint32_t k) {
 int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out, bool count_profile) {
   if (vt::scan_lds_bytes(j.d, 1) == 0)
     return fail(VT_ERR_UNSUPPORTED, "dimension " + std::to_string(j.d) + " exceeds what the scan kernel stages in LDS");
-  if (j.metric == VT_JACCARD && j.d >= 4096)
-    return fail(VT_ERR_UNSUPPORTED, "jaccard on device supports d < 4096");
   const uint32_t tile_rows = vt::scan_tile_rows(j.n, j.d, c.resident_waves());
   const uint32_t ntiles = (j.n + tile_rows - 1) / tile_rows;
   // very wide rows leave no LDS for the large candidate buffer: smaller passes
@@ -213,8 +233,8 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
   uint64_t lo = 0;
   bool has_lo = false;
   const size_t total = std::min<size_t>(want, j.n);
-  if (!j.gather && out.empty() && total > (size_t)vt::kSelListMax && total <= (size_t)kThresholdListCap &&
-      j.n >= kThresholdMinRows && !std::getenv("VT_NO_THRESHOLD_SELECT")) {
+  if (!j.gather && out.empty() && total > (size_t)vt::kSelListMax && j.n >= kThresholdMinRows &&
+      !std::getenv("VT_NO_THRESHOLD_SELECT")) {
     vt::ScanArgs a{};
     a.X = j.X;
     a.stride = j.stride;

@@ -493,11 +493,27 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
 
 int make_hits(const Shard *ix, const std::vector<vt::Entry> &entries, vt_hits **out) {
   auto h = std::make_unique<vt_hits>();
-  h->ids.reserve(entries.size());
-  for (const auto &e : entries) {
-    h->ids.push_back(ix->ids[e.row]);
-    h->raw.push_back(e.raw);
-    h->rank_key.push_back(rank_key_of(e.key));
+  const size_t m = entries.size();
+  if (m >= (1u << 17)) {
+    // limits in the hundreds of thousands (flat.ex:98-103 allows them): the id copies are most of
+    // the call -- one string per hit, picked from all over the table -- so they go on several threads
+    h->ids.resize(m);
+    h->raw.resize(m);
+    h->rank_key.resize(m);
+    parallel_for(m, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) {
+        h->ids[i] = ix->ids[entries[i].row];
+        h->raw[i] = entries[i].raw;
+        h->rank_key[i] = rank_key_of(entries[i].key);
+      }
+    });
+  } else {
+    h->ids.reserve(m);
+    for (const auto &e : entries) {
+      h->ids.push_back(ix->ids[e.row]);
+      h->raw.push_back(e.raw);
+      h->rank_key.push_back(rank_key_of(e.key));
+    }
   }
   *out = h.release();
   return VT_OK;

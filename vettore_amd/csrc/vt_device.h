@@ -120,8 +120,9 @@ hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hi
 // Lists of >= kSelTwoLevelMin keys are selected in two levels (kSelGroups blocks on
 // slices, then one block); scratch_keys/scratch_pay hold kSelGroups * k entries.
 // Exact k-th smallest of a key column by three 11-bit radix passes over the top 33 bits
-// (the whole rank key and the top id-rank bit), all decisions taken on the device:
-// launch_radix_pass for pass = 0, 1, 2 (hist zeroed beforehand), then launch_radix_collect
+// (the whole rank key and the top id-rank bit) -- or six passes over all 64 bits (RadixArgs.passes)
+// --, all decisions taken on the device:
+// launch_radix_pass for pass = 0, 1, 2 (.. 5) (hist zeroed beforehand), then launch_radix_collect
 // appends every key below the resolved 33-bit prefix, and the keys sharing it, to a list
 // (positions as payload rows); the caller selects the k best of that list.  A list overflow
 // raises kStatusRetry in *status.
@@ -137,6 +138,11 @@ struct RadixArgs {
   uint32_t cap;
   int *status;
   const Payload *pay_col;  // optional: per-position payload whose raw value travels with a collected key
+  // 3 (default when 0): the threshold is the k-th key's top 33 bits (its whole rank and the top
+  // id-rank bit), keys sharing them are all collected.  6: all 64 bits -- with unique keys the
+  // collect pass leaves exactly the k smallest, however many rows tie in their rank
+  // (hist then holds 6 * kRadixBins counters).
+  int passes;
 };
 hipError_t launch_radix_pass(const RadixArgs &a, int pass, uint32_t blocks, hipStream_t s);
 hipError_t launch_radix_collect(const RadixArgs &a, uint32_t blocks, hipStream_t s);

@@ -982,8 +982,13 @@ struct RadixPrefix {
   uint32_t krem;
 };
 
+// Digit q of a key: eleven bits from the top down, the sixth and last one the nine that remain
+// (q = 0..2 cover the rank and the top id-rank bit, q = 3..5 the rest of the id rank).
+__device__ __forceinline__ int radix_shift(int q) { return q < 5 ? 53 - 11 * q : 0; }
+__device__ __forceinline__ uint32_t radix_digit_mask(int q) { return q < 5 ? kRadixBins - 1 : 511u; }
+
 // Bin of `hist` holding the krem-th smallest (1-based), by one wave; updates krem.
-__device__ __forceinline__ uint32_t radix_find_bin(const uint32_t *hist, uint32_t *krem, int lane) {
+__device__ __forceinline__ uint32_t radix_find_bin(const uint32_t *hist, uint32_t *krem, int lane, uint32_t last_bin) {
   constexpr uint32_t B = kRadixBins / kWave;  // bins per lane
   uint32_t mine = 0;
   for (uint32_t j = 0; j < B; ++j) mine += hist[lane * B + j];
@@ -1009,7 +1014,7 @@ __device__ __forceinline__ uint32_t radix_find_bin(const uint32_t *hist, uint32_
   const uint64_t m = __ballot(bin != 0xFFFFFFFFu);
   const int src = m ? __ffsll((long long)m) - 1 : 0;
   const uint32_t rbin = __shfl(bin, src, kWave), rbelow = __shfl(below, src, kWave);
-  if (!m) return kRadixBins - 1;
+  if (!m) return last_bin;
   *krem = k - rbelow;
   return rbin;
 }
@@ -1027,10 +1032,10 @@ __device__ __forceinline__ RadixPrefix radix_prefix(const RadixArgs &a, int pass
     __syncthreads();
     if (threadIdx.x < kWave) {
       uint32_t krem = p.krem;
-      const uint32_t bin = radix_find_bin(lds_hist, &krem, lane);
-      const int shift = 53 - 11 * q;
+      const uint32_t bin = radix_find_bin(lds_hist, &krem, lane, radix_digit_mask(q));
+      const int shift = radix_shift(q);
       p.prefix |= (uint64_t)bin << shift;
-      p.mask |= (uint64_t)(kRadixBins - 1) << shift;
+      p.mask |= (uint64_t)radix_digit_mask(q) << shift;
       p.krem = krem;
       if (threadIdx.x == 0) *s_out = p;
     }
@@ -1048,17 +1053,18 @@ __global__ __launch_bounds__(256) void radix_pass_kernel(const RadixArgs a, int 
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < kRadixBins; i += blockDim.x) lds_hist[i] = 0;
   __syncthreads();
-  const int shift = 53 - 11 * pass;
+  const int shift = radix_shift(pass);
+  const uint32_t dmask = radix_digit_mask(pass);
   const u64x2 *k2 = reinterpret_cast<const u64x2 *>(a.keys);
   const uint32_t n2 = a.n / 2;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += gridDim.x * blockDim.x) {
     const u64x2 v = k2[i];
-    if ((v.x & p.mask) == p.prefix) atomicAdd(&lds_hist[(uint32_t)(v.x >> shift) & (kRadixBins - 1)], 1u);
-    if ((v.y & p.mask) == p.prefix) atomicAdd(&lds_hist[(uint32_t)(v.y >> shift) & (kRadixBins - 1)], 1u);
+    if ((v.x & p.mask) == p.prefix) atomicAdd(&lds_hist[(uint32_t)(v.x >> shift) & dmask], 1u);
+    if ((v.y & p.mask) == p.prefix) atomicAdd(&lds_hist[(uint32_t)(v.y >> shift) & dmask], 1u);
   }
   if ((a.n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) {
     const uint64_t v = a.keys[a.n - 1];
-    if ((v & p.mask) == p.prefix) atomicAdd(&lds_hist[(uint32_t)(v >> shift) & (kRadixBins - 1)], 1u);
+    if ((v & p.mask) == p.prefix) atomicAdd(&lds_hist[(uint32_t)(v >> shift) & dmask], 1u);
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < kRadixBins; i += blockDim.x) {
@@ -1070,7 +1076,7 @@ __global__ __launch_bounds__(256) void radix_pass_kernel(const RadixArgs a, int 
 __global__ __launch_bounds__(256) void radix_collect_kernel(const RadixArgs a) {
   __shared__ uint32_t lds_hist[kRadixBins];
   __shared__ RadixPrefix s_p;
-  const RadixPrefix p = radix_prefix(a, 3, lds_hist, &s_p);
+  const RadixPrefix p = radix_prefix(a, a.passes == 6 ? 6 : 3, lds_hist, &s_p);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
     const uint64_t v = a.keys[i];
     if (v != kEmptyKey && (v & p.mask) <= p.prefix) {
@@ -1110,7 +1116,18 @@ __global__ __launch_bounds__(64) void normalize_l2_kernel(const float *__restric
 
 size_t scan_lds_for(const ScanShape &p, uint32_t k) {
   const size_t buf = k <= (uint32_t)kSmallK ? WaveTopK<kCapSmall>::lds_bytes() : WaveTopK<kCapLarge>::lds_bytes();
-  return ((size_t)p.ld + (size_t)kWavesPerBlock * kTileRows * p.ss) * sizeof(float) + kWavesPerBlock * buf;
+  return ((size_t)(p.q_global ? 0u : p.ld) + (size_t)kWavesPerBlock * kTileRows * p.ss) * sizeof(float) + kWavesPerBlock * buf;
+}
+
+// A row too long for the query to share LDS with the panels: the query stays in global memory
+// (ScanShape.q_global) and the run-time-op kernel serves the scan.  Returns the LDS bytes.
+size_t scan_fit(ScanShape &p, uint32_t k) {
+  size_t bytes = scan_lds_for(p, k);
+  if (bytes > kMaxLds) {
+    p.q_global = 1;
+    bytes = scan_lds_for(p, k);
+  }
+  return bytes;
 }
 
 }  // namespace
@@ -1118,7 +1135,7 @@ size_t scan_lds_for(const ScanShape &p, uint32_t k) {
 size_t scan_lds_bytes(uint32_t d, uint32_t k) {
   ScanShape p;
   if (!make_scan_shape(d, 1, &p)) return 0;
-  const size_t bytes = scan_lds_for(p, k);
+  const size_t bytes = scan_fit(p, k);
   return bytes <= kMaxLds ? bytes : 0;
 }
 
@@ -1148,10 +1165,10 @@ hipError_t launch_scan(const ScanArgs &a, uint32_t blocks, hipStream_t s) {
   sd.a = a;
   if (!make_scan_shape(a.d, a.n, &sd.p, a.tile_rows ? a.tile_rows : (uint32_t)kTileRows)) return hipErrorInvalidValue;
   sd.p.tile_floats = sd.p.tr * (uint32_t)a.stride;
-  const size_t lds = scan_lds_for(sd.p, a.k);
+  const size_t lds = scan_fit(sd.p, a.k);
   if (lds > kMaxLds || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.stride < sd.p.ld || a.stride % 4 != 0)
     return hipErrorInvalidValue;
-  if (a.gather != nullptr) return launch_scan_general(sd, blocks, 1, lds, s);
+  if (a.gather != nullptr || sd.p.q_global) return launch_scan_general(sd, blocks, 1, lds, s);
   const bool padded = (a.d % kRowAlign) != 0;
   switch (metric_op(a.metric)) {
     case OP_DOT: return launch_scan_dot(sd, blocks, lds, padded, s);
@@ -1167,14 +1184,14 @@ hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hi
   // list over more waves (a 32-row tile is ~25 us of one wave's load latency)
   if (!make_scan_shape(a.d, a.batch_cap, &sd.p, 8)) return hipErrorInvalidValue;
   sd.p.tile_floats = sd.p.tr * (uint32_t)a.stride;
-  const size_t lds = scan_lds_for(sd.p, a.k);
+  const size_t lds = scan_fit(sd.p, a.k);
   if (lds > kMaxLds || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.stride < sd.p.ld || !a.gather || !a.batch_counts)
     return hipErrorInvalidValue;
   return launch_scan_general(sd, blocks, nq, lds, s);
 }
 
 hipError_t launch_radix_pass(const RadixArgs &a, int pass, uint32_t blocks, hipStream_t s) {
-  if (pass < 0 || pass > 2 || a.n == 0 || a.k == 0 || ((uintptr_t)a.keys & 15)) return hipErrorInvalidValue;
+  if (pass < 0 || pass >= (a.passes == 6 ? 6 : 3) || a.n == 0 || a.k == 0 || ((uintptr_t)a.keys & 15)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(radix_pass_kernel, dim3(blocks), dim3(256), 0, s, a, pass);
   return hipGetLastError();
 }

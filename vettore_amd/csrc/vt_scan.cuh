@@ -51,6 +51,10 @@ struct ScanShape {
   uint32_t segs;       // 1-KiB segments per panel of a tile = pc * tr / 32 (multiple of kU)
   uint32_t segs_last;
   uint32_t tile_floats;  // tr * row stride (contiguous scans)
+  // Rows too long for the query to sit in LDS beside the panels (d beyond ~24 000: the reference
+  // answers any d): the run-time-op kernel reads its query fragments from global memory instead
+  // (4 d bytes, cache-resident) -- slower per load, no bound on d.
+  uint32_t q_global;
 };
 
 // `tile_rows`: 32, 16 or 8 requested by the caller; a height whose panels are not a
@@ -82,6 +86,7 @@ inline bool make_scan_shape(uint32_t d, uint32_t n, ScanShape *out, uint32_t til
   p.segs = p.pc * tr / 32;
   p.segs_last = p.pc_last * tr / 32;
   p.tile_floats = 0;  // set by the launcher (needs the row stride)
+  p.q_global = 0;
   p.ntiles = (n + tr - 1) / tr;
   *out = p;
   return true;
@@ -196,9 +201,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
   const int lane = threadIdx.x & (kWave - 1);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int odd = lane & 1;
-  float *qs = lds;
-  float *S = lds + p.ld + wib * (kTileRows * p.ss);
-  unsigned char *tkbuf = reinterpret_cast<unsigned char *>(lds + p.ld + kWavesPerBlock * (kTileRows * p.ss)) +
+  const bool q_global = GENERAL && p.q_global;  // (only the run-time-op build carries this mode)
+  const uint32_t q_lds = q_global ? 0u : p.ld;
+  float *S = lds + q_lds + wib * (kTileRows * p.ss);
+  unsigned char *tkbuf = reinterpret_cast<unsigned char *>(lds + q_lds + kWavesPerBlock * (kTileRows * p.ss)) +
                          wib * WaveTopK<CAP>::lds_bytes();
 
   // batch mode (gathered scans): blockIdx.y selects the query and its row list
@@ -214,7 +220,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
     gather += (size_t)b * a.batch_cap * a.gather_stride;
     list_base = b * gridDim.x;
   }
-  for (uint32_t i = threadIdx.x; i < p.ld; i += blockDim.x) qs[i] = qsrc[i];
+  if (!q_global)
+    for (uint32_t i = threadIdx.x; i < p.ld; i += blockDim.x) lds[i] = qsrc[i];
+  const float *qs = q_global ? qsrc : lds;
   __syncthreads();
 
   const int op_rt = metric_op(a.metric);
@@ -300,6 +308,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       if (row_valid && a.id_rank) my_rank = a.id_rank[src_row];
 
       float acc = 0.0f;
+      // jaccard: (hamming count + 4096 * non-zero count) is exact in f32 within a panel (<= 776
+      // columns); across panels the two counts are carried as integers, so d is not bounded by it
+      uint32_t jac_ham = 0, jac_xnz = 0;
+      const bool jaccard = OP == OP_JAC || (OP < 0 && a.metric == M_JAC);
       Cursor cc;
       cc.t = t;
       for (cc.p = 0; cc.p < p.npanel; ++cc.p) {
@@ -351,6 +363,12 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
             if (p.tail && p.cfull >= c0 && p.cfull < c0 + nseg)
               for (uint32_t j = 0; j < p.tail; ++j) acc = comb<OP>(op_rt, acc, Sr[p.tail_base + j]);
           }
+          if (jaccard) {  // the panel's two counts leave the float while they are still exact in it
+            const uint32_t tot = (uint32_t)acc;
+            jac_xnz += tot >> 12;
+            jac_ham += tot & 4095u;
+            acc = 0.0f;
+          }
         }
         wave_lds_fence();
       }
@@ -360,9 +378,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       float raw = acc;
       if (metric == M_NIP) raw = -acc;
       else if (metric == M_L2) raw = finite_f32(acc) ? __builtin_sqrtf(acc) : acc;
-      else if (OP == OP_JAC || (OP < 0 && metric == M_JAC)) {
-        const uint32_t tot = (uint32_t)acc;
-        const uint32_t xnz = tot >> 12, ham = tot & 4095u;
+      else if (jaccard) {
+        const uint32_t xnz = jac_xnz, ham = jac_ham;
         const uint32_t uni = (a.q_nonzero + xnz + ham) >> 1;
         const uint32_t inter = (a.q_nonzero + xnz - ham) >> 1;
         raw = uni == 0 ? 0.0f : 1.0f - (float)inter / (float)uni;
