@@ -1,0 +1,282 @@
+// concurrency_check.cpp -- the host side's thread machinery (vettore_amd/csrc/host/vt_concurrency.h)
+// instantiated with stub operations and run under ThreadSanitizer (tests/test_concurrency.py):
+//   1. the coalescer: 64 threads x mixed limits and query lengths x injected failures (a query that is
+//      invalid on its own, a batch that fails as a whole, a batch that throws) x a "writer" that
+//      forces the disband path; every caller must get the answer of ITS query, nobody may be left
+//      waiting, the slot count must come back to zero;
+//   2. the context lease: 48 readers on a pool of at most 8 contexts, no context ever held twice;
+//   3. the workers: concurrent callers posting to 4 workers, every worker sees the callers' jobs in
+//      the same order (what matching collectives need), failures come back with their message.
+// TEST INFRASTRUCTURE.  Prints "ok" and exits 0, or says what went wrong.
+#include "../vettore_amd/csrc/host/vt_concurrency.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <new>
+#include <random>
+
+struct vt_hits {
+  uint64_t tag;
+};
+
+static std::atomic<long> g_live_hits{0};
+static vt_hits *make_hits(uint64_t tag) {
+  g_live_hits += 1;
+  return new vt_hits{tag};
+}
+static void free_hits(vt_hits *h) {
+  g_live_hits -= 1;
+  delete h;
+}
+
+#define CHECK(cond)                                                          \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      std::fprintf(stderr, "concurrency_check: %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      std::exit(1);                                                          \
+    }                                                                        \
+  } while (0)
+
+// ------------------------------------------------------------------ 1. coalescer
+struct FakeHandle {
+  vt_host::Coalescer co;
+  std::atomic<unsigned> slots{1};
+  std::atomic<bool> ranks_lazy{false};     // the writer's doing: batches must disband
+  std::atomic<uint64_t> alone{0}, batched{0}, batches{0}, failed_batches{0}, thrown{0};
+};
+
+static thread_local std::string t_last_error;
+
+// the "answer" of a query: a function of its content and limit only
+static uint64_t answer(const float *q, size_t n, size_t limit) {
+  uint64_t h = 1469598103934665603ull ^ limit;
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t b;
+    std::memcpy(&b, &q[i], 4);
+    h = (h ^ b) * 1099511628211ull;
+  }
+  return h;
+}
+static void spin(int us) { std::this_thread::sleep_for(std::chrono::microseconds(us)); }
+
+struct FakeOps {
+  static constexpr int kOutOfMemory = 9;
+  static vt_host::Coalescer &coalescer(FakeHandle *h) { return h->co; }
+  static unsigned slots(FakeHandle *h) { return h->slots.load(); }
+  static int search_direct(FakeHandle *h, const float *query, size_t n, size_t limit, vt_hits **out) {
+    if (query[0] < 0.0f) {  // "vector contains a non-finite value"
+      t_last_error = "bad query";
+      return 3;
+    }
+    spin(30);
+    h->alone += 1;
+    *out = make_hits(answer(query, n, limit));
+    return 0;
+  }
+  static void search_alone(FakeHandle *h, vt_host::Waiting *w) {
+    w->status = search_direct(h, w->query, w->n, w->limit, w->out);
+    if (w->status != 0) w->error = t_last_error;
+  }
+  static void judge(FakeHandle *, std::vector<vt_host::Waiting *> &members, std::vector<vt_host::Waiting *> *good) {
+    for (vt_host::Waiting *w : members) {
+      if (w->query[0] < 0.0f) {
+        w->status = 3;
+        w->error = "bad query";
+      } else {
+        good->push_back(w);
+      }
+    }
+  }
+  static int batch(FakeHandle *h, const float *queries, size_t nq, size_t n, size_t limit, vt_hits **outs) {
+    spin(60);
+    // injected: a batch that fails as a whole (one member's "metric overflow"), a batch that throws
+    const uint64_t roll = answer(queries, n, limit + nq);
+    if (roll % 29u == 0u) {
+      h->failed_batches += 1;
+      return 4;
+    }
+    if (roll % 211u == 1u) {
+      h->thrown += 1;
+      throw std::bad_alloc();
+    }
+    for (size_t i = 0; i < nq; ++i) outs[i] = make_hits(answer(queries + i * n, n, limit));
+    h->batched += nq;
+    h->batches += 1;
+    return 0;
+  }
+  static bool must_disband(FakeHandle *h, size_t) { return h->ranks_lazy.load(); }
+  static void run(FakeHandle *h, std::vector<vt_host::Waiting *> &members) { vt_host::run_coalesced_t<FakeHandle, FakeOps>(h, members); }
+  static void drop_hits(vt_hits *hits) { free_hits(hits); }
+  static void set_last_error(const std::string &msg) { t_last_error = msg; }
+};
+
+static void check_coalescer(int threads, int per_thread) {
+  FakeHandle h;
+  std::atomic<bool> stop{false};
+  std::atomic<uint64_t> ok{0}, bad{0}, oom{0};
+  std::thread writer([&] {  // flips the disband condition and the slot count while searches run
+    std::mt19937 rng(7);
+    while (!stop.load()) {
+      h.ranks_lazy = (rng() & 7u) == 0u;
+      h.slots = 1 + (rng() % 3u);
+      spin(200);
+    }
+    h.ranks_lazy = false;
+  });
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t)
+    pool.emplace_back([&, t] {
+      std::mt19937 rng(1000 + t);
+      for (int i = 0; i < per_thread; ++i) {
+        const size_t n = (rng() & 1u) ? 16 : 24;
+        const size_t limit = 1 + (rng() % 3u);
+        std::vector<float> q(n);
+        for (auto &v : q) v = (float)(rng() % 1000u) / 10.0f;
+        if ((rng() % 50u) == 0u) q[0] = -1.0f;  // invalid on its own
+        vt_hits *out = nullptr;
+        const int st = vt_host::coalesced_search_t<FakeHandle, FakeOps>(&h, q.data(), n, limit, &out);
+        if (q[0] < 0.0f) {
+          CHECK(st == 3 && out == nullptr && t_last_error == "bad query");
+          bad += 1;
+        } else if (st == FakeOps::kOutOfMemory) {
+          CHECK(out == nullptr);
+          oom += 1;
+        } else {
+          CHECK(st == 0 && out != nullptr && out->tag == answer(q.data(), n, limit));
+          free_hits(out);
+          ok += 1;
+        }
+      }
+    });
+  for (auto &th : pool) th.join();
+  stop = true;
+  writer.join();
+  {
+    std::lock_guard<std::mutex> g(h.co.mu);
+    CHECK(h.co.waiting.empty() && h.co.active == 0);
+  }
+  CHECK(ok + bad + oom == (uint64_t)threads * per_thread);
+  CHECK(g_live_hits.load() == 0);
+  CHECK(h.batches.load() > 0 && h.alone.load() > 0);
+  std::fprintf(stderr, "coalescer: %llu ok (%llu in %llu batches, %llu alone), %llu invalid, %llu after a thrown batch, %llu failed batches\n",
+               (unsigned long long)ok.load(), (unsigned long long)h.batched.load(), (unsigned long long)h.batches.load(),
+               (unsigned long long)h.alone.load(), (unsigned long long)bad.load(), (unsigned long long)oom.load(),
+               (unsigned long long)h.failed_batches.load());
+}
+
+// ------------------------------------------------------------------ 2. lease
+struct FakeCtx {
+  std::atomic<int> holders{0};
+  int device = 0;
+};
+struct FakeShard {
+  FakeCtx ctx;
+  std::mutex pool_mu;
+  std::condition_variable pool_cv;
+  std::vector<std::unique_ptr<FakeCtx>> extra;
+  std::vector<FakeCtx *> free_ctx;
+  bool ctx0_busy = false;
+};
+
+static void check_lease(int threads, int per_thread) {
+  FakeShard s;
+  std::atomic<int> made{0}, failed{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t)
+    pool.emplace_back([&, t] {
+      std::mt19937 rng(t);
+      for (int i = 0; i < per_thread; ++i) {
+        vt_host::LeaseT<FakeShard, FakeCtx> lease(&s, 8, [&](FakeShard *, int *status) -> std::unique_ptr<FakeCtx> {
+          if ((rng() % 97u) == 0u) {  // a context that cannot be made (out of device memory)
+            *status = 9;
+            failed += 1;
+            return nullptr;
+          }
+          made += 1;
+          return std::make_unique<FakeCtx>();
+        });
+        if (!lease.c) {
+          CHECK(lease.status == 9);
+          continue;
+        }
+        CHECK(lease.c->holders.fetch_add(1) == 0);  // never held twice
+        if ((rng() & 3u) == 0u) spin(5);
+        CHECK(lease.c->holders.fetch_sub(1) == 1);
+      }
+    });
+  for (auto &th : pool) th.join();
+  CHECK(s.extra.size() + 1 <= 8 && !s.ctx0_busy && s.free_ctx.size() == s.extra.size());
+  CHECK(made.load() == (int)s.extra.size());
+  std::fprintf(stderr, "lease: %d contexts made, %d refused\n", made.load(), failed.load());
+}
+
+// ------------------------------------------------------------------ 3. workers
+struct TestWorkerPolicy {
+  static void thread_start(int) {}
+  static int run(const std::function<int()> &fn, std::string *error) {
+    try {
+      const int st = fn();
+      if (st != 0) *error = "job failed with " + std::to_string(st);
+      return st;
+    } catch (...) {
+      *error = "job threw";
+      return 11;
+    }
+  }
+};
+using TestWorker = vt_host::WorkerT<TestWorkerPolicy>;
+
+static void check_workers(int callers, int per_caller) {
+  constexpr size_t S = 4;
+  std::vector<std::unique_ptr<TestWorker>> workers;
+  for (size_t s = 0; s < S; ++s) {
+    workers.push_back(std::make_unique<TestWorker>());
+    workers.back()->start((int)s);
+  }
+  std::mutex post_mu;
+  std::vector<std::vector<uint64_t>> seen(S);  // each touched by its worker thread only
+  std::atomic<int> failures{0};
+  std::vector<std::thread> pool;
+  for (int c = 0; c < callers; ++c)
+    pool.emplace_back([&, c] {
+      for (int i = 0; i < per_caller; ++i) {
+        const uint64_t id = ((uint64_t)c << 32) | (uint32_t)i;
+        const bool fails = (i % 37) == 5;
+        std::vector<size_t> all{0, 1, 2, 3};
+        std::string msg;
+        const int st = vt_host::run_on_workers(workers, post_mu, all,
+                                               [&](size_t s) -> int {
+                                                 seen[s].push_back(id);
+                                                 if (fails && s == 2) return 6;
+                                                 if (fails && s == 3) throw std::bad_alloc();
+                                                 return 0;
+                                               },
+                                               [&](int status, const std::string &error) {
+                                                 msg = error;
+                                                 return status;
+                                               });
+        if (fails) {
+          CHECK(st == 6 && msg == "job failed with 6");  // the first failing shard's
+          failures += 1;
+        } else {
+          CHECK(st == 0);
+        }
+      }
+    });
+  for (auto &th : pool) th.join();
+  workers.clear();  // joins
+  for (size_t s = 1; s < S; ++s) CHECK(seen[s] == seen[0]);  // one order for everybody
+  CHECK(seen[0].size() == (size_t)callers * per_caller);
+  std::fprintf(stderr, "workers: %zu jobs per worker in one order, %d failures reported\n", seen[0].size(), failures.load());
+}
+
+int main(int argc, char **argv) {
+  const int scale = argc > 1 ? std::atoi(argv[1]) : 1;
+  check_coalescer(64, 1600 * scale);  // 10^5 operations at scale 1
+  check_lease(48, 4000 * scale);
+  check_workers(8, 1500 * scale);
+  std::printf("ok\n");
+  return 0;
+}

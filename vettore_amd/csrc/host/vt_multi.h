@@ -31,19 +31,8 @@ inline uint32_t shard_of(const char *id, size_t len, size_t nshards) {
 // the status of the lowest failing shard wins (its detail text becomes this thread's).
 template <class F>
 int on_shards(vt_flat *h, const std::vector<size_t> &which, F fn) {
-  std::vector<Worker::Job> jobs(which.size());
-  for (size_t i = 0; i < which.size(); ++i) {
-    const size_t s = which[i];
-    jobs[i].fn = [&fn, s]() -> int { return fn(s); };
-  }
-  {
-    std::lock_guard<std::mutex> g(h->post_mu);
-    for (size_t i = 0; i < which.size(); ++i) h->workers[which[i]]->post(&jobs[i]);
-  }
-  for (size_t i = 0; i < which.size(); ++i) h->workers[which[i]]->wait(&jobs[i]);
-  for (size_t i = 0; i < which.size(); ++i)
-    if (jobs[i].status != VT_OK) return fail(jobs[i].status, jobs[i].error);
-  return VT_OK;
+  return vt_host::run_on_workers(h->workers, h->post_mu, which, fn,
+                                 [](int status, const std::string &error) { return fail(status, error); });
 }
 template <class F>
 int on_all_shards(vt_flat *h, F fn) {

@@ -203,47 +203,17 @@ namespace {
 constexpr size_t kMaxContexts = 8;  // readers in flight per shard
 
 // A context for one reader: the primary one if free, else a spare, else a new one (up to
-// kMaxContexts), else wait.  Held only under the handle's shared lock.
-struct CtxLease {
-  Shard *ix;
-  Ctx *c = nullptr;
-  int status = VT_OK;
-  explicit CtxLease(Shard *s) : ix(s) {
-    std::unique_lock<std::mutex> g(ix->pool_mu);
-    for (;;) {
-      if (!ix->ctx0_busy) {
-        ix->ctx0_busy = true;
-        c = &ix->ctx;
-        return;
-      }
-      if (!ix->free_ctx.empty()) {
-        c = ix->free_ctx.back();
-        ix->free_ctx.pop_back();
-        return;
-      }
-      if (ix->extra.size() + 1 < kMaxContexts) {
-        auto nc = std::make_unique<Ctx>();
-        status = nc->init(ix->ctx.device);
-        if (status != VT_OK) return;
-        nc->profiling = ix->ctx.profiling;
-        c = nc.get();
-        ix->extra.push_back(std::move(nc));
-        return;
-      }
-      ix->pool_cv.wait(g);
-    }
-  }
-  ~CtxLease() {
-    if (!c) return;
-    {
-      std::lock_guard<std::mutex> g(ix->pool_mu);
-      if (c == &ix->ctx) ix->ctx0_busy = false;
-      else ix->free_ctx.push_back(c);
-    }
-    ix->pool_cv.notify_one();
-  }
-  CtxLease(const CtxLease &) = delete;
-  CtxLease &operator=(const CtxLease &) = delete;
+// kMaxContexts), else wait (vt_host::LeaseT, host/vt_concurrency.h).  Held only under the handle's
+// shared lock.
+struct CtxLease : vt_host::LeaseT<Shard, Ctx> {
+  explicit CtxLease(Shard *s)
+      : vt_host::LeaseT<Shard, Ctx>(s, kMaxContexts, [](Shard *ix, int *status) -> std::unique_ptr<Ctx> {
+          auto nc = std::make_unique<Ctx>();
+          *status = nc->init(ix->ctx.device);
+          if (*status != VT_OK) return nullptr;
+          nc->profiling = ix->ctx.profiling;
+          return nc;
+        }) {}
 };
 
 // ---- RCCL, loaded on first use (librccl is half a gigabyte: a single-GPU index never maps it)
@@ -282,69 +252,20 @@ Rccl &rccl() {
   return r;
 }
 
-// One thread per shard of a multi-shard index, bound to the shard's device: the caller
-// posts the same job to all of them, so the launch overheads of the shards overlap and
-// each shard's kernels are issued by a thread whose current device never changes.
-struct Worker {
-  struct Job {
-    std::function<int()> fn;
-    int status = VT_OK;
-    std::string error;
-    bool done = false;
-  };
-  std::thread th;
-  std::mutex mu;
-  std::condition_variable cv, done_cv;
-  std::deque<Job *> queue;
-  bool stop = false;
-  int device = 0;
-
-  void start(int dev) {
-    device = dev;
-    th = std::thread([this] { loop(); });
-  }
-  void loop() {
-    (void)hipSetDevice(device);
-    for (;;) {
-      Job *job = nullptr;
-      {
-        std::unique_lock<std::mutex> g(mu);
-        cv.wait(g, [this] { return stop || !queue.empty(); });
-        if (queue.empty()) return;  // stop
-        job = queue.front();
-        queue.pop_front();
-      }
-      g_last_error.clear();
-      const int st = guarded(job->fn);
-      {
-        std::lock_guard<std::mutex> g(mu);
-        job->status = st;
-        if (st != VT_OK) job->error = g_last_error;
-        job->done = true;
-      }
-      done_cv.notify_all();
-    }
-  }
-  void post(Job *job) {
-    {
-      std::lock_guard<std::mutex> g(mu);
-      queue.push_back(job);
-    }
-    cv.notify_one();
-  }
-  void wait(Job *job) {
-    std::unique_lock<std::mutex> g(mu);
-    done_cv.wait(g, [job] { return job->done; });
-  }
-  ~Worker() {
-    {
-      std::lock_guard<std::mutex> g(mu);
-      stop = true;
-    }
-    cv.notify_one();
-    if (th.joinable()) th.join();
+// One thread per shard of a multi-shard index, bound to the shard's device (vt_host::WorkerT,
+// host/vt_concurrency.h): the caller posts the same job to all of them, so the launch overheads
+// of the shards overlap and each shard's kernels are issued by a thread whose current device
+// never changes.
+struct HipWorkerPolicy {
+  static void thread_start(int device) { (void)hipSetDevice(device); }
+  static int run(const std::function<int()> &fn, std::string *error) {
+    g_last_error.clear();
+    const int st = guarded(fn);
+    if (st != VT_OK) *error = g_last_error;
+    return st;
   }
 };
+using Worker = vt_host::WorkerT<HipWorkerPolicy>;
 
 }  // namespace
 
@@ -377,25 +298,9 @@ struct vt_flat {
   // sweep of the corpus answers up to eight of them (K1m), the matrix-core pass up to 256 (K2),
   // where the same callers on their own streams would read the whole corpus once each.  See
   // coalesced_search.
-  struct Waiting {
-    const float *query;
-    size_t n, limit;
-    vt_hits **out;
-    int status = VT_OK;
-    std::string error;
-    enum { QUEUED, LEADS, ALONE, DONE } state = QUEUED;
-    std::condition_variable wake;  // its own: a finished batch wakes exactly its members and the next leader
-    Waiting(const float *q, size_t n_, size_t limit_, vt_hits **out_) : query(q), n(n_), limit(limit_), out(out_) {}
-  };
-  struct Coalescer {
-    std::mutex mu;
-    std::condition_variable gather;  // a leader waiting a moment for the callers it expects back
-    std::deque<Waiting *> waiting;
-    unsigned active = 0;        // searches / batches running
-    size_t last_batch = 1;      // members of the last batch that ran
-    double last_seconds = 0.0;  // what it took
-    uint64_t batches = 0, batched_queries = 0;
-  } co;
+  using Waiting = vt_host::Waiting;
+  using Coalescer = vt_host::Coalescer;
+  Coalescer co;
   std::atomic<uint64_t> approx_bytes{0};  // rows x row stride, refreshed by mutations (the coalescer's only use of it is a size class)
 
   bool multi() const { return shards.size() > 1 || !workers.empty(); }

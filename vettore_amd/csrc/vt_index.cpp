@@ -31,6 +31,7 @@
 
 // The host side in reading order (one translation unit; see the note at the top of each part):
 #include "host/vt_idtable.h"
+#include "host/vt_concurrency.h"
 #include "host/vt_base.h"
 #include "host/vt_types.h"
 #include "host/vt_select.h"
