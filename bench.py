@@ -439,16 +439,24 @@ def run_side_mode(a, torch, nifs, device):
     print(json.dumps(out))
 
 
-def concurrent_callers(a, L, nifs, ref, threads, seconds):
+def concurrent_callers(a, L, nifs, ref, threads, seconds, quantized=0):
     """`threads` callers searching ONE handle at the same time (what BEAM dirty schedulers do under
     the reference's read lock, nifs.rs:297-309): the library lets searches that meet travel as one
-    batch.  Every answer is compared with the one the same query gets alone."""
+    batch.  Every answer is compared with the one the same query gets alone.  quantized = c > 0:
+    the callers run quantized_search(candidates: c) instead (collection.ex:276-295)."""
     import threading
     qs = normalized_queries(64, a.dim, SEED_QUERY + 9)
     hp = C.c_void_p()
+
+    def one(q, h):
+        qp = q.ctypes.data_as(C.POINTER(C.c_float))
+        if quantized:
+            return L.vt_flat_quantized_search(ref.handle, qp, a.dim, quantized, a.limit, C.byref(h))
+        return L.vt_flat_search(ref.handle, qp, a.dim, a.limit, C.byref(h))
+
     alone = []
     for q in qs:
-        assert L.vt_flat_search(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), a.dim, a.limit, C.byref(hp)) == 0
+        assert one(q, hp) == 0
         alone.append(hits_of(L, hp))
     stop, counts, wrong = threading.Event(), [0] * threads, []
 
@@ -457,7 +465,7 @@ def concurrent_callers(a, L, nifs, ref, threads, seconds):
         i = t
         while not stop.is_set():
             j = i % len(qs)
-            assert L.vt_flat_search(ref.handle, qs[j].ctypes.data_as(C.POINTER(C.c_float)), a.dim, a.limit, C.byref(h)) == 0
+            assert one(qs[j], h) == 0
             if counts[t] % 8 == 0:
                 if hits_of(L, h) != alone[j]:
                     wrong.append((t, j))
@@ -503,6 +511,10 @@ def side_legs(a, torch, nifs, L, device, main_ref):
     side["callers"] = {"workload": "index: :flat, metric: :cosine, d=%d, N=%d, limit=%d, T threads calling flat_search on one handle"
                                    % (a.dim, a.rows, a.limit),
                        "runs": [concurrent_callers(a, L, nifs, main_ref, t, 1.5) for t in (8, 64)]}
+    # ... and many quantized_search callers: up to eight share a sweep of the sign-bit matrix
+    side["callers_quantized"] = {"workload": "quantized_search candidates=100 limit=%d, d=%d, N=%d, T threads on one handle"
+                                             % (a.limit, a.dim, a.rows),
+                                 "runs": [concurrent_callers(a, L, nifs, main_ref, t, 1.0, quantized=100) for t in (1, 8, 64)]}
     # config 2: flat cosine top-10, N = 1M, single query
     rows2 = min(1_000_000, a.rows)
     x = build_shard(torch, device, rows2, a.dim, SEED_CORPUS + 2)

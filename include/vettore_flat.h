@@ -239,6 +239,12 @@ int vt_flat_load_device_matrix(vt_flat *index, size_t count, size_t d,
  * reranks with the f64 `cosine`, search.rs:56-60). */
 int vt_flat_quantized_search(vt_flat *index, const float *query, size_t n,
                              size_t candidates, size_t limit, vt_hits **out);
+/* `nq` quantized searches (queries of `d` floats back to back), out[i] = query i's hits --
+ * identical to nq vt_flat_quantized_search calls; groups of up to eight share ONE sweep of the
+ * sign-bit matrix (candidates <= 256).  Concurrent vt_flat_quantized_search callers on one handle
+ * are grouped the same way (they meet in the coalescer like plain searches do). */
+int vt_flat_quantized_search_batch(vt_flat *index, const float *queries, size_t nq, size_t d,
+                                   size_t candidates, size_t limit, vt_hits **out);
 
 /* funnel_search, lib/vettore/collection.ex:245-260, :674-691: for every prefix
  * length in `stages` (1..dimensions, else "invalid prefix dimensions") keep the
@@ -313,7 +319,7 @@ typedef struct vt_profile {
   uint64_t scan_bytes;      /* algorithmic bytes: rows * d * 4 */
   uint64_t hamming_launches;
   double hamming_ms;
-  uint64_t hamming_bytes;   /* rows * ceil(d/64) * 8 */
+  uint64_t hamming_bytes;   /* rows * ceil(d/64) * 8 per launch (one launch may serve up to 8 queries) */
   uint64_t merge_launches;
   double merge_ms;
   uint64_t batch_launches;  /* MFMA candidate passes (one per <= 256 queries) */
@@ -332,6 +338,7 @@ typedef struct vt_profile {
   uint64_t nominate_queries;
   uint64_t nominate_second_passes; /* passes re-run with thresholds from a first pass's exact hits */
   uint64_t nominate_candidates;   /* rows handed to the exact rescoring, summed over queries */
+  uint64_t hamming_queries;       /* queries served by grouped Hamming passes (0 for single-query passes) */
 } vt_profile;
 int vt_flat_set_profiling(vt_flat *index, int enabled);
 int vt_flat_get_profile(vt_flat *index, vt_profile *out, int reset);

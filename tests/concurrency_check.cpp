@@ -65,7 +65,8 @@ struct FakeOps {
   static constexpr int kOutOfMemory = 9;
   static vt_host::Coalescer &coalescer(FakeHandle *h) { return h->co; }
   static unsigned slots(FakeHandle *h) { return h->slots.load(); }
-  static int search_direct(FakeHandle *h, const float *query, size_t n, size_t limit, vt_hits **out) {
+  static int search_direct(FakeHandle *h, int kind, size_t aux, const float *query, size_t n, size_t limit, vt_hits **out) {
+    limit += 1000 * (size_t)kind + 100000 * aux;  // (the answer depends on the entry point and its parameter too)
     if (query[0] < 0.0f) {  // "vector contains a non-finite value"
       t_last_error = "bad query";
       return 3;
@@ -76,7 +77,7 @@ struct FakeOps {
     return 0;
   }
   static void search_alone(FakeHandle *h, vt_host::Waiting *w) {
-    w->status = search_direct(h, w->query, w->n, w->limit, w->out);
+    w->status = search_direct(h, w->kind, w->aux, w->query, w->n, w->limit, w->out);
     if (w->status != 0) w->error = t_last_error;
   }
   static void judge(FakeHandle *, std::vector<vt_host::Waiting *> &members, std::vector<vt_host::Waiting *> *good) {
@@ -89,7 +90,8 @@ struct FakeOps {
       }
     }
   }
-  static int batch(FakeHandle *h, const float *queries, size_t nq, size_t n, size_t limit, vt_hits **outs) {
+  static int batch(FakeHandle *h, int kind, size_t aux, const float *queries, size_t nq, size_t n, size_t limit, vt_hits **outs) {
+    limit += 1000 * (size_t)kind + 100000 * aux;
     spin(60);
     // injected: a batch that fails as a whole (one member's "metric overflow"), a batch that throws
     const uint64_t roll = answer(queries, n, limit + nq);
@@ -106,7 +108,7 @@ struct FakeOps {
     h->batches += 1;
     return 0;
   }
-  static bool must_disband(FakeHandle *h, size_t) { return h->ranks_lazy.load(); }
+  static bool must_disband(FakeHandle *h, int, size_t) { return h->ranks_lazy.load(); }
   static void run(FakeHandle *h, std::vector<vt_host::Waiting *> &members) { vt_host::run_coalesced_t<FakeHandle, FakeOps>(h, members); }
   static void drop_hits(vt_hits *hits) { free_hits(hits); }
   static void set_last_error(const std::string &msg) { t_last_error = msg; }
@@ -132,11 +134,13 @@ static void check_coalescer(int threads, int per_thread) {
       for (int i = 0; i < per_thread; ++i) {
         const size_t n = (rng() & 1u) ? 16 : 24;
         const size_t limit = 1 + (rng() % 3u);
+        const int kind = (int)(rng() % 2u);                       // two entry points (flat_search, quantized_search) ...
+        const size_t aux = kind ? 10 * (1 + rng() % 2u) : 0;      // ... the second with a parameter of its own
         std::vector<float> q(n);
         for (auto &v : q) v = (float)(rng() % 1000u) / 10.0f;
         if ((rng() % 50u) == 0u) q[0] = -1.0f;  // invalid on its own
         vt_hits *out = nullptr;
-        const int st = vt_host::coalesced_search_t<FakeHandle, FakeOps>(&h, q.data(), n, limit, &out);
+        const int st = vt_host::coalesced_search_t<FakeHandle, FakeOps>(&h, q.data(), n, limit, &out, kind, aux);
         if (q[0] < 0.0f) {
           CHECK(st == 3 && out == nullptr && t_last_error == "bad query");
           bad += 1;
@@ -144,7 +148,7 @@ static void check_coalescer(int threads, int per_thread) {
           CHECK(out == nullptr);
           oom += 1;
         } else {
-          CHECK(st == 0 && out != nullptr && out->tag == answer(q.data(), n, limit));
+          CHECK(st == 0 && out != nullptr && out->tag == answer(q.data(), n, limit + 1000 * (size_t)kind + 100000 * aux));
           free_hits(out);
           ok += 1;
         }

@@ -1312,3 +1312,100 @@ def test_rows_too_long_for_the_query_to_sit_in_lds(nifs, oracle_mod, d):
             got = unwrap(nifs.flat_search_batch(g.ref, np.stack([q, x[3], x[100]]), 5))
             for i, query in enumerate((q, x[3], x[100])):
                 assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, x, packed, query, 5))
+
+
+# ------------------------------------------------- several quantized searches per sweep
+@pytest.mark.parametrize("metric", [2, 0, 3, 5, 8])
+def test_quantized_search_batch_equals_single_calls(nifs, oracle_mod, metric):
+    """vt_flat_quantized_search_batch: groups of up to eight queries share ONE sweep of the sign
+    bits (hamming_dist_multi_kernel), every later stage runs with the queries on grid.y; each
+    query's hits must equal its own quantized_search AND the oracle's composition
+    (binary_top_k then vector_top_k, collection.ex:276-295) bit for bit.  Jaccard's rerank takes
+    the queries one by one (its non-zero count is per query)."""
+    n, d = 20_000, 200
+    x, ids = make_corpus(n, d, 4100 + metric, metric == 2, oracle_mod, tie_block=300)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(11)
+    sign = x >= 0
+    nifs.flat_set_profiling(g.ref, True)
+    for nq, cand, limit in ((2, 100, 10), (8, 100, 10), (17, 256, 30), (5, 7, 7), (9, 40, 100)):
+        qs = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+        qs[0] = x[n // 2]                                    # inside the block of identical rows
+        if metric == 2:
+            qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+        nifs.flat_get_profile(g.ref, reset=True)
+        got = unwrap(nifs.flat_quantized_search_batch(g.ref, qs, cand, limit))
+        prof = nifs.flat_get_profile(g.ref, reset=True)
+        assert len(got) == nq
+        if metric != 8:
+            assert prof["hamming_queries"] >= nq - 1 and prof["hamming_launches"] <= (nq + 7) // 8 + 1, (nq, prof)
+        for i in range(nq):
+            assert bits(got[i]) == bits(unwrap(nifs.flat_quantized_search(g.ref, qs[i], cand, limit))), (metric, nq, i)
+        for i in (0, nq - 1):
+            ham = (sign != (qs[i] >= 0)[None, :]).sum(axis=1)
+            order = sorted(range(n), key=lambda r: (int(ham[r]), ids[r]))[:cand]
+            want = oracle_mod.vector_top_k([(ids[r], x[r]) for r in order], qs[i], metric, d, limit)
+            assert bits(got[i]) == bits(want), (metric, nq, cand, limit, i)
+    # validation order and empty cases follow quantized_search
+    assert nifs.flat_quantized_search_batch(g.ref, np.zeros((3, d + 1), np.float32), 10, 5) == ("error", "dimension mismatch")
+    bad = np.zeros((4, d), np.float32)
+    bad[2, 1] = np.nan
+    assert nifs.flat_quantized_search_batch(g.ref, bad, 10, 5) == ("error", "vector contains a non-finite value")
+    assert unwrap(nifs.flat_quantized_search_batch(g.ref, qs[:3], 0, 5)) == [[]] * 3
+    assert unwrap(nifs.flat_quantized_search_batch(g.ref, qs[:3], 5, 0)) == [[]] * 3
+
+
+def test_quantized_groups_with_massive_ties_fall_back(nifs, oracle_mod):
+    """Rows drawn from two sign patterns: thousands of ties at the k-th Hamming distance, more than a
+    group's per-query list holds -- the group hands over to the single-query path, same answers."""
+    n, d = 30_000, 64
+    rng = np.random.default_rng(516)
+    base = rng.uniform(-1, 1, (2, d)).astype(np.float32)
+    x = base[rng.integers(0, 2, n)] * rng.uniform(0.5, 1.5, (n, 1)).astype(np.float32)
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    g = GpuIndex(nifs, 0)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    qs = rng.uniform(-1, 1, (6, d)).astype(np.float32)
+    got = unwrap(nifs.flat_quantized_search_batch(g.ref, qs, 100, 10))
+    for i in range(6):
+        assert bits(got[i]) == bits(unwrap(nifs.flat_quantized_search(g.ref, qs[i], 100, 10)))
+
+
+def test_concurrent_quantized_callers_share_sweeps(nifs, oracle_mod, monkeypatch):
+    """quantized_search callers that meet on one handle (collection.ex:276-295 under the read lock)
+    travel in groups like plain searches do; every answer equals the call made alone."""
+    import threading
+    monkeypatch.setenv("VT_COALESCE_SLOTS", "1")
+    n, d = 40_000, 128
+    x, ids = make_corpus(n, d, 4200, True, oracle_mod)
+    g = GpuIndex(nifs, 2)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(12)
+    qs = np.stack([oracle_mod.normalize_l2(q) for q in rng.uniform(-1, 1, (32, d)).astype(np.float32)])
+    alone = [bits(unwrap(nifs.flat_quantized_search(g.ref, q, 100, 10))) for q in qs]
+    alone50 = [bits(unwrap(nifs.flat_quantized_search(g.ref, q, 50, 10))) for q in qs]
+    plain = [bits(unwrap(nifs.flat_search(g.ref, q, 10))) for q in qs]
+    wrong, b0 = [], nifs.flat_coalesce_stats(g.ref)
+
+    def worker(t):
+        for r in range(40):
+            j = (t * 7 + r) % 32
+            kind = (t + r) % 4
+            if kind == 0:
+                res = bits(unwrap(nifs.flat_search(g.ref, qs[j], 10))) == plain[j]
+            elif kind == 1:
+                res = bits(unwrap(nifs.flat_quantized_search(g.ref, qs[j], 50, 10))) == alone50[j]
+            else:
+                res = bits(unwrap(nifs.flat_quantized_search(g.ref, qs[j], 100, 10))) == alone[j]
+            if not res:
+                wrong.append((t, r, kind))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    b1 = nifs.flat_coalesce_stats(g.ref)
+    assert not wrong, wrong[:5]
+    assert b1[1] - b0[1] >= 100, (b0, b1)   # most calls travelled in batches

@@ -656,6 +656,223 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
 }
 
 
+// ---- several quantized searches in ONE sweep of the bit matrix ------------------------------
+// collection.ex:276-295 for up to kHammingMultiMax queries at once, the way K1m carries several
+// plain searches: the 96 bytes of sign bits per row (0.96 GB at N = 10 M) are read once, every
+// stage behind them runs once with the queries on grid.y -- distance columns + histograms,
+// threshold collect, select, exact rerank (f64 cosine, or K1 on the gathered rows), select --
+// and one wait ends the group.  Each query's hits are what its own quantized_search returns,
+// bit for bit (same kernels, same keys).  kRetryInternal: something only the single-query path
+// sorts out (more ties at a k-th distance than a list holds, a metric overflow in the rerank).
+bool quantized_group_applies(const Shard *ix, size_t candidates, size_t limit) {
+  const uint32_t d = (uint32_t)ix->dim;
+  const size_t ncand = std::min<size_t>(candidates, ix->n);
+  return ix->n >= 16384 && ncand >= 1 && ncand <= (size_t)vt::kMaxFusedK && limit >= 1 && d <= vt::kHammingHistMaxDim &&
+         vt::hamming_multi_lds_bytes(d, (d + 63) / 64, 2) <= 64 * 1024 && !std::getenv("VT_HAMMING_LISTS") &&
+         !std::getenv("VT_NO_QUANTIZED_GROUPS") &&
+         (ix->metric == VT_COSINE ? (size_t)2 * ((d + 3) / 4 * 4) * 4 <= 160 * 1024 : vt::scan_lds_bytes(d, (uint32_t)std::min<size_t>(limit, ncand)) != 0);
+}
+// queries per sweep: what the nq histograms leave room for in 64 KiB of LDS
+uint32_t quantized_group_size(const Shard *ix) {
+  const uint32_t d = (uint32_t)ix->dim;
+  uint32_t nq = vt::kHammingMultiMax;
+  while (nq > 1 && vt::hamming_multi_lds_bytes(d, (d + 63) / 64, nq) > 64 * 1024) nq -= 1;
+  return nq;
+}
+
+int quantized_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size_t> &which, size_t candidates, size_t limit,
+                    vt_hits **out) {
+  const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
+  const uint32_t words = (d + 63) / 64, pairs = (words + 1) / 2;
+  const uint32_t nq = (uint32_t)which.size();
+  const uint32_t k1 = (uint32_t)std::min<size_t>(candidates, n);
+  const uint32_t k2 = (uint32_t)std::min<size_t>(limit, k1);
+  constexpr uint32_t kListCap = 8192;
+  const uint32_t hist_stride = (d + 1 + 63) / 64 * 64;
+  const uint32_t dist_stride = (std::max<uint32_t>(ix->cap, n) + 7) / 8 * 8;
+  VT_TRY(c.dBQ.ensure((size_t)nq * ld));
+  VT_TRY(c.hBQ.ensure((size_t)nq * ld));
+  VT_TRY(c.dBQbits.ensure((size_t)nq * words));
+  VT_TRY(c.hBQbits.ensure((size_t)nq * words));
+  VT_TRY(c.dDist16.ensure((size_t)nq * dist_stride));
+  VT_TRY(c.dHamHist.ensure(std::max<size_t>((size_t)nq * hist_stride, 2 * 8192)));
+  VT_TRY(c.dHamCount.ensure(vt::kHammingMultiMax));
+  VT_TRY(c.dPartKeys.ensure((size_t)nq * kListCap));
+  VT_TRY(c.dPartPay.ensure((size_t)nq * kListCap));
+  VT_TRY(c.dStageB.ensure(nq));
+  VT_TRY(c.dBOut.ensure((size_t)nq * k2));
+  VT_TRY(c.hBOut.ensure((size_t)nq * k2));
+  VT_TRY(c.dBOutCount.ensure(nq));
+  VT_TRY(c.hBOutCount.ensure(nq));
+  VT_TRY(c.dBCount.ensure(nq));
+  VT_TRY(c.hBCount.ensure(nq));
+  std::vector<uint32_t> qnz(nq, 0);
+  std::memset(c.hBQ.p, 0, (size_t)nq * ld * sizeof(float));
+  std::memset(c.hBQbits.p, 0, (size_t)nq * words * sizeof(uint64_t));
+  for (uint32_t i = 0; i < nq; ++i) {
+    const float *q = queries + which[i] * d;
+    std::memcpy(c.hBQ.p + (size_t)i * ld, q, (size_t)d * sizeof(float));
+    uint64_t *w = c.hBQbits.p + (size_t)i * words;
+    for (uint32_t j = 0; j < d; ++j) {
+      qnz[i] += q[j] != 0.0f ? 1u : 0u;
+      if (q[j] >= 0.0f) w[j / 64] |= 1ull << (j % 64);  // distances.rs:413-423
+    }
+    c.hBCount.p[i] = k1;
+  }
+  VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, (size_t)nq * ld * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  VT_HIP(hipMemcpyAsync(c.dBQbits.p, c.hBQbits.p, (size_t)nq * words * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
+  VT_HIP(hipMemcpyAsync(c.dBCount.p, c.hBCount.p, (size_t)nq * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+  VT_HIP(hipMemsetAsync(c.dHamHist.p, 0, (size_t)nq * hist_stride * sizeof(uint32_t), c.stream));
+  c.ham_dirty = true;  // (the single-query path's two alternating histograms live in the same buffer)
+  vt::HammingMultiArgs h{};
+  h.bits = ix->dBits.p;
+  h.qbits = c.dBQbits.p;
+  h.n = n;
+  h.words = words;
+  h.pairs = pairs;
+  h.d = d;
+  h.nq = nq;
+  h.dist = c.dDist16.p;
+  h.dist_stride = dist_stride;
+  h.hist = c.dHamHist.p;
+  h.hist_stride = hist_stride;
+  h.list_count = c.dHamCount.p;
+  const uint32_t blocks = c.grid_for((n + 63) / 64, vt::hamming_multi_lds_bytes(d, words, nq), c.hamming_blocks_per_cu);
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+  VT_HIP(vt::launch_hamming_dist_multi(h, blocks, c.stream));
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+  vt::HammingCollectArgs g{};
+  g.dist = c.dDist16.p;
+  g.id_rank = ix->dRank.p;
+  g.n = n;
+  g.d = d;
+  g.k = k1;
+  g.hist = c.dHamHist.p;
+  g.hist_next = nullptr;
+  g.list_count = c.dHamCount.p;
+  g.keys = c.dPartKeys.p;
+  g.pay = c.dPartPay.p;
+  g.cap = kListCap;
+  g.status = c.dStatus.p;
+  g.dist_stride = dist_stride;
+  g.hist_stride = hist_stride;
+  if (nq >= 2) {
+    VT_HIP(vt::launch_hamming_collect_multi(g, (uint32_t)c.num_cus, nq, c.stream));
+    VT_HIP(vt::launch_select_lists(c.dPartKeys.p, c.dPartPay.p, nq, kListCap, c.dHamCount.p, k1, c.dStageB.p,
+                                   (uint32_t)sizeof(ResultBlock), c.stream));
+  } else {
+    VT_HIP(vt::launch_hamming_collect(g, (uint32_t)c.num_cus * 4, c.stream));
+    VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, kListCap, k1, 0, 0, nullptr, c.dStageB.p, c.dSelKeys.p, c.dSelPay.p, c.stream,
+                             c.dHamCount.p));
+  }
+  // stage 2: vector_top_k over each query's candidates (search.rs:38-73)
+  const uint32_t gather_qstride = (uint32_t)(sizeof(ResultBlock) / sizeof(uint32_t));
+  if (ix->metric == VT_COSINE) {
+    VT_TRY(c.dCandKeys.ensure((size_t)nq * k1));
+    VT_TRY(c.dCandPay.ensure((size_t)nq * k1));
+    vt::CosineRerankArgs a{};
+    a.X = ix->dX;
+    a.stride = ix->ld;
+    a.q = c.dBQ.p;
+    a.id_rank = ix->dRank.p;
+    a.gather = &c.dStageB.p->e[0].row;
+    a.gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
+    a.n = k1;
+    a.d = d;
+    a.out_keys = c.dCandKeys.p;
+    a.out_pay = c.dCandPay.p;
+    a.status = c.dStatus.p;
+    a.q_stride = ld;
+    a.gather_qstride = gather_qstride;
+    VT_HIP(vt::launch_cosine_rerank_batch(a, nq, c.stream));
+    VT_HIP(vt::launch_batch_select(c.dCandKeys.p, c.dCandPay.p, nq, k1, k2, c.dBOut.p, c.dBOutCount.p, c.stream));
+  } else {
+    constexpr uint32_t kBlocksPerQuery = 2;
+    VT_TRY(c.dCandKeys.ensure((size_t)nq * kBlocksPerQuery * k2));
+    VT_TRY(c.dCandPay.ensure((size_t)nq * kBlocksPerQuery * k2));
+    // the stage-1 blocks are 4 112 bytes apart = 257 entries of 16: K1's batch mode walks query y's
+    // list at gather + y * batch_cap * gather_stride
+    static_assert(sizeof(ResultBlock) == 257 * sizeof(vt::Entry), "stage blocks as K1 batch lists");
+    vt::ScanArgs sa{};
+    sa.X = ix->dX;
+    sa.stride = ix->ld;
+    sa.q = c.dBQ.p;
+    sa.id_rank = ix->dRank.p;
+    sa.gather = &c.dStageB.p->e[0].row;
+    sa.gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
+    sa.n = 257;
+    sa.d = d;
+    sa.metric = ix->metric;
+    sa.order = ix->order;
+    sa.k = k2;
+    sa.part_keys = c.dCandKeys.p;
+    sa.part_pay = c.dCandPay.p;
+    sa.status = c.dStatus.p;
+    sa.batch_counts = c.dBCount.p;
+    sa.batch_cap = 257;
+    // (jaccard needs the query's non-zero count: one value per launch, so those go query by query)
+    if (ix->metric == VT_JACCARD) return kRetryInternal;
+    VT_HIP(vt::launch_scan_batch(sa, kBlocksPerQuery, nq, c.stream));
+    VT_HIP(vt::launch_batch_select(c.dCandKeys.p, c.dCandPay.p, nq, kBlocksPerQuery * k2, k2, c.dBOut.p, c.dBOutCount.p, c.stream));
+  }
+  int status = 0;
+  VT_HIP(hipMemcpyAsync(c.hBOut.p, c.dBOut.p, (size_t)nq * k2 * sizeof(vt::Entry), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(c.hBOutCount.p, c.dBOutCount.p, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(&status, c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  if (c.profiling) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    c.prof.hamming_launches += 1;
+    c.prof.hamming_ms += ms;
+    c.prof.hamming_bytes += (uint64_t)n * words * 8;
+    c.prof.hamming_queries += nq;
+  }
+  if (status != 0) return kRetryInternal;  // a tie list overflowed / a rerank overflowed: one by one, each reports its own
+  for (uint32_t i = 0; i < nq; ++i) {
+    const uint32_t got = std::min<uint32_t>(c.hBOutCount.p[i], k2);
+    std::vector<vt::Entry> entries(c.hBOut.p + (size_t)i * k2, c.hBOut.p + (size_t)i * k2 + got);
+    VT_TRY(make_hits(ix, entries, &out[which[i]]));
+  }
+  return VT_OK;
+}
+
+// quantized_search for nq queries (rows of `queries`): groups of up to eight share a sweep; what
+// the groups cannot take (one query left over, a shape outside the group path, a retry) goes
+// through quantized_ready one by one.  Ranks strictly current, sign bits current.
+int quantized_batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, size_t candidates, size_t limit,
+                          vt_hits **out) {
+  for (size_t i = 0; i < nq; ++i) VT_TRY(validate_vector(queries + i * d, d, ix->dim));
+  if (ix->n == 0 || candidates == 0 || limit == 0) {
+    for (size_t i = 0; i < nq; ++i) VT_TRY(empty_hits(&out[i]));
+    return VT_OK;
+  }
+  std::vector<char> done(nq, 0);
+  if (nq >= 2 && quantized_group_applies(ix, candidates, limit)) {
+    const uint32_t per = quantized_group_size(ix);
+    for (size_t g0 = 0; g0 < nq && per >= 2; g0 += per) {
+      std::vector<size_t> which;
+      for (size_t i = g0; i < std::min(nq, g0 + per); ++i) which.push_back(i);
+      if (which.size() < 2) break;
+      const int st = quantized_group(ix, c, queries, which, candidates, limit, out);
+      if (st == VT_OK) {
+        for (size_t i : which) done[i] = 1;
+      } else if (st == kRetryInternal) {
+        for (size_t i : which) {
+          delete out[i];
+          out[i] = nullptr;
+        }
+      } else {
+        return st;
+      }
+    }
+  }
+  for (size_t i = 0; i < nq; ++i)
+    if (!done[i]) VT_TRY(quantized_ready(ix, c, queries + i * d, d, candidates, limit, &out[i]));
+  return VT_OK;
+}
+
 // collection.ex:245-260 on a shard whose ranks are strictly current.
 int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *stages, size_t nstages,
                  size_t candidates, size_t limit, vt_hits **out, LocalStages *local = nullptr) {

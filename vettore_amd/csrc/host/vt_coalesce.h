@@ -31,15 +31,18 @@ bool coalescing_enabled() {
   return !(e && e[0] == '0');
 }
 
+enum { COALESCE_SEARCH = 0, COALESCE_QUANTIZED = 1 };  // vt_host::Waiting::kind (aux = candidates)
+
 struct CoalesceOps {
   static constexpr int kOutOfMemory = VT_ERR_NOMEM;
   static vt_host::Coalescer &coalescer(vt_flat *h) { return h->co; }
   static unsigned slots(vt_flat *h) { return coalesce_slots(h->approx_bytes.load(std::memory_order_relaxed)); }
-  static int search_direct(vt_flat *h, const float *query, size_t n, size_t limit, vt_hits **out) {
+  static int search_direct(vt_flat *h, int kind, size_t aux, const float *query, size_t n, size_t limit, vt_hits **out) {
+    if (kind == COALESCE_QUANTIZED) return quantized_direct(h, query, n, aux, limit, out);
     return ::search_direct(h, query, n, limit, out);
   }
   static void search_alone(vt_flat *h, vt_host::Waiting *w) {
-    w->status = ::search_direct(h, w->query, w->n, w->limit, w->out);
+    w->status = search_direct(h, w->kind, w->aux, w->query, w->n, w->limit, w->out);
     if (w->status != VT_OK) w->error = g_last_error;
   }
   // every query is judged on its own (flat.rs:97-101), as if it had come alone
@@ -56,12 +59,14 @@ struct CoalesceOps {
       }
     }
   }
-  static int batch(vt_flat *h, const float *queries, size_t nq, size_t n, size_t limit, vt_hits **outs) {
+  static int batch(vt_flat *h, int kind, size_t aux, const float *queries, size_t nq, size_t n, size_t limit, vt_hits **outs) {
+    if (kind == COALESCE_QUANTIZED) return quantized_batch_direct(h, queries, nq, n, aux, limit, outs);
     return batch_direct(h, queries, nq, n, limit, outs);
   }
   // a batch needs strictly current id ranks; a lone search after unsorted inserts does not
-  static bool must_disband(vt_flat *h, size_t limit) {
-    if (h->multi()) return false;
+  // (a quantized search needs them either way: nothing to spare by disbanding)
+  static bool must_disband(vt_flat *h, int kind, size_t limit) {
+    if (h->multi() || kind != COALESCE_SEARCH) return false;
     std::shared_lock<std::shared_mutex> rl(h->rw);
     return shard_stale(h->shards[0].get(), NEED_STRICT_RANKS, limit);
   }
@@ -73,6 +78,13 @@ struct CoalesceOps {
 int coalesced_search(vt_flat *h, const float *query, size_t n, size_t limit, vt_hits **out) {
   if (limit == 0 || limit > (size_t)vt::kMaxFusedK || n == 0 || !coalescing_enabled()) return search_direct(h, query, n, limit, out);
   return vt_host::coalesced_search_t<vt_flat, CoalesceOps>(h, query, n, limit, out);
+}
+
+// quantized_search callers that meet on a handle share sweeps of the bit matrix (quantized_group)
+int coalesced_quantized(vt_flat *h, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out) {
+  if (limit == 0 || candidates == 0 || candidates > (size_t)vt::kMaxFusedK || n == 0 || h->multi() || !coalescing_enabled())
+    return quantized_direct(h, query, n, candidates, limit, out);
+  return vt_host::coalesced_search_t<vt_flat, CoalesceOps>(h, query, n, limit, out, COALESCE_QUANTIZED, candidates);
 }
 
 }  // namespace

@@ -169,12 +169,15 @@ struct LeaseT {
 struct Waiting {
   const float *query;
   size_t n, limit;
+  int kind;    // which entry point (0: flat_search; the instantiating side names the others)
+  size_t aux;  // its extra parameter (quantized_search: candidates); only equals travel together
   vt_hits **out;
   int status = 0;
   std::string error;
   enum { QUEUED, LEADS, ALONE, DONE } state = QUEUED;
   std::condition_variable wake;  // its own: a finished batch wakes exactly its members and the next leader
-  Waiting(const float *q, size_t n_, size_t limit_, vt_hits **out_) : query(q), n(n_), limit(limit_), out(out_) {}
+  Waiting(const float *q, size_t n_, size_t limit_, int kind_, size_t aux_, vt_hits **out_)
+      : query(q), n(n_), limit(limit_), kind(kind_), aux(aux_), out(out_) {}
 };
 struct Coalescer {
   std::mutex mu;
@@ -192,7 +195,7 @@ constexpr size_t kCoalesceMax = 256;
 //   Ops::search_alone(h, w)                            w's own search; fills w->status / w->error
 //   Ops::judge(h, members, &good)                      every query judged on its own (flat.rs:97-101):
 //                                                      the bad ones get their status, the others go to `good`
-//   Ops::batch(h, queries, nq, n, limit, outs) -> st   one batch; outs[i] = query i's hits
+//   Ops::batch(h, kind, aux, queries, nq, n, limit, outs) -> st   one batch; outs[i] = query i's hits
 template <class H, class Ops>
 void run_coalesced_t(H *h, std::vector<Waiting *> &members) {
   const size_t limit = members[0]->limit, n = members[0]->n;
@@ -209,7 +212,7 @@ void run_coalesced_t(H *h, std::vector<Waiting *> &members) {
   std::vector<float> qs(good.size() * n);
   for (size_t i = 0; i < good.size(); ++i) std::memcpy(&qs[i * n], good[i]->query, n * sizeof(float));
   std::vector<vt_hits *> outs(good.size(), nullptr);
-  const int st = Ops::batch(h, qs.data(), good.size(), n, limit, outs.data());
+  const int st = Ops::batch(h, members[0]->kind, members[0]->aux, qs.data(), good.size(), n, limit, outs.data());
   if (st == 0) {
     for (size_t i = 0; i < good.size(); ++i) *good[i]->out = outs[i];
     return;
@@ -220,18 +223,18 @@ void run_coalesced_t(H *h, std::vector<Waiting *> &members) {
 
 //   Ops::coalescer(h) -> Coalescer &
 //   Ops::slots(h) -> unsigned                          operations in flight before callers queue
-//   Ops::search_direct(h, query, n, limit, out) -> st  a search outside the coalescer
-//   Ops::must_disband(h, limit) -> bool                a batch would force work a lone search avoids
+//   Ops::search_direct(h, kind, aux, query, n, limit, out) -> st  a search outside the coalescer
+//   Ops::must_disband(h, kind, limit) -> bool          a batch would force work a lone search avoids
 //   Ops::run(h, members)                               normally run_coalesced_t<H, Ops>
 //   Ops::drop_hits(hits)                               frees a hit list
 //   Ops::set_last_error(msg)                           the calling thread's error text
 //   Ops::kOutOfMemory                                  status of a batch that threw
 template <class H, class Ops>
-int coalesced_search_t(H *h, const float *query, size_t n, size_t limit, vt_hits **out) {
+int coalesced_search_t(H *h, const float *query, size_t n, size_t limit, vt_hits **out, int kind = 0, size_t aux = 0) {
   Coalescer &co = Ops::coalescer(h);
   const unsigned max_active = Ops::slots(h);
   *out = nullptr;  // ("answered" is read off this pointer if a batch dies half way)
-  Waiting me(query, n, limit, out);
+  Waiting me(query, n, limit, kind, aux, out);
   std::vector<Waiting *> members;
   members.reserve(kCoalesceMax);  // (no allocation once others depend on this caller)
   {
@@ -248,7 +251,7 @@ int coalesced_search_t(H *h, const float *query, size_t n, size_t limit, vt_hits
       }
       if (me.state == Waiting::ALONE) {
         lk.unlock();
-        return Ops::search_direct(h, query, n, limit, out);
+        return Ops::search_direct(h, kind, aux, query, n, limit, out);
       }
       // LEADS (the operation that just finished passed its slot on: `active` already counts this one).
       // Callers that have just been answered are about to come back -- give them a moment (a few
@@ -264,7 +267,7 @@ int coalesced_search_t(H *h, const float *query, size_t n, size_t limit, vt_hits
                              [&] { return co.waiting.size() >= want; });
       }
       for (auto it = co.waiting.begin(); it != co.waiting.end() && members.size() + 1 < kCoalesceMax;) {
-        if ((*it)->limit == limit && (*it)->n == n) {
+        if ((*it)->limit == limit && (*it)->n == n && (*it)->kind == kind && (*it)->aux == aux) {
           members.push_back(*it);
           it = co.waiting.erase(it);
         } else {
@@ -276,7 +279,7 @@ int coalesced_search_t(H *h, const float *query, size_t n, size_t limit, vt_hits
   }
   // a batch needs strictly current id ranks; a lone search after unsorted inserts does not
   // (lazy ranks): then nobody is made to wait for a re-rank -- everyone searches alone
-  const bool disband = members.size() > 1 && Ops::must_disband(h, limit);
+  const bool disband = members.size() > 1 && Ops::must_disband(h, kind, limit);
   const auto t0 = std::chrono::steady_clock::now();
   if (disband) {
     {

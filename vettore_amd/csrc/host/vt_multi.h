@@ -724,6 +724,42 @@ int search_direct(vt_flat *h, const float *query, size_t n, size_t limit, vt_hit
                      [&](Shard *ix, Ctx &c) -> int { return search_ready(ix, c, query, n, limit, out); });
 }
 
+// quantized_search as one caller runs it (collection.ex:276-295).
+int quantized_direct(vt_flat *h, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out) {
+  if (h->multi()) {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    if (h->poisoned) return poisoned_status();
+    return quantized_multi(h, query, n, candidates, limit, out);
+  }
+  return read_single(h, NEED_STRICT_RANKS | NEED_BITS, limit, [&](Shard *ix, Ctx &c) -> int {
+    return quantized_ready(ix, c, query, n, candidates, limit, out);
+  });
+}
+
+// nq quantized searches, one hit list each (or one status for all): groups of up to eight share
+// a sweep of the bit matrix on a one-shard handle; a multi-shard handle takes them one by one.
+int quantized_batch_direct(vt_flat *h, const float *queries, size_t nq, size_t d, size_t candidates, size_t limit, vt_hits **out) {
+  for (size_t i = 0; i < nq; ++i) out[i] = nullptr;
+  int st = VT_OK;
+  if (h->multi()) {
+    for (size_t i = 0; i < nq && st == VT_OK; ++i) st = quantized_direct(h, queries + i * d, d, candidates, limit, &out[i]);
+  } else {
+    st = read_single(h, NEED_STRICT_RANKS | NEED_BITS, limit, [&](Shard *ix, Ctx &c) -> int {
+      for (size_t i = 0; i < nq; ++i) {  // (a second run after an escalation starts clean)
+        delete out[i];
+        out[i] = nullptr;
+      }
+      return quantized_batch_ready(ix, c, queries, nq, d, candidates, limit, out);
+    });
+  }
+  if (st != VT_OK)
+    for (size_t i = 0; i < nq; ++i) {
+      delete out[i];
+      out[i] = nullptr;
+    }
+  return st;
+}
+
 // flat_search_batch: nq queries of d floats, one hit list each, or one status for all.
 int batch_direct(vt_flat *h, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
   for (size_t i = 0; i < nq; ++i) out[i] = nullptr;

@@ -42,6 +42,10 @@ struct Ctx {
   DevBuf<vt::Entry> dBOut;
   DevBuf<unsigned long long> dBNorm;
   DevBuf<unsigned char> dBQimage;  // K2b: the batch's queries in bf16, fragment order
+  // batched quantized search: the queries' sign bits, one stage-1 block per query
+  DevBuf<uint64_t> dBQbits;
+  PinnedBuf<uint64_t> hBQbits;
+  DevBuf<ResultBlock> dStageB;
   PinnedBuf<float> hBQ, hBTau;
   PinnedBuf<uint32_t> hBCount, hBOutCount;
   PinnedBuf<vt::Entry> hBOut;

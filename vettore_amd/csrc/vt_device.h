@@ -211,13 +211,38 @@ struct HammingCollectArgs {
   const uint32_t *id_rank;
   uint32_t n, d, k;
   const uint32_t *hist;
-  uint32_t *hist_next;    // the other histogram, cleared for the next query
+  uint32_t *hist_next;    // the other histogram, cleared for the next query (null: nothing to clear)
   uint32_t *list_count;
   uint64_t *keys;         // [cap]
   Payload *pay;           // [cap]
   uint32_t cap;
   int *status;
+  // several queries in one launch (grid.y = queries): query y reads dist + y * dist_stride and
+  // hist + y * hist_stride, counts in list_count[y] and appends to keys / pay + y * cap
+  uint32_t dist_stride, hist_stride;
 };
+// K4h for up to kHammingMultiMax queries in ONE sweep of the bit matrix (concurrent / batched
+// quantized searches): query y's distances land in dist + y * dist_stride, its histogram in
+// hist + y * hist_stride (zeroed beforehand); list_count[0..nq) is cleared for the collect pass.
+constexpr uint32_t kHammingMultiMax = 8;
+struct HammingMultiArgs {
+  const uint64_t *bits;   // tiled layout, as for K4
+  const uint64_t *qbits;  // [nq][words]
+  uint32_t n, words, pairs, d, nq;
+  uint16_t *dist;
+  uint32_t dist_stride;   // in u16 (a multiple of 8)
+  uint32_t *hist;
+  uint32_t hist_stride;   // in u32, >= d + 1
+  uint32_t *list_count;   // [nq]
+};
+size_t hamming_multi_lds_bytes(uint32_t d, uint32_t words, uint32_t nq);
+hipError_t launch_hamming_dist_multi(const HammingMultiArgs &a, uint32_t blocks, hipStream_t s);
+// the collect pass for nq queries at once (HammingCollectArgs with the strides set)
+hipError_t launch_hamming_collect_multi(const HammingCollectArgs &a, uint32_t blocks, uint32_t nq, hipStream_t s);
+// K3 for nq lists whose lengths were decided on the device: list y = keys / pay + y * m_stride,
+// m_dev[y] entries; winners (sorted) to the block at out + y * out_stride bytes.
+hipError_t launch_select_lists(const uint64_t *keys, const Payload *pay, uint32_t nq, uint32_t m_stride, const uint32_t *m_dev,
+                               uint32_t k, void *out, uint32_t out_stride, hipStream_t s);
 size_t hamming_hist_lds_bytes(uint32_t d);
 hipError_t launch_hamming_dist(const HammingHistArgs &a, uint32_t blocks, hipStream_t s);
 hipError_t launch_hamming_collect(const HammingCollectArgs &a, uint32_t blocks, hipStream_t s);
@@ -262,8 +287,12 @@ struct CosineRerankArgs {
   uint64_t *out_keys;      // [n]
   Payload *out_pay;        // [n]
   int *status;
+  // several queries in one launch (launch_cosine_rerank_batch, grid.y = queries): query y uses
+  // q + y * q_stride, gather + y * gather_qstride and writes to out_keys / out_pay + y * n
+  uint32_t q_stride, gather_qstride;
 };
 hipError_t launch_cosine_rerank(const CosineRerankArgs &a, hipStream_t s);
+hipError_t launch_cosine_rerank_batch(const CosineRerankArgs &a, uint32_t nq, hipStream_t s);
 
 // Cross-shard merge on the device: `blocks` is `world` ResultBlock prefixes
 // (16-B header + k entries each, `block_bytes` apart) as gathered from the shards;

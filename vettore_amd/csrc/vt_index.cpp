@@ -553,14 +553,15 @@ int vt_flat_quantized_search(vt_flat *h, const float *query, size_t n, size_t ca
   return guarded([&]() -> int {
   if (!h || !out || (!query && n)) return VT_ERR_ARGUMENT;
   *out = nullptr;
-  if (h->multi()) {
-    std::shared_lock<std::shared_mutex> rl(h->rw);
-    if (h->poisoned) return poisoned_status();
-    return quantized_multi(h, query, n, candidates, limit, out);
-  }
-  return read_single(h, NEED_STRICT_RANKS | NEED_BITS, limit, [&](Shard *ix, Ctx &c) -> int {
-    return quantized_ready(ix, c, query, n, candidates, limit, out);
+  return coalesced_quantized(h, query, n, candidates, limit, out);
   });
+}
+
+int vt_flat_quantized_search_batch(vt_flat *h, const float *queries, size_t nq, size_t d, size_t candidates, size_t limit,
+                                   vt_hits **out) {
+  return guarded([&]() -> int {
+  if (!h || !out || (nq && d && !queries)) return VT_ERR_ARGUMENT;
+  return quantized_batch_direct(h, queries, nq, d, candidates, limit, out);
   });
 }
 
@@ -814,6 +815,7 @@ int vt_flat_get_profile(vt_flat *h, vt_profile *out, int reset) {
       t.nominate_queries += p.nominate_queries;
       t.nominate_second_passes += p.nominate_second_passes;
       t.nominate_candidates += p.nominate_candidates;
+      t.hamming_queries += p.hamming_queries;
       if (reset) c.prof = vt_profile{};
     });
   if (reset) h->xprof = vt_profile{};

@@ -83,12 +83,14 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
                                                            Payload *__restrict__ part_pay,
                                                            const uint32_t *__restrict__ m_dev, uint32_t out_stride) {
   extern __shared__ __align__(16) unsigned char smem[];
-  if (m_dev) m = *m_dev < m ? *m_dev : m;  // list length decided on the device (hamming_collect_kernel)
+  const uint32_t m_stride = m;
+  // list length decided on the device (hamming_collect_kernel): one count per query
+  if (m_dev) m = m_dev[blockIdx.y] < m ? m_dev[blockIdx.y] : m;
   if (gridDim.y > 1) {
-    // one list of m keys per query (grid.y = queries): query y's winners go to the block
+    // one list of up to m keys per query (grid.y = queries): query y's winners go to the block
     // `out_stride` bytes after query y - 1's (header + k entries when packed tightly)
-    keys += (size_t)blockIdx.y * m;
-    pay += (size_t)blockIdx.y * m;
+    keys += (size_t)blockIdx.y * m_stride;
+    pay += (size_t)blockIdx.y * m_stride;
     out = reinterpret_cast<ResultBlock *>(reinterpret_cast<unsigned char *>(out) + (size_t)blockIdx.y * out_stride);
   }
   // part_keys != nullptr: the winners go, unsorted and padded with kEmptyKey, to
@@ -590,14 +592,102 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_dist_kernel(con
   }
 }
 
-__global__ __launch_bounds__(256) void hamming_collect_kernel(const HammingCollectArgs a) {
+// K4h's distance pass for up to kHammingMultiMax queries at once: the bit tiles are read ONCE,
+// every lane popcounts its row against all the queries (their words sit in LDS: one broadcast
+// ds_read_b64 per word and query), writes nq 2-byte distances and counts them in nq LDS
+// histograms.  Concurrent quantized_search callers (collection.ex:276-295 under the read lock)
+// then share a sweep of the 0.96-GB bit matrix the way plain searches share a scan of the rows.
+template <int PAIRS>
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_dist_multi_kernel(const HammingMultiArgs a) {
+  extern __shared__ __align__(16) uint32_t hm_lds[];  // [nq][d + 1] histograms, then [nq][2 * pairs] query words (u64)
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t pairs = PAIRS > 0 ? (uint32_t)PAIRS : a.pairs;
+  const uint32_t bins = a.d + 1;
+  const uint32_t hist_words = (a.nq * bins + 1u) & ~1u;
+  uint64_t *qw = reinterpret_cast<uint64_t *>(hm_lds + hist_words);  // [nq][2 * pairs], masked tail, zero padding word
+  const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+  const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
+  const uint32_t ntiles = (a.n + kWave - 1) / kWave;
+  const uint32_t rem = a.d % 64;
+  const uint64_t last_mask = rem ? ((1ull << rem) - 1) : ~0ull;  // distances.rs:472-481 word_mask
+  for (uint32_t i = threadIdx.x; i < a.nq * bins; i += blockDim.x) hm_lds[i] = 0;
+  for (uint32_t i = threadIdx.x; i < a.nq * 2 * pairs; i += blockDim.x) {
+    const uint32_t q = i / (2 * pairs), w = i - q * 2 * pairs;
+    qw[i] = w < a.words ? a.qbits[(size_t)q * a.words + w] & (w == a.words - 1 ? last_mask : ~0ull) : 0ull;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < a.nq) a.list_count[threadIdx.x] = 0;
+  __syncthreads();
+  const u64x2 *bits = reinterpret_cast<const u64x2 *>(a.bits);
+  for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
+    const u64x2 *base = bits + ((size_t)t * pairs * kWave + lane);
+    const uint32_t grow = t * kWave + lane;
+    auto row_words = [&](uint32_t j) -> u64x2 {
+      u64x2 v = __builtin_nontemporal_load(base + (size_t)j * kWave);
+      // (the row's padding bits beyond d are zero in the matrix; the tail mask is on the query side
+      // AND here, as packed_hamming masks both operands' last word)
+      if (2 * j == a.words - 1) v.x &= last_mask;
+      if (2 * j + 1 == a.words - 1) v.y &= last_mask;
+      if (2 * j + 1 >= a.words) v.y = 0ull;
+      return v;
+    };
+    if (PAIRS > 0) {
+      u64x2 v[PAIRS > 0 ? PAIRS : 1];
+#pragma unroll
+      for (int j = 0; j < PAIRS; ++j) v[j] = row_words(j);
+      for (uint32_t q = 0; q < a.nq; ++q) {
+        const uint64_t *w = qw + (size_t)q * 2 * PAIRS;
+        uint32_t ham = 0;
+#pragma unroll
+        for (int j = 0; j < PAIRS; ++j) ham += __popcll(v[j].x ^ w[2 * j]) + __popcll(v[j].y ^ w[2 * j + 1]);
+        if (grow < a.n) {
+          a.dist[(size_t)q * a.dist_stride + grow] = (uint16_t)ham;
+          atomicAdd(&hm_lds[q * bins + ham], 1u);
+        }
+      }
+    } else {
+      for (uint32_t q = 0; q < a.nq; ++q) {
+        const uint64_t *w = qw + (size_t)q * 2 * pairs;
+        uint32_t ham = 0;
+        for (uint32_t j = 0; j < pairs; ++j) {
+          const u64x2 v = row_words(j);
+          ham += __popcll(v.x ^ w[2 * j]) + __popcll(v.y ^ w[2 * j + 1]);
+        }
+        if (grow < a.n) {
+          a.dist[(size_t)q * a.dist_stride + grow] = (uint16_t)ham;
+          atomicAdd(&hm_lds[q * bins + ham], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < a.nq * bins; i += blockDim.x) {
+    const uint32_t c = hm_lds[i];
+    if (c) {
+      const uint32_t q = i / bins;
+      atomicAdd(&a.hist[(size_t)q * a.hist_stride + (i - q * bins)], c);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void hamming_collect_kernel(const HammingCollectArgs a0) {
   extern __shared__ uint32_t hc_lds[];  // [d + 1]
   __shared__ uint32_t s_dstar;
+  HammingCollectArgs a = a0;
+  if (gridDim.y > 1) {  // query y of a batch (launch_hamming_collect_multi)
+    const uint32_t y = blockIdx.y;
+    a.dist += (size_t)y * a.dist_stride;
+    a.hist += (size_t)y * a.hist_stride;
+    a.list_count += y;
+    a.keys += (size_t)y * a.cap;
+    a.pay += (size_t)y * a.cap;
+  }
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t bins = a.d + 1;
   for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) hc_lds[i] = a.hist[i];
   // clear the other histogram for the next query (grid-wide, bins are few)
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < bins; i += gridDim.x * blockDim.x) a.hist_next[i] = 0;
+  if (a.hist_next)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < bins; i += gridDim.x * blockDim.x) a.hist_next[i] = 0;
   __syncthreads();
   if (threadIdx.x < kWave) {
     // D* = smallest D with count(distance <= D) >= k; lane l owns bins [l*B, (l+1)*B)
@@ -743,8 +833,16 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
 // then lanes 0..2 run the three sequential f64 sums |q|^2, |x|^2, q.x in index
 // order side by side (distances.rs:179-185 f64_dot is a sequential fold; products
 // of two f32 are exact in f64, so only the order of the additions matters).
-__global__ __launch_bounds__(64) void cosine_rerank_kernel(const CosineRerankArgs a) {
+__global__ __launch_bounds__(64) void cosine_rerank_kernel(const CosineRerankArgs a0) {
   extern __shared__ __align__(16) float crs[];  // [ld] query, [ld] row
+  CosineRerankArgs a = a0;
+  if (gridDim.y > 1) {  // query y of a batch (launch_cosine_rerank_batch)
+    const uint32_t y = blockIdx.y;
+    a.q += (size_t)y * a.q_stride;
+    if (a.gather) a.gather += (size_t)y * a.gather_qstride;
+    a.out_keys += (size_t)y * a.n;
+    a.out_pay += (size_t)y * a.n;
+  }
   const uint32_t i = blockIdx.x;
   const int lane = threadIdx.x;
   const uint32_t src = a.gather ? a.gather[(size_t)i * a.gather_stride] : i;
@@ -1310,6 +1408,56 @@ hipError_t launch_hamming_collect(const HammingCollectArgs &a, uint32_t blocks, 
   return hipGetLastError();
 }
 
+hipError_t launch_hamming_collect_multi(const HammingCollectArgs &a, uint32_t blocks, uint32_t nq, hipStream_t s) {
+  if (a.d > kHammingHistMaxDim || a.k == 0 || nq == 0 || nq > kHammingMultiMax || a.hist_next) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(hamming_collect_kernel, dim3(blocks, nq), dim3(256), hamming_hist_lds_bytes(a.d), s, a);
+  return hipGetLastError();
+}
+
+size_t hamming_multi_lds_bytes(uint32_t d, uint32_t words, uint32_t nq) {
+  const size_t hist_words = ((size_t)nq * (d + 1) + 1) & ~(size_t)1;
+  return hist_words * sizeof(uint32_t) + (size_t)nq * 2 * ((words + 1) / 2) * sizeof(uint64_t);
+}
+
+hipError_t launch_hamming_dist_multi(const HammingMultiArgs &a, uint32_t blocks, hipStream_t s) {
+  if (a.words == 0 || a.pairs != (a.words + 1) / 2 || a.nq == 0 || a.nq > kHammingMultiMax || a.hist_stride < a.d + 1 ||
+      a.dist_stride % 8 != 0)
+    return hipErrorInvalidValue;
+  const size_t lds = hamming_multi_lds_bytes(a.d, a.words, a.nq);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+#define VT_HAMM_CASE(P)                                                                                        \
+  case P:                                                                                                      \
+    hipLaunchKernelGGL((hamming_dist_multi_kernel<P>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a); \
+    break;
+  switch (a.pairs) {
+    VT_HAMM_CASE(1)
+    VT_HAMM_CASE(2)
+    VT_HAMM_CASE(3)
+    VT_HAMM_CASE(4)
+    VT_HAMM_CASE(6)
+    VT_HAMM_CASE(8)
+    VT_HAMM_CASE(12)
+    VT_HAMM_CASE(16)
+    default:
+      hipLaunchKernelGGL((hamming_dist_multi_kernel<0>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+  }
+#undef VT_HAMM_CASE
+  return hipGetLastError();
+}
+
+hipError_t launch_select_lists(const uint64_t *keys, const Payload *pay, uint32_t nq, uint32_t m_stride, const uint32_t *m_dev,
+                               uint32_t k, void *out, uint32_t out_stride, hipStream_t s) {
+  if (k == 0 || k > (uint32_t)kMaxFusedK || nq == 0 || nq > 65535 || !m_dev || out_stride < 16 + k * sizeof(Entry) || out_stride % 16)
+    return hipErrorInvalidValue;
+  const size_t lds = ((size_t)k + kSelCand) * 12;
+  hipError_t e = allow_lds(select_topk_kernel, lds);
+  if (e != hipSuccess) return e;
+  // (grid.y >= 2 is what makes the kernel index its lists by query: a batch of one goes through launch_select)
+  hipLaunchKernelGGL(select_topk_kernel, dim3(1, nq), dim3(1024), lds, s, keys, pay, m_stride, k, 0ull, 0, nullptr,
+                     static_cast<ResultBlock *>(out), 0u, nullptr, nullptr, m_dev, out_stride);
+  return hipGetLastError();
+}
+
 hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32_t d, uint64_t *bits, int tiled,
                             hipStream_t s) {
   if (n == 0) return hipSuccess;
@@ -1351,13 +1499,15 @@ hipError_t launch_gather_rows(const float *src, uint32_t d, const uint32_t *map,
   return hipGetLastError();
 }
 
-hipError_t launch_cosine_rerank(const CosineRerankArgs &a, hipStream_t s) {
-  if (a.n == 0) return hipSuccess;
+hipError_t launch_cosine_rerank(const CosineRerankArgs &a, hipStream_t s) { return launch_cosine_rerank_batch(a, 1, s); }
+
+hipError_t launch_cosine_rerank_batch(const CosineRerankArgs &a, uint32_t nq, hipStream_t s) {
+  if (a.n == 0 || nq == 0) return hipSuccess;
   const size_t lds = (size_t)2 * ((a.d + 3) / 4 * 4) * sizeof(float);
   if (lds > kMaxLds) return hipErrorInvalidValue;
   hipError_t e = allow_lds(cosine_rerank_kernel, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(cosine_rerank_kernel, dim3(a.n), dim3(64), lds, s, a);
+  hipLaunchKernelGGL(cosine_rerank_kernel, dim3(a.n, nq), dim3(64), lds, s, a);
   return hipGetLastError();
 }
 

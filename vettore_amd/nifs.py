@@ -394,6 +394,20 @@ def flat_quantized_search(index: FlatRef, query, candidates: int, limit: int):
     return ("ok", _take_hits(h)) if st == 0 else _err(st)
 
 
+def flat_quantized_search_batch(index: FlatRef, queries, candidates: int, limit: int):
+    """Extension: nq quantized searches in one call ([nq][d] matrix); each hit list identical to
+    flat_quantized_search of that query -- groups of up to eight share a sweep of the sign bits."""
+    q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32))
+    if q.ndim != 2:
+        raise TypeError("badarg: queries must be a matrix")
+    nq, d = q.shape
+    outs = (C.c_void_p * max(nq, 1))()
+    st = _lib.load().vt_flat_quantized_search_batch(index.handle, _fp(q.reshape(-1)), nq, d, candidates, limit, outs)
+    if st != 0:
+        return _err(st)
+    return ("ok", [_take_hits(C.c_void_p(outs[i])) for i in range(nq)])
+
+
 def flat_funnel_search(index: FlatRef, query, stages: Sequence[int], candidates: int, limit: int):
     """collection.ex:245-260 as one native call on the resident corpus."""
     q = _f32_list(query)
