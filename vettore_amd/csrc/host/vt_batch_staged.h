@@ -690,43 +690,54 @@ int quantized_group(Shard *ix, Ctx &c, const float *queries, const std::vector<s
   constexpr uint32_t kListCap = 8192;
   const uint32_t hist_stride = (d + 1 + 63) / 64 * 64;
   const uint32_t dist_stride = (std::max<uint32_t>(ix->cap, n) + 7) / 8 * 8;
-  VT_TRY(c.dBQ.ensure((size_t)nq * ld));
-  VT_TRY(c.hBQ.ensure((size_t)nq * ld));
-  VT_TRY(c.dBQbits.ensure((size_t)nq * words));
-  VT_TRY(c.hBQbits.ensure((size_t)nq * words));
-  VT_TRY(c.dDist16.ensure((size_t)nq * dist_stride));
+  // ONE upload: the queries (f32, padded rows), their sign bits (all eight slots, the unused ones
+  // zero) and the candidate counts K1's batch mode wants sit behind each other in one pinned
+  // block and one device block (each async copy costs ~10 us of a 0.4-ms group)
+  const size_t q_floats = (size_t)nq * ld;
+  const size_t bit_words = (size_t)vt::kHammingMultiMax * 2 * pairs;  // u64, 8-byte aligned behind ld-multiples of floats
+  const size_t up_floats = q_floats + 2 * bit_words + vt::kHammingMultiMax;
+  VT_TRY(c.dBQ.ensure(up_floats));
+  VT_TRY(c.hBQ.ensure(up_floats));
+  VT_TRY(c.dDist16.ensure((size_t)vt::kHammingMultiMax * dist_stride));  // dist[row][8]
   VT_TRY(c.dHamHist.ensure(std::max<size_t>((size_t)nq * hist_stride, 2 * 8192)));
   VT_TRY(c.dHamCount.ensure(vt::kHammingMultiMax));
   VT_TRY(c.dPartKeys.ensure((size_t)nq * kListCap));
   VT_TRY(c.dPartPay.ensure((size_t)nq * kListCap));
   VT_TRY(c.dStageB.ensure(nq));
-  VT_TRY(c.dBOut.ensure((size_t)nq * k2));
-  VT_TRY(c.hBOut.ensure((size_t)nq * k2));
-  VT_TRY(c.dBOutCount.ensure(nq));
-  VT_TRY(c.hBOutCount.ensure(nq));
-  VT_TRY(c.dBCount.ensure(nq));
-  VT_TRY(c.hBCount.ensure(nq));
+  // results through the host mapping (no D2H copies): [nq][k2] entries, then nq counts, then the status word
+  const size_t res_bytes = (size_t)vt::kHammingMultiMax * vt::kMaxFusedK * sizeof(vt::Entry) + 64;
+  if (!c.dBigMapped || c.hBig.count < res_bytes) {
+    VT_TRY(c.hBig.ensure(std::max<size_t>(res_bytes, 16 + (size_t)vt::kSelListMax * sizeof(vt::Entry))));
+    VT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&c.dBigMapped), c.hBig.p, 0));
+  }
+  const size_t ent_bytes = (size_t)nq * k2 * sizeof(vt::Entry);
+  vt::Entry *dOut = reinterpret_cast<vt::Entry *>(c.dBigMapped);
+  uint32_t *dOutCount = reinterpret_cast<uint32_t *>(c.dBigMapped + ent_bytes);
+  const vt::Entry *hOut = reinterpret_cast<const vt::Entry *>(c.hBig.p);
+  const uint32_t *hOutCount = reinterpret_cast<const uint32_t *>(c.hBig.p + ent_bytes);
+  int *hStatus = reinterpret_cast<int *>(c.hBig.p + ent_bytes + 32);
   std::vector<uint32_t> qnz(nq, 0);
-  std::memset(c.hBQ.p, 0, (size_t)nq * ld * sizeof(float));
-  std::memset(c.hBQbits.p, 0, (size_t)nq * words * sizeof(uint64_t));
+  std::memset(c.hBQ.p, 0, up_floats * sizeof(float));
+  uint64_t *hbits = reinterpret_cast<uint64_t *>(c.hBQ.p + q_floats);
+  uint32_t *hcounts = reinterpret_cast<uint32_t *>(c.hBQ.p + q_floats + 2 * bit_words);
   for (uint32_t i = 0; i < nq; ++i) {
     const float *q = queries + which[i] * d;
     std::memcpy(c.hBQ.p + (size_t)i * ld, q, (size_t)d * sizeof(float));
-    uint64_t *w = c.hBQbits.p + (size_t)i * words;
+    uint64_t *w = hbits + (size_t)i * 2 * pairs;
     for (uint32_t j = 0; j < d; ++j) {
       qnz[i] += q[j] != 0.0f ? 1u : 0u;
       if (q[j] >= 0.0f) w[j / 64] |= 1ull << (j % 64);  // distances.rs:413-423
     }
-    c.hBCount.p[i] = k1;
+    hcounts[i] = k1;
   }
-  VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, (size_t)nq * ld * sizeof(float), hipMemcpyHostToDevice, c.stream));
-  VT_HIP(hipMemcpyAsync(c.dBQbits.p, c.hBQbits.p, (size_t)nq * words * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
-  VT_HIP(hipMemcpyAsync(c.dBCount.p, c.hBCount.p, (size_t)nq * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+  VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, up_floats * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  const uint64_t *dbits = reinterpret_cast<const uint64_t *>(c.dBQ.p + q_floats);
+  const uint32_t *dcounts = reinterpret_cast<const uint32_t *>(c.dBQ.p + q_floats + 2 * bit_words);
   VT_HIP(hipMemsetAsync(c.dHamHist.p, 0, (size_t)nq * hist_stride * sizeof(uint32_t), c.stream));
   c.ham_dirty = true;  // (the single-query path's two alternating histograms live in the same buffer)
   vt::HammingMultiArgs h{};
   h.bits = ix->dBits.p;
-  h.qbits = c.dBQbits.p;
+  h.qbits = dbits;
   h.n = n;
   h.words = words;
   h.pairs = pairs;
@@ -737,7 +748,9 @@ int quantized_group(Shard *ix, Ctx &c, const float *queries, const std::vector<s
   h.hist = c.dHamHist.p;
   h.hist_stride = hist_stride;
   h.list_count = c.dHamCount.p;
-  const uint32_t blocks = c.grid_for((n + 63) / 64, vt::hamming_multi_lds_bytes(d, words, nq), c.hamming_blocks_per_cu);
+  // (more waves per CU than the single pass keeps: eight queries' scalar loads and popcounts per tile
+  // want their latency hidden -- 0.230 ms at 2 blocks per CU, 0.210 at 4, N = 10 M)
+  const uint32_t blocks = c.grid_for((n + 63) / 64, vt::hamming_multi_lds_bytes(d, words, nq), std::max(4, c.hamming_blocks_per_cu));
   if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
   VT_HIP(vt::launch_hamming_dist_multi(h, blocks, c.stream));
   if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
@@ -756,15 +769,10 @@ int quantized_group(Shard *ix, Ctx &c, const float *queries, const std::vector<s
   g.status = c.dStatus.p;
   g.dist_stride = dist_stride;
   g.hist_stride = hist_stride;
-  if (nq >= 2) {
-    VT_HIP(vt::launch_hamming_collect_multi(g, (uint32_t)c.num_cus, nq, c.stream));
-    VT_HIP(vt::launch_select_lists(c.dPartKeys.p, c.dPartPay.p, nq, kListCap, c.dHamCount.p, k1, c.dStageB.p,
-                                   (uint32_t)sizeof(ResultBlock), c.stream));
-  } else {
-    VT_HIP(vt::launch_hamming_collect(g, (uint32_t)c.num_cus * 4, c.stream));
-    VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, kListCap, k1, 0, 0, nullptr, c.dStageB.p, c.dSelKeys.p, c.dSelPay.p, c.stream,
-                             c.dHamCount.p));
-  }
+  if (nq < 2) return kRetryInternal;  // (groups are of two or more: grid.y is what tells the selects apart)
+  VT_HIP(vt::launch_hamming_collect_multi(g, (uint32_t)c.num_cus * 4, nq, c.stream));
+  VT_HIP(vt::launch_select_lists(c.dPartKeys.p, c.dPartPay.p, nq, kListCap, c.dHamCount.p, k1, c.dStageB.p,
+                                 (uint32_t)sizeof(ResultBlock), c.stream));
   // stage 2: vector_top_k over each query's candidates (search.rs:38-73)
   const uint32_t gather_qstride = (uint32_t)(sizeof(ResultBlock) / sizeof(uint32_t));
   if (ix->metric == VT_COSINE) {
@@ -785,7 +793,7 @@ int quantized_group(Shard *ix, Ctx &c, const float *queries, const std::vector<s
     a.q_stride = ld;
     a.gather_qstride = gather_qstride;
     VT_HIP(vt::launch_cosine_rerank_batch(a, nq, c.stream));
-    VT_HIP(vt::launch_batch_select(c.dCandKeys.p, c.dCandPay.p, nq, k1, k2, c.dBOut.p, c.dBOutCount.p, c.stream));
+    VT_HIP(vt::launch_batch_select(c.dCandKeys.p, c.dCandPay.p, nq, k1, k2, dOut, dOutCount, c.stream));
   } else {
     constexpr uint32_t kBlocksPerQuery = 2;
     VT_TRY(c.dCandKeys.ensure((size_t)nq * kBlocksPerQuery * k2));
@@ -808,19 +816,17 @@ int quantized_group(Shard *ix, Ctx &c, const float *queries, const std::vector<s
     sa.part_keys = c.dCandKeys.p;
     sa.part_pay = c.dCandPay.p;
     sa.status = c.dStatus.p;
-    sa.batch_counts = c.dBCount.p;
+    sa.batch_counts = dcounts;
     sa.batch_cap = 257;
     // (jaccard needs the query's non-zero count: one value per launch, so those go query by query)
     if (ix->metric == VT_JACCARD) return kRetryInternal;
     VT_HIP(vt::launch_scan_batch(sa, kBlocksPerQuery, nq, c.stream));
-    VT_HIP(vt::launch_batch_select(c.dCandKeys.p, c.dCandPay.p, nq, kBlocksPerQuery * k2, k2, c.dBOut.p, c.dBOutCount.p, c.stream));
+    VT_HIP(vt::launch_batch_select(c.dCandKeys.p, c.dCandPay.p, nq, kBlocksPerQuery * k2, k2, dOut, dOutCount, c.stream));
   }
-  int status = 0;
-  VT_HIP(hipMemcpyAsync(c.hBOut.p, c.dBOut.p, (size_t)nq * k2 * sizeof(vt::Entry), hipMemcpyDeviceToHost, c.stream));
-  VT_HIP(hipMemcpyAsync(c.hBOutCount.p, c.dBOutCount.p, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
-  VT_HIP(hipMemcpyAsync(&status, c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpyAsync(hStatus, c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));  // (pinned: stays asynchronous)
   VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
   VT_HIP(hipStreamSynchronize(c.stream));
+  const int status = *hStatus;
   if (c.profiling) {
     float ms = 0.f;
     VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
@@ -831,8 +837,8 @@ int quantized_group(Shard *ix, Ctx &c, const float *queries, const std::vector<s
   }
   if (status != 0) return kRetryInternal;  // a tie list overflowed / a rerank overflowed: one by one, each reports its own
   for (uint32_t i = 0; i < nq; ++i) {
-    const uint32_t got = std::min<uint32_t>(c.hBOutCount.p[i], k2);
-    std::vector<vt::Entry> entries(c.hBOut.p + (size_t)i * k2, c.hBOut.p + (size_t)i * k2 + got);
+    const uint32_t got = std::min<uint32_t>(hOutCount[i], k2);
+    std::vector<vt::Entry> entries(hOut + (size_t)i * k2, hOut + (size_t)i * k2 + got);
     VT_TRY(make_hits(ix, entries, &out[which[i]]));
   }
   return VT_OK;
@@ -855,7 +861,11 @@ int quantized_batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, si
       std::vector<size_t> which;
       for (size_t i = g0; i < std::min(nq, g0 + per); ++i) which.push_back(i);
       if (which.size() < 2) break;
+      const auto tg = std::chrono::steady_clock::now();
       const int st = quantized_group(ix, c, queries, which, candidates, limit, out);
+      if (std::getenv("VT_TRACE_QGROUP"))
+        std::fprintf(stderr, "[vt] quantized group of %zu: status %d, %.3f ms\n", which.size(), st,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg).count());
       if (st == VT_OK) {
         for (size_t i : which) done[i] = 1;
       } else if (st == kRetryInternal) {

@@ -42,9 +42,7 @@ struct Ctx {
   DevBuf<vt::Entry> dBOut;
   DevBuf<unsigned long long> dBNorm;
   DevBuf<unsigned char> dBQimage;  // K2b: the batch's queries in bf16, fragment order
-  // batched quantized search: the queries' sign bits, one stage-1 block per query
-  DevBuf<uint64_t> dBQbits;
-  PinnedBuf<uint64_t> hBQbits;
+  // grouped quantized searches: one stage-1 block per query
   DevBuf<ResultBlock> dStageB;
   PinnedBuf<float> hBQ, hBTau;
   PinnedBuf<uint32_t> hBCount, hBOutCount;

@@ -217,27 +217,29 @@ struct HammingCollectArgs {
   Payload *pay;           // [cap]
   uint32_t cap;
   int *status;
-  // several queries in one launch (grid.y = queries): query y reads dist + y * dist_stride and
-  // hist + y * hist_stride, counts in list_count[y] and appends to keys / pay + y * cap
+  // launch_hamming_collect_multi (the queries of a group in one launch): `dist` is the
+  // interleaved column dist[row][8] (u16), query q's histogram starts at hist + q * hist_stride,
+  // its count is list_count[q], its list keys / pay + q * cap
   uint32_t dist_stride, hist_stride;
 };
 // K4h for up to kHammingMultiMax queries in ONE sweep of the bit matrix (concurrent / batched
-// quantized searches): query y's distances land in dist + y * dist_stride, its histogram in
-// hist + y * hist_stride (zeroed beforehand); list_count[0..nq) is cleared for the collect pass.
+// quantized searches): row r's eight distances land in dist[8 r .. 8 r + 8) (one 16-byte store),
+// query q's histogram in hist + q * hist_stride (zeroed beforehand); list_count[0..8) is cleared
+// for the collect pass.  qbits: [nq][2 * pairs] words, padding bits and the padding word clear.
 constexpr uint32_t kHammingMultiMax = 8;
 struct HammingMultiArgs {
   const uint64_t *bits;   // tiled layout, as for K4
   const uint64_t *qbits;  // [nq][words]
   uint32_t n, words, pairs, d, nq;
-  uint16_t *dist;
-  uint32_t dist_stride;   // in u16 (a multiple of 8)
+  uint16_t *dist;         // [n][8], 16-byte aligned
+  uint32_t dist_stride;   // (unused: the column is interleaved)
   uint32_t *hist;
   uint32_t hist_stride;   // in u32, >= d + 1
   uint32_t *list_count;   // [nq]
 };
 size_t hamming_multi_lds_bytes(uint32_t d, uint32_t words, uint32_t nq);
 hipError_t launch_hamming_dist_multi(const HammingMultiArgs &a, uint32_t blocks, hipStream_t s);
-// the collect pass for nq queries at once (HammingCollectArgs with the strides set)
+// the collect pass for the nq queries of a group in one sweep of the interleaved distance column
 hipError_t launch_hamming_collect_multi(const HammingCollectArgs &a, uint32_t blocks, uint32_t nq, hipStream_t s);
 // K3 for nq lists whose lengths were decided on the device: list y = keys / pay + y * m_stride,
 // m_dev[y] entries; winners (sorted) to the block at out + y * out_stride bytes.

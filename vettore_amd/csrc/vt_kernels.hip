@@ -592,72 +592,92 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_dist_kernel(con
   }
 }
 
-// K4h's distance pass for up to kHammingMultiMax queries at once: the bit tiles are read ONCE,
-// every lane popcounts its row against all the queries (their words sit in LDS: one broadcast
-// ds_read_b64 per word and query), writes nq 2-byte distances and counts them in nq LDS
-// histograms.  Concurrent quantized_search callers (collection.ex:276-295 under the read lock)
-// then share a sweep of the 0.96-GB bit matrix the way plain searches share a scan of the rows.
+// K4h's distance pass for up to kHammingMultiMax (8) queries at once: the bit tiles are read
+// ONCE, every lane popcounts its row against all the queries, writes the eight 2-byte distances
+// of its row as one 16-byte store (dist[row][8]) and counts them in nq LDS histograms.
+// Concurrent quantized_search callers (collection.ex:276-295 under the read lock) then share a
+// sweep of the 0.96-GB bit matrix the way plain searches share a scan of the rows.
+// The query words are wave-uniform: they come through the scalar cache (constant address space
+// => s_load) and enter v_xor as SGPR operands -- with the words in LDS (a ds_read_b64 per word
+// and query, then moves) eight queries were VALU-bound at 1.45x the single pass; this is two
+// vector instructions per 32 row bits and query.
 template <int PAIRS>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_dist_multi_kernel(const HammingMultiArgs a) {
-  extern __shared__ __align__(16) uint32_t hm_lds[];  // [nq][d + 1] histograms, then [nq][2 * pairs] query words (u64)
+  extern __shared__ __align__(16) uint32_t hm_lds[];  // [nq][d + 1] histograms
+  typedef const __attribute__((address_space(4))) uint64_t *cu64_p;
   const int lane = threadIdx.x & (kWave - 1);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t pairs = PAIRS > 0 ? (uint32_t)PAIRS : a.pairs;
   const uint32_t bins = a.d + 1;
-  const uint32_t hist_words = (a.nq * bins + 1u) & ~1u;
-  uint64_t *qw = reinterpret_cast<uint64_t *>(hm_lds + hist_words);  // [nq][2 * pairs], masked tail, zero padding word
   const uint32_t total_waves = gridDim.x * kWavesPerBlock;
   const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
   const uint32_t ntiles = (a.n + kWave - 1) / kWave;
   const uint32_t rem = a.d % 64;
   const uint64_t last_mask = rem ? ((1ull << rem) - 1) : ~0ull;  // distances.rs:472-481 word_mask
   for (uint32_t i = threadIdx.x; i < a.nq * bins; i += blockDim.x) hm_lds[i] = 0;
-  for (uint32_t i = threadIdx.x; i < a.nq * 2 * pairs; i += blockDim.x) {
-    const uint32_t q = i / (2 * pairs), w = i - q * 2 * pairs;
-    qw[i] = w < a.words ? a.qbits[(size_t)q * a.words + w] & (w == a.words - 1 ? last_mask : ~0ull) : 0ull;
-  }
-  if (blockIdx.x == 0 && threadIdx.x < a.nq) a.list_count[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < kHammingMultiMax) a.list_count[threadIdx.x] = 0;
   __syncthreads();
+  // (the host packs the queries' words with their padding bits clear and an even word count:
+  // qbits[q][2 * pairs])
+  cu64_p qc = (cu64_p)(uintptr_t)a.qbits;
   const u64x2 *bits = reinterpret_cast<const u64x2 *>(a.bits);
   for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
     const u64x2 *base = bits + ((size_t)t * pairs * kWave + lane);
     const uint32_t grow = t * kWave + lane;
     auto row_words = [&](uint32_t j) -> u64x2 {
       u64x2 v = __builtin_nontemporal_load(base + (size_t)j * kWave);
-      // (the row's padding bits beyond d are zero in the matrix; the tail mask is on the query side
-      // AND here, as packed_hamming masks both operands' last word)
+      // (packed_hamming masks both operands' last word; the matrix's own padding is zero already)
       if (2 * j == a.words - 1) v.x &= last_mask;
       if (2 * j + 1 == a.words - 1) v.y &= last_mask;
       if (2 * j + 1 >= a.words) v.y = 0ull;
       return v;
     };
+    // All eight query slots are computed (the host zero-fills the unused ones): no branches in
+    // here.  The words of a query are fetched anew for every tile -- hoisted out of the tile loop
+    // they are 192 SGPRs, which the compiler then parks in vector lanes (v_writelane / v_readlane
+    // around every use: the pass was VALU-bound at 1.45x the single one).
+    uint32_t ham[kHammingMultiMax];
+    typedef const __attribute__((address_space(4))) uint32_t *cu32_p;
     if (PAIRS > 0) {
       u64x2 v[PAIRS > 0 ? PAIRS : 1];
 #pragma unroll
       for (int j = 0; j < PAIRS; ++j) v[j] = row_words(j);
-      for (uint32_t q = 0; q < a.nq; ++q) {
-        const uint64_t *w = qw + (size_t)q * 2 * PAIRS;
-        uint32_t ham = 0;
 #pragma unroll
-        for (int j = 0; j < PAIRS; ++j) ham += __popcll(v[j].x ^ w[2 * j]) + __popcll(v[j].y ^ w[2 * j + 1]);
-        if (grow < a.n) {
-          a.dist[(size_t)q * a.dist_stride + grow] = (uint16_t)ham;
-          atomicAdd(&hm_lds[q * bins + ham], 1u);
+      for (uint32_t q = 0; q < kHammingMultiMax; ++q) {
+        uint64_t qaddr = (uint64_t)(uintptr_t)a.qbits + (uint64_t)q * 2 * PAIRS * 8;
+        asm volatile("" : "+s"(qaddr));  // (not loop-invariant as far as the compiler can tell)
+        cu32_p w = (cu32_p)(uintptr_t)qaddr;
+        uint32_t h = 0;
+#pragma unroll
+        for (int j = 0; j < PAIRS; ++j) {
+          h = __builtin_popcount((uint32_t)v[j].x ^ w[4 * j]) + h;
+          h = __builtin_popcount((uint32_t)(v[j].x >> 32) ^ w[4 * j + 1]) + h;
+          h = __builtin_popcount((uint32_t)v[j].y ^ w[4 * j + 2]) + h;
+          h = __builtin_popcount((uint32_t)(v[j].y >> 32) ^ w[4 * j + 3]) + h;
         }
+        ham[q] = h;
       }
     } else {
-      for (uint32_t q = 0; q < a.nq; ++q) {
-        const uint64_t *w = qw + (size_t)q * 2 * pairs;
-        uint32_t ham = 0;
-        for (uint32_t j = 0; j < pairs; ++j) {
-          const u64x2 v = row_words(j);
-          ham += __popcll(v.x ^ w[2 * j]) + __popcll(v.y ^ w[2 * j + 1]);
-        }
-        if (grow < a.n) {
-          a.dist[(size_t)q * a.dist_stride + grow] = (uint16_t)ham;
-          atomicAdd(&hm_lds[q * bins + ham], 1u);
+#pragma unroll
+      for (uint32_t q = 0; q < kHammingMultiMax; ++q) ham[q] = 0;
+      for (uint32_t j = 0; j < pairs; ++j) {
+        const u64x2 v = row_words(j);
+#pragma unroll
+        for (uint32_t q = 0; q < kHammingMultiMax; ++q) {
+          cu64_p w = qc + (size_t)q * 2 * pairs;
+          ham[q] += __popcll(v.x ^ w[2 * j]) + __popcll(v.y ^ w[2 * j + 1]);
         }
       }
+    }
+    if (grow < a.n) {
+      uint32_t packed[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) packed[i] = ham[2 * i] | (ham[2 * i + 1] << 16);
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      reinterpret_cast<u32x4 *>(a.dist)[grow] = u32x4{packed[0], packed[1], packed[2], packed[3]};
+#pragma unroll
+      for (uint32_t q = 0; q < kHammingMultiMax; ++q)
+        if (q < a.nq) atomicAdd(&hm_lds[q * bins + ham[q]], 1u);
     }
   }
   __syncthreads();
@@ -670,18 +690,80 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_dist_multi_kern
   }
 }
 
+// The collect pass for the nq queries of a group in ONE sweep of the interleaved distance column
+// (16 bytes per row): every block finds the nq thresholds D*_q from the nq histograms, then each
+// lane takes a row's eight distances and appends the row to the list of every query it
+// qualifies for (keyed (distance, id rank), as hamming_collect_kernel does for one).
+__global__ __launch_bounds__(256) void hamming_collect_multi_kernel(const HammingCollectArgs a, uint32_t nq) {
+  extern __shared__ uint32_t hcm_lds[];  // [d + 1] one histogram at a time
+  __shared__ uint32_t s_dstar[kHammingMultiMax];
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t bins = a.d + 1;
+  for (uint32_t q = 0; q < nq; ++q) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) hcm_lds[i] = a.hist[(size_t)q * a.hist_stride + i];
+    __syncthreads();
+    if (threadIdx.x < kWave) {
+      // D* = smallest D with count(distance <= D) >= k; lane l owns bins [l*B, (l+1)*B)
+      const uint32_t B = (bins + kWave - 1) / kWave;
+      uint32_t mine = 0;
+      for (uint32_t j = 0; j < B; ++j) {
+        const uint32_t b = lane * B + j;
+        mine += b < bins ? hcm_lds[b] : 0u;
+      }
+      uint32_t incl = mine;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += t;
+      }
+      const uint32_t excl = incl - mine;
+      const uint32_t total = __shfl(incl, kWave - 1, kWave);
+      if (lane == 0 && total < a.k) s_dstar[q] = a.d;  // fewer rows than k: everything qualifies
+      if (excl < a.k && a.k <= incl) {
+        uint32_t cum = excl, b = lane * B;
+        for (;; ++b) {
+          cum += hcm_lds[b];
+          if (cum >= a.k) break;
+        }
+        s_dstar[q] = b;
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t dstar[kHammingMultiMax];
+#pragma unroll
+  for (uint32_t q = 0; q < kHammingMultiMax; ++q) dstar[q] = q < nq ? s_dstar[q] : 0u;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 *d4 = reinterpret_cast<const u32x4 *>(a.dist);
+  for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < a.n; row += gridDim.x * blockDim.x) {
+    const u32x4 v = d4[row];
+    uint32_t rk = 0xFFFFFFFFu;
+#pragma unroll
+    for (uint32_t q = 0; q < kHammingMultiMax; ++q) {
+      const uint32_t dv = (v[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+      if (q < nq && dv <= dstar[q]) {
+        if (rk == 0xFFFFFFFFu) rk = a.id_rank ? a.id_rank[row] : row;
+        const uint32_t pos = atomicAdd(a.list_count + q, 1u);
+        if (pos < a.cap) {
+          const float raw = (float)dv;  // distance as f32 (distances.rs:436)
+          a.keys[(size_t)q * a.cap + pos] = ((uint64_t)orderable(raw) << 32) | rk;
+          Payload p;
+          p.row = row;
+          p.raw = raw;
+          a.pay[(size_t)q * a.cap + pos] = p;
+        } else {
+          atomicMax(a.status, kStatusRetry);  // more ties than the list holds: the caller takes the queries one by one
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void hamming_collect_kernel(const HammingCollectArgs a0) {
   extern __shared__ uint32_t hc_lds[];  // [d + 1]
   __shared__ uint32_t s_dstar;
-  HammingCollectArgs a = a0;
-  if (gridDim.y > 1) {  // query y of a batch (launch_hamming_collect_multi)
-    const uint32_t y = blockIdx.y;
-    a.dist += (size_t)y * a.dist_stride;
-    a.hist += (size_t)y * a.hist_stride;
-    a.list_count += y;
-    a.keys += (size_t)y * a.cap;
-    a.pay += (size_t)y * a.cap;
-  }
+  const HammingCollectArgs &a = a0;
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t bins = a.d + 1;
   for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) hc_lds[i] = a.hist[i];
@@ -1410,18 +1492,18 @@ hipError_t launch_hamming_collect(const HammingCollectArgs &a, uint32_t blocks, 
 
 hipError_t launch_hamming_collect_multi(const HammingCollectArgs &a, uint32_t blocks, uint32_t nq, hipStream_t s) {
   if (a.d > kHammingHistMaxDim || a.k == 0 || nq == 0 || nq > kHammingMultiMax || a.hist_next) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(hamming_collect_kernel, dim3(blocks, nq), dim3(256), hamming_hist_lds_bytes(a.d), s, a);
+  hipLaunchKernelGGL(hamming_collect_multi_kernel, dim3(blocks), dim3(256), hamming_hist_lds_bytes(a.d), s, a, nq);
   return hipGetLastError();
 }
 
 size_t hamming_multi_lds_bytes(uint32_t d, uint32_t words, uint32_t nq) {
-  const size_t hist_words = ((size_t)nq * (d + 1) + 1) & ~(size_t)1;
-  return hist_words * sizeof(uint32_t) + (size_t)nq * 2 * ((words + 1) / 2) * sizeof(uint64_t);
+  (void)words;
+  return (size_t)nq * (d + 1) * sizeof(uint32_t);
 }
 
 hipError_t launch_hamming_dist_multi(const HammingMultiArgs &a, uint32_t blocks, hipStream_t s) {
   if (a.words == 0 || a.pairs != (a.words + 1) / 2 || a.nq == 0 || a.nq > kHammingMultiMax || a.hist_stride < a.d + 1 ||
-      a.dist_stride % 8 != 0)
+      ((uintptr_t)a.dist & 15) || ((uintptr_t)a.qbits & 15))
     return hipErrorInvalidValue;
   const size_t lds = hamming_multi_lds_bytes(a.d, a.words, a.nq);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
