@@ -446,6 +446,7 @@ inline hipError_t launch_scan_t(const ScanDev &sd, uint32_t blocks, size_t lds, 
 hipError_t launch_scan_dot(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
 hipError_t launch_scan_l2(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
 hipError_t launch_scan_misc(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
+hipError_t launch_scan_l1(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
 hipError_t launch_scan_general(const ScanDev &sd, uint32_t blocks, uint32_t nq, size_t lds, hipStream_t s);
 
 // order (0..3) x candidate buffer (k <= kSmallK -> small) x padded

@@ -1,5 +1,5 @@
-// K1 instantiations: manhattan (lane order at run time), chebyshev, float
-// hamming and jaccard (order-insensitive: max / exact small-integer sums).
+// K1 instantiations: chebyshev, float hamming and jaccard (order-insensitive: max / exact
+// small-integer sums); manhattan has its own file (vt_scan_l1.hip).
 #include "vt_scan.cuh"
 
 namespace vt {
@@ -18,7 +18,7 @@ namespace dev {
 
 hipError_t launch_scan_misc(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s) {
   switch (metric_op(sd.a.metric)) {
-    case OP_L1: VT_SCAN_DISPATCH_FIXED(OP_L1, -1);
+    case OP_L1: return launch_scan_l1(sd, blocks, lds, padded, s);
     case OP_LINF: VT_SCAN_DISPATCH_FIXED(OP_LINF, 0);
     case OP_HAM: VT_SCAN_DISPATCH_FIXED(OP_HAM, 0);
     default: VT_SCAN_DISPATCH_FIXED(OP_JAC, 0);
