@@ -15,17 +15,19 @@ pmc() {  # name, counter, bench args...
   local name=$1 ctr=$2; shift 2
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$name -o p -- python3 $R/bench.py "$@" > $OUT/$name.log 2>&1
 }
-export RND=${RND:-r02}
+export RND=${RND:-r03}
 stats single --no-side          # the headline alone: the scan kernel's average is the bench line's avg_launch_ms
 stats default                   # the driver's command: headline + side legs (config 2 shares the scan kernel: 1 100 launches at N=1M)
 pmc single_fetch FETCH_SIZE --steps 20 --warmup 2 --no-cpu --no-side
 pmc single_write WRITE_SIZE --steps 20 --warmup 2 --no-cpu --no-side
-stats batch --mode batch --steps 6 --warmup 1 --no-cpu
+stats batch --mode batch --nominate f32 --steps 6 --warmup 1 --no-cpu          # K2: FP32 matrix cores
+stats batch_bf16 --mode batch --nominate bf16 --steps 24 --warmup 3 --no-cpu   # K2b: bf16 nomination (the default)
 stats quantized --mode quantized --steps 300 --warmup 20 --no-cpu
 pmc quantized_fetch FETCH_SIZE --mode quantized --steps 20 --warmup 2 --no-cpu
 stats funnel --mode funnel --steps 200 --warmup 5 --no-cpu
 pmc funnel_fetch FETCH_SIZE --mode funnel --steps 20 --warmup 2 --no-cpu
-pmc batch_fetch FETCH_SIZE --mode batch --steps 2 --warmup 1 --no-cpu
+pmc batch_fetch FETCH_SIZE --mode batch --nominate f32 --steps 2 --warmup 1 --no-cpu
+pmc batch_bf16_fetch FETCH_SIZE --mode batch --nominate bf16 --steps 4 --warmup 1 --no-cpu
 # K1m: 8 queries per sweep (manhattan, N=10M, d=768); the program after `--` is python3 itself
 export ROWS=10000000 NQS=8 METRICS=5
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/multi -o p -- python3 $R/tools/multi_probe.py > $OUT/multi.log 2>&1
@@ -35,7 +37,7 @@ cd $R
 python3 - <<'PY'
 import csv, glob, json, os
 out = 'gpurun_out/prof'
-RND = os.environ.get('RND', 'r02')
+RND = os.environ.get('RND', 'r03')
 def trim(src, dst):
     rows = list(csv.reader(open(src)))
     with open(dst, 'w', newline='') as f:
@@ -43,7 +45,7 @@ def trim(src, dst):
         for r in rows:
             r[0] = r[0][:140]
             w.writerow(r)
-for name in ('single', 'default', 'batch', 'quantized', 'funnel', 'multi'):
+for name in ('single', 'default', 'batch', 'batch_bf16', 'quantized', 'funnel', 'multi'):
     trim('%s/%s/p_kernel_stats.csv' % (out, name), '%s/%s_%s_kernel_stats.csv' % (out, RND, name))
 def per_launch(path, kernel_substr, counter):
     vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
@@ -80,15 +82,19 @@ hf, _ = per_launch(out + '/quantized_fetch/p_counter_collection.csv', 'hamming_d
 print("hamming FETCH_SIZE KiB per launch", hf, "x2 bytes", 2 * hf * 1024)
 ff, _ = per_launch(out + '/funnel_fetch/p_counter_collection.csv', 'cosine_scan_kernel', 'FETCH_SIZE')
 bf, _ = per_launch(out + '/batch_fetch/p_counter_collection.csv', 'mfma_scores_kernel<8, false>', 'FETCH_SIZE')
+b16, _ = per_launch(out + '/batch_bf16_fetch/p_counter_collection.csv', 'bf16_scores_kernel<false>', 'FETCH_SIZE')
+keep(out + '/batch_bf16_fetch/p_counter_collection.csv', out + '/%s_batch_bf16_pmc_fetch.csv' % RND, 'bf16_scores_kernel<false>')
+print("bf16_scores_kernel FETCH_SIZE x2 bytes", 2 * b16 * 1024)
 keep(out + '/funnel_fetch/p_counter_collection.csv', out + '/%s_funnel_pmc_fetch.csv' % RND, 'cosine_scan_kernel')
 keep(out + '/batch_fetch/p_counter_collection.csv', out + '/%s_batch_pmc_fetch.csv' % RND, 'mfma_scores_kernel<8, false>')
 print("cosine_scan FETCH_SIZE x2 bytes", 2 * ff * 1024, "mfma_scores<8> FETCH_SIZE x2 bytes", 2 * bf * 1024)
 # what the side legs of bench.py report as `traffic` (reads only: these kernels write a few KB of lists)
 json.dump({k: {"rows": 10000000, "dim": 768, "hbm_bytes_per_launch": 2 * v * 1024,
                "source": "FETCH_SIZE x 2 (gfx950 correction as in pmc_latest.json), %s pass of tools/refresh_profiles.sh" % k}
-           for k, v in (("hamming_dist_kernel", hf), ("cosine_scan_kernel", ff), ("mfma_scores_kernel", bf), ("scan_multi_kernel", mf))},
+           for k, v in (("hamming_dist_kernel", hf), ("cosine_scan_kernel", ff), ("mfma_scores_kernel", bf), ("scan_multi_kernel", mf),
+                        ("bf16_scores_kernel", b16))},
           open(out + '/pmc_side.json', 'w'), indent=1)
-for name in ('single', 'batch', 'quantized', 'funnel'):
+for name in ('single', 'batch', 'batch_bf16', 'quantized', 'funnel'):
     print(open('%s/%s.json' % (out, name)).read().strip())
     for r in csv.DictReader(open('%s/%s/p_kernel_stats.csv' % (out, name))):
         if 'vt::' in r['Name']:

@@ -361,30 +361,47 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
 #ifdef VT_TEST_HOOKS
     foreign = foreign || std::getenv("VT_TEST_FOREIGN_ROWS") != nullptr;  // (libvettore_hip_hooks.so only)
 #endif
-    if (foreign && ix->slab.mapped) {
-      // Rows that live on another device of the node, bound for a mapped slab: only this device
-      // has been given access to the slab's chunks (hipMemSetAccess), so a peer copy must not
-      // target it.  The rows cross into an ordinary buffer here first (blocks of <= 256 MB), and
-      // are placed from there by local copies.
+    if (foreign) {
+      // Rows that live on another device of the node.  A mapped slab admits no peer copy at all
+      // (only this device has been given access to its chunks, hipMemSetAccess), and a copy per
+      // row is two API calls and -- through a staging block -- a stream sync per row once the
+      // picks are not consecutive, which is the normal case: one matrix dealt to S shards by the
+      // hash of its ids leaves every shard every S-th row or so (100x slower than
+      // necessary).  So: ONE peer copy per block brings the whole source span pick[i] .. pick[e-1]
+      // (<= 256 MB; the rows of the other shards in between ride along) into an ordinary buffer
+      // here, one gather launch places this shard's rows from it (zero padded to ld; of an id that
+      // appears twice in the batch only the LAST occurrence, flat.rs:270-281), one sync per block.
       const size_t block_rows = std::max<size_t>(1, ((size_t)256 << 20) / (d * sizeof(float)));
+      std::unordered_map<uint32_t, size_t> last;
+      for (size_t i = 0; i < count; ++i) last[target[i]] = i;
       DevBuf<float> stage;
-      VT_TRY(stage.ensure(std::min(count, block_rows) * d));
+      DevBuf<uint32_t> dMap;
+      std::vector<uint32_t> map;
       size_t i = 0;
       while (i < count) {
-        // a run of consecutive source rows, at most one block long
-        size_t e = i + 1;
         const size_t p0 = src.pick ? src.pick[i] : i;
-        while (e < count && e - i < block_rows && (src.pick ? src.pick[e] : e) == p0 + (e - i)) ++e;
-        VT_HIP(hipMemcpyAsync(stage.p, src.device + p0 * d, (e - i) * d * sizeof(float), hipMemcpyDefault, c.stream));
-        for (size_t j = i; j < e;) {  // ... placed in runs of consecutive slab rows
-          size_t r = j + 1;
-          while (r < e && target[r] == target[j] + (uint32_t)(r - j)) ++r;
-          float *dst = ix->dX + (size_t)target[j] * ld;
-          if (ld == d) VT_HIP(hipMemcpyAsync(dst, stage.p + (j - i) * d, (r - j) * d * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
-          else VT_HIP(vt::launch_pad_rows(stage.p + (j - i) * d, (uint32_t)(r - j), (uint32_t)d, dst, ld, c.stream));
-          j = r;
+        size_t e = i + 1, p_hi = p0;
+        while (e < count) {  // picks ascending and within one block of the first
+          const size_t pe = src.pick ? src.pick[e] : e;
+          if (pe < p_hi || pe - p0 >= block_rows) break;
+          p_hi = pe;
+          ++e;
         }
-        VT_HIP(hipStreamSynchronize(c.stream));  // the block is reused
+        const size_t span = p_hi - p0 + 1;
+        VT_TRY(stage.ensure(span * d));
+        VT_HIP(hipMemcpyAsync(stage.p, src.device + p0 * d, span * d * sizeof(float), hipMemcpyDefault, c.stream));
+        map.clear();
+        for (size_t j = i; j < e; ++j) {
+          if (last[target[j]] != j) continue;
+          map.push_back((uint32_t)((src.pick ? src.pick[j] : j) - p0));
+          map.push_back(target[j]);
+        }
+        if (!map.empty()) {
+          VT_TRY(dMap.ensure(map.size()));
+          VT_HIP(hipMemcpyAsync(dMap.p, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+          VT_HIP(vt::launch_gather_rows(stage.p, (uint32_t)d, dMap.p, (uint32_t)(map.size() / 2), ix->dX, ld, c.stream));
+        }
+        VT_HIP(hipStreamSynchronize(c.stream));  // the block and the map are reused
         i = e;
       }
     } else if (all_appended_in_order && picks_dense) {
@@ -392,8 +409,8 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
       float *dst = ix->dX + (size_t)n_before * ld;
       if (ld == d) VT_HIP(hipMemcpyAsync(dst, first, count * d * sizeof(float), hipMemcpyDefault, c.stream));
       else VT_HIP(vt::launch_pad_rows(first, (uint32_t)count, (uint32_t)d, dst, ld, c.stream));
-    } else if (count < 64 || foreign) {
-      // (few rows, or rows that live on another device: plain copies, which need no peer mapping)
+    } else if (count < 64) {
+      // (few rows: plain copies)
       for (size_t i = 0; i < count; ++i) {
         float *dst = ix->dX + (size_t)target[i] * ld;
         const size_t p = src.pick ? src.pick[i] : i;
