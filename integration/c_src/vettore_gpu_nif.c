@@ -298,6 +298,63 @@ static ERL_NIF_TERM flat_search_batch(ErlNifEnv *env, int argc, const ERL_NIF_TE
   return enif_make_tuple2(env, mk_atom(env, "ok"), list);
 }
 
+/* [[float]] -> one malloc'ed [nq][d] f32 matrix; *st = VT_ERR_DIMENSION when the rows differ in length */
+static int get_f32_matrix(ErlNifEnv *env, ERL_NIF_TERM list, unsigned nq, float **out, size_t *d, int *st) {
+  float *qs = NULL;
+  ERL_NIF_TERM head, tail = list;
+  *st = VT_OK;
+  *d = 0;
+  for (unsigned i = 0; i < nq; ++i) {
+    float *q;
+    size_t n;
+    if (!enif_get_list_cell(env, tail, &head, &tail) || !get_f32_list(env, head, &q, &n)) { free(qs); return 0; }
+    if (i == 0) {
+      *d = n;
+      qs = (float *)malloc((size_t)nq * (n ? n : 1) * sizeof(float));
+    }
+    if (!qs || n != *d) {
+      free(q);
+      free(qs);
+      if (n != *d) { *st = VT_ERR_DIMENSION; return 1; }
+      return 0;
+    }
+    memcpy(qs + (size_t)i * n, q, n * sizeof(float));
+    free(q);
+  }
+  *out = qs;
+  return 1;
+}
+
+/* [vt_hits *] -> [[{id, raw}]] (frees them) */
+static ERL_NIF_TERM hit_lists(ErlNifEnv *env, vt_hits **out, unsigned nq) {
+  ERL_NIF_TERM list = enif_make_list(env, 0);
+  for (unsigned i = nq; i-- > 0;) list = enif_make_list_cell(env, hits_to_list(env, out[i]), list);
+  return enif_make_tuple2(env, mk_atom(env, "ok"), list);
+}
+
+/* flat_quantized_search_batch(ref, [[float]], candidates, limit) -> {:ok, [[{id, raw}]]}: B x
+ * quantized_search, groups of up to eight sharing one sweep of the sign bits */
+static ERL_NIF_TERM flat_quantized_search_batch(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  flat_res *r = get_flat(env, argv[0]);
+  unsigned nq;
+  size_t candidates, limit, d;
+  float *qs;
+  int st;
+  (void)argc;
+  if (!r || !enif_get_list_length(env, argv[1], &nq) || !get_size(env, argv[2], &candidates) || !get_size(env, argv[3], &limit))
+    return enif_make_badarg(env);
+  if (nq == 0) return enif_make_tuple2(env, mk_atom(env, "ok"), enif_make_list(env, 0));
+  if (!get_f32_matrix(env, argv[1], nq, &qs, &d, &st)) return enif_make_badarg(env);
+  if (st != VT_OK) return mk_error(env, st);
+  vt_hits **out = (vt_hits **)calloc(nq, sizeof(vt_hits *));
+  st = out ? vt_flat_quantized_search_batch(r->h, qs, nq, d, candidates, limit, out) : VT_ERR_NOMEM;
+  free(qs);
+  if (st != VT_OK) { free(out); return mk_error(env, st); }
+  ERL_NIF_TERM res = hit_lists(env, out, nq);
+  free(out);
+  return res;
+}
+
 /* flat_quantized_search(ref, [float], candidates, limit)   collection.ex:276-295 in one call */
 static ERL_NIF_TERM flat_quantized_search(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
   flat_res *r = get_flat(env, argv[0]);
@@ -531,6 +588,7 @@ static ErlNifFunc funcs[] = {
   {"flat_search", 3, flat_search, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"flat_search_batch", 3, flat_search_batch, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"flat_quantized_search", 4, flat_quantized_search, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"flat_quantized_search_batch", 4, flat_quantized_search_batch, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"flat_funnel_search", 5, flat_funnel_search, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"flat_hybrid_search", 4, flat_hybrid_search, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"normalize_l2", 1, normalize_l2, ERL_NIF_DIRTY_JOB_IO_BOUND},

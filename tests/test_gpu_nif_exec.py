@@ -241,6 +241,16 @@ def test_oracle_parity_5000x384_and_the_staged_searches(rt, oracle_mod):
         bits(nifs.flat_quantized_search(mirror, q, 100, 10)[1])
     assert bits(ok(rt.call("flat_funnel_search", ref, FloatList(q), [128], 100, 10))) == \
         bits(nifs.flat_funnel_search(mirror, q, [128], 100, 10)[1])
+    n3 = 20_000                                                                  # (enough rows for the grouped Hamming pass)
+    x3 = np.stack([oracle_mod.normalize_l2(r) for r in rng.uniform(-1, 1, (n3, 64)).astype(np.float32)])
+    ref3 = rt.call("flat_new", 2, [0])
+    assert rt.call("flat_load_binary", ref3, [b"g%d" % i for i in range(n3)], x3.tobytes(), 64) == UNIT
+    q3 = [FloatList(v) for v in x3[:5]]
+    grouped = ok(rt.call("flat_quantized_search_batch", ref3, q3, 100, 10))
+    assert [bits(h) for h in grouped] == [bits(ok(rt.call("flat_quantized_search", ref3, v, 100, 10))) for v in q3]
+    assert rt.call("flat_quantized_search_batch", ref3, [], 100, 10) == (OK, [])
+    assert rt.call("flat_quantized_search_batch", ref3, [q3[0], [1.0]], 100, 10) == (ERROR, b"dimension mismatch")
+    ref3.release()
     gens = [(0, 50, [64]), (1, 60, []), (2, 20, [])]
     assert bits(ok(rt.call("flat_hybrid_search", ref, FloatList(q), gens, 10))) == \
         bits(nifs.flat_hybrid_search(mirror, q, [(g[0], g[1], g[2]) for g in gens], 10)[1])
