@@ -15,7 +15,7 @@ ifdef EXPERIMENTS
 HIPFLAGS += -DVT_BATCH_TIMING_EXPERIMENTS
 endif
 
-DEVSRC  := vt_kernels vt_batch vt_batch_bf16 vt_scan_dot vt_scan_l2 vt_scan_l1 vt_scan_misc vt_scan_general vt_scan_multi
+DEVSRC  := vt_kernels vt_batch vt_batch_bf16 vt_scan_dot vt_scan_l2 vt_scan_l1 vt_scan_misc vt_scan_general vt_scan_gather vt_scan_multi
 DEVOBJ  := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(DEVSRC)))
 DEVHDR  := $(CSRC)/vt_device.h $(CSRC)/vt_common.cuh $(CSRC)/vt_scan.cuh
 

@@ -54,7 +54,11 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
       if (v >= 1) rank = std::min<uint32_t>((uint32_t)v, std::min<uint32_t>(sample_rows, n));
     }
   const uint32_t cand_cap = 8192;
-  constexpr uint32_t kBlocksPerQuery = 4;
+  static const uint32_t kBlocksPerQuery = [] {  // blocks of the exact rescoring per query (VT_RESCORE_BLOCKS: A/B)
+    const char *e = std::getenv("VT_RESCORE_BLOCKS");
+    const int v = e ? std::atoi(e) : 0;
+    return v >= 1 && v <= 64 ? (uint32_t)v : 8u;
+  }();
 
   VT_TRY(c.dBQ.ensure((size_t)nq_pad * ld));
   VT_TRY(c.hBQ.ensure((size_t)nq_pad * ld));

@@ -1296,7 +1296,7 @@ __global__ __launch_bounds__(64) void normalize_l2_kernel(const float *__restric
 
 size_t scan_lds_for(const ScanShape &p, uint32_t k) {
   const size_t buf = k <= (uint32_t)kSmallK ? WaveTopK<kCapSmall>::lds_bytes() : WaveTopK<kCapLarge>::lds_bytes();
-  return ((size_t)(p.q_global ? 0u : p.ld) + (size_t)kWavesPerBlock * kTileRows * p.ss) * sizeof(float) + kWavesPerBlock * buf;
+  return ((size_t)(p.q_global ? 0u : p.ld) + (size_t)kWavesPerBlock * p.tr * p.ss) * sizeof(float) + kWavesPerBlock * buf;
 }
 
 // A row too long for the query to share LDS with the panels: the query stays in global memory

@@ -115,6 +115,20 @@ __device__ __forceinline__ float elem(int op_rt, float q, float x) {
   }
 }
 
+// the four products of one lane's 16 bytes: ONE branch on a run-time operation, not four
+template <int OP>
+__device__ __forceinline__ f32x4 elem4(int op_rt, const f32x4 q, const f32x4 x) {
+  const int op = OP >= 0 ? OP : op_rt;
+  switch (op) {
+    case OP_DOT: return f32x4{elem<OP_DOT>(0, q.x, x.x), elem<OP_DOT>(0, q.y, x.y), elem<OP_DOT>(0, q.z, x.z), elem<OP_DOT>(0, q.w, x.w)};
+    case OP_L2: return f32x4{elem<OP_L2>(0, q.x, x.x), elem<OP_L2>(0, q.y, x.y), elem<OP_L2>(0, q.z, x.z), elem<OP_L2>(0, q.w, x.w)};
+    case OP_L1:
+    case OP_LINF: return f32x4{elem<OP_L1>(0, q.x, x.x), elem<OP_L1>(0, q.y, x.y), elem<OP_L1>(0, q.z, x.z), elem<OP_L1>(0, q.w, x.w)};
+    case OP_HAM: return f32x4{elem<OP_HAM>(0, q.x, x.x), elem<OP_HAM>(0, q.y, x.y), elem<OP_HAM>(0, q.z, x.z), elem<OP_HAM>(0, q.w, x.w)};
+    default: return f32x4{elem<OP_JAC>(0, q.x, x.x), elem<OP_JAC>(0, q.y, x.y), elem<OP_JAC>(0, q.z, x.z), elem<OP_JAC>(0, q.w, x.w)};
+  }
+}
+
 template <int OP>
 __device__ __forceinline__ float comb(int op_rt, float a, float b) {
   const int op = OP >= 0 ? OP : op_rt;
@@ -193,7 +207,11 @@ struct Cursor {
 // OP / ORDER < 0: taken from the arguments at run time.
 // GENERAL: rows addressed through `gather` and/or a stride != ld (prefix scan).
 // PADDED: d % 64 != 0 -- some chunks of a row are padding or the scalar tail.
-template <int OP, int ORDER, int CAP, bool GENERAL, bool PADDED>
+// QGLOBAL (ScanShape.q_global): the query is read from global memory, not LDS.  A COMPILE-time
+// property: a query pointer that may be either is a generic pointer, its loads are flat_load, a
+// flat_load counts against vmcnt as well as lgkmcnt, and the wait for the query fragment then
+// drains the whole register ring at every segment (r03, measured: gathered scans ran one load deep).
+template <int OP, int ORDER, int CAP, bool GENERAL, bool PADDED, bool QGLOBAL = false>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const ScanDev sd) {
   extern __shared__ __align__(16) float lds[];
   const ScanArgs &a = sd.a;
@@ -201,10 +219,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
   const int lane = threadIdx.x & (kWave - 1);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int odd = lane & 1;
-  const bool q_global = GENERAL && p.q_global;  // (only the run-time-op build carries this mode)
-  const uint32_t q_lds = q_global ? 0u : p.ld;
-  float *S = lds + q_lds + wib * (kTileRows * p.ss);
-  unsigned char *tkbuf = reinterpret_cast<unsigned char *>(lds + q_lds + kWavesPerBlock * (kTileRows * p.ss)) +
+  const uint32_t q_lds = QGLOBAL ? 0u : p.ld;
+  float *S = lds + q_lds + wib * (p.tr * p.ss);  // (a panel is as tall as the tiles: short tiles, more blocks per CU)
+  unsigned char *tkbuf = reinterpret_cast<unsigned char *>(lds + q_lds + kWavesPerBlock * (p.tr * p.ss)) +
                          wib * WaveTopK<CAP>::lds_bytes();
 
   // batch mode (gathered scans): blockIdx.y selects the query and its row list
@@ -220,9 +237,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
     gather += (size_t)b * a.batch_cap * a.gather_stride;
     list_base = b * gridDim.x;
   }
-  if (!q_global)
+  if (!QGLOBAL)
     for (uint32_t i = threadIdx.x; i < p.ld; i += blockDim.x) lds[i] = qsrc[i];
-  const float *qs = q_global ? qsrc : lds;
   __syncthreads();
 
   const int op_rt = metric_op(a.metric);
@@ -259,6 +275,35 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
         c.rowi += 1;
       }
     };
+    // GENERAL: lane r holds the source row of row r of the load cursor's tile (pf_idx), of the
+    // tile before it (pf_idx_prev: the compute side may still be there) and of the tile after it
+    // (pf_idx_next), fetched a whole tile ahead -- through the SCALAR cache: a tile's indices sit at
+    // a wave-uniform address (constant address space => s_load).  (Through r02 every load of a
+    // gathered scan first fetched its own index with a vector load: two dependent trips to memory
+    // per 1-KiB load -- and any conditional vector load in this loop makes the compiler wait for
+    // vmcnt(0) at every use of the ring: the eight-deep ring was one deep, 55 us per 8-row tile,
+    // 0.68 ms to re-score the 154 000 candidate rows of a K2b batch.)
+    uint32_t pf_idx = 0, pf_idx_prev = 0, pf_idx_next = 0;
+    auto tile_index = [&](uint32_t t) -> uint32_t {
+      const uint32_t g0 = t * p.tr;
+      if (g0 >= nrows || g0 / p.tr != t) return 0u;  // (rows past the end read row 0: harmless)
+      if (!gather) return ((uint32_t)lane < p.tr && g0 + (uint32_t)lane < nrows) ? g0 + (uint32_t)lane : 0u;
+      typedef const __attribute__((address_space(4))) uint32_t *cu32_p;
+      cu32_p sg = (cu32_p)(uintptr_t)(gather + (size_t)g0 * a.gather_stride);
+      uint32_t v = 0;
+      const uint32_t left = nrows - g0;  // >= 1; rows past the end repeat the last one (never used)
+      for (uint32_t i0 = 0; i0 < p.tr; i0 += 8) {  // (tr is 8, 16 or 32) eight scalar loads in flight, one wait
+        uint32_t sv[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+          const uint32_t i = i0 + j < left ? i0 + j : left - 1;
+          sv[j] = sg[(size_t)i * a.gather_stride];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) v = (uint32_t)lane == i0 + j ? sv[j] : v;
+      }
+      return v;
+    };
     auto advance = [&](Cursor &c) {
       const uint32_t nseg = c.p == lastp ? p.segs_last : p.segs;
       c.s += 1;
@@ -268,6 +313,11 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
         if (c.p == p.npanel) {
           c.p = 0;
           c.t += total_waves;
+          if (GENERAL) {
+            pf_idx_prev = pf_idx;
+            pf_idx = pf_idx_next;
+            pf_idx_next = tile_index(c.t + total_waves);
+          }
         }
         enter_panel(c);
       } else {
@@ -281,9 +331,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
         const float *base = a.X + (size_t)t * p.tile_floats;
         return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (c.rowi * (uint32_t)a.stride + colf)));
       }
-      const uint32_t gi = t * p.tr + c.rowi;
-      uint32_t src = 0;
-      if (gi < nrows) src = gather ? gather[(size_t)gi * a.gather_stride] : gi;
+      (void)t;
+      const uint32_t src = (uint32_t)__shfl((int)pf_idx, (int)c.rowi, kWave);
       return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.X + (size_t)src * a.stride + colf));
     };
 
@@ -292,6 +341,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
     pf.p = 0;
     pf.s = 0;
     enter_panel(pf);
+    if (GENERAL) {
+      pf_idx = tile_index(wave_global);
+      pf_idx_next = tile_index(wave_global + total_waves);
+    }
     f32x4 buf[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
@@ -303,7 +356,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       const uint32_t grow = t * p.tr + lane;  // lanes 0..tr-1 own a row
       const bool row_valid = (uint32_t)lane < p.tr && grow < nrows;
       uint32_t src_row = grow;
-      if (GENERAL && row_valid && gather) src_row = gather[(size_t)grow * a.gather_stride];
+      if (GENERAL && gather) src_row = pf.t == t ? pf_idx : pf_idx_prev;  // (the load cursor is in this tile or the next)
       uint32_t my_rank = src_row;
       if (row_valid && a.id_rank) my_rank = a.id_rank[src_row];
 
@@ -326,11 +379,11 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
             buf[u] = load_at(pf);
             advance(pf);
 
-            const f32x4 qv = *reinterpret_cast<const f32x4 *>(qs + c0 * 8 + cc.col);
-            const float p0 = elem<OP>(op_rt, qv.x, x.x);
-            const float p1 = elem<OP>(op_rt, qv.y, x.y);
-            const float p2 = elem<OP>(op_rt, qv.z, x.z);
-            const float p3 = elem<OP>(op_rt, qv.w, x.w);
+            f32x4 qv;
+            if (QGLOBAL) qv = *reinterpret_cast<const f32x4 *>(qsrc + c0 * 8 + cc.col);
+            else qv = *reinterpret_cast<const f32x4 *>(lds + c0 * 8 + cc.col);
+            const f32x4 pr = elem4<OP>(op_rt, qv, x);
+            const float p0 = pr.x, p1 = pr.y, p2 = pr.z, p3 = pr.w;
             const uint32_t cl = cc.col >> 3;  // chunk within the panel
             float *Srow = S + cc.rowi * p.ss;
             if (!PADDED || c0 + cl < p.cfull) {
@@ -387,7 +440,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       bool valid = row_valid;
       if (valid && !finite_f32(raw)) {
         float rec;
-        if (recover_overflow(metric, qs, a.X + (size_t)src_row * a.stride, a.d, &rec)) {
+        if (recover_overflow(metric, QGLOBAL ? qsrc : lds, a.X + (size_t)src_row * a.stride, a.d, &rec)) {
           raw = rec;
         } else {
           atomicMax(a.status, kErrOverflow);
@@ -433,9 +486,9 @@ inline hipError_t allow_lds(K kernel, size_t bytes) {
                              (int)bytes);
 }
 
-template <int OP, int ORDER, int CAP, bool GENERAL, bool PADDED>
+template <int OP, int ORDER, int CAP, bool GENERAL, bool PADDED, bool QGLOBAL = false>
 inline hipError_t launch_scan_t(const ScanDev &sd, uint32_t blocks, size_t lds, hipStream_t s, uint32_t nq = 1) {
-  auto kern = scan_topk_kernel<OP, ORDER, CAP, GENERAL, PADDED>;
+  auto kern = scan_topk_kernel<OP, ORDER, CAP, GENERAL, PADDED, QGLOBAL>;
   hipError_t e = allow_lds(kern, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(blocks, nq), dim3(kWavesPerBlock * kWave), lds, s, sd);
@@ -448,6 +501,8 @@ hipError_t launch_scan_l2(const ScanDev &sd, uint32_t blocks, size_t lds, bool p
 hipError_t launch_scan_misc(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
 hipError_t launch_scan_l1(const ScanDev &sd, uint32_t blocks, size_t lds, bool padded, hipStream_t s);
 hipError_t launch_scan_general(const ScanDev &sd, uint32_t blocks, uint32_t nq, size_t lds, hipStream_t s);
+hipError_t launch_scan_gather(const ScanDev &sd, uint32_t blocks, uint32_t nq, size_t lds, hipStream_t s);
+constexpr int kDefaultReduceOrder = 3;  // VT_ORDER_SSE2 (include/vettore_flat.h)
 
 // order (0..3) x candidate buffer (k <= kSmallK -> small) x padded
 #define VT_SCAN_ORDERS(OPV, CAPV, PADV)                                                            \
