@@ -15,8 +15,10 @@ def pytest_configure(config):
     # torch bundles its own libamdhip64 (same soname as ROCm's): whichever copy is
     # loaded first serves the whole process, and torch does not survive coming
     # second.  GPU sessions use both, so torch goes first.
+    # (also when GPU test files are named without -m: `pytest tests/test_gpu_x.py`)
     markexpr = config.getoption("-m", default="") or ""
-    if "gpu" in markexpr and "not gpu" not in markexpr.replace("not gpu_perf", ""):
+    named = any("test_gpu_" in str(a) for a in config.args)
+    if ("gpu" in markexpr or named) and "not gpu" not in markexpr.replace("not gpu_perf", ""):
         try:
             import torch  # noqa: F401
         except ImportError:

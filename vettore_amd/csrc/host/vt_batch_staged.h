@@ -281,9 +281,9 @@ int multi_scan_group(Shard *ix, Ctx &c, const float *queries, const std::vector<
   const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
   const uint32_t k = (uint32_t)std::min<size_t>(limit, n);
   const size_t nq = which.size();
-  const size_t lds = vt::scan_multi_lds_bytes(vt::kMultiMaxQueries);
+  const size_t lds = vt::scan_multi_lds_bytes(d, k, ix->metric);
   const uint32_t ntiles = (n + vt::scan_multi_tile_rows(vt::kMultiMaxQueries) - 1) / vt::scan_multi_tile_rows(vt::kMultiMaxQueries);
-  const uint32_t blocks = c.grid_for(ntiles, lds);
+  const uint32_t blocks = c.grid_for(ntiles, lds, vt::scan_multi_blocks_per_cu(d, k, ix->metric));
   // (a sweep always reads a full group of query rows: the last group is padded with zero rows)
   const size_t nq_pad = (nq + vt::kMultiMaxQueries - 1) / vt::kMultiMaxQueries * vt::kMultiMaxQueries;
   VT_TRY(c.dBQ.ensure(nq_pad * ld));

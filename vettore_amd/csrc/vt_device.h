@@ -108,7 +108,8 @@ struct MultiScanArgs {
 };
 uint32_t scan_multi_max_k(uint32_t nq);       // 64 for up to 4 queries per sweep, 32 for up to 8
 uint32_t scan_multi_tile_rows(uint32_t nq);   // rows per wave tile (grid sizing)
-size_t scan_multi_lds_bytes(uint32_t nq);
+size_t scan_multi_lds_bytes(uint32_t d, uint32_t k, int metric);
+int scan_multi_blocks_per_cu(uint32_t d, uint32_t k, int metric);  // 3 for the slim build (d % 64 == 0, k <= 16, dot/L2/L1/Linf), else 2
 hipError_t launch_scan_multi(const MultiScanArgs &a, uint32_t blocks, hipStream_t s);
 // Batch mode: `blocks` per query x `nq` queries.
 hipError_t launch_scan_batch(const ScanArgs &a, uint32_t blocks, uint32_t nq, hipStream_t s);

@@ -36,12 +36,23 @@ namespace dev {
 
 constexpr uint32_t kMqPanel = 256;  // floats per panel = one 1-KiB wave load per row
 constexpr uint32_t kMqSS = 44;      // dwords per LDS panel row: 32 chunk sums, 8 tail products, pad (4 * odd)
+// ... of the slim build: 32 chunk sums, no tail slots and no pad -- the 16-byte groups of row r are
+// stored at group position (g ^ r) instead, which spreads the chain phase's reads (lane = (query,
+// row), all lanes on the same group index) over the banks like the pad does
+constexpr uint32_t kMqSSSlim = 32;
 constexpr uint32_t kMqTail = 32;    // dword offset of the tail products in a panel row
 constexpr int kMqNQ = (int)kMultiMaxQueries;  // queries per sweep
 constexpr int kMqTR = kWave / kMqNQ;          // rows per tile: (query, row) pairs fill the wave exactly
 constexpr int kMqCap = 64;                    // candidate slots per query and wave (k <= 32, 8 offers at a time)
-constexpr uint32_t kMqQS = kMqTR * kMqSS + 8; // dwords between two queries' panels (the + 8 staggers their banks)
-constexpr uint32_t kMqRedo = 64;              // overflowed (query, row) pairs a wave can set aside for the f64 replay
+constexpr int kMqCapSlim = 32;                // ... of the slim build (k <= 16)
+constexpr uint32_t kMqSlimMaxK = 16;
+// dwords between two queries' panels (the + 8 staggers their banks)
+// (slim: + 4, and 8 replay slots: 50 KB per block.  At 54 KB three blocks did NOT become resident
+// on a CU, whatever 3 x 54 144 <= 163 840 says: wave-cycle counters showed two, and the statically
+// dealt tiles of the third ran as a tail, 8 % slower than the two-block build)
+constexpr uint32_t mq_qs(bool slim) { return kMqTR * (slim ? kMqSSSlim : kMqSS) + (slim ? 4 : 8); }
+// overflowed (query, row) pairs a wave can set aside for the f64 replay
+constexpr uint32_t mq_redo(bool slim) { return slim ? 8u : 64u; }
 
 // Per-element operation on PREPARED operands: for float hamming / jaccard the loaded row and
 // the query fragments are first turned into 0/1 indicators (x != 0), after which the element
@@ -155,10 +166,17 @@ __device__ __forceinline__ void released_too(f32x4 &v) { asm volatile("" : "+v"(
 // constant.  The last panel of a row may still be partial (d % 256 != 0): its surplus lanes
 // re-read columns of the same row (no extra HBM lines) and file sums the chain never reads.
 // Otherwise (ORDER = -1) bounds, tail and lane order are run-time and the loads the compiler's.
-template <int OP, int ORDER, bool FAST, bool TAILED>
-__global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(const MultiScanArgs a) {
+// SLIM (FAST, no tail, k <= 16): three blocks per CU instead of two.  What that takes: <= 168
+// VGPRs -- ONE set of query fragments instead of two (the next panel's are requested into the
+// same registers as soon as the panel's last row has been multiplied: the chain phase covers
+// their trip from L1/L2) -- and <= 53 KB of LDS per block: panel rows without tail slots, 32
+// candidate slots per (wave, query) instead of 64, 8 replay slots per wave instead of 64.
+template <int OP, int ORDER, bool FAST, bool TAILED, bool SLIM>
+__global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_multi_kernel(const MultiScanArgs a) {
+  static_assert(!SLIM || (FAST && !TAILED), "the slim build carries no tail");
   constexpr bool kTail = TAILED || !FAST;  // rows may end in chunks short of a group of four and in a scalar tail
-  constexpr int NQ = kMqNQ, TR = kMqTR, CAP = kMqCap;
+  constexpr int NQ = kMqNQ, TR = kMqTR, CAP = SLIM ? kMqCapSlim : kMqCap;
+  constexpr uint32_t kMqSS = SLIM ? kMqSSSlim : dev::kMqSS, kMqQS = mq_qs(SLIM), kMqRedo = mq_redo(SLIM);
   constexpr int SUM_OP = (OP == OP_HAM || OP == OP_JAC) ? OP_L1 : OP;  // how chunk sums combine
   constexpr bool kAbs = OP == OP_L1 || OP == OP_LINF || OP == OP_HAM;     // half_chunk leaves signed differences
   extern __shared__ __align__(16) float lds[];
@@ -241,7 +259,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(co
     // and nothing is copied.  Every vector-memory instruction of the loop is unconditional and
     // issued in the order its data is needed -- loads return in order, so a wait for the oldest
     // never has to wait for a younger one.
-    f32x4 qa[NQ], qb[NQ];
+    f32x4 qa[NQ], qb[SLIM ? 1 : NQ];
     query_fragment(0, qa);
     f32x4 bufa[TR], bufb[TR];
     load_group(bufa);
@@ -254,20 +272,31 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(co
         if (step + half >= total_steps) break;
         f32x4 *cur = half ? bufb : bufa;
         f32x4 *nxt = half ? bufa : bufb;
-        f32x4 *qcur = half ? qb : qa;
-        f32x4 *qnext = half ? qa : qb;
+        f32x4 *qcur = (half && !SLIM) ? qb : qa;
+        f32x4 *qnext = (half || SLIM) ? qa : qb;
         const uint32_t grow = t * TR + cr;  // the row of this lane's chain
         const bool row_valid = grow < a.n;
         // per step, in this order: the row's id rank (the column covers the slab's capacity), the
         // next panel's query fragments, the next group of corpus loads -- 1 + NQ + TR loads
         uint32_t my_rank = 0;
         if constexpr (FAST) issue_load_u32(my_rank, a.id_rank + grow);
-        query_fragment(pc + 1 == npanel ? 0 : pc + 1, qnext);
+        if constexpr (!SLIM) query_fragment(pc + 1 == npanel ? 0 : pc + 1, qnext);
         load_group(nxt);
         const uint32_t c = pc * (kMqPanel / 8) + ((uint32_t)lane >> 1);  // this lane pair's chunk of the row
 #pragma unroll
         for (int u = 0; u < TR; ++u) {
-          if constexpr (FAST) {
+          if constexpr (SLIM) {
+            // in flight, oldest first: cur's group, the fragments (requested at the end of the
+            // previous step), this step's rank and group.  One wait for all but the last 1 + TR
+            // releases the group and the fragments together.
+            if (u == 0) {
+              wait_all_but<1 + TR>(cur[0]);
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) released_too(qcur[q]);
+            } else {
+              released_too(cur[u]);
+            }
+          } else if constexpr (FAST) {
             // younger than cur[u]: the rest of its group and this step's 1 + NQ + TR loads
             switch (u) {
               case 0: wait_all_but<TR - 1 + 1 + NQ + TR>(cur[0]); break;
@@ -294,6 +323,14 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(co
           f32x2 pa[NQ], pb[NQ];
 #pragma unroll
           for (int q = 0; q < NQ; ++q) half_chunk<OP>(indicator<OP>(qcur[q]), x, x4k, pa[q], pb[q]);
+          if constexpr (SLIM) {
+            // the panel's last row has been multiplied: the fragments' registers take the next panel's
+            if (u == TR - 1) {
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(pa[q]), "v"(pb[q]));  // (products first)
+              query_fragment(pc + 1 == npanel ? 0 : pc + 1, qnext);
+            }
+          }
 #pragma unroll
           for (int q = 0; q < NQ; ++q) sum[q] = chunk_sum_packed<SUM_OP, ORDER, kAbs>(a.order, pa[q], pb[q], odd);
           if (kTail && tail && c == cfull) {  // tail chunk: the reference adds these products one by one
@@ -305,7 +342,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(co
           }
           // (sums of padding chunks land in slots the chain never reads)
 #pragma unroll
-          for (int qq = 0; qq < NQ; qq += 2) Sstore[qq * kMqQS + u * kMqSS] = pick_odd(sum[qq], sum[qq + 1]);
+          for (int qq = 0; qq < NQ; qq += 2) {
+            if constexpr (SLIM) (Sstore - (lane >> 1))[qq * kMqQS + u * kMqSS + (((uint32_t)lane >> 1) ^ ((uint32_t)u << 2))] = pick_odd(sum[qq], sum[qq + 1]);
+            else Sstore[qq * kMqQS + u * kMqSS] = pick_odd(sum[qq], sum[qq + 1]);
+          }
         }
         // The rank was requested first in this step: it has long arrived.  The wait is placed in
         // EVERY step, used or not -- a register whose load is still on its way must not look dead
@@ -319,10 +359,11 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(co
           if (FAST && !TAILED) {
             // chunks of this panel: 32, or what is left of the row (a multiple of 8 chunks)
             const uint32_t left = cfull - c0;
+            const uint32_t swz = SLIM ? (uint32_t)cr << 2 : 0u;  // (slim: row r keeps group g at g ^ r)
             if (left >= kMqPanel / 8) {
 #pragma unroll
               for (uint32_t i = 0; i < kMqPanel / 8; i += 4) {
-                const f32x4 w = *reinterpret_cast<const f32x4 *>(Schain + i);
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(Schain + (i ^ swz));
                 v = comb<SUM_OP>(SUM_OP, v, w.x);
                 v = comb<SUM_OP>(SUM_OP, v, w.y);
                 v = comb<SUM_OP>(SUM_OP, v, w.z);
@@ -330,7 +371,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(co
               }
             } else {
               for (uint32_t i = 0; i < left; i += 4) {
-                const f32x4 w = *reinterpret_cast<const f32x4 *>(Schain + i);
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(Schain + (i ^ swz));
                 v = comb<SUM_OP>(SUM_OP, v, w.x);
                 v = comb<SUM_OP>(SUM_OP, v, w.y);
                 v = comb<SUM_OP>(SUM_OP, v, w.z);
@@ -470,14 +511,23 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void scan_multi_kernel(co
   }
 }
 
-constexpr size_t kMqLds = (size_t)kWavesPerBlock * kMqNQ * ((size_t)kMqQS * 4 + WaveTopK<kMqCap>::lds_bytes());
+constexpr size_t mq_lds(bool slim) {
+  return (size_t)kWavesPerBlock * kMqNQ *
+         ((size_t)mq_qs(slim) * 4 + (slim ? WaveTopK<kMqCapSlim>::lds_bytes() : WaveTopK<kMqCap>::lds_bytes()));
+}
+// which launches take the slim build: see launch_multi_op
+inline bool mq_slim(uint32_t d, uint32_t k, int metric) {
+  static const bool off = std::getenv("VT_MULTI_NO_SLIM") != nullptr;  // A/B
+  const int op = metric_op(metric);
+  return !off && d % kRowAlign == 0 && k <= kMqSlimMaxK && (op == OP_DOT || op == OP_L2 || op == OP_L1 || op == OP_LINF);
+}
 
-template <int OP, int ORDER, bool FAST, bool TAILED = false>
+template <int OP, int ORDER, bool FAST, bool TAILED = false, bool SLIM = false>
 static hipError_t launch_multi_t(const MultiScanArgs &a, uint32_t blocks, hipStream_t s) {
-  auto kern = scan_multi_kernel<OP, ORDER, FAST, TAILED>;
-  hipError_t e = allow_lds(kern, kMqLds);
+  auto kern = scan_multi_kernel<OP, ORDER, FAST, TAILED, SLIM>;
+  hipError_t e = allow_lds(kern, mq_lds(SLIM));
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), kMqLds, s, a);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), mq_lds(SLIM), s, a);
   return hipGetLastError();
 }
 
@@ -499,6 +549,14 @@ static hipError_t launch_multi_op(const MultiScanArgs &a, uint32_t blocks, hipSt
     if (a.order == 2) return launch_multi_t<OP, ORDERED ? 2 : 0, true, true>(a, blocks, s);
     return launch_multi_t<OP, ORDERED ? 3 : 0, true, true>(a, blocks, s);
   }
+  if constexpr (OP == OP_DOT || OP == OP_L2 || OP == OP_L1 || OP == OP_LINF) {
+    if (mq_slim(a.d, a.k, a.metric)) {
+      if (!ORDERED || a.order == 0) return launch_multi_t<OP, 0, true, false, true>(a, blocks, s);
+      if (a.order == 1) return launch_multi_t<OP, ORDERED ? 1 : 0, true, false, true>(a, blocks, s);
+      if (a.order == 2) return launch_multi_t<OP, ORDERED ? 2 : 0, true, false, true>(a, blocks, s);
+      return launch_multi_t<OP, ORDERED ? 3 : 0, true, false, true>(a, blocks, s);
+    }
+  }
   if (!ORDERED || a.order == 0) return launch_multi_t<OP, 0, true>(a, blocks, s);
   if (a.order == 1) return launch_multi_t<OP, ORDERED ? 1 : 0, true>(a, blocks, s);
   if (a.order == 2) return launch_multi_t<OP, ORDERED ? 2 : 0, true>(a, blocks, s);
@@ -509,7 +567,8 @@ static hipError_t launch_multi_op(const MultiScanArgs &a, uint32_t blocks, hipSt
 
 uint32_t scan_multi_max_k(uint32_t) { return 32u; }
 uint32_t scan_multi_tile_rows(uint32_t) { return (uint32_t)dev::kMqTR; }
-size_t scan_multi_lds_bytes(uint32_t) { return dev::kMqLds; }
+size_t scan_multi_lds_bytes(uint32_t d, uint32_t k, int metric) { return dev::mq_lds(dev::mq_slim(d, k, metric)); }
+int scan_multi_blocks_per_cu(uint32_t d, uint32_t k, int metric) { return dev::mq_slim(d, k, metric) ? 3 : 2; }
 
 hipError_t launch_scan_multi(const MultiScanArgs &a, uint32_t blocks, hipStream_t s) {
   using namespace dev;
