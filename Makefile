@@ -53,6 +53,14 @@ $(LIBDIR)/vt_index_hooks.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h 
 $(LIBDIR)/libvettore_hip_hooks.so: $(DEVOBJ) $(LIBDIR)/vt_index_hooks.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread -ldl
 
+# K1m with its timing experiments compiled in (VT_MQ_DBG=<bits>: wrong results, for the cost
+# breakdown in DESIGN 4.4 only): `make mqdbg`, then VETTORE_HIP_LIB=.../libvettore_hip_mqdbg.so
+$(LIBDIR)/vt_scan_multi_dbg.o: $(CSRC)/vt_scan_multi.hip $(DEVHDR)
+	$(HIPCC) $(HIPFLAGS) -DVT_MULTI_TIMING_EXPERIMENTS -c $< -o $@
+$(LIBDIR)/libvettore_hip_mqdbg.so: $(filter-out %/vt_scan_multi.o,$(DEVOBJ)) $(LIBDIR)/vt_scan_multi_dbg.o $(LIBDIR)/vt_index.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread -ldl
+mqdbg: $(LIBDIR)/libvettore_hip_mqdbg.so
+
 oracle:
 	$(MAKE) -C oracle -s
 
@@ -65,4 +73,4 @@ tools/%: tools/%.hip
 clean:
 	rm -rf $(LIBDIR) oracle/libvt_oracle.so $(PROBES)
 
-.PHONY: all oracle clean probes
+.PHONY: all oracle clean probes mqdbg

@@ -319,6 +319,8 @@ int multi_scan_group(Shard *ix, Ctx &c, const float *queries, const std::vector<
     a.k = k;
     a.nq = gn;
     a.first_query = (uint32_t)g0;
+    static const uint32_t dbg = std::getenv("VT_MQ_DBG") ? (uint32_t)std::atoi(std::getenv("VT_MQ_DBG")) : 0u;
+    a.dbg = dbg;
     for (uint32_t i = 0; i < gn; ++i) a.q_nonzero[i] = qnz[g0 + i];
     a.part_keys = c.dPartKeys.p;
     a.part_pay = c.dPartPay.p;

@@ -101,6 +101,7 @@ struct MultiScanArgs {
   uint32_t k;               // <= scan_multi_max_k(nq)
   uint32_t nq;              // queries of this launch, 1..kMultiMaxQueries
   uint32_t first_query;     // index of Q[0] among the lists of the whole batch
+  uint32_t dbg;             // timing experiments (builds with -DVT_MULTI_TIMING_EXPERIMENTS only; VT_MQ_DBG): see the kernel
   uint32_t q_nonzero[kMultiMaxQueries];
   uint64_t *part_keys;
   Payload *part_pay;

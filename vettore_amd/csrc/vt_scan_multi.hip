@@ -313,6 +313,16 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
               for (int q = 0; q < NQ; ++q) released_too(qcur[q]);
             }
           }
+#ifdef VT_MULTI_TIMING_EXPERIMENTS
+          // (wrong results, timing only: `make mqdbg`) 1: no products / sums / stores, 2: no chain phase, 4: no stores
+          if (a.dbg & 1u) {
+            asm volatile("" ::"v"(cur[u]));
+            if constexpr (SLIM) {
+              if (u == TR - 1) query_fragment(pc + 1 == npanel ? 0 : pc + 1, qnext);
+            }
+            continue;
+          }
+#endif
           const f32x4 x = indicator<OP>(cur[u]);
           f32x4 x4k = x;
           if (OP == OP_JAC) x4k = f32x4{x.x * 4096.0f, x.y * 4096.0f, x.z * 4096.0f, x.w * 4096.0f};
@@ -340,6 +350,13 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
                   kAbs ? f32x4{fabsf(pa[q].x), fabsf(pa[q].y), fabsf(pb[q].x), fabsf(pb[q].y)}
                        : f32x4{pa[q].x, pa[q].y, pb[q].x, pb[q].y};
           }
+#ifdef VT_MULTI_TIMING_EXPERIMENTS
+          if (a.dbg & 4u) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(sum[q]));
+            continue;
+          }
+#endif
           // (sums of padding chunks land in slots the chain never reads)
 #pragma unroll
           for (int qq = 0; qq < NQ; qq += 2) {
@@ -353,6 +370,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
         if constexpr (FAST) wait_all_but<NQ + TR>(my_rank);
         // panel complete: every (query, row) chain advances by the panel's chunks
         wave_lds_fence();
+#ifdef VT_MULTI_TIMING_EXPERIMENTS
+        if (!(a.dbg & 2u))
+#endif
         {
           const uint32_t c0 = pc * (kMqPanel / 8);
           float v = pc == 0 ? 0.0f : acc;
