@@ -339,6 +339,7 @@ typedef struct vt_profile {
   uint64_t nominate_second_passes; /* passes re-run with thresholds from a first pass's exact hits */
   uint64_t nominate_candidates;   /* rows handed to the exact rescoring, summed over queries */
   uint64_t hamming_queries;       /* queries served by grouped Hamming passes (0 for single-query passes) */
+  uint64_t hybrid_device_chains;  /* hybrid searches whose generators, union and rerank ran as one device chain (one host wait) */
 } vt_profile;
 int vt_flat_set_profiling(vt_flat *index, int enabled);
 int vt_flat_get_profile(vt_flat *index, vt_profile *out, int reset);

@@ -658,6 +658,49 @@ def test_hybrid_search_matches_oracle_composition(nifs, oracle_mod, metric):
         assert bits(got) == bits(want), metric
 
 
+@pytest.mark.parametrize("metric", [2, 0, 1, 3, 5, 6, 7, 8])
+def test_hybrid_device_chain_equals_host_composition(nifs, oracle_mod, metric, monkeypatch):
+    """hybrid_search with every generator <= 256 candidates can run as ONE device chain (generator
+    blocks -> union of rows -> exact rerank; one host wait; opt-in, VT_HYBRID_CHAIN=1, because it
+    measured no faster): its hits equal the default host-composed path's bit for bit, for every metric, generator mix and overlap, on a corpus large
+    enough for the histogram Hamming pass and on a small one; the profile counts the chains."""
+    for n, d in ((40_000, 128), (900, 40)):
+        x, ids = make_corpus(n, d, 470 + metric, metric == 2, oracle_mod, tie_block=25)
+        g = GpuIndex(nifs, metric)
+        unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+        nifs.flat_set_profiling(g.ref, True)
+        rng = np.random.default_rng(16 + metric)
+        mixes = [
+            [(nifs.GEN_FUNNEL, 60, [d // 4, d // 2]), (nifs.GEN_QUANTIZED, 80, []), (nifs.GEN_SEARCH, 30, [])],
+            [(nifs.GEN_SEARCH, 256, [])],
+            [(nifs.GEN_QUANTIZED, 200, []), (nifs.GEN_QUANTIZED, 200, [])],       # the same rows twice: all repeats
+            [(nifs.GEN_FUNNEL, 256, [d]), (nifs.GEN_SEARCH, 1, []), (nifs.GEN_FUNNEL, 7, [3, 5, d])],
+            [(nifs.GEN_SEARCH, 100, [])] * 8,
+        ]
+        for gens in mixes:
+            for limit in (1, 10, 256):
+                q = rng.uniform(-1, 1, d).astype(np.float32)
+                if metric == 2:
+                    q = oracle_mod.normalize_l2(q)
+                q[:2] = x[n // 2][:2]
+                nifs.flat_get_profile(g.ref, reset=True)
+                monkeypatch.setenv("VT_HYBRID_CHAIN", "1")
+                got = nifs.flat_hybrid_search(g.ref, q, gens, limit)
+                chains = nifs.flat_get_profile(g.ref, reset=True)["hybrid_device_chains"]
+                monkeypatch.delenv("VT_HYBRID_CHAIN")
+                want = nifs.flat_hybrid_search(g.ref, q, gens, limit)
+                assert nifs.flat_get_profile(g.ref, reset=True)["hybrid_device_chains"] == 0
+                assert got[0] == want[0] == "ok", (metric, gens, got, want)
+                assert bits(got[1]) == bits(want[1]), (metric, n, gens, limit)
+                assert chains == 1, (metric, n, gens, limit)
+        # beyond what one chain holds: the host-composed path serves it
+        nifs.flat_get_profile(g.ref, reset=True)
+        monkeypatch.setenv("VT_HYBRID_CHAIN", "1")
+        unwrap(nifs.flat_hybrid_search(g.ref, q, [(nifs.GEN_SEARCH, 300, [])], 10))
+        monkeypatch.delenv("VT_HYBRID_CHAIN")
+        assert nifs.flat_get_profile(g.ref, reset=True)["hybrid_device_chains"] == 0
+
+
 def test_binary_top_k_with_massive_ties(nifs, oracle_mod):
     """One-word codes: only 65 distinct distances over 200k rows, so the k-th key
     sits in a crowded radix bin and ties are decided by id bytes alone."""

@@ -46,6 +46,7 @@ class Profile(C.Structure):
         ("nominate_flops", C.c_double), ("nominate_queries", C.c_uint64),
         ("nominate_second_passes", C.c_uint64), ("nominate_candidates", C.c_uint64),
         ("hamming_queries", C.c_uint64),
+        ("hybrid_device_chains", C.c_uint64),
     ]
 
 

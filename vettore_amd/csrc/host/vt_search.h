@@ -250,6 +250,44 @@ int funnel_stage(Shard *ix, Ctx &c, const float *query, uint32_t d, const std::v
   return run_scan(c, j, want, out, false);
 }
 
+// The index's own metric (K1 arithmetic: for a cosine index the f32 dot of normalised rows, like
+// flat_search) over the first `d` coordinates of `count` rows -- all rows, or the Entry.row column
+// of `src` -- on the device: the `want` <= kMaxFusedK best, sorted, into `dst`.  Nothing is waited
+// for; an overflow flag stays in c.dStatus until a select with `last` moves it into its block.
+int scan_stage_dev(Shard *ix, Ctx &c, uint32_t d, const ResultBlock *src, uint32_t count, uint32_t want, uint32_t qnz,
+                   ResultBlock *dst, bool last) {
+  const uint32_t *gather = src ? &src->e[0].row : nullptr;
+  const uint32_t gstride = sizeof(vt::Entry) / sizeof(uint32_t);
+  int *status = last ? c.dStatus.p : nullptr;
+  const uint32_t tile_rows = vt::scan_tile_rows(count, d, c.resident_waves());
+  const uint32_t ntiles = (count + tile_rows - 1) / tile_rows;
+  const uint32_t blocks = c.grid_for(ntiles, vt::scan_lds_bytes(d, want));
+  const uint32_t lists = vt::scan_lists(blocks);
+  VT_TRY(c.dPartKeys.ensure((size_t)lists * want));
+  VT_TRY(c.dPartPay.ensure((size_t)lists * want));
+  vt::ScanArgs a{};
+  a.X = ix->dX;
+  a.stride = ix->ld;
+  a.q = c.dQ.p;
+  a.id_rank = ix->dRank.p;
+  a.gather = gather;
+  a.gather_stride = gather ? gstride : 0;
+  a.n = count;
+  a.d = d;
+  a.metric = ix->metric;
+  a.order = ix->order;
+  a.k = want;
+  a.q_nonzero = qnz;
+  a.tile_rows = tile_rows;
+  a.part_keys = c.dPartKeys.p;
+  a.part_pay = c.dPartPay.p;
+  a.status = c.dStatus.p;
+  VT_HIP(vt::launch_scan(a, blocks, c.stream));
+  VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, lists * want, want, 0, 0, status, dst, c.dSelKeys.p, c.dSelPay.p,
+                           c.stream));
+  return VT_OK;
+}
+
 // One funnel / rerank stage that never leaves the device: scores `count` rows
 // (all rows, or the Entry.row column of the previous stage's block), keeps
 // `want` <= kMaxFusedK of them in `dst`.  Nothing is waited for; an overflow
@@ -257,10 +295,11 @@ int funnel_stage(Shard *ix, Ctx &c, const float *query, uint32_t d, const std::v
 // it into its block.
 int funnel_stage_dev(Shard *ix, Ctx &c, const float *query, uint32_t d, const ResultBlock *src, uint32_t count,
                      uint32_t want, uint32_t qnz, ResultBlock *dst, bool last) {
+  if (ix->metric != VT_COSINE) return scan_stage_dev(ix, c, d, src, count, want, qnz, dst, last);
   const uint32_t *gather = src ? &src->e[0].row : nullptr;
   const uint32_t gstride = sizeof(vt::Entry) / sizeof(uint32_t);
   int *status = last ? c.dStatus.p : nullptr;
-  if (ix->metric == VT_COSINE) {
+  {
     double qq = 0.0;  // f64_dot(q, q) over the prefix (distances.rs:179-185)
     for (uint32_t j = 0; j < d; ++j) qq += (double)query[j] * (double)query[j];
     if (!src) {
@@ -309,33 +348,6 @@ int funnel_stage_dev(Shard *ix, Ctx &c, const float *query, uint32_t d, const Re
                              c.stream));
     return VT_OK;
   }
-  const uint32_t tile_rows = vt::scan_tile_rows(count, d, c.resident_waves());
-  const uint32_t ntiles = (count + tile_rows - 1) / tile_rows;
-  const uint32_t blocks = c.grid_for(ntiles, vt::scan_lds_bytes(d, want));
-  const uint32_t lists = vt::scan_lists(blocks);
-  VT_TRY(c.dPartKeys.ensure((size_t)lists * want));
-  VT_TRY(c.dPartPay.ensure((size_t)lists * want));
-  vt::ScanArgs a{};
-  a.X = ix->dX;
-  a.stride = ix->ld;
-  a.q = c.dQ.p;
-  a.id_rank = ix->dRank.p;
-  a.gather = gather;
-  a.gather_stride = gather ? gstride : 0;
-  a.n = count;
-  a.d = d;
-  a.metric = ix->metric;
-  a.order = ix->order;
-  a.k = want;
-  a.q_nonzero = qnz;
-  a.tile_rows = tile_rows;
-  a.part_keys = c.dPartKeys.p;
-  a.part_pay = c.dPartPay.p;
-  a.status = c.dStatus.p;
-  VT_HIP(vt::launch_scan(a, blocks, c.stream));
-  VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, lists * want, want, 0, 0, status, dst, c.dSelKeys.p, c.dSelPay.p,
-                           c.stream));
-  return VT_OK;
 }
 
 // True when every stage of a funnel fits one fused pass on the device.

@@ -294,9 +294,18 @@ struct CosineRerankArgs {
   // several queries in one launch (launch_cosine_rerank_batch, grid.y = queries): query y uses
   // q + y * q_stride, gather + y * gather_qstride and writes to out_keys / out_pay + y * n
   uint32_t q_stride, gather_qstride;
+  // when set (single-query launches): only the first min(n, *n_dev) candidates exist, the other
+  // slots get the empty key -- a candidate list whose length only the device knows (launch_union_rows)
+  const uint32_t *n_dev;
 };
 hipError_t launch_cosine_rerank(const CosineRerankArgs &a, hipStream_t s);
 hipError_t launch_cosine_rerank_batch(const CosineRerankArgs &a, uint32_t nq, hipStream_t s);
+
+// hybrid_candidates (collection.ex:515-532) on the device: the rows of `nblocks` <= 8 candidate
+// blocks (each a top-k list, so without repeats of its own), every row once, in order of first
+// appearance, to rows_out[0 .. *count_out); rows_out holds the sum of the blocks' counts.
+hipError_t launch_union_rows(const ResultBlock *blocks, uint32_t nblocks, uint32_t *rows_out, uint32_t *count_out,
+                             hipStream_t s);
 
 // Cross-shard merge on the device: `blocks` is `world` ResultBlock prefixes
 // (16-B header + k entries each, `block_bytes` apart) as gathered from the shards;

@@ -816,6 +816,7 @@ int vt_flat_get_profile(vt_flat *h, vt_profile *out, int reset) {
       t.nominate_second_passes += p.nominate_second_passes;
       t.nominate_candidates += p.nominate_candidates;
       t.hamming_queries += p.hamming_queries;
+      t.hybrid_device_chains += p.hybrid_device_chains;
       if (reset) c.prof = vt_profile{};
     });
   if (reset) h->xprof = vt_profile{};

@@ -927,6 +927,10 @@ __global__ __launch_bounds__(64) void cosine_rerank_kernel(const CosineRerankArg
   }
   const uint32_t i = blockIdx.x;
   const int lane = threadIdx.x;
+  if (a.n_dev && i >= *a.n_dev) {  // (a list shorter than its buffer: nothing behind its end)
+    if (lane == 0) a.out_keys[i] = kEmptyKey;
+    return;
+  }
   const uint32_t src = a.gather ? a.gather[(size_t)i * a.gather_stride] : i;
   const uint32_t ld4 = (a.d + 3) / 4 * 4;
   float *qs = crs, *xs = crs + ld4;
@@ -1578,6 +1582,60 @@ hipError_t launch_gather_rows(const float *src, uint32_t d, const uint32_t *map,
   if (count == 0) return hipSuccess;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(count < 4096 ? count : 4096), dim3(256), 0, s, src, d, map, count, dst,
                      dst_stride);
+  return hipGetLastError();
+}
+
+// One block.  Entry (g, j) survives when no block before g holds its row (a block's own rows are
+// distinct: it is a top-k list); survivors keep their order.
+__global__ __launch_bounds__(1024) void union_rows_kernel(const ResultBlock *blocks, uint32_t nblocks, uint32_t *rows_out,
+                                                          uint32_t *count_out) {
+  __shared__ __align__(16) uint32_t s_rows[8 * kMaxFusedK];
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_base;
+  const uint32_t total = nblocks * (uint32_t)kMaxFusedK;
+  for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+    const uint32_t g = e / kMaxFusedK, j = e % kMaxFusedK;
+    s_rows[e] = j < blocks[g].count ? blocks[g].e[j].row : 0xFFFFFFFFu;
+  }
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  for (uint32_t e0 = 0; e0 < total; e0 += blockDim.x) {
+    const uint32_t e = e0 + threadIdx.x;
+    const uint32_t row = e < total ? s_rows[e] : 0xFFFFFFFFu;
+    bool keep = row != 0xFFFFFFFFu;
+    const uint32_t before = e < total ? (e / kMaxFusedK) * kMaxFusedK : 0u;  // entries of earlier blocks
+    // (no early exit: sixteen rows per step, four independent 16-byte LDS reads in flight -- a loop
+    // that stops at the first match waits out one LDS round trip per row: 35 us for three blocks)
+    for (uint32_t o = 0; o < before; o += 16) {
+      const uint4 r0 = *reinterpret_cast<const uint4 *>(s_rows + o), r1 = *reinterpret_cast<const uint4 *>(s_rows + o + 4),
+                  r2 = *reinterpret_cast<const uint4 *>(s_rows + o + 8), r3 = *reinterpret_cast<const uint4 *>(s_rows + o + 12);
+      keep = keep && r0.x != row && r0.y != row && r0.z != row && r0.w != row && r1.x != row && r1.y != row && r1.z != row &&
+             r1.w != row && r2.x != row && r2.y != row && r2.z != row && r2.w != row && r3.x != row && r3.y != row &&
+             r3.z != row && r3.w != row;
+    }
+    const uint64_t m = __ballot(keep);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t pos = s_base;
+    for (int w = 0; w < wave; ++w) pos += s_wave[w];
+    pos += (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    if (keep) rows_out[pos] = row;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t sum = 0;
+      for (int w = 0; w < 16; ++w) sum += s_wave[w];
+      s_base += sum;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count_out = s_base;
+}
+
+hipError_t launch_union_rows(const ResultBlock *blocks, uint32_t nblocks, uint32_t *rows_out, uint32_t *count_out,
+                             hipStream_t s) {
+  if (nblocks == 0 || nblocks > 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(union_rows_kernel, dim3(1), dim3(1024), 0, s, blocks, nblocks, rows_out, count_out);
   return hipGetLastError();
 }
 
