@@ -20,7 +20,9 @@ def no_matrix_cores(monkeypatch):
 @pytest.mark.parametrize("metric", range(9))
 def test_multi_query_scan_equals_single_queries_all_metrics(nifs, oracle_mod, metric):
     rng = np.random.default_rng(40 + metric)
-    for d in (7, 24, 64, 100, 192, 256, 384, 448, 1000):
+    # (64, 128, 320, 384, 640: the last panel of a row is 64 or 128 floats -- the builds that pack it
+    # for four or two rows into one load; 128 and 64 are that panel alone)
+    for d in (7, 24, 64, 100, 128, 192, 256, 320, 384, 448, 640, 1000):
         n = 6000 if d >= 384 else 12000
         x, ids = make_corpus(n, d, 700 + metric + d, metric == 2, oracle_mod, tie_block=40)
         if metric in (7, 8):                       # float hamming / jaccard: zeros must occur

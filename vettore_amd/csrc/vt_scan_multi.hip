@@ -171,9 +171,21 @@ __device__ __forceinline__ void released_too(f32x4 &v) { asm volatile("" : "+v"(
 // same registers as soon as the panel's last row has been multiplied: the chain phase covers
 // their trip from L1/L2) -- and <= 53 KB of LDS per block: panel rows without tail slots, 32
 // candidate slots per (wave, query) instead of 64, 8 replay slots per wave instead of 64.
-template <int OP, int ORDER, bool FAST, bool TAILED, bool SLIM>
+// PACK (slim builds; 2 or 4): the row's last panel is 256 / PACK floats wide (d % 256 = 128 or 64:
+// d = 384, 128, 64, 320 ...), and instead of leaving (PACK - 1) / PACK of every load's lanes to
+// re-read columns nobody sums, one load carries that panel of PACK consecutive rows: lane l sits
+// on row u * PACK + l / (64 / PACK), columns 4 * (l % (64 / PACK)) ... of the panel -- TR / PACK loads,
+// and as many rounds of products, for the step instead of TR.  The group still ISSUES TR loads -- the
+// surplus ones fetch the (cache-resident) query rows -- and every load of the loop stays
+// unconditional: with groups of two sizes the asm loads sat in two branches, the ring registers
+// met in phis, and the compiler resolved those with copies (`v_mov_b64` of ring registers on the
+// loop's back edge, in front of the counted waits) of registers whose loads were still in flight:
+// garbage scores, timing-dependent.  The same goes for two `s_waitcnt` statements in an if / else
+// (the copy of the released register was placed above one of them).  One size, one wait, no phi.
+template <int OP, int ORDER, bool FAST, bool TAILED, bool SLIM, int PACK = 1>
 __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_multi_kernel(const MultiScanArgs a) {
   static_assert(!SLIM || (FAST && !TAILED), "the slim build carries no tail");
+  static_assert(PACK == 1 || (SLIM && (PACK == 2 || PACK == 4)), "row packing lives in the slim builds");
   constexpr bool kTail = TAILED || !FAST;  // rows may end in chunks short of a group of four and in a scalar tail
   constexpr int NQ = kMqNQ, TR = kMqTR, CAP = SLIM ? kMqCapSlim : kMqCap;
   constexpr uint32_t kMqSS = SLIM ? kMqSSSlim : dev::kMqSS, kMqQS = mq_qs(SLIM), kMqRedo = mq_redo(SLIM);
@@ -202,6 +214,17 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
   const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
   const uint32_t ntiles = (a.n + TR - 1) / TR;
   const uint32_t lane_col = (uint32_t)lane * 4u;
+  // packed last panel: this lane's row within a load and its columns within the panel
+  // (derived from the lane id where they are used, behind an opaque copy of it: hoisted out of the
+  // loop they are two more live registers, and the packed builds sit exactly on the 168 that three
+  // blocks per CU allow -- one spilled vector register fails the build, tools/check_scratch.py)
+  constexpr uint32_t kPkLanes = kWave / PACK, kPkG = kMqTR / PACK;
+  auto pk_position = [&](uint32_t &sub, uint32_t &col) {
+    uint32_t l = (uint32_t)lane;
+    asm volatile("" : "+v"(l));
+    sub = l / kPkLanes;
+    col = (l % kPkLanes) * 4u;
+  };
   // compute phase: a lane pair owns chunk (lane >> 1) of the loaded row; the even lane files
   // the sums of the even queries, the odd lane those of the odd queries (one store per pair of queries)
   float *Sstore = S + odd * kMqQS + (lane >> 1);
@@ -224,9 +247,25 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
       uint32_t colf = lp * kMqPanel + lane_col;
       if (FAST && colf >= ld) colf %= ld;  // surplus lane of a partial panel: any column of the row will do
       const float *base = a.X + (size_t)t * TR * a.stride + colf;
+      // (PACK) the short last panel: PACK rows per load in the first TR / PACK loads; the rest repeat
+      // the last of those (lines already on their way: no new HBM traffic) -- one base and one stride
+      // are SELECTED, the load instructions are the same eight
+      const bool pk = PACK > 1 && lp + 1 == npanel;
+      const float *base_sel = base;
+      size_t stride_sel = a.stride;
+      if constexpr (PACK > 1) {
+        uint32_t pk_sub, pk_col;
+        pk_position(pk_sub, pk_col);
+        const float *base_pk = a.X + ((size_t)t * TR + pk_sub) * a.stride + lp * kMqPanel + pk_col;
+        base_sel = pk ? base_pk : base;
+        stride_sel = pk ? (size_t)PACK * a.stride : a.stride;
+      }
 #pragma unroll
       for (int u = 0; u < TR; ++u) {
-        if constexpr (FAST) {
+        if constexpr (PACK > 1) {
+          const uint32_t u_eff = (pk && u >= (int)kPkG) ? kPkG - 1 : (uint32_t)u;
+          issue_load_nt(buf[u], base_sel + (size_t)u_eff * stride_sel);
+        } else if constexpr (FAST) {
           issue_load_nt(buf[u], base + (size_t)u * a.stride);
         } else {
           // (rows up to the slab's capacity exist and are zero; a panel's lanes beyond the row end do not load)
@@ -242,6 +281,11 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
     };
     auto query_fragment = [&](uint32_t panel, f32x4 *qv) {
       uint32_t colf = panel * kMqPanel + lane_col;
+      if (PACK > 1 && panel + 1 == npanel) {
+        uint32_t pk_sub, pk_col;
+        pk_position(pk_sub, pk_col);
+        colf = panel * kMqPanel + pk_col;
+      }
       if (FAST && colf >= ld) colf %= ld;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -283,13 +327,21 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
         if constexpr (!SLIM) query_fragment(pc + 1 == npanel ? 0 : pc + 1, qnext);
         load_group(nxt);
         const uint32_t c = pc * (kMqPanel / 8) + ((uint32_t)lane >> 1);  // this lane pair's chunk of the row
+        // (PACK) is this step's panel the short one, and the one just requested?
+        const uint32_t nxt_panel = pc + 1 == npanel ? 0u : pc + 1;
+        const bool cur_pk = PACK > 1 && pc + 1 == npanel;
+        const int last_u = cur_pk ? (int)kPkG - 1 : TR - 1;
 #pragma unroll
         for (int u = 0; u < TR; ++u) {
+          if (PACK > 1 && u > last_u) break;
           if constexpr (SLIM) {
             // in flight, oldest first: cur's group, the fragments (requested at the end of the
             // previous step), this step's rank and group.  One wait for all but the last 1 + TR
             // releases the group and the fragments together.
             if (u == 0) {
+#ifdef VT_MULTI_TIMING_EXPERIMENTS
+              if (a.dbg & 8u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (8: every load in before a step's first use)
+#endif
               wait_all_but<1 + TR>(cur[0]);
 #pragma unroll
               for (int q = 0; q < NQ; ++q) released_too(qcur[q]);
@@ -317,8 +369,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
           // (wrong results, timing only: `make mqdbg`) 1: no products / sums / stores, 2: no chain phase, 4: no stores
           if (a.dbg & 1u) {
             asm volatile("" ::"v"(cur[u]));
-            if constexpr (SLIM) {
-              if (u == TR - 1) query_fragment(pc + 1 == npanel ? 0 : pc + 1, qnext);
+            if constexpr (SLIM && PACK == 1) {
+              if (u == TR - 1) query_fragment(nxt_panel, qnext);
             }
             continue;
           }
@@ -333,12 +385,12 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
           f32x2 pa[NQ], pb[NQ];
 #pragma unroll
           for (int q = 0; q < NQ; ++q) half_chunk<OP>(indicator<OP>(qcur[q]), x, x4k, pa[q], pb[q]);
-          if constexpr (SLIM) {
+          if constexpr (SLIM && PACK == 1) {
             // the panel's last row has been multiplied: the fragments' registers take the next panel's
             if (u == TR - 1) {
 #pragma unroll
               for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(pa[q]), "v"(pb[q]));  // (products first)
-              query_fragment(pc + 1 == npanel ? 0 : pc + 1, qnext);
+              query_fragment(nxt_panel, qnext);
             }
           }
 #pragma unroll
@@ -360,10 +412,25 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
           // (sums of padding chunks land in slots the chain never reads)
 #pragma unroll
           for (int qq = 0; qq < NQ; qq += 2) {
-            if constexpr (SLIM) (Sstore - (lane >> 1))[qq * kMqQS + u * kMqSS + (((uint32_t)lane >> 1) ^ ((uint32_t)u << 2))] = pick_odd(sum[qq], sum[qq + 1]);
-            else Sstore[qq * kMqQS + u * kMqSS] = pick_odd(sum[qq], sum[qq + 1]);
+            if constexpr (SLIM) {
+              // row of this lane's sums and its chunk within the panel; row r keeps 16-byte group g at g ^ r
+              uint32_t srow = (uint32_t)u, schunk = (uint32_t)lane >> 1;
+              if (cur_pk) {
+                uint32_t pk_sub, pk_col;
+                pk_position(pk_sub, pk_col);
+                srow = (uint32_t)u * PACK + pk_sub;
+                schunk = pk_col >> 3;
+              }
+              (S + odd * kMqQS)[qq * kMqQS + srow * kMqSS + (schunk ^ (srow << 2))] = pick_odd(sum[qq], sum[qq + 1]);
+            } else {
+              Sstore[qq * kMqQS + u * kMqSS] = pick_odd(sum[qq], sum[qq + 1]);
+            }
           }
         }
+        // (PACK: the step's rounds end at a run-time count, so the fragments' reload sits behind the
+        // loop, at ONE place in the program -- see the note on phis at the top of the kernel; the
+        // sums' LDS stores above cannot move below it, so every product has been formed)
+        if constexpr (SLIM && PACK > 1) query_fragment(nxt_panel, qnext);
         // The rank was requested first in this step: it has long arrived.  The wait is placed in
         // EVERY step, used or not -- a register whose load is still on its way must not look dead
         // to the register allocator, or the late write lands in whatever was put there since.
@@ -542,9 +609,9 @@ inline bool mq_slim(uint32_t d, uint32_t k, int metric) {
   return !off && d % kRowAlign == 0 && k <= kMqSlimMaxK && (op == OP_DOT || op == OP_L2 || op == OP_L1 || op == OP_LINF);
 }
 
-template <int OP, int ORDER, bool FAST, bool TAILED = false, bool SLIM = false>
+template <int OP, int ORDER, bool FAST, bool TAILED = false, bool SLIM = false, int PACK = 1>
 static hipError_t launch_multi_t(const MultiScanArgs &a, uint32_t blocks, hipStream_t s) {
-  auto kern = scan_multi_kernel<OP, ORDER, FAST, TAILED, SLIM>;
+  auto kern = scan_multi_kernel<OP, ORDER, FAST, TAILED, SLIM, PACK>;
   hipError_t e = allow_lds(kern, mq_lds(SLIM));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), mq_lds(SLIM), s, a);
@@ -571,6 +638,14 @@ static hipError_t launch_multi_op(const MultiScanArgs &a, uint32_t blocks, hipSt
   }
   if constexpr (OP == OP_DOT || OP == OP_L2 || OP == OP_L1 || OP == OP_LINF) {
     if (mq_slim(a.d, a.k, a.metric)) {
+      // a last panel of 128 or 64 floats (d = 384, 128, 64, 320 ...): two or four rows per load there
+      // (the default lane order only: two more builds per operation)
+      static const bool no_pack = std::getenv("VT_MULTI_NO_PACK") != nullptr;  // A/B
+      constexpr int kOrd = ORDERED ? kDefaultReduceOrder : 0;
+      if (!no_pack && (!ORDERED || a.order == kDefaultReduceOrder)) {
+        if (a.ld % kMqPanel == 128) return launch_multi_t<OP, kOrd, true, false, true, 2>(a, blocks, s);
+        if (a.ld % kMqPanel == 64) return launch_multi_t<OP, kOrd, true, false, true, 4>(a, blocks, s);
+      }
       if (!ORDERED || a.order == 0) return launch_multi_t<OP, 0, true, false, true>(a, blocks, s);
       if (a.order == 1) return launch_multi_t<OP, ORDERED ? 1 : 0, true, false, true>(a, blocks, s);
       if (a.order == 2) return launch_multi_t<OP, ORDERED ? 2 : 0, true, false, true>(a, blocks, s);
