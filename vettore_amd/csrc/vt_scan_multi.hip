@@ -205,6 +205,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
   // compiler's (its waits would drain the load stream).  More of them than fit: the launch
   // reports kStatusRetry and the host takes the queries one by one.
   __shared__ uint32_t s_redo[kWavesPerBlock][kMqRedo], s_redo_q[kWavesPerBlock][kMqRedo];
+  __shared__ uint32_t s_thr_hi[SLIM ? kWavesPerBlock : 1][SLIM ? kWave : 1];  // (slim builds: see the tile's end)
   uint32_t nredo = 0;  // wave-uniform
 
   const uint32_t ld = a.ld;
@@ -310,6 +311,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
 
     uint32_t t = wave_global, pc = 0;  // tile and panel of the step being consumed
     float acc = 0.0f;
+    uint32_t my_thr_hi = 0xFFFFFFFFu;  // score half of the threshold of this lane's query's list (see the tile's end)
+    if constexpr (SLIM) s_thr_hi[wib][lane] = 0xFFFFFFFFu;
+    (void)my_thr_hi;
     for (uint32_t step = 0; step < total_steps; step += 2) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -541,8 +545,24 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
           else if (metric == M_IP) rank = -raw;
           if constexpr (!FAST) my_rank = row_valid ? a.id_rank[grow] : 0u;
           const uint64_t key = ((uint64_t)orderable(rank) << 32) | my_rank;
+          // One compare and one ballot decide whether ANY of the eight lists takes anything from this
+          // tile: each lane keeps the high half (the score part) of the threshold of its own query's
+          // list -- an equal score goes on to the full comparison -- and thresholds only move inside
+          // an offer, so the copy is refreshed behind the offers.  (The slim builds have no register
+          // left for it -- the packed ones sit on the 168 that three blocks per CU allow -- and keep
+          // it in LDS: one read per tile.)  Once the lists have warmed up nearly every tile ends
+          // here -- eight compare / ballot / branch rounds were ~50 of the ~280 vector instructions
+          // of a tile at d = 128, ~1 600 at d = 768.
+          const uint32_t thr_hi = SLIM ? s_thr_hi[wib][lane] : my_thr_hi;
+          if (__ballot(valid && (uint32_t)(key >> 32) <= thr_hi) != 0ull) {
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) tk[q].offer(valid && cq == q, key, grow, raw, lane);
+            for (int q = 0; q < NQ; ++q) tk[q].offer(valid && cq == q, key, grow, raw, lane);
+            uint32_t now = (uint32_t)(tk[0].thr >> 32);
+#pragma unroll
+            for (int q = 1; q < NQ; ++q) now = cq == q ? (uint32_t)(tk[q].thr >> 32) : now;
+            if constexpr (SLIM) s_thr_hi[wib][lane] = now;
+            else my_thr_hi = now;
+          }
           pc = 0;
           t += total_waves;
         }
