@@ -1358,6 +1358,28 @@ def test_rows_too_long_for_the_query_to_sit_in_lds(nifs, oracle_mod, d):
 
 
 # ------------------------------------------------- several quantized searches per sweep
+def test_quantized_groups_with_partial_and_odd_words(nifs, oracle_mod):
+    """Row lengths whose sign bits end in a partial word and / or an odd word count (the grouped
+    pass relies on the padding bits and the pad word of rows and queries being zero)."""
+    rng = np.random.default_rng(77)
+    for d in (150, 65, 129, 200, 1):
+        n = 17_000
+        x, ids = make_corpus(n, d, 4300 + d, False, oracle_mod, tie_block=30)
+        g = GpuIndex(nifs, 0)
+        unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+        qs = rng.uniform(-1, 1, (8, d)).astype(np.float32)
+        qs[1] = -np.abs(qs[1])            # every sign bit clear
+        qs[2] = np.abs(qs[2])             # every sign bit set
+        got = unwrap(nifs.flat_quantized_search_batch(g.ref, qs, 64, 10))
+        sign = x >= 0
+        for i in range(8):
+            assert bits(got[i]) == bits(unwrap(nifs.flat_quantized_search(g.ref, qs[i], 64, 10))), (d, i)
+            ham = (sign != (qs[i] >= 0)[None, :]).sum(axis=1)
+            order = sorted(range(n), key=lambda r: (int(ham[r]), ids[r]))[:64]
+            want = oracle_mod.vector_top_k([(ids[r], x[r]) for r in order], qs[i], 0, d, 10)
+            assert bits(got[i]) == bits(want), (d, i)
+
+
 @pytest.mark.parametrize("metric", [2, 0, 3, 5, 8])
 def test_quantized_search_batch_equals_single_calls(nifs, oracle_mod, metric):
     """vt_flat_quantized_search_batch: groups of up to eight queries share ONE sweep of the sign

@@ -639,9 +639,12 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_dist_multi_kern
     uint32_t ham[kHammingMultiMax];
     typedef const __attribute__((address_space(4))) uint32_t *cu32_p;
     if (PAIRS > 0) {
+      // (no masking of the last word here: the matrix's padding bits and pad word are zero by
+      // construction -- sign_pack writes bits j < d only, into zeroed words -- and so are the query's,
+      // so they contribute nothing to the xor; the masks were 36 of ~600 vector instructions per tile)
       u64x2 v[PAIRS > 0 ? PAIRS : 1];
 #pragma unroll
-      for (int j = 0; j < PAIRS; ++j) v[j] = row_words(j);
+      for (int j = 0; j < PAIRS; ++j) v[j] = __builtin_nontemporal_load(base + (size_t)j * kWave);
 #pragma unroll
       for (uint32_t q = 0; q < kHammingMultiMax; ++q) {
         uint64_t qaddr = (uint64_t)(uintptr_t)a.qbits + (uint64_t)q * 2 * PAIRS * 8;
