@@ -439,17 +439,21 @@ def run_side_mode(a, torch, nifs, device):
     print(json.dumps(out))
 
 
-def concurrent_callers(a, L, nifs, ref, threads, seconds, quantized=0):
+def concurrent_callers(a, L, nifs, ref, threads, seconds, quantized=0, funnel=0):
     """`threads` callers searching ONE handle at the same time (what BEAM dirty schedulers do under
     the reference's read lock, nifs.rs:297-309): the library lets searches that meet travel as one
     batch.  Every answer is compared with the one the same query gets alone.  quantized = c > 0:
-    the callers run quantized_search(candidates: c) instead (collection.ex:276-295)."""
+    the callers run quantized_search(candidates: c) instead (collection.ex:276-295); funnel = p > 0:
+    funnel_search(stages: [p], candidates: 100) (collection.ex:245-260)."""
     import threading
     qs = normalized_queries(64, a.dim, SEED_QUERY + 9)
     hp = C.c_void_p()
+    stages = (C.c_size_t * 1)(funnel)
 
     def one(q, h):
         qp = q.ctypes.data_as(C.POINTER(C.c_float))
+        if funnel:
+            return L.vt_flat_funnel_search(ref.handle, qp, a.dim, stages, 1, 100, a.limit, C.byref(h))
         if quantized:
             return L.vt_flat_quantized_search(ref.handle, qp, a.dim, quantized, a.limit, C.byref(h))
         return L.vt_flat_search(ref.handle, qp, a.dim, a.limit, C.byref(h))
@@ -515,6 +519,10 @@ def side_legs(a, torch, nifs, L, device, main_ref):
     side["callers_quantized"] = {"workload": "quantized_search candidates=100 limit=%d, d=%d, N=%d, T threads on one handle"
                                              % (a.limit, a.dim, a.rows),
                                  "runs": [concurrent_callers(a, L, nifs, main_ref, t, 1.0, quantized=100) for t in (1, 8, 64)]}
+    # ... and funnel_search callers: up to eight share the sweep of the prefixes
+    side["callers_funnel"] = {"workload": "funnel_search stages=[%d] candidates=100 limit=%d, d=%d, N=%d, T threads on one handle"
+                                          % (min(a.dim, 128), a.limit, a.dim, a.rows),
+                              "runs": [concurrent_callers(a, L, nifs, main_ref, t, 1.0, funnel=min(a.dim, 128)) for t in (1, 8, 64)]}
     # config 2: flat cosine top-10, N = 1M, single query
     rows2 = min(1_000_000, a.rows)
     x = build_shard(torch, device, rows2, a.dim, SEED_CORPUS + 2)

@@ -254,6 +254,13 @@ int vt_flat_quantized_search_batch(vt_flat *index, const float *queries, size_t 
 int vt_flat_funnel_search(vt_flat *index, const float *query, size_t n,
                           const size_t *stages, size_t nstages, size_t candidates,
                           size_t limit, vt_hits **out);
+/* `nq` funnel searches with one set of stages (queries of `d` floats back to back), out[i] = query
+ * i's hits -- identical to nq vt_flat_funnel_search calls.  On a cosine collection groups of up to
+ * eight share ONE sweep of the rows' first stages[0] coordinates (candidates <= 256); anything else
+ * runs query by query. */
+int vt_flat_funnel_search_batch(vt_flat *index, const float *queries, size_t nq, size_t d,
+                                const size_t *stages, size_t nstages, size_t candidates,
+                                size_t limit, vt_hits **out);
 
 /* hybrid_search with rerank: :exact, lib/vettore/collection.ex:325-345, :515-592:
  * the union (first occurrence wins) of the candidate sets of `ngen` generators,
@@ -340,6 +347,7 @@ typedef struct vt_profile {
   uint64_t nominate_candidates;   /* rows handed to the exact rescoring, summed over queries */
   uint64_t hamming_queries;       /* queries served by grouped Hamming passes (0 for single-query passes) */
   uint64_t hybrid_device_chains;  /* hybrid searches whose generators, union and rerank ran as one device chain (one host wait) */
+  uint64_t prefix_queries;        /* queries served by grouped prefix scans (0 for single-query funnel searches) */
 } vt_profile;
 int vt_flat_set_profiling(vt_flat *index, int enabled);
 int vt_flat_get_profile(vt_flat *index, vt_profile *out, int reset);

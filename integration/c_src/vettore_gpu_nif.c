@@ -386,6 +386,31 @@ static ERL_NIF_TERM flat_funnel_search(ErlNifEnv *env, int argc, const ERL_NIF_T
   return st == VT_OK ? ok_hits(env, h) : mk_error(env, st);
 }
 
+/* flat_funnel_search_batch(ref, [[float]], [stage], candidates, limit) -> {:ok, [[{id, raw}]]}: B x
+ * funnel_search with one set of stages; on a cosine collection groups of up to eight share the
+ * stage-1 sweep of the prefixes */
+static ERL_NIF_TERM flat_funnel_search_batch(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  flat_res *r = get_flat(env, argv[0]);
+  unsigned nq;
+  size_t candidates, limit, d, nst, *stages;
+  float *qs;
+  int st;
+  (void)argc;
+  if (!r || !enif_get_list_length(env, argv[1], &nq) || !get_size(env, argv[3], &candidates) || !get_size(env, argv[4], &limit))
+    return enif_make_badarg(env);
+  if (nq == 0) return enif_make_tuple2(env, mk_atom(env, "ok"), enif_make_list(env, 0));
+  if (!get_size_list(env, argv[2], &stages, &nst)) return enif_make_badarg(env);
+  if (!get_f32_matrix(env, argv[1], nq, &qs, &d, &st)) { free(stages); return enif_make_badarg(env); }
+  if (st != VT_OK) { free(stages); return mk_error(env, st); }
+  vt_hits **out = (vt_hits **)calloc(nq, sizeof(vt_hits *));
+  st = out ? vt_flat_funnel_search_batch(r->h, qs, nq, d, stages, nst, candidates, limit, out) : VT_ERR_NOMEM;
+  free(qs); free(stages);
+  if (st != VT_OK) { free(out); return mk_error(env, st); }
+  ERL_NIF_TERM res = hit_lists(env, out, nq);
+  free(out);
+  return res;
+}
+
 /* flat_hybrid_search(ref, [float], [{kind, candidates, [stage]}], limit)   collection.ex:325-345, :515-592
  * kind: 0 funnel, 1 quantized, 2 search; rerank: :exact */
 static ERL_NIF_TERM flat_hybrid_search(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
@@ -589,6 +614,7 @@ static ErlNifFunc funcs[] = {
   {"flat_search_batch", 3, flat_search_batch, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"flat_quantized_search", 4, flat_quantized_search, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"flat_quantized_search_batch", 4, flat_quantized_search_batch, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"flat_funnel_search_batch", 5, flat_funnel_search_batch, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"flat_funnel_search", 5, flat_funnel_search, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"flat_hybrid_search", 4, flat_hybrid_search, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"normalize_l2", 1, normalize_l2, ERL_NIF_DIRTY_JOB_IO_BOUND},

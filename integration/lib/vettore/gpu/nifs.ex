@@ -24,6 +24,7 @@ defmodule Vettore.Gpu.Nifs do
   def flat_search_batch(_ref, _queries, _limit), do: :erlang.nif_error(:nif_not_loaded)
   def flat_quantized_search(_ref, _query, _candidates, _limit), do: :erlang.nif_error(:nif_not_loaded)
   def flat_quantized_search_batch(_ref, _queries, _candidates, _limit), do: :erlang.nif_error(:nif_not_loaded)
+  def flat_funnel_search_batch(_ref, _queries, _stages, _candidates, _limit), do: :erlang.nif_error(:nif_not_loaded)
   def flat_funnel_search(_ref, _query, _stages, _candidates, _limit), do: :erlang.nif_error(:nif_not_loaded)
   def flat_hybrid_search(_ref, _query, _generators, _limit), do: :erlang.nif_error(:nif_not_loaded)
   def normalize_l2(_vector), do: :erlang.nif_error(:nif_not_loaded)

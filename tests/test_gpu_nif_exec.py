@@ -250,6 +250,10 @@ def test_oracle_parity_5000x384_and_the_staged_searches(rt, oracle_mod):
     assert [bits(h) for h in grouped] == [bits(ok(rt.call("flat_quantized_search", ref3, v, 100, 10))) for v in q3]
     assert rt.call("flat_quantized_search_batch", ref3, [], 100, 10) == (OK, [])
     assert rt.call("flat_quantized_search_batch", ref3, [q3[0], [1.0]], 100, 10) == (ERROR, b"dimension mismatch")
+    grouped = ok(rt.call("flat_funnel_search_batch", ref3, q3, [16, 32], 100, 10))
+    assert [bits(h) for h in grouped] == [bits(ok(rt.call("flat_funnel_search", ref3, v, [16, 32], 100, 10))) for v in q3]
+    assert rt.call("flat_funnel_search_batch", ref3, [], [16], 100, 10) == (OK, [])
+    assert rt.call("flat_funnel_search_batch", ref3, q3, [65], 100, 10) == (ERROR, b"invalid prefix dimensions")
     ref3.release()
     gens = [(0, 50, [64]), (1, 60, []), (2, 20, [])]
     assert bits(ok(rt.call("flat_hybrid_search", ref, FloatList(q), gens, 10))) == \

@@ -1421,6 +1421,98 @@ def test_quantized_search_batch_equals_single_calls(nifs, oracle_mod, metric):
     assert unwrap(nifs.flat_quantized_search_batch(g.ref, qs[:3], 5, 0)) == [[]] * 3
 
 
+def test_funnel_search_batch_equals_single_calls(nifs, oracle_mod):
+    """vt_flat_funnel_search_batch: on a cosine collection groups of up to eight queries share ONE
+    sweep of the rows' prefixes (cosine_scan_multi_kernel: exact f64 cosines, a sampled threshold,
+    per-query lists, batched select), later stages and the exact rerank run with the queries on
+    grid.y; each query's hits must equal its own funnel_search AND the oracle's composition
+    (vector_top_k on each prefix, then on the full vectors; collection.ex:245-260) bit for bit.
+    Other metrics, long prefixes and large candidate counts take the calls one by one."""
+    n, d = 30_000, 160
+    x, ids = make_corpus(n, d, 4500, True, oracle_mod, tie_block=300)
+    g = GpuIndex(nifs, 2)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rows = [(ids[i], x[i]) for i in range(n)]
+    by_id = dict(rows)
+    rng = np.random.default_rng(21)
+    nifs.flat_set_profiling(g.ref, True)
+    for nq, stages, cand, limit in ((2, [32], 100, 10), (8, [64, 128], 60, 10), (17, [16], 256, 30), (5, [160], 7, 7),
+                                    (9, [8, 24, 96], 40, 100), (3, [1], 50, 5)):
+        qs = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+        qs[0] = x[n // 2]                                    # inside the block of identical rows
+        qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+        if nq >= 5:
+            qs[3, :stages[0]] = 0.0                          # a zero prefix: every stage-1 cosine is 0
+        nifs.flat_get_profile(g.ref, reset=True)
+        got = unwrap(nifs.flat_funnel_search_batch(g.ref, qs, stages, cand, limit))
+        prof = nifs.flat_get_profile(g.ref, reset=True)
+        assert len(got) == nq
+        assert prof["prefix_queries"] >= nq - 1 - (1 if nq >= 5 else 0), (nq, prof)   # (a lone last query goes alone; the zero prefix may)
+        for i in range(nq):
+            assert bits(got[i]) == bits(unwrap(nifs.flat_funnel_search(g.ref, qs[i], stages, cand, limit))), (nq, stages, i)
+        for i in (0, nq - 1):
+            cur = rows
+            for st in stages:
+                kept = oracle_mod.vector_top_k(cur, qs[i], 2, st, cand)
+                cur = [(j, by_id[j]) for j, _ in kept]
+            want = oracle_mod.vector_top_k(cur, qs[i], 2, d, limit)
+            assert bits(got[i]) == bits(want), (nq, stages, cand, limit, i)
+    # validation and empty cases follow funnel_search
+    assert nifs.flat_funnel_search_batch(g.ref, qs[:3], [0], 10, 5) == ("error", "invalid prefix dimensions")
+    assert nifs.flat_funnel_search_batch(g.ref, qs[:3], [d + 1], 10, 5) == ("error", "invalid prefix dimensions")
+    assert nifs.flat_funnel_search_batch(g.ref, qs[:3], [], 10, 5) == ("error", "invalid prefix dimensions")
+    assert nifs.flat_funnel_search_batch(g.ref, np.zeros((3, d + 1), np.float32), [4], 10, 5) == ("error", "dimension mismatch")
+    assert unwrap(nifs.flat_funnel_search_batch(g.ref, qs[:3], [4], 0, 5)) == [[]] * 3
+    assert unwrap(nifs.flat_funnel_search_batch(g.ref, qs[:3], [4], 5, 0)) == [[]] * 3
+    # another metric: query by query, same answers
+    g0 = GpuIndex(nifs, 0)
+    unwrap(nifs.flat_load_matrix(g0.ref, ids, x))
+    qs = rng.uniform(-1, 1, (4, d)).astype(np.float32)
+    got = unwrap(nifs.flat_funnel_search_batch(g0.ref, qs, [32, 64], 50, 10))
+    for i in range(4):
+        assert bits(got[i]) == bits(unwrap(nifs.flat_funnel_search(g0.ref, qs[i], [32, 64], 50, 10)))
+
+
+def test_concurrent_funnel_callers_share_sweeps(nifs, oracle_mod, monkeypatch):
+    """funnel_search callers that meet on one cosine handle travel in groups -- only those with the
+    same stages and candidates together; every answer equals the call made alone."""
+    import threading
+    monkeypatch.setenv("VT_COALESCE_SLOTS", "1")
+    n, d = 40_000, 128
+    x, ids = make_corpus(n, d, 4600, True, oracle_mod)
+    g = GpuIndex(nifs, 2)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(13)
+    qs = np.stack([oracle_mod.normalize_l2(q) for q in rng.uniform(-1, 1, (32, d)).astype(np.float32)])
+    shapes = [([32], 100), ([16, 64], 100), ([32], 50)]
+    alone = [[bits(unwrap(nifs.flat_funnel_search(g.ref, q, st, cand, 10))) for q in qs] for st, cand in shapes]
+    plain = [bits(unwrap(nifs.flat_search(g.ref, q, 10))) for q in qs]
+    wrong, b0 = [], nifs.flat_coalesce_stats(g.ref)
+
+    def worker(t):
+        for r in range(40):
+            j = (t * 7 + r) % 32
+            kind = (t + r) % 4
+            if kind == 3:
+                res = bits(unwrap(nifs.flat_search(g.ref, qs[j], 10))) == plain[j]
+            else:
+                st, cand = shapes[kind]
+                res = bits(unwrap(nifs.flat_funnel_search(g.ref, qs[j], st, cand, 10))) == alone[kind][j]
+            if not res:
+                wrong.append((t, r, kind))
+        # errors keep their own order and text
+        assert nifs.flat_funnel_search(g.ref, qs[0], [d + 1], 10, 5) == ("error", "invalid prefix dimensions")
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    b1 = nifs.flat_coalesce_stats(g.ref)
+    assert not wrong, wrong[:5]
+    print("coalesced: %d batches, %d calls in batches" % (b1[0] - b0[0], b1[1] - b0[1]))
+
+
 def test_quantized_groups_with_massive_ties_fall_back(nifs, oracle_mod):
     """Rows drawn from two sign patterns: thousands of ties at the k-th Hamming distance, more than a
     group's per-query list holds -- the group hands over to the single-query path, same answers."""

@@ -27,7 +27,7 @@ SYMBOLS = [
     "vt_flat_route_ids", "vt_flat_set_exchange", "vt_flat_exchange", "vt_flat_exchange_note", "vt_flat_rccl_ranks", "vt_flat_free", "vt_flat_insert", "vt_flat_insert_many", "vt_flat_delete",
     "vt_flat_search", "vt_flat_search_batch", "vt_flat_len", "vt_flat_dimension", "vt_flat_metric",
     "vt_flat_set_reduce_order", "vt_set_default_reduce_order", "vt_flat_set_batch_nominate", "vt_flat_batch_nominate",
-    "vt_flat_load_matrix", "vt_flat_load_device_matrix", "vt_flat_quantized_search", "vt_flat_quantized_search_batch", "vt_flat_funnel_search", "vt_flat_hybrid_search",
+    "vt_flat_load_matrix", "vt_flat_load_device_matrix", "vt_flat_quantized_search", "vt_flat_quantized_search_batch", "vt_flat_funnel_search", "vt_flat_funnel_search_batch", "vt_flat_hybrid_search",
     "vt_rank_ids", "vt_flat_set_id_ranks", "vt_flat_stream", "vt_flat_search_begin", "vt_flat_merge_gathered",
     "vt_vector_top_k", "vt_binary_top_k", "vt_normalize_l2", "vt_compress_sign_bits",
     "vt_flat_set_profiling", "vt_flat_get_profile",
@@ -47,6 +47,7 @@ class Profile(C.Structure):
         ("nominate_second_passes", C.c_uint64), ("nominate_candidates", C.c_uint64),
         ("hamming_queries", C.c_uint64),
         ("hybrid_device_chains", C.c_uint64),
+        ("prefix_queries", C.c_uint64),
     ]
 
 
@@ -123,6 +124,7 @@ def load() -> C.CDLL:
     L.vt_flat_quantized_search.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.vt_flat_quantized_search_batch.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.vt_flat_funnel_search.argtypes = [vp, f32p, C.c_size_t, szp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.vt_flat_funnel_search_batch.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, szp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.vt_flat_hybrid_search.argtypes = [vp, f32p, C.c_size_t, C.POINTER(C.c_int), szp, szp, szp, C.c_size_t, C.c_size_t,
                                         C.POINTER(vp)]
     u32p = C.POINTER(C.c_uint32)

@@ -967,6 +967,192 @@ int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *
 }
 
 
+// ---- several funnel searches per sweep of the prefixes (cosine collections) ------------------
+// collection.ex:245-260 for up to kCosineMultiMax queries at once, the way quantized searches share
+// a sweep of the sign bits: stage 1 -- the f64 cosine over the first stages[0] coordinates of
+// EVERY row, 0.8 ms of a 0.88-ms funnel search at N = 10 M -- reads the prefixes once for the whole
+// group (cosine_scan_multi_kernel).  The scores are exact, so a threshold needs no margin: tau_q =
+// the rank-th best score of a sample of the rows (~6 x candidates rows pass), every (query, row)
+// reaching it is listed, the lists are cut to their `candidates` best by the batched select, and
+// a query whose list came out short (or overflowed) takes the single path.  Later stages and the
+// exact rerank run once with the queries on grid.y (cosine_rerank_kernel); one wait.  Each
+// query's hits are what its own funnel_search returns, bit for bit.
+bool funnel_group_applies(const Shard *ix, const size_t *stages, size_t nstages, size_t candidates, size_t limit) {
+  if (ix->metric != VT_COSINE || nstages == 0 || std::getenv("VT_NO_FUNNEL_GROUPS")) return false;
+  const size_t k1 = std::min<size_t>(candidates, ix->n);
+  if (ix->n < 16384 || k1 == 0 || k1 > (size_t)vt::kMaxFusedK || limit == 0) return false;
+  return (size_t)2 * (((size_t)ix->dim + 3) / 4 * 4) * 4 <= 160 * 1024;  // the rerank keeps row + query in LDS
+}
+
+int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size_t> &which, const size_t *stages,
+                 size_t nstages, size_t candidates, size_t limit, vt_hits **out, std::vector<char> &done) {
+  const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
+  const uint32_t nq = (uint32_t)which.size();
+  const uint32_t d1 = (uint32_t)stages[0], ldq = vt::padded_dim(d1);
+  const uint32_t k1 = (uint32_t)std::min<size_t>(candidates, n);
+  const uint32_t k2 = (uint32_t)std::min<size_t>(limit, k1);
+  constexpr uint32_t kListCap = 8192, kSampleTiles = 1024;
+  const uint32_t ntiles = (n + 63) / 64;
+  const uint32_t sstride = (ntiles + kSampleTiles - 1) / kSampleTiles;
+  const uint32_t stiles = (ntiles + sstride - 1) / sstride;
+  const uint32_t sample_rows = stiles * 64;
+  // about six lists' worth of rows pass (the count is Gamma(rank)-distributed around its mean:
+  // at rank >= 6 a list shorter than `candidates` is a 1e-4 event; it costs a single search)
+  uint32_t rank = (uint32_t)std::ceil(6.0 * k1 * std::min(1.0, (double)sample_rows / (double)n));
+  rank = std::max<uint32_t>(6, std::min<uint32_t>(rank, std::min<uint32_t>(sample_rows, n)));
+  // one upload: full queries [nq][ld] (f32), their prefixes as f64 [8][ldq] (what stage 1 reads, through
+  // the scalar cache; ld and ldq are multiples of 64, so the block stays 32-byte aligned), list lengths
+  const size_t q_floats = (size_t)nq * ld, p_floats = (size_t)vt::kCosineMultiMax * ldq * 2;
+  const size_t up_floats = q_floats + p_floats + vt::kCosineMultiMax;
+  VT_TRY(c.dBQ.ensure(up_floats));
+  VT_TRY(c.hBQ.ensure(up_floats));
+  VT_TRY(c.dBSample.ensure((size_t)vt::kCosineMultiMax * sample_rows));
+  VT_TRY(c.dBTau.ensure(vt::kCosineMultiMax));
+  VT_TRY(c.dBCount.ensure(vt::kCosineMultiMax));
+  VT_TRY(c.dPartKeys.ensure((size_t)nq * kListCap));
+  VT_TRY(c.dPartPay.ensure((size_t)nq * kListCap));
+  VT_TRY(c.dStageB.ensure(nq));
+  VT_TRY(c.dCandKeys.ensure((size_t)nq * k1));
+  VT_TRY(c.dCandPay.ensure((size_t)nq * k1));
+  const size_t res_bytes = (size_t)vt::kHammingMultiMax * vt::kMaxFusedK * sizeof(vt::Entry) + 128;
+  if (!c.dBigMapped || c.hBig.count < res_bytes) {
+    VT_TRY(c.hBig.ensure(std::max<size_t>(res_bytes, 16 + (size_t)vt::kSelListMax * sizeof(vt::Entry))));
+    VT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&c.dBigMapped), c.hBig.p, 0));
+  }
+  const size_t ent_bytes = (size_t)nq * k2 * sizeof(vt::Entry);
+  vt::Entry *dOut = reinterpret_cast<vt::Entry *>(c.dBigMapped);
+  uint32_t *dOutCount = reinterpret_cast<uint32_t *>(c.dBigMapped + ent_bytes);
+  const vt::Entry *hOut = reinterpret_cast<const vt::Entry *>(c.hBig.p);
+  const uint32_t *hOutCount = reinterpret_cast<const uint32_t *>(c.hBig.p + ent_bytes);
+  int *hStatus = reinterpret_cast<int *>(c.hBig.p + ent_bytes + 32);
+  uint32_t *hListCount = reinterpret_cast<uint32_t *>(c.hBig.p + ent_bytes + 64);  // [8]: rows that reached tau
+  std::memset(c.hBQ.p, 0, up_floats * sizeof(float));
+  vt::CosineScanMultiArgs a{};
+  uint32_t *hcounts = reinterpret_cast<uint32_t *>(c.hBQ.p + q_floats + p_floats);
+  for (uint32_t i = 0; i < nq; ++i) {
+    const float *q = queries + which[i] * d;
+    std::memcpy(c.hBQ.p + (size_t)i * ld, q, (size_t)d * sizeof(float));
+    double *qd = reinterpret_cast<double *>(c.hBQ.p + q_floats) + (size_t)i * ldq;
+    double qq = 0.0;  // f64_dot(q, q) over the prefix (distances.rs:179-185)
+    for (uint32_t j = 0; j < d1; ++j) {
+      qd[j] = (double)q[j];
+      qq += (double)q[j] * (double)q[j];
+    }
+    a.qq[i] = qq;
+    hcounts[i] = k1;
+  }
+  VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, up_floats * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  const uint32_t *dcounts = reinterpret_cast<const uint32_t *>(c.dBQ.p + q_floats + p_floats);
+  VT_HIP(hipMemsetAsync(c.dBCount.p, 0, vt::kCosineMultiMax * sizeof(uint32_t), c.stream));
+  a.X = ix->dX;
+  a.stride = ix->ld;
+  a.Qd = reinterpret_cast<const double *>(c.dBQ.p + q_floats);
+  a.id_rank = ix->dRank.p;
+  a.n = n;
+  a.d = d1;
+  a.nq = nq;
+  a.status = c.dStatus.p;
+  const size_t lds = vt::cosine_scan_multi_lds_bytes();
+  // pass 0: the sample's scores -> one threshold per query
+  a.sample = c.dBSample.p;
+  a.sample_stride = sstride;
+  a.sample_rows = sample_rows;
+  VT_HIP(vt::launch_cosine_scan_multi(a, c.grid_for(stiles, lds), c.stream));
+  VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, vt::kCosineMultiMax, nq, rank, c.dBTau.p, c.stream));
+  // pass 1: every row's prefix once; (query, row) pairs at or above the thresholds into the lists
+  a.sample = nullptr;
+  a.tau = c.dBTau.p;
+  a.cand_keys = c.dPartKeys.p;
+  a.cand_pay = c.dPartPay.p;
+  a.cand_count = c.dBCount.p;
+  a.cand_cap = kListCap;
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+  VT_HIP(vt::launch_cosine_scan_multi(a, c.grid_for(ntiles, lds), c.stream));
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+  VT_HIP(hipMemcpyAsync(hListCount, c.dBCount.p, vt::kCosineMultiMax * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(vt::launch_select_lists(c.dPartKeys.p, c.dPartPay.p, nq, kListCap, c.dBCount.p, k1, c.dStageB.p,
+                                 (uint32_t)sizeof(ResultBlock), c.stream));
+  // later stages re-score the same candidates on a longer prefix (collection.ex:674-691), then
+  // exact_rerank on the full vectors (collection.ex:821-851): the queries on grid.y
+  vt::CosineRerankArgs r{};
+  r.X = ix->dX;
+  r.stride = ix->ld;
+  r.q = c.dBQ.p;
+  r.id_rank = ix->dRank.p;
+  r.gather = &c.dStageB.p->e[0].row;
+  r.gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
+  r.n = k1;
+  r.out_keys = c.dCandKeys.p;
+  r.out_pay = c.dCandPay.p;
+  r.status = c.dStatus.p;
+  r.q_stride = ld;
+  r.gather_qstride = (uint32_t)(sizeof(ResultBlock) / sizeof(uint32_t));
+  for (size_t i = 1; i < nstages; ++i) {
+    r.d = (uint32_t)stages[i];
+    VT_HIP(vt::launch_cosine_rerank_batch(r, nq, c.stream));
+    VT_HIP(vt::launch_select_lists(c.dCandKeys.p, c.dCandPay.p, nq, k1, dcounts, k1, c.dStageB.p, (uint32_t)sizeof(ResultBlock),
+                                   c.stream));
+  }
+  r.d = d;
+  VT_HIP(vt::launch_cosine_rerank_batch(r, nq, c.stream));
+  VT_HIP(vt::launch_batch_select(c.dCandKeys.p, c.dCandPay.p, nq, k1, k2, dOut, dOutCount, c.stream));
+  VT_HIP(hipMemcpyAsync(hStatus, c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));  // (pinned: stays asynchronous)
+  VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  if (c.profiling) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    c.prof.prefix_launches += 1;
+    c.prof.prefix_ms += ms;
+    c.prof.prefix_bytes += (uint64_t)n * d1 * 4;
+    c.prof.prefix_queries += nq;
+  }
+  if (*hStatus != 0) return kRetryInternal;  // an overflow somewhere: one by one, each reports its own
+  for (uint32_t i = 0; i < nq; ++i) {
+    if (hListCount[i] < k1 || hListCount[i] > kListCap) continue;  // the threshold missed: this one takes the single path
+    const uint32_t got = std::min<uint32_t>(hOutCount[i], k2);
+    std::vector<vt::Entry> entries(hOut + (size_t)i * k2, hOut + (size_t)i * k2 + got);
+    VT_TRY(make_hits(ix, entries, &out[which[i]]));
+    done[which[i]] = 1;
+  }
+  return VT_OK;
+}
+
+// funnel_search for nq queries (rows of `queries`) with one set of stages: groups of up to eight
+// share the stage-1 sweep; what the groups cannot take goes through funnel_ready one by one.
+int funnel_batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, const size_t *stages, size_t nstages,
+                       size_t candidates, size_t limit, vt_hits **out) {
+  for (size_t i = 0; i < nq; ++i) VT_TRY(validate_vector(queries + i * d, d, ix->dim));
+  if (nstages == 0) return VT_ERR_PREFIX;
+  for (size_t i = 0; i < nstages; ++i)
+    if (stages[i] == 0 || stages[i] > d) return VT_ERR_PREFIX;
+  if (ix->n == 0 || candidates == 0 || limit == 0) {
+    for (size_t i = 0; i < nq; ++i) VT_TRY(empty_hits(&out[i]));
+    return VT_OK;
+  }
+  std::vector<char> done(nq, 0);
+  if (nq >= 2 && funnel_group_applies(ix, stages, nstages, candidates, limit)) {
+    for (size_t g0 = 0; g0 < nq; g0 += vt::kCosineMultiMax) {
+      std::vector<size_t> which;
+      for (size_t i = g0; i < std::min<size_t>(nq, g0 + vt::kCosineMultiMax); ++i) which.push_back(i);
+      if (which.size() < 2) break;
+      const int st = funnel_group(ix, c, queries, which, stages, nstages, candidates, limit, out, done);
+      if (st == kRetryInternal) {
+        for (size_t i : which) {
+          delete out[i];
+          out[i] = nullptr;
+          done[i] = 0;
+        }
+      } else if (st != VT_OK) {
+        return st;
+      }
+    }
+  }
+  for (size_t i = 0; i < nq; ++i)
+    if (!done[i]) VT_TRY(funnel_ready(ix, c, queries + i * d, d, stages, nstages, candidates, limit, &out[i]));
+  return VT_OK;
+}
+
 // ---- hybrid_search as ONE device chain --------------------------------------------------------
 // collection.ex:325-345 when every generator keeps at most kMaxFusedK candidates: each generator
 // ends in a device block (funnel stages chained like funnel_ready's, K4h / K4 for the quantized

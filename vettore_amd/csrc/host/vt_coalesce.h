@@ -31,7 +31,13 @@ bool coalescing_enabled() {
   return !(e && e[0] == '0');
 }
 
-enum { COALESCE_SEARCH = 0, COALESCE_QUANTIZED = 1 };  // vt_host::Waiting::kind (aux = candidates)
+// vt_host::Waiting::kind; aux = candidates (quantized) / index into the handle's funnel shapes (funnel)
+enum { COALESCE_SEARCH = 0, COALESCE_QUANTIZED = 1, COALESCE_FUNNEL = 2 };
+
+vt_flat::FunnelShape funnel_shape(vt_flat *h, size_t index) {
+  std::lock_guard<std::mutex> g(h->funnel_mu);
+  return h->funnel_shapes[index];
+}
 
 struct CoalesceOps {
   static constexpr int kOutOfMemory = VT_ERR_NOMEM;
@@ -39,6 +45,10 @@ struct CoalesceOps {
   static unsigned slots(vt_flat *h) { return coalesce_slots(h->approx_bytes.load(std::memory_order_relaxed)); }
   static int search_direct(vt_flat *h, int kind, size_t aux, const float *query, size_t n, size_t limit, vt_hits **out) {
     if (kind == COALESCE_QUANTIZED) return quantized_direct(h, query, n, aux, limit, out);
+    if (kind == COALESCE_FUNNEL) {
+      const vt_flat::FunnelShape f = funnel_shape(h, aux);
+      return funnel_direct(h, query, n, f.stages.data(), f.stages.size(), f.candidates, limit, out);
+    }
     return ::search_direct(h, query, n, limit, out);
   }
   static void search_alone(vt_flat *h, vt_host::Waiting *w) {
@@ -61,6 +71,10 @@ struct CoalesceOps {
   }
   static int batch(vt_flat *h, int kind, size_t aux, const float *queries, size_t nq, size_t n, size_t limit, vt_hits **outs) {
     if (kind == COALESCE_QUANTIZED) return quantized_batch_direct(h, queries, nq, n, aux, limit, outs);
+    if (kind == COALESCE_FUNNEL) {
+      const vt_flat::FunnelShape f = funnel_shape(h, aux);
+      return funnel_batch_direct(h, queries, nq, n, f.stages.data(), f.stages.size(), f.candidates, limit, outs);
+    }
     return batch_direct(h, queries, nq, n, limit, outs);
   }
   // a batch needs strictly current id ranks; a lone search after unsorted inserts does not
@@ -85,6 +99,29 @@ int coalesced_quantized(vt_flat *h, const float *query, size_t n, size_t candida
   if (limit == 0 || candidates == 0 || candidates > (size_t)vt::kMaxFusedK || n == 0 || h->multi() || !coalescing_enabled())
     return quantized_direct(h, query, n, candidates, limit, out);
   return vt_host::coalesced_search_t<vt_flat, CoalesceOps>(h, query, n, limit, out, COALESCE_QUANTIZED, candidates);
+}
+
+// funnel_search callers that meet on a cosine handle share the stage-1 sweep of the prefixes
+// (funnel_group): only callers with the same stages and candidates travel together
+int coalesced_funnel(vt_flat *h, const float *query, size_t n, const size_t *stages, size_t nstages, size_t candidates,
+                     size_t limit, vt_hits **out) {
+  bool plain = limit == 0 || candidates == 0 || candidates > (size_t)vt::kMaxFusedK || n == 0 || nstages == 0 || nstages > 16 ||
+               h->multi() || !coalescing_enabled() || h->shards[0]->metric != VT_COSINE;
+  for (size_t i = 0; i < nstages && !plain; ++i) plain = stages[i] == 0 || stages[i] > n;  // (its own error, in its own order)
+  size_t shape = 0;
+  if (!plain) {
+    std::lock_guard<std::mutex> g(h->funnel_mu);
+    for (; shape < h->funnel_shapes.size(); ++shape) {
+      const vt_flat::FunnelShape &f = h->funnel_shapes[shape];
+      if (f.candidates == candidates && f.stages.size() == nstages && std::equal(stages, stages + nstages, f.stages.begin())) break;
+    }
+    if (shape == h->funnel_shapes.size()) {
+      if (shape >= 64) plain = true;  // (a handle asked for more shapes than anyone coalesces over)
+      else h->funnel_shapes.push_back(vt_flat::FunnelShape{std::vector<size_t>(stages, stages + nstages), candidates});
+    }
+  }
+  if (plain) return funnel_direct(h, query, n, stages, nstages, candidates, limit, out);
+  return vt_host::coalesced_search_t<vt_flat, CoalesceOps>(h, query, n, limit, out, COALESCE_FUNNEL, shape);
 }
 
 }  // namespace

@@ -760,6 +760,46 @@ int quantized_batch_direct(vt_flat *h, const float *queries, size_t nq, size_t d
   return st;
 }
 
+// funnel_search on any handle.
+int funnel_direct(vt_flat *h, const float *query, size_t n, const size_t *stages, size_t nstages, size_t candidates,
+                  size_t limit, vt_hits **out) {
+  *out = nullptr;
+  if (h->multi()) {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    if (h->poisoned) return poisoned_status();
+    return funnel_multi(h, query, n, stages, nstages, candidates, limit, out);
+  }
+  return read_single(h, NEED_STRICT_RANKS, limit, [&](Shard *ix, Ctx &c) -> int {
+    return funnel_ready(ix, c, query, n, stages, nstages, candidates, limit, out);
+  });
+}
+
+// funnel_search for nq queries with one set of stages (vt_flat_funnel_search_batch).
+int funnel_batch_direct(vt_flat *h, const float *queries, size_t nq, size_t d, const size_t *stages, size_t nstages,
+                        size_t candidates, size_t limit, vt_hits **out) {
+  for (size_t i = 0; i < nq; ++i) out[i] = nullptr;
+  int st = VT_OK;
+  if (h->multi()) {
+    std::shared_lock<std::shared_mutex> rl(h->rw);
+    if (h->poisoned) return poisoned_status();
+    for (size_t i = 0; i < nq && st == VT_OK; ++i) st = funnel_multi(h, queries + i * d, d, stages, nstages, candidates, limit, &out[i]);
+  } else {
+    st = read_single(h, NEED_STRICT_RANKS, limit, [&](Shard *ix, Ctx &c) -> int {
+      for (size_t i = 0; i < nq; ++i) {  // (a second run after an escalation starts clean)
+        delete out[i];
+        out[i] = nullptr;
+      }
+      return funnel_batch_ready(ix, c, queries, nq, d, stages, nstages, candidates, limit, out);
+    });
+  }
+  if (st != VT_OK)
+    for (size_t i = 0; i < nq; ++i) {
+      delete out[i];
+      out[i] = nullptr;
+    }
+  return st;
+}
+
 // flat_search_batch: nq queries of d floats, one hit list each, or one status for all.
 int batch_direct(vt_flat *h, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
   for (size_t i = 0; i < nq; ++i) out[i] = nullptr;

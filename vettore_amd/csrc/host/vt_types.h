@@ -303,6 +303,14 @@ struct vt_flat {
   using Waiting = vt_host::Waiting;
   using Coalescer = vt_host::Coalescer;
   Coalescer co;
+  // funnel_search callers travel together only with equal (stages, candidates): the shapes seen on
+  // this handle, by index -- the index is what a waiter carries as its `aux`
+  struct FunnelShape {
+    std::vector<size_t> stages;
+    size_t candidates;
+  };
+  std::mutex funnel_mu;
+  std::vector<FunnelShape> funnel_shapes;
   std::atomic<uint64_t> approx_bytes{0};  // rows x row stride, refreshed by mutations (the coalescer's only use of it is a size class)
 
   bool multi() const { return shards.size() > 1 || !workers.empty(); }

@@ -378,6 +378,36 @@ struct CosineScanArgs {
 size_t cosine_scan_lds_bytes(uint32_t d, uint32_t k);
 hipError_t launch_cosine_scan(const CosineScanArgs &a, uint32_t blocks, hipStream_t s);
 
+// K6b for up to kCosineMultiMax queries in ONE sweep of the rows' prefixes (funnel_search's stage 1,
+// collection.ex:245-260 -> search.rs:56-60, for several callers at once): every lane owns a row and
+// carries x.x once and q.x per query as sequential f64 chains -- the values are the single kernel's,
+// bit for bit.  No per-wave top-k buffers (eight of them would not fit beside the row panels):
+//   dense mode (`sample` set): the scores of every `sample_stride`-th tile of 64 rows go to
+//     sample[q * sample_rows + i] -- launch_sample_tau turns them into one threshold per query;
+//   sweep mode: every (query, row) with raw >= tau[q] is appended to the query's list as
+//     (key, {row, raw}) -- key as in the single kernel -- cand_count[q] counting ALL of them;
+//     the host checks k <= count <= cap (else that query takes the single path) and
+//     launch_select_lists cuts each list to its k best.
+constexpr uint32_t kCosineMultiMax = 8;
+struct CosineScanMultiArgs {
+  const float *X;
+  size_t stride;
+  const double *Qd;          // [kCosineMultiMax][padded_dim(d)] device: the queries' prefixes as f64 (exact), unused rows zero
+  double qq[kCosineMultiMax];  // f64_dot(q, q) over the first d coordinates (sequential, host)
+  const uint32_t *id_rank;
+  uint32_t n, d, nq;
+  float *sample;             // dense mode when set
+  uint32_t sample_stride, sample_rows;
+  const float *tau;          // [nq] sweep mode
+  uint64_t *cand_keys;       // [nq][cand_cap]
+  Payload *cand_pay;
+  uint32_t *cand_count;      // [nq], zeroed by the caller
+  uint32_t cand_cap;
+  int *status;
+};
+size_t cosine_scan_multi_lds_bytes();
+hipError_t launch_cosine_scan_multi(const CosineScanMultiArgs &a, uint32_t blocks, hipStream_t s);
+
 // Diagnostic: one pass of a plain read-only kernel over `bytes` of `buf` (vt_device_read_peak).
 hipError_t launch_read_peak(const void *buf, size_t bytes, float *sink, uint32_t blocks, hipStream_t s);
 

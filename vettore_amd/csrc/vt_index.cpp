@@ -570,14 +570,15 @@ int vt_flat_funnel_search(vt_flat *h, const float *query, size_t n, const size_t
   return guarded([&]() -> int {
   if (!h || !out || (!query && n) || (nstages && !stages)) return VT_ERR_ARGUMENT;
   *out = nullptr;
-  if (h->multi()) {
-    std::shared_lock<std::shared_mutex> rl(h->rw);
-    if (h->poisoned) return poisoned_status();
-    return funnel_multi(h, query, n, stages, nstages, candidates, limit, out);
-  }
-  return read_single(h, NEED_STRICT_RANKS, limit, [&](Shard *ix, Ctx &c) -> int {
-    return funnel_ready(ix, c, query, n, stages, nstages, candidates, limit, out);
+  return coalesced_funnel(h, query, n, stages, nstages, candidates, limit, out);
   });
+}
+
+int vt_flat_funnel_search_batch(vt_flat *h, const float *queries, size_t nq, size_t d, const size_t *stages, size_t nstages,
+                                size_t candidates, size_t limit, vt_hits **out) {
+  return guarded([&]() -> int {
+  if (!h || !out || (nq && d && !queries) || (nstages && !stages)) return VT_ERR_ARGUMENT;
+  return funnel_batch_direct(h, queries, nq, d, stages, nstages, candidates, limit, out);
   });
 }
 
@@ -817,6 +818,7 @@ int vt_flat_get_profile(vt_flat *h, vt_profile *out, int reset) {
       t.nominate_candidates += p.nominate_candidates;
       t.hamming_queries += p.hamming_queries;
       t.hybrid_device_chains += p.hybrid_device_chains;
+      t.prefix_queries += p.prefix_queries;
       if (reset) c.prof = vt_profile{};
     });
   if (reset) h->xprof = vt_profile{};

@@ -1654,6 +1654,149 @@ hipError_t launch_cosine_rerank_batch(const CosineRerankArgs &a, uint32_t nq, hi
   return hipGetLastError();
 }
 
+// K6b, several queries per sweep (CosineScanMultiArgs in vt_device.h).  The row walk is
+// cosine_scan_kernel's: a wave parks a 64-row x 64-float panel in LDS, the next panel's 16 loads
+// already on their way, then lane r walks row r -- one x.x chain and nq q.x chains, each the
+// single kernel's sequence of f64 FMAs.  The queries are wave-uniform: they come as f64 through
+// the scalar cache (constant address space => s_load) and enter the FMAs as SGPR operands -- read
+// from LDS as f32 like the single kernel's one query, eight queries cost 8 LDS reads and 32
+// conversions per 4 row elements and lane beside the 36 FMAs, and the pass was LDS / VALU bound
+// at 3.5 TB/s of prefix bytes.
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_multi_kernel(const CosineScanMultiArgs a) {
+  extern __shared__ __align__(16) float csm_lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t ldq = padded_dim(a.d);
+  typedef const __attribute__((address_space(4))) double *cd_p;
+  cd_p qd = (cd_p)(uintptr_t)a.Qd;
+  float *S = csm_lds + wib * (kCsRows * kCsStride);
+  const bool dense = a.sample != nullptr;
+  const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+  const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
+  const uint32_t ntiles_all = (a.n + kCsRows - 1) / kCsRows;
+  const uint32_t step = dense ? a.sample_stride : 1u;           // dense: every step-th tile
+  const uint32_t ntiles = (ntiles_all + step - 1) / step;        // tiles this launch walks
+  const uint32_t npanel = (a.d + kCsPanel - 1) / kCsPanel;
+  f32x4 v[16];
+  auto issue = [&](uint32_t ti, uint32_t p) {
+    const uint32_t t = ti * step;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      uint32_t r = t * kCsRows + 4 * s + (lane >> 4);
+      r = r < a.n ? r : a.n - 1;
+      v[s] = __builtin_nontemporal_load(
+          reinterpret_cast<const f32x4 *>(a.X + (size_t)r * a.stride + p * kCsPanel + (lane & 15) * 4));
+    }
+  };
+  if (wave_global < ntiles) issue(wave_global, 0);
+  for (uint32_t ti = wave_global; ti < ntiles; ti += total_waves) {
+    const uint32_t grow = ti * step * kCsRows + lane;
+    const bool valid_row = grow < a.n;
+    double xx = 0.0, qx[kCosineMultiMax];
+#pragma unroll
+    for (uint32_t q = 0; q < kCosineMultiMax; ++q) qx[q] = 0.0;
+    for (uint32_t p = 0; p < npanel; ++p) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        *reinterpret_cast<f32x4 *>(S + (4 * s + (lane >> 4)) * kCsStride + (lane & 15) * 4) = v[s];
+      wave_lds_fence();
+      if (p + 1 < npanel) issue(ti, p + 1);
+      else if (ti + total_waves < ntiles) issue(ti + total_waves, 0);
+      const uint32_t cnt = a.d - p * kCsPanel < (uint32_t)kCsPanel ? a.d - p * kCsPanel : (uint32_t)kCsPanel;
+      const float *Sr = S + lane * kCsStride;
+      cd_p qp = qd + p * kCsPanel;
+      // fma(x, y, acc) == acc + x*y here: the product of two f32 is exact in f64
+      uint32_t j = 0;
+      for (; j + 4 <= cnt; j += 4) {
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(Sr + j);
+        const double x0 = (double)xv.x, x1 = (double)xv.y, x2 = (double)xv.z, x3 = (double)xv.w;
+        xx = __builtin_fma(x0, x0, xx);
+        xx = __builtin_fma(x1, x1, xx);
+        xx = __builtin_fma(x2, x2, xx);
+        xx = __builtin_fma(x3, x3, xx);
+        // (all eight slots, unused ones zero: a branch between the queries puts a wait behind every
+        // scalar load; straight-line, the eight loads go out together)
+        double w[kCosineMultiMax][4];
+#pragma unroll
+        for (uint32_t q = 0; q < kCosineMultiMax; ++q) {
+          cd_p wp = qp + q * ldq + j;
+          w[q][0] = wp[0];
+          w[q][1] = wp[1];
+          w[q][2] = wp[2];
+          w[q][3] = wp[3];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < kCosineMultiMax; ++q) {
+          qx[q] = __builtin_fma(w[q][0], x0, qx[q]);
+          qx[q] = __builtin_fma(w[q][1], x1, qx[q]);
+          qx[q] = __builtin_fma(w[q][2], x2, qx[q]);
+          qx[q] = __builtin_fma(w[q][3], x3, qx[q]);
+        }
+      }
+      for (; j < cnt; ++j) {
+        const double xd = (double)Sr[j];
+        xx = __builtin_fma(xd, xd, xx);
+#pragma unroll
+        for (uint32_t q = 0; q < kCosineMultiMax; ++q) qx[q] = __builtin_fma(qp[q * ldq + j], xd, qx[q]);
+      }
+      wave_lds_fence();
+    }
+    // distances.rs:160-177, once per query
+    const double rn = sqrt(xx);
+    const uint32_t my_rank = (!dense && valid_row && a.id_rank) ? a.id_rank[grow] : grow;
+#pragma unroll
+    for (uint32_t q = 0; q < kCosineMultiMax; ++q) {
+      if (q >= a.nq) break;
+      const double ln = sqrt(a.qq[q]);
+      float raw = 0.0f;
+      bool valid = valid_row;
+      if (!(ln == 0.0 || rn == 0.0)) {
+        double sim = qx[q] / (ln * rn);
+        if (!isfinite(sim)) {
+          if (valid && !dense) atomicMax(a.status, kErrOverflow);
+          valid = false;
+        } else {
+          sim = sim < -1.0 ? -1.0 : (sim > 1.0 ? 1.0 : sim);
+          raw = (float)sim;
+        }
+      }
+      if (dense) {
+        const uint32_t i = ti * kCsRows + lane;  // position in the sample
+        if (i < a.sample_rows) a.sample[(size_t)q * a.sample_rows + i] = valid ? raw : -INFINITY;
+        continue;
+      }
+      const bool hit = valid && raw >= a.tau[q];
+      const uint64_t m = __ballot(hit);
+      if (m) {
+        uint32_t base = 0;
+        if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&a.cand_count[q], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(m), kWave);
+        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (hit && pos < a.cand_cap) {
+          a.cand_keys[(size_t)q * a.cand_cap + pos] = ((uint64_t)orderable(1.0f - raw) << 32) | my_rank;
+          Payload pv;
+          pv.row = grow;
+          pv.raw = raw;
+          a.cand_pay[(size_t)q * a.cand_cap + pos] = pv;
+        }
+      }
+    }
+  }
+}
+
+size_t cosine_scan_multi_lds_bytes() { return (size_t)kWavesPerBlock * kCsRows * kCsStride * sizeof(float); }
+
+hipError_t launch_cosine_scan_multi(const CosineScanMultiArgs &a, uint32_t blocks, hipStream_t s) {
+  const size_t lds = cosine_scan_multi_lds_bytes();
+  if (!a.Qd || ((uintptr_t)a.Qd & 31) || a.nq == 0 || a.nq > kCosineMultiMax || a.n == 0 || a.d == 0) return hipErrorInvalidValue;
+  if (a.sample ? (a.sample_stride == 0 || a.sample_rows == 0) : (!a.tau || !a.cand_keys || !a.cand_pay || !a.cand_count))
+    return hipErrorInvalidValue;
+  hipError_t e = allow_lds(cosine_scan_multi_kernel, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(cosine_scan_multi_kernel, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+  return hipGetLastError();
+}
+
 size_t cosine_scan_lds_bytes(uint32_t d, uint32_t k) {
   const size_t buf = k <= (uint32_t)kSmallK ? WaveTopK<kCapSmall>::lds_bytes() : WaveTopK<kCapLarge>::lds_bytes();
   const size_t bytes = ((size_t)padded_dim(d) + (size_t)kWavesPerBlock * kCsRows * kCsStride) * sizeof(float) +

@@ -417,6 +417,22 @@ def flat_funnel_search(index: FlatRef, query, stages: Sequence[int], candidates:
     return ("ok", _take_hits(h)) if rc == 0 else _err(rc)
 
 
+def flat_funnel_search_batch(index: FlatRef, queries, stages: Sequence[int], candidates: int, limit: int):
+    """Extension: nq funnel searches with one set of stages in one call ([nq][d] matrix); each hit list
+    identical to flat_funnel_search of that query -- on a cosine collection groups of up to eight
+    share the stage-1 sweep of the prefixes."""
+    q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32))
+    if q.ndim != 2:
+        raise TypeError("badarg: queries must be a matrix")
+    nq, d = q.shape
+    st = np.ascontiguousarray(np.asarray(list(stages), dtype=np.uintp))
+    outs = (C.c_void_p * max(nq, 1))()
+    rc = _lib.load().vt_flat_funnel_search_batch(index.handle, _fp(q.reshape(-1)), nq, d, _szp(st), st.size, candidates, limit, outs)
+    if rc != 0:
+        return _err(rc)
+    return ("ok", [_take_hits(C.c_void_p(outs[i])) for i in range(nq)])
+
+
 GEN_FUNNEL, GEN_QUANTIZED, GEN_SEARCH = 0, 1, 2
 
 
