@@ -95,8 +95,15 @@ int coalesced_search(vt_flat *h, const float *query, size_t n, size_t limit, vt_
 }
 
 // quantized_search callers that meet on a handle share sweeps of the bit matrix (quantized_group)
+// (corpora too small for the grouped passes -- fewer than 16 384 rows -- would be served one by one
+// by the batch's leader: their callers stay side by side on the reader contexts instead)
+bool too_small_for_groups(vt_flat *h) {
+  return h->approx_rows.load(std::memory_order_relaxed) < 16384;
+}
+
 int coalesced_quantized(vt_flat *h, const float *query, size_t n, size_t candidates, size_t limit, vt_hits **out) {
-  if (limit == 0 || candidates == 0 || candidates > (size_t)vt::kMaxFusedK || n == 0 || h->multi() || !coalescing_enabled())
+  if (limit == 0 || candidates == 0 || candidates > (size_t)vt::kMaxFusedK || n == 0 || h->multi() || !coalescing_enabled() ||
+      too_small_for_groups(h))
     return quantized_direct(h, query, n, candidates, limit, out);
   return vt_host::coalesced_search_t<vt_flat, CoalesceOps>(h, query, n, limit, out, COALESCE_QUANTIZED, candidates);
 }
@@ -106,7 +113,7 @@ int coalesced_quantized(vt_flat *h, const float *query, size_t n, size_t candida
 int coalesced_funnel(vt_flat *h, const float *query, size_t n, const size_t *stages, size_t nstages, size_t candidates,
                      size_t limit, vt_hits **out) {
   bool plain = limit == 0 || candidates == 0 || candidates > (size_t)vt::kMaxFusedK || n == 0 || nstages == 0 || nstages > 16 ||
-               h->multi() || !coalescing_enabled() || h->shards[0]->metric != VT_COSINE;
+               h->multi() || !coalescing_enabled() || h->shards[0]->metric != VT_COSINE || too_small_for_groups(h);
   for (size_t i = 0; i < nstages && !plain; ++i) plain = stages[i] == 0 || stages[i] > n;  // (its own error, in its own order)
   size_t shape = 0;
   if (!plain) {

@@ -702,9 +702,13 @@ int store_validated_rows(vt_flat *h, size_t count, const char *ids, const size_t
 long handle_dim(const vt_flat *h) { return h->multi() ? h->dim : h->shards[0]->dim; }
 
 void refresh_approx_bytes(vt_flat *h) {
-  uint64_t b = 0;
-  for (auto &sh : h->shards) b += (uint64_t)sh->n * sh->ld * sizeof(float);
+  uint64_t b = 0, r = 0;
+  for (auto &sh : h->shards) {
+    b += (uint64_t)sh->n * sh->ld * sizeof(float);
+    r += sh->n;
+  }
   h->approx_bytes.store(b, std::memory_order_relaxed);
+  h->approx_rows.store(r, std::memory_order_relaxed);
 }
 
 int store_validated(vt_flat *h, size_t count, const char *ids, const size_t *id_off, const RowSource &src, size_t d) {

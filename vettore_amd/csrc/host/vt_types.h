@@ -312,6 +312,7 @@ struct vt_flat {
   std::mutex funnel_mu;
   std::vector<FunnelShape> funnel_shapes;
   std::atomic<uint64_t> approx_bytes{0};  // rows x row stride, refreshed by mutations (the coalescer's only use of it is a size class)
+  std::atomic<uint64_t> approx_rows{0};   // rows, likewise
 
   bool multi() const { return shards.size() > 1 || !workers.empty(); }
   size_t total() const {
