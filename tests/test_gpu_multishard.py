@@ -169,6 +169,13 @@ def test_staged_searches_on_a_sharded_handle_equal_the_one_gpu_index(nifs, oracl
         gens = [(nifs.GEN_FUNNEL, 50, [32]), (nifs.GEN_QUANTIZED, 60, []), (nifs.GEN_SEARCH, 40, [])]
         got = unwrap(nifs.flat_hybrid_search(many.ref, q, gens, 15))
         assert bits(got) == bits(unwrap(nifs.flat_hybrid_search(one.ref, q, gens, 15))), (metric, qi)
+    # the batch forms on both kinds of handle: the one-GPU index groups its queries, the sharded one loops
+    qm = np.stack(qs)
+    for ref in (one.ref, many.ref):
+        got = unwrap(nifs.flat_funnel_search_batch(ref, qm, [16, 48], 64, 10))
+        assert [bits(h) for h in got] == [bits(unwrap(nifs.flat_funnel_search(one.ref, q, [16, 48], 64, 10))) for q in qs], metric
+        got = unwrap(nifs.flat_quantized_search_batch(ref, qm, 100, 10))
+        assert [bits(h) for h in got] == [bits(unwrap(nifs.flat_quantized_search(one.ref, q, 100, 10))) for q in qs], metric
     # after mutations on both (derived columns are patched per shard)
     for target in (one, many):
         target.insert("zz-new", x[7])
