@@ -109,6 +109,7 @@ struct FakeOps {
     return 0;
   }
   static bool must_disband(FakeHandle *h, int, size_t) { return h->ranks_lazy.load(); }
+  static size_t capacity(FakeHandle *, int kind) { return kind ? 8 : 256; }
   static void run(FakeHandle *h, std::vector<vt_host::Waiting *> &members) { vt_host::run_coalesced_t<FakeHandle, FakeOps>(h, members); }
   static void drop_hits(vt_hits *hits) { free_hits(hits); }
   static void set_last_error(const std::string &msg) { t_last_error = msg; }

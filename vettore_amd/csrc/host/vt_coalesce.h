@@ -84,6 +84,14 @@ struct CoalesceOps {
     std::shared_lock<std::shared_mutex> rl(h->rw);
     return shard_stale(h->shards[0].get(), NEED_STRICT_RANKS, limit);
   }
+  // a matrix-core pass carries up to 256 plain searches of the dot / L2 family; everything else
+  // rides in groups of eight per sweep (K1m, the grouped Hamming and prefix passes)
+  static size_t capacity(vt_flat *h, int kind) {
+    if (kind != COALESCE_SEARCH) return 8;
+    const int m = h->metric;
+    const bool gemm = m == VT_COSINE || m == VT_INNER_PRODUCT || m == VT_NEG_INNER_PRODUCT || m == VT_L2 || m == VT_L2_SQUARED;
+    return gemm && !std::getenv("VT_BATCH_NO_MFMA") ? 256 : 8;
+  }
   static void run(vt_flat *h, std::vector<vt_host::Waiting *> &members) { vt_host::run_coalesced_t<vt_flat, CoalesceOps>(h, members); }
   static void drop_hits(vt_hits *hits) { delete hits; }
   static void set_last_error(const std::string &msg) { g_last_error = msg; }

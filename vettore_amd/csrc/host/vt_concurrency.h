@@ -186,6 +186,7 @@ struct Coalescer {
   unsigned active = 0;        // searches / batches running
   size_t last_batch = 1;      // members of the last batch that ran
   double last_seconds = 0.0;  // what it took
+  std::chrono::steady_clock::time_point last_end{};  // when it ended
   uint64_t batches = 0, batched_queries = 0;
 };
 
@@ -225,6 +226,7 @@ void run_coalesced_t(H *h, std::vector<Waiting *> &members) {
 //   Ops::slots(h) -> unsigned                          operations in flight before callers queue
 //   Ops::search_direct(h, kind, aux, query, n, limit, out) -> st  a search outside the coalescer
 //   Ops::must_disband(h, kind, limit) -> bool          a batch would force work a lone search avoids
+//   Ops::capacity(h, kind) -> size_t                   callers one pass over the corpus carries at no extra cost
 //   Ops::run(h, members)                               normally run_coalesced_t<H, Ops>
 //   Ops::drop_hits(hits)                               frees a hit list
 //   Ops::set_last_error(msg)                           the calling thread's error text
@@ -237,10 +239,48 @@ int coalesced_search_t(H *h, const float *query, size_t n, size_t limit, vt_hits
   Waiting me(query, n, limit, kind, aux, out);
   std::vector<Waiting *> members;
   members.reserve(kCoalesceMax);  // (no allocation once others depend on this caller)
+  // Callers that have just been answered are about to come back: whoever starts the next pass
+  // gives them a moment (a few % of a pass) before it runs without them.  `already`: callers the
+  // starter can see now; it waits until as many more as the last batch had have queued up, or the
+  // window closes.  (wait_until on the system clock = pthread_cond_timedwait, which every
+  // ThreadSanitizer intercepts; wait_for's pthread_cond_clockwait is invisible to gcc 11's, which
+  // then believes the mutex is still held.  A clock step during these <= 300 us only ends the wait.)
+  // Only while the pass can still take them for free (Ops::capacity: callers one pass carries at no
+  // extra cost -- 256 for a matrix-core batch, 8 where groups of eight share a sweep): beyond that
+  // a batch takes as many passes as two smaller ones, and waiting buys nothing.
+  auto gather_returning = [&](std::unique_lock<std::mutex> &lk) {
+    const size_t capacity = std::min(kCoalesceMax, Ops::capacity(h, kind));
+    if (co.waiting.size() + 1 >= capacity) return;
+    const double window = std::min(300e-6, 0.03 * co.last_seconds);
+    const size_t want = std::min(capacity - 1, co.waiting.size() + co.last_batch - 1);
+    co.gather.wait_until(lk, std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::system_clock::duration>(
+                                                                   std::chrono::duration<double>(window)),
+                         [&] { return co.waiting.size() >= want; });
+  };
+  auto take_along = [&]() {
+    for (auto it = co.waiting.begin(); it != co.waiting.end() && members.size() + 1 < kCoalesceMax;) {
+      if ((*it)->limit == limit && (*it)->n == n && (*it)->kind == kind && (*it)->aux == aux) {
+        members.push_back(*it);
+        it = co.waiting.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  };
   {
     std::unique_lock<std::mutex> lk(co.mu);
     if (co.active < max_active && co.waiting.empty()) {
-      co.active += 1;  // nobody to wait for, nobody to take along
+      co.active += 1;  // nobody to wait for ...
+      // ... unless a batch has only just ended: its callers are on their way back, and the first
+      // of them to arrive would otherwise run alone, the others queue behind it, and the handle
+      // settles into passes of 1 and N - 1 callers (or two alternating halves) -- N callers per
+      // TWO passes.  (Only when this caller is the one operation in flight: with more slots the
+      // corpus is small and passes overlap anyway.)
+      if (max_active == 1 && co.last_batch > 1 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - co.last_end).count() < std::min(300e-6, 0.03 * co.last_seconds)) {
+        gather_returning(lk);
+        take_along();
+      }
     } else {
       co.waiting.push_back(&me);
       co.gather.notify_one();
@@ -254,26 +294,11 @@ int coalesced_search_t(H *h, const float *query, size_t n, size_t limit, vt_hits
         return Ops::search_direct(h, kind, aux, query, n, limit, out);
       }
       // LEADS (the operation that just finished passed its slot on: `active` already counts this one).
-      // Callers that have just been answered are about to come back -- give them a moment (a few
-      // % of a pass) before the next pass over the corpus starts without them
-      if (co.last_batch > 1 && co.waiting.size() + 1 < co.last_batch) {
-        const double window = std::min(300e-6, 0.03 * co.last_seconds);
-        const size_t want = co.last_batch - 1;
-        // (wait_until on the system clock = pthread_cond_timedwait, which every ThreadSanitizer
-        // intercepts; wait_for's pthread_cond_clockwait is invisible to gcc 11's, which then
-        // believes the mutex is still held.  A clock step during these <= 300 us only ends the wait.)
-        co.gather.wait_until(lk, std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::system_clock::duration>(
-                                                                       std::chrono::duration<double>(window)),
-                             [&] { return co.waiting.size() >= want; });
-      }
-      for (auto it = co.waiting.begin(); it != co.waiting.end() && members.size() + 1 < kCoalesceMax;) {
-        if ((*it)->limit == limit && (*it)->n == n && (*it)->kind == kind && (*it)->aux == aux) {
-          members.push_back(*it);
-          it = co.waiting.erase(it);
-        } else {
-          ++it;
-        }
-      }
+      // The callers of the batch that just ended are about to come back: wait a moment for them too
+      // (through r03 the leader only waited while FEWER callers than the last batch had were queued:
+      // two halves of the callers then took turns for good, each pass carrying half of them)
+      if (co.last_batch > 1) gather_returning(lk);
+      take_along();
     }
     members.insert(members.begin(), &me);
   }
@@ -312,6 +337,7 @@ int coalesced_search_t(H *h, const float *query, size_t n, size_t limit, vt_hits
     }
     co.last_batch = members.size();
     co.last_seconds = seconds;
+    co.last_end = std::chrono::steady_clock::now();
     if (members.size() > 1) {
       co.batches += 1;
       co.batched_queries += members.size();
