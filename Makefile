@@ -19,7 +19,7 @@ DEVSRC  := vt_kernels vt_batch vt_batch_bf16 vt_scan_dot vt_scan_l2 vt_scan_l1 v
 DEVOBJ  := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(DEVSRC)))
 DEVHDR  := $(CSRC)/vt_device.h $(CSRC)/vt_common.cuh $(CSRC)/vt_scan.cuh
 
-all: $(LIBDIR)/libvettore_hip.so $(LIBDIR)/libvettore_hip_hooks.so oracle
+all: $(LIBDIR)/libvettore_hip.so $(LIBDIR)/libvettore_hip_hooks.so $(LIBDIR)/libvt_callers.so oracle
 
 $(LIBDIR)/%.o: $(CSRC)/%.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
@@ -60,6 +60,10 @@ $(LIBDIR)/vt_scan_multi_dbg.o: $(CSRC)/vt_scan_multi.hip $(DEVHDR)
 $(LIBDIR)/libvettore_hip_mqdbg.so: $(filter-out %/vt_scan_multi.o,$(DEVOBJ)) $(LIBDIR)/vt_scan_multi_dbg.o $(LIBDIR)/vt_index.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread -ldl
 mqdbg: $(LIBDIR)/libvettore_hip_mqdbg.so
+
+# bench.py's native caller threads (tools/callers_native.cpp): measurement infrastructure, not product
+$(LIBDIR)/libvt_callers.so: tools/callers_native.cpp include/vettore_flat.h $(LIBDIR)/libvettore_hip.so
+	g++ -O2 -std=c++17 -fPIC -shared tools/callers_native.cpp -Iinclude -L$(LIBDIR) -lvettore_hip -lpthread -Wl,-rpath,'$$ORIGIN' -o $@
 
 oracle:
 	$(MAKE) -C oracle -s

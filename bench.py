@@ -439,6 +439,47 @@ def run_side_mode(a, torch, nifs, device):
     print(json.dumps(out))
 
 
+_CALLERS_LIB = None
+
+
+def native_callers(a, L, nifs, ref, threads, seconds, qs, quantized, funnel):
+    """The callers as NATIVE threads (vettore_amd/lib/libvt_callers.so, tools/callers_native.cpp): Python
+    threads must win the interpreter lock before they can call again and return to the handle in a
+    trickle, which hides how the library lets concurrent callers share a pass.  Every 8th
+    answer of a thread is compared with the same query's answer alone.  None when the helper is not
+    built: the caller falls back to Python threads."""
+    global _CALLERS_LIB
+    if _CALLERS_LIB is None:
+        path = os.path.join(ROOT, "vettore_amd", "lib", "libvt_callers.so")
+        try:
+            lib = C.CDLL(path) if os.path.exists(path) else False
+        except OSError:
+            lib = False
+        if lib:
+            lib.vt_callers_run.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
+                                           C.c_size_t, C.c_size_t, C.c_int, C.c_double, C.c_int,
+                                           C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+            lib.vt_callers_run.restype = C.c_int
+        _CALLERS_LIB = lib
+    if not _CALLERS_LIB:
+        return None
+    q = np.ascontiguousarray(qs, dtype=np.float32)
+    kind, param, cand = (2, funnel, 100) if funnel else (1, 0, quantized) if quantized else (0, 0, 0)
+    n, wrong, failed = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+    b0 = nifs.flat_coalesce_stats(ref)
+    t0 = time.perf_counter()
+    rc = _CALLERS_LIB.vt_callers_run(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), len(q), a.dim, a.limit, kind, param, cand,
+                                     threads, seconds, 8, C.byref(n), C.byref(wrong), C.byref(failed))
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        return None
+    b1 = nifs.flat_coalesce_stats(ref)
+    # (dt includes the answers taken alone before the threads start: the helper reports its own window)
+    return {"threads": threads, "callers": "native threads", "value": n.value / seconds, "unit": "queries/s", "seconds": round(seconds, 2),
+            "wall_seconds": round(dt, 2), "searches": n.value, "batches": b1[0] - b0[0], "searches_in_batches": b1[1] - b0[1],
+            "verified": wrong.value == 0 and failed.value == 0, "mean_latency_ms": seconds * threads / max(1, n.value) * 1e3}
+
+
 def concurrent_callers(a, L, nifs, ref, threads, seconds, quantized=0, funnel=0):
     """`threads` callers searching ONE handle at the same time (what BEAM dirty schedulers do under
     the reference's read lock, nifs.rs:297-309): the library lets searches that meet travel as one
@@ -447,6 +488,9 @@ def concurrent_callers(a, L, nifs, ref, threads, seconds, quantized=0, funnel=0)
     funnel_search(stages: [p], candidates: 100) (collection.ex:245-260)."""
     import threading
     qs = normalized_queries(64, a.dim, SEED_QUERY + 9)
+    native = native_callers(a, L, nifs, ref, threads, seconds, qs, quantized, funnel)
+    if native is not None:
+        return native
     hp = C.c_void_p()
     stages = (C.c_size_t * 1)(funnel)
 
@@ -490,7 +534,7 @@ def concurrent_callers(a, L, nifs, ref, threads, seconds, quantized=0, funnel=0)
     dt = time.perf_counter() - t0
     b1 = nifs.flat_coalesce_stats(ref)
     total = sum(counts)
-    return {"threads": threads, "value": total / dt, "unit": "queries/s", "seconds": round(dt, 2), "searches": total,
+    return {"threads": threads, "callers": "python threads", "value": total / dt, "unit": "queries/s", "seconds": round(dt, 2), "searches": total,
             "batches": b1[0] - b0[0], "searches_in_batches": b1[1] - b0[1], "verified": not wrong,
             "mean_latency_ms": dt * threads / max(1, total) * 1e3}
 
