@@ -137,3 +137,33 @@ def test_callers_that_meet_travel_together(nifs, monkeypatch):
     apart = _throughput(nifs, g, qs, 16)
     print("16 callers, queries/s: together %.0f, side by side %.0f; batches %d carrying %d" % (together, apart, stats[0], stats[1]))
     assert together > 2 * apart and stats[0] > 0
+
+
+def test_looping_callers_ride_one_pass(nifs):
+    """Callers that loop on one handle (the reference's normal load) must end up on ONE pass each:
+    the coalescer once settled into two halves of the callers taking turns -- half the callers per
+    pass, twice the latency.  Measured as the average batch size with 16 native threads on a corpus
+    large enough for one slot (vt_flat_coalesce_stats): close to 16, not 8."""
+    import ctypes as C
+    import os
+    import torch
+    import bench
+    path = os.path.join(bench.ROOT, "vettore_amd", "lib", "libvt_callers.so")
+    if not os.path.exists(path):
+        pytest.skip("libvt_callers.so not built")
+    from vettore_amd import _lib
+    L = _lib.load()
+    rows, dim = 3_000_000, 128            # 1.5 GB of rows: one operation in flight
+    x = bench.build_shard(torch, torch.device("cuda", 0), rows, dim, 123)
+    ref = nifs.flat_new_cosine()
+    assert nifs.flat_load_device_matrix(ref, bench.doc_ids(0, rows), x.data_ptr(), rows, dim) == ("ok", ())
+    del x
+
+    class A:
+        pass
+    a = A()
+    a.dim, a.limit, a.rows = dim, 10, rows
+    qs = bench.normalized_queries(64, dim, 5)
+    res = bench.native_callers(a, L, nifs, ref, 16, 1.0, qs, 0, 0)
+    assert res is not None and res["verified"], res
+    assert res["searches_in_batches"] / max(1, res["batches"]) > 12, res

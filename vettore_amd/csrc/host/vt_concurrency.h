@@ -251,7 +251,10 @@ int coalesced_search_t(H *h, const float *query, size_t n, size_t limit, vt_hits
   auto gather_returning = [&](std::unique_lock<std::mutex> &lk) {
     const size_t capacity = std::min(kCoalesceMax, Ops::capacity(h, kind));
     if (co.waiting.size() + 1 >= capacity) return;
-    const double window = std::min(300e-6, 0.03 * co.last_seconds);
+    // (a thread needs 20-50 us to wake up and call again: where one pass owns the card -- corpora of a
+    // GiB and more, passes of 0.2 ms and more -- the window does not go below 30 us)
+    double window = std::min(300e-6, 0.03 * co.last_seconds);
+    if (max_active == 1) window = std::max(window, 30e-6);
     const size_t want = std::min(capacity - 1, co.waiting.size() + co.last_batch - 1);
     co.gather.wait_until(lk, std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::system_clock::duration>(
                                                                    std::chrono::duration<double>(window)),
@@ -277,7 +280,8 @@ int coalesced_search_t(H *h, const float *query, size_t n, size_t limit, vt_hits
       // TWO passes.  (Only when this caller is the one operation in flight: with more slots the
       // corpus is small and passes overlap anyway.)
       if (max_active == 1 && co.last_batch > 1 &&
-          std::chrono::duration<double>(std::chrono::steady_clock::now() - co.last_end).count() < std::min(300e-6, 0.03 * co.last_seconds)) {
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - co.last_end).count() <
+              std::max(30e-6, std::min(300e-6, 0.03 * co.last_seconds))) {
         gather_returning(lk);
         take_along();
       }
