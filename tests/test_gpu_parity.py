@@ -737,7 +737,7 @@ def test_batched_search_equals_single_queries(nifs, oracle_mod, metric, nominate
     unwrap(nifs.flat_load_matrix(g.ref, ids, x))
     rng = np.random.default_rng(8)
     nifs.flat_set_profiling(g.ref, True)
-    for nq, k in ((8, 10), (37, 1), (256, 10), (300, 64)):
+    for nq, k in ((8, 10), (37, 1), (100, 10), (128, 3), (256, 10), (300, 64)):
         qs = rng.uniform(-1, 1, size=(nq, d)).astype(np.float32)
         qs[0] = x[n // 2]  # sits on the block of identical rows
         if metric == 2:

@@ -38,7 +38,7 @@ int main(int argc, char **argv) {
   hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, Q, (size_t)256 * ld, 2u);
   std::vector<float> ht(256, tau);
   CK(hipMemcpy(dtau, ht.data(), 256 * 4, hipMemcpyHostToDevice));
-  CK(vt::launch_batch_q_image(Q, ld, img, 0));
+  CK(vt::launch_batch_q_image(Q, ld, 256, img, 0));
   vt::BatchScoreArgs a{};
   a.X = X; a.stride = ld; a.Q = Q; a.ld = ld; a.nq_pad = 256; a.n = rows; a.n_total = rows;
   a.tau = dtau; a.cand = cand; a.cand_count = cnt; a.cand_cap = 8192; a.Qimage = img;

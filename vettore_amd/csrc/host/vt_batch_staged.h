@@ -25,7 +25,7 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   const auto t_begin = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
   double t_staged = 0, t_queued = 0, t_synced = 0;
-  uint32_t nq_pad = bf16 ? 256 : 32;
+  uint32_t nq_pad = bf16 ? vt::batch_bf16_pad((uint32_t)nq) : 32;
   while (nq_pad < nq) nq_pad *= 2;
   const uint32_t rows_per_block = bf16 ? vt::batch_bf16_rows_per_block() : vt::batch_rows_per_block(nq_pad);
   const uint32_t ntiles_total = (n + rows_per_block - 1) / rows_per_block;
@@ -92,7 +92,7 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   a.xnorm2 = l2_family ? ix->dXnorm2.p : nullptr;
   if (bf16) {
     a.Qimage = c.dBQimage.p;
-    VT_HIP(vt::launch_batch_q_image(c.dBQ.p, ld, c.dBQimage.p, c.stream));
+    VT_HIP(vt::launch_batch_q_image(c.dBQ.p, ld, nq_pad, c.dBQimage.p, c.stream));
   }
   auto scores = [&](bool dense, uint32_t blocks) {
     return bf16 ? vt::launch_batch_scores_bf16(a, dense, blocks, c.stream) : vt::launch_batch_scores(a, dense, blocks, c.stream);

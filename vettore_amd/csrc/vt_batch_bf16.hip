@@ -56,12 +56,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kWavesB = 8;              // waves per block
 constexpr int kRowsB = kWavesB * 32;    // rows per block tile
-constexpr int kNT = 8;                  // 32-query tiles: the image always holds 256 queries
+// QT = 32-query tiles of the batch: 8 (256 queries), 4 (128) or 2 (64).  A batch of 64 pads to 64
+// columns, not 256: a quarter of the MFMA work, and the pass that is co-limited by the matrix pipe
+// at 256 queries is plainly HBM-bound there (r03: callers that meet on a handle are usually fewer
+// than 256).
 constexpr int kStages = 3;
-constexpr uint32_t kQStageBytes = kNT * 2 * 1024;       // [t][s][lane] x 16 B
+constexpr uint32_t q_stage_bytes(int qt) { return (uint32_t)qt * 2 * 1024; }  // [t][s][lane] x 16 B
 constexpr uint32_t kXStageBytes = kRowsB * 128;         // [row][8 slots of 16 B], slots XOR-swizzled
 constexpr uint32_t kXWaveBytes = 32 * 128;
-constexpr int kPiecesPerChunk = 4 + 2;                  // per wave: 4 of rows, 2 of queries
+// DMA pieces per wave and chunk: 4 of rows; of the chunk's query image (QT x 2 KiB) every wave copies
+// 2 KiB at QT = 8 and 1 KiB below (at QT = 2 the 4 KiB are copied twice, waves w and w + 4 the same
+// KiB: every wave issues the same number of pieces, which is what the counted wait needs)
+constexpr int q_pieces(int qt) { return qt == 8 ? 2 : 1; }
 
 // One LDS-DMA piece: 64 lanes x 16 B from (wave-uniform base + 32-bit lane offset) to LDS at
 // lds_addr + lane * 16 (see vt_batch.hip: SGPR-base addressing, m0 written right in front).
@@ -89,11 +95,11 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
 
 // The queries as the B operand wants them: image[c][t][s][lane = 32h + r][e] =
 // bf16(Q[32t + r][32c + 16h + 8s + e]) -- a fragment read is 1 KiB of consecutive lanes.
-__global__ __launch_bounds__(256) void q_image_kernel(const float *__restrict__ Q, uint32_t ld, uint32_t nchunk,
+__global__ __launch_bounds__(256) void q_image_kernel(const float *__restrict__ Q, uint32_t ld, uint32_t nchunk, uint32_t qt,
                                                       bf16x8 *__restrict__ image) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // one 16-B fragment slot each
-  if (i >= nchunk * kNT * 2 * 64) return;
-  const uint32_t lane = i & 63, s = (i >> 6) & 1, t = (i >> 7) & (kNT - 1), c = i >> 10;
+  if (i >= nchunk * qt * 2 * 64) return;
+  const uint32_t lane = i & 63, s = (i >> 6) & 1, t = (i >> 7) % qt, c = (i >> 7) / qt;
   const uint32_t r = lane & 31, h = lane >> 5;
   const float *src = Q + (size_t)(32 * t + r) * ld + 32 * c + 16 * h + 8 * s;
   image[i] = pack8(*reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
@@ -124,8 +130,8 @@ __device__ __forceinline__ void append_candidates(const BatchScoreArgs &a, f32x1
 // What a wave does with a finished 32-row x 256-query tile (C layout: column = lane & 31 =
 // query, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)): pass 0 writes the dense sample
 // matrix, pass 1 appends the scores that reach the query's threshold.
-template <bool DENSE>
-__device__ __forceinline__ void tile_epilogue(const BatchScoreArgs &a, f32x16 (&acc)[kNT], const float (&tau)[kNT],
+template <bool DENSE, int QT>
+__device__ __forceinline__ void tile_epilogue(const BatchScoreArgs &a, f32x16 (&acc)[QT], const float (&tau)[QT],
                                               uint32_t grow0, uint32_t srow0, int r, int h) {
   // L2 family: the 32 row norms of this wave's tile.  The address is wave-uniform, so they come
   // through the scalar cache (constant address space => s_load): a vector load here would sit in
@@ -150,7 +156,7 @@ __device__ __forceinline__ void tile_epilogue(const BatchScoreArgs &a, f32x16 (&
     }
   }
 #pragma unroll
-  for (int t = 0; t < kNT; ++t) {
+  for (int t = 0; t < QT; ++t) {
     const uint32_t qcol = t * 32 + r;
     f32x16 v = acc[t];
     if (a.xnorm2) {
@@ -177,8 +183,10 @@ __device__ __forceinline__ void tile_epilogue(const BatchScoreArgs &a, f32x16 (&
   }
 }
 
-template <bool DENSE>
+template <bool DENSE, int QT>
 __global__ __launch_bounds__(kWavesB *kWave, 1) void bf16_scores_kernel(const BatchScoreArgs a) {
+  constexpr uint32_t kQStageBytes = q_stage_bytes(QT);
+  constexpr int kPiecesPerChunk = 4 + q_pieces(QT);
   extern __shared__ __align__(16) unsigned char lds[];  // [3] query stages, then [3][8 waves] row stages
   const int lane = threadIdx.x & (kWave - 1);
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -188,17 +196,19 @@ __global__ __launch_bounds__(kWavesB *kWave, 1) void bf16_scores_kernel(const Ba
   if (blockIdx.x >= ntiles) return;
   const uint32_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
 
-  float tau[kNT];
+  float tau[QT];
 #pragma unroll
-  for (int t = 0; t < kNT; ++t) tau[t] = DENSE ? 0.f : a.tau[t * 32 + r];
+  for (int t = 0; t < QT; ++t) tau[t] = DENSE ? 0.f : a.tau[t * 32 + r];
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
   const uint32_t xlds0 = lds0 + kStages * kQStageBytes + wid * kXWaveBytes;
   auto xslot = [&](uint32_t row, uint32_t s) { return s ^ ((row >> 1) & 7); };
 
-  // queries: the chunk's image is one 16-KiB run; this wave copies KiB 2w and 2w + 1 of it
+  // queries: the chunk's image is one run of QT x 2 KiB; this wave copies KiB 2w and 2w + 1 of it
+  // (QT = 8), KiB w (QT = 4), KiB w mod 4 (QT = 2)
   const char *qimg = reinterpret_cast<const char *>(a.Qimage);
-  const uint32_t qoff = (uint32_t)(wid * 2) * 1024 + lane * 16;
+  const uint32_t qkib = QT == 8 ? (uint32_t)wid * 2 : QT == 4 ? (uint32_t)wid : (uint32_t)wid & 3u;
+  const uint32_t qoff = qkib * 1024 + lane * 16;
   // rows: piece i = rows 8i .. 8i+7 of this wave's 32, lane L -> row L / 8, physical slot L % 8
   uint32_t xoff[4];
   const char *xbase = nullptr;  // first row of the DMA cursor's block tile (wave-uniform)
@@ -225,8 +235,8 @@ __global__ __launch_bounds__(kWavesB *kWave, 1) void bf16_scores_kernel(const Ba
     }
     if (!VT_DBG(a, 4u)) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        dma16<false>(lds0 + stage * kQStageBytes + (wid * 2 + i) * 1024, qimg + (size_t)c * kQStageBytes + i * 1024, qoff);
+      for (int i = 0; i < q_pieces(QT); ++i)
+        dma16<false>(lds0 + stage * kQStageBytes + (qkib + i) * 1024, qimg + (size_t)c * kQStageBytes + i * 1024, qoff);
     }
   };
   // DMA cursor; past the end of this block's sequence it stays on the last chunk, so the loop
@@ -256,9 +266,9 @@ __global__ __launch_bounds__(kWavesB *kWave, 1) void bf16_scores_kernel(const Ba
 
   int stage = 0;
   for (uint32_t k = 0; k < my_tiles; ++k) {
-    f32x16 acc[kNT];
+    f32x16 acc[QT];
 #pragma unroll
-    for (int t = 0; t < kNT; ++t)
+    for (int t = 0; t < QT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
@@ -283,26 +293,26 @@ __global__ __launch_bounds__(kWavesB *kWave, 1) void bf16_scores_kernel(const Ba
       // loop on random data sustains on this part, the clock drops to ~1.6 GHz under it.)
       const unsigned char *xs = lds + stage * kXStageBytes;
       const unsigned char *qs = lds + stage * kQStageBytes + qfrag;
-      bf16x8 qv[2][kNT];
+      bf16x8 qv[2][QT];
       const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xs + xfrag[0]);
       const f32x4 x1 = *reinterpret_cast<const f32x4 *>(xs + xfrag[1]);
 #pragma unroll
-      for (int t = 0; t < kNT; ++t) qv[0][t] = *reinterpret_cast<const bf16x8 *>(qs + (t * 2) * 1024);
+      for (int t = 0; t < QT; ++t) qv[0][t] = *reinterpret_cast<const bf16x8 *>(qs + (t * 2) * 1024);
       const f32x4 x2 = *reinterpret_cast<const f32x4 *>(xs + xfrag[2]);
       const f32x4 x3 = *reinterpret_cast<const f32x4 *>(xs + xfrag[3]);
 #pragma unroll
-      for (int t = 0; t < kNT; ++t) qv[1][t] = *reinterpret_cast<const bf16x8 *>(qs + (t * 2 + 1) * 1024);
+      for (int t = 0; t < QT; ++t) qv[1][t] = *reinterpret_cast<const bf16x8 *>(qs + (t * 2 + 1) * 1024);
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8 xb0 = pack8(x0, x1), xb1 = pack8(x2, x3);
 #pragma unroll
-      for (int t = 0; t < kNT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb0, qv[0][t], acc[t], 0, 0, 0);
+      for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb0, qv[0][t], acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < kNT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb1, qv[1][t], acc[t], 0, 0, 0);
+      for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb1, qv[1][t], acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       stage = stage == kStages - 1 ? 0 : stage + 1;
     }
 
-    tile_epilogue<DENSE>(a, acc, tau, tile_row0(k), (blockIdx.x + k * gridDim.x) * kRowsB + wid * 32, r, h);
+    tile_epilogue<DENSE, QT>(a, acc, tau, tile_row0(k), (blockIdx.x + k * gridDim.x) * kRowsB + wid * 32, r, h);
   }
 }
 
@@ -310,12 +320,14 @@ __global__ __launch_bounds__(kWavesB *kWave, 1) void bf16_scores_kernel(const Ba
 }  // namespace
 
 uint32_t batch_bf16_rows_per_block() { return kRowsB; }
-size_t batch_bf16_image_bytes(uint32_t ld) { return (size_t)(ld / 32) * kQStageBytes; }
+size_t batch_bf16_image_bytes(uint32_t ld) { return (size_t)(ld / 32) * q_stage_bytes(8); }
+uint32_t batch_bf16_pad(uint32_t nq) { return nq <= 64 ? 64u : nq <= 128 ? 128u : 256u; }
 
-hipError_t launch_batch_q_image(const float *Q, uint32_t ld, void *image, hipStream_t s) {
-  const uint32_t nchunk = ld / 32;
-  const uint32_t slots = nchunk * kNT * 2 * 64;
-  hipLaunchKernelGGL(q_image_kernel, dim3((slots + 255) / 256), dim3(256), 0, s, Q, ld, nchunk,
+hipError_t launch_batch_q_image(const float *Q, uint32_t ld, uint32_t nq_pad, void *image, hipStream_t s) {
+  if (nq_pad != 64 && nq_pad != 128 && nq_pad != 256) return hipErrorInvalidValue;
+  const uint32_t nchunk = ld / 32, qt = nq_pad / 32;
+  const uint32_t slots = nchunk * qt * 2 * 64;
+  hipLaunchKernelGGL(q_image_kernel, dim3((slots + 255) / 256), dim3(256), 0, s, Q, ld, nchunk, qt,
                      reinterpret_cast<bf16x8 *>(image));
   return hipGetLastError();
 }
@@ -334,10 +346,17 @@ hipError_t launch_batch_scores_bf16(const BatchScoreArgs &a0, bool dense, uint32
 #ifndef VT_BATCH_TIMING_EXPERIMENTS
   a.debug = 0u;
 #endif
-  if (a.ld % 32 != 0 || a.nq_pad != 256 || a.Qimage == nullptr) return hipErrorInvalidValue;
-  const size_t lds_bytes = (size_t)kStages * (kQStageBytes + kXStageBytes);
-  return dense ? launch_one(bf16_scores_kernel<true>, lds_bytes, a, blocks, s)
-               : launch_one(bf16_scores_kernel<false>, lds_bytes, a, blocks, s);
+  if (a.ld % 32 != 0 || (a.nq_pad != 256 && a.nq_pad != 128 && a.nq_pad != 64) || a.Qimage == nullptr) return hipErrorInvalidValue;
+  const int qt = (int)a.nq_pad / 32;
+  const size_t lds_bytes = (size_t)kStages * (q_stage_bytes(qt) + kXStageBytes);
+  if (qt == 8)
+    return dense ? launch_one(bf16_scores_kernel<true, 8>, lds_bytes, a, blocks, s)
+                 : launch_one(bf16_scores_kernel<false, 8>, lds_bytes, a, blocks, s);
+  if (qt == 4)
+    return dense ? launch_one(bf16_scores_kernel<true, 4>, lds_bytes, a, blocks, s)
+                 : launch_one(bf16_scores_kernel<false, 4>, lds_bytes, a, blocks, s);
+  return dense ? launch_one(bf16_scores_kernel<true, 2>, lds_bytes, a, blocks, s)
+               : launch_one(bf16_scores_kernel<false, 2>, lds_bytes, a, blocks, s);
 }
 
 }  // namespace vt

@@ -342,10 +342,11 @@ uint32_t batch_rows_per_block(uint32_t nq_pad);
 hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s);
 // K2b (vt_batch_bf16.hip): the same two passes with both operands rounded to bf16 on the way
 // into v_mfma_f32_32x32x16_bf16 -- HBM-bound instead of FP32-MFMA-bound.  Always 256 query
-// columns (nq_pad == 256, the padding ones zero); a.Qimage from launch_batch_q_image.
+// columns (nq_pad = 64, 128 or 256 -- batch_bf16_pad --, the padding ones zero); a.Qimage from launch_batch_q_image.
 uint32_t batch_bf16_rows_per_block();
 size_t batch_bf16_image_bytes(uint32_t ld);
-hipError_t launch_batch_q_image(const float *Q, uint32_t ld, void *image, hipStream_t s);
+uint32_t batch_bf16_pad(uint32_t nq);  // columns a batch of nq <= 256 queries is padded to: 64, 128 or 256
+hipError_t launch_batch_q_image(const float *Q, uint32_t ld, uint32_t nq_pad, void *image, hipStream_t s);
 hipError_t launch_batch_scores_bf16(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s);
 // tau[b] for the nq_real real queries; +inf for the padding columns b >= nq_real.
 hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t nq_real, uint32_t rank,
