@@ -374,13 +374,15 @@ bool batch_uses_mfma(const Shard *ix, size_t nq, size_t limit) {
     // K2b: HBM-bound at every batch size)
     const double bytes = (double)ix->n * ix->ld * 4.0;
     const bool bf16 = batch_nominates_bf16(ix);
-    double nq_pad = bf16 ? 256 : 32;
+    double nq_pad = bf16 ? (double)vt::batch_bf16_pad((uint32_t)std::min<size_t>(nq, 256)) : 32;
     while (nq_pad < (double)std::min<size_t>(nq, 256)) nq_pad *= 2;
     const double groups = std::ceil((double)nq / 256.0);
     // (K2b: the pass streams at ~0.85 of a plain scan's rate -- the matrix pipe is busy 60 % of
     // the time beside it -- and every query adds a few hundred candidates to re-score: 6.5-6.9 ms
     // per 256 queries at 30 GB where K1m's sweep of eight takes 5.5)
-    const double t_pass = bf16 ? std::max(1.2 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kNominateFlopsPerS) +
+    // (64 / 128 columns: 4.70 / 4.79 ms per pass at 30.72 GB against 4.48 for a plain scan; 256: 5.3-5.45)
+    const double k2b_stream = nq_pad <= 64 ? 1.05 : nq_pad <= 128 ? 1.08 : 1.2;
+    const double t_pass = bf16 ? std::max(k2b_stream * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kNominateFlopsPerS) +
                                      (double)std::min<size_t>(nq, 256) * 2.5e-6
                                : std::max(1.3 * bytes / kScanBytesPerS, 2.0 * ix->n * nq_pad * ix->ld / kBatchFlopsPerS);
     double t_other = (double)nq * scan_seconds(bytes);
