@@ -1568,3 +1568,55 @@ def test_concurrent_quantized_callers_share_sweeps(nifs, oracle_mod, monkeypatch
     # (how many calls met is a matter of timing -- Python threads on 0.1-ms calls -- and is measured
     # where it matters, bench.py's side.callers_quantized at N = 10 M; here only: whoever met got his own answer)
     print("coalesced: %d batches, %d calls in batches" % (b1[0] - b0[0], b1[1] - b0[1]))
+
+
+@pytest.mark.parametrize("metric", [7, 8])
+@pytest.mark.parametrize("d", [24, 100, 600, 768])
+def test_pattern_metrics_read_the_non_zero_bits(nifs, oracle_mod, metric, d):
+    """Float hamming / jaccard compare which coordinates are non-zero (distances.rs:319-347): on a
+    corpus of 16 384 rows or more flat_search reads a column of non-zero bits (K4) instead of the
+    rows.  Hits and scores must be the oracle's bit for bit -- single searches, limits that take
+    several K4 passes, batches -- before and after inserts in any id order, upserts (zeros that
+    become non-zero, -0.0 that stays zero) and deletes, which patch the column per row."""
+    n = 20_000
+    rng = np.random.default_rng(700 + metric + d)
+    density = rng.uniform(0.05, 0.95, (n + 300, 1))
+    x = (rng.uniform(-1, 1, (n + 300, d)) * (rng.uniform(0, 1, (n + 300, d)) < density)).astype(np.float32)
+    x[rng.uniform(0, 1, x.shape) < 0.01] = -0.0
+    x[5] = 0.0                                             # an all-zero row (jaccard: union 0 against a zero query)
+    ids = [b"doc-%05d" % i for i in range(n + 300)]
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids[:n], x[:n]))
+    cur = {ids[i]: x[i] for i in range(n)}
+    nifs.flat_set_profiling(g.ref, True)
+
+    def check(limits=(1, 10)):
+        keys = sorted(cur)
+        mat = np.stack([cur[k] for k in keys])
+        packed = oracle_mod.pack_ids(keys)
+        qs = [x[int(rng.integers(0, n))], np.zeros(d, np.float32),
+              (rng.uniform(-1, 1, d) * (rng.uniform(0, 1, d) < 0.3)).astype(np.float32)]
+        for q in qs:
+            for limit in limits:
+                nifs.flat_get_profile(g.ref, reset=True)
+                got = unwrap(nifs.flat_search(g.ref, q, limit))
+                prof = nifs.flat_get_profile(g.ref, reset=True)
+                assert bits(got) == bits(oracle_mod.matrix_search(metric, mat, packed, q, limit))
+                # (a boundary tie among rows that arrived out of id order may re-run once the ranks are rebuilt)
+                assert prof["hamming_launches"] >= 1 and prof["scan_launches"] == 0, prof
+        batch = np.stack(qs + [x[11], x[12]])
+        got = unwrap(nifs.flat_search_batch(g.ref, batch, 7))
+        for i in range(len(batch)):
+            assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, mat, packed, batch[i], 7))
+
+    check(limits=(1, 10, 300, 1500))
+    for step in range(4):
+        for j in range(25):                                # appends in descending id order (lazy ranks)
+            i = n + 299 - (step * 25 + j)
+            g.insert(ids[i], x[i]); cur[ids[i]] = x[i]
+        up = ids[step * 41 + 5]                            # upserts: zeros <-> non-zeros
+        v = np.where(cur[up] == 0, np.float32(0.5), np.float32(-0.0)).astype(np.float32)
+        g.insert(up, v); cur[up] = v
+        for victim in (ids[2000 + step], ids[n - 1 - step]):
+            g.delete(victim); cur.pop(victim, None)
+        check()

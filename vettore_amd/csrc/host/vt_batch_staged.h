@@ -450,7 +450,10 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
   // what the matrix cores did not take (no GEMM form for this metric, a small batch, a query
   // the bound could not certify): several queries per sweep of the corpus when their lists
   // fit, else one scan each
-  if (left.size() >= 2 && multi_scan_applies(ix, limit) &&
+  // (float hamming / jaccard with a current non-zero-bit column: each query is a K4 pass over 1/32
+  // of the bytes a sweep reads -- search_ready takes it)
+  const bool by_pattern = pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit);
+  if (!by_pattern && left.size() >= 2 && multi_scan_applies(ix, limit) &&
       (multi_scan_seconds(ix, left.size()) < (double)left.size() * scan_seconds((double)ix->n * ix->ld * 4.0) ||
        std::getenv("VT_FORCE_MULTI_SCAN"))) {  // (tests force the sweep on corpora of a few thousand rows)
     const int st = multi_scan_group(ix, c, queries, left, limit, out);

@@ -375,7 +375,7 @@ int batch_multi(vt_flat *h, const float *queries, size_t nq, size_t d, size_t li
   std::vector<std::vector<vt_hits *>> per(S, std::vector<vt_hits *>(nq, nullptr));
   int rc = on_all_shards(h, [&](size_t s) -> int {
     Shard *ix = h->shards[s].get();
-    const unsigned need = NEED_STRICT_RANKS | (batch_uses_mfma(ix, nq, limit) ? NEED_NORMS : 0u);
+    const unsigned need = NEED_STRICT_RANKS | NEED_NZBITS | (batch_uses_mfma(ix, nq, limit) ? NEED_NORMS : 0u);
     if (shard_stale(ix, need, limit)) VT_TRY(shard_prepare(ix, need, limit));
     return batch_ready(ix, ix->ctx, queries, nq, d, limit, per[s].data());
   });
@@ -724,7 +724,7 @@ int search_direct(vt_flat *h, const float *query, size_t n, size_t limit, vt_hit
     if (h->poisoned) return poisoned_status();
     return search_multi(h, query, n, limit, out);
   }
-  return read_single(h, NEED_RANKS, limit,
+  return read_single(h, NEED_RANKS | NEED_NZBITS, limit,
                      [&](Shard *ix, Ctx &c) -> int { return search_ready(ix, c, query, n, limit, out); });
 }
 
@@ -813,7 +813,7 @@ int batch_direct(vt_flat *h, const float *queries, size_t nq, size_t d, size_t l
     if (h->poisoned) return poisoned_status();
     st = batch_multi(h, queries, nq, d, limit, out);
   } else {
-    unsigned need = NEED_STRICT_RANKS;
+    unsigned need = NEED_STRICT_RANKS | NEED_NZBITS;
     {
       std::shared_lock<std::shared_mutex> rl(h->rw);
       if (batch_uses_mfma(h->shards[0].get(), nq, limit)) need |= NEED_NORMS;

@@ -6,7 +6,7 @@
 namespace {
 
 // ---- what a reader needs up to date before it may run under the shared lock ----------
-enum : unsigned { NEED_RANKS = 1, NEED_STRICT_RANKS = 2, NEED_BITS = 4, NEED_NORMS = 8 };
+enum : unsigned { NEED_RANKS = 1, NEED_STRICT_RANKS = 2, NEED_BITS = 4, NEED_NORMS = 8, NEED_NZBITS = 16 };
 // Internal: only the true id order can decide (a tie at the boundary of a lazy search).
 constexpr int kEscalate = -101;
 
@@ -22,6 +22,21 @@ bool lazy_ranks_ok(const Shard *ix, size_t limit) {
          ix->unranked <= std::max<size_t>(65536, ix->n / 8) && !std::getenv("VT_EAGER_RANKS");
 }
 
+// Float hamming and jaccard compare which coordinates are non-zero and nothing else
+// (distances.rs:319-347), so on a collection under one of them flat_search is K4 over a column of
+// non-zero bits -- d / 8 bytes per row instead of 4 d, the same integers, the same f32 score, the
+// same keys -- once the corpus is big enough for the column to pay for its upkeep and as long as
+// the hits fit a few K4 passes (K1's one-pass threshold path serves the larger limits).
+// NEED_NZBITS asks for that column and means nothing where this says no.
+constexpr size_t kPatternMinRows = 16384, kPatternMaxWant = 8 * (size_t)vt::kMaxFusedK;
+bool pattern_metric(int metric) {
+  static const bool off = std::getenv("VT_NO_PATTERN_BITS") != nullptr;  // (A/B and the parity tests' second leg)
+  return (metric == VT_HAMMING || metric == VT_JACCARD) && !off;
+}
+bool pattern_search_applies(const Shard *ix, size_t limit) {
+  return pattern_metric(ix->metric) && ix->n >= kPatternMinRows && std::min<size_t>(limit, ix->n) + 1 <= kPatternMaxWant;
+}
+
 bool shard_stale(const Shard *ix, unsigned need, size_t limit) {
   if (ix->n == 0) return false;
   const size_t rows = std::max<size_t>(ix->cap, ix->n);
@@ -33,11 +48,15 @@ bool shard_stale(const Shard *ix, unsigned need, size_t limit) {
     const size_t bwords = vt::hamming_matrix_words((uint32_t)rows, ((uint32_t)ix->dim + 63) / 64);
     if (!ix->bits_valid || !ix->bits_dirty.empty() || ix->dBits.count < bwords) return true;
   }
+  if ((need & NEED_NZBITS) && pattern_search_applies(ix, limit)) {
+    const size_t bwords = vt::hamming_matrix_words((uint32_t)rows, ((uint32_t)ix->dim + 63) / 64);
+    if (!ix->nz_valid || !ix->nz_dirty.empty() || ix->dNzBits.count < bwords) return true;
+  }
   if ((need & NEED_NORMS) && (ix->max_sqnorm < 0.0 || !ix->norm_dirty.empty() || ix->dXnorm2.count < rows)) return true;
   return false;
 }
 
-int index_ensure_bits(Shard *ix);
+int index_ensure_bits(Shard *ix, bool nonzero = false);
 int index_ensure_norms(Shard *ix);
 
 // Brings the derived columns a reader needs up to date (exclusive access; primary context).
@@ -48,6 +67,7 @@ int shard_prepare(Shard *ix, unsigned need, size_t limit) {
     else VT_TRY(index_sync_ranks(ix, false));
   }
   if (need & NEED_BITS) VT_TRY(index_ensure_bits(ix));
+  if ((need & NEED_NZBITS) && pattern_search_applies(ix, limit)) VT_TRY(index_ensure_bits(ix, true));
   if (need & NEED_NORMS) VT_TRY(index_ensure_norms(ix));
   return VT_OK;
 }
@@ -60,8 +80,10 @@ int search_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t limit, 
   if (ix->n == 0) return empty_hits(out);
   const bool lazy = !ix->ranks_clean;
   const size_t lazy_want = std::min<size_t>(limit, ix->n) + (limit < ix->n ? 1 : 0);
+  // (a non-zero-bit column that is not current is simply not used: the rows always are)
+  const bool by_pattern = pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit);
   uint32_t qnz = 0;
-  VT_TRY(upload_query(c, query, n, &qnz));
+  VT_TRY(upload_query(c, query, n, &qnz, by_pattern ? 2 : 0));
   ScanJob j{};
   j.X = ix->dX;
   j.stride = ix->ld;
@@ -74,10 +96,15 @@ int search_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t limit, 
   j.order = ix->order;
   j.q_nonzero = qnz;
   std::vector<vt::Entry> entries;
+  auto best_rows = [&](size_t want) -> int {
+    if (by_pattern)
+      return run_hamming(c, ix->dNzBits.p, c.dQbits, ix->dRank.p, ix->n, j.d, want, entries, true, ix->metric == VT_JACCARD);
+    return run_scan(c, j, want, entries, true);
+  };
   if (lazy) {
     // one hit more than asked for: if it does not tie with the last wanted one, the set is
     // exact whatever the unranked rows' id order is, and equal-rank runs are put in id order here
-    VT_TRY(run_scan(c, j, lazy_want, entries, true));
+    VT_TRY(best_rows(lazy_want));
     const bool ambiguous = limit < ix->n && entries.size() == lazy_want &&
                            rank_key_of(entries[limit - 1].key) == rank_key_of(entries[limit].key);
     if (ambiguous) return kEscalate;  // a tie across the boundary: only the true id order can cut it
@@ -92,14 +119,14 @@ int search_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t limit, 
     }
     return make_hits(ix, entries, out);
   }
-  VT_TRY(run_scan(c, j, limit, entries, true));
+  VT_TRY(best_rows(limit));
   return make_hits(ix, entries, out);
 }
 
 // The same for a caller that owns the shard outright (a shard worker, or any caller under
 // the exclusive lock): prepare, run on the primary context, settle a boundary tie.
 int search_owner(Shard *ix, const float *query, size_t n, size_t limit, vt_hits **out) {
-  if (shard_stale(ix, NEED_RANKS, limit)) VT_TRY(shard_prepare(ix, NEED_RANKS, limit));
+  if (shard_stale(ix, NEED_RANKS | NEED_NZBITS, limit)) VT_TRY(shard_prepare(ix, NEED_RANKS | NEED_NZBITS, limit));
   int st = search_ready(ix, ix->ctx, query, n, limit, out);
   if (st == kEscalate) {
     VT_TRY(shard_prepare(ix, NEED_STRICT_RANKS, limit));
@@ -383,26 +410,30 @@ int funnel_rows(Shard *ix, Ctx &c, const float *query, const size_t *stages, siz
   return VT_OK;
 }
 
-// Sign bits of every stored row in K4's layout, built on first use.
-int index_ensure_bits(Shard *ix) {
+// Sign bits of every stored row in K4's layout, built on first use (`nonzero`: the column of
+// non-zero bits that flat_search under float hamming / jaccard reads instead of the rows).
+int index_ensure_bits(Shard *ix, bool nonzero) {
   Ctx &c = ix->ctx;
   const uint32_t d = (uint32_t)ix->dim, words = (d + 63) / 64;
+  DevBuf<uint64_t> &col = nonzero ? ix->dNzBits : ix->dBits;
+  bool &valid = nonzero ? ix->nz_valid : ix->bits_valid;
+  std::vector<uint32_t> &dirty = nonzero ? ix->nz_dirty : ix->bits_dirty;
   // compress_sign_bits of every stored row (collection.ex:926): kept in HBM
   const size_t bwords = vt::hamming_matrix_words(std::max<uint32_t>(ix->cap, ix->n), words);
-  if (ix->bits_valid && ix->dBits.count >= bwords) {
+  if (valid && col.count >= bwords) {
     // only the rows mutated since the last use
     uint32_t count = 0;
-    VT_TRY(upload_row_list(ix, ix->bits_dirty, &count));
-    VT_HIP(vt::launch_sign_pack_rows(ix->dX, ix->ld, c.dRankPairs.p, count, d, ix->dBits.p, c.stream));
+    VT_TRY(upload_row_list(ix, dirty, &count));
+    VT_HIP(vt::launch_sign_pack_rows(ix->dX, ix->ld, c.dRankPairs.p, count, d, col.p, c.stream, nonzero ? 1 : 0));
     if (count) VT_HIP(hipStreamSynchronize(c.stream));  // the pinned list is reused by the next caller
-    ix->bits_dirty.clear();
+    dirty.clear();
     return VT_OK;
   }
-  ix->bits_dirty.clear();
-  VT_TRY(ix->dBits.ensure(bwords));
-  VT_HIP(hipMemsetAsync(ix->dBits.p, 0, bwords * sizeof(uint64_t), c.stream));
-  VT_HIP(vt::launch_sign_pack(ix->dX, ix->ld, ix->n, d, ix->dBits.p, 1, c.stream));
-  ix->bits_valid = true;
+  dirty.clear();
+  VT_TRY(col.ensure(bwords));
+  VT_HIP(hipMemsetAsync(col.p, 0, bwords * sizeof(uint64_t), c.stream));
+  VT_HIP(vt::launch_sign_pack(ix->dX, ix->ld, ix->n, d, col.p, 1, c.stream, nonzero ? 1 : 0));
+  valid = true;
   return VT_OK;
 }
 

@@ -359,7 +359,7 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
 }
 
 int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint32_t *id_rank, uint32_t n, uint32_t d,
-                size_t want, std::vector<vt::Entry> &out, bool count_profile) {
+                size_t want, std::vector<vt::Entry> &out, bool count_profile, bool jaccard = false) {
   const uint32_t words = (d + 63) / 64;
   const uint32_t ntiles = (n + 63) / 64;
   uint64_t lo = 0;
@@ -384,6 +384,7 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
     a.has_lo = has_lo ? 1 : 0;
     a.part_keys = c.dPartKeys.p;
     a.part_pay = c.dPartPay.p;
+    a.jaccard = jaccard ? 1 : 0;
     if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
     VT_HIP(vt::launch_hamming(a, blocks, c.stream));
     if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
@@ -408,7 +409,9 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
 // `with_bits`: the query's sign bits (compress_sign_bits, distances.rs:413-423: bit i % 64 of
 // word i / 64 set iff v[i] >= 0.0, padding bits zero) are packed on the host -- n compares --
 // and ride behind the floats in the same copy; c.dQbits points at them.
-int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero, bool with_bits = false) {
+// with_bits == 2: the non-zero bits instead (bit set iff v[i] != 0.0: what float hamming / jaccard
+// compare, distances.rs:319-347).
+int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero, int with_bits = 0) {
   const uint32_t ld = vt::padded_dim((uint32_t)n);
   const size_t words = (n + 63) / 64;
   const size_t total = (size_t)ld + (with_bits ? 2 * words : 0);  // in floats (ld is a multiple of 64: the words are 8-byte aligned)
@@ -425,7 +428,7 @@ int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero, bool wit
     uint64_t *w = reinterpret_cast<uint64_t *>(c.hQ.p + ld);
     for (size_t i = 0; i < words; ++i) w[i] = 0;
     for (size_t i = 0; i < n; ++i)
-      if (q[i] >= 0.0f) w[i / 64] |= 1ull << (i % 64);
+      if (with_bits == 2 ? q[i] != 0.0f : q[i] >= 0.0f) w[i / 64] |= 1ull << (i % 64);
     c.dQbits = reinterpret_cast<uint64_t *>(c.dQ.p + ld);
   }
   VT_HIP(hipMemcpyAsync(c.dQ.p, c.hQ.p, total * sizeof(float), hipMemcpyHostToDevice, c.stream));

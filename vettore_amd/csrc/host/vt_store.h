@@ -68,8 +68,10 @@ int index_set_dim(Shard *ix, size_t d) {
   const uint32_t ld = vt::padded_dim((uint32_t)d);
   ix->for_each_ctx([](Ctx &c) { c.ham_dirty = true; });  // K4h's histograms are cleared for d + 1 bins only: a new dimension starts clean
   ix->bits_valid = false;    // derived per-row data belongs to the old rows
+  ix->nz_valid = false;
   ix->max_sqnorm = -1.0;
   ix->bits_dirty.clear();
+  ix->nz_dirty.clear();
   ix->norm_dirty.clear();
   if (ld != ix->ld) {
     VT_HIP(hipStreamSynchronize(ix->ctx.stream));
@@ -256,13 +258,20 @@ struct RowSource {
 
 constexpr size_t kMaxDerivedDirty = 65536;  // more mutated rows than this: rebuild instead of patching
 
-// Row `r` changed: its sign bits and norm are stale.
+// Row `r` changed: its sign bits, non-zero bits and norm are stale.
 inline void index_touch_row(Shard *ix, uint32_t r) {
   if (ix->bits_valid) {
     ix->bits_dirty.push_back(r);
     if (ix->bits_dirty.size() > kMaxDerivedDirty) {
       ix->bits_valid = false;
       ix->bits_dirty.clear();
+    }
+  }
+  if (ix->nz_valid) {
+    ix->nz_dirty.push_back(r);
+    if (ix->nz_dirty.size() > kMaxDerivedDirty) {
+      ix->nz_valid = false;
+      ix->nz_dirty.clear();
     }
   }
   if (ix->max_sqnorm >= 0.0) {
@@ -343,8 +352,10 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
 #endif
   if (count > kMaxDerivedDirty) {
     ix->bits_valid = false;
+    ix->nz_valid = false;
     ix->max_sqnorm = -1.0;
     ix->bits_dirty.clear();
+    ix->nz_dirty.clear();
     ix->norm_dirty.clear();
   } else {
     for (size_t i = 0; i < count; ++i) index_touch_row(ix, target[i]);

@@ -169,6 +169,12 @@ struct Shard {
   // Rows mutated since the bit matrix / the norms were last brought up to date; patched in
   // place at the next use (a full rebuild is a pass over the whole corpus).
   std::vector<uint32_t> bits_dirty, norm_dirty;
+  // The same for float hamming / jaccard collections: one bit per coordinate, set iff it is
+  // non-zero -- all those two metrics look at (distances.rs:319-347) -- in K4's layout; flat_search
+  // reads these 1/32 of the row bytes instead of the rows (vt_search.h, pattern_search_applies).
+  DevBuf<uint64_t> dNzBits;
+  bool nz_valid = false;
+  std::vector<uint32_t> nz_dirty;
   double max_sqnorm = -1.0;  // max_i sum_j x_ij^2, < 0 = stale (error margin of the batched path)
   DevBuf<float> dXnorm2;     // per-row squared norms, valid with max_sqnorm
   // ids

@@ -194,6 +194,7 @@ struct HammingArgs {
   int has_lo;
   uint64_t *part_keys;
   Payload *part_pay;
+  int jaccard;  // the bits are non-zero patterns and the score is distances.rs:327-347's (else the differing bits)
 };
 hipError_t launch_hamming(const HammingArgs &a, uint32_t blocks, hipStream_t s);
 
@@ -253,8 +254,10 @@ hipError_t launch_hamming_collect(const HammingCollectArgs &a, uint32_t blocks, 
 
 // rows[n][stride] (first d columns) -> sign bits, bit j%64 of word j/64 set iff
 // v[j] >= 0.0 (distances.rs:413-423).  tiled: K4's layout, else plain [n][words].
+// nonzero: the bit says v[j] != 0.0 instead (the "truthiness" float hamming / jaccard compare,
+// distances.rs:319-347).
 hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32_t d, uint64_t *bits, int tiled,
-                            hipStream_t s);
+                            hipStream_t s, int nonzero = 0);
 
 // *flag |= 1 if any of the first d columns of any row is non-finite.
 hipError_t launch_check_finite(const float *rows, size_t stride, uint32_t n, uint32_t d, int *flag, hipStream_t s);
@@ -269,7 +272,7 @@ hipError_t launch_gather_rows(const float *src, uint32_t d, const uint32_t *map,
 
 // K5 / row norms for a device list of rows (derived data of mutated rows patched in place).
 hipError_t launch_sign_pack_rows(const float *rows, size_t stride, const uint32_t *list, uint32_t count, uint32_t d,
-                                 uint64_t *bits, hipStream_t s);
+                                 uint64_t *bits, hipStream_t s, int nonzero = 0);
 hipError_t launch_row_sqnorms_rows(const float *X, size_t stride, const uint32_t *list, uint32_t count, uint32_t d,
                                    float *xnorm2, unsigned long long *out_bits, hipStream_t s);
 

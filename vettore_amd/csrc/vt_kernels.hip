@@ -489,7 +489,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
   tk.init(hsmem + wib * WaveTopK<CAP>::lds_bytes(), a.k);
   for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
     const u64x2 *base = bits + ((size_t)t * pairs * kWave + lane);
-    uint32_t ham = 0;
+    // `ham` counts the differing bits; in the pattern mode for jaccard `both` counts the bits set on
+    // both sides as well (padding bits are zero on both sides there: no mask needed for the AND)
+    uint32_t ham = 0, both = 0;
     if (PAIRS > 0) {
       u64x2 v[PAIRS > 0 ? PAIRS : 1];
 #pragma unroll
@@ -500,6 +502,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
         const uint64_t q0 = a.qbits[w0], q1 = w1 < a.words ? a.qbits[w1] : 0ull;
         const uint64_t m0 = w0 == last_word ? last_mask : ~0ull, m1 = w1 == last_word ? last_mask : ~0ull;
         ham += __popcll((v[j].x ^ q0) & m0) + __popcll((v[j].y ^ q1) & m1);
+        if (a.jaccard) both += __popcll(v[j].x & q0 & m0) + __popcll(v[j].y & q1 & m1);
       }
     } else {
       for (uint32_t j = 0; j < pairs; ++j) {
@@ -508,12 +511,17 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
         const uint64_t q0 = a.qbits[w0], q1 = w1 < a.words ? a.qbits[w1] : 0ull;
         const uint64_t m0 = w0 == last_word ? last_mask : ~0ull, m1 = w1 == last_word ? last_mask : ~0ull;
         ham += __popcll((v.x ^ q0) & m0) + __popcll((v.y ^ q1) & m1);
+        if (a.jaccard) both += __popcll(v.x & q0 & m0) + __popcll(v.y & q1 & m1);
       }
     }
     const uint32_t grow = t * kWave + lane;
     bool valid = grow < a.n;
     const uint32_t my_rank = (valid && a.id_rank) ? a.id_rank[grow] : grow;
-    const float raw = (float)ham;  // distance as f32 (distances.rs:436)
+    float raw = (float)ham;  // distance as f32 (distances.rs:436; :319-324 over non-zero bits)
+    if (a.jaccard) {         // distances.rs:327-347: union = differing + common coordinates
+      const uint32_t uni = ham + both;
+      raw = uni == 0 ? 0.0f : 1.0f - (float)both / (float)uni;
+    }
     const uint64_t key = ((uint64_t)orderable(raw) << 32) | my_rank;
     if (a.has_lo) valid = valid && key > a.lo_key;
     tk.offer(valid, key, grow, raw, lane);
@@ -835,7 +843,7 @@ __global__ __launch_bounds__(256) void hamming_collect_kernel(const HammingColle
 // tiled != 0 writes K4's [tile][pair][row][2] layout, else plain [row][word].
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sign_pack_kernel(const float *__restrict__ rows, size_t stride, uint32_t n,
-                                                        uint32_t d, uint64_t *__restrict__ bits, int tiled) {
+                                                        uint32_t d, uint64_t *__restrict__ bits, int tiled, int nonzero) {
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t W = (d + 63) / 64;
   const uint32_t pairs = (W + 1) / 2;
@@ -845,7 +853,10 @@ __global__ __launch_bounds__(256) void sign_pack_kernel(const float *__restrict_
     const uint32_t r = (uint32_t)(w / W), wi = (uint32_t)(w - (uint64_t)r * W);
     const uint32_t j = wi * 64 + lane;
     bool bit = false;
-    if (j < d) bit = rows[(size_t)r * stride + j] >= 0.0f;
+    if (j < d) {
+      const float v = rows[(size_t)r * stride + j];
+      bit = nonzero ? v != 0.0f : v >= 0.0f;
+    }
     const uint64_t word = __ballot(bit);
     if (lane == 0) {
       const size_t at = tiled ? hamming_word_index(r, wi, pairs) : (size_t)w;
@@ -868,7 +879,7 @@ __global__ __launch_bounds__(256) void check_finite_kernel(const float *__restri
 // K5 for a list of rows (bits of mutated rows patched in place, tiled layout).
 __global__ __launch_bounds__(256) void sign_pack_rows_kernel(const float *__restrict__ rows, size_t stride,
                                                              const uint32_t *__restrict__ list, uint32_t count, uint32_t d,
-                                                             uint64_t *__restrict__ bits) {
+                                                             uint64_t *__restrict__ bits, int nonzero) {
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t W = (d + 63) / 64;
   const uint32_t pairs = (W + 1) / 2;
@@ -879,7 +890,10 @@ __global__ __launch_bounds__(256) void sign_pack_rows_kernel(const float *__rest
     const uint32_t r = list[i];
     const uint32_t j = wi * 64 + lane;
     bool bit = false;
-    if (j < d) bit = rows[(size_t)r * stride + j] >= 0.0f;
+    if (j < d) {
+      const float v = rows[(size_t)r * stride + j];
+      bit = nonzero ? v != 0.0f : v >= 0.0f;
+    }
     const uint64_t word = __ballot(bit);
     if (lane == 0) bits[hamming_word_index(r, wi, pairs)] = word;
   }
@@ -1548,9 +1562,9 @@ hipError_t launch_select_lists(const uint64_t *keys, const Payload *pay, uint32_
 }
 
 hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32_t d, uint64_t *bits, int tiled,
-                            hipStream_t s) {
+                            hipStream_t s, int nonzero) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(sign_pack_kernel, dim3(2048), dim3(256), 0, s, rows, stride, n, d, bits, tiled);
+  hipLaunchKernelGGL(sign_pack_kernel, dim3(2048), dim3(256), 0, s, rows, stride, n, d, bits, tiled, nonzero);
   return hipGetLastError();
 }
 
@@ -1561,10 +1575,11 @@ hipError_t launch_check_finite(const float *rows, size_t stride, uint32_t n, uin
 }
 
 hipError_t launch_sign_pack_rows(const float *rows, size_t stride, const uint32_t *list, uint32_t count, uint32_t d,
-                                 uint64_t *bits, hipStream_t s) {
+                                 uint64_t *bits, hipStream_t s, int nonzero) {
   if (count == 0) return hipSuccess;
   const uint32_t blocks = (uint32_t)std::min<uint64_t>(2048, ((uint64_t)count * ((d + 63) / 64) + 3) / 4);
-  hipLaunchKernelGGL(sign_pack_rows_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, rows, stride, list, count, d, bits);
+  hipLaunchKernelGGL(sign_pack_rows_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, rows, stride, list, count, d, bits,
+                     nonzero);
   return hipGetLastError();
 }
 
