@@ -324,7 +324,7 @@ typedef struct vt_profile {
   double scan_ms;           /* sum of their durations (hipEventElapsedTime) */
   uint64_t scan_rows;       /* rows scanned by those launches */
   uint64_t scan_bytes;      /* algorithmic bytes: rows * d * 4 */
-  uint64_t hamming_launches;
+  uint64_t hamming_launches; /* packed-bit passes: quantized candidates; flat searches under float hamming / jaccard */
   double hamming_ms;
   uint64_t hamming_bytes;   /* rows * ceil(d/64) * 8 per launch (one launch may serve up to 8 queries) */
   uint64_t merge_launches;

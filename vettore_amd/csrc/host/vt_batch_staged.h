@@ -451,8 +451,13 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
   // the bound could not certify): several queries per sweep of the corpus when their lists
   // fit, else one scan each
   // (float hamming / jaccard with a current non-zero-bit column: each query is a K4 pass over 1/32
-  // of the bytes a sweep reads -- search_ready takes it)
-  const bool by_pattern = pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit);
+  // of the bytes a sweep reads, and search_ready below takes it -- unless a sweep of the rows for
+  // eight queries is cheaper than eight such passes with their ~50 us of launches, select and wait
+  // each, as it is on corpora below a GB or two)
+  const double pattern_s = 50e-6 + (double)ix->n * (double)(((size_t)ix->dim + 63) / 64 * 8) / 5.5e12;
+  const bool by_pattern = pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit) &&
+                          (left.size() < 2 || !multi_scan_applies(ix, limit) ||
+                           (double)left.size() * pattern_s < multi_scan_seconds(ix, left.size()));
   if (!by_pattern && left.size() >= 2 && multi_scan_applies(ix, limit) &&
       (multi_scan_seconds(ix, left.size()) < (double)left.size() * scan_seconds((double)ix->n * ix->ld * 4.0) ||
        std::getenv("VT_FORCE_MULTI_SCAN"))) {  // (tests force the sweep on corpora of a few thousand rows)
