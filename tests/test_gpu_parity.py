@@ -1620,3 +1620,26 @@ def test_pattern_metrics_read_the_non_zero_bits(nifs, oracle_mod, metric, d):
         for victim in (ids[2000 + step], ids[n - 1 - step]):
             g.delete(victim); cur.pop(victim, None)
         check()
+
+
+def test_no_room_for_the_non_zero_bits_means_reading_the_rows(nifs, oracle_mod, request, monkeypatch):
+    """The non-zero-bit column is an accelerator: when the card has no room for it the searches keep
+    reading the rows, with the same hits.  (The refused allocation is injected --
+    VT_TEST_REFUSE_NZBITS, libvettore_hip_hooks.so only: the test re-runs itself there.)"""
+    if support.rerun_with_hooks_library(request):
+        return
+    monkeypatch.setenv("VT_TEST_REFUSE_NZBITS", "1")
+    n, d = 20_000, 100
+    rng = np.random.default_rng(77)
+    x = (rng.uniform(-1, 1, (n, d)) * (rng.uniform(0, 1, (n, d)) < 0.4)).astype(np.float32)
+    ids = [b"doc-%05d" % i for i in range(n)]
+    packed = oracle_mod.pack_ids(ids)
+    for metric in (7, 8):
+        g = GpuIndex(nifs, metric)
+        unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+        nifs.flat_set_profiling(g.ref, True)
+        for q in (x[3], x[4]):
+            got = unwrap(nifs.flat_search(g.ref, q, 10))
+            assert bits(got) == bits(oracle_mod.matrix_search(metric, x, packed, q, 10))
+        prof = nifs.flat_get_profile(g.ref, reset=True)
+        assert prof["hamming_launches"] == 0 and prof["scan_launches"] >= 2, prof

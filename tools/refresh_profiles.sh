@@ -82,8 +82,10 @@ hf, _ = per_launch(out + '/quantized_fetch/p_counter_collection.csv', 'hamming_d
 print("hamming FETCH_SIZE KiB per launch", hf, "x2 bytes", 2 * hf * 1024)
 ff, _ = per_launch(out + '/funnel_fetch/p_counter_collection.csv', 'cosine_scan_kernel', 'FETCH_SIZE')
 bf, _ = per_launch(out + '/batch_fetch/p_counter_collection.csv', 'mfma_scores_kernel<8, false>', 'FETCH_SIZE')
-b16, _ = per_launch(out + '/batch_bf16_fetch/p_counter_collection.csv', 'bf16_scores_kernel<false>', 'FETCH_SIZE')
-keep(out + '/batch_bf16_fetch/p_counter_collection.csv', out + '/%s_batch_bf16_pmc_fetch.csv' % RND, 'bf16_scores_kernel<false>')
+# (the 256-column candidate pass of a 256-query batch: bf16_scores_kernel<DENSE = false, QT = 8>)
+K2B = 'bf16_scores_kernel<false, 8>'
+b16, _ = per_launch(out + '/batch_bf16_fetch/p_counter_collection.csv', K2B, 'FETCH_SIZE')
+keep(out + '/batch_bf16_fetch/p_counter_collection.csv', out + '/%s_batch_bf16_pmc_fetch.csv' % RND, K2B)
 print("bf16_scores_kernel FETCH_SIZE x2 bytes", 2 * b16 * 1024)
 keep(out + '/funnel_fetch/p_counter_collection.csv', out + '/%s_funnel_pmc_fetch.csv' % RND, 'cosine_scan_kernel')
 keep(out + '/batch_fetch/p_counter_collection.csv', out + '/%s_batch_pmc_fetch.csv' % RND, 'mfma_scores_kernel<8, false>')

@@ -34,7 +34,8 @@ bool pattern_metric(int metric) {
   return (metric == VT_HAMMING || metric == VT_JACCARD) && !off;
 }
 bool pattern_search_applies(const Shard *ix, size_t limit) {
-  return pattern_metric(ix->metric) && ix->n >= kPatternMinRows && std::min<size_t>(limit, ix->n) + 1 <= kPatternMaxWant;
+  return pattern_metric(ix->metric) && !ix->nz_refused && ix->n >= kPatternMinRows &&
+         std::min<size_t>(limit, ix->n) + 1 <= kPatternMaxWant;
 }
 
 bool shard_stale(const Shard *ix, unsigned need, size_t limit) {
@@ -430,7 +431,25 @@ int index_ensure_bits(Shard *ix, bool nonzero) {
     return VT_OK;
   }
   dirty.clear();
-  VT_TRY(col.ensure(bwords));
+  if (nonzero) {
+    // (an accelerator, not a requirement: on a card too full for d / 8 more bytes per row the
+    // searches keep reading the rows)
+    valid = false;
+    bool refused = col.ensure(bwords) != VT_OK;
+#ifdef VT_TEST_HOOKS
+    // (libvettore_hip_hooks.so only: the allocation "fails", tests/test_gpu_parity.py checks what follows)
+    if (std::getenv("VT_TEST_REFUSE_NZBITS")) {
+      col.release();
+      refused = true;
+    }
+#endif
+    if (refused) {
+      ix->nz_refused = true;
+      return VT_OK;
+    }
+  } else {
+    VT_TRY(col.ensure(bwords));
+  }
   VT_HIP(hipMemsetAsync(col.p, 0, bwords * sizeof(uint64_t), c.stream));
   VT_HIP(vt::launch_sign_pack(ix->dX, ix->ld, ix->n, d, col.p, 1, c.stream, nonzero ? 1 : 0));
   valid = true;

@@ -69,6 +69,7 @@ int index_set_dim(Shard *ix, size_t d) {
   ix->for_each_ctx([](Ctx &c) { c.ham_dirty = true; });  // K4h's histograms are cleared for d + 1 bins only: a new dimension starts clean
   ix->bits_valid = false;    // derived per-row data belongs to the old rows
   ix->nz_valid = false;
+  ix->nz_refused = false;
   ix->max_sqnorm = -1.0;
   ix->bits_dirty.clear();
   ix->nz_dirty.clear();

@@ -174,6 +174,7 @@ struct Shard {
   // reads these 1/32 of the row bytes instead of the rows (vt_search.h, pattern_search_applies).
   DevBuf<uint64_t> dNzBits;
   bool nz_valid = false;
+  bool nz_refused = false;  // the card had no room for the column: searches keep reading the rows (until the index is emptied)
   std::vector<uint32_t> nz_dirty;
   double max_sqnorm = -1.0;  // max_i sum_j x_ij^2, < 0 = stale (error margin of the batched path)
   DevBuf<float> dXnorm2;     // per-row squared norms, valid with max_sqnorm
