@@ -1604,10 +1604,18 @@ def test_pattern_metrics_read_the_non_zero_bits(nifs, oracle_mod, metric, d):
                 assert bits(got) == bits(oracle_mod.matrix_search(metric, mat, packed, q, limit))
                 # (a boundary tie among rows that arrived out of id order may re-run once the ranks are rebuilt)
                 assert prof["hamming_launches"] >= 1 and prof["scan_launches"] == 0, prof
-        batch = np.stack(qs + [x[11], x[12]])
-        got = unwrap(nifs.flat_search_batch(g.ref, batch, 7))
-        for i in range(len(batch)):
-            assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, mat, packed, batch[i], 7))
+        # batches: up to eight queries per sweep of the column (K4p) when the lists fit its wave
+        # buffers (limit <= 64) and the row length has an unrolled build (not d = 600: 5 word pairs)
+        batch = np.stack(qs + [x[11 + i] for i in range(16)])            # 19 queries: sweeps of 8 + 8 + 3
+        for limit in (7, 64, 65):
+            nifs.flat_get_profile(g.ref, reset=True)
+            got = unwrap(nifs.flat_search_batch(g.ref, batch, limit))
+            prof = nifs.flat_get_profile(g.ref, reset=True)
+            for i in range(len(batch)):
+                assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, mat, packed, batch[i], limit))
+            grouped = limit <= 64 and d != 600
+            assert prof["hamming_queries"] == (len(batch) if grouped else 0), (limit, prof)
+            assert prof["scan_launches"] == 0 or not grouped, (limit, prof)
 
     check(limits=(1, 10, 300, 1500))
     for step in range(4):
@@ -1643,3 +1651,37 @@ def test_no_room_for_the_non_zero_bits_means_reading_the_rows(nifs, oracle_mod, 
             assert bits(got) == bits(oracle_mod.matrix_search(metric, x, packed, q, 10))
         prof = nifs.flat_get_profile(g.ref, reset=True)
         assert prof["hamming_launches"] == 0 and prof["scan_launches"] >= 2, prof
+
+
+@pytest.mark.parametrize("metric", [7, 8])
+def test_concurrent_pattern_metric_callers_share_sweeps(nifs, oracle_mod, metric, monkeypatch):
+    """flat_search callers that meet on a float hamming / jaccard handle travel as a batch, and the batch
+    is sweeps of the non-zero-bit column (K4p); every answer equals the call made alone and the oracle's."""
+    import threading
+    monkeypatch.setenv("VT_COALESCE_SLOTS", "1")
+    n, d = 30_000, 256
+    rng = np.random.default_rng(900 + metric)
+    x = (rng.uniform(-1, 1, (n, d)) * (rng.uniform(0, 1, (n, d)) < 0.3)).astype(np.float32)
+    ids = [b"doc-%05d" % i for i in range(n)]
+    packed = oracle_mod.pack_ids(ids)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    qs = (rng.uniform(-1, 1, (24, d)) * (rng.uniform(0, 1, (24, d)) < 0.3)).astype(np.float32)
+    want = {limit: [bits(oracle_mod.matrix_search(metric, x, packed, q, limit)) for q in qs] for limit in (10, 100)}
+    for limit in (10, 100):
+        assert [bits(unwrap(nifs.flat_search(g.ref, q, limit))) for q in qs] == want[limit]
+    wrong = []
+
+    def worker(t):
+        for r in range(30):
+            j = (t * 5 + r) % 24
+            limit = 100 if (t + r) % 5 == 0 else 10          # (lists of 100 do not fit K4p: those callers go alone)
+            if bits(unwrap(nifs.flat_search(g.ref, qs[j], limit))) != want[limit][j]:
+                wrong.append((t, r, limit))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not wrong, wrong[:5]

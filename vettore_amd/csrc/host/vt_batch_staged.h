@@ -357,6 +357,84 @@ int multi_scan_group(Shard *ix, Ctx &c, const float *queries, const std::vector<
   return VT_OK;
 }
 
+// Float hamming / jaccard batches on a current non-zero-bit column: up to eight queries per sweep of
+// the column (K4p) when their lists fit its small wave buffers and the row length has an unrolled build.
+bool pattern_group_applies(const Shard *ix, size_t limit) {
+  const uint32_t words = ((uint32_t)ix->dim + 63) / 64;
+  return pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit) && limit >= 1 &&
+         std::min<size_t>(limit, ix->n) <= (size_t)vt::kSmallK && vt::pattern_multi_supports((words + 1) / 2) &&
+         std::getenv("VT_NO_PATTERN_GROUPS") == nullptr;
+}
+
+// `count` queries (rows `which[i]` of `queries`) in ceil(count / 8) sweeps of the non-zero-bit
+// column, every sweep and one batched select queued before the single wait.  Ranks strictly current.
+int pattern_scan_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size_t> &which, size_t limit, vt_hits **out) {
+  const uint32_t d = (uint32_t)ix->dim, n = ix->n;
+  const uint32_t words = (d + 63) / 64, pairs = (words + 1) / 2;
+  const uint32_t k = (uint32_t)std::min<size_t>(limit, n);
+  const size_t nq = which.size();
+  const size_t lds = vt::pattern_multi_lds_bytes();
+  const uint32_t blocks = c.grid_for((n + 63) / 64, lds, 2);
+  const size_t q_words = (size_t)2 * pairs;  // u64 per query
+  const size_t up_floats = nq * q_words * 2;
+  VT_TRY(c.dBQ.ensure(up_floats));
+  VT_TRY(c.hBQ.ensure(up_floats));
+  VT_TRY(c.dPartKeys.ensure(nq * blocks * k));
+  VT_TRY(c.dPartPay.ensure(nq * blocks * k));
+  const uint32_t out_stride = 16 + k * (uint32_t)sizeof(vt::Entry);  // per query a packed result block: header + k entries
+  VT_TRY(c.dBOut.ensure(nq * (k + 1)));
+  VT_TRY(c.hBOut.ensure(nq * (k + 1)));
+  uint64_t *hbits = reinterpret_cast<uint64_t *>(c.hBQ.p);
+  std::memset(hbits, 0, nq * q_words * sizeof(uint64_t));
+  for (size_t i = 0; i < nq; ++i) {
+    const float *q = queries + which[i] * d;
+    uint64_t *w = hbits + i * q_words;
+    for (uint32_t j = 0; j < d; ++j)
+      if (q[j] != 0.0f) w[j / 64] |= 1ull << (j % 64);  // distances.rs:319-347: what the two metrics compare
+  }
+  VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, nq * q_words * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+  uint32_t sweeps = 0;
+  for (size_t g0 = 0; g0 < nq; g0 += vt::kPatternMultiMax, ++sweeps) {
+    vt::PatternMultiArgs a{};
+    a.bits = ix->dNzBits.p;
+    a.qbits = reinterpret_cast<const uint64_t *>(c.dBQ.p) + g0 * q_words;
+    a.id_rank = ix->dRank.p;
+    a.n = n;
+    a.words = words;
+    a.pairs = pairs;
+    a.d = d;
+    a.k = k;
+    a.nq = (uint32_t)std::min<size_t>(vt::kPatternMultiMax, nq - g0);
+    a.first_query = (uint32_t)g0;
+    a.jaccard = ix->metric == VT_JACCARD ? 1 : 0;
+    a.part_keys = c.dPartKeys.p;
+    a.part_pay = c.dPartPay.p;
+    VT_HIP(vt::launch_pattern_multi(a, blocks, c.stream));
+  }
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+  VT_HIP(vt::launch_select_queries(c.dPartKeys.p, c.dPartPay.p, (uint32_t)nq, blocks * k, k, c.dBOut.p, out_stride, c.stream));
+  VT_HIP(hipMemcpyAsync(c.hBOut.p, c.dBOut.p, nq * out_stride, hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipStreamSynchronize(c.stream));
+  if (c.profiling) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    c.prof.hamming_launches += sweeps;
+    c.prof.hamming_ms += ms;
+    c.prof.hamming_bytes += (uint64_t)sweeps * n * words * 8;
+    c.prof.hamming_queries += nq;
+  }
+  for (size_t i = 0; i < nq; ++i) {
+    const vt::Entry *blk = c.hBOut.p + i * (k + 1);  // [0] is the header
+    uint32_t got = 0;
+    std::memcpy(&got, reinterpret_cast<const unsigned char *>(blk) + 4, 4);
+    got = std::min<uint32_t>(got, k);
+    std::vector<vt::Entry> entries(blk + 1, blk + 1 + got);
+    VT_TRY(make_hits(ix, entries, &out[which[i]]));
+  }
+  return VT_OK;
+}
+
 // K2b applies wherever K2 does; which of the two nominates is the shard's setting
 // (vt_flat_set_batch_nominate / VT_BATCH_NOMINATE, default bf16).
 bool batch_nominates_bf16(const Shard *ix) { return ix->nominate == VT_NOMINATE_BF16; }
@@ -454,6 +532,7 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
   // of the bytes a sweep reads, and search_ready below takes it -- unless a sweep of the rows for
   // eight queries is cheaper than eight such passes with their ~50 us of launches, select and wait
   // each, as it is on corpora below a GB or two)
+  if (left.size() >= 2 && pattern_group_applies(ix, limit)) return pattern_scan_group(ix, c, queries, left, limit, out);
   const double pattern_s = 50e-6 + (double)ix->n * (double)(((size_t)ix->dim + 63) / 64 * 8) / 5.5e12;
   const bool by_pattern = pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit) &&
                           (left.size() < 2 || !multi_scan_applies(ix, limit) ||

@@ -101,9 +101,11 @@ struct CoalesceOps {
 
 int coalesced_search(vt_flat *h, const float *query, size_t n, size_t limit, vt_hits **out) {
   if (limit == 0 || limit > (size_t)vt::kMaxFusedK || n == 0 || !coalescing_enabled()) return search_direct(h, query, n, limit, out);
-  // float hamming / jaccard on a corpus with its non-zero-bit column: every search is one short K4
-  // pass of its own, and callers run side by side on the reader contexts (nothing to share a sweep for)
-  if (pattern_metric(h->shards[0]->metric) && h->approx_rows.load(std::memory_order_relaxed) >= kPatternMinRows)
+  // float hamming / jaccard on a corpus with its non-zero-bit column: callers whose lists fit K4p's
+  // wave buffers share sweeps of the column like everyone else; longer lists are one short K4 pass
+  // (or a few) per caller, side by side on the reader contexts
+  if (limit > (size_t)vt::kSmallK && pattern_metric(h->shards[0]->metric) &&
+      h->approx_rows.load(std::memory_order_relaxed) >= kPatternMinRows)
     return search_direct(h, query, n, limit, out);
   return vt_host::coalesced_search_t<vt_flat, CoalesceOps>(h, query, n, limit, out);
 }

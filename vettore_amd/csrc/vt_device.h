@@ -198,6 +198,23 @@ struct HammingArgs {
 };
 hipError_t launch_hamming(const HammingArgs &a, uint32_t blocks, hipStream_t s);
 
+// K4p (vt_kernels.hip): K4's pattern mode (non-zero bits; float hamming / jaccard scores) for up to
+// kPatternMultiMax queries in one sweep of the column; k <= kSmallK; unsorted lists of k per
+// (query, block) at part_keys / part_pay + ((first_query + q) * blocks + block) * k.
+constexpr uint32_t kPatternMultiMax = 8;
+struct PatternMultiArgs {
+  const uint64_t *bits;     // the non-zero-bit column, K4's tiled layout
+  const uint64_t *qbits;    // [nq][2 * pairs] (device): each query's words, an odd count padded with a zero word
+  const uint32_t *id_rank;  // per row or null
+  uint32_t n, words, pairs, d, k, nq, first_query;
+  int jaccard;
+  uint64_t *part_keys;
+  Payload *part_pay;
+};
+size_t pattern_multi_lds_bytes();
+bool pattern_multi_supports(uint32_t pairs);  // word-pair counts with an unrolled build (d up to 2 048 in steps)
+hipError_t launch_pattern_multi(const PatternMultiArgs &a, uint32_t blocks, hipStream_t s);
+
 // K4h (vt_kernels.hip): distance column + histogram, then threshold collect.
 constexpr uint32_t kHammingHistMaxDim = 8191;  // (d + 1) u32 bins must fit comfortably in LDS
 constexpr int kStatusRetry = 100;              // internal: the tie list overflowed, take the K4 path

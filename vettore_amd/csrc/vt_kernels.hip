@@ -532,6 +532,106 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
 }
 
 // ---------------------------------------------------------------------------
+// K4p: flat_search under float hamming / jaccard for up to kPatternMultiMax queries in ONE sweep
+// of the non-zero-bit column (batches; callers that met on a handle).  A lane owns a row as in
+// K4 and keeps its words in registers; the queries' words are wave-uniform (scalar loads), so a
+// query costs the popcounts and one offer to ITS wave list -- the tile is read once.  Scores and
+// keys as in K4's pattern mode (distances.rs:319-347); lists of k <= kSmallK per (query, wave),
+// merged per block and filed per query for launch_select_queries.  Padding bits are zero on both
+// sides (K5 and the host's query packing write none), so no word needs a mask.
+// ---------------------------------------------------------------------------
+template <int PAIRS, bool JACCARD>
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void pattern_topk_multi_kernel(const PatternMultiArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+  const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
+  const uint32_t ntiles = (a.n + kWave - 1) / kWave;
+  const u64x2 *bits = reinterpret_cast<const u64x2 *>(a.bits);
+  extern __shared__ __align__(16) unsigned char hsmem[];
+  constexpr size_t kList = WaveTopK<kCapSmall>::lds_bytes();
+  uint32_t *s_counts = reinterpret_cast<uint32_t *>(hsmem + (size_t)kPatternMultiMax * kWavesPerBlock * kList);
+
+  WaveTopK<kCapSmall> tk[kPatternMultiMax];
+#pragma unroll
+  for (int q = 0; q < (int)kPatternMultiMax; ++q) tk[q].init(hsmem + ((size_t)q * kWavesPerBlock + wib) * kList, a.k);
+  // 64 KB of lists leave two blocks on a CU -- two waves per SIMD, too few to hide a trip to HBM
+  // behind the other wave's popcounts -- so a wave keeps its next U tiles in flight while it works
+  // on the current U (registers are what this kernel has to spare).
+  // A query's words are scalar loads: their latency is paid once per query and U tiles, not per tile.
+  constexpr int U = PAIRS <= 4 ? 4 : PAIRS <= 6 ? 3 : PAIRS <= 8 ? 2 : 1;
+  u64x2 cur[U][PAIRS], nxt[U][PAIRS];
+  auto load_tiles = [&](u64x2(&dst)[U][PAIRS], uint32_t t0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t t = t0 + (uint32_t)u * total_waves;
+      if (t < ntiles) {
+        const u64x2 *base = bits + ((size_t)t * PAIRS * kWave + lane);
+#pragma unroll
+        for (int j = 0; j < PAIRS; ++j) dst[u][j] = __builtin_nontemporal_load(base + (size_t)j * kWave);
+      }
+    }
+  };
+  load_tiles(cur, wave_global);
+  for (uint32_t t0 = wave_global; t0 < ntiles; t0 += (uint32_t)U * total_waves) {
+    load_tiles(nxt, t0 + (uint32_t)U * total_waves);
+    uint32_t grow[U], my_rank[U];
+    bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t t = t0 + (uint32_t)u * total_waves;
+      grow[u] = t * kWave + lane;
+      valid[u] = t < ntiles && grow[u] < a.n;
+      my_rank[u] = (valid[u] && a.id_rank) ? a.id_rank[grow[u]] : grow[u];
+    }
+#pragma unroll
+    for (int q = 0; q < (int)kPatternMultiMax; ++q) {
+      if ((uint32_t)q < a.nq) {  // (wave-uniform)
+        // (read through the constant address space => s_load, and the words enter v_xor / v_and as
+        // SGPR operands, as in K4hm: nothing writes them while the kernel runs)
+        typedef const __attribute__((address_space(4))) uint64_t *cu64_p;
+        const cu64_p qb = (cu64_p)(uintptr_t)a.qbits + (size_t)q * 2 * PAIRS;
+        uint64_t qw[2 * PAIRS];
+#pragma unroll
+        for (int j = 0; j < 2 * PAIRS; ++j) qw[j] = qb[j];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (t0 + (uint32_t)u * total_waves < ntiles) {  // (wave-uniform)
+            uint32_t ham = 0, both = 0;
+#pragma unroll
+            for (int j = 0; j < PAIRS; ++j) {
+              ham += __popcll(cur[u][j].x ^ qw[2 * j]) + __popcll(cur[u][j].y ^ qw[2 * j + 1]);
+              if (JACCARD) both += __popcll(cur[u][j].x & qw[2 * j]) + __popcll(cur[u][j].y & qw[2 * j + 1]);
+            }
+            float raw = (float)ham;
+            if (JACCARD) {
+              const uint32_t uni = ham + both;
+              raw = uni == 0 ? 0.0f : 1.0f - (float)both / (float)uni;
+            }
+            const uint64_t key = ((uint64_t)orderable(raw) << 32) | my_rank[u];
+            tk[q].offer(valid[u], key, grow[u], raw, lane);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < PAIRS; ++j) cur[u][j] = nxt[u][j];
+  }
+#pragma unroll
+  for (int q = 0; q < (int)kPatternMultiMax; ++q) {
+    if ((uint32_t)q < a.nq) {
+      tk[q].merge_block(wib, kWavesPerBlock, s_counts + q * kWavesPerBlock, lane);
+      if (wib == 0) {
+        const size_t list = ((size_t)(a.first_query + q) * gridDim.x + blockIdx.x) * a.k;
+        tk[q].store(a.part_keys + list, a.part_pay + list, lane);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K4h: the Hamming candidate pass as a pure stream (resident corpus, k <= 256).
 // Distances are integers 0..d, so the k-th smallest is found exactly from a
 // histogram instead of carrying k-entry lists through the scan:
@@ -1478,6 +1578,44 @@ hipError_t launch_hamming_r(const HammingArgs &a, uint32_t blocks, hipStream_t s
 hipError_t launch_hamming(const HammingArgs &a, uint32_t blocks, hipStream_t s) {
   if (a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.words == 0 || a.pairs != (a.words + 1) / 2) return hipErrorInvalidValue;
   return a.k <= (uint32_t)kSmallK ? launch_hamming_r<kCapSmall>(a, blocks, s) : launch_hamming_r<kCapLarge>(a, blocks, s);
+}
+
+size_t pattern_multi_lds_bytes() {
+  return (size_t)kPatternMultiMax * kWavesPerBlock * WaveTopK<kCapSmall>::lds_bytes() + kPatternMultiMax * kWavesPerBlock * sizeof(uint32_t);
+}
+bool pattern_multi_supports(uint32_t pairs) {
+  return pairs == 1 || pairs == 2 || pairs == 3 || pairs == 4 || pairs == 6 || pairs == 8 || pairs == 12 || pairs == 16;
+}
+hipError_t launch_pattern_multi(const PatternMultiArgs &a, uint32_t blocks, hipStream_t s) {
+  if (a.k == 0 || a.k > (uint32_t)kSmallK || a.nq == 0 || a.nq > kPatternMultiMax || a.pairs != (a.words + 1) / 2 ||
+      !pattern_multi_supports(a.pairs))
+    return hipErrorInvalidValue;
+  const size_t lds = pattern_multi_lds_bytes();
+#define VT_PAT_CASE(P)                                                                                                   \
+  case P: {                                                                                                              \
+    hipError_t e = a.jaccard ? allow_lds(pattern_topk_multi_kernel<P, true>, lds)                                        \
+                             : allow_lds(pattern_topk_multi_kernel<P, false>, lds);                                      \
+    if (e != hipSuccess) return e;                                                                                       \
+    if (a.jaccard)                                                                                                       \
+      hipLaunchKernelGGL((pattern_topk_multi_kernel<P, true>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);   \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((pattern_topk_multi_kernel<P, false>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);  \
+    break;                                                                                                               \
+  }
+  switch (a.pairs) {
+    VT_PAT_CASE(1)
+    VT_PAT_CASE(2)
+    VT_PAT_CASE(3)
+    VT_PAT_CASE(4)
+    VT_PAT_CASE(6)
+    VT_PAT_CASE(8)
+    VT_PAT_CASE(12)
+    VT_PAT_CASE(16)
+    default:
+      return hipErrorInvalidValue;
+  }
+#undef VT_PAT_CASE
+  return hipGetLastError();
 }
 
 size_t hamming_hist_lds_bytes(uint32_t d) { return ((size_t)d + 1) * sizeof(uint32_t); }
