@@ -512,3 +512,44 @@ def test_device_resident_batches_with_scattered_rows(nifs, oracle_mod, devices):
         assert bits(g.search(q, 20)) == bits(o.search(q, 20))
     # the row written twice holds its LAST value
     assert g.search(up[len(pick)], 1)[0] == (ids[int(pick[0])], 0.0)
+
+
+@pytest.mark.parametrize("metric", [7, 8])
+def test_pattern_metrics_on_a_sharded_handle(nifs, oracle_mod, metric):
+    """Float hamming / jaccard on two shards of 16 384 rows or more each: every shard answers from its
+    own column of non-zero bits (K4 / K4p on the shard's worker), the lists meet by (rank key, id
+    bytes); single searches, batches, after mutations -- the oracle's hits over all rows, bit for bit."""
+    n, d, S = 44_000, 128, 2
+    rng = np.random.default_rng(1700 + metric)
+    x = (rng.uniform(-1, 1, (n + 60, d)) * (rng.uniform(0, 1, (n + 60, d)) < 0.35)).astype(np.float32)
+    ids = [b"doc-%05d" % i for i in range(n + 60)]
+    ref = ShardedIndex(nifs, metric, [0] * S)
+    unwrap(nifs.flat_load_matrix(ref.ref, ids[:n], x[:n]))
+    assert min(nifs.flat_shard_lens(ref.ref)) >= 16_384
+    cur = {ids[i]: x[i] for i in range(n)}
+    nifs.flat_set_profiling(ref.ref, True)
+
+    def check():
+        keys = sorted(cur)
+        mat = np.stack([cur[k] for k in keys])
+        packed = oracle_mod.pack_ids(keys)
+        qs = np.stack([x[3], np.zeros(d, np.float32), x[n // 2], x[77], x[78]])
+        nifs.flat_get_profile(ref.ref, reset=True)
+        for q in qs[:3]:
+            for limit in (1, 10, 300):
+                got = unwrap(nifs.flat_search(ref.ref, q, limit))
+                assert bits(got) == bits(oracle_mod.matrix_search(metric, mat, packed, q, limit))
+        got = unwrap(nifs.flat_search_batch(ref.ref, qs, 10))
+        for i in range(len(qs)):
+            assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, mat, packed, qs[i], 10))
+        prof = nifs.flat_get_profile(ref.ref, reset=True)
+        assert prof["hamming_launches"] >= 1 and prof["scan_launches"] == 0, prof
+
+    check()
+    for i in range(n + 59, n - 1, -1):                    # appends in descending id order
+        ref.insert(ids[i], x[i]); cur[ids[i]] = x[i]
+    for victim in (ids[5], ids[n - 3]):
+        ref.delete(victim); cur.pop(victim, None)
+    v = np.where(cur[ids[9]] == 0, np.float32(1.5), np.float32(0.0)).astype(np.float32)
+    ref.insert(ids[9], v); cur[ids[9]] = v
+    check()
