@@ -264,6 +264,20 @@ def verify_against_oracle(nifs, dim, order_code, limit=10):
                 out[name] = all(bits(got[i]) == bits(oracle.matrix_search(2, x, packed, qs[i], limit)) for i in range(16))
         finally:
             del os.environ["VT_FORCE_BATCH_MFMA"]
+        # flat_search under float hamming / jaccard from the non-zero-bit column (K4), a batch in K4p sweeps
+        xs = (rng.uniform(-1, 1, (n, dim)) * (rng.uniform(0, 1, (n, dim)) < 0.5)).astype(np.float32)
+        qsp = (rng.uniform(-1, 1, (16, dim)) * (rng.uniform(0, 1, (16, dim)) < 0.5)).astype(np.float32)
+        for name, code in (("pattern_hamming", 7), ("pattern_jaccard", 8)):
+            refp = nifs._flat_new(code)
+            assert nifs.flat_load_matrix(refp, ids, xs) == ("ok", ())
+            nifs.flat_set_profiling(refp, True)
+            got1 = nifs.flat_search(refp, qsp[0], limit)[1]
+            gotb = nifs.flat_search_batch(refp, qsp, limit)[1]
+            prof = nifs.flat_get_profile(refp, reset=True)
+            out[name] = (bits(got1) == bits(oracle.matrix_search(code, xs, packed, qsp[0], limit)) and
+                         all(bits(gotb[i]) == bits(oracle.matrix_search(code, xs, packed, qsp[i], limit)) for i in range(16)) and
+                         prof["scan_launches"] == 0 and prof["hamming_launches"] >= 2)
+            del refp
         assert all(out.values()), out
         return {"checker": "oracle/ (CPU restatement of flat.rs / search.rs / distances.rs)", "side_index_rows": n, "equal_bit_for_bit": out}
     finally:
@@ -295,7 +309,7 @@ def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidat
             res = [C.c_void_p(outs[j]) for j in range(per)]
         else:
             h = C.c_void_p()
-            if mode == "single":
+            if mode in ("single", "pattern"):
                 st = L.vt_flat_search(ref.handle, qp, dim, limit, C.byref(h))
             elif mode == "funnel":
                 st = L.vt_flat_funnel_search(ref.handle, qp, dim, st_arr, len(stages), candidates, limit, C.byref(h))
@@ -368,13 +382,17 @@ def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidat
                            "avg_launch_ms": ms,
                            "algorithmic_flops_per_launch": p["batch_flops"] / max(1, p["batch_launches"])}
     else:
-        key = {"single": "scan", "funnel": "prefix", "quantized": "hamming"}[mode]
-        kern = {"single": "scan_topk_kernel", "funnel": "cosine_scan_kernel", "quantized": "hamming_dist_kernel"}[mode]
+        key = {"single": "scan", "funnel": "prefix", "quantized": "hamming", "pattern": "hamming"}[mode]
+        kern = {"single": "scan_topk_kernel", "funnel": "cosine_scan_kernel", "quantized": "hamming_dist_kernel",
+                "pattern": "hamming_topk_kernel"}[mode]
+        if mode == "pattern" and len(ref) >= 16384:  # (every search a pass over the non-zero-bit column, none a scan of the rows)
+            assert p["scan_launches"] == 0 and p["hamming_launches"] >= steps, p
         launches = max(1, p[key + "_launches"])
         ms = p[key + "_ms"] / launches
         gbs = p[key + "_bytes"] / launches / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out["roofline"] = {"bound": "hbm", "kernel": kern, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_side_traffic(kern, len(ref), dim) if mode != "single" else None,
+                           "frac": gbs / HBM_PEAK_GBS,
+                           "traffic": pmc_side_traffic(kern, len(ref), dim) if mode not in ("single", "pattern") else None,
                            "avg_launch_ms": ms,
                            "algorithmic_bytes_per_launch": p[key + "_bytes"] / launches}
         # end to end against the same algorithmic bytes (launch chain + host waits included)
@@ -600,6 +618,41 @@ def side_legs(a, torch, nifs, L, device, main_ref):
         workload="index: :flat, metric: :dot, d=%d, N=%d, batch=256 queries (bf16 MFMA nomination, HBM-bound, + exact f32 rescoring)"
         % (a.dim, a.rows), dtype="f32 (exact rescoring; bf16 nomination)")
     del ref3
+    torch.cuda.empty_cache()
+    # float hamming (distances.rs:319-324) on N sparse rows: flat_search reads the non-zero-bit column
+    # (K4) -- N * ceil(d / 64) * 8 algorithmic bytes per search instead of N * d * 4
+    x = build_shard(torch, device, a.rows, a.dim, SEED_CORPUS + 7)
+    g = torch.Generator(device=device)
+    g.manual_seed(SEED_CORPUS + 8)
+    for s0 in range(0, a.rows, 1 << 20):
+        e0 = min(a.rows, s0 + (1 << 20))
+        x[s0:e0] *= (torch.rand((e0 - s0, a.dim), generator=g, device=device) < 0.5)
+    ref7 = nifs._flat_new(7)
+    assert nifs.flat_load_device_matrix(ref7, doc_ids(0, a.rows), x.data_ptr(), a.rows, a.dim) == ("ok", ())
+    del x
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(SEED_QUERY + 7)
+    qs = (rng.uniform(-1, 1, (330, a.dim)) * (rng.uniform(0, 1, (330, a.dim)) < 0.5)).astype(np.float32)
+    side["pattern_hamming"] = dict(leg(a, L, nifs, ref7, "pattern", qs, 300, 30),
+                                   workload="index: :flat, metric: :hamming (float), d=%d, N=%d, single query; K4 over the non-zero-bit column"
+                                   % (a.dim, a.rows), dtype="u64")
+    # ... and a batch of 64 (K4p: eight queries per sweep of the column), every 8th answer against its single search
+    outs = (C.c_void_p * 64)()
+    qb = np.ascontiguousarray(qs[:64])
+    qbp = qb.ctypes.data_as(C.POINTER(C.c_float))
+    times = []
+    for rep in range(4):
+        t1 = time.perf_counter()
+        assert L.vt_flat_search_batch(ref7.handle, qbp, 64, a.dim, a.limit, outs) == 0
+        times.append(time.perf_counter() - t1)
+        got = [hits_of(L, C.c_void_p(outs[j])) for j in range(64)]
+    for j in range(0, 64, 8):
+        h = C.c_void_p()
+        assert L.vt_flat_search(ref7.handle, qb[j].ctypes.data_as(C.POINTER(C.c_float)), a.dim, a.limit, C.byref(h)) == 0
+        assert hits_of(L, h) == got[j], "batched pattern search differs from the single search"
+    side["pattern_hamming"]["batch64_ms"] = min(times[1:]) * 1e3
+    side["pattern_hamming"]["batch64_queries_per_s"] = 64 / min(times[1:])
+    del ref7
     torch.cuda.empty_cache()
     side["seconds"] = round(time.perf_counter() - t0, 1)
     return side
