@@ -345,7 +345,7 @@ typedef struct vt_profile {
   uint64_t nominate_queries;
   uint64_t nominate_second_passes; /* passes re-run with thresholds from a first pass's exact hits */
   uint64_t nominate_candidates;   /* rows handed to the exact rescoring, summed over queries */
-  uint64_t hamming_queries;       /* queries served by grouped Hamming passes (0 for single-query passes) */
+  uint64_t hamming_queries;       /* queries served by grouped passes over a bit column: quantized groups, float hamming / jaccard batches (0 for single-query passes) */
   uint64_t hybrid_device_chains;  /* hybrid searches whose generators, union and rerank ran as one device chain (one host wait) */
   uint64_t prefix_queries;        /* queries served by grouped prefix scans (0 for single-query funnel searches) */
 } vt_profile;

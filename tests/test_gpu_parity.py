@@ -1685,3 +1685,22 @@ def test_concurrent_pattern_metric_callers_share_sweeps(nifs, oracle_mod, metric
     for th in ths:
         th.join()
     assert not wrong, wrong[:5]
+
+
+def test_pattern_metric_batches_beyond_one_group_call(nifs, oracle_mod):
+    """300 queries under float hamming: K4p sweeps in two calls of at most 256 queries (the last one a
+    partial sweep), every list the oracle's."""
+    n, d = 17_000, 64
+    rng = np.random.default_rng(4242)
+    x = (rng.uniform(-1, 1, (n, d)) * (rng.uniform(0, 1, (n, d)) < 0.4)).astype(np.float32)
+    ids = [b"doc-%05d" % i for i in range(n)]
+    packed = oracle_mod.pack_ids(ids)
+    g = GpuIndex(nifs, 7)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    qs = (rng.uniform(-1, 1, (300, d)) * (rng.uniform(0, 1, (300, d)) < 0.4)).astype(np.float32)
+    nifs.flat_set_profiling(g.ref, True)
+    got = unwrap(nifs.flat_search_batch(g.ref, qs, 5))
+    prof = nifs.flat_get_profile(g.ref, reset=True)
+    assert prof["hamming_queries"] == 300 and prof["hamming_launches"] == 32 + 6 and prof["scan_launches"] == 0, prof
+    for i in range(300):
+        assert bits(got[i]) == bits(oracle_mod.matrix_search(7, x, packed, qs[i], 5))

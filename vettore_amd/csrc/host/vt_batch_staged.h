@@ -532,7 +532,14 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
   // of the bytes a sweep reads, and search_ready below takes it -- unless a sweep of the rows for
   // eight queries is cheaper than eight such passes with their ~50 us of launches, select and wait
   // each, as it is on corpora below a GB or two)
-  if (left.size() >= 2 && pattern_group_applies(ix, limit)) return pattern_scan_group(ix, c, queries, left, limit, out);
+  if (left.size() >= 2 && pattern_group_applies(ix, limit)) {
+    // (256 queries per call: the partial lists take blocks * k entries per query)
+    for (size_t g0 = 0; g0 < left.size(); g0 += 256) {
+      const std::vector<size_t> part(left.begin() + g0, left.begin() + std::min(left.size(), g0 + 256));
+      VT_TRY(pattern_scan_group(ix, c, queries, part, limit, out));
+    }
+    return VT_OK;
+  }
   const double pattern_s = 50e-6 + (double)ix->n * (double)(((size_t)ix->dim + 63) / 64 * 8) / 5.5e12;
   const bool by_pattern = pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit) &&
                           (left.size() < 2 || !multi_scan_applies(ix, limit) ||
