@@ -553,3 +553,67 @@ def test_pattern_metrics_on_a_sharded_handle(nifs, oracle_mod, metric):
     v = np.where(cur[ids[9]] == 0, np.float32(1.5), np.float32(0.0)).astype(np.float32)
     ref.insert(ids[9], v); cur[ids[9]] = v
     check()
+
+
+@pytest.mark.parametrize("metric", [7, 8])
+def test_pattern_metric_readers_and_a_writer_on_one_handle(nifs, oracle_mod, metric):
+    """The same under float hamming / jaccard: readers answer from the non-zero-bit column (singly on
+    their own contexts, or as K4p batches when they meet) while a writer inserts, upserts and deletes
+    rows -- every one of which dirties the column -- that can never reach a top-10; every answer equals
+    the oracle's."""
+    n, d = 20_000, 64
+    rng = np.random.default_rng(1300 + metric)
+    x = (rng.uniform(-1, 1, (n, d)) * (rng.uniform(0, 1, (n, d)) < 0.3)).astype(np.float32)
+    ids = [b"doc-%05d" % i for i in range(n)]
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    packed = oracle_mod.pack_ids(ids)
+    qs = [x[n // 2]] + [(rng.uniform(-1, 1, d) * (rng.uniform(0, 1, d) < 0.3)).astype(np.float32) for _ in range(7)]
+    want = [bits(oracle_mod.matrix_search(metric, x, packed, q, 10)) for q in qs]
+    # far from every query: all coordinates non-zero under hamming (distance >= 64 - |q|); one non-zero
+    # coordinate under jaccard (distance >= 1 - 1 / |q|, where random rows reach ~0.5)
+    far = rng.uniform(0.5, 1.0, (400, d)).astype(np.float32)
+    if metric == 8:
+        far *= np.eye(d, dtype=np.float32)[rng.integers(0, d, 400)]
+    errors, stop = [], threading.Event()
+
+    def reader(t):
+        try:
+            for i in range(150):
+                j = (t + i) % len(qs)
+                mode = (t + i) % 3
+                if mode == 0:
+                    got = bits(unwrap(nifs.flat_search(g.ref, qs[j], 10)))
+                elif mode == 1:
+                    got = bits(unwrap(nifs.flat_search_batch(g.ref, np.stack([qs[j], qs[j]]), 10))[1])
+                else:
+                    got = bits(unwrap(nifs.flat_search(g.ref, qs[j], 100))[:10])
+                if got != want[j]:
+                    errors.append(("reader", t, i, mode))
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append(("reader", t, repr(e)))
+
+    def writer():
+        try:
+            i = 0
+            while not stop.is_set():
+                g.insert("zz-far-%d" % (i % 400), far[i % 400])
+                if i % 3 == 2:
+                    g.delete("zz-far-%d" % ((i - 2) % 400))
+                if i % 7 == 0:
+                    g.insert_many([("aa-far-%d" % (i % 50), far[(i * 3) % 400])])   # sorts in front of every "doc-"
+                i += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(("writer", repr(e)))
+
+    ths = [threading.Thread(target=reader, args=(t,)) for t in range(8)]
+    w = threading.Thread(target=writer)
+    w.start()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    stop.set()
+    w.join()
+    assert not errors, errors[:3]
