@@ -413,7 +413,7 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
 // compare, distances.rs:319-347).
 int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero, int with_bits = 0) {
   const uint32_t ld = vt::padded_dim((uint32_t)n);
-  const size_t words = (n + 63) / 64;
+  const size_t words = ((n + 63) / 64 + 1) / 2 * 2;  // an even count (the odd one out zero): K4 / K4h read whole word pairs
   const size_t total = (size_t)ld + (with_bits ? 2 * words : 0);  // in floats (ld is a multiple of 64: the words are 8-byte aligned)
   VT_TRY(c.dQ.ensure(total));
   VT_TRY(c.hQ.ensure(total));

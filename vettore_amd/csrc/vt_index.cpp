@@ -719,10 +719,12 @@ int vt_binary_top_k(int device, size_t count, const char *ids, const size_t *id_
   DevBuf<uint64_t> dBits, dQ;
   DevBuf<uint32_t> dRank;
   VT_TRY(dBits.ensure(packed.size()));
-  VT_TRY(dQ.ensure(W));
+  std::vector<uint64_t> qwords(2 * (size_t)pairs, 0);  // (K4 reads whole word pairs: an odd count is padded with a zero word)
+  std::copy(query, query + W, qwords.begin());
+  VT_TRY(dQ.ensure(qwords.size()));
   VT_TRY(dRank.ensure(n));
   VT_HIP(hipMemcpyAsync(dBits.p, packed.data(), packed.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
-  VT_HIP(hipMemcpyAsync(dQ.p, query, W * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
+  VT_HIP(hipMemcpyAsync(dQ.p, qwords.data(), qwords.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
   VT_HIP(hipMemcpyAsync(dRank.p, rank.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
   std::vector<vt::Entry> entries;
   VT_TRY(run_hamming(c, dBits.p, dQ.p, dRank.p, n, (uint32_t)dimensions, limit, entries, false));

@@ -487,10 +487,22 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
 
   WaveTopK<CAP> tk;
   tk.init(hsmem + wib * WaveTopK<CAP>::lds_bytes(), a.k);
+  // Unrolled builds: the query's words (the host hands over an even count, the odd one out zero)
+  // are read once, through the constant address space (s_load), and stay in SGPRs; only the last
+  // word pair can hold the word that needs distances.rs:472-481's mask (words is 2 PAIRS - 1 or
+  // 2 PAIRS), and a pad word is zero on both sides.
+  typedef const __attribute__((address_space(4))) uint64_t *cu64_p;
+  uint64_t qw[PAIRS > 0 ? 2 * PAIRS : 1];
+  if (PAIRS > 0) {
+#pragma unroll
+    for (int j = 0; j < 2 * PAIRS; ++j) qw[j] = ((cu64_p)(uintptr_t)a.qbits)[j];
+  }
+  const uint64_t mask_even = a.words == 2u * PAIRS - 1 ? last_mask : ~0ull;
+  const uint64_t mask_odd = a.words == 2u * PAIRS ? last_mask : ~0ull;
   for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
     const u64x2 *base = bits + ((size_t)t * pairs * kWave + lane);
     // `ham` counts the differing bits; in the pattern mode for jaccard `both` counts the bits set on
-    // both sides as well (padding bits are zero on both sides there: no mask needed for the AND)
+    // both sides as well
     uint32_t ham = 0, both = 0;
     if (PAIRS > 0) {
       u64x2 v[PAIRS > 0 ? PAIRS : 1];
@@ -498,11 +510,14 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
       for (int j = 0; j < PAIRS; ++j) v[j] = __builtin_nontemporal_load(base + (size_t)j * kWave);
 #pragma unroll
       for (int j = 0; j < PAIRS; ++j) {
-        const uint32_t w0 = 2 * j, w1 = 2 * j + 1;
-        const uint64_t q0 = a.qbits[w0], q1 = w1 < a.words ? a.qbits[w1] : 0ull;
-        const uint64_t m0 = w0 == last_word ? last_mask : ~0ull, m1 = w1 == last_word ? last_mask : ~0ull;
-        ham += __popcll((v[j].x ^ q0) & m0) + __popcll((v[j].y ^ q1) & m1);
-        if (a.jaccard) both += __popcll(v[j].x & q0 & m0) + __popcll(v[j].y & q1 & m1);
+        const uint64_t q0 = qw[2 * j], q1 = qw[2 * j + 1];
+        if (j < PAIRS - 1) {
+          ham += __popcll(v[j].x ^ q0) + __popcll(v[j].y ^ q1);
+          if (a.jaccard) both += __popcll(v[j].x & q0) + __popcll(v[j].y & q1);
+        } else {
+          ham += __popcll((v[j].x ^ q0) & mask_even) + __popcll((v[j].y ^ q1) & mask_odd);
+          if (a.jaccard) both += __popcll(v[j].x & q0 & mask_even) + __popcll(v[j].y & q1 & mask_odd);
+        }
       }
     } else {
       for (uint32_t j = 0; j < pairs; ++j) {
@@ -664,6 +679,15 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_dist_kernel(con
   for (uint32_t i = threadIdx.x; i <= a.d; i += blockDim.x) hh_lds[i] = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.list_count = 0;
   __syncthreads();
+  // (query words in SGPRs, a mask on the last word pair only: as in K4)
+  typedef const __attribute__((address_space(4))) uint64_t *cu64_p;
+  uint64_t qw[PAIRS > 0 ? 2 * PAIRS : 1];
+  if (PAIRS > 0) {
+#pragma unroll
+    for (int j = 0; j < 2 * PAIRS; ++j) qw[j] = ((cu64_p)(uintptr_t)a.qbits)[j];
+  }
+  const uint64_t mask_even = a.words == 2u * PAIRS - 1 ? last_mask : ~0ull;
+  const uint64_t mask_odd = a.words == 2u * PAIRS ? last_mask : ~0ull;
   for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
     const u64x2 *base = bits + ((size_t)t * pairs * kWave + lane);
     uint32_t ham = 0;
@@ -673,10 +697,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_dist_kernel(con
       for (int j = 0; j < PAIRS; ++j) v[j] = __builtin_nontemporal_load(base + (size_t)j * kWave);
 #pragma unroll
       for (int j = 0; j < PAIRS; ++j) {
-        const uint32_t w0 = 2 * j, w1 = 2 * j + 1;
-        const uint64_t q0 = a.qbits[w0], q1 = w1 < a.words ? a.qbits[w1] : 0ull;
-        const uint64_t m0 = w0 == last_word ? last_mask : ~0ull, m1 = w1 == last_word ? last_mask : ~0ull;
-        ham += __popcll((v[j].x ^ q0) & m0) + __popcll((v[j].y ^ q1) & m1);
+        const uint64_t q0 = qw[2 * j], q1 = qw[2 * j + 1];
+        if (j < PAIRS - 1) ham += __popcll(v[j].x ^ q0) + __popcll(v[j].y ^ q1);
+        else ham += __popcll((v[j].x ^ q0) & mask_even) + __popcll((v[j].y ^ q1) & mask_odd);
       }
     } else {
       for (uint32_t j = 0; j < pairs; ++j) {
