@@ -988,6 +988,60 @@ __global__ __launch_bounds__(256) void sign_pack_kernel(const float *__restrict_
   }
 }
 
+// K5 for the resident corpus (tiled layout, rows on the slab's 256-byte grid): a wave takes
+// 256 consecutive floats of a row as one coalesced 1-KiB load (float4 per lane) -- four words of
+// the row.  Component c of all 64 lanes is one ballot; word w of the four is the 16 ballot bits of
+// lanes 16w..16w+15 of each component, interleaved (bit 4i + c), which lanes 0..3 do with shifts
+// and masks.  One pass over the rows at streaming rate instead of a 256-byte load per wave.
+__global__ __launch_bounds__(256) void sign_pack_tiled_kernel(const float *__restrict__ rows, size_t stride, uint32_t n,
+                                                              uint32_t d, uint64_t *__restrict__ bits, int nonzero) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t W = (d + 63) / 64;
+  const uint32_t pairs = (W + 1) / 2;
+  const uint32_t segs = (d + 255) / 256;  // per row
+  const uint64_t total = (uint64_t)n * segs;
+  const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / kWave);
+  constexpr int U = 4;  // segments in flight per wave (one 1-KiB load each)
+  for (uint64_t g0 = ((uint64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6)) * U; g0 < total; g0 += nwaves * U) {
+    f32x4 v[U];
+    uint32_t r[U], sg[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t g = g0 + u;
+      r[u] = (uint32_t)(g / segs);
+      sg[u] = (uint32_t)(g - (uint64_t)r[u] * segs);
+      const uint32_t j0 = sg[u] * 256 + (uint32_t)lane * 4;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (g < total && j0 < stride) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rows + (size_t)r[u] * stride + j0));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (g0 + u >= total) break;  // (wave-uniform)
+      const uint32_t j0 = sg[u] * 256 + (uint32_t)lane * 4;
+      const float c[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      uint64_t m[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = __ballot(j0 + k < d && (nonzero ? c[k] != 0.0f : c[k] >= 0.0f));
+      if (lane < 4) {
+        const uint32_t wi = sg[u] * 4 + (uint32_t)lane;
+        if (wi < W) {
+          uint64_t word = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            uint64_t x = (m[k] >> (16 * lane)) & 0xffffull;  // bit i -> bit 4 i
+            x = (x | (x << 24)) & 0x000000ff000000ffull;
+            x = (x | (x << 12)) & 0x000f000f000f000full;
+            x = (x | (x << 6)) & 0x0303030303030303ull;
+            x = (x | (x << 3)) & 0x1111111111111111ull;
+            word |= x << k;
+          }
+          bits[hamming_word_index(r[u], wi, pairs)] = word;
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void check_finite_kernel(const float *__restrict__ rows, size_t stride, uint32_t n,
                                                            uint32_t d, int *flag) {
   const uint64_t total = (uint64_t)n * d;
@@ -1725,6 +1779,10 @@ hipError_t launch_select_lists(const uint64_t *keys, const Payload *pay, uint32_
 hipError_t launch_sign_pack(const float *rows, size_t stride, uint32_t n, uint32_t d, uint64_t *bits, int tiled,
                             hipStream_t s, int nonzero) {
   if (n == 0) return hipSuccess;
+  if (tiled && stride % 4 == 0 && ((uintptr_t)rows & 15) == 0) {
+    hipLaunchKernelGGL(sign_pack_tiled_kernel, dim3(4096), dim3(256), 0, s, rows, stride, n, d, bits, nonzero);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(sign_pack_kernel, dim3(2048), dim3(256), 0, s, rows, stride, n, d, bits, tiled, nonzero);
   return hipGetLastError();
 }
