@@ -528,10 +528,8 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
   // what the matrix cores did not take (no GEMM form for this metric, a small batch, a query
   // the bound could not certify): several queries per sweep of the corpus when their lists
   // fit, else one scan each
-  // (float hamming / jaccard with a current non-zero-bit column: each query is a K4 pass over 1/32
-  // of the bytes a sweep reads, and search_ready below takes it -- unless a sweep of the rows for
-  // eight queries is cheaper than eight such passes with their ~50 us of launches, select and wait
-  // each, as it is on corpora below a GB or two)
+  // Float hamming / jaccard with a current non-zero-bit column: eight queries per sweep of the column
+  // (K4p) when their lists fit ...
   if (left.size() >= 2 && pattern_group_applies(ix, limit)) {
     // (256 queries per call: the partial lists take blocks * k entries per query)
     for (size_t g0 = 0; g0 < left.size(); g0 += 256) {
@@ -540,6 +538,9 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
     }
     return VT_OK;
   }
+  // ... else each query is a K4 pass over 1/32 of the bytes a sweep of the rows reads (search_ready
+  // below takes it) -- unless a sweep of the rows for eight queries is cheaper than eight such
+  // passes with their ~50 us of launches, select and wait each, as it is on corpora below a GB or two.
   const double pattern_s = 50e-6 + (double)ix->n * (double)(((size_t)ix->dim + 63) / 64 * 8) / 5.5e12;
   const bool by_pattern = pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit) &&
                           (left.size() < 2 || !multi_scan_applies(ix, limit) ||
