@@ -652,6 +652,10 @@ def side_legs(a, torch, nifs, L, device, main_ref):
         assert hits_of(L, h) == got[j], "batched pattern search differs from the single search"
     side["pattern_hamming"]["batch64_ms"] = min(times[1:]) * 1e3
     side["pattern_hamming"]["batch64_queries_per_s"] = 64 / min(times[1:])
+    # ... and callers that meet on the handle: they travel as such batches (native threads; every 8th answer checked)
+    runs = [native_callers(a, L, nifs, ref7, t, 1.0, qb, 0, 0) for t in (8, 64)]
+    if all(r is not None for r in runs):
+        side["pattern_hamming"]["callers"] = runs
     del ref7
     torch.cuda.empty_cache()
     side["seconds"] = round(time.perf_counter() - t0, 1)
