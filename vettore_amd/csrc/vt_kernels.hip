@@ -599,6 +599,17 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void pattern_topk_multi_kern
       valid[u] = t < ntiles && grow[u] < a.n;
       my_rank[u] = (valid[u] && a.id_rank) ? a.id_rank[grow[u]] : grow[u];
     }
+    // jaccard: |x or q| = |x| + |q| - |x and q|, and |x| is the row's own (once per tile, not per
+    // query), |q| a scalar: a query costs one v_and + one v_bcnt per 32 row bits, like hamming's xor
+    uint32_t px[U];
+    if (JACCARD) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        px[u] = 0;
+#pragma unroll
+        for (int j = 0; j < PAIRS; ++j) px[u] += __popcll(cur[u][j].x) + __popcll(cur[u][j].y);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < (int)kPatternMultiMax; ++q) {
       if ((uint32_t)q < a.nq) {  // (wave-uniform)
@@ -609,18 +620,23 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void pattern_topk_multi_kern
         uint64_t qw[2 * PAIRS];
 #pragma unroll
         for (int j = 0; j < 2 * PAIRS; ++j) qw[j] = qb[j];
+        uint32_t pq = 0;
+        if (JACCARD) {
+#pragma unroll
+          for (int j = 0; j < 2 * PAIRS; ++j) pq += __popcll(qw[j]);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (t0 + (uint32_t)u * total_waves < ntiles) {  // (wave-uniform)
             uint32_t ham = 0, both = 0;
 #pragma unroll
             for (int j = 0; j < PAIRS; ++j) {
-              ham += __popcll(cur[u][j].x ^ qw[2 * j]) + __popcll(cur[u][j].y ^ qw[2 * j + 1]);
               if (JACCARD) both += __popcll(cur[u][j].x & qw[2 * j]) + __popcll(cur[u][j].y & qw[2 * j + 1]);
+              else ham += __popcll(cur[u][j].x ^ qw[2 * j]) + __popcll(cur[u][j].y ^ qw[2 * j + 1]);
             }
             float raw = (float)ham;
             if (JACCARD) {
-              const uint32_t uni = ham + both;
+              const uint32_t uni = px[u] + pq - both;
               raw = uni == 0 ? 0.0f : 1.0f - (float)both / (float)uni;
             }
             const uint64_t key = ((uint64_t)orderable(raw) << 32) | my_rank[u];
