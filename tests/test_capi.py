@@ -111,3 +111,16 @@ def test_product_does_not_touch_the_oracle():
     so = os.path.join(pkg, "lib", "libvettore_hip.so")
     needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
     assert "oracle" not in needed
+
+
+def test_product_library_carries_no_test_hooks():
+    """The fault-injection switches (VT_TEST_*) exist in libvettore_hip_hooks.so only: the product
+    library has no environment variable that makes it fail or take a detour on purpose."""
+    lib_dir = os.path.join(ROOT, "vettore_amd", "lib")
+    product = open(os.path.join(lib_dir, "libvettore_hip.so"), "rb").read()
+    assert b"VT_TEST_" not in product
+    hooks = os.path.join(lib_dir, "libvettore_hip_hooks.so")
+    if os.path.exists(hooks):
+        data = open(hooks, "rb").read()
+        for name in (b"VT_TEST_FAIL_AFTER_ID_UPDATE", b"VT_TEST_EXCHANGE_STALL_MS", b"VT_TEST_REFUSE_NZBITS"):
+            assert name in data, name
