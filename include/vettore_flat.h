@@ -36,7 +36,12 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 2
+/* Bumped whenever a struct of this header grows or an entry point changes (r04: vt_profile grew,
+ * vt_flat_set_batch_shadow / vt_flat_batch_shadow / vt_flat_get_profile_sized arrived).  A binding
+ * compares it with vt_abi_version() when it loads the library (vettore_amd/_lib.py, the erl_nif
+ * shim's load callback): a caller built against an older header would hand vt_flat_get_profile a
+ * struct that is too small. */
+#define VT_ABI_VERSION 3
 
 /* Metric codes == Metric::from_code, native/vettore/src/distances.rs:24-38,
  * mirrored by lib/vettore/collection.ex:1306-1315. */
@@ -220,6 +225,22 @@ int vt_flat_set_reduce_order(vt_flat *index, int order);
 #define VT_NOMINATE_BF16 2
 int vt_flat_set_batch_nominate(vt_flat *index, int mode);
 int vt_flat_batch_nominate(const vt_flat *index);
+/* The bf16 pass reads a bf16 SHADOW of the rows when the index keeps one: an image of every row,
+ * rounded once (round to nearest even, what the pass itself would do on the fly) and laid out as
+ * the matrix cores take their operands, kept beside the f32 slab -- half the bytes per pass, no
+ * conversion in it.  It costs dimension * 2 bytes per row (half the slab again), is built by the
+ * first batch that wants it, patched per mutated row like the other derived columns, and given
+ * back at once when the rows themselves need the room (a growing slab never fails because of it).
+ * The hits do not depend on it: same rounding, same bound, the exact kernel decides.
+ *   VT_SHADOW_AUTO (default)  keep one when, after allocating it, at least a quarter of the
+ *                             card's memory is still free
+ *   VT_SHADOW_OFF             never (the pass streams the f32 rows and rounds in registers)
+ * Override for new indexes: VT_BATCH_SHADOW=0.  vt_flat_batch_shadow reports shard 0's state. */
+enum { VT_SHADOW_OFF = 0, VT_SHADOW_AUTO = 1 };
+enum { VT_SHADOW_STATE_OFF = 0, VT_SHADOW_STATE_NONE = 1, VT_SHADOW_STATE_CURRENT = 2, VT_SHADOW_STATE_STALE = 3,
+       VT_SHADOW_STATE_REFUSED = 4 };
+int vt_flat_set_batch_shadow(vt_flat *index, int mode);
+int vt_flat_batch_shadow(const vt_flat *index);   /* VT_SHADOW_STATE_*; -1: no index */
 /* Order used by indexes created afterwards and by the stateless helpers. */
 int vt_set_default_reduce_order(int order);
 
@@ -340,7 +361,7 @@ typedef struct vt_profile {
   /* K2b: candidate passes with bf16 operands (HBM-bound; batch_* above count the FP32 passes) */
   uint64_t nominate_launches;
   double nominate_ms;
-  uint64_t nominate_bytes;        /* algorithmic bytes: rows * d * 4 per pass */
+  uint64_t nominate_bytes;        /* algorithmic bytes: what a pass reads -- rows * d * 4 from the f32 rows, rows * d * 2 from the bf16 shadow */
   double nominate_flops;          /* 2 * rows * 256 * padded dims per pass */
   uint64_t nominate_queries;
   uint64_t nominate_second_passes; /* passes re-run with thresholds from a first pass's exact hits */
@@ -348,9 +369,17 @@ typedef struct vt_profile {
   uint64_t hamming_queries;       /* queries served by grouped passes over a bit column: quantized groups, float hamming / jaccard batches (0 for single-query passes) */
   uint64_t hybrid_device_chains;  /* hybrid searches whose generators, union and rerank ran as one device chain (one host wait) */
   uint64_t prefix_queries;        /* queries served by grouped prefix scans (0 for single-query funnel searches) */
+  /* r04 (VT_ABI_VERSION 3) */
+  uint64_t nominate_shadow_launches; /* of nominate_launches: the passes that read the bf16 shadow (K2s) */
+  uint64_t shadow_builds;            /* whole-image builds of the bf16 shadow */
+  double shadow_build_ms;
+  uint64_t shadow_patched_rows;      /* rows re-rounded in place after mutations */
 } vt_profile;
 int vt_flat_set_profiling(vt_flat *index, int enabled);
 int vt_flat_get_profile(vt_flat *index, vt_profile *out, int reset);
+/* The same for a caller that says how large ITS vt_profile is: at most `out_bytes` are written
+ * (a binding built against an older header keeps working). */
+int vt_flat_get_profile_sized(vt_flat *index, void *out, size_t out_bytes, int reset);
 
 #ifdef __cplusplus
 }

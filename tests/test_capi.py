@@ -49,7 +49,7 @@ def test_error_strings_are_the_references(lib):
     }
     for code, text in want.items():
         assert lib.vt_strerror(code).decode() == text
-    assert lib.vt_abi_version() == 2
+    assert lib.vt_abi_version() == 3
 
 
 def test_header_cites_the_reference_interface():

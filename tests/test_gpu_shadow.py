@@ -1,0 +1,242 @@
+"""GPU parity tests for K2s: query batches nominated from the bf16 SHADOW of the rows
+(vettore_amd/csrc/vt_batch_shadow.hip).
+
+The shadow is an accelerator of the nomination pass and must never show in a result: every
+query of a batch equals its own flat_search and the oracle's restatement of flat.rs:96-124 bit
+for bit -- with the shadow current, after mutations that leave it to be patched, with it
+switched off, and when the card "has no room" for it.
+"""
+import numpy as np
+import pytest
+
+import support
+from test_gpu_parity import GpuIndex, bits, make_corpus, nifs, unwrap  # noqa: F401  (nifs: fixture)
+
+pytestmark = pytest.mark.gpu
+
+SHADOW_OFF, SHADOW_AUTO = 0, 1
+
+
+def check_batch(nifs, oracle_mod, g, metric, x, ids, qs, k, note=""):
+    packed = oracle_mod.pack_ids(ids)
+    got = unwrap(nifs.flat_search_batch(g.ref, qs, k))
+    assert len(got) == len(qs)
+    for i, q in enumerate(qs):
+        assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, x, packed, q, k)), (note, metric, len(qs), k, i)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("d", [192, 100])
+def test_batches_from_the_shadow_equal_the_oracle(nifs, oracle_mod, metric, d, monkeypatch):
+    """All five matrix-core metrics, rows on and off the 64-float grid (d = 100 pads to 128), the
+    three pass widths (64 / 128 / 256 query columns), a trailing group, limits 1..64."""
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")   # the cost model would send these small corpora to single scans
+    n = 20000
+    x, ids = make_corpus(n, d, 4100 + metric, metric == 2, oracle_mod, tie_block=48)
+    g = GpuIndex(nifs, metric)
+    assert nifs.flat_batch_shadow(g.ref) == "none"
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(81)
+    nifs.flat_set_profiling(g.ref, True)
+    for nq, k in ((8, 10), (37, 1), (100, 10), (128, 3), (256, 10), (300, 64)):
+        qs = rng.uniform(-1, 1, size=(nq, d)).astype(np.float32)
+        qs[0] = x[n // 2]  # sits on the block of identical rows
+        if metric == 2:
+            qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+        check_batch(nifs, oracle_mod, g, metric, x, ids, qs, k)
+    assert nifs.flat_batch_shadow(g.ref) == "current"
+    prof = nifs.flat_get_profile(g.ref)
+    assert prof["shadow_builds"] == 1, prof
+    assert prof["nominate_launches"] >= 6 and prof["nominate_shadow_launches"] == prof["nominate_launches"], prof
+    assert prof["batch_launches"] == 0, prof
+    assert prof["batch_fallbacks"] <= prof["nominate_queries"] // 10, prof
+    # the bytes the passes are priced at are the shadow's: rows * d * 2 each
+    assert prof["nominate_bytes"] == prof["nominate_launches"] * n * d * 2, prof
+
+
+def test_mutations_patch_the_shadow(nifs, oracle_mod, monkeypatch):
+    """Upserts, deletes (swap with the last row), appends past the slab's capacity, emptying and
+    re-dimensioning: the shadow follows (patched rows, rebuilds) and the batches keep equalling
+    the oracle over the current rows."""
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    n, d = 9000, 128
+    metric = 3
+    x, ids = make_corpus(n, d, 4242, False, oracle_mod, tie_block=20)
+    x = x.copy()
+    ids = list(ids)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    nifs.flat_set_profiling(g.ref, True)
+    rng = np.random.default_rng(5)
+    qs = rng.uniform(-1, 1, size=(40, d)).astype(np.float32)
+    check_batch(nifs, oracle_mod, g, metric, x, ids, qs, 10, "fresh")
+    assert nifs.flat_batch_shadow(g.ref) == "current"
+
+    # upserts: the new rows must be the ones nominated (they are made the best hits of query 0)
+    for r in (0, 17, n - 1, 4500):
+        x[r] = (qs[0] * (3.0 + r % 5)).astype(np.float32)
+        unwrap(nifs.flat_insert(g.ref, ids[r], x[r]))
+    assert nifs.flat_batch_shadow(g.ref) == "stale"
+    check_batch(nifs, oracle_mod, g, metric, x, ids, qs, 10, "upserts")
+    assert nifs.flat_batch_shadow(g.ref) == "current"
+    prof = nifs.flat_get_profile(g.ref)
+    assert prof["shadow_builds"] == 1 and prof["shadow_patched_rows"] == 4, prof
+
+    # deletes: the last row moves into the hole
+    for r in (3, 4500, 100):
+        last = len(ids) - 1
+        unwrap(nifs.flat_delete(g.ref, ids[r]))
+        if r != last:
+            x[r] = x[last]
+            ids[r] = ids[last]
+        x = x[:last]
+        ids.pop()
+    check_batch(nifs, oracle_mod, g, metric, x, ids, qs, 10, "deletes")
+
+    # appends in small and in bulk form (the second one outgrows the slab: a rebuild)
+    extra = rng.uniform(-1, 1, size=(50, d)).astype(np.float32)
+    extra[7] = (qs[1] * 5.0).astype(np.float32)
+    new_ids = [b"new-%d" % i for i in range(50)]
+    unwrap(nifs.flat_insert_many(g.ref, list(zip(new_ids, extra))))
+    x = np.concatenate([x, extra])
+    ids += new_ids
+    check_batch(nifs, oracle_mod, g, metric, x, ids, qs, 10, "small append")
+    bulk = rng.uniform(-1, 1, size=(70000, d)).astype(np.float32)
+    bulk[69999] = (qs[2] * 7.0).astype(np.float32)
+    bulk_ids = [b"bulk-%d" % i for i in range(len(bulk))]
+    unwrap(nifs.flat_load_matrix(g.ref, bulk_ids, bulk))
+    x = np.concatenate([x, bulk])
+    ids += bulk_ids
+    check_batch(nifs, oracle_mod, g, metric, x, ids, qs, 10, "bulk append")
+    prof = nifs.flat_get_profile(g.ref)
+    assert prof["shadow_builds"] >= 2, prof
+    assert prof["nominate_shadow_launches"] == prof["nominate_launches"] >= 5, prof
+
+
+def test_an_emptied_index_gives_the_shadow_back(nifs, oracle_mod, monkeypatch):
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    n, d = 6000, 64
+    x, ids = make_corpus(n, d, 77, False, oracle_mod)
+    g = GpuIndex(nifs, 0)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    qs = np.random.default_rng(1).uniform(-1, 1, size=(16, d)).astype(np.float32)
+    check_batch(nifs, oracle_mod, g, 0, x, ids, qs, 5)
+    assert nifs.flat_batch_shadow(g.ref) == "current"
+    for i in ids:
+        unwrap(nifs.flat_delete(g.ref, i))
+    assert g.dimension is None
+    # another dimension altogether
+    d2 = 200
+    x2, ids2 = make_corpus(5000, d2, 78, False, oracle_mod)
+    unwrap(nifs.flat_load_matrix(g.ref, ids2, x2))
+    assert nifs.flat_batch_shadow(g.ref) == "none"
+    qs2 = np.random.default_rng(2).uniform(-1, 1, size=(70, d2)).astype(np.float32)
+    check_batch(nifs, oracle_mod, g, 0, x2, ids2, qs2, 5)
+    assert nifs.flat_batch_shadow(g.ref) == "current"
+
+
+def test_the_shadow_switched_off_and_on(nifs, oracle_mod, monkeypatch):
+    """VT_SHADOW_OFF: the pass streams the f32 rows (K2b) -- same hits; switching it back on builds anew."""
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    n, d = 12000, 192
+    x, ids = make_corpus(n, d, 9, True, oracle_mod, tie_block=30)
+    g = GpuIndex(nifs, 2)
+    assert nifs.flat_set_batch_shadow(g.ref, SHADOW_OFF) == ("ok", ())
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    nifs.flat_set_profiling(g.ref, True)
+    qs = np.stack([oracle_mod.normalize_l2(q) for q in np.random.default_rng(3).uniform(-1, 1, size=(64, d)).astype(np.float32)])
+    check_batch(nifs, oracle_mod, g, 2, x, ids, qs, 10, "off")
+    assert nifs.flat_batch_shadow(g.ref) == "off"
+    prof = nifs.flat_get_profile(g.ref, reset=True)
+    assert prof["nominate_launches"] == 1 and prof["nominate_shadow_launches"] == 0 and prof["shadow_builds"] == 0, prof
+    assert prof["nominate_bytes"] == n * d * 4, prof
+    assert nifs.flat_set_batch_shadow(g.ref, SHADOW_AUTO) == ("ok", ())
+    check_batch(nifs, oracle_mod, g, 2, x, ids, qs, 10, "on again")
+    assert nifs.flat_batch_shadow(g.ref) == "current"
+    prof = nifs.flat_get_profile(g.ref, reset=True)
+    assert prof["nominate_shadow_launches"] == 1 and prof["shadow_builds"] == 1, prof
+    assert nifs.flat_set_batch_shadow(g.ref, SHADOW_OFF) == ("ok", ())
+    assert nifs.flat_batch_shadow(g.ref) == "off"
+    check_batch(nifs, oracle_mod, g, 2, x, ids, qs, 10, "off again")
+    # the f32 matrix cores never look at it
+    assert nifs.flat_set_batch_shadow(g.ref, SHADOW_AUTO) == ("ok", ())
+    assert nifs.flat_set_batch_nominate(g.ref, 1) == "ok"
+    check_batch(nifs, oracle_mod, g, 2, x, ids, qs, 10, "f32 nomination")
+    assert nifs.flat_batch_shadow(g.ref) == "none"
+
+
+def test_no_room_for_the_shadow_means_streaming_the_rows(nifs, oracle_mod, request, monkeypatch):
+    """The shadow is an accelerator: when the card has no room for it the batches keep reading the f32
+    rows, with the same hits.  (The refused allocation is injected -- VT_TEST_REFUSE_SHADOW,
+    libvettore_hip_hooks.so only: the test re-runs itself there.)"""
+    if support.rerun_with_hooks_library(request):
+        return
+    monkeypatch.setenv("VT_TEST_REFUSE_SHADOW", "1")
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    n, d = 10000, 128
+    x, ids = make_corpus(n, d, 31, False, oracle_mod)
+    g = GpuIndex(nifs, 1)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    nifs.flat_set_profiling(g.ref, True)
+    qs = np.random.default_rng(4).uniform(-1, 1, size=(33, d)).astype(np.float32)
+    for _ in range(2):
+        check_batch(nifs, oracle_mod, g, 1, x, ids, qs, 7)
+    assert nifs.flat_batch_shadow(g.ref) == "refused"
+    prof = nifs.flat_get_profile(g.ref)
+    assert prof["nominate_launches"] == 2 and prof["nominate_shadow_launches"] == 0 and prof["shadow_builds"] == 0, prof
+
+
+def test_rows_that_round_to_infinity_through_the_shadow(nifs, oracle_mod, monkeypatch):
+    """f32's largest values round to +inf in bf16 -- in the shadow as in K2b's registers: inf * 0 = NaN
+    nominates nothing, the handle's largest row norm keeps such a corpus from ever being certified,
+    the exact paths answer."""
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    n, d = 6000, 64
+    rng = np.random.default_rng(22)
+    x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    big = np.finfo(np.float32).max
+    for r in (5, 700, 5999):
+        x[r, 0] = big
+        x[r, 1:] = 2.0
+    ids = [b"r%d" % i for i in range(n)]
+    g = GpuIndex(nifs, 3)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    qs = rng.uniform(-1, 1, size=(16, d)).astype(np.float32)
+    qs[:, 0] = 0.0
+    check_batch(nifs, oracle_mod, g, 3, x, ids, qs, 5)
+
+
+def test_concurrent_callers_travel_through_the_shadow(nifs, oracle_mod, monkeypatch):
+    """flat_search callers that meet on a handle go as one batch (vt_coalesce.h); with a shadow that
+    batch is a K2s pass, and a reader that finds the shadow stale escalates once to patch it."""
+    import threading
+    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    monkeypatch.setenv("VT_COALESCE_SLOTS", "1")
+    n, d = 30000, 256
+    x, ids = make_corpus(n, d, 61, True, oracle_mod, tie_block=16)
+    packed = oracle_mod.pack_ids(ids)
+    g = GpuIndex(nifs, 2)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    nifs.flat_set_profiling(g.ref, True)
+    rng = np.random.default_rng(6)
+    qs = np.stack([oracle_mod.normalize_l2(q) for q in rng.uniform(-1, 1, size=(24, d)).astype(np.float32)])
+    want = [bits(oracle_mod.matrix_search(2, x, packed, q, 10)) for q in qs]
+    errors = []
+
+    def caller(i):
+        try:
+            for _ in range(6):
+                got = unwrap(nifs.flat_search(g.ref, qs[i], 10))
+                if bits(got) != want[i]:
+                    errors.append(i)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=caller, args=(i,)) for i in range(len(qs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    prof = nifs.flat_get_profile(g.ref)
+    assert prof["nominate_shadow_launches"] >= 1 and prof["nominate_shadow_launches"] == prof["nominate_launches"], prof

@@ -16,6 +16,8 @@ LIB_PATH = os.environ.get("VETTORE_HIP_LIB") or os.path.join(_HERE, "lib", "libv
 VT_OK = 0
 ORDER_PAIR, ORDER_AVX, ORDER_SEQ, ORDER_SSE2 = 0, 1, 2, 3
 NOMINATE_F32, NOMINATE_BF16 = 1, 2
+SHADOW_OFF, SHADOW_AUTO = 0, 1
+SHADOW_STATE = {0: "off", 1: "none", 2: "current", 3: "stale", 4: "refused"}
 EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1
 
 # every symbol include/vettore_flat.h declares
@@ -30,8 +32,10 @@ SYMBOLS = [
     "vt_flat_load_matrix", "vt_flat_load_device_matrix", "vt_flat_quantized_search", "vt_flat_quantized_search_batch", "vt_flat_funnel_search", "vt_flat_funnel_search_batch", "vt_flat_hybrid_search",
     "vt_rank_ids", "vt_flat_set_id_ranks", "vt_flat_stream", "vt_flat_search_begin", "vt_flat_merge_gathered",
     "vt_vector_top_k", "vt_binary_top_k", "vt_normalize_l2", "vt_compress_sign_bits",
-    "vt_flat_set_profiling", "vt_flat_get_profile",
+    "vt_flat_set_profiling", "vt_flat_get_profile", "vt_flat_get_profile_sized",
+    "vt_flat_set_batch_shadow", "vt_flat_batch_shadow",
 ]
+ABI_VERSION = 3  # VT_ABI_VERSION of the include/vettore_flat.h this file was written against
 
 
 class Profile(C.Structure):
@@ -48,6 +52,8 @@ class Profile(C.Structure):
         ("hamming_queries", C.c_uint64),
         ("hybrid_device_chains", C.c_uint64),
         ("prefix_queries", C.c_uint64),
+        ("nominate_shadow_launches", C.c_uint64), ("shadow_builds", C.c_uint64), ("shadow_build_ms", C.c_double),
+        ("shadow_patched_rows", C.c_uint64),
     ]
 
 
@@ -142,6 +148,13 @@ def load() -> C.CDLL:
     L.vt_compress_sign_bits.argtypes = [C.c_int, C.c_size_t, C.c_size_t, f32p, u64p]
     L.vt_flat_set_profiling.argtypes = [vp, C.c_int]
     L.vt_flat_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
+    L.vt_flat_get_profile_sized.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    L.vt_flat_set_batch_shadow.argtypes = [vp, C.c_int]
+    L.vt_flat_batch_shadow.argtypes = [vp]
+    # a library built from another header would be handed structs of the wrong size
+    if L.vt_abi_version() != ABI_VERSION:
+        raise ImportError("%s speaks ABI version %d, this binding %d: rebuild with `make`"
+                          % (LIB_PATH, L.vt_abi_version(), ABI_VERSION))
     _lib = L
     return L
 

@@ -30,6 +30,14 @@ int initial_nominate() {
   return VT_NOMINATE_BF16;
 }
 int g_default_nominate = initial_nominate();
+// Whether new indexes keep a bf16 shadow of their rows for that pass (include/vettore_flat.h,
+// vt_flat_set_batch_shadow): VT_BATCH_SHADOW=0 says no.
+int initial_shadow() {
+  const char *e = std::getenv("VT_BATCH_SHADOW");
+  if (e && (std::string(e) == "0" || std::string(e) == "off")) return VT_SHADOW_OFF;
+  return VT_SHADOW_AUTO;
+}
+int g_default_shadow = initial_shadow();
 // smallest sample rank K2b's threshold is taken from (VT_BF16_MIN_RANK: tools/nominate_probe.py sweeps it).
 // The count of rows passing a threshold taken at sample rank r is Gamma(r)-distributed around its
 // mean: at r = 4 one query in ~700 drew a threshold so high that its k-th hit could not clear it by

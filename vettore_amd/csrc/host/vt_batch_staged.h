@@ -27,7 +27,12 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   double t_staged = 0, t_queued = 0, t_synced = 0;
   uint32_t nq_pad = bf16 ? vt::batch_bf16_pad((uint32_t)nq) : 32;
   while (nq_pad < nq) nq_pad *= 2;
-  const uint32_t rows_per_block = bf16 ? vt::batch_bf16_rows_per_block() : vt::batch_rows_per_block(nq_pad);
+  // K2s: the pass reads the bf16 shadow of the rows when the shard keeps a current one (half the bytes, no
+  // conversion; the same rounding, so everything below -- sample, tau, bound -- is K2b's)
+  const bool shadow = bf16 && shadow_wanted(ix) && shadow_current(ix);
+  const uint32_t rows_per_block = shadow ? vt::batch_shadow_rows_per_block()
+                                  : bf16 ? vt::batch_bf16_rows_per_block()
+                                         : vt::batch_rows_per_block(nq_pad);
   const uint32_t ntiles_total = (n + rows_per_block - 1) / rows_per_block;
   // pass-0 sample: 1/64 of the row tiles, 128..512 of them, spread over the corpus.
   // A larger sample gives a tighter tau: fewer candidates to rescore and, above
@@ -74,7 +79,7 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   VT_TRY(c.hBOutCount.ensure(nq_pad + 1));  // (+ the status word: a copy into pageable memory would wait for the stream)
   VT_TRY(c.dPartKeys.ensure((size_t)nq_pad * kBlocksPerQuery * k));
   VT_TRY(c.dPartPay.ensure((size_t)nq_pad * kBlocksPerQuery * k));
-  if (bf16) VT_TRY(c.dBQimage.ensure(vt::batch_bf16_image_bytes(ld)));
+  if (bf16) VT_TRY(c.dBQimage.ensure(std::max(vt::batch_bf16_image_bytes(ld), vt::batch_shadow_image_bytes(ld))));
 
   std::vector<double> qnorm(nq);  // (filled while the device works: see below)
   std::memset(c.hBQ.p, 0, (size_t)nq_pad * ld * sizeof(float));
@@ -92,9 +97,15 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   a.xnorm2 = l2_family ? ix->dXnorm2.p : nullptr;
   if (bf16) {
     a.Qimage = c.dBQimage.p;
-    VT_HIP(vt::launch_batch_q_image(c.dBQ.p, ld, nq_pad, c.dBQimage.p, c.stream));
+    if (shadow) {
+      a.Xshadow = ix->dShadow.p;
+      VT_HIP(vt::launch_batch_q_image16(c.dBQ.p, ld, nq_pad, c.dBQimage.p, c.stream));
+    } else {
+      VT_HIP(vt::launch_batch_q_image(c.dBQ.p, ld, nq_pad, c.dBQimage.p, c.stream));
+    }
   }
   auto scores = [&](bool dense, uint32_t blocks) {
+    if (shadow) return vt::launch_batch_scores_shadow(a, dense, blocks, c.stream);
     return bf16 ? vt::launch_batch_scores_bf16(a, dense, blocks, c.stream) : vt::launch_batch_scores(a, dense, blocks, c.stream);
   };
   const uint32_t grid_cap = (uint32_t)c.num_cus;
@@ -165,7 +176,8 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
     if (bf16) {
       c.prof.nominate_launches += 1;
       c.prof.nominate_ms += ms;
-      c.prof.nominate_bytes += (uint64_t)n * d * 4;
+      c.prof.nominate_bytes += (uint64_t)n * d * (shadow ? 2 : 4);
+      c.prof.nominate_shadow_launches += shadow ? 1 : 0;
       c.prof.nominate_flops += 2.0 * (double)n * (double)nq_pad * (double)ld;
       c.prof.nominate_queries += nq;
       c.prof.nominate_second_passes += tau_given ? 1 : 0;

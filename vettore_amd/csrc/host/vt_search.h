@@ -38,6 +38,22 @@ bool pattern_search_applies(const Shard *ix, size_t limit) {
          std::min<size_t>(limit, ix->n) + 1 <= kPatternMaxWant;
 }
 
+// The bf16 shadow of the rows (K2s, vt_batch_shadow.hip) travels with NEED_NORMS: both are what a
+// matrix-core batch wants current, and nothing else reads either.
+bool shadow_metric(int metric) {
+  return metric == VT_COSINE || metric == VT_INNER_PRODUCT || metric == VT_NEG_INNER_PRODUCT || metric == VT_L2 ||
+         metric == VT_L2_SQUARED;
+}
+bool shadow_wanted(const Shard *ix) {
+  return ix->shadow_mode == VT_SHADOW_AUTO && !ix->sh_refused && ix->nominate == VT_NOMINATE_BF16 && shadow_metric(ix->metric) &&
+         ix->n > 0 && ix->dim > 0;
+}
+size_t shadow_rows(const Shard *ix) { return std::max<size_t>(ix->cap, ix->n); }
+bool shadow_current(const Shard *ix) {
+  return ix->sh_valid && ix->sh_dirty.empty() && ix->dShadow.p != nullptr &&
+         ix->dShadow.count >= vt::shadow_elems((uint32_t)shadow_rows(ix), ix->ld);
+}
+
 bool shard_stale(const Shard *ix, unsigned need, size_t limit) {
   if (ix->n == 0) return false;
   const size_t rows = std::max<size_t>(ix->cap, ix->n);
@@ -54,11 +70,13 @@ bool shard_stale(const Shard *ix, unsigned need, size_t limit) {
     if (!ix->nz_valid || !ix->nz_dirty.empty() || ix->dNzBits.count < bwords) return true;
   }
   if ((need & NEED_NORMS) && (ix->max_sqnorm < 0.0 || !ix->norm_dirty.empty() || ix->dXnorm2.count < rows)) return true;
+  if ((need & NEED_NORMS) && shadow_wanted(ix) && !shadow_current(ix)) return true;
   return false;
 }
 
 int index_ensure_bits(Shard *ix, bool nonzero = false);
 int index_ensure_norms(Shard *ix);
+int index_ensure_shadow(Shard *ix);
 
 // Brings the derived columns a reader needs up to date (exclusive access; primary context).
 int shard_prepare(Shard *ix, unsigned need, size_t limit) {
@@ -70,6 +88,7 @@ int shard_prepare(Shard *ix, unsigned need, size_t limit) {
   if (need & NEED_BITS) VT_TRY(index_ensure_bits(ix));
   if ((need & NEED_NZBITS) && pattern_search_applies(ix, limit)) VT_TRY(index_ensure_bits(ix, true));
   if (need & NEED_NORMS) VT_TRY(index_ensure_norms(ix));
+  if ((need & NEED_NORMS) && shadow_wanted(ix)) VT_TRY(index_ensure_shadow(ix));
   return VT_OK;
 }
 
@@ -452,7 +471,74 @@ int index_ensure_bits(Shard *ix, bool nonzero) {
   }
   VT_HIP(hipMemsetAsync(col.p, 0, bwords * sizeof(uint64_t), c.stream));
   VT_HIP(vt::launch_sign_pack(ix->dX, ix->ld, ix->n, d, col.p, 1, c.stream, nonzero ? 1 : 0));
+  // The column counts as current from here on, for readers on OTHER streams too (leased contexts
+  // under the shared lock): the build must have finished before the exclusive lock can drop, also on
+  // the paths that return without touching this stream again (limit == 0, a query that fails
+  // validation) -- ADVICE r3.
+  VT_HIP(hipStreamSynchronize(c.stream));
   valid = true;
+  return VT_OK;
+}
+
+// The bf16 shadow of the rows brought up to date (exclusive access; primary context): the rows
+// mutated since its last use are re-rounded in place; a first use, a slab that outgrew it or more
+// than kMaxDerivedDirty mutations rebuild the whole image (one pass over the rows: ~10 ms per
+// 30 GB).  An accelerator, not a requirement: without room for it -- after the allocation at least
+// a quarter of the card must still be free, the rows will want to grow -- the shard is marked
+// `sh_refused` and its batches keep streaming the f32 rows (until the index is emptied).
+int index_ensure_shadow(Shard *ix) {
+  Ctx &c = ix->ctx;
+  const uint32_t rows = (uint32_t)shadow_rows(ix);
+  const size_t elems = vt::shadow_elems(rows, ix->ld);
+  if (ix->sh_valid && ix->dShadow.p && ix->dShadow.count >= elems) {
+    uint32_t count = 0;
+    VT_TRY(upload_row_list(ix, ix->sh_dirty, &count));
+    VT_HIP(vt::launch_shadow_rows(ix->dX, ix->ld, c.dRankPairs.p, count, ix->ld, ix->dShadow.p, c.stream));
+    if (count) VT_HIP(hipStreamSynchronize(c.stream));  // the pinned list is reused by the next caller; readers on other streams follow
+    c.prof.shadow_patched_rows += count;
+    ix->sh_dirty.clear();
+    return VT_OK;
+  }
+  ix->sh_valid = false;
+  ix->sh_dirty.clear();
+  if (ix->dShadow.count < elems) {
+    ix->dShadow.release();
+    size_t free_b = 0, total_b = 0;
+    VT_HIP(hipMemGetInfo(&free_b, &total_b));
+    bool refused = free_b < elems * sizeof(uint16_t) || free_b - elems * sizeof(uint16_t) < total_b / 4;
+    // (geometric head room: a corpus that arrives in appends would otherwise re-allocate at every growth of the slab)
+    size_t want = elems;
+    if (!refused) {
+      const size_t roomy = elems + elems / 4;
+      if (free_b >= roomy * sizeof(uint16_t) && free_b - roomy * sizeof(uint16_t) >= total_b / 4) want = roomy;
+      refused = ix->dShadow.ensure(want) != VT_OK;
+    }
+#ifdef VT_TEST_HOOKS
+    // (libvettore_hip_hooks.so only: the allocation "fails", tests/test_gpu_shadow.py checks what follows)
+    if (std::getenv("VT_TEST_REFUSE_SHADOW")) {
+      ix->dShadow.release();
+      refused = true;
+    }
+#endif
+    if (refused) {
+      ix->sh_refused = true;
+      return VT_OK;
+    }
+  }
+  const uint32_t rows_img = (uint32_t)(vt::shadow_elems(rows, ix->ld) / ix->ld);
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+  VT_HIP(vt::launch_shadow_build(ix->dX, ix->ld, std::min<uint32_t>(rows, ix->cap), rows_img, ix->ld, ix->dShadow.p, c.stream));
+  if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
+  // current from here on, for readers on other streams too: the build has finished before the
+  // exclusive lock can drop
+  VT_HIP(hipStreamSynchronize(c.stream));
+  if (c.profiling) {
+    float ms = 0.f;
+    VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    c.prof.shadow_builds += 1;
+    c.prof.shadow_build_ms += ms;
+  }
+  ix->sh_valid = true;
   return VT_OK;
 }
 

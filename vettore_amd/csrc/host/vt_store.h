@@ -6,7 +6,23 @@
 namespace {
 
 // ------------------------------------------------------------------ index ops
+int index_reserve_once(Shard *ix, uint32_t want_rows);
+// The rows come first: when the slab cannot grow and the shard keeps a bf16 shadow (an accelerator
+// of the batch pass, half the slab's size), the shadow goes and the growth is tried once more.
 int index_reserve(Shard *ix, uint32_t want_rows) {
+  int st = index_reserve_once(ix, want_rows);
+  if (st != VT_OK && st != VT_ERR_UNSUPPORTED && ix->dShadow.p) {
+    (void)hipStreamSynchronize(ix->ctx.stream);
+    ix->dShadow.release();
+    ix->sh_valid = false;
+    ix->sh_refused = true;
+    ix->sh_dirty.clear();
+    st = index_reserve_once(ix, want_rows);
+  }
+  return st;
+}
+
+int index_reserve_once(Shard *ix, uint32_t want_rows) {
   if (want_rows <= ix->cap) return VT_OK;
   const size_t row_bytes = (size_t)ix->ld * sizeof(float);
   auto tiles_up = [](uint64_t rows) { return (rows + vt::kTileRows - 1) / vt::kTileRows * vt::kTileRows; };
@@ -74,6 +90,10 @@ int index_set_dim(Shard *ix, size_t d) {
   ix->bits_dirty.clear();
   ix->nz_dirty.clear();
   ix->norm_dirty.clear();
+  ix->sh_valid = false;
+  ix->sh_refused = false;
+  ix->sh_dirty.clear();
+  ix->dShadow.release();  // (an emptied index gives the room back; the next batch builds anew)
   if (ld != ix->ld) {
     VT_HIP(hipStreamSynchronize(ix->ctx.stream));
     ix->slab.release();
@@ -282,6 +302,13 @@ inline void index_touch_row(Shard *ix, uint32_t r) {
       ix->norm_dirty.clear();
     }
   }
+  if (ix->sh_valid) {
+    ix->sh_dirty.push_back(r);
+    if (ix->sh_dirty.size() > kMaxDerivedDirty) {
+      ix->sh_valid = false;
+      ix->sh_dirty.clear();
+    }
+  }
 }
 
 // Uploads a row list (rows still < n) for the patch kernels; returns its length.
@@ -358,6 +385,8 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     ix->bits_dirty.clear();
     ix->nz_dirty.clear();
     ix->norm_dirty.clear();
+    ix->sh_valid = false;
+    ix->sh_dirty.clear();
   } else {
     for (size_t i = 0; i < count; ++i) index_touch_row(ix, target[i]);
   }

@@ -176,6 +176,15 @@ struct Shard {
   bool nz_valid = false;
   bool nz_refused = false;  // the card had no room for the column: searches keep reading the rows (until the index is emptied)
   std::vector<uint32_t> nz_dirty;
+  // K2s: the rows once more, rounded to bf16, in the order the matrix cores take their operands in
+  // (vt_device.h shadow_index) -- what the bf16 nomination pass reads instead of the f32 rows when
+  // the card has room for it (vt_search.h, index_ensure_shadow).  Kept like the bit columns: built
+  // by the first batch that wants it, patched per mutated row, given back when the slab needs the room.
+  DevBuf<uint16_t> dShadow;
+  int shadow_mode = g_default_shadow;  // VT_SHADOW_*
+  bool sh_valid = false;
+  bool sh_refused = false;  // no room (or the slab took the room back): batches stream the f32 rows until the index is emptied
+  std::vector<uint32_t> sh_dirty;
   double max_sqnorm = -1.0;  // max_i sum_j x_ij^2, < 0 = stale (error margin of the batched path)
   DevBuf<float> dXnorm2;     // per-row squared norms, valid with max_sqnorm
   // ids

@@ -356,7 +356,8 @@ struct BatchScoreArgs {
   uint32_t cand_cap;
   const float *xnorm2;    // null: score = q.x; else score = 2 q.x - xnorm2[row] (= |q|^2 - |q - x|^2)
   uint32_t debug;         // VT_BATCH_DEBUG timing experiments (results invalid when non-zero)
-  const void *Qimage;     // K2b only: the 256 queries rounded to bf16, in fragment order (launch_batch_q_image)
+  const void *Qimage;     // K2b / K2s: the queries rounded to bf16, in fragment order (launch_batch_q_image / _q_image16)
+  const void *Xshadow;    // K2s only: the rows rounded to bf16, in fragment order (shadow_index; launch_shadow_build)
 };
 uint32_t batch_rows_per_block(uint32_t nq_pad);
 hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s);
@@ -368,6 +369,26 @@ size_t batch_bf16_image_bytes(uint32_t ld);
 uint32_t batch_bf16_pad(uint32_t nq);  // columns a batch of nq <= 256 queries is padded to: 64, 128 or 256
 hipError_t launch_batch_q_image(const float *Q, uint32_t ld, uint32_t nq_pad, void *image, hipStream_t s);
 hipError_t launch_batch_scores_bf16(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s);
+// K2s (vt_batch_shadow.hip): K2b fed from a bf16 image of the rows kept beside the slab -- half the
+// HBM bytes, no conversion in the pass, both operands through LDS as whole fragments of
+// v_mfma_f32_16x16x32_bf16.  Same rounding as K2b's (round to nearest even), so the same bound applies.
+// Element (row, col) of the image of rows `ld` floats long (ld a multiple of 64) sits at
+// [row / 16][col / 32][(col / 8) % 4][row % 16][col % 8]: 1 KiB per (16 rows, 32 columns), lane
+// 16 g + r of a wave holding row r, k = 8 g .. 8 g + 7 -- one A operand.
+__host__ __device__ inline size_t shadow_index(uint32_t row, uint32_t col, uint32_t ld) {
+  return ((size_t)(row >> 4) * (ld >> 5) + (col >> 5)) * 512 + ((col >> 3) & 3u) * 128 + (row & 15u) * 8 + (col & 7u);
+}
+uint32_t batch_shadow_rows_per_block();
+size_t shadow_elems(uint32_t rows, uint32_t ld);   // bf16 elements of an image of `rows` rows (padded to whole block tiles)
+size_t batch_shadow_image_bytes(uint32_t ld);      // the query image of up to 256 queries
+// rows [0, rows_src) of X -> image rows [0, rows_img) (rows_img a multiple of 256; rows >= rows_src zero)
+hipError_t launch_shadow_build(const float *X, size_t stride, uint32_t rows_src, uint32_t rows_img, uint32_t ld, void *img,
+                               hipStream_t s);
+// the rows of a device list (mutated rows patched in place)
+hipError_t launch_shadow_rows(const float *X, size_t stride, const uint32_t *list, uint32_t count, uint32_t ld, void *img,
+                              hipStream_t s);
+hipError_t launch_batch_q_image16(const float *Q, uint32_t ld, uint32_t nq_pad, void *image, hipStream_t s);
+hipError_t launch_batch_scores_shadow(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s);
 // tau[b] for the nq_real real queries; +inf for the padding columns b >= nq_real.
 hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t nq_real, uint32_t rank,
                              float *tau, hipStream_t s);

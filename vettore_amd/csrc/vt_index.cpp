@@ -317,6 +317,35 @@ int vt_flat_set_batch_nominate(vt_flat *h, int mode) {
 }
 int vt_flat_batch_nominate(const vt_flat *h) { return h && !h->shards.empty() ? h->shards[0]->nominate : -1; }
 
+int vt_flat_set_batch_shadow(vt_flat *h, int mode) {
+  return guarded([&]() -> int {
+  if (!h || (mode != VT_SHADOW_OFF && mode != VT_SHADOW_AUTO)) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  for (auto &s : h->shards) {
+    s->shadow_mode = mode;
+    if (mode == VT_SHADOW_OFF) {  // the room goes back at once
+      (void)hipSetDevice(s->ctx.device);
+      (void)hipStreamSynchronize(s->ctx.stream);
+      s->dShadow.release();
+      s->sh_valid = false;
+      s->sh_dirty.clear();
+    } else {
+      s->sh_refused = false;  // asked for again: the next batch looks at the free memory anew
+    }
+  }
+  return VT_OK;
+  });
+}
+int vt_flat_batch_shadow(const vt_flat *h) {
+  if (!h || h->shards.empty()) return -1;
+  std::shared_lock<std::shared_mutex> rl(h->rw);
+  const Shard *ix = h->shards[0].get();
+  if (ix->shadow_mode == VT_SHADOW_OFF) return VT_SHADOW_STATE_OFF;
+  if (ix->sh_refused) return VT_SHADOW_STATE_REFUSED;
+  if (!ix->dShadow.p || !ix->sh_valid) return VT_SHADOW_STATE_NONE;
+  return shadow_current(ix) ? VT_SHADOW_STATE_CURRENT : VT_SHADOW_STATE_STALE;
+}
+
 int vt_flat_insert(vt_flat *h, const char *id, size_t id_len, const float *vector, size_t n) {
   return guarded([&]() -> int {
   if (!h || (!id && id_len) || (!vector && n)) return VT_ERR_ARGUMENT;
@@ -821,12 +850,24 @@ int vt_flat_get_profile(vt_flat *h, vt_profile *out, int reset) {
       t.hamming_queries += p.hamming_queries;
       t.hybrid_device_chains += p.hybrid_device_chains;
       t.prefix_queries += p.prefix_queries;
+      t.nominate_shadow_launches += p.nominate_shadow_launches;
+      t.shadow_builds += p.shadow_builds;
+      t.shadow_build_ms += p.shadow_build_ms;
+      t.shadow_patched_rows += p.shadow_patched_rows;
       if (reset) c.prof = vt_profile{};
     });
   if (reset) h->xprof = vt_profile{};
   *out = t;
   return VT_OK;
   });
+}
+
+int vt_flat_get_profile_sized(vt_flat *h, void *out, size_t out_bytes, int reset) {
+  if (!out) return VT_ERR_ARGUMENT;
+  vt_profile t{};
+  const int st = vt_flat_get_profile(h, &t, reset);
+  if (st == VT_OK) std::memcpy(out, &t, std::min(out_bytes, sizeof t));
+  return st;
 }
 
 }  // extern "C"

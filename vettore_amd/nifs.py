@@ -520,6 +520,17 @@ def flat_batch_nominate(index: FlatRef) -> int:
     return int(_lib.load().vt_flat_batch_nominate(index.handle))
 
 
+def flat_set_batch_shadow(index: FlatRef, mode: int):
+    """Whether the bf16 nomination pass may keep a bf16 shadow of the rows: _lib.SHADOW_AUTO (default) or SHADOW_OFF."""
+    st = _lib.load().vt_flat_set_batch_shadow(index.handle, mode)
+    return ("ok", ()) if st == _lib.VT_OK else ("error", _lib.error_text(st))
+
+
+def flat_batch_shadow(index: FlatRef) -> str:
+    """State of shard 0's shadow: "off", "none" (not built yet), "current", "stale" or "refused" (no room)."""
+    return _lib.SHADOW_STATE.get(int(_lib.load().vt_flat_batch_shadow(index.handle)), "?")
+
+
 def set_default_reduce_order(order: int):
     st = _lib.load().vt_set_default_reduce_order(order)
     return "ok" if st == 0 else _err(st)
