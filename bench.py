@@ -43,6 +43,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PMC_SIDE_SOURCE = "profiles/pmc_side.json (rocprofv3 --pmc FETCH_SIZE passes of this script's --mode legs, tools/refresh_profiles.sh; not this run)"
+PMC_SOURCE = "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script, tools/refresh_profiles.sh; not this run)"
 SEED_CORPUS, SEED_QUERY = 20260721, 20260722
 
 
@@ -77,7 +79,20 @@ def parse():
                     help="one process, N devices: HIP ordinals of the shards (default 0..N-1); an ordinal may repeat, "
                          "which puts several shards on one GPU (how a one-GPU box exercises --gpus 2)")
     ap.add_argument("--exchange", choices=["auto", "rccl", "host"], default="auto",
-                    help="one process, N devices: how the shards' lists meet (auto = the library's default)")
+                    help="how the shards' lists meet: one process, N devices: the library's RCCL all-gather or its host-mapped "
+                         "lists; under torch.distributed.run: backend nccl (RCCL) with the device-side merge, or gloo with "
+                         "64-byte records (auto = RCCL first, see --supervise)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = --rows is the whole corpus, sharded over the GPUs (the north star's curve); "
+                         "weak = --rows per GPU (N x --rows in all), reported as \"scaling\": \"weak\"")
+    ap.add_argument("--shadow", choices=["auto", "off"], default="auto",
+                    help="batch mode: let the bf16 pass keep a bf16 shadow of the rows (K2s) or stream the f32 rows (K2b)")
+    ap.add_argument("--supervise", action="store_true",
+                    help="run the measurement in a child process and, should it fail or hang, once more over the host exchange "
+                         "(always on for N > 1; this flag switches it on at N = 1, with --exchange rccl|host)")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # (the supervised measurement itself)
+    ap.add_argument("--child-timeout", type=float, default=900.0, help="seconds a supervised measurement may take")
+    ap.add_argument("--exchange-note", default=None, help=argparse.SUPPRESS)  # (why this child runs over the host exchange)
     return ap.parse_args()
 
 
@@ -97,15 +112,17 @@ def doc_ids(start, count, idx=None):
     return blob, off
 
 
-def build_shard(torch, device, rows, dim, seed, chunk=1 << 20):
-    """uniform(-1,1) rows, L2-normalised, 1% verbatim duplicates, generated in HBM."""
+def build_shard(torch, device, rows, dim, seed, chunk=1 << 20, normalize=True):
+    """uniform(-1,1) rows, L2-normalised (cosine collections: collection.ex:1317-1319; the other
+    metrics store what they are given), 1% verbatim duplicates, generated in HBM."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     x = torch.empty((rows, dim), dtype=torch.float32, device=device)
     for s in range(0, rows, chunk):
         e = min(rows, s + chunk)
         blk = torch.rand((e - s, dim), generator=g, device=device, dtype=torch.float32) * 2.0 - 1.0
-        blk /= torch.linalg.vector_norm(blk.double(), dim=1, keepdim=True).float()
+        if normalize:
+            blk /= torch.linalg.vector_norm(blk.double(), dim=1, keepdim=True).float()
         x[s:e] = blk
         del blk
     ndup = rows // 100
@@ -118,54 +135,41 @@ def build_shard(torch, device, rows, dim, seed, chunk=1 << 20):
 
 
 def cpu_baseline(dim, limit, budget_s):
-    """The oracle in the reference's own shape (hash map of separately allocated
-    rows, per-row id clone, bounded heap: flat.rs:96-124) on a bounded sample of
-    the same workload.  A reference search is single-threaded; its throughput
-    comes from T callers searching concurrently under the read lock
-    (nifs.rs:304-308), so both are timed: one thread, then T = host cores."""
-    import threading
-    import oracle
-    rows = 200_000
-    rng = np.random.default_rng(SEED_CORPUS)
-    x = rng.uniform(-1.0, 1.0, size=(rows, dim)).astype(np.float32)
-    x /= np.sqrt(np.sum(x.astype(np.float64) ** 2, axis=1, keepdims=True)).astype(np.float32)
-    ids = [b"doc-%d" % (i + 1) for i in range(rows)]
-    ix = oracle.FlatIndex(oracle.METRIC_CODE["cosine"])
-    ix.insert_matrix(ids, x)
-    qrng = np.random.default_rng(SEED_QUERY)
-    qs = qrng.uniform(-1, 1, size=(64, dim)).astype(np.float32)
-    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
-    ix.search(qs[0], limit)
-    # one thread
+    """The CPU beside it: the oracle -- the reference's algorithm restated in C, pinned to
+    the reference's own test vectors -- timed on this box's host cores on a bounded sample of the same
+    workload.  The reference cannot be built here (Rust + un-vendored crates), so kind = "port".  Every
+    flavour SURVEY 8d names is timed (tools/cpu_variants.py, one child process per build):
+      * shape: the reference's own (hash map of separately allocated rows, id clone per row, bounded
+        heap: flat.rs:96-124) and a contiguous row matrix ("best-effort CPU": what the reference's
+        layout costs it stays visible);
+      * build: -O3 for baseline x86-64 (what a precompiled release NIF targets) and -march=native
+        (Taskfile.yml:12);
+      * 1 thread (a reference search is single-threaded) and T = host cores concurrent readers (how
+        the reference gets throughput: dirty schedulers under RwLock::read, nifs.rs:304-308).
+    The sample is >= 4 GB of rows, far beyond the last-level cache (r03 timed 614 MB, which flattered
+    the CPU on a 256-core box).  `value` is the reference-shaped, x86-64, T-reader
+    figure: what a user of the published NIF gets from this box."""
+    import subprocess
+    rows = max(200_000, int(4.0e9 / (dim * 4)))
+    legs = 8
+    per_leg = max(1.0, budget_s / legs)
+    env = dict(os.environ, ROWS=str(rows), SECONDS_PER_LEG="%.2f" % per_leg)
     t0 = time.perf_counter()
-    done = 0
-    while done < len(qs) and time.perf_counter() - t0 < budget_s * 0.5:
-        ix.search(qs[done], limit)
-        done += 1
-    dt1 = time.perf_counter() - t0
-    single = rows * done / dt1
-    # T concurrent readers (ctypes releases the GIL inside the C search)
-    threads = max(1, os.cpu_count() or 1)
-    counts = [0] * threads
-    stop = time.perf_counter() + budget_s * 0.5
-
-    def reader(t):
-        i = t
-        while time.perf_counter() < stop:
-            ix.search(qs[i % len(qs)], limit)
-            counts[t] += 1
-            i += 1
-
-    t0 = time.perf_counter()
-    ths = [threading.Thread(target=reader, args=(t,)) for t in range(threads)]
-    for th in ths:
-        th.start()
-    for th in ths:
-        th.join()
-    dtn = time.perf_counter() - t0
-    multi = rows * sum(counts) / dtn
-    return {"rows_per_s_1": single, "rows_per_s_T": multi, "threads": threads, "sample_rows": rows,
-            "queries_1": done, "queries_T": sum(counts), "seconds": dt1 + dtn}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_variants.py")], env=env, capture_output=True, text=True,
+                         timeout=600)
+    if res.returncode != 0:
+        raise RuntimeError("tools/cpu_variants.py failed: " + res.stderr[-2000:])
+    variants = [json.loads(line) for line in res.stdout.splitlines() if line.startswith("{")]
+    for v in variants:
+        v["shape"] = "reference" if v["shape"].startswith("reference") else "contiguous"
+    def pick(build, shape, many):
+        for v in variants:
+            if v["build"] == build and v["shape"] == shape and (v["threads"] > 1) == many:
+                return v
+        return None
+    head, one = pick("x86-64", "reference", True), pick("x86-64", "reference", False)
+    return {"rows_per_s_T": head["rows_per_s"], "rows_per_s_1": one["rows_per_s"], "threads": head["threads"], "sample_rows": rows,
+            "sample_bytes": rows * dim * 4, "seconds": time.perf_counter() - t0, "seconds_per_leg": per_leg, "variants": variants}
 
 
 _READ_PEAK = {}
@@ -358,29 +362,16 @@ def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidat
         assert call(warmup + steps - 1, keep=True) == last and len(last[0]) == limit
     out = {"ms_per_step": dt / steps * 1e3, "value": steps * per / dt, "unit": "queries/s", "steps": steps, "warmup": warmup,
            "ms_per_step_with_event_timing": dt_profiled / steps * 1e3, "verified": True}
-    if mode == "batch" and p["nominate_launches"]:
-        # K2b: candidates nominated with bf16 operands -- the pass is priced against HBM (one
-        # launch reads every row once for all 256 queries); hits are exact all the same
-        assert p["batch_launches"] == 0
-        launches = p["nominate_launches"]
-        ms = p["nominate_ms"] / launches
-        gbs = p["nominate_bytes"] / launches / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    if mode == "batch":
         out["fallback_queries"] = p["batch_fallbacks"]
-        out["second_passes"] = p["nominate_second_passes"]
-        out["candidates_per_query"] = p["nominate_candidates"] / max(1, p["nominate_queries"])
-        out["roofline"] = {"bound": "hbm", "kernel": "bf16_scores_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_side_traffic("bf16_scores_kernel", len(ref), dim),
-                           "avg_launch_ms": ms, "algorithmic_bytes_per_launch": p["nominate_bytes"] / launches,
-                           "bf16_mfma_TFLOPs": p["nominate_flops"] / launches / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
-        out["end_to_end_frac"] = p["nominate_bytes"] / launches / (dt / steps) / 1e9 / HBM_PEAK_GBS
-    elif mode == "batch":
-        ms = p["batch_ms"] / max(1, p["batch_launches"])
-        tf = p["batch_flops"] / max(1e-9, p["batch_ms"]) / 1e9
-        out["fallback_queries"] = p["batch_fallbacks"]
-        out["roofline"] = {"bound": "mfma", "kernel": "mfma_scores_kernel", "achieved": tf, "peak": 157.3,
-                           "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": pmc_side_traffic("mfma_scores_kernel", len(ref), dim),
-                           "avg_launch_ms": ms,
-                           "algorithmic_flops_per_launch": p["batch_flops"] / max(1, p["batch_launches"])}
+        out["roofline"] = batch_roofline(p, len(ref), dim)
+        if p["nominate_launches"]:
+            assert p["batch_launches"] == 0
+            launches = p["nominate_launches"]
+            out["second_passes"] = p["nominate_second_passes"]
+            out["candidates_per_query"] = p["nominate_candidates"] / max(1, p["nominate_queries"])
+            out["bf16_shadow"] = nifs.flat_batch_shadow(ref)
+            out["end_to_end_frac"] = p["nominate_bytes"] / launches / (dt / steps) / 1e9 / HBM_PEAK_GBS
     else:
         key = {"single": "scan", "funnel": "prefix", "quantized": "hamming", "pattern": "hamming"}[mode]
         kern = {"single": "scan_topk_kernel", "funnel": "cosine_scan_kernel", "quantized": "hamming_dist_kernel",
@@ -424,6 +415,8 @@ def run_side_mode(a, torch, nifs, device):
         ref = nifs.flat_new_cosine()
     nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
     assert nifs.flat_set_batch_nominate(ref, _lib.NOMINATE_BF16 if a.nominate == "bf16" else _lib.NOMINATE_F32) == "ok"
+    if a.shadow == "off":
+        assert nifs.flat_set_batch_shadow(ref, _lib.SHADOW_OFF) == ("ok", ())
     assert nifs.flat_load_device_matrix(ref, doc_ids(0, a.rows), x.data_ptr(), a.rows, a.dim) == ("ok", ())
     del x
     torch.cuda.empty_cache()
@@ -443,7 +436,9 @@ def run_side_mode(a, torch, nifs, device):
     if batch:
         out["metric"] = "queries/sec, flat dot top-%d, N=%d d=%d, batch=%d" % (a.limit, a.rows, a.dim, per)
         out["config"] = {"workload": "index: :flat, metric: :dot, d=%d, N=%d, batch=%d queries (%s MFMA Q x D^T + exact rescoring)"
-                         % (a.dim, a.rows, per, a.nominate), "fallback_queries": r["fallback_queries"]}
+                         % (a.dim, a.rows, per, a.nominate), "fallback_queries": r["fallback_queries"],
+                         "bf16_shadow": r.get("bf16_shadow")}
+        out["ms_per_step_with_event_timing"] = r["ms_per_step_with_event_timing"]
     elif a.mode == "funnel":
         out["metric"] = "queries/sec, funnel_search (f64 cosine on prefix %s, keep %d, exact rerank top-%d), N=%d d=%d" % (
             a.stages, a.candidates, a.limit, a.rows, a.dim)
@@ -662,8 +657,251 @@ def side_legs(a, torch, nifs, L, device, main_ref):
     return side
 
 
+def batch_roofline(p, rows, dim, dt_per_step=None):
+    """The roofline object of a matrix-core batch leg from the library's HIP-event profile `p`:
+    K2s / K2b (bf16 nomination: one pass reads every row once for all <= 256 queries -- HBM-bound) or
+    K2 (FP32 matrix cores -- MFMA-bound).  Hits are exact either way."""
+    if p["nominate_launches"]:
+        launches = p["nominate_launches"]
+        ms = p["nominate_ms"] / launches
+        gbs = p["nominate_bytes"] / launches / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        from_shadow = p["nominate_shadow_launches"] == launches
+        kern = "shadow_scores_kernel" if from_shadow else "bf16_scores_kernel"
+        r = {"bound": "hbm", "kernel": kern, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_side_traffic(kern, rows, dim),
+             "traffic_source": PMC_SIDE_SOURCE if pmc_side_traffic(kern, rows, dim) is not None else None,
+             "avg_launch_ms": ms, "algorithmic_bytes_per_launch": p["nominate_bytes"] / launches,
+             "algorithmic_bytes_note": ("rows x d x 2: the pass reads the bf16 shadow of the rows (K2s)" if from_shadow else
+                                        "rows x d x 4: the pass streams the f32 rows and rounds them in registers (K2b)")
+                                       + "; the exact rescoring of ~%d gathered rows per query is a launch of its own"
+                                       % round(p["nominate_candidates"] / max(1, p["nominate_queries"])),
+             "bf16_mfma_TFLOPs": p["nominate_flops"] / launches / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+             "bf16_mfma_frac_of_2500_TFLOPs": p["nominate_flops"] / launches / (ms * 1e-3) / 1e12 / 2500.0 if ms > 0 else 0.0}
+        return r
+    ms = p["batch_ms"] / max(1, p["batch_launches"])
+    tf = p["batch_flops"] / max(1e-9, p["batch_ms"]) / 1e9
+    return {"bound": "mfma", "kernel": "mfma_scores_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+            "traffic": pmc_side_traffic("mfma_scores_kernel", rows, dim),
+            "traffic_source": PMC_SIDE_SOURCE if pmc_side_traffic("mfma_scores_kernel", rows, dim) is not None else None,
+            "avg_launch_ms": ms, "algorithmic_flops_per_launch": p["batch_flops"] / max(1, p["batch_launches"])}
+
+
+def measure_batches(a, torch, dist, nifs, _lib, L, ref, sharded, use_dist, launched, rank, world, devices, shards_in_process,
+                    force_sharded, total_rows, count, rccl_ranks, sharding, host_exchange, device):
+    """`--mode batch` on N > 1 GPUs (BASELINE configs[3]'s batched leg: 16 batches of 256 on the
+    row-sharded corpus): every shard answers the whole batch on its rows (K2s / K2b / K2 + exact
+    rescoring), the per-query lists meet once per batch -- inside the library on a one-process handle
+    (host-mapped lists, merge by (rank key, id bytes)), or as ONE all_gather of wire blocks between
+    ranks (vettore_amd/sharded.py search_batch) -- and are merged per query."""
+    per = a.batch
+    assert nifs.flat_set_batch_nominate(ref, _lib.NOMINATE_BF16 if a.nominate == "bf16" else _lib.NOMINATE_F32) == "ok"
+    nq = (a.steps + a.warmup) * per
+    qs = np.random.default_rng(SEED_QUERY).uniform(-1, 1, size=(nq, a.dim)).astype(np.float32)
+    if a.metric == "cosine":
+        qs /= np.linalg.norm(qs.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+    outs = (C.c_void_p * per)()
+    between_ranks = sharded is not None and use_dist
+
+    def step(i, keep=False):
+        q = np.ascontiguousarray(qs[i * per:(i + 1) * per])
+        if between_ranks:
+            res = sharded.search_batch(q, a.limit)
+            return [[(h[0], np.float32(h[1]).tobytes()) for h in hits] for hits in res] if keep else None
+        st = L.vt_flat_search_batch(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), per, a.dim, a.limit, outs)
+        if st != 0:
+            sys.exit("bench.py: flat_search_batch failed with status %d: %s" % (st, (L.vt_last_error() or b"").decode()))
+        if keep:
+            return [hits_of(L, C.c_void_p(outs[j])) for j in range(per)]
+        for j in range(per):
+            L.vt_hits_free(C.c_void_p(outs[j]))
+        return None
+
+    def single(q):
+        if between_ranks:
+            return [(h[0], np.float32(h[1]).tobytes()) for h in sharded.search(q, a.limit)]
+        h = C.c_void_p()
+        assert L.vt_flat_search(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), a.dim, a.limit, C.byref(h)) == 0
+        return hits_of(L, h)
+
+    t_build = time.perf_counter()
+    step(0)   # settles id ranks, row norms and the bf16 shadow: setup, not a step
+    t_build = time.perf_counter() - t_build
+
+    def sync():
+        if launched:
+            dist.barrier()
+        for dv in (set(devices) if (shards_in_process > 1 or force_sharded) else ()):
+            torch.cuda.synchronize(dv)
+        torch.cuda.synchronize()
+
+    def timed_run(profiling):
+        for i in range(a.warmup):
+            step(i)
+        nifs.flat_set_profiling(ref, profiling)
+        nifs.flat_get_profile(ref, reset=True)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(a.warmup, a.warmup + a.steps):
+            step(i)
+        sync()
+        dt = time.perf_counter() - t0
+        prof = nifs.flat_get_profile(ref, reset=True)
+        nifs.flat_set_profiling(ref, False)
+        if launched:
+            t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if host_exchange else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, prof
+
+    dt_events, prof = timed_run(True)
+    dt, _ = timed_run(False)
+    # outside the timed region: the batch equals its queries' single searches (every rank takes part)
+    last = step(a.warmup + a.steps - 1, keep=True)
+    for j in (0, per - 1):
+        assert single(qs[(a.warmup + a.steps - 1) * per + j]) == last[j], "batched result differs from the single-query path"
+    if use_dist:
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    out = {
+        "metric": "queries/sec, flat %s top-%d, N=%d d=%d, batch=%d on %d GPUs" % (a.metric, a.limit, total_rows, a.dim, per, a.gpus),
+        "value": a.steps * per / dt, "unit": "queries/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "ms_per_step_with_event_timing": dt_events / a.steps * 1e3,
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+        "dtype": "f32" if a.nominate == "f32" else "f32 (exact rescoring; bf16 nomination)", "data": "synthetic",
+        "rccl_ranks": rccl_ranks,
+        "config": {"workload": "index: :flat, metric: :%s, d=%d, N=%d, batch=%d queries (%s MFMA Q x D^T + exact rescoring), rows sharded over %d GPUs"
+                               % (a.metric, a.dim, total_rows, per, a.nominate, a.gpus),
+                   "rows_per_gpu": count, "reduce_order": a.reduce_order, "sharding": sharding, "processes": world,
+                   "setup_s": round(t_build, 1), "fallback_queries": prof["batch_fallbacks"], "verified": True},
+        "roofline": batch_roofline(prof, count, a.dim),
+    }
+    launches = max(1, prof["nominate_launches"] + prof["batch_launches"])
+    pass_ms = (prof["nominate_ms"] + prof["batch_ms"]) / launches
+    out["config"]["per_shard_pass_ms"] = pass_ms
+    out["config"]["exchange_ms"] = dt / a.steps * 1e3 - pass_ms   # rescoring, select, hand-off, exchange, merge: everything but the pass
+    if shards_in_process > 1 or force_sharded:
+        out["config"]["exchange_note"] = nifs.flat_exchange_note(ref)
+        out["config"]["devices"] = devices
+    if a.exchange_note:
+        out["config"]["exchange_note"] = (out["config"].get("exchange_note", "") + "; " if out["config"].get("exchange_note") else "") + a.exchange_note
+    C.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
+
+
+def json_line_of(text):
+    """The last line of `text` that parses as a JSON object (a child's result), or None."""
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def run_child(argv, exchange, note, port_shift, timeout):
+    """One supervised measurement: this script again with --child, in a process (group) of its own.
+    Returns (exit status or -9 after a timeout, its stdout, seconds).  The supervisor itself never
+    touches a GPU: a process that has initialised one cannot be replaced by another program, and a
+    wedged collective can only be left behind by ending the process that holds it."""
+    import signal
+    import subprocess
+    # (VT_BENCH_CHILD: tests/test_bench_supervisor.py puts a stand-in for the measurement there -- the
+    # supervisor's logic runs on a CPU box)
+    script = os.environ.get("VT_BENCH_CHILD") or os.path.abspath(__file__)
+    cmd = [sys.executable, script] + [v for v in argv if v != "--supervise"] + ["--child", "--exchange", exchange]
+    if note:
+        cmd += ["--exchange-note", note]
+    env = dict(os.environ)
+    if port_shift and "MASTER_PORT" in env:
+        env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + port_shift)  # (a rendezvous the first run left half open stays out of the way)
+    t0 = time.perf_counter()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)   # the group this call started, nothing else
+        except ProcessLookupError:
+            pass
+        out, _ = proc.communicate()
+        rc = -9
+    return rc, out.decode(errors="replace"), time.perf_counter() - t0
+
+
+def ranks_agree(tag, rank, world, ok, wait_s):
+    """Under torch.distributed.run every rank supervises its own child, and all of them must take
+    the same next step (a rank that goes on to the host exchange alone would wait for the others
+    for ever).  Each writes its verdict into a directory named after this launch (the launcher's
+    pid and the rendezvous port) and reads the others'; a rank that never reports counts as failed."""
+    import tempfile
+    d = os.path.join(tempfile.gettempdir(), "vt_bench_%d_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), tag))
+    os.makedirs(d, exist_ok=True)
+    tmp = os.path.join(d, "rank%d.tmp" % rank)
+    with open(tmp, "w") as f:
+        f.write("1" if ok else "0")
+    os.replace(tmp, os.path.join(d, "rank%d" % rank))
+    deadline = time.perf_counter() + wait_s
+    while time.perf_counter() < deadline:
+        seen = []
+        for r in range(world):
+            try:
+                with open(os.path.join(d, "rank%d" % r)) as f:
+                    seen.append(f.read().strip())
+            except OSError:
+                break
+        if len(seen) == world:
+            return all(v == "1" for v in seen)
+        time.sleep(0.05)
+    return False
+
+
+def supervise(a, argv):
+    """`bench.py --gpus N` for N > 1 (and `--supervise` at N = 1): the measurement runs in a fresh child
+    process over RCCL; should that child exit non-zero or not come back within --child-timeout -- a
+    communicator that does not initialise, an all-gather whose peers never arrive (the library then
+    fails the search with "RCCL exchange timed out ...", vt_multi.h) -- a second fresh child runs the
+    same steps over the host exchange, and its line is printed with config.exchange_note saying why.
+    The first multi-GPU run of a new node cannot come back empty (VERDICT r3 #2)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    launched = "WORLD_SIZE" in os.environ and world > 1
+    first = a.exchange if a.exchange != "auto" else "rccl"
+    attempts = [first] + (["host"] if first != "host" else [])
+    why = None
+    for i, exchange in enumerate(attempts):
+        rc, out, secs = run_child(argv, exchange, why, i, a.child_timeout)
+        line = json_line_of(out)
+        ok = rc == 0 and (line is not None or rank != 0)
+        mine = ok
+        if launched:
+            ok = ranks_agree("try%d" % i, rank, world, ok, a.child_timeout + 60.0)
+        if ok:
+            if rank == 0:
+                print(json.dumps(line), flush=True)
+            return 0
+        how = "was killed after %.0f s without an answer" % secs if rc == -9 else \
+              "exited with status %d after %.0f s" % (rc, secs) if rc != 0 else \
+              ("printed no result line" if not mine else "succeeded here but failed on another rank")
+        why = "the %s-exchange run %s; this line is the run over the host exchange" % (exchange, how)
+        sys.stderr.write("bench.py[rank %d]: %s\n" % (rank, why if i + 1 < len(attempts) else "the %s-exchange run %s" % (exchange, how)))
+        sys.stderr.flush()
+    return 1
+
+
 def main():
     a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    launched = "WORLD_SIZE" in os.environ and world > 1
+    if not a.child and (a.gpus > 1 or launched or a.supervise):
+        sys.exit(supervise(a, sys.argv[1:]))
+    return measure(a)
+
+
+def measure(a):
     steps_default = a.steps is None
     a.steps = 1000 if a.steps is None else a.steps
     a.warmup = 50 if a.warmup is None else a.warmup
@@ -679,6 +917,10 @@ def main():
     force_sharded = not launched and a.gpus == 1 and a.exchange != "auto"
     if force_sharded:
         os.environ["VT_SHARD_FORCE_WORKERS"] = "1"
+    # weak scaling: --rows is one GPU's share
+    total_rows = a.rows * a.gpus if a.scaling == "weak" else a.rows
+    normalize = a.metric == "cosine"   # (collection.ex:1317-1319: only cosine collections normalise what they store)
+    host_exchange = a.exchange == "host"
 
     import torch  # first: its bundled libamdhip64 must be the one the process shares
     import torch.distributed as dist
@@ -686,6 +928,10 @@ def main():
     from vettore_amd.sharded import ShardedFlat
     L = _lib.load()
 
+    if launched and a.devices:
+        # (under a launcher --devices names every rank's GPU: `--devices 0,0` lets a one-GPU box run two ranks,
+        # over the host exchange -- RCCL wants a device per rank)
+        local_rank = [int(v) for v in a.devices.split(",")][rank]
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = launched or a.force_exchange
@@ -693,15 +939,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         import datetime
-        # (a collective that does not complete fails the run after two minutes instead of torch's ten)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=120))
+        # (a collective that does not complete fails the run after two minutes instead of torch's ten;
+        # the host exchange needs no RCCL at all: 64-byte records over gloo)
+        if host_exchange:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=120))
     nifs.set_device(local_rank)
-    if a.mode != "single":
-        if a.gpus > 1:
+    multi = a.gpus > 1 or launched or force_sharded
+    if a.mode != "single" and not (a.mode == "batch" and multi):
+        if multi:
             sys.exit("--mode %s is a single-GPU measurement" % a.mode)
         if a.mode == "batch" and steps_default:
             a.steps, a.warmup = 8, 2
         return run_side_mode(a, torch, nifs, device)
+    if a.mode == "batch" and steps_default:
+        a.steps, a.warmup = 16, 2   # BASELINE configs[3]: 16 batches of 256
 
     t_build = time.perf_counter()
     rccl_ranks = 0
@@ -717,13 +970,13 @@ def main():
             os.environ["VT_SHARD_EXCHANGE"] = a.exchange
         ref = nifs.flat_new_sharded(nifs.METRIC_CODE[a.metric], devices)
         nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
-        all_idx = np.arange(1, a.rows + 1, dtype=np.int64)
-        route = nifs.flat_route_ids(ref, doc_ids(0, a.rows))
+        all_idx = np.arange(1, total_rows + 1, dtype=np.int64)
+        route = nifs.flat_route_ids(ref, doc_ids(0, total_rows))
         for s in range(shards_in_process):
             idx = all_idx[route == s]
             dev_s = torch.device("cuda", devices[s])
             with torch.cuda.device(dev_s):
-                x = build_shard(torch, dev_s, len(idx), a.dim, SEED_CORPUS + s)
+                x = build_shard(torch, dev_s, len(idx), a.dim, SEED_CORPUS + s, normalize=normalize)
                 res = nifs.flat_load_device_matrix(ref, doc_ids(0, 0, idx), x.data_ptr(), len(idx), a.dim)
                 assert res == ("ok", ()), res
                 del x
@@ -736,10 +989,10 @@ def main():
         sharded = None
     else:
         # ---- this rank's row block of the N-row corpus (one device per process) ----------------
-        per = a.rows // world
+        per = total_rows // world
         start = rank * per
-        count = per if rank < world - 1 else a.rows - start
-        x = build_shard(torch, device, count, a.dim, SEED_CORPUS + rank)
+        count = per if rank < world - 1 else total_rows - start
+        x = build_shard(torch, device, count, a.dim, SEED_CORPUS + rank, normalize=normalize)
         ids = doc_ids(start, count)
         ref = nifs._flat_new(nifs.METRIC_CODE[a.metric])
         nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
@@ -747,17 +1000,26 @@ def main():
         assert res == ("ok", ()), res
         del x
         torch.cuda.empty_cache()
-        sharded = ShardedFlat(ref, dist if use_dist else None, device, force_exchange=a.force_exchange)
-        if use_dist and os.environ.get("VT_HOST_EXCHANGE") is None:
+        # (over gloo the records travel as host tensors)
+        sharded = ShardedFlat(ref, dist if use_dist else None, torch.device("cpu") if host_exchange else device,
+                              force_exchange=a.force_exchange)
+        if use_dist and not host_exchange and os.environ.get("VT_HOST_EXCHANGE") is None:
             # one ordering of all ids -> shard keys compare on the device (see vettore_amd/sharded.py)
             sharded.enable_device_exchange(ids, max_limit=max(a.limit, 16))
         if use_dist:
             rccl_ranks = dist.get_world_size()
-        sharding = ("row blocks, one rank per GPU, all_gather of per-shard top-k (%s merge)" % ("device" if sharded._dev else "host")) \
-            if use_dist else "none"
+        sharding = ("row blocks, one rank per GPU, all_gather of per-shard top-k over %s (%s merge)"
+                    % ("gloo" if host_exchange else "RCCL", "device" if sharded._dev else "host")) if use_dist else "none"
+    for sh in ([ref] if a.shadow == "off" else []):
+        assert nifs.flat_set_batch_shadow(sh, _lib.SHADOW_OFF) == ("ok", ())
+
+    if a.mode == "batch":
+        return measure_batches(a, torch, dist, nifs, _lib, L, ref, sharded, use_dist, launched, rank, world, devices,
+                               shards_in_process, force_sharded, total_rows, count, rccl_ranks, sharding, host_exchange, device)
 
     nq = a.steps + a.warmup
-    qs = normalized_queries(nq, a.dim, SEED_QUERY)
+    qs = normalized_queries(nq, a.dim, SEED_QUERY) if normalize else \
+        np.random.default_rng(SEED_QUERY).uniform(-1, 1, size=(nq, a.dim)).astype(np.float32)
     hp = C.c_void_p()
 
     def search_c(q):
@@ -784,10 +1046,10 @@ def main():
             torch.cuda.synchronize(dv)
         torch.cuda.synchronize()
 
-    def timed_run():
+    def timed_run(profiling):
         for i in range(a.warmup):
             search(qs[i])
-        nifs.flat_set_profiling(ref, True)
+        nifs.flat_set_profiling(ref, profiling)
         nifs.flat_get_profile(ref, reset=True)
         sync()
         t0 = time.perf_counter()
@@ -797,14 +1059,19 @@ def main():
         dt = time.perf_counter() - t0
         prof = nifs.flat_get_profile(ref, reset=True)
         nifs.flat_set_profiling(ref, False)
-        assert len(hits) == min(a.limit, a.rows)
+        assert len(hits) == min(a.limit, total_rows)
+        if launched:
+            t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if host_exchange else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
         return dt, prof
 
-    dt, prof = timed_run()
-    if launched:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # The K timed steps twice, like every side leg: first WITH the library's
+    # HIP-event bookkeeping -- the dominant kernel's own duration, measured live on the stream it is
+    # launched on: the roofline figure --, then WITHOUT it -- two event records per call are two
+    # barrier packets in a chain of three launches -- end to end: `value` and `ms_per_step`.
+    dt_events, prof = timed_run(True)
+    dt, _ = timed_run(False)
 
     out = None
     if rank == 0:
@@ -813,21 +1080,22 @@ def main():
         bytes_per_launch = prof["scan_bytes"] / max(1, prof["scan_launches"])
         achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         out = {
-            "metric": "queries/sec, flat %s top-%d, N=%d d=%d (achieved HBM GB/s in roofline)" % (a.metric, a.limit, a.rows, a.dim),
+            "metric": "queries/sec, flat %s top-%d, N=%d d=%d (achieved HBM GB/s in roofline)" % (a.metric, a.limit, total_rows, a.dim),
             "value": qps,
             "unit": "queries/s",
             "n_gpus": a.gpus,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
+            "ms_per_step_with_event_timing": dt_events / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "rccl_ranks": rccl_ranks,
             "config": {
-                "workload": "index: :flat, metric: :%s, d=%d, N=%d, limit=%d, single query in flight" % (a.metric, a.dim, a.rows, a.limit),
+                "workload": "index: :flat, metric: :%s, d=%d, N=%d, limit=%d, single query in flight" % (a.metric, a.dim, total_rows, a.limit),
                 "rows_per_gpu": count,
                 "reduce_order": a.reduce_order,
                 "sharding": sharding,
@@ -842,6 +1110,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(count, a.dim),
+                "traffic_source": PMC_SOURCE if pmc_traffic(count, a.dim) is not None else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": scan_ms,
                 "measured_read_peak": measured_read_peak(devices[0]),
@@ -857,14 +1126,16 @@ def main():
         if shards_in_process > 1 or force_sharded:
             out["config"]["exchange_note"] = nifs.flat_exchange_note(ref)
             out["config"]["devices"] = devices
+        if a.exchange_note:
+            out["config"]["exchange_note"] = (out["config"].get("exchange_note", "") + "; " if out["config"].get("exchange_note") else "") + a.exchange_note
             if len(set(devices)) < len(devices):
                 # several shards on one GPU: their scans overlap, a launch sees a share of the card
                 out["roofline"]["note"] = "shards share a device: per-launch figures are one overlapping scan's share"
-                out["roofline"]["whole_job_GBps"] = a.rows * a.dim * 4 / (dt / a.steps) / 1e9 / len(set(devices))
+                out["roofline"]["whole_job_GBps"] = total_rows * a.dim * 4 / (dt / a.steps) / 1e9 / len(set(devices))
         if (shards_in_process > 1 or force_sharded) and rccl_ranks:
             # the same steps over the other exchange, for comparison (not the headline)
             assert nifs.flat_set_exchange(ref, _lib.EXCHANGE_HOST) == "ok"
-            dt2, _ = timed_run()
+            dt2, _ = timed_run(False)
             out["config"]["host_exchange_ms_per_step"] = dt2 / a.steps * 1e3
             assert nifs.flat_set_exchange(ref, _lib.EXCHANGE_RCCL) == "ok"
         if a.gpus == 1 and not launched and not a.no_side and not force_sharded and a.metric == "cosine":
@@ -876,12 +1147,15 @@ def main():
                 "unit": "queries/s",
                 "cores": cb["threads"],
                 "kind": "port",
-                "sample": "%d concurrent readers, %d queries over %d rows x %d in %.1f s (plus %d single-thread queries); "
-                          "rows/s scaled to N=%d" % (cb["threads"], cb["queries_T"], cb["sample_rows"], a.dim,
-                                                     cb["seconds"], cb["queries_1"], a.rows),
+                "sample": "reference-shaped search (flat.rs:96-124), -O3 for baseline x86-64, %d concurrent readers for %.1f s over a "
+                          "%d-row x %d sample of the same corpus (%.1f GB: beyond the last-level cache); rows/s scaled to N=%d; "
+                          "`variants`: the same sample under both builds, both layouts, 1 and T threads (%.0f s in all)"
+                          % (cb["threads"], cb["seconds_per_leg"], cb["sample_rows"], a.dim, cb["sample_bytes"] / 1e9, a.rows, cb["seconds"]),
                 "single_thread_value": cb["rows_per_s_1"] / a.rows,
                 "effective_GBps": cb["rows_per_s_T"] * a.dim * 4 / 1e9,
                 "single_thread_effective_GBps": cb["rows_per_s_1"] * a.dim * 4 / 1e9,
+                "variants": [{"build": v["build"], "shape": v["shape"], "threads": v["threads"],
+                              "value": v["rows_per_s"] / a.rows, "effective_GBps": v["effective_GBps"]} for v in cb["variants"]],
             }
     if use_dist:
         dist.destroy_process_group()

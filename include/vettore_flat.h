@@ -95,10 +95,12 @@ const char *vt_last_error(void);
 int vt_abi_version(void);
 /* Number of visible HIP devices (0 if none); never fails. */
 int vt_device_count(void);
-/* Diagnostic (bench.py's `measured_read_peak`): GB/s of the plainest read-only streaming kernel
- * over a scratch buffer of `bytes` (zero-filled; allocated and freed here) on `device`, best of
- * `reps` passes after one warm-up pass, timed with HIP events.  The yardstick beside the 8 TB/s
- * spec figure: no search kernel can stream faster than this one does on the same box. */
+/* Diagnostic (bench.py's `measured_read_peak`): GB/s of a bare read-only stream over a scratch buffer
+ * of `bytes` (random floats; allocated and freed here) on `device`, best of `reps` passes after one
+ * warm-up pass, timed with HIP events.  The stream is the LDS-DMA ring the batch passes read through
+ * with nothing consuming it (whole 384-KiB tiles, 1-KiB pieces, 64 KiB in flight per CU): the
+ * yardstick beside the 8 TB/s spec figure -- a search kernel that reads this way and also computes
+ * cannot stream faster on the same box. */
 int vt_device_read_peak(int device, size_t bytes, int reps, double *gbps);
 
 /* ------------------------------------------------------------------ hits
@@ -120,6 +122,17 @@ uint32_t vt_hits_rank_key(const vt_hits *hits, size_t i);
 #define VT_HIT_RECORD_BYTES 64
 #define VT_HIT_RECORD_ID_BYTES 52
 size_t vt_hits_pack(const vt_hits *hits, void *records, size_t cap);
+/* The same for the `nq` hit lists of a query batch, as the process-per-GPU exchange ships them
+ * (vettore_amd/sharded.py): `blocks` receives nq blocks of (limit + 1) records -- record 0 of a block
+ * is its header {u32 count, u32 long_ids}: the hits that follow, and whether an id of the block is
+ * longer than VT_HIT_RECORD_ID_BYTES (only its first bytes travel inline then). */
+void vt_hits_pack_many(const vt_hits *const *hits, size_t nq, size_t limit, void *blocks);
+/* ... and the merge on the receiving side: `blocks` holds world x nq such blocks (rank-major, as an
+ * all-gather leaves them); out_blocks receives nq blocks with the `limit` best hits of each query over
+ * all ranks by (rank key, id bytes) == FlatHit::cmp (flat.rs:34-40) -- one index over all rows would
+ * return exactly these.  A block whose header says long_ids is merged by the inline bytes only and keeps
+ * the flag: the caller must then order ties by the whole ids itself. */
+int vt_hit_blocks_merge(const void *blocks, size_t world, size_t nq, size_t limit, void *out_blocks);
 /* All hits in one call (bindings that would otherwise cross the ABI three times per hit):
  * vt_hits_id_bytes = total id bytes; vt_hits_export fills ids (concatenated), id_off
  * (len + 1 offsets), raw and rank_key (each len entries; null pointers are skipped). */

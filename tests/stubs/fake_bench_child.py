@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Stand-in for bench.py's supervised measurement (tests/test_bench_supervisor.py): takes the
+arguments the supervisor passes its child and behaves as FAKE_CHILD says, per rank --
+  ok            prints a result line (rank 0) and exits 0
+  rccl_fails    exits 3 under --exchange rccl (FAKE_FAIL_RANKS: only on those ranks), fine under host
+  rccl_hangs    sleeps under --exchange rccl (the supervisor's timeout must end it), fine under host
+  always_fails  exits 4 whatever the exchange
+No GPU, no library: the supervisor's logic is what runs."""
+import json
+import os
+import sys
+import time
+
+args = sys.argv[1:]
+assert "--child" in args, args
+exchange = [args[i + 1] for i, v in enumerate(args) if v == "--exchange"][-1]
+note = ([args[i + 1] for i, v in enumerate(args) if v == "--exchange-note"] or [None])[-1]
+rank = int(os.environ.get("RANK", "0"))
+mode = os.environ.get("FAKE_CHILD", "ok")
+fail_ranks = [int(v) for v in os.environ.get("FAKE_FAIL_RANKS", "").split(",") if v] or None
+hit = fail_ranks is None or rank in fail_ranks
+if mode == "always_fails":
+    sys.exit(4)
+if exchange == "rccl" and hit:
+    if mode == "rccl_fails":
+        sys.stderr.write("fake child: RCCL exchange timed out on shard 0\n")
+        sys.exit(3)
+    if mode == "rccl_hangs":
+        time.sleep(120)
+print("some banner a library prints on stdout")
+if rank == 0:
+    print(json.dumps({"metric": "fake", "value": 1.0, "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+                      "config": {"exchange": exchange, "exchange_note": note, "master_port": os.environ.get("MASTER_PORT")}}))

@@ -1,0 +1,93 @@
+"""bench.py's supervisor on a CPU box: `bench.py --gpus N` runs its measurement in a
+child process and, should that child fail or hang, once more over the host exchange -- the first
+multi-GPU run of a node must not come back empty.  The child here is tests/stubs/fake_bench_child.py
+(VT_BENCH_CHILD); the GPU leg of the same path is tests/test_gpu_bench_supervisor.py."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+FAKE = os.path.join(ROOT, "tests", "stubs", "fake_bench_child.py")
+
+
+def run(args, fake, timeout=60, **env):
+    e = dict(os.environ, VT_BENCH_CHILD=FAKE, FAKE_CHILD=fake)
+    e.update({k: str(v) for k, v in env.items()})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        if k not in env:
+            e.pop(k, None)
+    return subprocess.run([sys.executable, BENCH] + args, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def last_json(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, text   # ONE JSON line, whatever the children printed
+    return json.loads(lines[0])
+
+
+def test_a_healthy_rccl_run_is_printed_as_it_is():
+    r = run(["--gpus", "2", "--steps", "3"], "ok")
+    assert r.returncode == 0, r.stderr
+    line = last_json(r.stdout)
+    assert line["config"]["exchange"] == "rccl" and line["config"]["exchange_note"] is None
+
+
+def test_a_failing_rccl_child_is_followed_by_a_host_exchange_child():
+    r = run(["--gpus", "2", "--steps", "3"], "rccl_fails")
+    assert r.returncode == 0, r.stderr
+    line = last_json(r.stdout)
+    assert line["config"]["exchange"] == "host"
+    assert "rccl-exchange run exited with status 3" in line["config"]["exchange_note"], line
+    assert "host exchange" in r.stderr
+
+
+def test_a_hanging_rccl_child_is_killed_and_replaced():
+    r = run(["--gpus", "2", "--steps", "3", "--child-timeout", "1.5"], "rccl_hangs")
+    assert r.returncode == 0, r.stderr
+    line = last_json(r.stdout)
+    assert line["config"]["exchange"] == "host" and "was killed after" in line["config"]["exchange_note"], line
+
+
+def test_both_runs_failing_is_a_failure_with_no_line():
+    r = run(["--gpus", "2", "--steps", "3"], "always_fails")
+    assert r.returncode == 1 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_an_explicit_host_exchange_has_no_second_attempt():
+    r = run(["--gpus", "2", "--exchange", "host"], "always_fails")
+    assert r.returncode == 1
+    r = run(["--gpus", "2", "--exchange", "host"], "ok")
+    assert last_json(r.stdout)["config"]["exchange"] == "host"
+
+
+def test_one_gpu_runs_unsupervised_unless_asked():
+    # (N = 1 without --supervise goes straight into the measurement, which needs a GPU: only the supervised form is tested here)
+    r = run(["--gpus", "1", "--supervise", "--exchange", "rccl"], "rccl_fails")
+    assert r.returncode == 0 and last_json(r.stdout)["config"]["exchange"] == "host"
+
+
+def test_ranks_under_a_launcher_take_the_second_step_together():
+    """Two supervisors as torch.distributed.run would start them (RANK / WORLD_SIZE / MASTER_PORT): rank 1's
+    RCCL child fails, rank 0's succeeds -- both must go on to the host exchange (on the next port), and
+    only rank 0 prints."""
+    env = dict(os.environ, VT_BENCH_CHILD=FAKE, FAKE_CHILD="rccl_fails", FAKE_FAIL_RANKS="1", WORLD_SIZE="2", MASTER_PORT="29641",
+               MASTER_ADDR="127.0.0.1")
+    procs = []
+    for rank in (0, 1):
+        procs.append(subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--steps", "3"], env=dict(env, RANK=str(rank), LOCAL_RANK=str(rank)),
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    line = last_json(outs[0][0])
+    assert line["config"]["exchange"] == "host" and line["config"]["master_port"] == "29642", line
+    assert "failed on another rank" in line["config"]["exchange_note"]
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+
+
+def test_json_line_of_takes_the_last_object():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.json_line_of('x\n{"a": 1}\nNCCL banner\n{"b": 2}\ntrailing') == {"b": 2}
+    assert bench.json_line_of("nothing here") is None

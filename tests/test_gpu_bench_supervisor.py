@@ -1,0 +1,74 @@
+"""bench.py's multi-GPU forms on the one-GPU boxes of this pool: the supervisor's
+fallback driven by a real wedged all-gather, weak scaling, the batched leg on a sharded handle and
+between ranks.  What no test here can exercise is the wire between two devices."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+HOOKS = os.path.join(ROOT, "vettore_amd", "lib", "libvettore_hip_hooks.so")
+
+
+def bench(args, timeout=600, launcher=None, **env):
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher), "--master-addr", "127.0.0.1",
+                "--master-port", "29713"]
+    r = subprocess.run(cmd + [BENCH] + args, env=e, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_a_wedged_all_gather_ends_in_a_host_exchange_line():
+    """The RCCL child meets an all-gather that does not complete (the stall hook of libvettore_hip_hooks.so
+    in front of it, a 300-ms deadline behind it): the library fails the search with its message, the
+    child exits non-zero, the supervisor starts the host-exchange child and prints ITS line."""
+    assert os.path.exists(HOOKS)
+    r, line = bench(["--gpus", "1", "--supervise", "--exchange", "rccl", "--rows", "200000", "--steps", "20", "--warmup", "3",
+                     "--no-cpu", "--no-side"],
+                    VETTORE_HIP_LIB=HOOKS, VT_TEST_EXCHANGE_STALL_MS=2000, VT_EXCHANGE_TIMEOUT_MS=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "RCCL exchange timed out" in r.stderr
+    note = line["config"]["exchange_note"]
+    assert "rccl-exchange run exited with status" in note and "host exchange" in note, line
+    assert line["value"] > 0 and line["n_gpus"] == 1
+
+
+def test_a_healthy_one_rank_rccl_run_needs_no_second_child():
+    r, line = bench(["--gpus", "1", "--supervise", "--exchange", "rccl", "--rows", "200000", "--steps", "20", "--warmup", "3", "--no-cpu",
+                     "--no-side"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["rccl_ranks"] == 1 and "this line is the run over the host exchange" not in line["config"].get("exchange_note", "")
+    assert "exchange_ms" in line["config"] and "per_shard_scan_ms" in line["config"]
+
+
+def test_weak_scaling_and_the_batched_leg_on_a_two_shard_handle():
+    r, line = bench(["--gpus", "2", "--devices", "0,0", "--scaling", "weak", "--rows", "150000", "--steps", "10", "--warmup", "2", "--no-cpu"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["scaling"] == "weak" and "N=300000" in line["metric"] and line["n_gpus"] == 2, line
+    r, line = bench(["--gpus", "2", "--devices", "0,0", "--mode", "batch", "--metric", "l2", "--batch", "64", "--rows", "300000",
+                     "--steps", "4", "--warmup", "1", "--no-cpu"], VT_FORCE_BATCH_MFMA=1)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["config"]["verified"] and "batch=64" in line["metric"] and line["roofline"]["kernel"] == "shadow_scores_kernel", line
+    assert line["config"]["per_shard_pass_ms"] > 0
+
+
+def test_two_ranks_under_the_launcher_over_the_host_exchange():
+    """torch.distributed.run with two ranks on the one GPU: RCCL cannot serve that, so the line comes from the
+    gloo / 64-byte-record exchange -- single queries and the batched leg."""
+    r, line = bench(["--gpus", "2", "--devices", "0,0", "--exchange", "host", "--rows", "200000", "--steps", "10", "--warmup", "2", "--no-cpu"],
+                    launcher=2)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["config"]["processes"] == 2 and "gloo" in line["config"]["sharding"], line
+    r, line = bench(["--gpus", "2", "--devices", "0,0", "--exchange", "host", "--mode", "batch", "--metric", "l2", "--batch", "32",
+                     "--rows", "200000", "--steps", "3", "--warmup", "1", "--no-cpu"], launcher=2, VT_FORCE_BATCH_MFMA=1)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["config"]["verified"] and line["config"]["processes"] == 2, line

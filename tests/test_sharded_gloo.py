@@ -45,11 +45,19 @@ def _worker(rank, world, port, outq):
                 return [(i, r, total_key(oracle.rank_value(metric, r)) + (1 << 31)) for i, r in hits]
 
             sf = ShardedFlat(None, dist, None, local_search=local)
+            batch = []
             for qi in range(4):
                 q = x[(qi * 37) % n] if qi % 2 == 0 else rng.uniform(-1, 1, d).astype(np.float32)
+                batch.append(q)
                 got = sf.search(q, 10)
                 whole = oracle.matrix_search(metric, x, oracle.pack_ids(ids), q, 10)
                 results.append(got == whole)
+            # the batched form (configs[3]'s 16 x 256 leg): one all_gather of wire blocks for the whole
+            # batch, merged per query by vt_hit_blocks_merge (or, with ids too long for a record, here)
+            got_b = sf.search_batch(np.stack(batch), 10)
+            whole_b = [oracle.matrix_search(metric, x, oracle.pack_ids(ids), q, 10) for q in batch]
+            results.append([[(h[0], np.float32(h[1]).tobytes()) for h in hits] for hits in got_b] ==
+                           [[(h[0], np.float32(h[1]).tobytes()) for h in hits] for hits in whole_b])
         # the global id ranking behind the device-side exchange: uneven shards, ids that
         # sort differently bytewise and numerically ("doc-10" < "doc-9")
         from vettore_amd.sharded import gather_global_ranks
@@ -83,7 +91,7 @@ def test_two_rank_sharded_search_equals_single_index():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(o[0] for o in outs) == [0, 1]
-    assert all(o[1] for o in outs) and all(o[2] == 13 for o in outs), outs
+    assert all(o[1] for o in outs) and all(o[2] == 16 for o in outs), outs
 
 
 def test_pack_unpack_roundtrip():

@@ -32,8 +32,11 @@ def build(tag):
 def child(tag, rows, dim, seconds):
     import oracle
     rng = np.random.default_rng(20260721)
-    x = rng.uniform(-1.0, 1.0, size=(rows, dim)).astype(np.float32)
-    x /= np.sqrt(np.sum(x.astype(np.float64) ** 2, axis=1, keepdims=True)).astype(np.float32)
+    x = np.empty((rows, dim), dtype=np.float32)
+    for s0 in range(0, rows, 1 << 16):   # (in pieces: a sample of several GB must not exist twice, let alone in f64)
+        blk = rng.random((min(rows, s0 + (1 << 16)) - s0, dim), dtype=np.float32) * 2.0 - 1.0
+        blk /= np.sqrt(np.sum(blk.astype(np.float64) ** 2, axis=1, keepdims=True)).astype(np.float32)
+        x[s0:s0 + len(blk)] = blk
     ids = [b"doc-%d" % (i + 1) for i in range(rows)]
     packed = oracle.pack_ids(ids)
     ix = oracle.FlatIndex(2)
@@ -42,7 +45,7 @@ def child(tag, rows, dim, seconds):
     qs /= np.linalg.norm(qs, axis=1, keepdims=True)
     shapes = {"reference-shaped (hash map of rows, id clone per row)": lambda q: ix.search(q, 10),
               "contiguous matrix": lambda q: oracle.matrix_search(2, x, packed, q, 10)}
-    T = max(1, os.cpu_count() or 1)
+    T = max(1, int(os.environ.get("THREADS", "0")) or os.cpu_count() or 1)
     for shape, fn in shapes.items():
         for threads in (1, T):
             counts = [0] * threads

@@ -450,8 +450,12 @@ struct CosineScanMultiArgs {
 size_t cosine_scan_multi_lds_bytes();
 hipError_t launch_cosine_scan_multi(const CosineScanMultiArgs &a, uint32_t blocks, hipStream_t s);
 
-// Diagnostic: one pass of a plain read-only kernel over `bytes` of `buf` (vt_device_read_peak).
+// Diagnostic (vt_device_read_peak): one pass of the bare LDS-DMA read stream over the whole 384-KiB tiles of
+// `buf` (read_peak_bytes(bytes) of it), `blocks` blocks of 512 threads -- one per CU; launch_peak_fill puts
+// random floats there first.
 hipError_t launch_read_peak(const void *buf, size_t bytes, float *sink, uint32_t blocks, hipStream_t s);
+size_t read_peak_bytes(size_t bytes);
+hipError_t launch_peak_fill(void *buf, size_t bytes, hipStream_t s);
 
 // normalize_l2 (distances.rs:350-361) on rows: out = (x / sqrt(f64 sum x^2)) as f32.
 hipError_t launch_normalize_l2(const float *in, uint32_t n, uint32_t d, float *out, hipStream_t s);

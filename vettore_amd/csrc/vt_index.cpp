@@ -91,10 +91,11 @@ int vt_device_read_peak(int device, size_t bytes, int reps, double *gbps) {
   auto body = [&]() -> int {
     VT_HIP(hipMalloc(&buf, bytes));
     VT_HIP(hipMalloc(reinterpret_cast<void **>(&sink), 16));
-    VT_HIP(hipMemset(buf, 0, bytes));
+    VT_HIP(vt::launch_peak_fill(buf, bytes, nullptr));
     VT_HIP(hipEventCreate(&e0));
     VT_HIP(hipEventCreate(&e1));
-    const uint32_t blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8;
+    const uint32_t blocks = (uint32_t)std::max(1, prop.multiProcessorCount);  // one 8-wave block per CU (80 KiB of LDS each)
+    const size_t read_bytes = vt::read_peak_bytes(bytes);
     for (int r = 0; r <= reps; ++r) {  // pass 0 warms up
       VT_HIP(hipEventRecord(e0, nullptr));
       VT_HIP(vt::launch_read_peak(buf, bytes, sink, blocks, nullptr));
@@ -102,7 +103,7 @@ int vt_device_read_peak(int device, size_t bytes, int reps, double *gbps) {
       VT_HIP(hipEventSynchronize(e1));
       float ms = 0.f;
       VT_HIP(hipEventElapsedTime(&ms, e0, e1));
-      if (r > 0 && ms > 0.f) best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
+      if (r > 0 && ms > 0.f) best = std::max(best, (double)read_bytes / (ms * 1e-3) / 1e9);
     }
     return VT_OK;
   };
@@ -137,6 +138,75 @@ size_t vt_hits_pack(const vt_hits *h, void *records, size_t cap) {
   }
   return n;
 }
+void vt_hits_pack_many(const vt_hits *const *hits, size_t nq, size_t limit, void *blocks) {
+  if (!hits || !blocks) return;
+  unsigned char *out = static_cast<unsigned char *>(blocks);
+  const size_t block = (limit + 1) * VT_HIT_RECORD_BYTES;
+  for (size_t i = 0; i < nq; ++i) {
+    unsigned char *b = out + i * block;
+    std::memset(b, 0, VT_HIT_RECORD_BYTES);
+    const uint32_t n = hits[i] ? (uint32_t)vt_hits_pack(hits[i], b + VT_HIT_RECORD_BYTES, limit) : 0u;
+    uint32_t long_ids = 0;
+    for (uint32_t j = 0; j < n; ++j) long_ids |= hits[i]->ids[j].size() > VT_HIT_RECORD_ID_BYTES ? 1u : 0u;
+    std::memcpy(b, &n, 4);
+    std::memcpy(b + 4, &long_ids, 4);
+  }
+}
+
+int vt_hit_blocks_merge(const void *blocks, size_t world, size_t nq, size_t limit, void *out_blocks) {
+  return guarded([&]() -> int {
+  if (!blocks || !out_blocks || world == 0) return VT_ERR_ARGUMENT;
+  const unsigned char *in = static_cast<const unsigned char *>(blocks);
+  unsigned char *out = static_cast<unsigned char *>(out_blocks);
+  const size_t block = (limit + 1) * VT_HIT_RECORD_BYTES;
+  struct Rec {
+    uint32_t key;
+    const unsigned char *p;
+  };
+  auto less = [](const Rec &a, const Rec &b) {
+    if (a.key != b.key) return a.key < b.key;
+    uint32_t la, lb;
+    std::memcpy(&la, a.p + 8, 4);
+    std::memcpy(&lb, b.p + 8, 4);
+    const size_t ia = std::min<size_t>(la, VT_HIT_RECORD_ID_BYTES), ib = std::min<size_t>(lb, VT_HIT_RECORD_ID_BYTES);
+    const int c = std::memcmp(a.p + 12, b.p + 12, std::min(ia, ib));
+    if (c) return c < 0;
+    return la < lb;  // bytewise String order: a prefix sorts first
+  };
+  parallel_for(nq, 32, [&](size_t lo, size_t hi) {
+    std::vector<Rec> recs;
+    for (size_t q = lo; q < hi; ++q) {
+      recs.clear();
+      uint32_t long_ids = 0;
+      for (size_t r = 0; r < world; ++r) {
+        const unsigned char *b = in + (r * nq + q) * block;
+        uint32_t n, fl;
+        std::memcpy(&n, b, 4);
+        std::memcpy(&fl, b + 4, 4);
+        long_ids |= fl;
+        n = (uint32_t)std::min<size_t>(n, limit);
+        for (uint32_t j = 0; j < n; ++j) {
+          const unsigned char *p = b + (size_t)(j + 1) * VT_HIT_RECORD_BYTES;
+          Rec rc;
+          std::memcpy(&rc.key, p, 4);
+          rc.p = p;
+          recs.push_back(rc);
+        }
+      }
+      const size_t k = std::min(limit, recs.size());
+      std::partial_sort(recs.begin(), recs.begin() + k, recs.end(), less);
+      unsigned char *o = out + q * block;
+      std::memset(o, 0, block);
+      const uint32_t n = (uint32_t)k;
+      std::memcpy(o, &n, 4);
+      std::memcpy(o + 4, &long_ids, 4);
+      for (size_t j = 0; j < k; ++j) std::memcpy(o + (j + 1) * VT_HIT_RECORD_BYTES, recs[j].p, VT_HIT_RECORD_BYTES);
+    }
+  });
+  return VT_OK;
+  });
+}
+
 size_t vt_hits_id_bytes(const vt_hits *h) {
   size_t total = 0;
   if (h)

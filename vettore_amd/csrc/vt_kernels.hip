@@ -2071,27 +2071,62 @@ hipError_t launch_cosine_scan(const CosineScanArgs &a, uint32_t blocks, hipStrea
   return hipGetLastError();
 }
 
-// The plainest read-only streaming kernel (tools/hbm_peak.hip's `read`): every lane sums 16-byte
-// non-temporal loads, 8 in flight, nothing is written.  What it reaches is the yardstick
-// bench.py quotes beside the 8 TB/s spec figure (vt_device_read_peak).
-__global__ __launch_bounds__(256) void read_peak_kernel(const f32x4 *__restrict__ p, size_t n16, float *out) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (; i + 7 * stride < n16; i += 8 * stride) {
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + i + u * stride);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[u];
+// The yardstick bench.py quotes beside the 8 TB/s spec figure (vt_device_read_peak): a read-only
+// stream that does strictly less than any search kernel and reads the way the fastest of them do --
+// the LDS-DMA ring of the batch passes (vt_batch_shadow.hip) with nobody consuming it.  A block of 8
+// waves owns 384-KiB tiles of the buffer; wave w streams two 24-KiB runs of a tile KiB by KiB
+// (global_load_lds_dwordx4 nt: 64 lanes x 16 B per piece) into its 2 KiB of each of five LDS stages,
+// four chunks = 64 KiB per CU in flight behind a counted vmcnt.  Nothing is computed or written.
+// (r03's yardstick -- 16-byte loads to registers strided over the whole grid, on a zero-filled buffer
+// -- read SLOWER than the product's scan: a yardstick below the thing it measures is noise)
+constexpr uint32_t kPeakStages = 5, kPeakRun = 24 * 1024, kPeakTile = 16 * kPeakRun;
+__global__ __launch_bounds__(512, 1) void read_peak_kernel(const char *__restrict__ p, uint32_t ntiles) {
+  extern __shared__ __align__(16) unsigned char peak_lds[];
+  const uint32_t lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)peak_lds;
+  const uint32_t off0 = (2 * wid) * kPeakRun + lane * 16, off1 = off0 + kPeakRun;
+  uint32_t stage = 0;
+  for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const char *base = p + (size_t)t * kPeakTile;
+    for (uint32_t c = 0; c < kPeakRun / 1024; ++c) {
+      stage = __builtin_amdgcn_readfirstlane(stage);
+      const uint64_t b = reinterpret_cast<uint64_t>(base + (size_t)c * 1024);
+      const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+      const uint32_t m0a = lds0 + stage * 16384 + (2 * wid) * 1024, m0b = m0a + 1024;
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this stage's previous two pieces (five chunks ago) have landed
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" : : "s"(m0a), "v"(off0), "s"(sb) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" : : "s"(m0b), "v"(off1), "s"(sb) : "memory");
+      stage = stage + 1 == kPeakStages ? 0u : stage + 1;
+    }
   }
-  for (; i < n16; i += stride) acc += __builtin_nontemporal_load(p + i);
-  const float s = acc.x + acc.y + acc.z + acc.w;
-  if (s == 123456.789f) out[0] = s;  // never true for a zero-filled buffer: keeps the loads alive
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(256) void peak_fill_kernel(uint32_t *p, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint32_t h = (uint32_t)i * 2654435761u + 12345u;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    p[i] = (h & 0x807fffffu) | 0x3f000000u;  // floats of either sign in [0.5, 1): random mantissas, like rows
+  }
 }
 
 hipError_t launch_read_peak(const void *buf, size_t bytes, float *sink, uint32_t blocks, hipStream_t s) {
-  hipLaunchKernelGGL(read_peak_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(buf), bytes / 16, sink);
+  (void)sink;
+  const uint32_t ntiles = (uint32_t)(bytes / kPeakTile);  // (whole tiles only: read_peak_bytes() says how much that is)
+  const int lds_bytes = (int)(kPeakStages * 16384);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(read_peak_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(read_peak_kernel, dim3(blocks), dim3(512), lds_bytes, s, reinterpret_cast<const char *>(buf), ntiles);
+  return hipGetLastError();
+}
+size_t read_peak_bytes(size_t bytes) { return bytes / kPeakTile * kPeakTile; }
+hipError_t launch_peak_fill(void *buf, size_t bytes, hipStream_t s) {
+  hipLaunchKernelGGL(peak_fill_kernel, dim3(4096), dim3(256), 0, s, reinterpret_cast<uint32_t *>(buf), bytes / 4);
   return hipGetLastError();
 }
 

@@ -307,6 +307,51 @@ def flat_search_packed(index: FlatRef, query, limit: int, records: np.ndarray):
     return ("ok", (int(n), long_ids))
 
 
+def flat_search_batch_blocks(index: FlatRef, queries, limit: int, blocks: np.ndarray):
+    """flat_search_batch whose hit lists land as wire blocks (vt_hits_pack_many) in the caller's
+    uint8 array [nq][limit + 1][64]: record 0 of a block is its header {u32 count, u32 long_ids}.
+    Returns ("ok", long_ids) where long_ids is None or, when some id does not fit a record, the
+    ids of every hit as [[bytes] per query]."""
+    q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32))
+    if q.ndim != 2:
+        raise TypeError("badarg: queries must be a matrix")
+    nq, d = q.shape
+    assert blocks.dtype == np.uint8 and blocks.shape == (nq, limit + 1, 64) and blocks.flags.c_contiguous
+    L = _lib.load()
+    outs = (C.c_void_p * max(nq, 1))()
+    st = L.vt_flat_search_batch(index.handle, _fp(q.reshape(-1)), nq, d, limit, outs)
+    if st != 0:
+        return _err(st)
+    try:
+        L.vt_hits_pack_many(outs, nq, limit, blocks.ctypes.data_as(C.c_void_p))
+        long_ids = None
+        if nq and int(blocks[:, 0, 4:8].view(np.uint32).max()) != 0:
+            ln = C.c_size_t()
+            long_ids = [[C.string_at(L.vt_hits_id(C.c_void_p(outs[i]), j, C.byref(ln)), ln.value)
+                         for j in range(L.vt_hits_len(C.c_void_p(outs[i])))] for i in range(nq)]
+    finally:
+        for i in range(nq):
+            L.vt_hits_free(C.c_void_p(outs[i]))
+    return ("ok", long_ids)
+
+
+def hit_blocks_merge(blocks: np.ndarray, world: int, nq: int, limit: int) -> np.ndarray:
+    """[world][nq][limit + 1][64] gathered wire blocks -> [nq][limit + 1][64]: per query the `limit` best
+    over all ranks by (rank key, id bytes) (vt_hit_blocks_merge; FlatHit::cmp, flat.rs:34-40)."""
+    b = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(world, nq, limit + 1, 64)
+    out = np.zeros((nq, limit + 1, 64), dtype=np.uint8)
+    st = _lib.load().vt_hit_blocks_merge(b.ctypes.data_as(C.c_void_p), world, nq, limit, out.ctypes.data_as(C.c_void_p))
+    if st != 0:
+        raise RuntimeError(_lib.error_text(st))
+    return out
+
+
+def unpack_block(block: np.ndarray):
+    """[(id, raw)] of one wire block ([limit + 1][64]); ids longer than 52 bytes come back as None."""
+    head = block[0, :8].view(np.uint32)
+    return [(h[0], h[1]) for h in unpack_records(block[1:], int(head[0]))]
+
+
 def unpack_records(records: np.ndarray, count: int):
     """[(id, raw, rank_key)] from `count` wire records (ids longer than 52 bytes come back as None)."""
     out = []

@@ -188,6 +188,71 @@ class ShardedFlat:
             buf = self._bufs[limit] = (send_host, send_host.numpy(), send_dev, gathered, on_gpu)
         return buf
 
+    def search_batch(self, queries, limit: int) -> List[List[Tuple[bytes, float]]]:
+        """flat_search_batch over all shards (BASELINE configs[3]'s batched leg: 16 x 256 queries):
+        every rank answers the whole batch on its rows (one shared pass per <= 256 queries), the ranks'
+        hit lists meet in ONE all_gather of fixed-size wire blocks (nq x (limit + 1) x 64 B per rank:
+        180 KB at 256 queries, limit 10) and are merged per query by (rank key, id bytes) in the
+        library (vt_hit_blocks_merge).  `local_search_batch` may stand in for the shard (CPU tests)."""
+        from . import nifs
+        q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32))
+        nq = q.shape[0]
+        if self.dist is None or (self.world == 1 and not self.force_exchange):
+            if self._local is not None:
+                return [[(h[0], h[1]) for h in self._local(v, limit)] for v in q]
+            res = nifs.flat_search_batch(self.ref, q, limit)
+            if res[0] != "ok":
+                raise RuntimeError(res[1])
+            return res[1]
+        torch = self._torch
+        on_gpu = self.device is not None and getattr(self.device, "type", "cpu") != "cpu"
+        key = ("batch", nq, limit)
+        buf = self._bufs.get(key)
+        if buf is None:
+            send_host = torch.zeros((nq, limit + 1, REC), dtype=torch.uint8)
+            if on_gpu:
+                send_host = send_host.pin_memory()
+            send_dev = torch.empty_like(send_host, device=self.device) if on_gpu else send_host
+            gathered = torch.empty(self.world * nq * (limit + 1) * REC, dtype=torch.uint8, device=send_dev.device)
+            buf = self._bufs[key] = (send_host, send_host.numpy(), send_dev, gathered)
+        send_host, send_np, send_dev, gathered = buf
+        long_ids = None
+        if self._local is None:
+            res = nifs.flat_search_batch_blocks(self.ref, q, limit, send_np)
+            if res[0] != "ok":
+                raise RuntimeError(res[1])
+            long_ids = res[1]
+        else:
+            for i in range(nq):
+                hits = self._local(q[i], limit)
+                send_np[i] = pack_hits(hits, limit).reshape(limit + 1, REC)
+                if any(len(h[0]) > MAX_ID for h in hits):
+                    long_ids = long_ids or [None] * nq
+                    long_ids[i] = [h[0] for h in hits]
+        if on_gpu:
+            send_dev.copy_(send_host, non_blocking=True)
+        self.dist.all_gather_into_tensor(gathered, send_dev.reshape(-1))
+        host = gathered.cpu().numpy().reshape(self.world, nq, limit + 1, REC)
+        any_long = bool(host[:, :, 0, 4:8].view(np.uint32).any())
+        if not any_long:
+            merged = nifs.hit_blocks_merge(host, self.world, nq, limit)
+            return [nifs.unpack_block(merged[i]) for i in range(nq)]
+        # ids longer than a record: a second (object) exchange carries them whole, the merge runs here
+        objs = [None] * self.world
+        if long_ids is None:
+            long_ids = [None] * nq
+        mine = [long_ids[i] if long_ids[i] is not None else [h[0] for h in unpack_hits(send_np[i].reshape(-1), limit)[0]]
+                for i in range(nq)]
+        self.dist.all_gather_object(objs, mine)
+        out = []
+        for i in range(nq):
+            per_rank = []
+            for r in range(self.world):
+                h, _ = unpack_hits(host[r, i].reshape(-1), limit)
+                per_rank.append([(objs[r][i][j], x[1], x[2]) for j, x in enumerate(h)])
+            out.append(merge_shards(per_rank, limit))
+        return out
+
     def search(self, query, limit: int) -> List[Tuple[bytes, float]]:
         if self.dist is None or (self.world == 1 and not self.force_exchange):
             return [(h[0], h[1]) for h in self._local_search(query, limit)]
