@@ -29,59 +29,76 @@ def build(tag):
     return out
 
 
-def child(tag, rows, dim, seconds):
+def child(tags, rows, dim, seconds):
+    """Both builds in ONE process over ONE sample (the sample costs more to make than to scan).  The
+    sample is cut into 8 parts, each an index of its own; a reader walks the parts round-robin (every
+    reader from another start) and stops when its time is up, so a leg takes `seconds` plus at most
+    one part -- 256 readers each finishing a whole 4-GB scan would be a minute per leg -- while the
+    working set stays the whole sample."""
+    import gc
     import oracle
     rng = np.random.default_rng(20260721)
     x = np.empty((rows, dim), dtype=np.float32)
     for s0 in range(0, rows, 1 << 16):   # (in pieces: a sample of several GB must not exist twice, let alone in f64)
         blk = rng.random((min(rows, s0 + (1 << 16)) - s0, dim), dtype=np.float32) * 2.0 - 1.0
-        blk /= np.sqrt(np.sum(blk.astype(np.float64) ** 2, axis=1, keepdims=True)).astype(np.float32)
+        blk /= np.sqrt(np.einsum("ij,ij->i", blk, blk, dtype=np.float64))[:, None].astype(np.float32)
         x[s0:s0 + len(blk)] = blk
     ids = [b"doc-%d" % (i + 1) for i in range(rows)]
-    packed = oracle.pack_ids(ids)
-    ix = oracle.FlatIndex(2)
-    ix.insert_matrix(ids, x)
     qs = np.random.default_rng(20260722).uniform(-1, 1, size=(64, dim)).astype(np.float32)
     qs /= np.linalg.norm(qs, axis=1, keepdims=True)
-    shapes = {"reference-shaped (hash map of rows, id clone per row)": lambda q: ix.search(q, 10),
-              "contiguous matrix": lambda q: oracle.matrix_search(2, x, packed, q, 10)}
+    P = 8
+    cut = [rows * p // P for p in range(P + 1)]
     T = max(1, int(os.environ.get("THREADS", "0")) or os.cpu_count() or 1)
-    for shape, fn in shapes.items():
-        for threads in (1, T):
-            counts = [0] * threads
-            stop = time.perf_counter() + seconds
+    for tag in tags:
+        os.environ["VT_ORACLE_LIB"] = build(tag)
+        oracle._lib = None   # bind this build (every object of the previous one is gone by now)
+        oracle.lib()
+        packed = [oracle.pack_ids(ids[cut[p]:cut[p + 1]]) for p in range(P)]
+        parts = []
+        for p in range(P):
+            ix = oracle.FlatIndex(2)
+            ix.insert_matrix(ids[cut[p]:cut[p + 1]], x[cut[p]:cut[p + 1]])
+            parts.append(ix)
+        shapes = {"reference-shaped (hash map of rows, id clone per row)": lambda q, p: parts[p].search(q, 10),
+                  "contiguous matrix": lambda q, p: oracle.matrix_search(2, x[cut[p]:cut[p + 1]], packed[p], q, 10)}
+        for shape, fn in shapes.items():
+            for threads in (1, T):
+                scanned = [0] * threads
+                fn(qs[0], 0)
+                stop = time.perf_counter() + seconds
 
-            def reader(t):
-                i = t
-                while time.perf_counter() < stop:
-                    fn(qs[i % len(qs)])
-                    counts[t] += 1
-                    i += 1
+                def reader(t):
+                    i = t
+                    while time.perf_counter() < stop:
+                        p = i % P
+                        fn(qs[(i // P) % len(qs)], p)
+                        scanned[t] += cut[p + 1] - cut[p]
+                        i += 1
 
-            fn(qs[0])
-            t0 = time.perf_counter()
-            ths = [threading.Thread(target=reader, args=(t,)) for t in range(threads)]
-            for th in ths:
-                th.start()
-            for th in ths:
-                th.join()
-            dt = time.perf_counter() - t0
-            rps = rows * sum(counts) / dt
-            print(json.dumps({"build": tag, "shape": shape, "threads": threads, "sample_rows": rows, "dim": dim,
-                              "rows_per_s": round(rps), "effective_GBps": round(rps * dim * 4 / 1e9, 2),
-                              "queries_per_s_at_10M": round(rps / 1e7, 3)}), flush=True)
+                t0 = time.perf_counter()
+                ths = [threading.Thread(target=reader, args=(t,)) for t in range(threads)]
+                for th in ths:
+                    th.start()
+                for th in ths:
+                    th.join()
+                dt = time.perf_counter() - t0
+                rps = sum(scanned) / dt
+                print(json.dumps({"build": tag, "shape": shape, "threads": threads, "sample_rows": rows, "dim": dim,
+                                  "rows_per_s": round(rps), "effective_GBps": round(rps * dim * 4 / 1e9, 2),
+                                  "queries_per_s_at_10M": round(rps / 1e7, 3), "leg_seconds": round(dt, 2)}), flush=True)
+        del parts, shapes, fn, ix
+        gc.collect()
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
-        child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
+        child(sys.argv[2].split(","), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
         return
     rows = int(os.environ.get("ROWS", "200000"))
     seconds = float(os.environ.get("SECONDS_PER_LEG", "4"))
     for tag in FLAGS:
-        env = dict(os.environ, VT_ORACLE_LIB=build(tag))
-        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", tag, str(rows), "768", str(seconds)],
-                              env=env)
+        build(tag)
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", ",".join(FLAGS), str(rows), "768", str(seconds)])
 
 
 if __name__ == "__main__":

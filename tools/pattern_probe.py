@@ -15,7 +15,10 @@ from vettore_amd import nifs  # noqa: E402
 
 rows, d = int(os.environ.get("ROWS", "10000000")), int(os.environ.get("D", "768"))
 rng = np.random.default_rng(5)
+only = [int(v) for v in os.environ.get("METRICS", "7,8").split(",")]   # METRICS=7: float hamming alone (the pass bench.py's side leg prices)
 for metric, name in ((7, "hamming"), (8, "jaccard")):
+    if metric not in only:
+        continue
     ref = nifs._flat_new(metric)
     chunk = 500_000
     for at in range(0, rows, chunk):
