@@ -600,6 +600,8 @@ static ERL_NIF_TERM binary_top_k(ErlNifEnv *env, int argc, const ERL_NIF_TERM ar
 
 static int load(ErlNifEnv *env, void **priv, ERL_NIF_TERM info) {
   (void)priv; (void)info;
+  /* a libvettore_hip.so built from another header would be handed structs of the wrong size */
+  if (vt_abi_version() != VT_ABI_VERSION) return 1;
   FLAT = enif_open_resource_type(env, NULL, "vettore_gpu_flat", flat_dtor, ERL_NIF_RT_CREATE, NULL);
   return FLAT ? 0 : 1;
 }

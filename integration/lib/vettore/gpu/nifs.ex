@@ -10,8 +10,22 @@ defmodule Vettore.Gpu.Nifs do
   """
   @on_load :load
 
+  # priv/vettore_gpu_nif.so of the application this module is compiled into (:vettore_gpu as the
+  # project under integration/ builds it; :vettore if the three files are copied into Vettore
+  # itself), or wherever VETTORE_GPU_NIF points (path without the extension).  libvettore_hip.so is
+  # found through the NIF's rpath ($ORIGIN: the Makefile puts it beside the NIF).  A library built
+  # from another include/vettore_flat.h (VT_ABI_VERSION) refuses to load: {:error, {:load_failed, _}}.
   def load do
-    path = :filename.join(:code.priv_dir(:vettore), ~c"vettore_gpu_nif")
+    path =
+      case System.get_env("VETTORE_GPU_NIF") do
+        nil ->
+          app = Application.get_application(__MODULE__) || :vettore_gpu
+          :filename.join(:code.priv_dir(app), ~c"vettore_gpu_nif")
+
+        given ->
+          String.to_charlist(given)
+      end
+
     :erlang.load_nif(path, 0)
   end
 

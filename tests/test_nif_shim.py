@@ -78,3 +78,75 @@ def test_elixir_stubs_and_nif_table_agree():
     for m in re.finditer(r"def ([a-z0-9_]+)\(([^)]*)\), do: :erlang\.nif_error", ex):
         stubs[m.group(1)] = len([a for a in m.group(2).split(",") if a.strip()])
     assert table == stubs and len(table) >= 14
+
+
+# ---- integration/ as a project (VERDICT r3 #4): what can be checked without OTP ----------------
+INTEGRATION = os.path.join(ROOT, "integration")
+
+
+def elixir_calls(text, module):
+    """[(function, arity)] of every `Module.fun(args)` call in Elixir source `text`."""
+    out = []
+    for m in re.finditer(r"(?<![A-Za-z0-9_.])%s\.([a-z0-9_]+)\(" % re.escape(module), text):
+        i, depth = m.end(), 1
+        while depth:
+            depth += text[i] in "([{"
+            depth -= text[i] in ")]}"
+            i += 1
+        out.append((m.group(1), len(split_args(text[m.end():i - 1]))))
+    return out
+
+
+def test_the_makefile_compile_line_passes_with_the_stub_header():
+    res = subprocess.run(["make", "-C", INTEGRATION, "check-syntax", "ERTS_INCLUDE_DIR=" + STUBS], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    # and the real target links the library with an rpath beside the NIF
+    res = subprocess.run(["make", "-C", INTEGRATION, "-n", "all", "ERTS_INCLUDE_DIR=" + STUBS, "MIX_APP_PATH=/tmp/vt_mix_app"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0 and "-lvettore_hip" in res.stdout and "rpath" in res.stdout, res.stdout + res.stderr
+
+
+def test_every_nif_call_from_elixir_matches_a_stub():
+    shim = strip_comments(open(SHIM).read())
+    table = {m.group(1): int(m.group(2)) for m in re.finditer(r'\{"([a-z0-9_]+)",\s*(\d+),\s*[a-z0-9_]+,', shim)}
+    seen = 0
+    for rel, modules in (("lib/vettore/index/flat_gpu.ex", ("Nifs",)), ("test/flat_gpu_test.exs", ("Vettore.Gpu.Nifs",))):
+        text = open(os.path.join(INTEGRATION, rel)).read()
+        for module in modules:
+            for fun, arity in elixir_calls(text, module):
+                assert table.get(fun) == arity, (rel, fun, arity, table.get(fun))
+                seen += 1
+    assert seen >= 12
+
+
+def test_the_plugin_module_exports_the_behaviour():
+    text = open(os.path.join(INTEGRATION, "lib", "vettore", "index", "flat_gpu.ex")).read()
+    assert "@behaviour Vettore.Index" in text
+    for head in ("def new(metric, options)", "def put(%Collection{", "def put_many(%Collection{", "def delete(%Collection{",
+                 "def search(%Collection{} = collection, query, opts)"):
+        assert head in text, head
+    assert text.count("@impl true") >= 5
+
+
+def test_the_mix_project_and_its_exunit_file_hang_together():
+    import json
+    mix = open(os.path.join(INTEGRATION, "mix.exs")).read()
+    assert "app: :vettore_gpu" in mix and ":elixir_make" in mix and "{:vettore," in mix and "compilers: [:elixir_make]" in mix
+    nifs_ex = open(EX_NIFS).read()
+    assert "@on_load :load" in nifs_ex and "VETTORE_GPU_NIF" in nifs_ex and "vettore_gpu_nif" in nifs_ex
+    test = open(os.path.join(INTEGRATION, "test", "flat_gpu_test.exs")).read()
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "elixir_nif.json")))
+    used = set(re.findall(r'@cases\["([a-z_]+)"\]', test))
+    assert used and used <= set(cases), used - set(cases)
+    assert len(used) >= 7
+    assert "index: Vettore.Index.FlatGpu" in test and test.count('test "') >= 8
+    # the fields the tests read exist in the fixture
+    for var_case in re.finditer(r'c = @cases\["([a-z_]+)"\](.*?)(?=\n  test |\nend)', test, flags=re.S):
+        body = var_case.group(2)
+        for field in set(re.findall(r'\bc\["([a-z_]+)"\]', body)):
+            assert field in cases[var_case.group(1)], (var_case.group(1), field)
+
+
+def test_the_shim_refuses_a_library_of_another_abi():
+    shim = open(SHIM).read()
+    assert "vt_abi_version() != VT_ABI_VERSION" in shim
