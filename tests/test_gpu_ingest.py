@@ -1,0 +1,104 @@
+"""Bulk loads (vt_flat_load_matrix of >= 65 536 rows on a one-shard handle) run their phases side by
+side -- rows to the device, finiteness check, id table, id ranks (host/vt_store.h
+index_store_bulk_host) -- and must still be flat.rs:69-85: the whole batch validated before anything
+is stored, the last duplicate of an id wins, ids in any order."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import GpuIndex, bits, nifs, unwrap  # noqa: F401  (nifs: fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def corpus(n, d, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    x[n // 3:n // 3 + 40] = x[n // 3]   # identical rows: the id bytes decide
+    return x
+
+
+def check(nifs, oracle_mod, g, metric, x, ids, seed, k=12):
+    packed = oracle_mod.pack_ids(ids)
+    rng = np.random.default_rng(seed)
+    for q in (x[len(x) // 3], rng.uniform(-1, 1, x.shape[1]).astype(np.float32), x[-1]):
+        assert bits(g.search(q, k)) == bits(oracle_mod.matrix_search(metric, x, packed, q, k))
+
+
+@pytest.mark.parametrize("order", ["sorted", "unsorted"])
+def test_bulk_loads_in_both_id_orders(nifs, oracle_mod, order):
+    n, d = 150_000, 24
+    x = corpus(n, d, 1)
+    ids = [b"doc-%07d" % i for i in range(n)] if order == "sorted" else [b"doc-%d" % (i * 7919 % n) for i in range(n)]
+    g = GpuIndex(nifs, 0)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    assert len(g) == n and g.dimension == d
+    check(nifs, oracle_mod, g, 0, x, ids, 2)
+    # a second bulk load behind the first (appended rows; the ids interleave with the old ones)
+    m = 90_000
+    x2 = corpus(m, d, 3)
+    ids2 = [b"doc-%07d-b" % i for i in range(m)] if order == "sorted" else [b"e%d" % (i * 104729 % m) for i in range(m)]
+    unwrap(nifs.flat_load_matrix(g.ref, ids2, x2))
+    check(nifs, oracle_mod, g, 0, np.concatenate([x, x2]), ids + ids2, 4)
+    # batches of queries need strictly current ranks
+    allx, allids = np.concatenate([x, x2]), ids + ids2
+    qs = np.random.default_rng(5).uniform(-1, 1, size=(9, d)).astype(np.float32)
+    got = unwrap(nifs.flat_search_batch(g.ref, qs, 5))
+    packed = oracle_mod.pack_ids(allids)
+    for i in range(9):
+        assert bits(got[i]) == bits(oracle_mod.matrix_search(0, allx, packed, qs[i], 5))
+
+
+def test_a_non_finite_row_rejects_the_whole_bulk_load(nifs, oracle_mod):
+    n, d = 120_000, 16
+    x = corpus(n, d, 7)
+    ids = [b"r%d" % i for i in range(n)]
+    g = GpuIndex(nifs, 2)
+    bad = x.copy()
+    bad[n - 5, 3] = np.inf   # near the end: most rows are on their way to the device by the time it is found
+    assert nifs.flat_load_matrix(g.ref, ids, bad) == ("error", "vector contains a non-finite value")
+    assert len(g) == 0 and g.dimension is None
+    # the index takes another dimension afterwards (nothing of the rejected batch stayed behind)
+    x8 = corpus(70_000, 8, 8)
+    ids8 = [b"s%d" % i for i in range(len(x8))]
+    unwrap(nifs.flat_load_matrix(g.ref, ids8, x8))
+    check(nifs, oracle_mod, g, 2, x8, ids8, 9)
+    # rejected on top of a loaded index: the rows that were there answer as before, and the free rows behind them are zeros again
+    bad8 = corpus(80_000, 8, 10)
+    bad8[100, 0] = np.nan
+    assert nifs.flat_load_matrix(g.ref, [b"t%d" % i for i in range(len(bad8))], bad8) == ("error", "vector contains a non-finite value")
+    assert len(g) == len(x8)
+    check(nifs, oracle_mod, g, 2, x8, ids8, 11)
+    more = corpus(66_000, 8, 12)
+    ids_more = [b"u%d" % i for i in range(len(more))]
+    unwrap(nifs.flat_load_matrix(g.ref, ids_more, more))
+    check(nifs, oracle_mod, g, 2, np.concatenate([x8, more]), ids8 + ids_more, 13)
+
+
+def test_upserts_and_duplicates_inside_a_bulk_load(nifs, oracle_mod):
+    """Not every id new and distinct: the batch takes the general path after all (flat.rs:270-281: last wins)."""
+    n, d = 100_000, 16
+    x = corpus(n, d, 21)
+    ids = [b"k%d" % i for i in range(n)]
+    g = GpuIndex(nifs, 1)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    x2 = corpus(80_000, d, 22)
+    ids2 = [b"k%d" % (i * 3) if i % 4 == 0 and i * 3 < n else b"n%d" % i for i in range(len(x2))]   # a quarter upserts
+    ids2[70_001] = ids2[70_000]          # ... and a duplicate inside the batch
+    unwrap(nifs.flat_load_matrix(g.ref, ids2, x2))
+    want = oracle_mod.FlatIndex(1)
+    want.insert_matrix(ids, x)
+    want.insert_matrix(ids2, x2)
+    assert len(g) == len(want)
+    rng = np.random.default_rng(23)
+    for q in (x2[70_001], x2[0], rng.uniform(-1, 1, d).astype(np.float32)):
+        assert bits(g.search(q, 10)) == bits(want.search(q, 10))
+
+
+def test_the_serial_path_gives_the_same_index(nifs, oracle_mod, monkeypatch):
+    n, d = 70_000, 16
+    x = corpus(n, d, 31)
+    ids = [b"z%d" % (i * 31 % n) for i in range(n)]
+    monkeypatch.setenv("VT_INGEST_SERIAL", "1")
+    g = GpuIndex(nifs, 3)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    check(nifs, oracle_mod, g, 3, x, ids, 32)

@@ -126,11 +126,19 @@ int validate_finite(const float *v, size_t n) {
   return VT_OK;
 }
 
+// The same test on the bit patterns (auto-vectorises: the bulk loads run it over tens of GB).
+inline bool all_finite_bits(const float *v, size_t n) {
+  const uint32_t *u = reinterpret_cast<const uint32_t *>(v);
+  uint32_t worst = 0;
+  for (size_t i = 0; i < n; ++i) worst = std::max(worst, u[i] & 0x7f800000u);
+  return worst != 0x7f800000u;
+}
+
 // Splits [0, n) over up to 16 host threads (bulk ingest: validation and staging copies
 // are plain memory passes).  `f(lo, hi)` must not throw.
 template <class F>
-void parallel_for(size_t n, size_t grain, F f) {
-  unsigned threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+void parallel_for(size_t n, size_t grain, F f, unsigned max_threads = 16u) {
+  unsigned threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), max_threads);
   if (grain == 0) grain = 1;
   threads = (unsigned)std::min<size_t>(threads, n / grain);
   if (threads <= 1) {

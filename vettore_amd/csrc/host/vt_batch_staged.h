@@ -796,7 +796,9 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
 bool quantized_group_applies(const Shard *ix, size_t candidates, size_t limit) {
   const uint32_t d = (uint32_t)ix->dim;
   const size_t ncand = std::min<size_t>(candidates, ix->n);
-  return ix->n >= 16384 && ncand >= 1 && ncand <= (size_t)vt::kMaxFusedK && limit >= 1 && d <= vt::kHammingHistMaxDim &&
+  // (jaccard: the rerank's non-zero count of the query is one launch argument, so those go query by query -- said
+  // here, before a sweep of the bit matrix has been spent on finding out)
+  return ix->metric != VT_JACCARD && ix->n >= 16384 && ncand >= 1 && ncand <= (size_t)vt::kMaxFusedK && limit >= 1 && d <= vt::kHammingHistMaxDim &&
          vt::hamming_multi_lds_bytes(d, (d + 63) / 64, 2) <= 64 * 1024 && !std::getenv("VT_HAMMING_LISTS") &&
          !std::getenv("VT_NO_QUANTIZED_GROUPS") &&
          (ix->metric == VT_COSINE ? (size_t)2 * ((d + 3) / 4 * 4) * 4 <= 160 * 1024 : vt::scan_lds_bytes(d, (uint32_t)std::min<size_t>(limit, ncand)) != 0);
@@ -843,6 +845,7 @@ int quantized_group_finish(Shard *ix, Ctx &c, const QuantizedGroupSlot &gs, cons
 // calls quantized_group_finish for the slot.
 int quantized_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size_t> &which, size_t candidates, size_t limit,
                     vt_hits **out, uint32_t slot = 0, uint32_t nslots = 1, bool defer = false) {
+  if (which.size() < 2) return kRetryInternal;  // (groups are of two or more: grid.y is what tells the selects apart)
   const QuantizedGroupSlot gs = quantized_group_slot(ix, slot, nslots);
   const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
   const uint32_t words = (d + 63) / 64, pairs = (words + 1) / 2;
@@ -931,7 +934,6 @@ int quantized_group(Shard *ix, Ctx &c, const float *queries, const std::vector<s
   g.status = c.dStatus.p;
   g.dist_stride = dist_stride;
   g.hist_stride = hist_stride;
-  if (nq < 2) return kRetryInternal;  // (groups are of two or more: grid.y is what tells the selects apart)
   VT_HIP(vt::launch_hamming_collect_multi(g, (uint32_t)c.num_cus * 4, nq, c.stream));
   VT_HIP(vt::launch_select_lists(c.dPartKeys.p, c.dPartPay.p, nq, kListCap, c.dHamCount.p, k1, c.dStageB.p,
                                  (uint32_t)sizeof(ResultBlock), c.stream));
@@ -1182,7 +1184,7 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   VT_TRY(c.dStageB.ensure(nq));
   VT_TRY(c.dCandKeys.ensure((size_t)nq * k1));
   VT_TRY(c.dCandPay.ensure((size_t)nq * k1));
-  const size_t res_bytes = (size_t)vt::kHammingMultiMax * vt::kMaxFusedK * sizeof(vt::Entry) + 128;
+  const size_t res_bytes = (size_t)vt::kHammingMultiMax * vt::kMaxFusedK * sizeof(vt::Entry) + 256;
   if (!c.dBigMapped || c.hBig.count < res_bytes) {
     VT_TRY(c.hBig.ensure(std::max<size_t>(res_bytes, 16 + (size_t)vt::kSelListMax * sizeof(vt::Entry))));
     VT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&c.dBigMapped), c.hBig.p, 0));
@@ -1194,6 +1196,8 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   const uint32_t *hOutCount = reinterpret_cast<const uint32_t *>(c.hBig.p + ent_bytes);
   int *hStatus = reinterpret_cast<int *>(c.hBig.p + ent_bytes + 32);
   uint32_t *hListCount = reinterpret_cast<uint32_t *>(c.hBig.p + ent_bytes + 64);  // [8]: rows that reached tau
+  float *hTau = reinterpret_cast<float *>(c.hBig.p + ent_bytes + 96);             // [8]: the thresholds themselves
+  uint64_t *hLastKey = reinterpret_cast<uint64_t *>(c.hBig.p + ent_bytes + 128);  // [8]: key of each list's k1-th (last kept) row
   std::memset(c.hBQ.p, 0, up_floats * sizeof(float));
   vt::CosineScanMultiArgs a{};
   uint32_t *hcounts = reinterpret_cast<uint32_t *>(c.hBQ.p + q_floats + p_floats);
@@ -1240,6 +1244,11 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   VT_HIP(hipMemcpyAsync(hListCount, c.dBCount.p, vt::kCosineMultiMax * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(vt::launch_select_lists(c.dPartKeys.p, c.dPartPay.p, nq, kListCap, c.dBCount.p, k1, c.dStageB.p,
                                  (uint32_t)sizeof(ResultBlock), c.stream));
+  // what the acceptance test below looks at: the thresholds and the key of every list's last kept row
+  // (copied out here: later stages reuse the blocks)
+  VT_HIP(hipMemcpyAsync(hTau, c.dBTau.p, vt::kCosineMultiMax * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+  VT_HIP(hipMemcpy2DAsync(hLastKey, sizeof(uint64_t), &c.dStageB.p->e[k1 - 1].key, sizeof(ResultBlock), sizeof(uint64_t), nq,
+                          hipMemcpyDeviceToHost, c.stream));
   // later stages re-score the same candidates on a longer prefix (collection.ex:674-691), then
   // exact_rerank on the full vectors (collection.ex:821-851): the queries on grid.y
   vt::CosineRerankArgs r{};
@@ -1276,8 +1285,19 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
     c.prof.prefix_queries += nq;
   }
   if (*hStatus != 0) return kRetryInternal;  // an overflow somewhere: one by one, each reports its own
+  auto orderable_host = [](float f) {  // f32::total_cmp as an order-preserving u32 (the device's `orderable`)
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  };
   for (uint32_t i = 0; i < nq; ++i) {
     if (hListCount[i] < k1 || hListCount[i] > kListCap) continue;  // the threshold missed: this one takes the single path
+    // The list was cut by raw >= tau, the single path cuts by key = orderable(1.0f - raw) << 32 | id rank: below
+    // raw = 0.5 the f32 subtraction puts neighbouring raws on ONE rank, so a row just under tau can carry the rank of
+    // the list's last kept row and beat it on its id -- the single path would keep it, the list never saw it
+    // (ADVICE r3).  Every excluded row has 1.0f - raw >= 1.0f - tau (rounding is monotone): the list is the single
+    // path's exactly when its last kept rank lies strictly below the rank of tau itself.
+    if ((uint32_t)(hLastKey[i] >> 32) >= orderable_host(1.0f - hTau[i])) continue;
     const uint32_t got = std::min<uint32_t>(hOutCount[i], k2);
     std::vector<vt::Entry> entries(hOut + (size_t)i * k2, hOut + (size_t)i * k2 + got);
     VT_TRY(make_hits(ix, entries, &out[which[i]]));

@@ -149,7 +149,8 @@ uint32_t index_row_for(Shard *ix, const char *id, size_t len, bool *is_new, uint
 
 // Recomputes id_rank (position of each row's id in bytewise order) if stale
 // and makes the device copy current.
-int index_sync_ranks(Shard *ix, bool force_upload) {
+// host_only: the ranking itself (ranks_clean afterwards), the device column left for the caller to bring up to date.
+int index_sync_ranks(Shard *ix, bool force_upload, bool host_only = false) {
   if (!ix->ranks_clean) {
     // Rows that kept a rank from before are still in the right relative order
     // (ranks only need to be order-isomorphic to the ids): sort them by rank
@@ -209,7 +210,9 @@ int index_sync_ranks(Shard *ix, bool force_upload) {
     ix->ranks_clean = true;
     ix->unranked = 0;
     force_upload = true;
+    if (host_only) ix->rank_dirty_all = true;
   }
+  if (host_only) return VT_OK;
   if (force_upload) {
     ix->rank_dirty.clear();
     ix->rank_dirty_all = false;
@@ -275,6 +278,9 @@ struct RowSource {
   const float *device = nullptr;  // dense device matrix [count][d]
   size_t d = 0;
   const uint32_t *pick = nullptr;  // optional: row i of this batch is row pick[i] of the source
+  // dense host rows whose finiteness has NOT been checked yet: a bulk store checks them itself, beside
+  // the copy to the device (index_store_bulk_host) -- anything else must be handed validated rows
+  bool unvalidated = false;
 };
 
 constexpr size_t kMaxDerivedDirty = 65536;  // more mutated rows than this: rebuild instead of patching
@@ -326,6 +332,182 @@ int upload_row_list(Shard *ix, std::vector<uint32_t> &list, uint32_t *count) {
   return VT_OK;
 }
 
+// ---- a dense host matrix of new rows, all at once (vt_flat_load_matrix: the snapshot rebuild of
+// collection.ex:427-433, a first load) ------------------------------------------------------------
+// r03 ran the phases one after the other -- finiteness check, id table, rows to the device, id ranks:
+// 0.14 + 0.30 + 0.15 s per 4 M rows, the link idle half the time (18 GB/s).  Here they overlap:
+//   * the rows start for the device at once, through the two pinned halves, into the FREE rows behind
+//     the index (row n + i for batch row i: where they belong if every id is new, the normal case);
+//   * the finiteness check (flat.rs:69-85: the whole batch before anything is stored) runs beside the
+//     copy on threads of its own; the index itself is not touched before it has passed -- rows that
+//     reached the slab's free space by then are zeroed again and the call fails as a whole;
+//   * the id table (one thread: hash + insert per id) and, behind it, the ranking of the ids start
+//     when the check has passed and run while the link is still busy.
+// Ids that turn out not to be all new and distinct (upserts, duplicates in the batch) send the batch
+// through the general path below after all (the free rows zeroed first).
+constexpr int kRetryGeneral = -201;
+int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_off, const RowSource &src, bool *began);
+
+int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t *id_off, const RowSource &src, bool *began) {
+  Ctx &c = ix->ctx;
+  const size_t d = (size_t)ix->dim;
+  const uint32_t ld = ix->ld;
+  const uint32_t n_before = ix->n;
+  const bool trace = std::getenv("VT_TRACE_INGEST") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  {
+    const size_t need = (size_t)ix->n + count;  // (as in the general path: no regrowth inside the id loop)
+    if (need * 10 > ix->row_of.slots() * 7) ix->row_of.reserve(std::max(need, 2 * ix->row_of.size()));
+    if (need > ix->ids.capacity()) ix->ids.reserve(std::max(need, 2 * ix->ids.capacity()));
+    if (need > ix->rank_host.capacity()) ix->rank_host.reserve(std::max(need, 2 * ix->rank_host.capacity()));
+  }
+  // (1) the check, on its own threads
+  std::atomic<int> checked{src.unvalidated ? 0 : 1};  // 0 running, 1 passed, 2 failed
+  std::thread checker;
+  double t_checked = 0.0;
+  if (src.unvalidated)
+    checker = std::thread([&] {
+      std::atomic<bool> bad{false};
+      parallel_for(count, 8192, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi && !bad.load(std::memory_order_relaxed); i += 256) {
+          const size_t e = std::min(hi, i + 256);
+          if (!all_finite_bits(src.host + i * d, (e - i) * d)) bad.store(true);
+        }
+      }, 32u);
+      t_checked = since();
+      checked.store(bad.load() ? 2 : 1);
+    });
+  // (2) ids and ranks, once the check has passed
+  std::vector<uint32_t> target(count);
+  bool in_order = true;
+  int id_status = VT_OK;
+  std::string id_error;
+  double t_ids = 0.0, t_ranked = 0.0;
+  bool ranked_here = false;
+  std::thread idt([&] {
+    while (checked.load() == 0) std::this_thread::yield();
+    if (checked.load() != 1) return;
+    *began = true;
+    id_status = no_throw([&]() -> int {
+      constexpr size_t kAhead = 8;
+      uint64_t ring[kAhead];
+      for (size_t i = 0; i < std::min(count, kAhead); ++i) {
+        ring[i] = vt_host::hash_id(ids + id_off[i], id_off[i + 1] - id_off[i]);
+        ix->row_of.prefetch(ring[i]);
+      }
+      for (size_t i = 0; i < count; ++i) {
+        const uint64_t hash = ring[i % kAhead];
+        if (i + kAhead < count) {
+          ring[i % kAhead] = vt_host::hash_id(ids + id_off[i + kAhead], id_off[i + kAhead + 1] - id_off[i + kAhead]);
+          ix->row_of.prefetch(ring[i % kAhead]);
+        }
+        bool is_new = false;
+        target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new, hash);
+        if (!is_new || target[i] != n_before + i) in_order = false;
+      }
+      t_ids = since();
+#ifdef VT_TEST_HOOKS
+      if (std::getenv("VT_TEST_FAIL_AFTER_ID_UPDATE")) return fail(VT_ERR_DEVICE, "injected failure after the id table changed");
+#endif
+      // the host half of the ranking (index_sync_ranks sorts ids; its upload waits for the rows' stream below)
+      if (in_order && !ix->ranks_clean && count >= (size_t)n_before / 4) {
+        VT_TRY(index_sync_ranks(ix, false, /*host_only=*/true));
+        ranked_here = true;
+      }
+      t_ranked = since();
+      return VT_OK;
+    });
+    if (id_status != VT_OK) id_error = g_last_error;
+  });
+  // (3) the rows, on this thread
+  int copy_status = VT_OK;
+  {
+    const size_t row_bytes = (size_t)ld * sizeof(float);
+    const size_t stage_rows = std::max<size_t>(1, std::min<size_t>(count, (256u << 20) / row_bytes));
+    copy_status = c.hStage.ensure(2 * stage_rows * row_bytes);
+    hipEvent_t done[2] = {c.ev2, c.ev3};
+    bool used[2] = {false, false};
+    size_t i = 0;
+    for (int half = 0; i < count && copy_status == VT_OK && checked.load() != 2; half ^= 1) {
+      float *stage = reinterpret_cast<float *>(c.hStage.p) + (size_t)half * stage_rows * ld;
+      const size_t chunk = std::min(stage_rows, count - i);
+      if (used[half] && hipEventSynchronize(done[half]) != hipSuccess) copy_status = fail(VT_ERR_DEVICE, "hipEventSynchronize (staging half)");
+      parallel_for(chunk, 2048, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+          float *dst = stage + j * ld;
+          std::memcpy(dst, src.host + (i + j) * src.d, d * sizeof(float));
+          for (size_t t = d; t < ld; ++t) dst[t] = 0.0f;
+        }
+      });
+      if (copy_status == VT_OK && hipMemcpyAsync(ix->dX + (size_t)(n_before + i) * ld, stage, chunk * row_bytes, hipMemcpyHostToDevice, c.stream) != hipSuccess)
+        copy_status = fail(VT_ERR_DEVICE, "hipMemcpyAsync (rows to the device)");
+      if (copy_status == VT_OK && hipEventRecord(done[half], c.stream) != hipSuccess) copy_status = fail(VT_ERR_DEVICE, "hipEventRecord");
+      used[half] = true;
+      i += chunk;
+    }
+    if (copy_status != VT_OK) (void)hipGetLastError();
+  }
+  const double t_copied = since();
+  const std::string copy_error = g_last_error;
+  if (checker.joinable()) checker.join();
+  idt.join();
+  (void)hipStreamSynchronize(c.stream);
+  auto zero_free_rows = [&]() {  // what reached the slab behind the index goes again: rows n .. cap are zeros
+    const size_t from = (size_t)ix->n * ld, to = (size_t)(n_before + count) * ld;
+    if (to > from) {
+      (void)hipMemsetAsync(ix->dX + from, 0, (to - from) * sizeof(float), c.stream);
+      (void)hipStreamSynchronize(c.stream);
+    }
+  };
+  if (checked.load() == 2) {  // flat.rs:69-85: nothing has been stored
+    zero_free_rows();
+    if (ix->n == 0) ix->dim = -1;  // (the dimension was set for this batch: a rejected first batch leaves none behind)
+    return VT_ERR_NON_FINITE;
+  }
+  if (id_status != VT_OK) return fail(id_status, id_error);    // (*began is set: the caller poisons the handle)
+  if (copy_status != VT_OK) return fail(copy_status, copy_error);
+  if (!in_order) {
+    // upserts / duplicates in the batch: the ids are in the table already (target[] says where every row belongs);
+    // the general path places the rows -- it finds every id present and changes nothing else
+    zero_free_rows();
+    return kRetryGeneral;
+  }
+  // derived columns: everything behind n_before is new
+  if (count > kMaxDerivedDirty) {
+    ix->bits_valid = false;
+    ix->nz_valid = false;
+    ix->max_sqnorm = -1.0;
+    ix->bits_dirty.clear();
+    ix->nz_dirty.clear();
+    ix->norm_dirty.clear();
+    ix->sh_valid = false;
+    ix->sh_dirty.clear();
+  } else {
+    for (size_t i = 0; i < count; ++i) index_touch_row(ix, target[i]);
+  }
+  // the rank column on the device
+  if (ranked_here || ix->ranks_clean) {
+    // (ids that arrived in order extend the ranks in place: only the new ones travel, unless the column has to be regrown)
+    uint32_t from = ranked_here ? 0 : n_before;
+    if (ix->dRank.count < std::max<size_t>(ix->cap, ix->n)) {
+      VT_TRY(ix->dRank.ensure(std::max<size_t>(ix->cap, ix->n)));
+      from = 0;
+    }
+    VT_HIP(hipMemcpyAsync(ix->dRank.p + from, ix->rank_host.data() + from, (size_t)(ix->n - from) * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, c.stream));
+    VT_HIP(hipStreamSynchronize(c.stream));
+    ix->rank_dirty.clear();
+    ix->rank_dirty_all = false;
+  } else {
+    ix->rank_dirty_all = true;  // a small part of a large index: the next search that needs them ranks (as in the general path)
+  }
+  if (trace)
+    std::fprintf(stderr, "[vt ingest] %zu rows, phases overlapped: finiteness check done at %.3f s, id table at %.3f s, id ranks at %.3f s, rows on the device at %.3f s, all at %.3f s\n",
+                 count, t_checked, t_ids, t_ranked, t_copied, since());
+  return VT_OK;
+}
+
 // Shared body of insert / insert_many / load_matrix: rows are already validated.
 // `*began` is set once the index has started to change: a failure after that point
 // leaves it inconsistent (the caller poisons the handle).
@@ -335,6 +517,12 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
   const size_t d = (size_t)ix->dim;
   if ((uint64_t)ix->n + count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
   VT_TRY(index_reserve(ix, ix->n + (uint32_t)count));
+  if (src.host && !src.device && !src.off && !src.pick && count >= 65536 && std::getenv("VT_INGEST_SERIAL") == nullptr) {
+    const int st = index_store_bulk_host(ix, count, ids, id_off, src, began);
+    if (st != kRetryGeneral) return st;
+  } else if (src.unvalidated) {
+    VT_TRY(validate_matrix(src.host, count, src.d, ix->dim));
+  }
   const uint32_t n_before = ix->n;
   std::vector<uint32_t> target(count);
   bool all_appended_in_order = true;

@@ -35,9 +35,9 @@
 // Timing experiments (tools/k2s_probe.hip): only with -DVT_BATCH_TIMING_EXPERIMENTS; results are
 // garbage with any bit set.  1: no MFMAs, 2: no barrier, 4: no query DMA, 8: no candidate
 // append, 16: no row DMA, 32: no fragment reads.
-// (the switches live in instantiations of their own -- EXP -- which a launch takes only when a.debug is
-// set: with no bit set the probe times the product kernel itself)
-#define VT_SDBG(a, bit) (EXP && ((a).debug & (bit)))
+// (the switches are a template argument -- DBG -- so that a mode keeps the product kernel's schedule, minus
+// what it leaves out: a run-time test in the hot loop would cut the MFMA cluster into basic blocks)
+#define VT_SDBG(a, bit) ((DBG & (bit)) != 0)
 
 namespace vt {
 
@@ -150,7 +150,7 @@ __device__ __forceinline__ void append_candidates16(const BatchScoreArgs &a, f32
 // A wave's finished 64-row x (16 QTW)-query tile (C layout of 16x16x32: column = lane & 15 = query,
 // row = 4 (lane >> 4) + register): pass 0 writes the dense sample matrix, pass 1 appends the scores
 // that reach the query's threshold.  grow0 / srow0: the wave's first row in the index / the sample.
-template <bool DENSE, int QTW, bool EXP>
+template <bool DENSE, int QTW, unsigned DBG>
 __device__ __forceinline__ void tile_epilogue16(const BatchScoreArgs &a, f32x4 (&acc)[kRT][QTW], const float (&tau)[QTW],
                                                 uint32_t grow0, uint32_t srow0, uint32_t qbase, int lane) {
   const int c16 = lane & 15, g = lane >> 4;
@@ -196,7 +196,7 @@ __device__ __forceinline__ void tile_epilogue16(const BatchScoreArgs &a, f32x4 (
   }
 }
 
-template <bool DENSE, int QTW, int S, bool EXP>
+template <bool DENSE, int QTW, int S, unsigned DBG>
 __global__ __launch_bounds__(kWavesS *kWave, 1) void shadow_scores_kernel(const BatchScoreArgs a) {
   constexpr uint32_t kBStage = b_stage(QTW);
   constexpr uint32_t kStage = kAStage + kBStage;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kWavesS *kWave, 1) void shadow_scores_kernel(const 
         // the order above is the order wanted: left alone the compiler issues all 32 MFMAs first and
         // the 12 reads behind them -- which the next iteration's lgkmcnt(0) then waits for with the
         // matrix pipe idle
-        if (!EXP) {
+        if (!VT_SDBG(a, 32u)) {
           __builtin_amdgcn_sched_group_barrier(0x100, kRT, 0);
 #pragma unroll
           for (int j = 0; j < QTW; ++j) {
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kWavesS *kWave, 1) void shadow_scores_kernel(const 
     }
 
     const uint32_t tile = tile_index(k);
-    tile_epilogue16<DENSE, QTW, EXP>(a, acc, tau, tile * kRowsS + rg * 64, (blockIdx.x + k * gridDim.x) * kRowsS + rg * 64, qbase, lane);
+    tile_epilogue16<DENSE, QTW, DBG>(a, acc, tau, tile * kRowsS + rg * 64, (blockIdx.x + k * gridDim.x) * kRowsS + rg * 64, qbase, lane);
   }
 }
 
@@ -359,10 +359,17 @@ template <int QTW, int S>
 hipError_t launch_qs(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
   const size_t lds_bytes = (size_t)S * (kAStage + b_stage(QTW));
 #ifdef VT_BATCH_TIMING_EXPERIMENTS
-  if (a.debug && !dense) return launch_one_s(shadow_scores_kernel<false, QTW, S, true>, lds_bytes, a, blocks, s);
+  if (a.debug && !dense && QTW == 8 && S == 5) {  // (the modes tools/k2s_probe.hip asks for: 256 columns, five stages)
+    switch (a.debug) {
+#define VT_MODE(M) case M: return launch_one_s(shadow_scores_kernel<false, 8, 5, M>, lds_bytes, a, blocks, s);
+      VT_MODE(2u) VT_MODE(8u) VT_MODE(10u) VT_MODE(1u) VT_MODE(3u) VT_MODE(5u) VT_MODE(16u) VT_MODE(20u) VT_MODE(22u) VT_MODE(48u) VT_MODE(52u) VT_MODE(54u)
+#undef VT_MODE
+      default: return hipErrorInvalidValue;
+    }
+  }
 #endif
-  return dense ? launch_one_s(shadow_scores_kernel<true, QTW, S, false>, lds_bytes, a, blocks, s)
-               : launch_one_s(shadow_scores_kernel<false, QTW, S, false>, lds_bytes, a, blocks, s);
+  return dense ? launch_one_s(shadow_scores_kernel<true, QTW, S, 0u>, lds_bytes, a, blocks, s)
+               : launch_one_s(shadow_scores_kernel<false, QTW, S, 0u>, lds_bytes, a, blocks, s);
 }
 
 // stages of the LDS ring: 5 x 32 KiB is all of a CU's LDS at 256 query columns

@@ -462,11 +462,20 @@ int vt_flat_load_matrix(vt_flat *h, size_t count, size_t d, const char *ids, con
   VT_TRY(h->shards[0]->ctx.bind());
   long expected = handle_dim(h);
   if (expected < 0 && count > 0) expected = (long)d;
-  VT_TRY(validate_matrix(rows, count, d, expected));
+  // A bulk load on a one-shard handle checks finiteness beside the copy to the device (index_store_bulk_host:
+  // the index is not touched before the whole batch has passed, flat.rs:69-85); everything else here, up front.
+  const bool check_beside_copy = !h->multi() && count >= 65536 && std::getenv("VT_INGEST_SERIAL") == nullptr;
+  if (check_beside_copy) {
+    if (d == 0) return VT_ERR_EMPTY;
+    if ((long)d != expected) return VT_ERR_DIMENSION;
+  } else {
+    VT_TRY(validate_matrix(rows, count, d, expected));
+  }
   if (count == 0) return VT_OK;
   RowSource src;
   src.host = rows;
   src.d = d;
+  src.unvalidated = check_beside_copy;
   return store_validated(h, count, ids, id_off, src, d);
   });
 }
