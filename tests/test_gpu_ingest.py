@@ -24,8 +24,13 @@ def check(nifs, oracle_mod, g, metric, x, ids, seed, k=12):
         assert bits(g.search(q, k)) == bits(oracle_mod.matrix_search(metric, x, packed, q, k))
 
 
+@pytest.mark.parametrize("chunk_mb", [None, 2])
 @pytest.mark.parametrize("order", ["sorted", "unsorted"])
-def test_bulk_loads_in_both_id_orders(nifs, oracle_mod, order):
+def test_bulk_loads_in_both_id_orders(nifs, oracle_mod, order, chunk_mb, monkeypatch):
+    """chunk_mb = 2: the slab is a mapped range of 2-MiB chunks (1 GiB in production), so these small loads map
+    their chunks on a thread AHEAD of the copy, as a 30-GB load does."""
+    if chunk_mb:
+        monkeypatch.setenv("VT_SLAB_CHUNK_MB", str(chunk_mb))
     n, d = 150_000, 24
     x = corpus(n, d, 1)
     ids = [b"doc-%07d" % i for i in range(n)] if order == "sorted" else [b"doc-%d" % (i * 7919 % n) for i in range(n)]
@@ -48,7 +53,10 @@ def test_bulk_loads_in_both_id_orders(nifs, oracle_mod, order):
         assert bits(got[i]) == bits(oracle_mod.matrix_search(0, allx, packed, qs[i], 5))
 
 
-def test_a_non_finite_row_rejects_the_whole_bulk_load(nifs, oracle_mod):
+@pytest.mark.parametrize("chunk_mb", [None, 2])
+def test_a_non_finite_row_rejects_the_whole_bulk_load(nifs, oracle_mod, chunk_mb, monkeypatch):
+    if chunk_mb:
+        monkeypatch.setenv("VT_SLAB_CHUNK_MB", str(chunk_mb))
     n, d = 120_000, 16
     x = corpus(n, d, 7)
     ids = [b"r%d" % i for i in range(n)]

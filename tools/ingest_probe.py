@@ -15,11 +15,22 @@ import torch  # noqa: E402,F401
 from vettore_amd import nifs  # noqa: E402
 
 
+def rows_f32(n, d, seed):
+    """n x d uniform(-1, 1) floats, made in pieces (a 10 M x 768 sample is 30.7 GB: it must not exist in f64 as well)"""
+    rng = np.random.default_rng(seed)
+    x = np.empty((n, d), dtype=np.float32)
+    for s0 in range(0, n, 1 << 17):
+        e0 = min(n, s0 + (1 << 17))
+        x[s0:e0] = rng.random((e0 - s0, d), dtype=np.float32) * 2.0 - 1.0
+    return x
+
+
 def main():
-    n, d = int(os.environ.get("ROWS", "2000000")), 768
-    rng = np.random.default_rng(1)
-    x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
-    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    n, d = int(os.environ.get("ROWS", "2000000")), int(os.environ.get("D", "768"))
+    sorted_ids = os.environ.get("IDS", "sorted") == "sorted"
+    x = rows_f32(n, d, 1)
+    # (ids in bytewise order -- zero-padded, what a snapshot rebuild sorted by id hands over, collection.ex:427-433 -- or not)
+    ids = [b"doc-%09d" % (i + 1) for i in range(n)] if sorted_ids else [b"doc-%d" % (i + 1) for i in range(n)]
     ref = nifs.flat_new_cosine()
     tp = time.perf_counter()
     idb, ioff = nifs.pack_ids(ids)
@@ -33,8 +44,26 @@ def main():
     print(json.dumps({"python_pack_ids_s": round(t0 - tp, 3)}), flush=True)
     st, hits = nifs.flat_search(ref, x[5], 3)  # first search: id ranking happens here if it was deferred
     t2 = time.perf_counter()
-    print(json.dumps({"op": "load_matrix", "rows": n, "seconds": round(t1 - t0, 3), "rows_per_s": round(n / (t1 - t0)),
+    assert hits[0][0] == ids[5], hits
+    print(json.dumps({"op": "load_matrix", "ids": "sorted" if sorted_ids else "unsorted", "serial": os.environ.get("VT_INGEST_SERIAL") is not None,
+                      "rows": n, "d": d, "seconds": round(t1 - t0, 3), "rows_per_s": round(n / (t1 - t0)),
                       "GBps": round(n * d * 4 / (t1 - t0) / 1e9, 2), "first_search_s": round(t2 - t1, 3)}), flush=True)
+    if os.environ.get("SHIM"):
+        # the same rows through the erl_nif shim's flat_load_binary (fake term runtime, tests/nif_runtime.py): what the
+        # Elixir side's one-binary put_many costs on top (id list decoding, the binary is used in place)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import nif_runtime
+        rt = nif_runtime.Runtime()
+        ref2 = rt.call("flat_new", 2, [0])
+        blob = x.tobytes()
+        t0 = time.perf_counter()
+        res = rt.call("flat_load_binary", ref2, ids, blob, d)
+        t1 = time.perf_counter()
+        print(json.dumps({"op": "shim flat_load_binary (fake erl_nif runtime; includes building %d id terms from Python)" % n,
+                          "result": repr(res), "seconds": round(t1 - t0, 3), "GBps": round(n * d * 4 / (t1 - t0) / 1e9, 2)}), flush=True)
+        del ref2
+    if os.environ.get("LOAD_ONLY"):
+        return
     # incremental: 64 batches of 1000 rows with fresh ids, then a search (re-rank of the newcomers)
     extra = rng.uniform(-1, 1, size=(64000, d)).astype(np.float32)
     t0 = time.perf_counter()

@@ -267,6 +267,7 @@ int wait_exchange(vt_flat *h, Ctx &c, size_t shard) {
       const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
       if (waited >= timeout_ms) {
         h->poisoned = true;
+        h->wedged = true;
         return fail(VT_ERR_DEVICE, "RCCL exchange timed out on shard " + std::to_string(shard) + " (device " +
                                        std::to_string(c.device) + ") after " + std::to_string(waited) +
                                        " ms: the all-gather of the shards' top-k lists did not complete; the handle is unusable");

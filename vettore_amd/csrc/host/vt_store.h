@@ -150,7 +150,8 @@ uint32_t index_row_for(Shard *ix, const char *id, size_t len, bool *is_new, uint
 // Recomputes id_rank (position of each row's id in bytewise order) if stale
 // and makes the device copy current.
 // host_only: the ranking itself (ranks_clean afterwards), the device column left for the caller to bring up to date.
-int index_sync_ranks(Shard *ix, bool force_upload, bool host_only = false) {
+// fresh_sorted: the unranked rows already in id order (a bulk load sorts its ids while the rows travel), or null.
+int index_sync_ranks(Shard *ix, bool force_upload, bool host_only = false, const std::vector<uint32_t> *fresh_sorted = nullptr) {
   if (!ix->ranks_clean) {
     // Rows that kept a rank from before are still in the right relative order
     // (ranks only need to be order-isomorphic to the ids): sort them by rank
@@ -180,7 +181,8 @@ int index_sync_ranks(Shard *ix, bool force_upload, bool host_only = false) {
       for (uint32_t i = 0; i < ix->n; ++i) (rk[i] == kUnranked ? fresh : ranked).push_back(i);
       parallel_sort(ranked, [&rk](uint32_t a, uint32_t b) { return rk[a] < rk[b]; });
     }
-    parallel_sort(fresh, [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+    if (fresh_sorted && fresh_sorted->size() == fresh.size()) fresh = *fresh_sorted;
+    else parallel_sort(fresh, [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
     std::vector<uint32_t> order(ix->n);
     if (fresh.size() < ranked.size() / 16) {
       // few newcomers: each finds its place among the ranked rows by binary search (string
@@ -353,6 +355,7 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   const size_t d = (size_t)ix->dim;
   const uint32_t ld = ix->ld;
   const uint32_t n_before = ix->n;
+  const size_t unranked_before = ix->unranked;
   const bool trace = std::getenv("VT_TRACE_INGEST") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
@@ -378,6 +381,80 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
       t_checked = since();
       checked.store(bad.load() ? 2 : 1);
     });
+  // (1a) the batch's ids in bytewise order, for the ranking behind the id table: needs nothing but the bytes, so it starts
+  // now (ids that arrive in order -- a snapshot rebuild sorts by id, collection.ex:427-433 -- are found out in one pass)
+  std::vector<uint32_t> batch_order;
+  std::thread sorter([&] {
+    auto id_less_at = [&](uint32_t x, uint32_t y) {
+      const size_t lx = id_off[x + 1] - id_off[x], ly = id_off[y + 1] - id_off[y];
+      const size_t m = std::min(lx, ly);
+      const int cmp = m ? std::memcmp(ids + id_off[x], ids + id_off[y], m) : 0;
+      if (cmp) return cmp < 0;
+      return lx < ly;
+    };
+    bool ascending = true;
+    for (size_t i = 1; i < count && ascending; ++i) ascending = id_less_at((uint32_t)(i - 1), (uint32_t)i);
+    if (ascending) return;
+    batch_order.resize(count);
+    for (size_t i = 0; i < count; ++i) batch_order[i] = (uint32_t)i;
+    parallel_sort(batch_order, id_less_at);
+  });
+  // (1b) room for the rows.  A slab that is (or starts as) a mapped range grows by mapping 1-GiB chunks behind the rows:
+  // 29 of them for 10 M x 768 rows are 0.25 s of hipMemCreate / hipMemMap -- a thread maps them AHEAD of the copy, which
+  // only waits when it catches up.  Taken only when the card says it has the room (a growth that fails half way could
+  // not be taken back once the ids are in; one that fails up front fails as a whole, below).
+  Slab &sl = ix->slab;
+  const size_t row_bytes_ = (size_t)ld * sizeof(float);
+  const uint64_t rows_up = ((uint64_t)n_before + count + vt::kTileRows - 1) / vt::kTileRows * vt::kTileRows;
+  const size_t need_bytes = (size_t)rows_up * row_bytes_;
+  std::atomic<size_t> mapped_bytes{0};
+  std::atomic<int> map_status{VT_OK};
+  std::string map_error;
+  std::thread mapper;
+  bool progressive = false;
+  auto join_helpers = [&]() {
+    if (checker.joinable()) checker.join();
+    if (mapper.joinable()) mapper.join();
+    if (sorter.joinable()) sorter.join();
+  };
+  if (Slab::mapping_allowed() && need_bytes >= Slab::chunk_bytes() && need_bytes > sl.bytes && (sl.mapped || (n_before == 0 && sl.p == nullptr))) {
+    size_t free_b = 0, total_b = 0;
+    const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (need_bytes - sl.bytes) + 2 * Slab::chunk_bytes();
+    (void)hipGetLastError();
+    if (room) {
+      int st = VT_OK;
+      if (!sl.mapped) st = sl.start_mapped(std::min(need_bytes, 2 * Slab::chunk_bytes()), c.device);
+      if (st == VT_OK) {
+        progressive = true;
+        ix->dX = sl.p;
+        mapped_bytes.store(sl.bytes);
+        mapper = std::thread([&] {
+          (void)hipSetDevice(c.device);
+          while (sl.bytes < need_bytes) {
+            const int ms = no_throw([&]() -> int { return sl.map_up_to(std::min(need_bytes, sl.bytes + sl.chunk), c.device); });
+            if (ms != VT_OK) {
+              map_error = g_last_error;
+              map_status.store(ms);
+              return;
+            }
+            mapped_bytes.store(sl.bytes);
+          }
+        });
+      } else if (st != VT_ERR_UNSUPPORTED) {
+        join_helpers();
+        return st;
+      }
+    }
+  }
+  if (!progressive) {
+    const int st = index_reserve(ix, (uint32_t)(n_before + count));
+    if (st != VT_OK) {
+      join_helpers();
+      return st;
+    }
+    mapped_bytes.store(ix->slab.bytes);
+  }
+  const double t_room = since();
   // (2) ids and ranks, once the check has passed
   std::vector<uint32_t> target(count);
   bool in_order = true;
@@ -412,7 +489,17 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
 #endif
       // the host half of the ranking (index_sync_ranks sorts ids; its upload waits for the rows' stream below)
       if (in_order && !ix->ranks_clean && count >= (size_t)n_before / 4) {
-        VT_TRY(index_sync_ranks(ix, false, /*host_only=*/true));
+        if (sorter.joinable()) sorter.join();
+        // (the batch's rows are n_before + i: its sorted ids are the sorted newcomers, if nobody else was waiting for a rank)
+        // of them, the rows that are still waiting for a rank -- an ascending run at the start of the batch got ranks as it arrived
+        std::vector<uint32_t> fresh;
+        if (batch_order.size() == count && unranked_before == 0) {
+          fresh.reserve(ix->unranked);
+          for (size_t i = 0; i < count; ++i)
+            if (ix->rank_host[n_before + batch_order[i]] == kUnranked) fresh.push_back(n_before + batch_order[i]);
+          if (fresh.size() != ix->unranked) fresh.clear();
+        }
+        VT_TRY(index_sync_ranks(ix, false, /*host_only=*/true, fresh.empty() ? nullptr : &fresh));
         ranked_here = true;
       }
       t_ranked = since();
@@ -440,6 +527,9 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
           for (size_t t = d; t < ld; ++t) dst[t] = 0.0f;
         }
       });
+      // (the chunks behind this half are mapped by now, or will be in a moment)
+      while (progressive && mapped_bytes.load() < (size_t)(n_before + i + chunk) * row_bytes && map_status.load() == VT_OK) std::this_thread::yield();
+      if (map_status.load() != VT_OK) copy_status = fail(map_status.load(), map_error);
       if (copy_status == VT_OK && hipMemcpyAsync(ix->dX + (size_t)(n_before + i) * ld, stage, chunk * row_bytes, hipMemcpyHostToDevice, c.stream) != hipSuccess)
         copy_status = fail(VT_ERR_DEVICE, "hipMemcpyAsync (rows to the device)");
       if (copy_status == VT_OK && hipEventRecord(done[half], c.stream) != hipSuccess) copy_status = fail(VT_ERR_DEVICE, "hipEventRecord");
@@ -450,9 +540,18 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   }
   const double t_copied = since();
   const std::string copy_error = g_last_error;
-  if (checker.joinable()) checker.join();
-  idt.join();
+  idt.join();  // (first: it joins the sorter itself when it needs the order)
+  join_helpers();
   (void)hipStreamSynchronize(c.stream);
+  if (progressive) {
+    // what index_reserve does after a growth: the slab's new space beyond the rows is zeros, the capacity follows
+    const size_t rows_end = std::min(sl.bytes, (size_t)(n_before + count) * row_bytes_);
+    if (sl.bytes > rows_end) (void)hipMemsetAsync(reinterpret_cast<char *>(sl.p) + rows_end, 0, sl.bytes - rows_end, c.stream);
+    (void)hipStreamSynchronize(c.stream);
+    sl.defined = sl.bytes;
+    ix->cap = (uint32_t)std::min<uint64_t>(sl.bytes / row_bytes_ / vt::kTileRows * vt::kTileRows, 0xFFFFFFE0ull);
+    if (map_status.load() != VT_OK && copy_status == VT_OK) copy_status = fail(map_status.load(), map_error);
+  }
   auto zero_free_rows = [&]() {  // what reached the slab behind the index goes again: rows n .. cap are zeros
     const size_t from = (size_t)ix->n * ld, to = (size_t)(n_before + count) * ld;
     if (to > from) {
@@ -503,8 +602,8 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
     ix->rank_dirty_all = true;  // a small part of a large index: the next search that needs them ranks (as in the general path)
   }
   if (trace)
-    std::fprintf(stderr, "[vt ingest] %zu rows, phases overlapped: finiteness check done at %.3f s, id table at %.3f s, id ranks at %.3f s, rows on the device at %.3f s, all at %.3f s\n",
-                 count, t_checked, t_ids, t_ranked, t_copied, since());
+    std::fprintf(stderr, "[vt ingest] %zu rows, phases overlapped: room %s at %.3f s, finiteness check done at %.3f s, id table at %.3f s, id ranks at %.3f s, rows on the device at %.3f s, all at %.3f s\n",
+                 count, progressive ? "being mapped ahead of the copy from" : "made by", t_room, t_checked, t_ids, t_ranked, t_copied, since());
   return VT_OK;
 }
 
@@ -516,12 +615,12 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
   Ctx &c = ix->ctx;
   const size_t d = (size_t)ix->dim;
   if ((uint64_t)ix->n + count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
-  VT_TRY(index_reserve(ix, ix->n + (uint32_t)count));
   if (src.host && !src.device && !src.off && !src.pick && count >= 65536 && std::getenv("VT_INGEST_SERIAL") == nullptr) {
-    const int st = index_store_bulk_host(ix, count, ids, id_off, src, began);
+    const int st = index_store_bulk_host(ix, count, ids, id_off, src, began);  // (makes room itself, beside the check)
     if (st != kRetryGeneral) return st;
-  } else if (src.unvalidated) {
-    VT_TRY(validate_matrix(src.host, count, src.d, ix->dim));
+  } else {
+    if (src.unvalidated) VT_TRY(validate_matrix(src.host, count, src.d, ix->dim));
+    VT_TRY(index_reserve(ix, ix->n + (uint32_t)count));
   }
   const uint32_t n_before = ix->n;
   std::vector<uint32_t> target(count);

@@ -296,6 +296,10 @@ struct vt_flat {
   // "flat lock poisoned" (nifs.rs:269).
   // (atomic: a reader that finds the exchange wedged sets it under the shared lock)
   std::atomic<bool> poisoned{false};
+  // an exchange timed out (wait_exchange): the shard streams still hold the stuck collective, and anything that
+  // synchronises with them -- hipStreamDestroy, hipFree -- would block for ever.  vt_flat_free then LEAKS the handle
+  // (the process is expected to end).
+  std::atomic<bool> wedged{false};
   int metric = 0;
   long dim = -1;  // FlatIndex.dimension across all shards
   std::vector<std::unique_ptr<Shard>> shards;

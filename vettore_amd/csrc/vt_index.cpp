@@ -297,7 +297,14 @@ int vt_flat_new_sharded(int metric_code, const int *devices, size_t ndev, vt_fla
 
 int vt_flat_new(int metric_code, int device, vt_flat **out) { return vt_flat_new_sharded(metric_code, &device, 1, out); }
 
-void vt_flat_free(vt_flat *h) { delete h; }
+void vt_flat_free(vt_flat *h) {
+  if (h && h->wedged.load()) {
+    // (see vt_flat::wedged: freeing would wait for a collective that never completes; the workers are detached with
+    // the handle, the memory goes when the process does)
+    return;
+  }
+  delete h;
+}
 
 size_t vt_flat_len(const vt_flat *h) {
   if (!h) return 0;
