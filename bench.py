@@ -391,6 +391,54 @@ def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidat
     return out
 
 
+def leg_single_via_shadow(a, L, nifs, ref, qs, steps, warmup, limit):
+    """A side leg, never the headline: lone flat_search calls on the headline index with
+    vt_flat_set_single_nominate on -- each answered like a batch of one: the bf16 pass over the bf16
+    shadow of the rows (N x d x 2 bytes, half of what the exact scan reads) nominates a few hundred
+    rows, the exact kernel re-scores them, the bound certifies the top k; a query it cannot certify
+    takes the exact scan.  Every timed answer is compared with the plain scan's (taken first)."""
+    import torch
+    dim = qs.shape[1]
+    h = C.c_void_p()
+
+    def call(i, keep=False):
+        st = L.vt_flat_search(ref.handle, qs[i].ctypes.data_as(C.POINTER(C.c_float)), dim, limit, C.byref(h))
+        assert st == 0, st
+        if keep:
+            return hits_of(L, h)
+        L.vt_hits_free(h)
+        return None
+
+    plain = [call(i, keep=True) for i in range(warmup, warmup + steps)]
+    assert nifs.flat_set_single_nominate(ref, True) == ("ok", ())
+    try:
+        t0 = time.perf_counter()
+        call(0)   # builds the row norms and the shadow: setup
+        setup_s = time.perf_counter() - t0
+        for i in range(warmup):
+            call(i)
+        nifs.flat_set_profiling(ref, True)
+        nifs.flat_get_profile(ref, reset=True)
+        got = [call(i, keep=True) for i in range(warmup, warmup + steps)]   # (first pass: verification and the kernel's own time)
+        p = nifs.flat_get_profile(ref, reset=True)
+        nifs.flat_set_profiling(ref, False)
+        assert got == plain, "a search through the shadow differs from the exact scan"
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(warmup, warmup + steps):
+            call(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        assert nifs.flat_set_single_nominate(ref, False) == ("ok", ())
+    out = {"ms_per_step": dt / steps * 1e3, "value": steps / dt, "unit": "queries/s", "steps": steps, "warmup": warmup, "verified": True,
+           "certified": p["nominate_queries"] - p["batch_fallbacks"], "took_the_exact_scan": p["batch_fallbacks"],
+           "shadow_setup_s": round(setup_s, 2), "roofline": batch_roofline(p, len(ref), dim),
+           "candidates_per_query": p["nominate_candidates"] / max(1, p["nominate_queries"])}
+    out["end_to_end_frac"] = p["nominate_bytes"] / max(1, p["nominate_launches"]) / (dt / steps) / 1e9 / HBM_PEAK_GBS
+    return out
+
+
 def _lib_consts():
     from vettore_amd import _lib
     return _lib
@@ -568,6 +616,12 @@ def side_legs(a, torch, nifs, L, device, main_ref):
     side["funnel"] = dict(leg(a, L, nifs, main_ref, "funnel", qs, 100, 10, stages=(min(a.dim, 128),), candidates=100),
                           workload="funnel_search stages=[%d] candidates=100 limit=10, d=%d, N=%d" % (min(a.dim, 128), a.dim, a.rows),
                           dtype="f64")
+    # lone searches through the bf16 shadow of the headline index (opt-in; a side leg, never the headline)
+    qs = normalized_queries(230, a.dim, SEED_QUERY + 11)
+    side["single_via_shadow"] = dict(leg_single_via_shadow(a, L, nifs, main_ref, qs, 200, 30, a.limit),
+                                     workload="index: :flat, metric: :cosine, d=%d, N=%d, single query, vt_flat_set_single_nominate on: "
+                                              "bf16 pass over the bf16 shadow + exact rescoring + certified bound" % (a.dim, a.rows),
+                                     dtype="f32 (exact rescoring; bf16 nomination)")
     # many callers on the one handle (the headline has one query in flight)
     side["callers"] = {"workload": "index: :flat, metric: :cosine, d=%d, N=%d, limit=%d, T threads calling flat_search on one handle"
                                    % (a.dim, a.rows, a.limit),

@@ -254,6 +254,14 @@ enum { VT_SHADOW_STATE_OFF = 0, VT_SHADOW_STATE_NONE = 1, VT_SHADOW_STATE_CURREN
        VT_SHADOW_STATE_REFUSED = 4 };
 int vt_flat_set_batch_shadow(vt_flat *index, int mode);
 int vt_flat_batch_shadow(const vt_flat *index);   /* VT_SHADOW_STATE_*; -1: no index */
+/* Opt-in (off by default; VT_SINGLE_NOMINATE=1 for new indexes): a lone vt_flat_search on an index whose bf16 shadow is
+ * current is answered like a batch of one -- the bf16 pass over the shadow (half the bytes of the exact scan) nominates
+ * a few hundred rows, the exact kernel re-scores them, the bound certifies that no other row can reach the top k; a
+ * query the bound cannot certify takes the exact scan as before.  Same hits bit for bit, ~0.6 of the scan's time
+ * (dot-family metrics, limit <= 256, ids ranked).  The default stays the exact scan of the f32 rows: what the
+ * reference does (flat.rs:96-124), and what the headline benchmark measures. */
+int vt_flat_set_single_nominate(vt_flat *index, int enabled);
+int vt_flat_single_nominate(const vt_flat *index);
 /* Order used by indexes created afterwards and by the stateless helpers. */
 int vt_set_default_reduce_order(int order);
 

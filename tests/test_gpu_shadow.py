@@ -240,3 +240,30 @@ def test_concurrent_callers_travel_through_the_shadow(nifs, oracle_mod, monkeypa
     assert not errors, errors
     prof = nifs.flat_get_profile(g.ref)
     assert prof["nominate_shadow_launches"] >= 1 and prof["nominate_shadow_launches"] == prof["nominate_launches"], prof
+
+
+def test_a_lone_search_through_the_shadow(nifs, oracle_mod):
+    """vt_flat_set_single_nominate: flat_search as a batch of one -- the bf16 pass over the shadow nominates, the exact
+    kernel decides; hits equal the oracle's (and the plain scan's) bit for bit, tie blocks included."""
+    for metric in (2, 0, 3):
+        n, d = 30000, 192
+        x, ids = make_corpus(n, d, 900 + metric, metric == 2, oracle_mod, tie_block=40)
+        packed = oracle_mod.pack_ids(ids)
+        g = GpuIndex(nifs, metric)
+        unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+        assert nifs.flat_set_single_nominate(g.ref, True) == ("ok", ())
+        nifs.flat_set_profiling(g.ref, True)
+        rng = np.random.default_rng(17)
+        qs = [x[n // 2], x[7]] + [rng.uniform(-1, 1, d).astype(np.float32) for _ in range(6)]
+        if metric == 2:
+            qs = [oracle_mod.normalize_l2(q) for q in qs]
+        for k in (1, 10, 100):
+            for q in qs:
+                assert bits(g.search(q, k)) == bits(oracle_mod.matrix_search(metric, x, packed, q, k)), (metric, k)
+        assert bits(g.search(qs[2], 300)) == bits(oracle_mod.matrix_search(metric, x, packed, qs[2], 300))   # beyond one pass: the scan
+        prof = nifs.flat_get_profile(g.ref)
+        assert prof["nominate_shadow_launches"] >= 20 and prof["shadow_builds"] == 1, prof
+        # after a mutation the next lone search patches the shadow and goes on
+        x[5] = (qs[3] * 4).astype(np.float32) if metric != 2 else qs[3]
+        unwrap(nifs.flat_insert(g.ref, ids[5], x[5]))
+        assert bits(g.search(qs[3], 10)) == bits(oracle_mod.matrix_search(metric, x, packed, qs[3], 10))

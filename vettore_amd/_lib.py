@@ -33,7 +33,7 @@ SYMBOLS = [
     "vt_rank_ids", "vt_flat_set_id_ranks", "vt_flat_stream", "vt_flat_search_begin", "vt_flat_merge_gathered",
     "vt_vector_top_k", "vt_binary_top_k", "vt_normalize_l2", "vt_compress_sign_bits",
     "vt_flat_set_profiling", "vt_flat_get_profile", "vt_flat_get_profile_sized",
-    "vt_flat_set_batch_shadow", "vt_flat_batch_shadow",
+    "vt_flat_set_batch_shadow", "vt_flat_batch_shadow", "vt_flat_set_single_nominate", "vt_flat_single_nominate",
 ]
 ABI_VERSION = 3  # VT_ABI_VERSION of the include/vettore_flat.h this file was written against
 
@@ -154,6 +154,8 @@ def load() -> C.CDLL:
     L.vt_flat_get_profile_sized.argtypes = [vp, vp, C.c_size_t, C.c_int]
     L.vt_flat_set_batch_shadow.argtypes = [vp, C.c_int]
     L.vt_flat_batch_shadow.argtypes = [vp]
+    L.vt_flat_set_single_nominate.argtypes = [vp, C.c_int]
+    L.vt_flat_single_nominate.argtypes = [vp]
     # a library built from another header would be handed structs of the wrong size
     if L.vt_abi_version() != ABI_VERSION:
         raise ImportError("%s speaks ABI version %d, this binding %d: rebuild with `make`"

@@ -38,6 +38,10 @@ int initial_shadow() {
   return VT_SHADOW_AUTO;
 }
 int g_default_shadow = initial_shadow();
+int g_default_single_nominate = [] {
+  const char *e = std::getenv("VT_SINGLE_NOMINATE");
+  return e && e[0] == '1' ? 1 : 0;
+}();
 // smallest sample rank K2b's threshold is taken from (VT_BF16_MIN_RANK: tools/nominate_probe.py sweeps it).
 // The count of rows passing a threshold taken at sample rank r is Gamma(r)-distributed around its
 // mean: at r = 4 one query in ~700 drew a threshold so high that its k-th hit could not clear it by

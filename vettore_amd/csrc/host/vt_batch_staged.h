@@ -18,7 +18,7 @@ namespace {
 // k exact hits exist, the threshold with which a second pass is certain to certify it (NaN
 // where there is none).
 int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit, vt_hits **out, std::vector<char> &done,
-                bool bf16, const float *tau_given = nullptr, std::vector<float> *retry_tau = nullptr) {
+                bool bf16, const float *tau_given, std::vector<float> *retry_tau) {
   const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
   const uint32_t k = (uint32_t)std::min<size_t>(limit, n);
   static const bool trace = std::getenv("VT_TRACE_BATCH") != nullptr;  // phases of a group on stderr

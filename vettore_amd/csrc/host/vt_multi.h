@@ -725,8 +725,11 @@ int search_direct(vt_flat *h, const float *query, size_t n, size_t limit, vt_hit
     if (h->poisoned) return poisoned_status();
     return search_multi(h, query, n, limit, out);
   }
-  return read_single(h, NEED_RANKS | NEED_NZBITS, limit,
-                     [&](Shard *ix, Ctx &c) -> int { return search_ready(ix, c, query, n, limit, out); });
+  // (vt_flat_set_single_nominate: the first lone search then also brings the norms and the bf16 shadow up to date)
+  const Shard *s0 = h->shards[0].get();
+  const unsigned need = NEED_RANKS | NEED_NZBITS |
+                        (s0->single_nominate && limit <= (size_t)vt::kMaxFusedK ? NEED_NORMS | NEED_STRICT_RANKS : 0u);
+  return read_single(h, need, limit, [&](Shard *ix, Ctx &c) -> int { return search_ready(ix, c, query, n, limit, out); });
 }
 
 // quantized_search as one caller runs it (collection.ex:276-295).

@@ -92,12 +92,33 @@ int shard_prepare(Shard *ix, unsigned need, size_t limit) {
   return VT_OK;
 }
 
+int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit, vt_hits **out, std::vector<char> &done,
+                bool bf16, const float *tau_given, std::vector<float> *retry_tau);
+
+// A lone search as a batch of one through the bf16 shadow (vt_flat_set_single_nominate): applies when everything the
+// batch path wants is current already -- a reader under the shared lock never waits for a build.
+bool single_nominate_applies(const Shard *ix, size_t limit) {
+  return ix->single_nominate && ix->ranks_clean && limit >= 1 && limit <= (size_t)vt::kMaxFusedK && ix->n >= 4096 &&
+         shadow_wanted(ix) && shadow_current(ix) && !shard_stale(ix, NEED_NORMS, limit);
+}
+
 // flat.rs:96-124 on a shard whose rank column shard_prepare has brought up to date --
 // strictly (ranks_clean) or lazily (newcomers share kUnranked).  Read-only on the shard.
 int search_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t limit, vt_hits **out) {
   if (limit == 0) return empty_hits(out);
   VT_TRY(validate_vector(query, n, ix->dim));
   if (ix->n == 0) return empty_hits(out);
+  if (single_nominate_applies(ix, limit)) {
+    std::vector<char> done(1, 0);
+    vt_hits *one = nullptr;
+    VT_TRY(batch_group(ix, c, query, 1, limit, &one, done, true, nullptr, nullptr));
+    if (done[0]) {
+      *out = one;
+      return VT_OK;
+    }
+    delete one;  // (not certified: the exact scan decides)
+    c.prof.batch_fallbacks += 1;
+  }
   const bool lazy = !ix->ranks_clean;
   const size_t lazy_want = std::min<size_t>(limit, ix->n) + (limit < ix->n ? 1 : 0);
   // (a non-zero-bit column that is not current is simply not used: the rows always are)

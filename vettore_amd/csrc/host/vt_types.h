@@ -182,6 +182,7 @@ struct Shard {
   // by the first batch that wants it, patched per mutated row, given back when the slab needs the room.
   DevBuf<uint16_t> dShadow;
   int shadow_mode = g_default_shadow;  // VT_SHADOW_*
+  int single_nominate = g_default_single_nominate;  // vt_flat_set_single_nominate: lone searches through the shadow
   bool sh_valid = false;
   bool sh_refused = false;  // no room (or the slab took the room back): batches stream the f32 rows until the index is emptied
   std::vector<uint32_t> sh_dirty;

@@ -413,6 +413,15 @@ int vt_flat_set_batch_shadow(vt_flat *h, int mode) {
   return VT_OK;
   });
 }
+int vt_flat_set_single_nominate(vt_flat *h, int enabled) {
+  return guarded([&]() -> int {
+  if (!h) return VT_ERR_ARGUMENT;
+  std::unique_lock<std::shared_mutex> wl(h->rw);
+  for (auto &s : h->shards) s->single_nominate = enabled ? 1 : 0;
+  return VT_OK;
+  });
+}
+int vt_flat_single_nominate(const vt_flat *h) { return h && !h->shards.empty() ? h->shards[0]->single_nominate : -1; }
 int vt_flat_batch_shadow(const vt_flat *h) {
   if (!h || h->shards.empty()) return -1;
   std::shared_lock<std::shared_mutex> rl(h->rw);
