@@ -1704,3 +1704,36 @@ def test_pattern_metric_batches_beyond_one_group_call(nifs, oracle_mod):
     assert prof["hamming_queries"] == 300 and prof["hamming_launches"] == 32 + 6 and prof["scan_launches"] == 0, prof
     for i in range(300):
         assert bits(got[i]) == bits(oracle_mod.matrix_search(7, x, packed, qs[i], 5))
+
+
+@pytest.mark.parametrize("metric", [7, 8])
+def test_funnel_under_float_hamming_and_jaccard_reads_the_non_zero_bits(nifs, oracle_mod, metric):
+    """funnel_search on a float hamming / jaccard collection (collection.ex:245-260 -> search.rs:38-73 on prefixes):
+    the stage over ALL rows looks at nothing but which of the first `stage` coordinates are non-zero
+    (distances.rs:319-347), so it reads that prefix of the non-zero-bit column (K4 with a prefix mask) instead of
+    the rows; later stages and the rerank gather rows.  Prefixes on and off word and word-pair borders; equal to
+    the oracle's composition bit for bit, and to the same search with the column switched off."""
+    n, d = 30_000, 200
+    rng = np.random.default_rng(60 + metric)
+    x = (rng.uniform(-1, 1, (n, d)) * (rng.uniform(0, 1, (n, d)) < 0.45)).astype(np.float32)
+    x[500:530] = x[500]
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    nifs.flat_set_profiling(g.ref, True)
+    rows = [(ids[i], x[i]) for i in range(n)]
+    by_id = dict(rows)
+    for stages, cand, limit in (([64], 100, 10), ([100], 60, 5), ([129, 200], 256, 20), ([1], 30, 30), ([200], 10, 10), ([13, 70], 300, 7)):
+        q = (rng.uniform(-1, 1, d) * (rng.uniform(0, 1, d) < 0.45)).astype(np.float32)
+        if stages == [64]:
+            q = x[500]
+        cur = rows
+        for st in stages:
+            kept = oracle_mod.vector_top_k(cur, q, metric, st, cand)
+            cur = [(i, by_id[i]) for i, _ in kept]
+        want = oracle_mod.vector_top_k(cur, q, metric, d, limit)
+        got = unwrap(nifs.flat_funnel_search(g.ref, q, stages, cand, limit))
+        assert bits(got) == bits(want), (metric, stages, cand, limit)
+    prof = nifs.flat_get_profile(g.ref)
+    # every first stage was a pass over the bit column (K4, or its host-staged form for 300 candidates): none scanned the rows' prefixes
+    assert prof["hamming_launches"] + prof["prefix_launches"] >= 6, prof

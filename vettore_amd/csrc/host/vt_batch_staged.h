@@ -1084,7 +1084,8 @@ int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *
     if (stages[i] == 0 || stages[i] > n) return VT_ERR_PREFIX;
   if (ix->n == 0 || candidates == 0 || limit == 0) return empty_hits(out);
   uint32_t qnz_full = 0;
-  VT_TRY(upload_query(c, query, n, &qnz_full));
+  // (float hamming / jaccard: the query's non-zero bits ride along -- the stage over all rows reads the bit column)
+  VT_TRY(upload_query(c, query, n, &qnz_full, pattern_metric(ix->metric) ? 2 : 0));
   std::vector<vt::Entry> entries;
   // (`local`: the rerank keeps every candidate -- see LocalStages)
   if (funnel_fits_device(ix, stages, nstages, candidates, local ? candidates : limit)) {

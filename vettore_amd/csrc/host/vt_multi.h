@@ -423,7 +423,7 @@ int multi_stage(vt_flat *h, StageKind kind, uint32_t d, const float *query, size
     const unsigned need = NEED_STRICT_RANKS | (kind == STAGE_HAMMING ? NEED_BITS : 0u);
     if (shard_stale(ix, need, keep)) VT_TRY(shard_prepare(ix, need, keep));
     uint32_t qnz_full = 0;
-    VT_TRY(upload_query(c, query, n, &qnz_full, kind == STAGE_HAMMING));
+    VT_TRY(upload_query(c, query, n, &qnz_full, kind == STAGE_HAMMING ? 1 : (kind == STAGE_PREFIX && pattern_metric(ix->metric)) ? 2 : 0));
     if (kind == STAGE_HAMMING) {
       std::vector<uint32_t> rows;
       return quantized_rows(ix, c, keep, rows, &per[s]);
@@ -777,7 +777,8 @@ int funnel_direct(vt_flat *h, const float *query, size_t n, const size_t *stages
     if (h->poisoned) return poisoned_status();
     return funnel_multi(h, query, n, stages, nstages, candidates, limit, out);
   }
-  return read_single(h, NEED_STRICT_RANKS, limit, [&](Shard *ix, Ctx &c) -> int {
+  // (NEED_NZBITS: on a float hamming / jaccard collection the first stage reads the non-zero-bit column)
+  return read_single(h, NEED_STRICT_RANKS | NEED_NZBITS, std::min<size_t>(candidates, vt::kMaxFusedK), [&](Shard *ix, Ctx &c) -> int {
     return funnel_ready(ix, c, query, n, stages, nstages, candidates, limit, out);
   });
 }

@@ -273,6 +273,16 @@ int run_cosine_scan(Ctx &c, Shard *ix, uint32_t d, double qq, size_t want, std::
   return VT_OK;
 }
 
+// A stage over ALL rows of a float hamming / jaccard collection -- vector_top_k on the first d coordinates
+// (search.rs:38-73; distances.rs:319-347 look at nothing but which coordinates are non-zero) -- reads the
+// first ceil(d / 64) words of every row's non-zero bits instead of the rows: K4 with a prefix mask, 1/32 of the
+// bytes.  Applies when the column is current (a reader never waits for it) and the query's non-zero bits are
+// what c.dQbits holds (upload_query with_bits = 2).
+bool pattern_stage_applies(const Shard *ix, const Ctx &c, size_t want) {
+  return c.qbits_kind == 2 && want >= 1 && want <= (size_t)vt::kMaxFusedK && pattern_search_applies(ix, want) &&
+         !shard_stale(ix, NEED_NZBITS, want);
+}
+
 // One vector_top_k stage (search.rs:38-73) on the resident corpus: prefix length
 // `d`, over all rows (`rows` empty) or over the candidate rows of the previous
 // stage; keeps `want` hits.
@@ -304,6 +314,9 @@ int funnel_stage(Shard *ix, Ctx &c, const float *query, uint32_t d, const std::v
     VT_HIP(vt::launch_cosine_rerank(a, c.stream));
     return collect_from_keys(c, c.dCandKeys.p, c.dCandPay.p, (uint32_t)rows.size(), want, out);
   }
+  if (all_rows && pattern_stage_applies(ix, c, want))
+    return run_hamming(c, ix->dNzBits.p, c.dQbits, ix->dRank.p, ix->n, d, want, out, true, ix->metric == VT_JACCARD,
+                       (((uint32_t)ix->dim + 63) / 64 + 1) / 2);
   ScanJob j{};
   j.X = ix->dX;
   j.stride = ix->ld;
@@ -327,6 +340,36 @@ int scan_stage_dev(Shard *ix, Ctx &c, uint32_t d, const ResultBlock *src, uint32
   const uint32_t *gather = src ? &src->e[0].row : nullptr;
   const uint32_t gstride = sizeof(vt::Entry) / sizeof(uint32_t);
   int *status = last ? c.dStatus.p : nullptr;
+  if (!src && pattern_stage_applies(ix, c, want)) {
+    // all rows under float hamming / jaccard: the non-zero bits of the prefix (K4) instead of the rows
+    const uint32_t words = (d + 63) / 64;
+    const uint32_t hblocks = c.grid_for((ix->n + 63) / 64, vt::hamming_lds_bytes(want), c.hamming_blocks_per_cu);
+    const uint32_t hlists = vt::scan_lists(hblocks);
+    VT_TRY(c.dPartKeys.ensure((size_t)hlists * want));
+    VT_TRY(c.dPartPay.ensure((size_t)hlists * want));
+    vt::HammingArgs h{};
+    h.bits = ix->dNzBits.p;
+    h.qbits = c.dQbits;
+    h.id_rank = ix->dRank.p;
+    h.n = ix->n;
+    h.words = words;
+    h.pairs = (words + 1) / 2;
+    h.d = d;
+    h.k = want;
+    h.part_keys = c.dPartKeys.p;
+    h.part_pay = c.dPartPay.p;
+    h.jaccard = ix->metric == VT_JACCARD ? 1 : 0;
+    h.tile_pairs = (((uint32_t)ix->dim + 63) / 64 + 1) / 2;
+    if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
+    VT_HIP(vt::launch_hamming(h, hblocks, c.stream));
+    if (c.profiling) {
+      VT_HIP(hipEventRecord(c.ev1, c.stream));
+      c.prefix_pending += 1;
+      c.prof.prefix_bytes += (uint64_t)ix->n * words * 8;
+    }
+    VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, hlists * want, want, 0, 0, status, dst, c.dSelKeys.p, c.dSelPay.p, c.stream));
+    return VT_OK;
+  }
   const uint32_t tile_rows = vt::scan_tile_rows(count, d, c.resident_waves());
   const uint32_t ntiles = (count + tile_rows - 1) / tile_rows;
   const uint32_t blocks = c.grid_for(ntiles, vt::scan_lds_bytes(d, want));

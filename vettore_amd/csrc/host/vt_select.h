@@ -358,8 +358,9 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
   return VT_OK;
 }
 
+// tile_pairs != 0: `d` is a prefix of rows whose bit tiles hold tile_pairs word pairs (HammingArgs).
 int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint32_t *id_rank, uint32_t n, uint32_t d,
-                size_t want, std::vector<vt::Entry> &out, bool count_profile, bool jaccard = false) {
+                size_t want, std::vector<vt::Entry> &out, bool count_profile, bool jaccard = false, uint32_t tile_pairs = 0) {
   const uint32_t words = (d + 63) / 64;
   const uint32_t ntiles = (n + 63) / 64;
   uint64_t lo = 0;
@@ -385,6 +386,7 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
     a.part_keys = c.dPartKeys.p;
     a.part_pay = c.dPartPay.p;
     a.jaccard = jaccard ? 1 : 0;
+    a.tile_pairs = tile_pairs;
     if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
     VT_HIP(vt::launch_hamming(a, blocks, c.stream));
     if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
@@ -431,6 +433,7 @@ int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero, int with
       if (with_bits == 2 ? q[i] != 0.0f : q[i] >= 0.0f) w[i / 64] |= 1ull << (i % 64);
     c.dQbits = reinterpret_cast<uint64_t *>(c.dQ.p + ld);
   }
+  c.qbits_kind = with_bits;
   VT_HIP(hipMemcpyAsync(c.dQ.p, c.hQ.p, total * sizeof(float), hipMemcpyHostToDevice, c.stream));
   return VT_OK;
 }

@@ -14,6 +14,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   DevBuf<float> dQ;
   uint64_t *dQbits = nullptr;  // the query's sign bits, behind the query in dQ (upload_query with_bits)
+  int qbits_kind = 0;          // what dQbits holds for the query last uploaded: 0 nothing, 1 sign bits, 2 non-zero bits
   DevBuf<uint64_t> dPartKeys;
   DevBuf<vt::Payload> dPartPay;
   DevBuf<uint64_t> dSelKeys;  // second level of the two-level select: kSelGroups * kMaxFusedK entries

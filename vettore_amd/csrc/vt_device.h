@@ -195,6 +195,10 @@ struct HammingArgs {
   uint64_t *part_keys;
   Payload *part_pay;
   int jaccard;  // the bits are non-zero patterns and the score is distances.rs:327-347's (else the differing bits)
+  // A PREFIX of the rows' bits (funnel stages under float hamming / jaccard, vector_top_k on the first d
+  // coordinates, search.rs:38-73): words / pairs / d describe the prefix, tile_pairs the word pairs a tile of
+  // the matrix really holds (0: the same as `pairs`).  Words behind the prefix are never counted.
+  uint32_t tile_pairs;
 };
 hipError_t launch_hamming(const HammingArgs &a, uint32_t blocks, hipStream_t s);
 

@@ -498,9 +498,12 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
     for (int j = 0; j < 2 * PAIRS; ++j) qw[j] = ((cu64_p)(uintptr_t)a.qbits)[j];
   }
   const uint64_t mask_even = a.words == 2u * PAIRS - 1 ? last_mask : ~0ull;
-  const uint64_t mask_odd = a.words == 2u * PAIRS ? last_mask : ~0ull;
+  // (an odd word count: the last pair's second word is a zero pad on both sides for whole rows, and the first word
+  // BEHIND a prefix -- which must not count -- for a prefix pass)
+  const uint64_t mask_odd = a.words == 2u * PAIRS ? last_mask : 0ull;
+  const uint32_t tile_pairs = a.tile_pairs ? a.tile_pairs : pairs;
   for (uint32_t t = wave_global; t < ntiles; t += total_waves) {
-    const u64x2 *base = bits + ((size_t)t * pairs * kWave + lane);
+    const u64x2 *base = bits + ((size_t)t * tile_pairs * kWave + lane);
     // `ham` counts the differing bits; in the pattern mode for jaccard `both` counts the bits set on
     // both sides as well
     uint32_t ham = 0, both = 0;
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void hamming_topk_kernel(con
         const u64x2 v = __builtin_nontemporal_load(base + (size_t)j * kWave);
         const uint32_t w0 = 2 * j, w1 = 2 * j + 1;
         const uint64_t q0 = a.qbits[w0], q1 = w1 < a.words ? a.qbits[w1] : 0ull;
-        const uint64_t m0 = w0 == last_word ? last_mask : ~0ull, m1 = w1 == last_word ? last_mask : ~0ull;
+        const uint64_t m0 = w0 == last_word ? last_mask : ~0ull, m1 = w1 < a.words ? (w1 == last_word ? last_mask : ~0ull) : 0ull;
         ham += __popcll((v.x ^ q0) & m0) + __popcll((v.y ^ q1) & m1);
         if (a.jaccard) both += __popcll(v.x & q0 & m0) + __popcll(v.y & q1 & m1);
       }
@@ -1669,7 +1672,8 @@ hipError_t launch_hamming_r(const HammingArgs &a, uint32_t blocks, hipStream_t s
 }
 
 hipError_t launch_hamming(const HammingArgs &a, uint32_t blocks, hipStream_t s) {
-  if (a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.words == 0 || a.pairs != (a.words + 1) / 2) return hipErrorInvalidValue;
+  if (a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.words == 0 || a.pairs != (a.words + 1) / 2 || (a.tile_pairs && a.tile_pairs < a.pairs))
+    return hipErrorInvalidValue;
   return a.k <= (uint32_t)kSmallK ? launch_hamming_r<kCapSmall>(a, blocks, s) : launch_hamming_r<kCapLarge>(a, blocks, s);
 }
 
