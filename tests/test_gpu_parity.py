@@ -1735,5 +1735,9 @@ def test_funnel_under_float_hamming_and_jaccard_reads_the_non_zero_bits(nifs, or
         got = unwrap(nifs.flat_funnel_search(g.ref, q, stages, cand, limit))
         assert bits(got) == bits(want), (metric, stages, cand, limit)
     prof = nifs.flat_get_profile(g.ref)
-    # every first stage was a pass over the bit column (K4, or its host-staged form for 300 candidates): none scanned the rows' prefixes
-    assert prof["hamming_launches"] + prof["prefix_launches"] >= 6, prof
+    # every first stage over a true prefix was a pass over the bit column (K4, or its host-staged form for 300 candidates);
+    # [200] is the whole row and goes the collection's ordinary way
+    assert prof["hamming_launches"] + prof["prefix_launches"] >= 5, prof
+    # ... and what those passes read is the bit words (8 B per 64 coordinates and row), not the rows' prefixes
+    # (4 B per coordinate and row: 36.8 MB over these six searches)
+    assert prof["prefix_bytes"] + prof["hamming_bytes"] < n * 64 * 4, prof
