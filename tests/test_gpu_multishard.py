@@ -185,6 +185,50 @@ def test_staged_searches_on_a_sharded_handle_equal_the_one_gpu_index(nifs, oracl
     assert bits(unwrap(nifs.flat_funnel_search(many.ref, q, [32], 100, 10))) == bits(unwrap(nifs.flat_funnel_search(one.ref, q, [32], 100, 10)))
 
 
+@pytest.mark.parametrize("metric", [7, 8])
+@pytest.mark.parametrize("rounds", ["one", "per-stage"])
+def test_pattern_funnel_on_a_sharded_handle_equals_the_one_gpu_index(nifs, oracle_mod, metric, rounds, monkeypatch):
+    """funnel_search / hybrid_search on float hamming / jaccard collections (collection.ex:245-260, :325-345): the
+    first stage of each shard reads the prefix of its non-zero-bit column.  Equal to the one-GPU index (pinned to the
+    oracle's composition in test_gpu_parity) single, batched, and after mutations patched the column."""
+    if rounds == "per-stage":
+        monkeypatch.setenv("VT_STAGED_ROUNDS", "1")
+    n, d = 60_000, 130
+    rng = np.random.default_rng(77 + metric)
+    x = (rng.uniform(-1, 1, (n, d)) * (rng.uniform(0, 1, (n, d)) < 0.4)).astype(np.float32)
+    x[100:140] = x[100]
+    ids = [b"doc-%d" % (i + 1) for i in range(n)]
+    one = GpuIndex(nifs, metric)
+    many = ShardedIndex(nifs, metric, [0, 0, 0])
+    unwrap(nifs.flat_load_matrix(one.ref, ids, x))
+    unwrap(nifs.flat_load_matrix(many.ref, ids, x))
+    qs = [x[100], x[n - 1]] + [(rng.uniform(-1, 1, d) * (rng.uniform(0, 1, d) < 0.4)).astype(np.float32) for _ in range(3)]
+    for qi, q in enumerate(qs):
+        for stages, cand, limit in (([64], 100, 10), ([70, 129], 64, 10), ([24], 300, 20), ([130], 20, 20)):
+            got = unwrap(nifs.flat_funnel_search(many.ref, q, stages, cand, limit))
+            assert bits(got) == bits(unwrap(nifs.flat_funnel_search(one.ref, q, stages, cand, limit))), (metric, qi, stages)
+        gens = [(nifs.GEN_FUNNEL, 50, [65]), (nifs.GEN_SEARCH, 40, [])]
+        got = unwrap(nifs.flat_hybrid_search(many.ref, q, gens, 15))
+        assert bits(got) == bits(unwrap(nifs.flat_hybrid_search(one.ref, q, gens, 15))), (metric, qi)
+    qm = np.stack(qs)
+    for ref in (one.ref, many.ref):
+        got = unwrap(nifs.flat_funnel_search_batch(ref, qm, [70, 129], 64, 10))
+        assert [bits(h) for h in got] == [bits(unwrap(nifs.flat_funnel_search(one.ref, q, [70, 129], 64, 10))) for q in qs], metric
+    by_id = {ids[i]: x[i] for i in range(n)}
+    newrow = x[n - 1].copy()
+    for target in (one, many):
+        target.insert("zz-new", newrow)
+        target.delete(ids[101])
+    by_id[b"zz-new"] = newrow
+    del by_id[ids[101]]
+    rows = list(by_id.items())
+    q = qs[1]
+    kept = oracle_mod.vector_top_k(rows, q, metric, 70, 100)
+    want = oracle_mod.vector_top_k([(i, by_id[i]) for i, _ in kept], q, metric, d, 10)
+    assert bits(unwrap(nifs.flat_funnel_search(one.ref, q, [70], 100, 10))) == bits(want)
+    assert bits(unwrap(nifs.flat_funnel_search(many.ref, q, [70], 100, 10))) == bits(want)
+
+
 def test_one_round_staged_search_ignores_an_overflow_outside_the_candidate_set(nifs, oracle_mod):
     """The one-round form reranks every shard's OWN candidates; one of them may be a row the
     handle-wide candidate set does not contain.  If that row's full-length distance overflows
