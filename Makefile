@@ -15,7 +15,7 @@ ifdef EXPERIMENTS
 HIPFLAGS += -DVT_BATCH_TIMING_EXPERIMENTS
 endif
 
-DEVSRC  := vt_kernels vt_batch vt_batch_bf16 vt_batch_shadow vt_scan_dot vt_scan_l2 vt_scan_l1 vt_scan_misc vt_scan_general vt_scan_gather vt_scan_multi
+DEVSRC  := vt_kernels vt_batch vt_batch_bf16 vt_batch_shadow vt_scan_dot vt_scan_l2 vt_scan_l1 vt_scan_misc vt_scan_general vt_scan_gather vt_scan_multi vt_prefix_multi
 DEVOBJ  := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(DEVSRC)))
 DEVHDR  := $(CSRC)/vt_device.h $(CSRC)/vt_common.cuh $(CSRC)/vt_scan.cuh
 
@@ -34,6 +34,10 @@ $(LIBDIR)/vt_batch_bf16.o: $(CSRC)/vt_batch_bf16.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_batch_bf16.resources
 	python3 tools/check_scratch.py $(LIBDIR)/vt_batch_bf16.resources bf16_scores_kernel
+$(LIBDIR)/vt_prefix_multi.o: $(CSRC)/vt_prefix_multi.hip $(DEVHDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_prefix_multi.resources
+	python3 tools/check_scratch.py $(LIBDIR)/vt_prefix_multi.resources prefix_multi_kernel
 $(LIBDIR)/vt_batch_shadow.o: $(CSRC)/vt_batch_shadow.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_batch_shadow.resources

@@ -294,7 +294,7 @@ def hits_of(L, handle_ptr):
     return [(h[0], np.float32(h[1]).tobytes()) for h in nifs._take_hits(handle_ptr)]
 
 
-def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidates=100, limit=10):
+def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidates=100, limit=10, kernel=None):
     """Times `steps` calls of one entry point on the resident index `ref` (after `warmup`
     untimed ones) and returns {ms_per_step, value, roofline...} from the library's HIP-event
     profile.  At full size a result per leg is compared with the single-query path (batch) or
@@ -376,6 +376,7 @@ def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidat
         key = {"single": "scan", "funnel": "prefix", "quantized": "hamming", "pattern": "hamming"}[mode]
         kern = {"single": "scan_topk_kernel", "funnel": "cosine_scan_kernel", "quantized": "hamming_dist_kernel",
                 "pattern": "hamming_topk_kernel"}[mode]
+        kern = kernel or kern
         if mode == "pattern" and len(ref) >= 16384:  # (every search a pass over the non-zero-bit column, none a scan of the rows)
             assert p["scan_launches"] == 0 and p["hamming_launches"] >= steps, p
         launches = max(1, p[key + "_launches"])
@@ -651,7 +652,46 @@ def side_legs(a, torch, nifs, L, device, main_ref):
     ref3 = nifs.flat_new_inner_product()
     nifs.flat_set_reduce_order(ref3, ORDER_CODE[a.reduce_order])
     assert nifs.flat_load_device_matrix(ref3, doc_ids(0, a.rows), x.data_ptr(), a.rows, a.dim) == ("ok", ())
+    # (the same rows as an L2 collection: the funnel legs below)
+    ref0 = nifs._flat_new(0)
+    nifs.flat_set_reduce_order(ref0, ORDER_CODE[a.reduce_order])
+    assert nifs.flat_load_device_matrix(ref0, doc_ids(0, a.rows), x.data_ptr(), a.rows, a.dim) == ("ok", ())
     del x
+    torch.cuda.empty_cache()
+    # funnel_search on an L2 collection: stage 1 is K1's arithmetic on the prefix (one caller: K1 itself over the
+    # rows' first 128 floats; callers that meet: K1p, up to eight per sweep of the prefixes)
+    p128 = min(a.dim, 128)
+    qs = np.random.default_rng(SEED_QUERY + 12).uniform(-1, 1, size=(110, a.dim)).astype(np.float32)
+    side["funnel_l2"] = dict(leg(a, L, nifs, ref0, "funnel", qs, 100, 10, stages=(p128,), candidates=100, kernel="scan_topk_kernel (prefix)"),
+                             workload="index: :flat, metric: :l2, funnel_search stages=[%d] candidates=100 limit=10, d=%d, N=%d" % (p128, a.dim, a.rows),
+                             dtype="f32")
+    outs64 = (C.c_void_p * 64)()
+    qb = np.ascontiguousarray(qs[:64])
+    st_arr = (C.c_size_t * 1)(p128)
+    nifs.flat_set_profiling(ref0, True)
+    times = []
+    for rep in range(4):
+        nifs.flat_get_profile(ref0, reset=True)
+        t1 = time.perf_counter()
+        assert L.vt_flat_funnel_search_batch(ref0.handle, qb.ctypes.data_as(C.POINTER(C.c_float)), 64, a.dim, st_arr, 1, 100, a.limit, outs64) == 0
+        times.append(time.perf_counter() - t1)
+        got = [hits_of(L, C.c_void_p(outs64[j])) for j in range(64)]
+    pf = nifs.flat_get_profile(ref0, reset=True)
+    nifs.flat_set_profiling(ref0, False)
+    for j in range(0, 64, 8):
+        h = C.c_void_p()
+        assert L.vt_flat_funnel_search(ref0.handle, qb[j].ctypes.data_as(C.POINTER(C.c_float)), a.dim, st_arr, 1, 100, a.limit, C.byref(h)) == 0
+        assert hits_of(L, h) == got[j], "batched funnel search differs from the single call"
+    sweep_ms = pf["prefix_ms"] / max(1, pf["prefix_launches"])
+    side["funnel_l2"]["batch64"] = {
+        "ms": min(times[1:]) * 1e3, "queries_per_s": 64 / min(times[1:]), "sweeps": pf["prefix_launches"],
+        "queries_in_sweeps": pf["prefix_queries"], "kernel": "prefix_multi_kernel", "avg_sweep_ms": sweep_ms,
+        "sweep_GBps": pf["prefix_bytes"] / max(1, pf["prefix_launches"]) / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0,
+        "verified": True}
+    side["callers_funnel_l2"] = {"workload": "index: :flat, metric: :l2, funnel_search stages=[%d] candidates=100 limit=%d, d=%d, N=%d, "
+                                             "T threads on one handle" % (p128, a.limit, a.dim, a.rows),
+                                 "runs": [concurrent_callers(a, L, nifs, ref0, t, 1.0, funnel=p128) for t in (1, 8, 64)]}
+    del ref0
     torch.cuda.empty_cache()
     qs = np.random.default_rng(SEED_QUERY + 3).uniform(-1, 1, size=(7 * 256, a.dim)).astype(np.float32)
     # ... candidates nominated on the FP32 matrix cores (K2, the r01/r02 path, unchanged) ...

@@ -1427,7 +1427,7 @@ def test_funnel_search_batch_equals_single_calls(nifs, oracle_mod):
     per-query lists, batched select), later stages and the exact rerank run with the queries on
     grid.y; each query's hits must equal its own funnel_search AND the oracle's composition
     (vector_top_k on each prefix, then on the full vectors; collection.ex:245-260) bit for bit.
-    Other metrics, long prefixes and large candidate counts take the calls one by one."""
+    The pattern metrics and large candidate counts take the calls one by one."""
     n, d = 30_000, 160
     x, ids = make_corpus(n, d, 4500, True, oracle_mod, tie_block=300)
     g = GpuIndex(nifs, 2)
@@ -1464,13 +1464,76 @@ def test_funnel_search_batch_equals_single_calls(nifs, oracle_mod):
     assert nifs.flat_funnel_search_batch(g.ref, np.zeros((3, d + 1), np.float32), [4], 10, 5) == ("error", "dimension mismatch")
     assert unwrap(nifs.flat_funnel_search_batch(g.ref, qs[:3], [4], 0, 5)) == [[]] * 3
     assert unwrap(nifs.flat_funnel_search_batch(g.ref, qs[:3], [4], 5, 0)) == [[]] * 3
-    # another metric: query by query, same answers
+    # another metric (its own grouped sweep: test_funnel_batches_of_the_k1_families_share_the_prefix_sweep), same answers
     g0 = GpuIndex(nifs, 0)
     unwrap(nifs.flat_load_matrix(g0.ref, ids, x))
     qs = rng.uniform(-1, 1, (4, d)).astype(np.float32)
     got = unwrap(nifs.flat_funnel_search_batch(g0.ref, qs, [32, 64], 50, 10))
     for i in range(4):
         assert bits(got[i]) == bits(unwrap(nifs.flat_funnel_search(g0.ref, qs[i], [32, 64], 50, 10)))
+
+
+@pytest.mark.parametrize("metric", [0, 3, 1, 4, 5, 6])
+def test_funnel_batches_of_the_k1_families_share_the_prefix_sweep(nifs, oracle_mod, metric):
+    """vt_flat_funnel_search_batch on L2 / dot / L1 / Linf collections: groups of up to eight share ONE sweep of the
+    prefixes (K1p, prefix_multi_kernel: K1's chunked f32 arithmetic per query; threshold from a sample on
+    -rank_value; per-query lists cut to `candidates`), later stages and the rerank run K1's batch mode over each
+    query's candidates.  Every query's hits equal its own funnel_search and the oracle's composition
+    (collection.ex:245-260: vector_top_k on each prefix, then on the full rows) bit for bit -- prefixes with and
+    without a scalar tail, narrower and wider than one 64-float panel, identical rows, all four lane orders."""
+    n, d = 30_000, 200
+    x, ids = make_corpus(n, d, 4700 + metric, False, oracle_mod, tie_block=300)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rows = [(ids[i], x[i]) for i in range(n)]
+    by_id = dict(rows)
+    rng = np.random.default_rng(31 + metric)
+    nifs.flat_set_profiling(g.ref, True)
+    shapes = ((2, [32], 100, 10), (8, [64, 128], 60, 10), (17, [13], 256, 30), (5, [200], 7, 7), (9, [8, 27, 96], 40, 100),
+              (3, [1], 50, 5), (6, [70], 120, 12))
+    if metric not in (0, 3):
+        shapes = shapes[1:3] + shapes[6:]
+    for nq, stages, cand, limit in shapes:
+        qs = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+        qs[0] = x[n // 2]                                    # inside the block of identical rows
+        nifs.flat_get_profile(g.ref, reset=True)
+        got = unwrap(nifs.flat_funnel_search_batch(g.ref, qs, stages, cand, limit))
+        prof = nifs.flat_get_profile(g.ref, reset=True)
+        assert len(got) == nq
+        assert prof["prefix_queries"] >= nq - 1 - nq // 8, (nq, stages, prof)   # (a lone last query goes alone; a threshold may miss)
+        for i in range(nq):
+            assert bits(got[i]) == bits(unwrap(nifs.flat_funnel_search(g.ref, qs[i], stages, cand, limit))), (metric, nq, stages, i)
+        for i in (0, nq - 1):
+            cur = rows
+            for st in stages:
+                kept = oracle_mod.vector_top_k(cur, qs[i], metric, st, cand)
+                cur = [(j, by_id[j]) for j, _ in kept]
+            want = oracle_mod.vector_top_k(cur, qs[i], metric, d, limit)
+            assert bits(got[i]) == bits(want), (metric, nq, stages, cand, limit, i)
+    if metric in (0, 3):
+        # the other lane orders of wide's reduce_add (DESIGN 3.3): the sweep's arithmetic follows the handle's
+        for order in (0, 1, 2):
+            h = GpuIndex(nifs, metric, order=order)
+            unwrap(nifs.flat_load_matrix(h.ref, ids[:20_000], x[:20_000]))
+            qs = rng.uniform(-1, 1, (5, d)).astype(np.float32)
+            got = unwrap(nifs.flat_funnel_search_batch(h.ref, qs, [45, 128], 80, 10))
+            for i in range(5):
+                assert bits(got[i]) == bits(unwrap(nifs.flat_funnel_search(h.ref, qs[i], [45, 128], 80, 10))), (metric, order, i)
+    # a stage that overflows for one query: that query reports it, the batch call returns the first error like the loop would
+    if metric == 3:
+        big = GpuIndex(nifs, 3)
+        xb = x[:20_000].copy()
+        xb[77, :8] = 3e38
+        unwrap(nifs.flat_load_matrix(big.ref, ids[:20_000], xb))
+        qs = rng.uniform(-1, 1, (4, d)).astype(np.float32)
+        qs[2, :8] = 3e38
+        singles = [nifs.flat_funnel_search(big.ref, q, [16], 50, 5) for q in qs]
+        got = nifs.flat_funnel_search_batch(big.ref, qs, [16], 50, 5)
+        firsterr = next((r for r in singles if r[0] == "error"), None)
+        if firsterr is not None:
+            assert got == firsterr
+        else:
+            assert [bits(h) for h in unwrap(got)] == [bits(unwrap(r)) for r in singles]
 
 
 def test_concurrent_funnel_callers_share_sweeps(nifs, oracle_mod, monkeypatch):

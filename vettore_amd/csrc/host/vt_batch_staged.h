@@ -1148,10 +1148,18 @@ int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *
 // a query whose list came out short (or overflowed) takes the single path.  Later stages and the
 // exact rerank run once with the queries on grid.y (cosine_rerank_kernel); one wait.  Each
 // query's hits are what its own funnel_search returns, bit for bit.
+//
+// Collections of the dot / L2 / L1 / Linf families go the same way with their own arithmetic: stage 1 is K1p
+// (prefix_multi_kernel: K1's chunked f32 sums over the prefix for up to eight queries per sweep), the threshold is
+// taken on -rank_value (exact negation: the list is cut by the very order the keys sort in, so a list of at least
+// `candidates` rows IS the single path's stage), later stages and the rerank are K1's batch mode over the
+// candidates (queries on grid.y), the arithmetic the single path's scan_stage_dev runs.
 bool funnel_group_applies(const Shard *ix, const size_t *stages, size_t nstages, size_t candidates, size_t limit) {
-  if (ix->metric != VT_COSINE || nstages == 0 || std::getenv("VT_NO_FUNNEL_GROUPS")) return false;
+  if (nstages == 0 || std::getenv("VT_NO_FUNNEL_GROUPS")) return false;
+  if (ix->metric != VT_COSINE && !vt::prefix_multi_supports(ix->metric)) return false;
   const size_t k1 = std::min<size_t>(candidates, ix->n);
   if (ix->n < 16384 || k1 == 0 || k1 > (size_t)vt::kMaxFusedK || limit == 0) return false;
+  if (ix->metric != VT_COSINE) return vt::scan_lds_bytes((uint32_t)ix->dim, (uint32_t)k1) != 0;
   return (size_t)2 * (((size_t)ix->dim + 3) / 4 * 4) * 4 <= 160 * 1024;  // the rerank keeps row + query in LDS
 }
 
@@ -1173,8 +1181,11 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   rank = std::max<uint32_t>(6, std::min<uint32_t>(rank, std::min<uint32_t>(sample_rows, n)));
   // one upload: full queries [nq][ld] (f32), their prefixes as f64 [8][ldq] (what stage 1 reads, through
   // the scalar cache; ld and ldq are multiples of 64, so the block stays 32-byte aligned), list lengths
-  const size_t q_floats = (size_t)nq * ld, p_floats = (size_t)vt::kCosineMultiMax * ldq * 2;
-  const size_t up_floats = q_floats + p_floats + vt::kCosineMultiMax;
+  const bool cosine = ix->metric == VT_COSINE;
+  static_assert(vt::kPrefixMultiMax == vt::kCosineMultiMax, "one group size");
+  // (K1p reads all eight query rows whatever nq is: the buffer always holds eight)
+  const size_t q_floats = (size_t)vt::kCosineMultiMax * ld, p_floats = (size_t)vt::kCosineMultiMax * ldq * 2;
+  const size_t up_floats = q_floats + p_floats + 2 * vt::kCosineMultiMax;  // (+ [8] candidates per list, [8] keys per K1 stage list)
   VT_TRY(c.dBQ.ensure(up_floats));
   VT_TRY(c.hBQ.ensure(up_floats));
   VT_TRY(c.dBSample.ensure((size_t)vt::kCosineMultiMax * sample_rows));
@@ -1183,8 +1194,12 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   VT_TRY(c.dPartKeys.ensure((size_t)nq * kListCap));
   VT_TRY(c.dPartPay.ensure((size_t)nq * kListCap));
   VT_TRY(c.dStageB.ensure(nq));
-  VT_TRY(c.dCandKeys.ensure((size_t)nq * k1));
-  VT_TRY(c.dCandPay.ensure((size_t)nq * k1));
+  constexpr uint32_t kStageBlocks = 4;  // K1 batch mode: blocks per query over its <= 256 candidates (8-row tiles)
+  VT_TRY(c.dCandKeys.ensure((size_t)nq * k1 * kStageBlocks));
+  VT_TRY(c.dCandPay.ensure((size_t)nq * k1 * kStageBlocks));
+  // (a list that came out short leaves the tail of its block as it was: rows a later stage may still gather --
+  // zeroed, they are row 0)
+  VT_HIP(hipMemsetAsync(c.dStageB.p, 0, (size_t)nq * sizeof(ResultBlock), c.stream));
   const size_t res_bytes = (size_t)vt::kHammingMultiMax * vt::kMaxFusedK * sizeof(vt::Entry) + 256;
   if (!c.dBigMapped || c.hBig.count < res_bytes) {
     VT_TRY(c.hBig.ensure(std::max<size_t>(res_bytes, 16 + (size_t)vt::kSelListMax * sizeof(vt::Entry))));
@@ -1205,6 +1220,9 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   for (uint32_t i = 0; i < nq; ++i) {
     const float *q = queries + which[i] * d;
     std::memcpy(c.hBQ.p + (size_t)i * ld, q, (size_t)d * sizeof(float));
+    hcounts[i] = k1;
+    hcounts[vt::kCosineMultiMax + i] = kStageBlocks * k1;
+    if (!cosine) continue;
     double *qd = reinterpret_cast<double *>(c.hBQ.p + q_floats) + (size_t)i * ldq;
     double qq = 0.0;  // f64_dot(q, q) over the prefix (distances.rs:179-185)
     for (uint32_t j = 0; j < d1; ++j) {
@@ -1212,10 +1230,10 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
       qq += (double)q[j] * (double)q[j];
     }
     a.qq[i] = qq;
-    hcounts[i] = k1;
   }
   VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, up_floats * sizeof(float), hipMemcpyHostToDevice, c.stream));
   const uint32_t *dcounts = reinterpret_cast<const uint32_t *>(c.dBQ.p + q_floats + p_floats);
+  const uint32_t *dlens = dcounts + vt::kCosineMultiMax;
   VT_HIP(hipMemsetAsync(c.dBCount.p, 0, vt::kCosineMultiMax * sizeof(uint32_t), c.stream));
   a.X = ix->dX;
   a.stride = ix->ld;
@@ -1225,22 +1243,36 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   a.d = d1;
   a.nq = nq;
   a.status = c.dStatus.p;
-  const size_t lds = vt::cosine_scan_multi_lds_bytes();
+  vt::PrefixMultiArgs pa{};
+  pa.X = ix->dX;
+  pa.stride = ix->ld;
+  pa.Q = c.dBQ.p;
+  pa.q_stride = ld;
+  pa.id_rank = ix->dRank.p;
+  pa.n = n;
+  pa.d = d1;
+  pa.nq = nq;
+  pa.metric = ix->metric;
+  pa.order = ix->order;
+  pa.status = c.dStatus.p;
+  const size_t lds = cosine ? vt::cosine_scan_multi_lds_bytes() : vt::prefix_multi_lds_bytes();
   // pass 0: the sample's scores -> one threshold per query
-  a.sample = c.dBSample.p;
-  a.sample_stride = sstride;
-  a.sample_rows = sample_rows;
-  VT_HIP(vt::launch_cosine_scan_multi(a, c.grid_for(stiles, lds), c.stream));
+  a.sample = pa.sample = c.dBSample.p;
+  a.sample_stride = pa.sample_stride = sstride;
+  a.sample_rows = pa.sample_rows = sample_rows;
+  if (cosine) VT_HIP(vt::launch_cosine_scan_multi(a, c.grid_for(stiles, lds), c.stream));
+  else VT_HIP(vt::launch_prefix_multi(pa, c.grid_for(stiles, lds), c.stream));
   VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, vt::kCosineMultiMax, nq, rank, c.dBTau.p, c.stream));
   // pass 1: every row's prefix once; (query, row) pairs at or above the thresholds into the lists
-  a.sample = nullptr;
-  a.tau = c.dBTau.p;
-  a.cand_keys = c.dPartKeys.p;
-  a.cand_pay = c.dPartPay.p;
-  a.cand_count = c.dBCount.p;
-  a.cand_cap = kListCap;
+  a.sample = pa.sample = nullptr;
+  a.tau = pa.tau = c.dBTau.p;
+  a.cand_keys = pa.cand_keys = c.dPartKeys.p;
+  a.cand_pay = pa.cand_pay = c.dPartPay.p;
+  a.cand_count = pa.cand_count = c.dBCount.p;
+  a.cand_cap = pa.cand_cap = kListCap;
   if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
-  VT_HIP(vt::launch_cosine_scan_multi(a, c.grid_for(ntiles, lds), c.stream));
+  if (cosine) VT_HIP(vt::launch_cosine_scan_multi(a, c.grid_for(ntiles, lds), c.stream));
+  else VT_HIP(vt::launch_prefix_multi(pa, c.grid_for(ntiles, lds), c.stream));
   if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
   VT_HIP(hipMemcpyAsync(hListCount, c.dBCount.p, vt::kCosineMultiMax * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(vt::launch_select_lists(c.dPartKeys.p, c.dPartPay.p, nq, kListCap, c.dBCount.p, k1, c.dStageB.p,
@@ -1265,15 +1297,49 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   r.status = c.dStatus.p;
   r.q_stride = ld;
   r.gather_qstride = (uint32_t)(sizeof(ResultBlock) / sizeof(uint32_t));
+  // (the other families: K1 over each query's candidate rows, kStageBlocks lists of `k` per query)
+  vt::ScanArgs sa{};
+  sa.X = ix->dX;
+  sa.stride = ix->ld;
+  sa.q = c.dBQ.p;
+  sa.id_rank = ix->dRank.p;
+  sa.gather = &c.dStageB.p->e[0].row;
+  sa.gather_stride = sizeof(vt::Entry) / sizeof(uint32_t);
+  sa.n = k1;
+  sa.metric = ix->metric;
+  sa.order = ix->order;
+  sa.part_keys = c.dCandKeys.p;
+  sa.part_pay = c.dCandPay.p;
+  sa.status = c.dStatus.p;
+  sa.batch_counts = dcounts;
+  sa.batch_cap = k1;
+  sa.batch_qstride = ld;
+  sa.batch_gather_stride = (uint32_t)(sizeof(ResultBlock) / sizeof(uint32_t));
+  static const uint32_t kListsPerQuery = vt::scan_lists(kStageBlocks);
   for (size_t i = 1; i < nstages; ++i) {
-    r.d = (uint32_t)stages[i];
-    VT_HIP(vt::launch_cosine_rerank_batch(r, nq, c.stream));
-    VT_HIP(vt::launch_select_lists(c.dCandKeys.p, c.dCandPay.p, nq, k1, dcounts, k1, c.dStageB.p, (uint32_t)sizeof(ResultBlock),
-                                   c.stream));
+    if (cosine) {
+      r.d = (uint32_t)stages[i];
+      VT_HIP(vt::launch_cosine_rerank_batch(r, nq, c.stream));
+      VT_HIP(vt::launch_select_lists(c.dCandKeys.p, c.dCandPay.p, nq, k1, dcounts, k1, c.dStageB.p, (uint32_t)sizeof(ResultBlock),
+                                     c.stream));
+    } else {
+      sa.d = (uint32_t)stages[i];
+      sa.k = k1;
+      VT_HIP(vt::launch_scan_batch(sa, kStageBlocks, nq, c.stream));
+      VT_HIP(vt::launch_select_lists(c.dCandKeys.p, c.dCandPay.p, nq, kListsPerQuery * k1, dlens, k1, c.dStageB.p,
+                                     (uint32_t)sizeof(ResultBlock), c.stream));
+    }
   }
-  r.d = d;
-  VT_HIP(vt::launch_cosine_rerank_batch(r, nq, c.stream));
-  VT_HIP(vt::launch_batch_select(c.dCandKeys.p, c.dCandPay.p, nq, k1, k2, dOut, dOutCount, c.stream));
+  if (cosine) {
+    r.d = d;
+    VT_HIP(vt::launch_cosine_rerank_batch(r, nq, c.stream));
+    VT_HIP(vt::launch_batch_select(c.dCandKeys.p, c.dCandPay.p, nq, k1, k2, dOut, dOutCount, c.stream));
+  } else {
+    sa.d = d;
+    sa.k = k2;
+    VT_HIP(vt::launch_scan_batch(sa, kStageBlocks, nq, c.stream));
+    VT_HIP(vt::launch_batch_select(c.dCandKeys.p, c.dCandPay.p, nq, kListsPerQuery * k2, k2, dOut, dOutCount, c.stream));
+  }
   VT_HIP(hipMemcpyAsync(hStatus, c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));  // (pinned: stays asynchronous)
   VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
   VT_HIP(hipStreamSynchronize(c.stream));
@@ -1298,7 +1364,8 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
     // the list's last kept row and beat it on its id -- the single path would keep it, the list never saw it
     // (ADVICE r3).  Every excluded row has 1.0f - raw >= 1.0f - tau (rounding is monotone): the list is the single
     // path's exactly when its last kept rank lies strictly below the rank of tau itself.
-    if ((uint32_t)(hLastKey[i] >> 32) >= orderable_host(1.0f - hTau[i])) continue;
+    // (the other families cut by the order their keys sort in: nothing to check)
+    if (cosine && (uint32_t)(hLastKey[i] >> 32) >= orderable_host(1.0f - hTau[i])) continue;
     const uint32_t got = std::min<uint32_t>(hOutCount[i], k2);
     std::vector<vt::Entry> entries(hOut + (size_t)i * k2, hOut + (size_t)i * k2 + got);
     VT_TRY(make_hits(ix, entries, &out[which[i]]));

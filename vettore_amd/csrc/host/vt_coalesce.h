@@ -124,12 +124,13 @@ int coalesced_quantized(vt_flat *h, const float *query, size_t n, size_t candida
   return vt_host::coalesced_search_t<vt_flat, CoalesceOps>(h, query, n, limit, out, COALESCE_QUANTIZED, candidates);
 }
 
-// funnel_search callers that meet on a cosine handle share the stage-1 sweep of the prefixes
+// funnel_search callers that meet on a cosine / dot / L2 / L1 / Linf handle share the stage-1 sweep of the prefixes
 // (funnel_group): only callers with the same stages and candidates travel together
 int coalesced_funnel(vt_flat *h, const float *query, size_t n, const size_t *stages, size_t nstages, size_t candidates,
                      size_t limit, vt_hits **out) {
   bool plain = limit == 0 || candidates == 0 || candidates > (size_t)vt::kMaxFusedK || n == 0 || nstages == 0 || nstages > 16 ||
-               h->multi() || !coalescing_enabled() || h->shards[0]->metric != VT_COSINE || too_small_for_groups(h);
+               h->multi() || !coalescing_enabled() || too_small_for_groups(h) ||
+               !(h->shards[0]->metric == VT_COSINE || vt::prefix_multi_supports(h->shards[0]->metric));
   for (size_t i = 0; i < nstages && !plain; ++i) plain = stages[i] == 0 || stages[i] > n;  // (its own error, in its own order)
   size_t shape = 0;
   if (!plain) {

@@ -793,7 +793,8 @@ int funnel_batch_direct(vt_flat *h, const float *queries, size_t nq, size_t d, c
     if (h->poisoned) return poisoned_status();
     for (size_t i = 0; i < nq && st == VT_OK; ++i) st = funnel_multi(h, queries + i * d, d, stages, nstages, candidates, limit, &out[i]);
   } else {
-    st = read_single(h, NEED_STRICT_RANKS, limit, [&](Shard *ix, Ctx &c) -> int {
+    // (NEED_NZBITS: as funnel_direct -- the singles of a float hamming / jaccard batch read the bit column)
+    st = read_single(h, NEED_STRICT_RANKS | NEED_NZBITS, std::min<size_t>(candidates, vt::kMaxFusedK), [&](Shard *ix, Ctx &c) -> int {
       for (size_t i = 0; i < nq; ++i) {  // (a second run after an escalation starts clean)
         delete out[i];
         out[i] = nullptr;

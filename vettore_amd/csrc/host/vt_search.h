@@ -393,7 +393,14 @@ int scan_stage_dev(Shard *ix, Ctx &c, uint32_t d, const ResultBlock *src, uint32
   a.part_keys = c.dPartKeys.p;
   a.part_pay = c.dPartPay.p;
   a.status = c.dStatus.p;
+  const bool timed = c.profiling && !src && d < (uint32_t)ix->dim;  // a sweep of every row's prefix: priced like the cosine one
+  if (timed) VT_HIP(hipEventRecord(c.ev0, c.stream));
   VT_HIP(vt::launch_scan(a, blocks, c.stream));
+  if (timed) {
+    VT_HIP(hipEventRecord(c.ev1, c.stream));
+    c.prefix_pending += 1;
+    c.prof.prefix_bytes += (uint64_t)ix->n * d * 4;
+  }
   VT_HIP(vt::launch_select(c.dPartKeys.p, c.dPartPay.p, lists * want, want, 0, 0, status, dst, c.dSelKeys.p, c.dSelPay.p,
                            c.stream));
   return VT_OK;

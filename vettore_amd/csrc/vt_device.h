@@ -65,6 +65,8 @@ struct ScanArgs {
   // min(batch_counts[b], batch_cap) rows and writes list (b * grid.x + blockIdx.x).
   const uint32_t *batch_counts;
   uint32_t batch_cap;
+  uint32_t batch_qstride;       // floats between the queries of a batch (0: padded_dim(d))
+  uint32_t batch_gather_stride; // u32 words between the row lists of a batch (0: batch_cap * gather_stride)
   uint32_t tile_rows;      // 0 / 32 (default), 16 or 8: rows per wave tile, see scan_tile_rows()
   // Key-column mode (limits above kMaxFusedK): instead of keeping the k best, every scanned
   // position i writes key_out[i] (kEmptyKey if the row is excluded) and, if given, pay_out[i].
@@ -453,6 +455,37 @@ struct CosineScanMultiArgs {
 };
 size_t cosine_scan_multi_lds_bytes();
 hipError_t launch_cosine_scan_multi(const CosineScanMultiArgs &a, uint32_t blocks, hipStream_t s);
+
+// K1p: the index's own metric (K1's arithmetic: eight separately rounded products per chunk, the horizontal add in
+// the lane order `order`, acc += chunk sum, the scalar tail -- distances.rs:197-262) over the first d coordinates of
+// EVERY row for up to kPrefixMultiMax queries in ONE sweep of the prefixes: stage 1 of funnel_search on an L2 / dot /
+// L1 / Linf collection (collection.ex:245-260 -> search.rs:56-60) for several callers at once.  Lane r walks row r
+// through a 64 x 64-float LDS panel like K6b; the queries come through the scalar cache.  Modes as K6b's:
+//   dense (`sample` set): -rank_value of every sample_stride-th tile's rows to sample[q * sample_rows + i]
+//     (larger = better: launch_sample_tau's order);
+//   sweep: every (query, row) with -rank_value >= tau[q] is appended to the query's list as (key, {row, raw}),
+//     key as in K1; cand_count[q] counts all of them.
+constexpr uint32_t kPrefixMultiMax = 8;
+struct PrefixMultiArgs {
+  const float *X;
+  size_t stride;
+  const float *Q;            // [kPrefixMultiMax][q_stride] f32 queries (device; unused rows readable), q_stride % 8 == 0
+  uint32_t q_stride;
+  const uint32_t *id_rank;
+  uint32_t n, d, nq;
+  int metric, order;         // metrics of the dot / L2 / L1 / Linf families (not cosine, not the pattern metrics)
+  float *sample;
+  uint32_t sample_stride, sample_rows;
+  const float *tau;
+  uint64_t *cand_keys;       // [nq][cand_cap]
+  Payload *cand_pay;
+  uint32_t *cand_count;      // [nq], zeroed by the caller
+  uint32_t cand_cap;
+  int *status;
+};
+bool prefix_multi_supports(int metric);
+size_t prefix_multi_lds_bytes();
+hipError_t launch_prefix_multi(const PrefixMultiArgs &a, uint32_t blocks, hipStream_t s);
 
 // Diagnostic (vt_device_read_peak): one pass of the bare LDS-DMA read stream over the whole 384-KiB tiles of
 // `buf` (read_peak_bytes(bytes) of it), `blocks` blocks of 512 threads -- one per CU; launch_peak_fill puts

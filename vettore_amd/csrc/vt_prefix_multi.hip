@@ -1,0 +1,213 @@
+// vt_prefix_multi.hip -- K1p: K1's arithmetic over the first d coordinates of every row for up to eight
+// queries per sweep (gfx950).  PrefixMultiArgs in vt_device.h says what it is for: stage 1 of funnel_search on an
+// L2 / dot / L1 / Linf collection (collection.ex:245-260 -> search.rs:56-60 -> distances.rs:42-68) for several
+// callers at once.
+//
+// A prefix is a narrow thing: 64..256 floats of a 768-float row, i.e. 256-B..1-KiB runs at the rows' 3-KiB stride.
+// The walk is K6b's (vt_kernels.hip, cosine_scan_multi_kernel): a wave parks a 64-row x 64-float panel in its own
+// LDS slice -- sixteen 1-KiB loads (4 rows x 256 B each), the next panel's already on their way -- and then lane r
+// walks row r, chunk by chunk.  What differs is the arithmetic, which is K1's to the bit: per 8-float chunk eight
+// separately rounded elements (q*x, (q-x)^2, |q-x|; never an FMA), their horizontal combination in the lane order
+// of wide::f32x8::reduce_add (`order`: the four orders of vt_scan.cuh's chunk_sum, here inside one lane), then
+// acc = acc + chunk sum down the row and the scalar tail one element at a time.  The queries are wave-uniform:
+// eight floats per query and chunk through the scalar cache, used as SGPR operands.
+// Cost: 16 (dot) to 24 (L2) VALU instructions per query and chunk, 8 queries: 1 024..1 536 per 16-KiB panel and wave
+// -- the kernel sits between the VALU and the prefix reads (DESIGN.md 4.6 has the measured rates).
+#include "vt_scan.cuh"
+
+namespace vt {
+
+using namespace dev;
+
+namespace {
+
+constexpr int kPmRows = 64, kPmPanel = 64, kPmStride = 68;  // K6b's panel: 64 rows x 64 floats, rows 272 B apart
+
+template <int OP>
+__device__ __forceinline__ float pm_elem(float q, float x) {
+  return elem<OP>(0, q, x);
+}
+
+// wide::f32x8::reduce_add of one chunk's eight elements e[0..7], all in this lane (vt_scan.cuh chunk_sum: the even
+// lane of a pair holds l0..l3, the odd one l4..l7)
+template <int OP, int ORDER>
+__device__ __forceinline__ float pm_reduce(const float (&e)[8]) {
+  if (ORDER == 1)  // AVX: ((l0+l4)+(l2+l6)) + ((l1+l5)+(l3+l7))
+    return comb<OP>(0, comb<OP>(0, comb<OP>(0, e[0], e[4]), comb<OP>(0, e[2], e[6])),
+                    comb<OP>(0, comb<OP>(0, e[1], e[5]), comb<OP>(0, e[3], e[7])));
+  if (ORDER == 2)  // SEQ: (((l0+l1)+l2)+l3) + (((l4+l5)+l6)+l7)
+    return comb<OP>(0, comb<OP>(0, comb<OP>(0, comb<OP>(0, e[0], e[1]), e[2]), e[3]),
+                    comb<OP>(0, comb<OP>(0, comb<OP>(0, e[4], e[5]), e[6]), e[7]));
+  if (ORDER == 3)  // SSE2: ((l0+l2)+(l1+l3)) + ((l4+l6)+(l5+l7))
+    return comb<OP>(0, comb<OP>(0, comb<OP>(0, e[0], e[2]), comb<OP>(0, e[1], e[3])),
+                    comb<OP>(0, comb<OP>(0, e[4], e[6]), comb<OP>(0, e[5], e[7])));
+  // PAIR: ((l0+l1)+(l2+l3)) + ((l4+l5)+(l6+l7))
+  return comb<OP>(0, comb<OP>(0, comb<OP>(0, e[0], e[1]), comb<OP>(0, e[2], e[3])),
+                  comb<OP>(0, comb<OP>(0, e[4], e[5]), comb<OP>(0, e[6], e[7])));
+}
+
+template <int OP, int ORDER>
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(const PrefixMultiArgs a) {
+  extern __shared__ __align__(16) float pm_lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  typedef const __attribute__((address_space(4))) float *cf_p;
+  cf_p qs = (cf_p)(uintptr_t)a.Q;
+  const uint32_t qst = a.q_stride;
+  float *S = pm_lds + wib * (kPmRows * kPmStride);
+  const bool dense = a.sample != nullptr;
+  const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+  const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wib;
+  const uint32_t ntiles_all = (a.n + kPmRows - 1) / kPmRows;
+  const uint32_t step = dense ? a.sample_stride : 1u;      // dense: every step-th tile
+  const uint32_t ntiles = (ntiles_all + step - 1) / step;   // tiles this launch walks
+  const uint32_t npanel = (a.d + kPmPanel - 1) / kPmPanel;
+  const uint32_t cfull = a.d / 8, tail = a.d % 8;
+  f32x4 v[16];
+  auto issue = [&](uint32_t ti, uint32_t p) {
+    const uint32_t t = ti * step;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      uint32_t r = t * kPmRows + 4 * s + (lane >> 4);
+      r = r < a.n ? r : a.n - 1;
+      v[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.X + (size_t)r * a.stride + p * kPmPanel + (lane & 15) * 4));
+    }
+  };
+  if (wave_global < ntiles) issue(wave_global, 0);
+  for (uint32_t ti = wave_global; ti < ntiles; ti += total_waves) {
+    const uint32_t grow = ti * step * kPmRows + lane;
+    const bool valid_row = grow < a.n;
+    float acc[kPrefixMultiMax];
+#pragma unroll
+    for (uint32_t q = 0; q < kPrefixMultiMax; ++q) acc[q] = 0.0f;
+    for (uint32_t p = 0; p < npanel; ++p) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) *reinterpret_cast<f32x4 *>(S + (4 * s + (lane >> 4)) * kPmStride + (lane & 15) * 4) = v[s];
+      wave_lds_fence();
+      if (p + 1 < npanel) issue(ti, p + 1);
+      else if (ti + total_waves < ntiles) issue(ti + total_waves, 0);
+      const float *Sr = S + lane * kPmStride;
+      const uint32_t c0 = p * (kPmPanel / 8);
+      const uint32_t nfull = cfull > c0 ? (cfull - c0 < (uint32_t)(kPmPanel / 8) ? cfull - c0 : (uint32_t)(kPmPanel / 8)) : 0u;
+      for (uint32_t c = 0; c < nfull; ++c) {
+        const f32x4 xa = *reinterpret_cast<const f32x4 *>(Sr + c * 8);
+        const f32x4 xb = *reinterpret_cast<const f32x4 *>(Sr + c * 8 + 4);
+        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        cf_p qp = qs + (size_t)(c0 + c) * 8;
+        // (all eight slots, straight-line, four queries' floats at a time: the scalar loads of a half go out together
+        // and the 32 SGPRs they fill leave the wave's other scalars in registers; an unused slot reads a readable row)
+#pragma unroll
+        for (uint32_t h = 0; h < kPrefixMultiMax; h += 4) {
+          float w[4][8];
+#pragma unroll
+          for (uint32_t q = 0; q < 4; ++q)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) w[q][l] = qp[(size_t)(h + q) * qst + l];
+#pragma unroll
+          for (uint32_t q = 0; q < 4; ++q) {
+            float e[8];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) e[l] = pm_elem<OP>(w[q][l], x[l]);
+            acc[h + q] = comb<OP>(0, acc[h + q], pm_reduce<OP, ORDER>(e));
+          }
+        }
+      }
+      // the scalar tail: the chunk after the last full one, element by element (distances.rs:212-216 and its siblings)
+      if (tail && cfull >= c0 && cfull < c0 + (uint32_t)(kPmPanel / 8)) {
+        const uint32_t cl = cfull - c0;
+        cf_p qp = qs + (size_t)cfull * 8;
+        for (uint32_t j = 0; j < tail; ++j) {
+          const float xv = Sr[cl * 8 + j];
+#pragma unroll
+          for (uint32_t q = 0; q < kPrefixMultiMax; ++q) acc[q] = comb<OP>(0, acc[q], pm_elem<OP>(qp[(size_t)q * qst + j], xv));
+        }
+      }
+      wave_lds_fence();
+    }
+    // distances.rs:42-68 compute(): value, finiteness, f64 recovery; :113-119 rank_value
+    const uint32_t my_rank = (!dense && valid_row && a.id_rank) ? a.id_rank[grow] : grow;
+    const int metric = a.metric;
+#pragma unroll
+    for (uint32_t q = 0; q < kPrefixMultiMax; ++q) {
+      if (q >= a.nq) break;
+      float raw = acc[q];
+      if (metric == M_NIP) raw = -raw;
+      else if (metric == M_L2) raw = finite_f32(raw) ? __builtin_sqrtf(raw) : raw;
+      bool valid = valid_row;
+      if (valid && !finite_f32(raw)) {
+        float rec;
+        if (recover_overflow(metric, a.Q + (size_t)q * qst, a.X + (size_t)grow * a.stride, a.d, &rec)) {
+          raw = rec;
+        } else {
+          if (!dense) atomicMax(a.status, kErrOverflow);
+          valid = false;
+        }
+      }
+      const float rank = metric == M_IP ? -raw : raw;
+      const float good = -rank;  // larger = better: the order the sample's threshold is taken in
+      if (dense) {
+        const uint32_t i = ti * kPmRows + lane;  // position in the sample
+        if (i < a.sample_rows) a.sample[(size_t)q * a.sample_rows + i] = valid ? good : -INFINITY;
+        continue;
+      }
+      const bool hit = valid && good >= a.tau[q];
+      const uint64_t m = __ballot(hit);
+      if (m) {
+        uint32_t base = 0;
+        if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&a.cand_count[q], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(m), kWave);
+        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (hit && pos < a.cand_cap) {
+          a.cand_keys[(size_t)q * a.cand_cap + pos] = ((uint64_t)orderable(rank) << 32) | my_rank;
+          Payload pv;
+          pv.row = grow;
+          pv.raw = raw;
+          a.cand_pay[(size_t)q * a.cand_cap + pos] = pv;
+        }
+      }
+    }
+  }
+}
+
+template <int OP, int ORDER>
+hipError_t launch_pm(const PrefixMultiArgs &a, uint32_t blocks, size_t lds, hipStream_t s) {
+  hipError_t e = allow_lds(prefix_multi_kernel<OP, ORDER>, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((prefix_multi_kernel<OP, ORDER>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+  return hipGetLastError();
+}
+
+template <int OP>
+hipError_t launch_pm_op(const PrefixMultiArgs &a, uint32_t blocks, size_t lds, hipStream_t s) {
+  switch (a.order) {
+    case 1: return launch_pm<OP, 1>(a, blocks, lds, s);
+    case 2: return launch_pm<OP, 2>(a, blocks, lds, s);
+    case 3: return launch_pm<OP, 3>(a, blocks, lds, s);
+    default: return launch_pm<OP, 0>(a, blocks, lds, s);
+  }
+}
+
+}  // namespace
+
+bool prefix_multi_supports(int metric) {
+  return metric == M_L2 || metric == M_L2SQ || metric == M_IP || metric == M_NIP || metric == M_L1 || metric == M_LINF;
+}
+
+size_t prefix_multi_lds_bytes() { return (size_t)kWavesPerBlock * kPmRows * kPmStride * sizeof(float); }
+
+hipError_t launch_prefix_multi(const PrefixMultiArgs &a, uint32_t blocks, hipStream_t s) {
+  if (!prefix_multi_supports(a.metric) || !a.Q || ((uintptr_t)a.Q & 31) || a.q_stride % 8 != 0 || a.q_stride < a.d || a.nq == 0 ||
+      a.nq > kPrefixMultiMax || a.n == 0 || a.d == 0 || a.stride < padded_dim(a.d) || a.order < 0 || a.order > 3)
+    return hipErrorInvalidValue;
+  if (a.sample ? (a.sample_stride == 0 || a.sample_rows == 0) : (!a.tau || !a.cand_keys || !a.cand_pay || !a.cand_count || !a.status))
+    return hipErrorInvalidValue;
+  const size_t lds = prefix_multi_lds_bytes();
+  switch (metric_op(a.metric)) {
+    case OP_DOT: return launch_pm_op<OP_DOT>(a, blocks, lds, s);
+    case OP_L2: return launch_pm_op<OP_L2>(a, blocks, lds, s);
+    case OP_L1: return launch_pm_op<OP_L1>(a, blocks, lds, s);
+    default: return launch_pm_op<OP_LINF>(a, blocks, lds, s);
+  }
+}
+
+}  // namespace vt

@@ -233,8 +233,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
     const uint32_t b = blockIdx.y;
     const uint32_t c = a.batch_counts[b];
     nrows = c < a.batch_cap ? c : a.batch_cap;
-    qsrc += (size_t)b * p.ld;
-    gather += (size_t)b * a.batch_cap * a.gather_stride;
+    qsrc += (size_t)b * (a.batch_qstride ? a.batch_qstride : p.ld);
+    gather += (size_t)b * (a.batch_gather_stride ? a.batch_gather_stride : a.batch_cap * a.gather_stride);
     list_base = b * gridDim.x;
   }
   if (!QGLOBAL)
