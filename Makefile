@@ -34,9 +34,11 @@ $(LIBDIR)/vt_batch_bf16.o: $(CSRC)/vt_batch_bf16.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_batch_bf16.resources
 	python3 tools/check_scratch.py $(LIBDIR)/vt_batch_bf16.resources bf16_scores_kernel
+# (-fno-slp-vectorize: K1p packs two ELEMENTS of a query per instruction by hand; the SLP pass re-packs two QUERIES
+# instead, with a register move per operand pair -- 22-26 % more VALU cycles per chunk, measured)
 $(LIBDIR)/vt_prefix_multi.o: $(CSRC)/vt_prefix_multi.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_prefix_multi.resources
+	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_prefix_multi.resources
 	python3 tools/check_scratch.py $(LIBDIR)/vt_prefix_multi.resources prefix_multi_kernel
 $(LIBDIR)/vt_batch_shadow.o: $(CSRC)/vt_batch_shadow.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)

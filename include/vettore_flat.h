@@ -395,6 +395,7 @@ typedef struct vt_profile {
   uint64_t shadow_builds;            /* whole-image builds of the bf16 shadow */
   double shadow_build_ms;
   uint64_t shadow_patched_rows;      /* rows re-rounded in place after mutations */
+  uint64_t sweep_queries;            /* plain searches of a batch served by K1p sweeps (their sweeps count as scan_launches) */
 } vt_profile;
 int vt_flat_set_profiling(vt_flat *index, int enabled);
 int vt_flat_get_profile(vt_flat *index, vt_profile *out, int reset);

@@ -108,3 +108,29 @@ def test_multi_query_scan_at_config_shape(nifs, oracle_mod):
         assert bits(got[i]) == bits(unwrap(nifs.flat_search(g.ref, qs[i], 10))), i
     for i in range(4):
         assert got[i][0] == (b"doc-%d" % (i + 1), 0.0)
+
+
+@pytest.mark.parametrize("metric,d,n,limit", [(5, 100, 140_000, 10), (0, 200, 70_000, 10), (6, 320, 52_000, 7), (3, 72, 260_000, 20),
+                                              (5, 256, 70_000, 100), (1, 768, 22_000, 256), (4, 64, 300_000, 33)])
+def test_batches_as_k1p_sweeps_equal_single_queries(nifs, oracle_mod, metric, d, n, limit):
+    """flat_search_batch on rows off K1m's 256-float panel grid, or with lists longer than K1m's wave buffers hold (32):
+    groups of eight as K1p sweeps -- prefix_multi_kernel over the WHOLE row, `limit` candidates (host/vt_batch_staged.h
+    sweep_group_applies).  Every query's hits are its own flat_search's, bit for bit, and the oracle's."""
+    x, ids = make_corpus(n, d, 9100 + metric + d, False, oracle_mod, tie_block=60)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    nifs.flat_set_profiling(g.ref, True)
+    rng = np.random.default_rng(metric * 100 + d)
+    packed = oracle_mod.pack_ids(ids)
+    for nq in (2, 8, 11):
+        qs = rng.uniform(-1, 1, size=(nq, d)).astype(np.float32)
+        qs[0] = x[n // 2]                  # sits on the block of identical rows
+        nifs.flat_get_profile(g.ref, reset=True)
+        got = unwrap(nifs.flat_search_batch(g.ref, qs, limit))
+        prof = nifs.flat_get_profile(g.ref, reset=True)
+        assert prof["sweep_queries"] >= nq - 1 - nq // 8, (nq, prof)     # (a lone last query goes alone; a threshold may miss)
+        for i in range(nq):
+            assert bits(got[i]) == bits(unwrap(nifs.flat_search(g.ref, qs[i], limit))), (metric, d, nq, i)
+        for i in (0, nq - 1):
+            want = oracle_mod.matrix_search(metric, x, packed, qs[i], limit)
+            assert bits(got[i]) == bits(want), (metric, d, nq, i)

@@ -53,7 +53,7 @@ class Profile(C.Structure):
         ("hybrid_device_chains", C.c_uint64),
         ("prefix_queries", C.c_uint64),
         ("nominate_shadow_launches", C.c_uint64), ("shadow_builds", C.c_uint64), ("shadow_build_ms", C.c_double),
-        ("shadow_patched_rows", C.c_uint64),
+        ("shadow_patched_rows", C.c_uint64), ("sweep_queries", C.c_uint64),
     ]
 
 

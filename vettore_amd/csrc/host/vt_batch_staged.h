@@ -482,6 +482,25 @@ bool batch_uses_mfma(const Shard *ix, size_t nq, size_t limit) {
   return use_mfma;
 }
 
+bool funnel_group_applies(const Shard *ix, const size_t *stages, size_t nstages, size_t candidates, size_t limit);
+int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size_t> &which, const size_t *stages, size_t nstages,
+                 size_t candidates, size_t limit, vt_hits **out, std::vector<char> &done, bool as_scan = false);
+
+// A batch of plain searches as K1p sweeps (funnel_group with the whole row as its one stage and `limit` candidates:
+// the sweep's arithmetic over all d coordinates is K1's, the lists' `limit` best are flat_search's hits).  Measured
+// beside K1m (tools/prefix_multi_probe.py, 8 queries per sweep, N x d x 4 = 7.7 GB): 4.3 / 5.1 / 5.8 / 5.9 TB/s at
+// d = 64 / 128 / 320 / 640 where K1m walks 2.5 / 3.4 / 4.2 / 4.5 -- rows that are not whole 256-float panels -- and
+// level with it where they are (d = 768: 5.21 against 5.24-5.37 ms); and it takes lists of up to 256, K1m's wave
+// buffers 32.  So: rows off K1m's panel grid, or lists K1m cannot hold; from 64 MB of rows (six launches and a
+// sample pass instead of two launches).
+bool sweep_group_applies(const Shard *ix, size_t limit) {
+  if (!vt::prefix_multi_supports(ix->metric) || std::getenv("VT_NO_SWEEP_GROUPS")) return false;
+  const size_t stage = (size_t)ix->dim;
+  if (!funnel_group_applies(ix, &stage, 1, limit, limit)) return false;
+  if ((double)ix->n * ix->ld * 4.0 < 64e6) return false;
+  return ix->ld % 256 != 0 || !multi_scan_applies(ix, limit);
+}
+
 // Rank column strictly current, norms current when batch_uses_mfma (shard_prepare).
 int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
   // every query is validated like flat_search would (flat.rs:97-101), in order
@@ -557,6 +576,26 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
   const bool by_pattern = pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit) &&
                           (left.size() < 2 || !multi_scan_applies(ix, limit) ||
                            (double)left.size() * pattern_s < multi_scan_seconds(ix, left.size()));
+  if (!by_pattern && left.size() >= 2 && sweep_group_applies(ix, limit)) {
+    const size_t stage = (size_t)ix->dim;
+    for (size_t g0 = 0; g0 + 2 <= left.size(); g0 += vt::kPrefixMultiMax) {
+      const std::vector<size_t> which(left.begin() + g0, left.begin() + std::min(left.size(), g0 + vt::kPrefixMultiMax));
+      const int st = funnel_group(ix, c, queries, which, &stage, 1, limit, limit, out, done, true);
+      if (st == kRetryInternal) {  // an overflow somewhere: these go on below, each reporting its own
+        for (size_t i : which) {
+          delete out[i];
+          out[i] = nullptr;
+          done[i] = 0;
+        }
+      } else if (st != VT_OK) {
+        return st;
+      }
+    }
+    std::vector<size_t> rest;
+    for (size_t i : left)
+      if (!done[i]) rest.push_back(i);
+    left.swap(rest);
+  }
   if (!by_pattern && left.size() >= 2 && multi_scan_applies(ix, limit) &&
       (multi_scan_seconds(ix, left.size()) < (double)left.size() * scan_seconds((double)ix->n * ix->ld * 4.0) ||
        std::getenv("VT_FORCE_MULTI_SCAN"))) {  // (tests force the sweep on corpora of a few thousand rows)
@@ -1164,7 +1203,7 @@ bool funnel_group_applies(const Shard *ix, const size_t *stages, size_t nstages,
 }
 
 int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size_t> &which, const size_t *stages,
-                 size_t nstages, size_t candidates, size_t limit, vt_hits **out, std::vector<char> &done) {
+                 size_t nstages, size_t candidates, size_t limit, vt_hits **out, std::vector<char> &done, bool as_scan) {
   const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
   const uint32_t nq = (uint32_t)which.size();
   const uint32_t d1 = (uint32_t)stages[0], ldq = vt::padded_dim(d1);
@@ -1346,10 +1385,18 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   if (c.profiling) {
     float ms = 0.f;
     VT_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
-    c.prof.prefix_launches += 1;
-    c.prof.prefix_ms += ms;
-    c.prof.prefix_bytes += (uint64_t)n * d1 * 4;
-    c.prof.prefix_queries += nq;
+    if (as_scan) {  // (a batch of plain searches: the sweep is its scan)
+      c.prof.scan_launches += 1;
+      c.prof.scan_ms += ms;
+      c.prof.scan_rows += n;
+      c.prof.scan_bytes += (uint64_t)n * d1 * 4;
+      c.prof.sweep_queries += nq;
+    } else {
+      c.prof.prefix_launches += 1;
+      c.prof.prefix_ms += ms;
+      c.prof.prefix_bytes += (uint64_t)n * d1 * 4;
+      c.prof.prefix_queries += nq;
+    }
   }
   if (*hStatus != 0) return kRetryInternal;  // an overflow somewhere: one by one, each reports its own
   auto orderable_host = [](float f) {  // f32::total_cmp as an order-preserving u32 (the device's `orderable`)

@@ -949,6 +949,7 @@ int vt_flat_get_profile(vt_flat *h, vt_profile *out, int reset) {
       t.shadow_builds += p.shadow_builds;
       t.shadow_build_ms += p.shadow_build_ms;
       t.shadow_patched_rows += p.shadow_patched_rows;
+      t.sweep_queries += p.sweep_queries;
       if (reset) c.prof = vt_profile{};
     });
   if (reset) h->xprof = vt_profile{};

@@ -46,6 +46,52 @@ __device__ __forceinline__ float pm_reduce(const float (&e)[8]) {
                   comb<OP>(0, comb<OP>(0, e[4], e[5]), comb<OP>(0, e[6], e[7])));
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One chunk of one query: acc' = acc (+|max) reduce_add(elements).  x / q as four pairs (l0,l1) (l2,l3) (l4,l5) (l6,l7) --
+// the pairs a ds_read_b128 / s_load_dwordx8 deliver.  The SSE2 and AVX orders add pairs to pairs: the elements and the
+// first levels of the tree are packed instructions over two ELEMENTS of one query (v_pk_mul_f32 / v_pk_add_f32; left to
+// itself the compiler packs over two QUERIES instead and pays for it with a register move per operand pair).
+template <int OP, int ORDER>
+__device__ __forceinline__ float pm_chunk(float acc, const f32x2 (&x)[4], const f32x2 (&q)[4]) {
+  if (OP == OP_L1 && (ORDER == 3 || ORDER == 1)) {
+    // |q - x|: packed differences; the absolute values are operand modifiers of the (plain) adds that follow
+    f32x2 t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = q[i] - x[i];
+    auto ab = [](float v) { return __builtin_fabsf(v); };
+    if (ORDER == 3)
+      return acc + (((ab(t[0].x) + ab(t[1].x)) + (ab(t[0].y) + ab(t[1].y))) + ((ab(t[2].x) + ab(t[3].x)) + (ab(t[2].y) + ab(t[3].y))));
+    return acc + (((ab(t[0].x) + ab(t[2].x)) + (ab(t[1].x) + ab(t[3].x))) + ((ab(t[0].y) + ab(t[2].y)) + (ab(t[1].y) + ab(t[3].y))));
+  }
+  if ((OP == OP_DOT || OP == OP_L2) && (ORDER == 3 || ORDER == 1)) {
+    f32x2 e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (OP == OP_DOT) {
+        e[i] = q[i] * x[i];
+      } else {
+        const f32x2 t = q[i] - x[i];
+        e[i] = t * t;
+      }
+    }
+    if (ORDER == 3) {  // ((l0+l2)+(l1+l3)) + ((l4+l6)+(l5+l7))
+      const f32x2 a = e[0] + e[1], b = e[2] + e[3];
+      return acc + ((a.x + a.y) + (b.x + b.y));
+    }
+    // AVX: ((l0+l4)+(l2+l6)) + ((l1+l5)+(l3+l7))
+    const f32x2 t = (e[0] + e[2]) + (e[1] + e[3]);
+    return acc + (t.x + t.y);
+  }
+  float e[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    e[2 * i] = pm_elem<OP>(q[i].x, x[i].x);
+    e[2 * i + 1] = pm_elem<OP>(q[i].y, x[i].y);
+  }
+  return comb<OP>(0, acc, pm_reduce<OP, ORDER>(e));
+}
+
 template <int OP, int ORDER>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(const PrefixMultiArgs a) {
   extern __shared__ __align__(16) float pm_lds[];
@@ -92,24 +138,19 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
       for (uint32_t c = 0; c < nfull; ++c) {
         const f32x4 xa = *reinterpret_cast<const f32x4 *>(Sr + c * 8);
         const f32x4 xb = *reinterpret_cast<const f32x4 *>(Sr + c * 8 + 4);
-        const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        const f32x2 x[4] = {f32x2{xa.x, xa.y}, f32x2{xa.z, xa.w}, f32x2{xb.x, xb.y}, f32x2{xb.z, xb.w}};
         cf_p qp = qs + (size_t)(c0 + c) * 8;
-        // (all eight slots, straight-line, four queries' floats at a time: the scalar loads of a half go out together
-        // and the 32 SGPRs they fill leave the wave's other scalars in registers; an unused slot reads a readable row)
+        // (all eight slots, straight-line, four queries' floats at a time: the scalar loads of a half go out together;
+        // an unused slot reads a readable row)
 #pragma unroll
         for (uint32_t h = 0; h < kPrefixMultiMax; h += 4) {
-          float w[4][8];
+          f32x2 w[4][4];
 #pragma unroll
           for (uint32_t q = 0; q < 4; ++q)
 #pragma unroll
-            for (int l = 0; l < 8; ++l) w[q][l] = qp[(size_t)(h + q) * qst + l];
+            for (int l = 0; l < 4; ++l) w[q][l] = f32x2{qp[(size_t)(h + q) * qst + 2 * l], qp[(size_t)(h + q) * qst + 2 * l + 1]};
 #pragma unroll
-          for (uint32_t q = 0; q < 4; ++q) {
-            float e[8];
-#pragma unroll
-            for (int l = 0; l < 8; ++l) e[l] = pm_elem<OP>(w[q][l], x[l]);
-            acc[h + q] = comb<OP>(0, acc[h + q], pm_reduce<OP, ORDER>(e));
-          }
+          for (uint32_t q = 0; q < 4; ++q) acc[h + q] = pm_chunk<OP, ORDER>(acc[h + q], x, w[q]);
         }
       }
       // the scalar tail: the chunk after the last full one, element by element (distances.rs:212-216 and its siblings)
