@@ -110,7 +110,7 @@ def test_multi_query_scan_at_config_shape(nifs, oracle_mod):
         assert got[i][0] == (b"doc-%d" % (i + 1), 0.0)
 
 
-@pytest.mark.parametrize("metric,d,n,limit", [(5, 100, 140_000, 10), (0, 200, 70_000, 10), (6, 320, 52_000, 7), (3, 72, 260_000, 20),
+@pytest.mark.parametrize("metric,d,n,limit", [(5, 100, 140_000, 10), (0, 300, 52_000, 10), (6, 320, 52_000, 7), (3, 72, 260_000, 20),
                                               (5, 256, 70_000, 100), (1, 768, 22_000, 256), (4, 64, 300_000, 33)])
 def test_batches_as_k1p_sweeps_equal_single_queries(nifs, oracle_mod, metric, d, n, limit):
     """flat_search_batch on rows off K1m's 256-float panel grid, or with lists longer than K1m's wave buffers hold (32):
