@@ -37,6 +37,11 @@ export ROWS=10000000 NQS=8 METRICS=5
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/multi -o p -- python3 $R/tools/multi_probe.py > $OUT/multi.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/multi_fetch -o p -- python3 $R/tools/multi_probe.py > $OUT/multi_fetch.log 2>&1
 unset ROWS NQS METRICS
+# K1p: eight L2 funnel searches per sweep of the 128-float prefixes (N=10M, d=768) -- stats pass, FETCH pass
+export METRICS=0 PREFIXES=128 K1M=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prefix_multi -o p -- python3 $R/tools/prefix_multi_probe.py > $OUT/prefix_multi.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prefix_multi_fetch -o p -- python3 $R/tools/prefix_multi_probe.py > $OUT/prefix_multi_fetch.log 2>&1
+unset METRICS PREFIXES K1M
 cd $R
 python3 - <<'PY'
 import csv, glob, json, os
@@ -49,7 +54,7 @@ def trim(src, dst):
         for r in rows:
             r[0] = r[0][:140]
             w.writerow(r)
-for name in ('single', 'default', 'batch', 'batch_bf16', 'batch_k2b', 'quantized', 'funnel', 'multi', 'pattern_hamming'):
+for name in ('single', 'default', 'batch', 'batch_bf16', 'batch_k2b', 'quantized', 'funnel', 'multi', 'pattern_hamming', 'prefix_multi'):
     trim('%s/%s/p_kernel_stats.csv' % (out, name), '%s/%s_%s_kernel_stats.csv' % (out, RND, name))
 def per_launch(path, kernel_substr, counter):
     vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
@@ -69,6 +74,9 @@ keep(out + '/single_write/p_counter_collection.csv', out + '/%s_single_pmc_write
 keep(out + '/quantized_fetch/p_counter_collection.csv', out + '/%s_quantized_pmc_fetch.csv' % RND, 'hamming_dist_kernel')
 keep(out + '/multi_fetch/p_counter_collection.csv', out + '/%s_multi_pmc_fetch.csv' % RND, 'scan_multi_kernel')
 mf, mn = per_launch(out + '/multi_fetch/p_counter_collection.csv', 'scan_multi_kernel', 'FETCH_SIZE')
+keep(out + '/prefix_multi_fetch/p_counter_collection.csv', out + '/%s_prefix_multi_pmc_fetch.csv' % RND, 'prefix_multi_kernel')
+pf, pn = per_launch(out + '/prefix_multi_fetch/p_counter_collection.csv', 'prefix_multi_kernel', 'FETCH_SIZE')
+print("K1p FETCH_SIZE KiB per launch (sample passes and sweeps mixed)", pf, "launches", pn)
 print("K1m FETCH_SIZE KiB per sweep", mf, "x2 bytes", 2 * mf * 1024, "launches", mn)
 fetch, n1 = per_launch(out + '/single_fetch/p_counter_collection.csv', 'scan_topk_kernel', 'FETCH_SIZE')
 write, n2 = per_launch(out + '/single_write/p_counter_collection.csv', 'scan_topk_kernel', 'WRITE_SIZE')
@@ -110,8 +118,14 @@ for name in ('single', 'batch', 'batch_bf16', 'batch_k2b', 'quantized', 'funnel'
             print('   ', r['Name'][:70], r['Calls'], r['AverageNs'])
 PY
 # counters of the two matrix-core passes (MFMA-busy and friends; VERDICT r3 missing #5): K2 on the FP32 pipe, K2s on the bf16 one
-bash $R/tools/pmc_kernel.sh "mfma_scores_kernel<8" $OUT/${RND}_k2_pmc.txt -- --mode batch --nominate f32 --steps 2 --warmup 1 --no-cpu
+bash $R/tools/pmc_kernel.sh "mfma_scores_kernel<8, false>" $OUT/${RND}_k2_pmc.txt -- --mode batch --nominate f32 --steps 2 --warmup 1 --no-cpu
 bash $R/tools/pmc_kernel.sh "shadow_scores_kernel<false, 8" $OUT/${RND}_k2s_pmc.txt -- --mode batch --nominate bf16 --steps 4 --warmup 1 --no-cpu
+# probes without the profiler: K1p beside K1m and the single prefix scan; pattern funnels from the bit column and from the rows
+cd /tmp
+python3 $R/tools/prefix_multi_probe.py 2>/dev/null | grep "^{" > $OUT/${RND}_prefix_multi_probe.jsonl
+ROWS=5000000 DIM=384 PREFIXES=128,384 python3 $R/tools/prefix_multi_probe.py 2>/dev/null | grep "^{" >> $OUT/${RND}_prefix_multi_probe.jsonl
+python3 $R/tools/pattern_funnel_probe.py 2>/dev/null | grep "^{" > $OUT/${RND}_pattern_funnel_probe.jsonl
+cd $R
 # the 8-GPU operating points priced on one GPU (a shard of 10 M / 8 and of 40 M / 8 rows through worker + RCCL exchange + merge)
 cd /tmp
 python3 $R/bench.py --gpus 1 --exchange rccl --rows 1250000 --no-cpu > $OUT/${RND}_shard_10m_of_8.json 2> $OUT/shard_a.log
