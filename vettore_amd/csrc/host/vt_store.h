@@ -463,24 +463,30 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   double t_ids = 0.0, t_ranked = 0.0;
   bool ranked_here = false;
   std::thread idt([&] {
+    // (the ids' hashes change nothing in the index: they are formed on a few threads while the check still runs)
+    std::vector<uint64_t> hashes;
+    const int hst = no_throw([&]() -> int {
+      hashes.resize(count);
+      parallel_for(count, 1u << 16, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) hashes[i] = vt_host::hash_id(ids + id_off[i], id_off[i + 1] - id_off[i]);
+      }, 8u);
+      return VT_OK;
+    });
     while (checked.load() == 0) std::this_thread::yield();
     if (checked.load() != 1) return;
+    if (hst != VT_OK) {
+      id_status = hst;
+      id_error = g_last_error;
+      return;
+    }
     *began = true;
     id_status = no_throw([&]() -> int {
-      constexpr size_t kAhead = 8;
-      uint64_t ring[kAhead];
-      for (size_t i = 0; i < std::min(count, kAhead); ++i) {
-        ring[i] = vt_host::hash_id(ids + id_off[i], id_off[i + 1] - id_off[i]);
-        ix->row_of.prefetch(ring[i]);
-      }
+      constexpr size_t kAhead = 16;
+      for (size_t i = 0; i < std::min(count, kAhead); ++i) ix->row_of.prefetch(hashes[i]);
       for (size_t i = 0; i < count; ++i) {
-        const uint64_t hash = ring[i % kAhead];
-        if (i + kAhead < count) {
-          ring[i % kAhead] = vt_host::hash_id(ids + id_off[i + kAhead], id_off[i + kAhead + 1] - id_off[i + kAhead]);
-          ix->row_of.prefetch(ring[i % kAhead]);
-        }
+        if (i + kAhead < count) ix->row_of.prefetch(hashes[i + kAhead]);
         bool is_new = false;
-        target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new, hash);
+        target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new, hashes[i]);
         if (!is_new || target[i] != n_before + i) in_order = false;
       }
       t_ids = since();
@@ -511,15 +517,27 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   int copy_status = VT_OK;
   {
     const size_t row_bytes = (size_t)ld * sizeof(float);
-    const size_t stage_rows = std::max<size_t>(1, std::min<size_t>(count, (256u << 20) / row_bytes));
-    copy_status = c.hStage.ensure(2 * stage_rows * row_bytes);
-    hipEvent_t done[2] = {c.ev2, c.ev3};
-    bool used[2] = {false, false};
+    // Four pinned quarters of 128 MiB, their DMAs alternating between two streams: two copies are in flight while a
+    // third quarter is being filled (one stream = one SDMA queue: 41 GB/s of the link's 64; VT_INGEST_STREAMS=1: A/B)
+    static const int kStreams = [] {
+      const char *e = std::getenv("VT_INGEST_STREAMS");
+      return e && e[0] == '1' ? 1 : 2;
+    }();
+    constexpr int kQuarters = 4;
+    const size_t stage_rows = std::max<size_t>(1, std::min<size_t>(count, (128u << 20) / row_bytes));
+    copy_status = c.hStage.ensure(kQuarters * stage_rows * row_bytes);
+    hipStream_t second = nullptr;
+    hipEvent_t done[kQuarters] = {};
+    for (int q = 0; q < kQuarters && copy_status == VT_OK; ++q)
+      if (hipEventCreateWithFlags(&done[q], hipEventDisableTiming) != hipSuccess) copy_status = fail(VT_ERR_DEVICE, "hipEventCreate (staging)");
+    if (copy_status == VT_OK && kStreams == 2 && hipStreamCreateWithFlags(&second, hipStreamNonBlocking) != hipSuccess)
+      copy_status = fail(VT_ERR_DEVICE, "hipStreamCreate (staging)");
+    bool used[kQuarters] = {};
     size_t i = 0;
-    for (int half = 0; i < count && copy_status == VT_OK && checked.load() != 2; half ^= 1) {
-      float *stage = reinterpret_cast<float *>(c.hStage.p) + (size_t)half * stage_rows * ld;
+    for (int q = 0; i < count && copy_status == VT_OK && checked.load() != 2; q = (q + 1) % kQuarters) {
+      float *stage = reinterpret_cast<float *>(c.hStage.p) + (size_t)q * stage_rows * ld;
       const size_t chunk = std::min(stage_rows, count - i);
-      if (used[half] && hipEventSynchronize(done[half]) != hipSuccess) copy_status = fail(VT_ERR_DEVICE, "hipEventSynchronize (staging half)");
+      if (used[q] && hipEventSynchronize(done[q]) != hipSuccess) copy_status = fail(VT_ERR_DEVICE, "hipEventSynchronize (staging quarter)");
       parallel_for(chunk, 2048, [&](size_t lo, size_t hi) {
         for (size_t j = lo; j < hi; ++j) {
           float *dst = stage + j * ld;
@@ -527,15 +545,22 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
           for (size_t t = d; t < ld; ++t) dst[t] = 0.0f;
         }
       });
-      // (the chunks behind this half are mapped by now, or will be in a moment)
+      // (the chunks behind this quarter are mapped by now, or will be in a moment)
       while (progressive && mapped_bytes.load() < (size_t)(n_before + i + chunk) * row_bytes && map_status.load() == VT_OK) std::this_thread::yield();
       if (map_status.load() != VT_OK) copy_status = fail(map_status.load(), map_error);
-      if (copy_status == VT_OK && hipMemcpyAsync(ix->dX + (size_t)(n_before + i) * ld, stage, chunk * row_bytes, hipMemcpyHostToDevice, c.stream) != hipSuccess)
+      hipStream_t lane = (second && (q & 1)) ? second : c.stream;
+      if (copy_status == VT_OK && hipMemcpyAsync(ix->dX + (size_t)(n_before + i) * ld, stage, chunk * row_bytes, hipMemcpyHostToDevice, lane) != hipSuccess)
         copy_status = fail(VT_ERR_DEVICE, "hipMemcpyAsync (rows to the device)");
-      if (copy_status == VT_OK && hipEventRecord(done[half], c.stream) != hipSuccess) copy_status = fail(VT_ERR_DEVICE, "hipEventRecord");
-      used[half] = true;
+      if (copy_status == VT_OK && hipEventRecord(done[q], lane) != hipSuccess) copy_status = fail(VT_ERR_DEVICE, "hipEventRecord");
+      used[q] = true;
       i += chunk;
     }
+    if (second) {
+      if (hipStreamSynchronize(second) != hipSuccess && copy_status == VT_OK) copy_status = fail(VT_ERR_DEVICE, "hipStreamSynchronize (staging)");
+      (void)hipStreamDestroy(second);
+    }
+    for (int q = 0; q < kQuarters; ++q)
+      if (done[q]) (void)hipEventDestroy(done[q]);
     if (copy_status != VT_OK) (void)hipGetLastError();
   }
   const double t_copied = since();
