@@ -1536,17 +1536,20 @@ def test_funnel_batches_of_the_k1_families_share_the_prefix_sweep(nifs, oracle_m
             assert [bits(h) for h in unwrap(got)] == [bits(unwrap(r)) for r in singles]
 
 
-def test_concurrent_funnel_callers_share_sweeps(nifs, oracle_mod, monkeypatch):
-    """funnel_search callers that meet on one cosine handle travel in groups -- only those with the
-    same stages and candidates together; every answer equals the call made alone."""
+@pytest.mark.parametrize("metric", [2, 0, 5])
+def test_concurrent_funnel_callers_share_sweeps(nifs, oracle_mod, monkeypatch, metric):
+    """funnel_search callers that meet on one handle (cosine: K6bm; L2 / manhattan: K1p) travel in groups -- only
+    those with the same stages and candidates together; every answer equals the call made alone."""
     import threading
     monkeypatch.setenv("VT_COALESCE_SLOTS", "1")
     n, d = 40_000, 128
-    x, ids = make_corpus(n, d, 4600, True, oracle_mod)
-    g = GpuIndex(nifs, 2)
+    x, ids = make_corpus(n, d, 4600 + metric, metric == 2, oracle_mod)
+    g = GpuIndex(nifs, metric)
     unwrap(nifs.flat_load_matrix(g.ref, ids, x))
     rng = np.random.default_rng(13)
-    qs = np.stack([oracle_mod.normalize_l2(q) for q in rng.uniform(-1, 1, (32, d)).astype(np.float32)])
+    qs = rng.uniform(-1, 1, (32, d)).astype(np.float32)
+    if metric == 2:
+        qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
     shapes = [([32], 100), ([16, 64], 100), ([32], 50)]
     alone = [[bits(unwrap(nifs.flat_funnel_search(g.ref, q, st, cand, 10))) for q in qs] for st, cand in shapes]
     plain = [bits(unwrap(nifs.flat_search(g.ref, q, 10))) for q in qs]
@@ -1573,6 +1576,7 @@ def test_concurrent_funnel_callers_share_sweeps(nifs, oracle_mod, monkeypatch):
         th.join()
     b1 = nifs.flat_coalesce_stats(g.ref)
     assert not wrong, wrong[:5]
+    assert b1[1] - b0[1] > 0, "no caller ever travelled in a batch"
     print("coalesced: %d batches, %d calls in batches" % (b1[0] - b0[0], b1[1] - b0[1]))
 
 

@@ -497,6 +497,7 @@ bool sweep_group_applies(const Shard *ix, size_t limit) {
   if (!vt::prefix_multi_supports(ix->metric) || std::getenv("VT_NO_SWEEP_GROUPS")) return false;
   const size_t stage = (size_t)ix->dim;
   if (!funnel_group_applies(ix, &stage, 1, limit, limit)) return false;
+  if (std::getenv("VT_FORCE_SWEEP_GROUPS")) return true;  // (tests and soaks on corpora of a few MB)
   if ((double)ix->n * ix->ld * 4.0 < 64e6) return false;
   return ix->ld % 256 != 0 || !multi_scan_applies(ix, limit);
 }
