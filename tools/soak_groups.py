@@ -26,6 +26,9 @@ def ok(res):
     return res[1]
 
 
+COUNTS = {"funnel_batches": 0, "plain_batches": 0, "queries": 0, "oracle_checks": 0, "grouped_queries": 0}
+
+
 def run(seed, metric):
     rng = np.random.default_rng(seed)
     n = int(rng.integers(17_000, 40_000))
@@ -42,6 +45,7 @@ def run(seed, metric):
     ids = [b"doc-%d" % (i + 1) for i in range(n)]
     ref = nifs._flat_new(metric)
     ok(nifs.flat_load_matrix(ref, ids, x))
+    nifs.flat_set_profiling(ref, True)
     rows = dict(zip(ids, x))
     # a few mutations through the ordinary entry points (derived columns get patched, ranks go lazy)
     for _ in range(int(rng.integers(0, 6))):
@@ -69,11 +73,14 @@ def run(seed, metric):
     for step in range(6):
         nq = int(rng.integers(2, 18))
         qs = np.stack([query() for _ in range(nq)])
+        COUNTS["queries"] += nq
+        COUNTS["oracle_checks"] += 2
         try:
             if step % 2 == 0:
                 stages = sorted(int(p) for p in rng.integers(1, d + 1, size=int(rng.integers(1, 3))))
                 cand, k = int(rng.integers(1, 257)), int(rng.integers(1, 40))
                 got = ok(nifs.flat_funnel_search_batch(ref, qs, stages, cand, k))
+                COUNTS["funnel_batches"] += 1
                 for i in range(nq):
                     assert bits(got[i]) == bits(ok(nifs.flat_funnel_search(ref, qs[i], stages, cand, k))), ("funnel batch vs single", stages, cand, k, i)
                 for i in (0, nq - 1):
@@ -84,6 +91,7 @@ def run(seed, metric):
             else:
                 k = int(rng.integers(1, 257))
                 got = ok(nifs.flat_search_batch(ref, qs, k))
+                COUNTS["plain_batches"] += 1
                 for i in range(nq):
                     assert bits(got[i]) == bits(ok(nifs.flat_search(ref, qs[i], k))), ("batch vs single", k, i)
                 for i in (0, nq - 1):
@@ -91,6 +99,8 @@ def run(seed, metric):
         except AssertionError as e:
             print("MISMATCH seed", seed, "metric", metric, "n", n, "d", d, "step", step, e.args, flush=True)
             return False
+    p = nifs.flat_get_profile(ref)
+    COUNTS["grouped_queries"] += p["prefix_queries"] + p["sweep_queries"] + p["hamming_queries"]
     return True
 
 
@@ -103,7 +113,7 @@ def main():
             runs += 1
             bad += 0 if run(seed, m) else 1
             seed += 1
-    print("runs", runs, "mismatches", bad, "seconds", round(time.time() - t0, 1))
+    print("runs", runs, "mismatches", bad, "seconds", round(time.time() - t0, 1), COUNTS)
     sys.exit(1 if bad else 0)
 
 
