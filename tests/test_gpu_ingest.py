@@ -5,6 +5,7 @@ is stored, the last duplicate of an id wins, ids in any order."""
 import numpy as np
 import pytest
 
+import support
 from test_gpu_parity import GpuIndex, bits, nifs, unwrap  # noqa: F401  (nifs: fixture)
 
 pytestmark = pytest.mark.gpu
@@ -110,3 +111,75 @@ def test_the_serial_path_gives_the_same_index(nifs, oracle_mod, monkeypatch):
     g = GpuIndex(nifs, 3)
     unwrap(nifs.flat_load_matrix(g.ref, ids, x))
     check(nifs, oracle_mod, g, 3, x, ids, 32)
+
+
+@pytest.mark.parametrize("separate_check", [False, True])
+def test_ids_that_went_in_before_a_bad_row_was_found_come_out_again(nifs, oracle_mod, monkeypatch, separate_check):
+    """The check rides on the copy (host/vt_store.h: the threads that fill the pinned quarters look at the rows they
+    copy), and the id thread follows the verified mark -- so a non-finite row near the END of a batch is found when
+    most ids are in the table already.  flat.rs:69-85: nothing of the batch may stay -- ids, ranks (in-place for
+    ascending ids, lazy otherwise), the dimension of an empty index, the rows behind the index.  Quarters of 1 MiB
+    (VT_INGEST_STAGE_MB: 4 096 rows of this width) make the batches cross twenty of them; VT_INGEST_SEPARATE_CHECK is the other form."""
+    monkeypatch.setenv("VT_INGEST_STAGE_MB", "1")
+    if separate_check:
+        monkeypatch.setenv("VT_INGEST_SEPARATE_CHECK", "1")
+    n, d = 90_000, 16
+    x = corpus(n, d, 41)
+    g = GpuIndex(nifs, 0)
+    # (1) on an empty index, ascending ids (their ranks are written as they arrive)
+    bad = x.copy()
+    bad[n - 3, 5] = np.nan
+    ids = [b"a%07d" % i for i in range(n)]
+    assert nifs.flat_load_matrix(g.ref, ids, bad) == ("error", "vector contains a non-finite value")
+    assert len(g) == 0 and g.dimension is None
+    assert unwrap(nifs.flat_search(g.ref, [1.0, 2.0], 3)) == []          # (any dimension: the index is empty)
+    # (2) the same ids, clean, are all new afterwards
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    check(nifs, oracle_mod, g, 0, x, ids, 42)
+    # (3) on top of it, ids out of order (lazy ranks), the bad row in the last quarter: the old rows answer as before,
+    # singly and in a batch (strict ranks), none of the new ids exists
+    more = corpus(80_000, d, 43)
+    ids_more = [b"m%d" % (i * 7919 % 80_000) for i in range(80_000)]
+    bad2 = more.copy()
+    bad2[79_990, 0] = -np.inf
+    assert nifs.flat_load_matrix(g.ref, ids_more, bad2) == ("error", "vector contains a non-finite value")
+    assert len(g) == n
+    check(nifs, oracle_mod, g, 0, x, ids, 44)
+    qs = np.random.default_rng(45).uniform(-1, 1, size=(5, d)).astype(np.float32)
+    packed = oracle_mod.pack_ids(ids)
+    got = unwrap(nifs.flat_search_batch(g.ref, qs, 7))
+    for i in range(5):
+        assert bits(got[i]) == bits(oracle_mod.matrix_search(0, x, packed, qs[i], 7))
+    unwrap(nifs.flat_delete(g.ref, ids_more[5]))                         # (a no-op: the id never made it)
+    assert len(g) == n
+    # (4) ... and the clean batch goes in
+    unwrap(nifs.flat_load_matrix(g.ref, ids_more, more))
+    check(nifs, oracle_mod, g, 0, np.concatenate([x, more]), ids + ids_more, 46)
+
+
+def test_every_id_placed_before_the_bad_row_is_taken_back(nifs, oracle_mod, request, monkeypatch, capfd):
+    """The same with the race taken out (VT_TEST_INGEST_LOCKSTEP, libvettore_hip_hooks.so only: the test re-runs itself
+    there): the id thread keeps step with the verified quarters, so when the bad row of the LAST quarter is found every
+    id of the earlier ones is in the table -- and the trace says how many came out again."""
+    if support.rerun_with_hooks_library(request):
+        return
+    monkeypatch.setenv("VT_INGEST_STAGE_MB", "1")
+    monkeypatch.setenv("VT_TEST_INGEST_LOCKSTEP", "1")
+    monkeypatch.setenv("VT_TRACE_INGEST", "1")
+    n, d = 90_000, 16                                    # rows are 256 B in the slab: 1-MiB quarters of 4 096 rows
+    x = corpus(n, d, 51)
+    ids = [b"a%07d" % i for i in range(n)]
+    g = GpuIndex(nifs, 0)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    more = corpus(80_000, d, 52)
+    ids_more = [b"m%d" % (i * 7919 % 80_000) for i in range(80_000)]
+    bad = more.copy()
+    bad[79_999, 15] = np.inf
+    capfd.readouterr()
+    assert nifs.flat_load_matrix(g.ref, ids_more, bad) == ("error", "vector contains a non-finite value")
+    err = capfd.readouterr().err
+    assert "77824 ids taken back" in err, err            # nineteen whole quarters were verified (and their ids placed) before the twentieth failed
+    assert len(g) == n
+    check(nifs, oracle_mod, g, 0, x, ids, 53)
+    unwrap(nifs.flat_load_matrix(g.ref, ids_more, more))
+    check(nifs, oracle_mod, g, 0, np.concatenate([x, more]), ids + ids_more, 54)

@@ -365,11 +365,21 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
     if (need > ix->ids.capacity()) ix->ids.reserve(std::max(need, 2 * ix->ids.capacity()));
     if (need > ix->rank_host.capacity()) ix->rank_host.reserve(std::max(need, 2 * ix->rank_host.capacity()));
   }
-  // (1) the check, on its own threads
+  // (1) the check.  Fused (the default): the threads that fill the pinned quarters look at every row they copy -- the
+  // caller's matrix is read from host memory ONCE (a checker of its own read the same 30 GB beside them, and both slowed
+  // down together: 0.85-1.04 s for the rows of 10 M x 768) -- and publish how far the batch is known to be finite
+  // (`verified`); the id thread follows that mark and TAKES BACK what it inserted if a later row fails (rollback below:
+  // flat.rs:69-85 stores nothing of a rejected batch).  VT_INGEST_SEPARATE_CHECK=1: the r04 first form, a checker on 32
+  // threads beside the copy, the ids only once it has passed.
+  const bool fused = src.unvalidated && std::getenv("VT_INGEST_SEPARATE_CHECK") == nullptr;
   std::atomic<int> checked{src.unvalidated ? 0 : 1};  // 0 running, 1 passed, 2 failed
+  std::atomic<size_t> verified{src.unvalidated ? (size_t)0 : count};  // rows [0, verified) are known to be finite
+  std::atomic<bool> aborted{false};                   // the copy gave up (device error): nobody will finish the check
+  std::atomic<size_t> ids_done{0};                    // ids the id thread has placed (the lock-step test hook waits on it)
+  std::atomic<bool> id_exited{false};
   std::thread checker;
   double t_checked = 0.0;
-  if (src.unvalidated)
+  if (src.unvalidated && !fused)
     checker = std::thread([&] {
       std::atomic<bool> bad{false};
       parallel_for(count, 8192, [&](size_t lo, size_t hi) {
@@ -379,6 +389,7 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
         }
       }, 32u);
       t_checked = since();
+      if (!bad.load()) verified.store(count, std::memory_order_release);
       checked.store(bad.load() ? 2 : 1);
     });
   // (1a) the batch's ids in bytewise order, for the ranking behind the id table: needs nothing but the bytes, so it starts
@@ -461,7 +472,7 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   int id_status = VT_OK;
   std::string id_error;
   double t_ids = 0.0, t_ranked = 0.0;
-  bool ranked_here = false;
+  bool ranked_here = false, rolled_back = false;
   std::thread idt([&] {
     // (the ids' hashes change nothing in the index: they are formed on a few threads while the check still runs)
     std::vector<uint64_t> hashes;
@@ -472,22 +483,61 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
       }, 8u);
       return VT_OK;
     });
-    while (checked.load() == 0) std::this_thread::yield();
-    if (checked.load() != 1) return;
     if (hst != VT_OK) {
+      while (checked.load() == 0 && !aborted.load()) std::this_thread::yield();
       id_status = hst;
       id_error = g_last_error;
       return;
     }
-    *began = true;
+    // what index_row_for changes, for the way back
+    const uint32_t s_n = ix->n, s_max_rank = ix->max_rank;
+    const uint64_t s_epoch = ix->epoch;
+    const bool s_external = ix->external_ranks, s_clean = ix->ranks_clean, s_dirty_all = ix->rank_dirty_all;
+    const size_t s_unranked = ix->unranked;
+    const std::string s_max_id = ix->max_id;
+    std::vector<uint32_t> s_rank_host;
     id_status = no_throw([&]() -> int {
+      if (s_external) s_rank_host = ix->rank_host;  // (a new id drops externally supplied ranks: the column is refilled)
       constexpr size_t kAhead = 16;
-      for (size_t i = 0; i < std::min(count, kAhead); ++i) ix->row_of.prefetch(hashes[i]);
-      for (size_t i = 0; i < count; ++i) {
-        if (i + kAhead < count) ix->row_of.prefetch(hashes[i + kAhead]);
-        bool is_new = false;
-        target[i] = index_row_for(ix, ids + id_off[i], id_off[i + 1] - id_off[i], &is_new, hashes[i]);
-        if (!is_new || target[i] != n_before + i) in_order = false;
+      size_t done = 0;
+      for (;;) {
+        const size_t lim = verified.load(std::memory_order_acquire);
+        if (done < lim) {
+          *began = true;
+          for (size_t i = done; i < std::min(lim, done + kAhead); ++i) ix->row_of.prefetch(hashes[i]);
+          for (; done < lim; ++done) {
+            if (done + kAhead < lim) ix->row_of.prefetch(hashes[done + kAhead]);
+            bool is_new = false;
+            target[done] = index_row_for(ix, ids + id_off[done], id_off[done + 1] - id_off[done], &is_new, hashes[done]);
+            if (!is_new || target[done] != n_before + done) in_order = false;
+          }
+          ids_done.store(done, std::memory_order_release);
+          continue;
+        }
+        if (done == count) break;
+        if (checked.load() == 2 || aborted.load()) {
+          // a row behind the mark is not finite (or the copy gave up): the ids that went in come out again, newest first
+          if (trace) std::fprintf(stderr, "[vt ingest] the batch is rejected behind row %zu: %u ids taken back\n", done, ix->n - s_n);
+          for (uint32_t r = ix->n; r-- > s_n;) {
+            const std::string &k = ix->ids[r];
+            ix->row_of.erase(k.data(), k.size(), vt_host::hash_id(k.data(), k.size()));
+          }
+          ix->ids.resize(s_n);
+          ix->rank_host.resize(s_n);
+          if (s_external) ix->rank_host = s_rank_host;
+          ix->n = s_n;
+          ix->epoch = s_epoch;
+          ix->external_ranks = s_external;
+          ix->ranks_clean = s_clean;
+          ix->rank_dirty_all = s_dirty_all;
+          ix->unranked = s_unranked;
+          ix->max_rank = s_max_rank;
+          ix->max_id = s_max_id;
+          *began = false;
+          rolled_back = true;
+          return VT_OK;
+        }
+        std::this_thread::yield();
       }
       t_ids = since();
 #ifdef VT_TEST_HOOKS
@@ -512,6 +562,7 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
       return VT_OK;
     });
     if (id_status != VT_OK) id_error = g_last_error;
+    id_exited.store(true);
   });
   // (3) the rows, on this thread
   int copy_status = VT_OK;
@@ -524,7 +575,13 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
       return e && e[0] == '1' ? 1 : 2;
     }();
     constexpr int kQuarters = 4;
-    const size_t stage_rows = std::max<size_t>(1, std::min<size_t>(count, (128u << 20) / row_bytes));
+    // (VT_INGEST_STAGE_MB: tests take quarters of 1 MiB, so that a batch of a few MB crosses many of them)
+    const size_t kQuarterBytes = [] {  // (read per call: tests set it for one load)
+      const char *e = std::getenv("VT_INGEST_STAGE_MB");
+      const long v = e ? std::atol(e) : 0;
+      return (size_t)(v >= 1 && v <= 1024 ? v : 128) << 20;
+    }();
+    const size_t stage_rows = std::max<size_t>(1, std::min<size_t>(count, kQuarterBytes / row_bytes));
     copy_status = c.hStage.ensure(kQuarters * stage_rows * row_bytes);
     hipStream_t second = nullptr;
     hipEvent_t done[kQuarters] = {};
@@ -538,13 +595,37 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
       float *stage = reinterpret_cast<float *>(c.hStage.p) + (size_t)q * stage_rows * ld;
       const size_t chunk = std::min(stage_rows, count - i);
       if (used[q] && hipEventSynchronize(done[q]) != hipSuccess) copy_status = fail(VT_ERR_DEVICE, "hipEventSynchronize (staging quarter)");
+      std::atomic<bool> bad{false};
       parallel_for(chunk, 2048, [&](size_t lo, size_t hi) {
         for (size_t j = lo; j < hi; ++j) {
+          const float *from = src.host + (i + j) * src.d;
+          if (fused && !all_finite_bits(from, d)) {
+            bad.store(true);
+            return;
+          }
           float *dst = stage + j * ld;
-          std::memcpy(dst, src.host + (i + j) * src.d, d * sizeof(float));
+          std::memcpy(dst, from, d * sizeof(float));
           for (size_t t = d; t < ld; ++t) dst[t] = 0.0f;
         }
       });
+      if (fused) {
+        if (bad.load()) {
+          t_checked = since();
+          checked.store(2);
+          break;
+        }
+        verified.store(i + chunk, std::memory_order_release);
+#ifdef VT_TEST_HOOKS
+        // (libvettore_hip_hooks.so only: the ids keep step with the verified rows, so a bad row in the last quarter is
+        // found with every earlier id in the table -- tests/test_gpu_ingest.py checks that they all come out again)
+        if (std::getenv("VT_TEST_INGEST_LOCKSTEP"))
+          while (ids_done.load(std::memory_order_acquire) < i + chunk && !id_exited.load()) std::this_thread::yield();
+#endif
+        if (i + chunk == count) {
+          t_checked = since();
+          checked.store(1);
+        }
+      }
       // (the chunks behind this quarter are mapped by now, or will be in a moment)
       while (progressive && mapped_bytes.load() < (size_t)(n_before + i + chunk) * row_bytes && map_status.load() == VT_OK) std::this_thread::yield();
       if (map_status.load() != VT_OK) copy_status = fail(map_status.load(), map_error);
@@ -561,6 +642,7 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
     }
     for (int q = 0; q < kQuarters; ++q)
       if (done[q]) (void)hipEventDestroy(done[q]);
+    if (copy_status != VT_OK) aborted.store(true);  // (the id thread must not wait for rows nobody will look at)
     if (copy_status != VT_OK) (void)hipGetLastError();
   }
   const double t_copied = since();
@@ -590,7 +672,10 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
     return VT_ERR_NON_FINITE;
   }
   if (id_status != VT_OK) return fail(id_status, id_error);    // (*began is set: the caller poisons the handle)
-  if (copy_status != VT_OK) return fail(copy_status, copy_error);
+  if (copy_status != VT_OK) {
+    if (rolled_back) zero_free_rows();  // (the ids came out again: nothing of the batch stays)
+    return fail(copy_status, copy_error);
+  }
   if (!in_order) {
     // upserts / duplicates in the batch: the ids are in the table already (target[] says where every row belongs);
     // the general path places the rows -- it finds every id present and changes nothing else
