@@ -158,31 +158,54 @@ int index_sync_ranks(Shard *ix, bool force_upload, bool host_only = false, const
     // (integers), sort only the unranked newcomers by id (strings), and merge.
     const std::vector<std::string> &ids = ix->ids;
     const std::vector<uint32_t> &rk = ix->rank_host;
-    std::vector<uint32_t> ranked, fresh;
+    std::vector<uint32_t> ranked, fresh_own;
     uint32_t maxr = 0;
     size_t nranked = 0;
-    for (uint32_t i = 0; i < ix->n; ++i)
-      if (rk[i] != kUnranked) {
-        maxr = std::max(maxr, rk[i]);
-        ++nranked;
-      }
+    {
+      // (a bulk load of ten million unsorted ids comes through here once: the passes over the column are shared out)
+      std::mutex mu;
+      parallel_for(ix->n, [&](size_t lo, size_t hi) {
+        uint32_t m = 0;
+        size_t c = 0;
+        for (size_t i = lo; i < hi; ++i)
+          if (rk[i] != kUnranked) {
+            m = std::max(m, rk[i]);
+            ++c;
+          }
+        std::lock_guard<std::mutex> g(mu);
+        maxr = std::max(maxr, m);
+        nranked += c;
+      });
+    }
+    // the caller's newcomers, already in id order, are taken as they are when they are ALL the unranked rows
+    const bool given = fresh_sorted && fresh_sorted->size() == (size_t)ix->n - nranked;
     if (nranked && (uint64_t)maxr < 4ull * ix->n + 1024) {
       // ranks are unique: a bucket pass puts the ranked rows in rank (= id) order without sorting
       std::vector<uint32_t> slot((size_t)maxr + 1, kUnranked);
-      for (uint32_t i = 0; i < ix->n; ++i)
-        if (rk[i] != kUnranked) slot[rk[i]] = i;
+      parallel_for(ix->n, [&](size_t lo, size_t hi) {  // (ranks are unique: every slot has one writer)
+        for (size_t i = lo; i < hi; ++i)
+          if (rk[i] != kUnranked) slot[rk[i]] = (uint32_t)i;
+      });
       ranked.reserve(nranked);
       for (uint32_t v : slot)
         if (v != kUnranked) ranked.push_back(v);
-      for (uint32_t i = 0; i < ix->n; ++i)
-        if (rk[i] == kUnranked) fresh.push_back(i);
+      if (!given) {
+        fresh_own.reserve((size_t)ix->n - nranked);
+        for (uint32_t i = 0; i < ix->n; ++i)
+          if (rk[i] == kUnranked) fresh_own.push_back(i);
+      }
+    } else if (nranked == 0 && given) {
+      // (nothing ranked yet: no pass at all)
     } else {
-      ranked.reserve(ix->n);
-      for (uint32_t i = 0; i < ix->n; ++i) (rk[i] == kUnranked ? fresh : ranked).push_back(i);
+      ranked.reserve(nranked);
+      for (uint32_t i = 0; i < ix->n; ++i) {
+        if (rk[i] != kUnranked) ranked.push_back(i);
+        else if (!given) fresh_own.push_back(i);
+      }
       parallel_sort(ranked, [&rk](uint32_t a, uint32_t b) { return rk[a] < rk[b]; });
     }
-    if (fresh_sorted && fresh_sorted->size() == fresh.size()) fresh = *fresh_sorted;
-    else parallel_sort(fresh, [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+    if (!given) parallel_sort(fresh_own, [&ids](uint32_t a, uint32_t b) { return ids[a] < ids[b]; });
+    const std::vector<uint32_t> &fresh = given ? *fresh_sorted : fresh_own;
     std::vector<uint32_t> order(ix->n);
     if (fresh.size() < ranked.size() / 16) {
       // few newcomers: each finds its place among the ranked rows by binary search (string
@@ -550,9 +573,19 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
         // of them, the rows that are still waiting for a rank -- an ascending run at the start of the batch got ranks as it arrived
         std::vector<uint32_t> fresh;
         if (batch_order.size() == count && unranked_before == 0) {
+          // (ten million look-ups all over the rank column: shared out, the pieces put together in order)
+          constexpr size_t kParts = 16;
+          std::vector<uint32_t> piece[kParts];
+          std::vector<std::thread> th;
+          for (size_t t = 0; t < kParts; ++t)
+            th.emplace_back([&, t] {
+              const size_t lo = count * t / kParts, hi = count * (t + 1) / kParts;
+              for (size_t i = lo; i < hi; ++i)
+                if (ix->rank_host[n_before + batch_order[i]] == kUnranked) piece[t].push_back(n_before + batch_order[i]);
+            });
+          for (auto &t : th) t.join();
           fresh.reserve(ix->unranked);
-          for (size_t i = 0; i < count; ++i)
-            if (ix->rank_host[n_before + batch_order[i]] == kUnranked) fresh.push_back(n_before + batch_order[i]);
+          for (size_t t = 0; t < kParts; ++t) fresh.insert(fresh.end(), piece[t].begin(), piece[t].end());
           if (fresh.size() != ix->unranked) fresh.clear();
         }
         VT_TRY(index_sync_ranks(ix, false, /*host_only=*/true, fresh.empty() ? nullptr : &fresh));
