@@ -361,13 +361,15 @@ int upload_row_list(Shard *ix, std::vector<uint32_t> &list, uint32_t *count) {
 // collection.ex:427-433, a first load) ------------------------------------------------------------
 // r03 ran the phases one after the other -- finiteness check, id table, rows to the device, id ranks:
 // 0.14 + 0.30 + 0.15 s per 4 M rows, the link idle half the time (18 GB/s).  Here they overlap:
-//   * the rows start for the device at once, through the two pinned halves, into the FREE rows behind
-//     the index (row n + i for batch row i: where they belong if every id is new, the normal case);
-//   * the finiteness check (flat.rs:69-85: the whole batch before anything is stored) runs beside the
-//     copy on threads of its own; the index itself is not touched before it has passed -- rows that
-//     reached the slab's free space by then are zeroed again and the call fails as a whole;
-//   * the id table (one thread: hash + insert per id) and, behind it, the ranking of the ids start
-//     when the check has passed and run while the link is still busy.
+//   * the rows start for the device at once, through four pinned quarters whose copies alternate between two
+//     streams, into the FREE rows behind the index (row n + i for batch row i: where they belong if every id is
+//     new, the normal case);
+//   * the finiteness check (flat.rs:69-85: the whole batch before anything is stored) rides on that copy: the
+//     threads that fill a quarter look at every row they copy, and publish how far the batch is verified;
+//   * the id table (one thread: hashes formed beforehand on several, then an insert per id) follows that mark,
+//     and the ranking of the ids runs behind it, while the link is still busy;
+//   * a row that fails the check after ids went in: they come out again (rollback in the id thread), the rows
+//     that reached the slab's free space are zeroed again, the call fails as a whole and the index is what it was.
 // Ids that turn out not to be all new and distinct (upserts, duplicates in the batch) send the batch
 // through the general path below after all (the free rows zeroed first).
 constexpr int kRetryGeneral = -201;
