@@ -91,7 +91,7 @@ def parse():
                     help="run the measurement in a child process and, should it fail or hang, once more over the host exchange "
                          "(always on for N > 1; this flag switches it on at N = 1, with --exchange rccl|host)")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # (the supervised measurement itself)
-    ap.add_argument("--child-timeout", type=float, default=900.0, help="seconds a supervised measurement may take")
+    ap.add_argument("--child-timeout", type=float, default=480.0, help="seconds a supervised measurement may take")
     ap.add_argument("--exchange-note", default=None, help=argparse.SUPPRESS)  # (why this child runs over the host exchange)
     return ap.parse_args()
 
