@@ -611,7 +611,10 @@ def side_legs(a, torch, nifs, L, device, main_ref):
     # config 5: quantized_search on the resident cosine corpus (sign bits are built by the first call)
     qs = normalized_queries(330, a.dim, SEED_QUERY + 5)
     side["config5"] = dict(leg(a, L, nifs, main_ref, "quantized", qs, 300, 30, candidates=100),
-                           workload="quantized_search candidates=100 limit=10, d=%d, N=%d" % (a.dim, a.rows), dtype="u64")
+                           workload="quantized_search candidates=100 limit=10, d=%d, N=%d" % (a.dim, a.rows), dtype="u64",
+                           note="end to end = upload + five launches + one wait around a distance pass that sits at the small-transfer "
+                                "floor (a bare read of the same 0.96 GB: 0.153 ms); fusing the chain was measured and lost to L2 "
+                                "write-back (DESIGN_APPENDIX A.12)")
     # funnel_search, prefix 128
     qs = normalized_queries(110, a.dim, SEED_QUERY + 6)
     side["funnel"] = dict(leg(a, L, nifs, main_ref, "funnel", qs, 100, 10, stages=(min(a.dim, 128),), candidates=100),
@@ -765,6 +768,9 @@ def batch_roofline(p, rows, dim, dt_per_step=None):
              "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_side_traffic(kern, rows, dim),
              "traffic_source": PMC_SIDE_SOURCE if pmc_side_traffic(kern, rows, dim) is not None else None,
              "avg_launch_ms": ms, "algorithmic_bytes_per_launch": p["nominate_bytes"] / launches,
+             "bound_note": ("at 256 columns neither roof: the part holds 1.72-1.88 GHz under bf16 MFMA at > 1 PFLOP/s beside 4 TB/s of "
+                            "reads (2.38 GHz without the row DMA; profiles/r04_k2s_pmc.txt, DESIGN 4.5); 128 / 64 columns: 0.81 / 0.91 of HBM"
+                            if from_shadow else None),
              "algorithmic_bytes_note": ("rows x d x 2: the pass reads the bf16 shadow of the rows (K2s)" if from_shadow else
                                         "rows x d x 4: the pass streams the f32 rows and rounds them in registers (K2b)")
                                        + "; the exact rescoring of ~%d gathered rows per query is a launch of its own"
