@@ -310,6 +310,10 @@ def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidat
         qp = q.ctypes.data_as(C.POINTER(C.c_float))
         if mode == "batch":
             assert L.vt_flat_search_batch(ref.handle, qp, per, dim, limit, outs) == 0
+            if not keep:
+                # (one call hands the lists back: 256 separate frees through ctypes were 0.2 ms of Python per 4.4-ms step)
+                L.vt_hits_free_many(outs, per)
+                return None
             res = [C.c_void_p(outs[j]) for j in range(per)]
         else:
             h = C.c_void_p()
@@ -812,8 +816,7 @@ def measure_batches(a, torch, dist, nifs, _lib, L, ref, sharded, use_dist, launc
             sys.exit("bench.py: flat_search_batch failed with status %d: %s" % (st, (L.vt_last_error() or b"").decode()))
         if keep:
             return [hits_of(L, C.c_void_p(outs[j])) for j in range(per)]
-        for j in range(per):
-            L.vt_hits_free(C.c_void_p(outs[j]))
+        L.vt_hits_free_many(outs, per)
         return None
 
     def single(q):

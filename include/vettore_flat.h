@@ -139,6 +139,9 @@ int vt_hit_blocks_merge(const void *blocks, size_t world, size_t nq, size_t limi
 size_t vt_hits_id_bytes(const vt_hits *hits);
 void vt_hits_export(const vt_hits *hits, char *ids, size_t *id_off, float *raw, uint32_t *rank_key);
 void vt_hits_free(vt_hits *hits);
+/* The same for the `n` lists a batch call returned (null entries are skipped): one call across the boundary instead of
+ * `n` -- through a foreign-function interface 256 separate frees cost more than the lists took to build (r04). */
+void vt_hits_free_many(vt_hits **hits, size_t n);
 
 /* ----------------------------------------------------------- flat index
  * FlatResource(RwLock<FlatIndex>), flat.rs:13-17, :131-134. */

@@ -24,7 +24,7 @@ EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1
 SYMBOLS = [
     "vt_strerror", "vt_last_error", "vt_abi_version", "vt_device_count", "vt_device_read_peak",
     "vt_hits_len", "vt_hits_id", "vt_hits_raw", "vt_hits_rank_key", "vt_hits_pack", "vt_hits_pack_many", "vt_hit_blocks_merge", "vt_hits_id_bytes", "vt_hits_export",
-    "vt_hits_free",
+    "vt_hits_free", "vt_hits_free_many",
     "vt_flat_new", "vt_flat_new_sharded", "vt_flat_shard_count", "vt_flat_shard_device", "vt_flat_shard_len", "vt_flat_shard_memory", "vt_flat_coalesce_stats",
     "vt_flat_route_ids", "vt_flat_set_exchange", "vt_flat_exchange", "vt_flat_exchange_note", "vt_flat_rccl_ranks", "vt_flat_free", "vt_flat_insert", "vt_flat_insert_many", "vt_flat_delete",
     "vt_flat_search", "vt_flat_search_batch", "vt_flat_len", "vt_flat_dimension", "vt_flat_metric",
@@ -95,6 +95,8 @@ def load() -> C.CDLL:
     L.vt_hits_export.argtypes = [vp, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.vt_hits_free.restype = None
     L.vt_hits_free.argtypes = [vp]
+    L.vt_hits_free_many.restype = None
+    L.vt_hits_free_many.argtypes = [C.POINTER(vp), C.c_size_t]
     L.vt_flat_new.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
     L.vt_flat_new_sharded.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_size_t, C.POINTER(vp)]
     L.vt_flat_shard_count.restype = C.c_size_t

@@ -116,27 +116,22 @@ constexpr size_t kMaxDirtyRanks = 16384;  // above this the whole rank column is
 constexpr uint32_t kUnranked = 0xFFFFFFFFu;  // id_rank of a row inserted out of id order, until the next re-rank
 
 // flat.rs:136-144 validate_vector: empty, then dimension, then finiteness.
-int validate_vector(const float *v, size_t n, long dimension) {
-  if (n == 0) return VT_ERR_EMPTY;
-  if (dimension >= 0 && n != (size_t)dimension) return VT_ERR_DIMENSION;
-  for (size_t i = 0; i < n; ++i)
-    if (!std::isfinite(v[i])) return VT_ERR_NON_FINITE;
-  return VT_OK;
-}
-
-int validate_finite(const float *v, size_t n) {
-  for (size_t i = 0; i < n; ++i)
-    if (!std::isfinite(v[i])) return VT_ERR_NON_FINITE;
-  return VT_OK;
-}
-
-// The same test on the bit patterns (auto-vectorises: the bulk loads run it over tens of GB).
+// Finiteness on the bit patterns (auto-vectorises: the bulk loads run it over tens of GB, a batch of 256 queries over
+// 200 000 floats -- the scalar isfinite loop with its early exit took 0.1-0.2 ms of a 4.3-ms batch).
 inline bool all_finite_bits(const float *v, size_t n) {
   const uint32_t *u = reinterpret_cast<const uint32_t *>(v);
   uint32_t worst = 0;
   for (size_t i = 0; i < n; ++i) worst = std::max(worst, u[i] & 0x7f800000u);
   return worst != 0x7f800000u;
 }
+
+int validate_vector(const float *v, size_t n, long dimension) {
+  if (n == 0) return VT_ERR_EMPTY;
+  if (dimension >= 0 && n != (size_t)dimension) return VT_ERR_DIMENSION;
+  return all_finite_bits(v, n) ? VT_OK : VT_ERR_NON_FINITE;
+}
+
+int validate_finite(const float *v, size_t n) { return all_finite_bits(v, n) ? VT_OK : VT_ERR_NON_FINITE; }
 
 // Splits [0, n) over up to 16 host threads (bulk ingest: validation and staging copies
 // are plain memory passes).  `f(lo, hi)` must not throw.

@@ -228,6 +228,13 @@ void vt_hits_export(const vt_hits *h, char *ids, size_t *id_off, float *raw, uin
 }
 
 void vt_hits_free(vt_hits *h) { delete h; }
+void vt_hits_free_many(vt_hits **hs, size_t n) {
+  if (!hs) return;
+  for (size_t i = 0; i < n; ++i) {
+    delete hs[i];
+    hs[i] = nullptr;
+  }
+}
 
 int vt_flat_new_sharded(int metric_code, const int *devices, size_t ndev, vt_flat **out) {
   return guarded([&]() -> int {
