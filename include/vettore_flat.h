@@ -300,9 +300,11 @@ int vt_flat_funnel_search(vt_flat *index, const float *query, size_t n,
                           const size_t *stages, size_t nstages, size_t candidates,
                           size_t limit, vt_hits **out);
 /* `nq` funnel searches with one set of stages (queries of `d` floats back to back), out[i] = query
- * i's hits -- identical to nq vt_flat_funnel_search calls.  On a cosine collection groups of up to
- * eight share ONE sweep of the rows' first stages[0] coordinates (candidates <= 256); anything else
- * runs query by query. */
+ * i's hits -- identical to nq vt_flat_funnel_search calls.  Groups of up to eight share ONE sweep of the
+ * rows' first stages[0] coordinates (candidates <= 256, 16 384 rows or more): the f64 cosine on a cosine
+ * collection, the metric's own f32 arithmetic on dot / L2 / manhattan / chebyshev ones (r04); under float
+ * hamming / jaccard every query is a pass over the prefix of the non-zero-bit column (r04).  Anything else runs
+ * query by query. */
 int vt_flat_funnel_search_batch(vt_flat *index, const float *queries, size_t nq, size_t d,
                                 const size_t *stages, size_t nstages, size_t candidates,
                                 size_t limit, vt_hits **out);
@@ -379,9 +381,9 @@ typedef struct vt_profile {
   double batch_flops;       /* 2 * rows * padded queries * padded dims per pass */
   uint64_t batch_queries;
   uint64_t batch_fallbacks; /* queries the bound could not certify (re-run singly) */
-  uint64_t prefix_launches; /* f64 cosine prefix scans (funnel stage over all rows) */
+  uint64_t prefix_launches; /* funnel stages over ALL rows: f64 cosine prefix scans, K1 / K1p prefix sweeps, K4 passes over the bit column's prefix */
   double prefix_ms;
-  uint64_t prefix_bytes;    /* rows * prefix dimensions * 4 */
+  uint64_t prefix_bytes;    /* rows * prefix dimensions * 4 (rows * ceil(prefix / 64) * 8 from the bit column) */
   /* K2b: candidate passes with bf16 operands (HBM-bound; batch_* above count the FP32 passes) */
   uint64_t nominate_launches;
   double nominate_ms;
