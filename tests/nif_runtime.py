@@ -195,6 +195,23 @@ class Runtime:
             self.L.fake_env_free(env)
 
 
+    def call_timed(self, name, *args):
+        """call(), and the seconds the NIF itself took: the argument terms are built before the clock starts, the
+        result is read after it has stopped (a probe's view of the shim, without this runtime's Python in it)."""
+        import time
+        env = self.L.fake_env_new()
+        try:
+            argv = (C.c_void_p * max(1, len(args)))(*[self.to_term(env, a) for a in args])
+            t0 = time.perf_counter()
+            r = self.L.fake_call(env, name.encode(), len(args), argv)
+            dt = time.perf_counter() - t0
+            if not r:
+                raise AttributeError("%s/%d is not in the NIF table" % (name, len(args)))
+            return self.from_term(r), dt
+        finally:
+            self.L.fake_env_free(env)
+
+
 class FloatList:
     """[float] built in one call (long vectors)."""
 
