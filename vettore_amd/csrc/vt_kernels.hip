@@ -1931,6 +1931,18 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_multi_kerne
   const uint32_t step = dense ? a.sample_stride : 1u;           // dense: every step-th tile
   const uint32_t ntiles = (ntiles_all + step - 1) / step;        // tiles this launch walks
   const uint32_t npanel = (a.d + kCsPanel - 1) / kCsPanel;
+  // the thresholds, once, through the scalar cache (read per tile as vector loads each brought a wait for the NEXT
+  // tile's sixteen panel loads into the epilogue: K1p's note, vt_prefix_multi.hip)
+  typedef const __attribute__((address_space(4))) float *cf_p;
+  float tauv[kCosineMultiMax];
+#pragma unroll
+  for (uint32_t q = 0; q < kCosineMultiMax; ++q) tauv[q] = INFINITY;
+  if (!dense) {
+    cf_p tp = (cf_p)(uintptr_t)a.tau;
+#pragma unroll
+    for (uint32_t q = 0; q < kCosineMultiMax; ++q)
+      if (q < a.nq) tauv[q] = tp[q];
+  }
   f32x4 v[16];
   auto issue = [&](uint32_t ti, uint32_t p) {
     const uint32_t t = ti * step;
@@ -1997,7 +2009,6 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_multi_kerne
     }
     // distances.rs:160-177, once per query
     const double rn = sqrt(xx);
-    const uint32_t my_rank = (!dense && valid_row && a.id_rank) ? a.id_rank[grow] : grow;
 #pragma unroll
     for (uint32_t q = 0; q < kCosineMultiMax; ++q) {
       if (q >= a.nq) break;
@@ -2019,7 +2030,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_multi_kerne
         if (i < a.sample_rows) a.sample[(size_t)q * a.sample_rows + i] = valid ? raw : -INFINITY;
         continue;
       }
-      const bool hit = valid && raw >= a.tau[q];
+      const bool hit = valid && raw >= tauv[q];
       const uint64_t m = __ballot(hit);
       if (m) {
         uint32_t base = 0;
@@ -2027,6 +2038,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_multi_kerne
         base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(m), kWave);
         const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
         if (hit && pos < a.cand_cap) {
+          const uint32_t my_rank = a.id_rank ? a.id_rank[grow] : grow;  // (only in the rare lanes that list a row)
           a.cand_keys[(size_t)q * a.cand_cap + pos] = ((uint64_t)orderable(1.0f - raw) << 32) | my_rank;
           Payload pv;
           pv.row = grow;

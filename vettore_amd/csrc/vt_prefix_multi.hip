@@ -12,7 +12,7 @@
 // acc = acc + chunk sum down the row and the scalar tail one element at a time.  The queries are wave-uniform:
 // eight floats per query and chunk through the scalar cache, used as SGPR operands.
 // Cost: 16 (dot) to 24 (L2) VALU instructions per query and chunk, 8 queries: 1 024..1 536 per 16-KiB panel and wave
-// -- the kernel sits between the VALU and the prefix reads (DESIGN.md 4.6 has the measured rates).
+// -- the kernel sits between the VALU and the prefix reads (DESIGN.md 5.3 has the measured rates).
 #include "vt_scan.cuh"
 
 namespace vt {
@@ -92,6 +92,14 @@ __device__ __forceinline__ float pm_chunk(float acc, const f32x2 (&x)[4], const 
   return comb<OP>(0, acc, pm_reduce<OP, ORDER>(e));
 }
 
+// recover_overflow (vt_scan.cuh) with the result by value -- NaN where there is none: an out-parameter lives in scratch
+// memory, and the s_waitcnt vmcnt(0) the compiler puts behind the (rare) branch that reloads it sits in EVERY tile's
+// epilogue, once per query, where it waits for the next tile's sixteen panel loads
+__device__ __noinline__ static float recover_or_nan(int metric, const float *q, const float *x, uint32_t d) {
+  float rec;
+  return recover_overflow(metric, q, x, d, &rec) ? rec : __builtin_nanf("");
+}
+
 template <int OP, int ORDER>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(const PrefixMultiArgs a) {
   extern __shared__ __align__(16) float pm_lds[];
@@ -109,6 +117,17 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
   const uint32_t ntiles = (ntiles_all + step - 1) / step;   // tiles this launch walks
   const uint32_t npanel = (a.d + kPmPanel - 1) / kPmPanel;
   const uint32_t cfull = a.d / 8, tail = a.d % 8;
+  // the thresholds, once, through the scalar cache: read per tile as vector loads they each brought an s_waitcnt vmcnt(0)
+  // into the epilogue -- eight times per tile the wave waited for its NEXT tile's sixteen panel loads
+  float tauv[kPrefixMultiMax];
+#pragma unroll
+  for (uint32_t q = 0; q < kPrefixMultiMax; ++q) tauv[q] = INFINITY;
+  if (!dense) {
+    cf_p tp = (cf_p)(uintptr_t)a.tau;
+#pragma unroll
+    for (uint32_t q = 0; q < kPrefixMultiMax; ++q)
+      if (q < a.nq) tauv[q] = tp[q];
+  }
   f32x4 v[16];
   auto issue = [&](uint32_t ti, uint32_t p) {
     const uint32_t t = ti * step;
@@ -166,7 +185,6 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
       wave_lds_fence();
     }
     // distances.rs:42-68 compute(): value, finiteness, f64 recovery; :113-119 rank_value
-    const uint32_t my_rank = (!dense && valid_row && a.id_rank) ? a.id_rank[grow] : grow;
     const int metric = a.metric;
 #pragma unroll
     for (uint32_t q = 0; q < kPrefixMultiMax; ++q) {
@@ -176,10 +194,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
       else if (metric == M_L2) raw = finite_f32(raw) ? __builtin_sqrtf(raw) : raw;
       bool valid = valid_row;
       if (valid && !finite_f32(raw)) {
-        float rec;
-        if (recover_overflow(metric, a.Q + (size_t)q * qst, a.X + (size_t)grow * a.stride, a.d, &rec)) {
-          raw = rec;
-        } else {
+        raw = recover_or_nan(metric, a.Q + (size_t)q * qst, a.X + (size_t)grow * a.stride, a.d);
+        if (raw != raw) {
           if (!dense) atomicMax(a.status, kErrOverflow);
           valid = false;
         }
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
         if (i < a.sample_rows) a.sample[(size_t)q * a.sample_rows + i] = valid ? good : -INFINITY;
         continue;
       }
-      const bool hit = valid && good >= a.tau[q];
+      const bool hit = valid && good >= tauv[q];
       const uint64_t m = __ballot(hit);
       if (m) {
         uint32_t base = 0;
@@ -199,6 +215,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
         base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(m), kWave);
         const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
         if (hit && pos < a.cand_cap) {
+          // (the id rank only here, in the rare lanes that list a row: a load per tile would be one more wait on vmcnt)
+          const uint32_t my_rank = a.id_rank ? a.id_rank[grow] : grow;
           a.cand_keys[(size_t)q * a.cand_cap + pos] = ((uint64_t)orderable(rank) << 32) | my_rank;
           Payload pv;
           pv.row = grow;
