@@ -214,6 +214,15 @@ __global__ __launch_bounds__(kWavesS *kWave, 1) void shadow_scores_kernel(const 
   float tau[QTW];
 #pragma unroll
   for (int j = 0; j < QTW; ++j) tau[j] = DENSE ? 0.f : a.tau[qbase + 16 * j + (lane & 15)];
+  // The compiler counts these loads in vmcnt and never sees them retire (the DMA below is inline asm, its waits are
+  // hand-placed): left alone it puts s_waitcnt vmcnt(7), (6), ... (0) in front of every tile's threshold compares -- the
+  // last of them waits until NO piece of the DMA ring is in flight, once per tile.  Each value is therefore taken
+  // through an asm operand right here: the wait happens once, before the first piece is issued.  (Measured: nothing --
+  // 3.59-3.62 ms either way at 10 M x 768 x 256; the ring is full again before the pass misses it.  Kept for the ISA.)
+  if (!DENSE) {
+#pragma unroll
+    for (int j = 0; j < QTW; ++j) asm volatile("" : "+v"(tau[j]));
+  }
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
   // DMA: this wave's pieces of a chunk.  Rows: 16-row tiles 2 w and 2 w + 1 of the block tile (their
