@@ -42,8 +42,15 @@ def main():
     assert rc == 0
     t1 = time.perf_counter()
     print(json.dumps({"python_pack_ids_s": round(t0 - tp, 3)}), flush=True)
+    if os.environ.get("SLEEP_MS"):
+        time.sleep(float(os.environ["SLEEP_MS"]) / 1e3)
+        t1 = time.perf_counter()
+    nifs.flat_set_profiling(ref, True)
     st, hits = nifs.flat_search(ref, x[5], 3)  # first search: id ranking happens here if it was deferred
     t2 = time.perf_counter()
+    p0 = nifs.flat_get_profile(ref, reset=True)
+    print(json.dumps({"first_search_kernel_ms": round(p0["scan_ms"], 3), "first_search_wall_ms": round((t2 - t1) * 1e3, 3)}), flush=True)
+    nifs.flat_set_profiling(ref, False)
     assert hits[0][0] == ids[5], hits
     more = []
     for _ in range(3):
