@@ -167,3 +167,70 @@ def test_looping_callers_ride_one_pass(nifs):
     res = bench.native_callers(a, L, nifs, ref, 16, 1.0, qs, 0, 0)
     assert res is not None and res["verified"], res
     assert res["searches_in_batches"] / max(1, res["batches"]) > 12, res
+
+
+def test_the_shadow_pass_beats_streaming_the_f32_rows(nifs):
+    """Round 4's floor for config 3's shape, scaled down: a 256-query dot batch nominated from the bf16 shadow (K2s) must
+    not be slower than the same batch with the shadow off (K2b reads twice the bytes) -- measured 1.3-1.4x faster."""
+    import torch
+    from bench import build_shard, doc_ids
+    rows, dim = 2_000_000, 768
+    x = build_shard(torch, torch.device("cuda", 0), rows, dim, 77)
+    g = GpuIndex(nifs, 3)
+    assert nifs.flat_load_device_matrix(g.ref, doc_ids(0, rows), x.data_ptr(), rows, dim) == ("ok", ())
+    del x
+    qs = np.random.default_rng(1).uniform(-1, 1, (256, dim)).astype(np.float32)
+
+    def timed():
+        unwrap(nifs.flat_search_batch(g.ref, qs, 10))
+        t0 = time.perf_counter()
+        for _ in range(5):
+            unwrap(nifs.flat_search_batch(g.ref, qs, 10))
+        return (time.perf_counter() - t0) / 5
+
+    with_shadow = timed()
+    assert nifs.flat_batch_shadow(g.ref) == "current"
+    assert nifs.flat_set_batch_shadow(g.ref, 0) == ("ok", ())      # VT_SHADOW_OFF
+    without = timed()
+    assert with_shadow < 1.02 * without, (with_shadow, without)
+
+
+def test_funnel_callers_on_an_l2_handle_share_sweeps(nifs):
+    """Eight funnel batches' worth of queries through vt_flat_funnel_search_batch (K1p: eight per sweep of the prefixes)
+    against the same queries one by one: measured 5-6x at N = 10 M; the guard asks for 2x at 2 M rows."""
+    import torch
+    from bench import build_shard, doc_ids
+    rows, dim = 2_000_000, 768
+    x = build_shard(torch, torch.device("cuda", 0), rows, dim, 78)
+    g = GpuIndex(nifs, 0)
+    assert nifs.flat_load_device_matrix(g.ref, doc_ids(0, rows), x.data_ptr(), rows, dim) == ("ok", ())
+    del x
+    qs = np.random.default_rng(2).uniform(-1, 1, (64, dim)).astype(np.float32)
+    unwrap(nifs.flat_funnel_search_batch(g.ref, qs, [128], 100, 10))
+    t0 = time.perf_counter()
+    grouped = unwrap(nifs.flat_funnel_search_batch(g.ref, qs, [128], 100, 10))
+    t_grouped = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    singles = [unwrap(nifs.flat_funnel_search(g.ref, q, [128], 100, 10)) for q in qs]
+    t_singles = time.perf_counter() - t0
+    assert [bits(h) for h in grouped] == [bits(h) for h in singles]
+    assert t_grouped * 2 < t_singles, (t_grouped, t_singles)
+
+
+def test_bulk_ingest_keeps_the_link_busy(nifs):
+    """vt_flat_load_matrix of 2 M x 768 host rows: 36-43 GB/s measured at 10 M rows; the guard asks for 20 GB/s (the
+    serial path of round 3 did 18)."""
+    rows, dim = 2_000_000, 768
+    rng = np.random.default_rng(3)
+    x = np.empty((rows, dim), dtype=np.float32)
+    for s0 in range(0, rows, 1 << 17):
+        e0 = min(rows, s0 + (1 << 17))
+        x[s0:e0] = rng.random((e0 - s0, dim), dtype=np.float32) * 2.0 - 1.0
+    ids = [b"doc-%09d" % i for i in range(rows)]
+    g = GpuIndex(nifs, 2)
+    warm = GpuIndex(nifs, 2)
+    unwrap(nifs.flat_load_matrix(warm.ref, ids[:200_000], x[:200_000]))   # (pinned staging, code objects: once per process)
+    t0 = time.perf_counter()
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    dt = time.perf_counter() - t0
+    assert rows * dim * 4 / dt / 1e9 > 20.0, dt
