@@ -397,12 +397,6 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   const bool trace = std::getenv("VT_TRACE_INGEST") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-  {
-    const size_t need = (size_t)ix->n + count;  // (as in the general path: no regrowth inside the id loop)
-    if (need * 10 > ix->row_of.slots() * 7) ix->row_of.reserve(std::max(need, 2 * ix->row_of.size()));
-    if (need > ix->ids.capacity()) ix->ids.reserve(std::max(need, 2 * ix->ids.capacity()));
-    if (need > ix->rank_host.capacity()) ix->rank_host.reserve(std::max(need, 2 * ix->rank_host.capacity()));
-  }
   // (1) the check.  Fused (the default): the threads that fill the pinned quarters look at every row they copy -- the
   // caller's matrix is read from host memory ONCE (a checker of its own read the same 30 GB beside them, and both slowed
   // down together: 0.85-1.04 s for the rows of 10 M x 768) -- and publish how far the batch is known to be finite
@@ -509,12 +503,18 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   bool in_order = true;
   int id_status = VT_OK;
   std::string id_error;
-  double t_ids = 0.0, t_ranked = 0.0;
+  double t_ids = 0.0, t_ranked = 0.0, t_staged = 0.0;
   bool ranked_here = false, rolled_back = false;
   std::thread idt([&] {
-    // (the ids' hashes change nothing in the index: they are formed on a few threads while the check still runs)
+    // (the ids' hashes change nothing in the index: they are formed on a few threads while the check still runs; so is
+    // the room in the id tables -- as in the general path no regrowth inside the id loop; reserving it on the calling
+    // thread held the first copy back by 40 ms per ten million ids: a 256-MB slot array to clear)
     std::vector<uint64_t> hashes;
     const int hst = no_throw([&]() -> int {
+      const size_t need = (size_t)ix->n + count;
+      if (need * 10 > ix->row_of.slots() * 7) ix->row_of.reserve(std::max(need, 2 * ix->row_of.size()));
+      if (need > ix->ids.capacity()) ix->ids.reserve(std::max(need, 2 * ix->ids.capacity()));
+      if (need > ix->rank_host.capacity()) ix->rank_host.reserve(std::max(need, 2 * ix->rank_host.capacity()));
       hashes.resize(count);
       parallel_for(count, 1u << 16, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) hashes[i] = vt_host::hash_id(ids + id_off[i], id_off[i + 1] - id_off[i]);
@@ -631,6 +631,7 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
     }();
     const size_t stage_rows = std::max<size_t>(1, std::min<size_t>(count, kQuarterBytes / row_bytes));
     copy_status = c.hStage.ensure(kQuarters * stage_rows * row_bytes);
+    t_staged = since();
     hipStream_t second = nullptr;
     hipEvent_t done[kQuarters] = {};
     for (int q = 0; q < kQuarters && copy_status == VT_OK; ++q)
@@ -760,8 +761,8 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
     ix->rank_dirty_all = true;  // a small part of a large index: the next search that needs them ranks (as in the general path)
   }
   if (trace)
-    std::fprintf(stderr, "[vt ingest] %zu rows, phases overlapped: room %s at %.3f s, finiteness check done at %.3f s, id table at %.3f s, id ranks at %.3f s, rows on the device at %.3f s, all at %.3f s\n",
-                 count, progressive ? "being mapped ahead of the copy from" : "made by", t_room, t_checked, t_ids, t_ranked, t_copied, since());
+    std::fprintf(stderr, "[vt ingest] %zu rows, phases overlapped: room %s at %.3f s, pinned staging ready at %.3f s, finiteness check done at %.3f s, id table at %.3f s, id ranks at %.3f s, rows on the device at %.3f s, all at %.3f s\n",
+                 count, progressive ? "being mapped ahead of the copy from" : "made by", t_room, t_staged, t_checked, t_ids, t_ranked, t_copied, since());
   return VT_OK;
 }
 
