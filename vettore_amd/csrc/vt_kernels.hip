@@ -592,7 +592,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void pattern_topk_multi_kern
   };
   load_tiles(cur, wave_global);
   for (uint32_t t0 = wave_global; t0 < ntiles; t0 += (uint32_t)U * total_waves) {
-    load_tiles(nxt, t0 + (uint32_t)U * total_waves);
+    // (the id ranks of the CURRENT tiles are asked for before the next tiles' words: loads return in order, so a rank
+    // requested behind the prefetch could only be waited for together with it -- every iteration then drained what it
+    // had just put in flight)
     uint32_t grow[U], my_rank[U];
     bool valid[U];
 #pragma unroll
@@ -602,6 +604,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void pattern_topk_multi_kern
       valid[u] = t < ntiles && grow[u] < a.n;
       my_rank[u] = (valid[u] && a.id_rank) ? a.id_rank[grow[u]] : grow[u];
     }
+    load_tiles(nxt, t0 + (uint32_t)U * total_waves);
     // jaccard: |x or q| = |x| + |q| - |x and q|, and |x| is the row's own (once per tile, not per
     // query), |q| a scalar: a query costs one v_and + one v_bcnt per 32 row bits, like hamming's xor
     uint32_t px[U];
