@@ -919,7 +919,12 @@ def run_child(argv, exchange, note, port_shift, timeout):
         cmd += ["--exchange-note", note]
     env = dict(os.environ)
     if port_shift and "MASTER_PORT" in env:
-        env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + port_shift)  # (a rendezvous the first run left half open stays out of the way)
+        # a rendezvous the first run left half open stays out of the way: the second run's ranks meet on the next port --
+        # where rank 0 must host the store ITSELF: under torch.distributed.run the launcher's agent hosts the one at
+        # MASTER_PORT and tells its workers to come as clients only (TORCHELASTIC_USE_AGENT_STORE); nobody listens one
+        # port up (found with the driver's own command on one GPU: both ranks' clients timed out after 2 x 120 s)
+        env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + port_shift)
+        env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
     t0 = time.perf_counter()
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
     try:

@@ -30,4 +30,5 @@ if exchange == "rccl" and hit:
 print("some banner a library prints on stdout")
 if rank == 0:
     print(json.dumps({"metric": "fake", "value": 1.0, "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
-                      "config": {"exchange": exchange, "exchange_note": note, "master_port": os.environ.get("MASTER_PORT")}}))
+                      "config": {"exchange": exchange, "exchange_note": note, "master_port": os.environ.get("MASTER_PORT"),
+                                 "agent_store": os.environ.get("TORCHELASTIC_USE_AGENT_STORE")}}))

@@ -73,7 +73,7 @@ def test_ranks_under_a_launcher_take_the_second_step_together():
     RCCL child fails, rank 0's succeeds -- both must go on to the host exchange (on the next port), and
     only rank 0 prints."""
     env = dict(os.environ, VT_BENCH_CHILD=FAKE, FAKE_CHILD="rccl_fails", FAKE_FAIL_RANKS="1", WORLD_SIZE="2", MASTER_PORT="29641",
-               MASTER_ADDR="127.0.0.1")
+               MASTER_ADDR="127.0.0.1", TORCHELASTIC_USE_AGENT_STORE="True")   # (what torch.distributed.run's agent puts there)
     procs = []
     for rank in (0, 1):
         procs.append(subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--steps", "3"], env=dict(env, RANK=str(rank), LOCAL_RANK=str(rank)),
@@ -82,6 +82,8 @@ def test_ranks_under_a_launcher_take_the_second_step_together():
     assert [p.returncode for p in procs] == [0, 0], outs
     line = last_json(outs[0][0])
     assert line["config"]["exchange"] == "host" and line["config"]["master_port"] == "29642", line
+    # ... where the second run's rank 0 hosts the store itself: the launcher's agent only listens on the first port
+    assert line["config"]["agent_store"] == "False", line
     assert "failed on another rank" in line["config"]["exchange_note"]
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
 
