@@ -17,7 +17,7 @@ endif
 
 DEVSRC  := vt_kernels vt_batch vt_batch_bf16 vt_batch_shadow vt_scan_dot vt_scan_l2 vt_scan_l1 vt_scan_misc vt_scan_general vt_scan_gather vt_scan_multi vt_prefix_multi
 DEVOBJ  := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(DEVSRC)))
-DEVHDR  := $(CSRC)/vt_device.h $(CSRC)/vt_common.cuh $(CSRC)/vt_scan.cuh
+DEVHDR  := $(CSRC)/vt_device.h $(CSRC)/vt_common.cuh $(CSRC)/vt_scan.cuh $(CSRC)/vt_env.h
 
 all: $(LIBDIR)/libvettore_hip.so $(LIBDIR)/libvettore_hip_hooks.so $(LIBDIR)/libvt_callers.so oracle
 
@@ -46,7 +46,7 @@ $(LIBDIR)/vt_batch_shadow.o: $(CSRC)/vt_batch_shadow.hip $(DEVHDR)
 	python3 tools/check_scratch.py $(LIBDIR)/vt_batch_shadow.resources shadow_scores_kernel
 
 HOSTHDR := $(wildcard $(CSRC)/host/*.h)
-$(LIBDIR)/vt_index.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h include/vettore_flat.h
+$(LIBDIR)/vt_index.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h $(CSRC)/vt_env.h include/vettore_flat.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
@@ -56,7 +56,7 @@ $(LIBDIR)/libvettore_hip.so: $(DEVOBJ) $(LIBDIR)/vt_index.o
 # The same library with the fault-injection hooks compiled into the host side (VT_TEST_FAIL_AFTER_ID_UPDATE,
 # VT_TEST_FOREIGN_ROWS): test infrastructure, loaded only by the two tests that need them
 # (VETTORE_HIP_LIB=...); the product library carries no such switch.
-$(LIBDIR)/vt_index_hooks.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h include/vettore_flat.h
+$(LIBDIR)/vt_index_hooks.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h $(CSRC)/vt_env.h include/vettore_flat.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DVT_TEST_HOOKS -x hip -c $< -o $@
 

@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--supervise", action="store_true",
                     help="run the measurement in a child process and, should it fail or hang, once more over the host exchange "
                          "(always on for N > 1; this flag switches it on at N = 1, with --exchange rccl|host)")
+    ap.add_argument("--debug-set", action="append", default=[], metavar="NAME=VALUE",
+                    help="a library setting for this run (vt_debug_set, include/vettore_flat.h), e.g. force_batch_mfma=1 on a small corpus")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # (the supervised measurement itself)
     ap.add_argument("--child-timeout", type=float, default=480.0, help="seconds a supervised measurement may take")
     ap.add_argument("--exchange-note", default=None, help=argparse.SUPPRESS)  # (why this child runs over the host exchange)
@@ -260,14 +262,11 @@ def verify_against_oracle(nifs, dim, order_code, limit=10):
         out["funnel"] = bits(nifs.flat_funnel_search(ref, q, [stage], 100, limit)[1]) == bits(want)
         # a query batch through the matrix cores (both nominations) == the oracle's single searches
         qs = np.stack([oracle.normalize_l2(v) for v in rng.uniform(-1, 1, (16, dim)).astype(np.float32)])
-        os.environ["VT_FORCE_BATCH_MFMA"] = "1"
-        try:
+        with nifs.debug_setting("force_batch_mfma", 1):   # (the cost model would send a corpus this small to single scans)
             for name, mode in (("batch_bf16", 2), ("batch_f32", 1)):
                 nifs.flat_set_batch_nominate(ref, mode)
                 got = nifs.flat_search_batch(ref, qs, limit)[1]
                 out[name] = all(bits(got[i]) == bits(oracle.matrix_search(2, x, packed, qs[i], limit)) for i in range(16))
-        finally:
-            del os.environ["VT_FORCE_BATCH_MFMA"]
         # flat_search under float hamming / jaccard from the non-zero-bit column (K4), a batch in K4p sweeps
         xs = (rng.uniform(-1, 1, (n, dim)) * (rng.uniform(0, 1, (n, dim)) < 0.5)).astype(np.float32)
         qsp = (rng.uniform(-1, 1, (16, dim)) * (rng.uniform(0, 1, (16, dim)) < 0.5)).astype(np.float32)
@@ -375,7 +374,9 @@ def leg(a, L, nifs, ref, mode, qs, steps, warmup, per=1, stages=(128,), candidat
             out["second_passes"] = p["nominate_second_passes"]
             out["candidates_per_query"] = p["nominate_candidates"] / max(1, p["nominate_queries"])
             out["bf16_shadow"] = nifs.flat_batch_shadow(ref)
-            out["end_to_end_frac"] = p["nominate_bytes"] / launches / (dt / steps) / 1e9 / HBM_PEAK_GBS
+            # (all the passes of the timed steps over the time of those steps: a step of 16 x 256 is sixteen passes)
+            out["end_to_end_frac"] = p["nominate_bytes"] / dt / 1e9 / HBM_PEAK_GBS
+            out["passes_per_step"] = launches / steps
     else:
         key = {"single": "scan", "funnel": "prefix", "quantized": "hamming", "pattern": "hamming"}[mode]
         kern = {"single": "scan_topk_kernel", "funnel": "cosine_scan_kernel", "quantized": "hamming_dist_kernel",
@@ -713,6 +714,15 @@ def side_legs(a, torch, nifs, L, device, main_ref):
         leg(a, L, nifs, ref3, "batch", qs, 20, 4, per=256),
         workload="index: :flat, metric: :dot, d=%d, N=%d, batch=256 queries (bf16 MFMA nomination, HBM-bound, + exact f32 rescoring)"
         % (a.dim, a.rows), dtype="f32 (exact rescoring; bf16 nomination)")
+    # ... and the config as BASELINE.json writes it -- "16 batches x 256"  -- as ONE vt_flat_search_batch of
+    # 4 096 queries: consecutive groups of 256 alternate between two contexts, group g + 1's upload / sample / threshold
+    # beside group g's exact rescoring, group g's verdicts and hit lists under group g + 1's pass over the rows
+    qs = np.random.default_rng(SEED_QUERY + 5).uniform(-1, 1, size=(5 * 4096, a.dim)).astype(np.float32)
+    r16 = leg(a, L, nifs, ref3, "batch", qs, 4, 1, per=4096)
+    side["config3_bf16_nominate"]["one_call_16x256"] = {
+        k: r16[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "fallback_queries", "second_passes",
+                            "candidates_per_query", "end_to_end_frac", "passes_per_step", "verified")}
+    side["config3_bf16_nominate"]["one_call_16x256"]["kernel_avg_launch_ms"] = r16["roofline"]["avg_launch_ms"]
     del ref3
     torch.cuda.empty_cache()
     # float hamming (distances.rs:319-324) on N sparse rows: flat_search reads the non-zero-bit column
@@ -1023,8 +1033,6 @@ def measure(a):
     # `--gpus 1 --exchange rccl|host`: the one shard goes through the multi-shard machinery anyway
     # (worker thread, exchange, host merge) -- prices that machinery on a one-GPU box
     force_sharded = not launched and a.gpus == 1 and a.exchange != "auto"
-    if force_sharded:
-        os.environ["VT_SHARD_FORCE_WORKERS"] = "1"
     # weak scaling: --rows is one GPU's share
     total_rows = a.rows * a.gpus if a.scaling == "weak" else a.rows
     normalize = a.metric == "cosine"   # (collection.ex:1317-1319: only cosine collections normalise what they store)
@@ -1035,6 +1043,11 @@ def measure(a):
     from vettore_amd import nifs, _lib
     from vettore_amd.sharded import ShardedFlat
     L = _lib.load()
+    for item in a.debug_set:   # (--debug-set name=value: vt_debug_set)
+        name, _, value = item.partition("=")
+        nifs.debug_set(name, int(value or 1))
+    if force_sharded:
+        nifs.debug_set("shard_force_workers", 1)
 
     if launched and a.devices:
         # (under a launcher --devices names every rank's GPU: `--devices 0,0` lets a one-GPU box run two ranks,
@@ -1075,7 +1088,7 @@ def measure(a):
             sys.exit("--gpus %d needs %d visible devices (or --devices with %d ordinals < %d)" % (
                 shards_in_process, shards_in_process, shards_in_process, ndev))
         if a.exchange != "auto":
-            os.environ["VT_SHARD_EXCHANGE"] = a.exchange
+            nifs.debug_set("shard_exchange", {"host": 1, "rccl": 2}[a.exchange])
         ref = nifs.flat_new_sharded(nifs.METRIC_CODE[a.metric], devices)
         nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
         all_idx = np.arange(1, total_rows + 1, dtype=np.int64)

@@ -41,7 +41,7 @@ extern "C" {
  * compares it with vt_abi_version() when it loads the library (vettore_amd/_lib.py, the erl_nif
  * shim's load callback): a caller built against an older header would hand vt_flat_get_profile a
  * struct that is too small. */
-#define VT_ABI_VERSION 3
+#define VT_ABI_VERSION 4   /* r05: vt_debug_set / vt_debug_get */
 
 /* Metric codes == Metric::from_code, native/vettore/src/distances.rs:24-38,
  * mirrored by lib/vettore/collection.ex:1306-1315. */
@@ -102,6 +102,23 @@ int vt_device_count(void);
  * yardstick beside the 8 TB/s spec figure -- a search kernel that reads this way and also computes
  * cannot stream faster on the same box. */
 int vt_device_read_peak(int device, size_t bytes, int reps, double *gbps);
+
+/* ------------------------------------------------------------------ settings
+ * The library reads the process environment exactly ONCE, while it is being loaded (dlopen /
+ * :erlang.load_nif): every VT_* variable of DESIGN_APPENDIX.md A.10 lands in a table of atomic integers
+ * (csrc/vt_env.h) and no search, insert or load ever calls getenv -- inside a BEAM `System.put_env/2`
+ * may run setenv on a scheduler thread at any time, and the reference NIF itself reads no process state
+ * (nifs.rs:297-309).  After loading, a setting changes only through vt_debug_set: `name` is the
+ * variable's name without "VT_", lower case ("batch_no_mfma", "coalesce_slots", "slab_chunk_mb" ...;
+ * string-valued ones take their code: reduce_order 0..3 = VT_ORDER_*, batch_nominate VT_NOMINATE_*,
+ * batch_shadow VT_SHADOW_*, slab 1 = malloc, shard_exchange 1 = host / 2 = rccl).  Four switches have
+ * no environment name at all -- "force_batch_mfma", "force_sweep_groups", "force_multi_scan",
+ * "force_threshold_select" (take a path on corpora the cost model would never send there) and
+ * "bf16_rank" (K2b's threshold from exactly that sample rank): tests and soaks only.  A debugging and
+ * testing aid, process-wide, effective for calls that start afterwards; VT_ERR_ARGUMENT for a name this
+ * build does not know (the fault hooks "test_*" exist in libvettore_hip_hooks.so only). */
+int vt_debug_set(const char *name, long value);
+int vt_debug_get(const char *name, long *value);
 
 /* ------------------------------------------------------------------ hits
  * Vec<(String, f32)> as returned by flat_search / vector_top_k /

@@ -6,9 +6,17 @@
 //      waiting, the slot count must come back to zero;
 //   2. the context lease: 48 readers on a pool of at most 8 contexts, no context ever held twice;
 //   3. the workers: concurrent callers posting to 4 workers, every worker sees the callers' jobs in
-//      the same order (what matching collectives need), failures come back with their message.
+//      the same order (what matching collectives need), failures come back with their message;
+//   4. the settings table (vettore_amd/csrc/vt_env.h): the path-choice reads of a search -- vt::env::get --
+//      beside a thread that calls setenv / unsetenv all the time (what System.put_env/2 does to a NIF
+//      library inside a BEAM) and one that stores settings: the table was filled once, before any of
+//      them started, and a read never goes back to the environment;
+//   5. a second context beside the one a reader holds (SpareLeaseT): never the primary, never held
+//      twice, never a wait -- 48 readers that each hold one and ask for another must all come through.
 // TEST INFRASTRUCTURE.  Prints "ok" and exits 0, or says what went wrong.
 #include "../vettore_amd/csrc/host/vt_concurrency.h"
+#define VT_ENV_IMPLEMENTATION
+#include "../vettore_amd/csrc/vt_env.h"
 
 #include <atomic>
 #include <cstdio>
@@ -277,10 +285,87 @@ static void check_workers(int callers, int per_caller) {
   std::fprintf(stderr, "workers: %zu jobs per worker in one order, %d failures reported\n", seen[0].size(), failures.load());
 }
 
+// ------------------------------------------------------------------ 4. settings beside setenv
+static void check_settings(int readers, int per_reader) {
+  // what the table holds was decided when this program was loaded (VT_COALESCE_SLOTS=3 from the test's environment)
+  CHECK(vt::env::get(vt::env::COALESCE_SLOTS) == 3);
+  CHECK(vt::env::get(vt::env::BF16_MIN_RANK) == 6 && vt::env::get(vt::env::FORCE_BATCH_MFMA) == 0);
+  CHECK(vt::env::find("force_batch_mfma") == (int)vt::env::FORCE_BATCH_MFMA && vt::env::find("VT_FORCE_BATCH_MFMA") < 0);
+  CHECK(vt::env::find("test_refuse_shadow") < 0);  // (a fault hook: not in a build without -DVT_TEST_HOOKS)
+  std::atomic<bool> stop{false};
+  std::thread meddler([&] {  // System.put_env/2 on a scheduler thread
+    for (unsigned i = 0; !stop.load(); ++i) {
+      setenv("VT_COALESCE_SLOTS", (i & 1u) ? "7" : "9", 1);
+      setenv("VT_BATCH_NO_MFMA", "1", 1);
+      unsetenv("VT_BATCH_NO_MFMA");
+      setenv("SOME_OTHER_VARIABLE_THAT_GROWS_THE_ENVIRONMENT", std::to_string(i).c_str(), 1);
+    }
+  });
+  std::thread setter([&] {  // vt_debug_set from a test thread
+    for (unsigned i = 0; !stop.load(); ++i) vt::env::set(vt::env::RESCORE_BLOCKS, 4 + (long)(i & 7u));
+  });
+  std::atomic<long> sum{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < readers; ++t)
+    pool.emplace_back([&] {
+      long local = 0;
+      for (int i = 0; i < per_reader; ++i) {
+        // batch_uses_mfma / multi_scan_applies / sweep_group_applies / coalesce_slots, as the library asks them
+        CHECK(!vt::env::on(vt::env::BATCH_NO_MFMA) && !vt::env::on(vt::env::FORCE_BATCH_MFMA));
+        CHECK(!vt::env::on(vt::env::NO_MULTI_SCAN) && !vt::env::on(vt::env::NO_SWEEP_GROUPS) && !vt::env::on(vt::env::NO_GROUP_PIPELINE));
+        CHECK(vt::env::get(vt::env::COALESCE_SLOTS) == 3);  // not 7, not 9: the environment is not looked at again
+        const long b = vt::env::get(vt::env::RESCORE_BLOCKS);
+        CHECK(b >= 4 && b <= 11);
+        local += b;
+      }
+      sum += local;
+    });
+  for (auto &th : pool) th.join();
+  stop = true;
+  meddler.join();
+  setter.join();
+  std::fprintf(stderr, "settings: %d readers x %d rounds beside setenv (checksum %ld)\n", readers, per_reader, sum.load());
+}
+
+// ------------------------------------------------------------------ 5. a second context
+static void check_spare_lease(int threads, int per_thread) {
+  FakeShard s;
+  std::atomic<int> got{0}, none{0};
+  std::vector<std::thread> pool;
+  auto make = [](FakeShard *, int *) -> std::unique_ptr<FakeCtx> { return std::make_unique<FakeCtx>(); };
+  for (int t = 0; t < threads; ++t)
+    pool.emplace_back([&, t] {
+      std::mt19937 rng(1000 + t);
+      for (int i = 0; i < per_thread; ++i) {
+        vt_host::LeaseT<FakeShard, FakeCtx> lease(&s, 8, make);
+        CHECK(lease.c != nullptr);
+        CHECK(lease.c->holders.fetch_add(1) == 0);
+        {
+          vt_host::SpareLeaseT<FakeShard, FakeCtx> spare((rng() & 1u) ? &s : nullptr, 8, make);
+          if (spare.c) {
+            CHECK(spare.c != &s.ctx && spare.c != lease.c);
+            CHECK(spare.c->holders.fetch_add(1) == 0);  // never held twice
+            if ((rng() & 3u) == 0u) spin(3);
+            CHECK(spare.c->holders.fetch_sub(1) == 1);
+            got += 1;
+          } else {
+            none += 1;
+          }
+        }
+        CHECK(lease.c->holders.fetch_sub(1) == 1);
+      }
+    });
+  for (auto &th : pool) th.join();  // (returning at all is the point: nobody waits for a second context)
+  CHECK(s.extra.size() + 1 <= 8 && !s.ctx0_busy && s.free_ctx.size() == s.extra.size());
+  std::fprintf(stderr, "spare lease: %d second contexts handed out, %d times none to be had\n", got.load(), none.load());
+}
+
 int main(int argc, char **argv) {
   const int scale = argc > 1 ? std::atoi(argv[1]) : 1;
+  check_settings(16, 20000 * scale);
   check_coalescer(64, 1600 * scale);  // 10^5 operations at scale 1
   check_lease(48, 4000 * scale);
+  check_spare_lease(48, 2000 * scale);
   check_workers(8, 1500 * scale);
   std::printf("ok\n");
   return 0;

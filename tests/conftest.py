@@ -32,6 +32,37 @@ def oracle_mod():
     return oracle
 
 
+class _Settings:
+    """Library settings for the length of one test (vt_debug_set, include/vettore_flat.h).  The library reads
+    the VT_* variables once, when it is loaded -- long before a test body runs -- so a test names the setting
+    ("batch_no_mfma", "coalesce_slots", "force_batch_mfma" ...) instead of patching the environment."""
+
+    def __init__(self):
+        self.saved = {}
+
+    def set(self, name, value):
+        from vettore_amd import nifs
+        if name not in self.saved:
+            self.saved[name] = nifs.debug_get(name)
+        nifs.debug_set(name, value)
+
+    def reset(self, name):
+        from vettore_amd import nifs
+        if name in self.saved:
+            nifs.debug_set(name, self.saved.pop(name))
+
+    def restore(self):
+        for name in list(self.saved):
+            self.reset(name)
+
+
+@pytest.fixture
+def vt_debug():
+    s = _Settings()
+    yield s
+    s.restore()
+
+
 def pytest_collection_modifyitems(config, items):
     # gpu_perf tests run only when asked for by name (-m gpu_perf): `-m "not gpu"` on a CPU box
     # and `-m gpu` on the driver's box both leave them out

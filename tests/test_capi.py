@@ -49,7 +49,7 @@ def test_error_strings_are_the_references(lib):
     }
     for code, text in want.items():
         assert lib.vt_strerror(code).decode() == text
-    assert lib.vt_abi_version() == 3
+    assert lib.vt_abi_version() == 4
 
 
 def test_header_cites_the_reference_interface():
@@ -114,13 +114,49 @@ def test_product_does_not_touch_the_oracle():
 
 
 def test_product_library_carries_no_test_hooks():
-    """The fault-injection switches (VT_TEST_*) exist in libvettore_hip_hooks.so only: the product
-    library has no environment variable that makes it fail or take a detour on purpose."""
+    """The fault-injection switches (test_* settings, VT_TEST_* variables) exist in libvettore_hip_hooks.so only, and
+    the switches that force a path on corpora the cost model would never send there have no environment name at all:
+    the product library has no environment variable that makes it fail or take a detour on purpose."""
     lib_dir = os.path.join(ROOT, "vettore_amd", "lib")
     product = open(os.path.join(lib_dir, "libvettore_hip.so"), "rb").read()
-    assert b"VT_TEST_" not in product
+    assert b"VT_TEST_" not in product and b"VT_FORCE_" not in product and b"test_fail_after_id_update" not in product
     hooks = os.path.join(lib_dir, "libvettore_hip_hooks.so")
     if os.path.exists(hooks):
         data = open(hooks, "rb").read()
-        for name in (b"VT_TEST_FAIL_AFTER_ID_UPDATE", b"VT_TEST_EXCHANGE_STALL_MS", b"VT_TEST_REFUSE_NZBITS"):
+        for name in (b"test_fail_after_id_update", b"test_exchange_stall_ms", b"test_refuse_nzbits"):
             assert name in data, name
+
+
+def test_settings_by_name(lib):
+    """vt_debug_set / vt_debug_get (include/vettore_flat.h): the library's switches after the one read of the
+    environment at load time.  No device needed."""
+    v = C.c_long(-1)
+    assert lib.vt_debug_get(b"bf16_min_rank", C.byref(v)) == 0 and v.value == 6
+    assert lib.vt_debug_get(b"force_batch_mfma", C.byref(v)) == 0 and v.value == 0
+    assert lib.vt_debug_set(b"force_batch_mfma", 1) == 0
+    assert lib.vt_debug_get(b"force_batch_mfma", C.byref(v)) == 0 and v.value == 1
+    assert lib.vt_debug_set(b"force_batch_mfma", 0) == 0
+    for bad in (b"VT_FORCE_BATCH_MFMA", b"no_such_switch", b"test_refuse_shadow", b""):
+        assert lib.vt_debug_set(bad, 1) == 19, bad      # VT_ERR_ARGUMENT
+    assert lib.vt_debug_set(None, 1) == 19 and lib.vt_debug_get(b"coalesce", None) == 19
+    # the environment is not consulted again: a variable set now changes nothing
+    os.environ["VT_COALESCE_SLOTS"] = "5"
+    try:
+        assert lib.vt_debug_get(b"coalesce_slots", C.byref(v)) == 0 and v.value == 0
+    finally:
+        del os.environ["VT_COALESCE_SLOTS"]
+
+
+def test_the_environment_is_read_when_the_library_is_loaded():
+    """... and only then: a fresh process with VT_* set sees them in the table (string-valued ones as their codes)."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, vettore_amd._lib as L; l = L.load(); v = C.c_long()\n"
+            "out = []\n"
+            "for n in (b'reduce_order', b'batch_nominate', b'batch_shadow', b'slab', b'shard_exchange', b'coalesce', b'no_multi_scan', b'rescore_blocks'):\n"
+            "    assert l.vt_debug_get(n, C.byref(v)) == 0; out.append(v.value)\n"
+            "print(out)")
+    env = dict(os.environ, VT_REDUCE_ORDER="avx", VT_BATCH_NOMINATE="f32", VT_BATCH_SHADOW="off", VT_SLAB="malloc",
+               VT_SHARD_EXCHANGE="rccl", VT_COALESCE="0", VT_NO_MULTI_SCAN="1", VT_RESCORE_BLOCKS="16")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "[1, 1, 0, 1, 2, 0, 1, 16]", (r.stdout, r.stderr[-2000:])

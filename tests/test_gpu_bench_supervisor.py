@@ -55,7 +55,7 @@ def test_weak_scaling_and_the_batched_leg_on_a_two_shard_handle():
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["scaling"] == "weak" and "N=300000" in line["metric"] and line["n_gpus"] == 2, line
     r, line = bench(["--gpus", "2", "--devices", "0,0", "--mode", "batch", "--metric", "l2", "--batch", "64", "--rows", "300000",
-                     "--steps", "4", "--warmup", "1", "--no-cpu"], VT_FORCE_BATCH_MFMA=1)
+                     "--steps", "4", "--warmup", "1", "--no-cpu", "--debug-set", "force_batch_mfma=1"])
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["config"]["verified"] and "batch=64" in line["metric"] and line["roofline"]["kernel"] == "shadow_scores_kernel", line
     assert line["config"]["per_shard_pass_ms"] > 0
@@ -69,7 +69,7 @@ def test_two_ranks_under_the_launcher_over_the_host_exchange():
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["n_gpus"] == 2 and line["config"]["processes"] == 2 and "gloo" in line["config"]["sharding"], line
     r, line = bench(["--gpus", "2", "--devices", "0,0", "--exchange", "host", "--mode", "batch", "--metric", "l2", "--batch", "32",
-                     "--rows", "200000", "--steps", "3", "--warmup", "1", "--no-cpu"], launcher=2, VT_FORCE_BATCH_MFMA=1)
+                     "--rows", "200000", "--steps", "3", "--warmup", "1", "--no-cpu", "--debug-set", "force_batch_mfma=1"], launcher=2)
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["config"]["verified"] and line["config"]["processes"] == 2, line
 

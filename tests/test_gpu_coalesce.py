@@ -36,7 +36,7 @@ def _hammer(nifs, ref, jobs, threads, rounds):
 
 
 @pytest.mark.parametrize("metric,devices", [(2, None), (0, None), (5, None), (2, [0, 0, 0])])
-def test_coalesced_searches_equal_searches_alone(nifs, oracle_mod, monkeypatch, metric, devices):
+def test_coalesced_searches_equal_searches_alone(nifs, oracle_mod, monkeypatch, metric, devices, vt_debug):
     n, d = 40_000, 96
     x, ids = make_corpus(n, d, 910 + metric, metric == 2, oracle_mod, tie_block=40)
     g = GpuIndex(nifs, metric)
@@ -47,7 +47,7 @@ def test_coalesced_searches_equal_searches_alone(nifs, oracle_mod, monkeypatch, 
     qs = [x[n // 2], x[3]] + [rng.uniform(-1, 1, d).astype(np.float32) for _ in range(30)]
     if metric == 2:
         qs = [oracle_mod.normalize_l2(q) for q in qs]
-    monkeypatch.setenv("VT_COALESCE", "0")
+    vt_debug.set("coalesce", 0)
     jobs = []
     for i, q in enumerate(qs):
         k = (10, 10, 10, 5, 32, 300)[i % 6]          # 300 > 256: never batched
@@ -55,8 +55,8 @@ def test_coalesced_searches_equal_searches_alone(nifs, oracle_mod, monkeypatch, 
     jobs.append((np.ones(d + 1, np.float32), 10, ("error", "dimension mismatch")))
     jobs.append((np.full(d, np.nan, np.float32), 10, ("error", "vector contains a non-finite value")))
     assert jobs[0][2] == bits(oracle_mod.matrix_search(metric, x, oracle_mod.pack_ids(ids), qs[0], 10))
-    monkeypatch.delenv("VT_COALESCE")
-    monkeypatch.setenv("VT_COALESCE_SLOTS", "1")
+    vt_debug.reset("coalesce")
+    vt_debug.set("coalesce_slots", 1)
     before = nifs.flat_coalesce_stats(g.ref)
     bad = _hammer(nifs, g.ref, jobs, threads=16, rounds=60)
     after = nifs.flat_coalesce_stats(g.ref)
@@ -64,7 +64,7 @@ def test_coalesced_searches_equal_searches_alone(nifs, oracle_mod, monkeypatch, 
     assert after[0] > before[0] and after[1] - before[1] >= 2 * (after[0] - before[0])   # batches ran, >= 2 searches each
 
 
-def test_coalescing_steps_aside_for_lazy_ranks_and_survives_mutations(nifs, oracle_mod, monkeypatch):
+def test_coalescing_steps_aside_for_lazy_ranks_and_survives_mutations(nifs, oracle_mod, monkeypatch, vt_debug):
     """Unsorted inserts leave the id ranks lazy: a batch would force a re-rank that lone searches
     avoid, so the queued callers are released to search side by side; a writer keeps inserting
     rows that never reach a result while 12 readers check their answers."""
@@ -76,7 +76,7 @@ def test_coalescing_steps_aside_for_lazy_ranks_and_survives_mutations(nifs, orac
     qs = [x[n // 2]] + [rng.uniform(-1, 1, d).astype(np.float32) for _ in range(11)]
     jobs = [(q, 10, bits(unwrap(nifs.flat_search(g.ref, q, 10)))) for q in qs]
     far = (rng.uniform(-1, 1, (400, d)) * 0.01 + 50.0).astype(np.float32)
-    monkeypatch.setenv("VT_COALESCE_SLOTS", "1")
+    vt_debug.set("coalesce_slots", 1)
     stop = threading.Event()
 
     def writer():

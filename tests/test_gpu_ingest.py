@@ -27,11 +27,11 @@ def check(nifs, oracle_mod, g, metric, x, ids, seed, k=12):
 
 @pytest.mark.parametrize("chunk_mb", [None, 2])
 @pytest.mark.parametrize("order", ["sorted", "unsorted"])
-def test_bulk_loads_in_both_id_orders(nifs, oracle_mod, order, chunk_mb, monkeypatch):
+def test_bulk_loads_in_both_id_orders(nifs, oracle_mod, order, chunk_mb, monkeypatch, vt_debug):
     """chunk_mb = 2: the slab is a mapped range of 2-MiB chunks (1 GiB in production), so these small loads map
     their chunks on a thread AHEAD of the copy, as a 30-GB load does."""
     if chunk_mb:
-        monkeypatch.setenv("VT_SLAB_CHUNK_MB", str(chunk_mb))
+        vt_debug.set("slab_chunk_mb", chunk_mb)
     n, d = 150_000, 24
     x = corpus(n, d, 1)
     ids = [b"doc-%07d" % i for i in range(n)] if order == "sorted" else [b"doc-%d" % (i * 7919 % n) for i in range(n)]
@@ -55,9 +55,9 @@ def test_bulk_loads_in_both_id_orders(nifs, oracle_mod, order, chunk_mb, monkeyp
 
 
 @pytest.mark.parametrize("chunk_mb", [None, 2])
-def test_a_non_finite_row_rejects_the_whole_bulk_load(nifs, oracle_mod, chunk_mb, monkeypatch):
+def test_a_non_finite_row_rejects_the_whole_bulk_load(nifs, oracle_mod, chunk_mb, monkeypatch, vt_debug):
     if chunk_mb:
-        monkeypatch.setenv("VT_SLAB_CHUNK_MB", str(chunk_mb))
+        vt_debug.set("slab_chunk_mb", chunk_mb)
     n, d = 120_000, 16
     x = corpus(n, d, 7)
     ids = [b"r%d" % i for i in range(n)]
@@ -103,26 +103,26 @@ def test_upserts_and_duplicates_inside_a_bulk_load(nifs, oracle_mod):
         assert bits(g.search(q, 10)) == bits(want.search(q, 10))
 
 
-def test_the_serial_path_gives_the_same_index(nifs, oracle_mod, monkeypatch):
+def test_the_serial_path_gives_the_same_index(nifs, oracle_mod, monkeypatch, vt_debug):
     n, d = 70_000, 16
     x = corpus(n, d, 31)
     ids = [b"z%d" % (i * 31 % n) for i in range(n)]
-    monkeypatch.setenv("VT_INGEST_SERIAL", "1")
+    vt_debug.set("ingest_serial", 1)
     g = GpuIndex(nifs, 3)
     unwrap(nifs.flat_load_matrix(g.ref, ids, x))
     check(nifs, oracle_mod, g, 3, x, ids, 32)
 
 
 @pytest.mark.parametrize("separate_check", [False, True])
-def test_ids_that_went_in_before_a_bad_row_was_found_come_out_again(nifs, oracle_mod, monkeypatch, separate_check):
+def test_ids_that_went_in_before_a_bad_row_was_found_come_out_again(nifs, oracle_mod, monkeypatch, separate_check, vt_debug):
     """The check rides on the copy (host/vt_store.h: the threads that fill the pinned quarters look at the rows they
     copy), and the id thread follows the verified mark -- so a non-finite row near the END of a batch is found when
     most ids are in the table already.  flat.rs:69-85: nothing of the batch may stay -- ids, ranks (in-place for
     ascending ids, lazy otherwise), the dimension of an empty index, the rows behind the index.  Quarters of 1 MiB
     (VT_INGEST_STAGE_MB: 4 096 rows of this width) make the batches cross twenty of them; VT_INGEST_SEPARATE_CHECK is the other form."""
-    monkeypatch.setenv("VT_INGEST_STAGE_MB", "1")
+    vt_debug.set("ingest_stage_mb", 1)
     if separate_check:
-        monkeypatch.setenv("VT_INGEST_SEPARATE_CHECK", "1")
+        vt_debug.set("ingest_separate_check", 1)
     n, d = 90_000, 16
     x = corpus(n, d, 41)
     g = GpuIndex(nifs, 0)
@@ -157,15 +157,15 @@ def test_ids_that_went_in_before_a_bad_row_was_found_come_out_again(nifs, oracle
     check(nifs, oracle_mod, g, 0, np.concatenate([x, more]), ids + ids_more, 46)
 
 
-def test_every_id_placed_before_the_bad_row_is_taken_back(nifs, oracle_mod, request, monkeypatch, capfd):
+def test_every_id_placed_before_the_bad_row_is_taken_back(nifs, oracle_mod, request, monkeypatch, capfd, vt_debug):
     """The same with the race taken out (VT_TEST_INGEST_LOCKSTEP, libvettore_hip_hooks.so only: the test re-runs itself
     there): the id thread keeps step with the verified quarters, so when the bad row of the LAST quarter is found every
     id of the earlier ones is in the table -- and the trace says how many came out again."""
     if support.rerun_with_hooks_library(request):
         return
-    monkeypatch.setenv("VT_INGEST_STAGE_MB", "1")
-    monkeypatch.setenv("VT_TEST_INGEST_LOCKSTEP", "1")
-    monkeypatch.setenv("VT_TRACE_INGEST", "1")
+    vt_debug.set("ingest_stage_mb", 1)
+    vt_debug.set("test_ingest_lockstep", 1)
+    vt_debug.set("trace_ingest", 1)
     n, d = 90_000, 16                                    # rows are 256 B in the slab: 1-MiB quarters of 4 096 rows
     x = corpus(n, d, 51)
     ids = [b"a%07d" % i for i in range(n)]

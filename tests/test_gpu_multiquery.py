@@ -10,11 +10,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def no_matrix_cores(monkeypatch):
+def no_matrix_cores(monkeypatch, vt_debug):
     # dot-family batches would otherwise take the shared MFMA pass: here K1m serves every metric
-    monkeypatch.setenv("VT_BATCH_NO_MFMA", "1")
+    vt_debug.set("batch_no_mfma", 1)
     # ... and on corpora of a few thousand rows two or three single scans would be priced lower than a sweep
-    monkeypatch.setenv("VT_FORCE_MULTI_SCAN", "1")
+    vt_debug.set("force_multi_scan", 1)
 
 
 @pytest.mark.parametrize("metric", range(9))

@@ -134,7 +134,7 @@ def test_sharded_validation_and_unsupported_calls(nifs, oracle_mod):
 
 @pytest.mark.parametrize("metric", [2, 0, 3])
 @pytest.mark.parametrize("rounds", ["one", "per-stage"])
-def test_staged_searches_on_a_sharded_handle_equal_the_one_gpu_index(nifs, oracle_mod, metric, rounds, monkeypatch):
+def test_staged_searches_on_a_sharded_handle_equal_the_one_gpu_index(nifs, oracle_mod, metric, rounds, monkeypatch, vt_debug):
     """quantized_search, funnel_search and hybrid_search (collection.ex:276-295, :245-260,
     :325-345) on a 3-shard resource: every step keeps the best rows of a row set, per shard and
     then merged by (rank key, id bytes) -- the results must equal the one-GPU index's (which the
@@ -142,7 +142,7 @@ def test_staged_searches_on_a_sharded_handle_equal_the_one_gpu_index(nifs, oracl
     Both ways the handle can run them: one fan-out (every shard its whole chain, the handle
     cuts afterwards) and one fan-out per stage (`VT_STAGED_ROUNDS`, also the fallback)."""
     if rounds == "per-stage":
-        monkeypatch.setenv("VT_STAGED_ROUNDS", "1")
+        vt_debug.set("staged_rounds", 1)
     n, d = 60_000, 96     # 20 000 rows per shard: the histogram form of the Hamming pass (n >= 16 384) runs in each
     x, ids = make_corpus(n, d, 2100 + metric, metric == 2, oracle_mod, tie_block=50)
     one = GpuIndex(nifs, metric)
@@ -187,12 +187,12 @@ def test_staged_searches_on_a_sharded_handle_equal_the_one_gpu_index(nifs, oracl
 
 @pytest.mark.parametrize("metric", [7, 8])
 @pytest.mark.parametrize("rounds", ["one", "per-stage"])
-def test_pattern_funnel_on_a_sharded_handle_equals_the_one_gpu_index(nifs, oracle_mod, metric, rounds, monkeypatch):
+def test_pattern_funnel_on_a_sharded_handle_equals_the_one_gpu_index(nifs, oracle_mod, metric, rounds, monkeypatch, vt_debug):
     """funnel_search / hybrid_search on float hamming / jaccard collections (collection.ex:245-260, :325-345): the
     first stage of each shard reads the prefix of its non-zero-bit column.  Equal to the one-GPU index (pinned to the
     oracle's composition in test_gpu_parity) single, batched, and after mutations patched the column."""
     if rounds == "per-stage":
-        monkeypatch.setenv("VT_STAGED_ROUNDS", "1")
+        vt_debug.set("staged_rounds", 1)
     n, d = 60_000, 130
     rng = np.random.default_rng(77 + metric)
     x = (rng.uniform(-1, 1, (n, d)) * (rng.uniform(0, 1, (n, d)) < 0.4)).astype(np.float32)
@@ -262,12 +262,12 @@ def test_one_round_staged_search_ignores_an_overflow_outside_the_candidate_set(n
     assert nifs.flat_funnel_search(many.ref, q, [8], 7, 3) == ("error", "metric overflow")
 
 
-def test_rccl_exchange_with_a_one_rank_communicator(nifs, oracle_mod, monkeypatch):
+def test_rccl_exchange_with_a_one_rank_communicator(nifs, oracle_mod, monkeypatch, vt_debug):
     """The RCCL leg of the exchange (librccl loaded at run time, ncclCommInitAll, one ncclAllGather
     per shard queued behind the scan, gathered lists copied out by shard 0) on the only GPU of
     the box: a one-shard resource forced onto the worker path."""
-    monkeypatch.setenv("VT_SHARD_FORCE_WORKERS", "1")
-    monkeypatch.setenv("VT_SHARD_EXCHANGE", "rccl")
+    vt_debug.set("shard_force_workers", 1)
+    vt_debug.set("shard_exchange", 2)
     n, d = 30_000, 128
     x, ids = make_corpus(n, d, 77, True, oracle_mod, tie_block=30)
     g = ShardedIndex(nifs, 2, [0])
@@ -288,7 +288,7 @@ def test_rccl_exchange_with_a_one_rank_communicator(nifs, oracle_mod, monkeypatc
     ids2 = [ids[i] for i in keep] + [b"aaa-first"]
     assert bits(g.search(x[3], 5)) == bits(oracle_mod.matrix_search(2, x2, oracle_mod.pack_ids(ids2), x[3], 5))
     # two shards on ONE device cannot form a communicator: the handle says so and stays on the host path
-    monkeypatch.delenv("VT_SHARD_EXCHANGE")
+    vt_debug.reset("shard_exchange")
     two = ShardedIndex(nifs, 2, [0, 0])
     assert nifs.flat_exchange(two.ref) == _lib.EXCHANGE_HOST and nifs.flat_rccl_ranks(two.ref) == 0
     res = nifs.flat_set_exchange(two.ref, _lib.EXCHANGE_RCCL)
@@ -298,7 +298,7 @@ def test_rccl_exchange_with_a_one_rank_communicator(nifs, oracle_mod, monkeypatc
     assert "share a device" in nifs.flat_exchange_note(two.ref)
 
 
-def test_a_wedged_exchange_times_out_with_a_message(nifs, oracle_mod, monkeypatch, request):
+def test_a_wedged_exchange_times_out_with_a_message(nifs, oracle_mod, monkeypatch, request, vt_debug):
     """The first 8-GPU run must not hang without a word if a collective never completes (VERDICT r2
     next #7a): the wait behind a shard's all-gather has a deadline (VT_EXCHANGE_TIMEOUT_MS); past it
     the search fails with "RCCL exchange timed out on shard s ...", the handle is poisoned (its
@@ -307,19 +307,19 @@ def test_a_wedged_exchange_times_out_with_a_message(nifs, oracle_mod, monkeypatc
     if support.rerun_with_hooks_library(request):
         return
     import time
-    monkeypatch.setenv("VT_SHARD_FORCE_WORKERS", "1")
-    monkeypatch.setenv("VT_SHARD_EXCHANGE", "rccl")
-    monkeypatch.setenv("VT_EXCHANGE_TIMEOUT_MS", "250")     # (read once per process: before the first exchange)
+    vt_debug.set("shard_force_workers", 1)
+    vt_debug.set("shard_exchange", 2)
+    vt_debug.set("exchange_timeout_ms", 250)     # (read once per process: before the first exchange)
     g = ShardedIndex(nifs, 0, [0])
     g.insert_many([("a", [0.0, 0.0]), ("b", [1.0, 0.0]), ("c", [2.0, 0.0])])
     assert [h[0] for h in g.search([0.9, 0.0], 2)] == [b"b", b"a"]
-    monkeypatch.setenv("VT_TEST_EXCHANGE_STALL_MS", "1500")
+    vt_debug.set("test_exchange_stall_ms", 1500)
     t0 = time.perf_counter()
     res = nifs.flat_search(g.ref, [0.9, 0.0], 2)
     waited = time.perf_counter() - t0
     assert res[0] == "error" and "RCCL exchange timed out on shard 0" in res[1], res
     assert 0.2 < waited < 1.2, waited
-    monkeypatch.delenv("VT_TEST_EXCHANGE_STALL_MS")
+    vt_debug.reset("test_exchange_stall_ms")
     assert nifs.flat_search(g.ref, [0.9, 0.0], 2) == ("error", "flat lock poisoned")
     assert nifs.flat_insert(g.ref, "d", [3.0, 0.0]) == ("error", "flat lock poisoned")
     time.sleep(1.6)                                         # the injected stall ends; the stream drains before the handle goes
@@ -328,14 +328,14 @@ def test_a_wedged_exchange_times_out_with_a_message(nifs, oracle_mod, monkeypatc
     assert fresh.search([1.0, 1.0], 1) == [(b"x", 0.0)]
 
 
-def test_concurrent_searches_over_the_rccl_exchange_keep_their_own_lists(nifs, oracle_mod, monkeypatch):
+def test_concurrent_searches_over_the_rccl_exchange_keep_their_own_lists(nifs, oracle_mod, monkeypatch, vt_debug):
     """Searches run under the shared lock, so two callers can be in the RCCL leg at once: their jobs
     pass through every shard's worker in one order, but each caller merges on its own thread --
     from its own copy of the gathered lists (shard 0's pinned buffer is refilled by the next job).
     Eight threads, distinct queries, every answer checked."""
-    monkeypatch.setenv("VT_SHARD_FORCE_WORKERS", "1")
-    monkeypatch.setenv("VT_SHARD_EXCHANGE", "rccl")
-    monkeypatch.setenv("VT_COALESCE", "0")          # every caller runs its own search_multi
+    vt_debug.set("shard_force_workers", 1)
+    vt_debug.set("shard_exchange", 2)
+    vt_debug.set("coalesce", 0)          # every caller runs its own search_multi
     n, d = 20_000, 64
     x, ids = make_corpus(n, d, 78, True, oracle_mod, tie_block=30)
     g = ShardedIndex(nifs, 2, [0])
@@ -501,7 +501,7 @@ def test_bench_runs_as_the_driver_invokes_it_for_two_gpus():
 
 
 @pytest.mark.parametrize("devices", [[0], [0, 0]])
-def test_a_mutation_that_dies_half_way_poisons_the_handle(nifs, oracle_mod, devices, monkeypatch, request):
+def test_a_mutation_that_dies_half_way_poisons_the_handle(nifs, oracle_mod, devices, monkeypatch, request, vt_debug):
     """nifs.rs:266-309: a panic under the write lock poisons the RwLock and every later NIF call
     returns {:error, "flat lock poisoned"}.  Here: a device failure after a mutation began changing
     the index (injected between the id table's update and the rows' arrival).  Validation errors
@@ -516,10 +516,10 @@ def test_a_mutation_that_dies_half_way_poisons_the_handle(nifs, oracle_mod, devi
     with pytest.raises(GpuError, match="non-finite"):
         g.insert_many([("d", [1.0, 1.0]), ("e", [float("nan"), 0.0])])
     assert [h[0] for h in g.search([0.9, 0.0], 2)] == [b"b", b"a"] and len(g) == 3      # still healthy
-    monkeypatch.setenv("VT_TEST_FAIL_AFTER_ID_UPDATE", "1")
+    vt_debug.set("test_fail_after_id_update", 1)
     res = nifs.flat_insert(g.ref, "d", [3.0, 0.0])
     assert res[0] == "error" and "injected" in res[1]
-    monkeypatch.delenv("VT_TEST_FAIL_AFTER_ID_UPDATE")
+    vt_debug.reset("test_fail_after_id_update")
     for res in (nifs.flat_search(g.ref, [0.9, 0.0], 2), nifs.flat_insert(g.ref, "e", [4.0, 0.0]),
                 nifs.flat_delete(g.ref, "a"), nifs.flat_search_batch(g.ref, np.zeros((2, 2), np.float32), 1),
                 nifs.flat_quantized_search(g.ref, [0.9, 0.0], 3, 2)):

@@ -659,7 +659,7 @@ def test_hybrid_search_matches_oracle_composition(nifs, oracle_mod, metric):
 
 
 @pytest.mark.parametrize("metric", [2, 0, 1, 3, 5, 6, 7, 8])
-def test_hybrid_device_chain_equals_host_composition(nifs, oracle_mod, metric, monkeypatch):
+def test_hybrid_device_chain_equals_host_composition(nifs, oracle_mod, metric, monkeypatch, vt_debug):
     """hybrid_search with every generator <= 256 candidates can run as ONE device chain (generator
     blocks -> union of rows -> exact rerank; one host wait; opt-in, VT_HYBRID_CHAIN=1, because it
     measured no faster): its hits equal the default host-composed path's bit for bit, for every metric, generator mix and overlap, on a corpus large
@@ -684,10 +684,10 @@ def test_hybrid_device_chain_equals_host_composition(nifs, oracle_mod, metric, m
                     q = oracle_mod.normalize_l2(q)
                 q[:2] = x[n // 2][:2]
                 nifs.flat_get_profile(g.ref, reset=True)
-                monkeypatch.setenv("VT_HYBRID_CHAIN", "1")
+                vt_debug.set("hybrid_chain", 1)
                 got = nifs.flat_hybrid_search(g.ref, q, gens, limit)
                 chains = nifs.flat_get_profile(g.ref, reset=True)["hybrid_device_chains"]
-                monkeypatch.delenv("VT_HYBRID_CHAIN")
+                vt_debug.reset("hybrid_chain")
                 want = nifs.flat_hybrid_search(g.ref, q, gens, limit)
                 assert nifs.flat_get_profile(g.ref, reset=True)["hybrid_device_chains"] == 0
                 assert got[0] == want[0] == "ok", (metric, gens, got, want)
@@ -695,9 +695,9 @@ def test_hybrid_device_chain_equals_host_composition(nifs, oracle_mod, metric, m
                 assert chains == 1, (metric, n, gens, limit)
         # beyond what one chain holds: the host-composed path serves it
         nifs.flat_get_profile(g.ref, reset=True)
-        monkeypatch.setenv("VT_HYBRID_CHAIN", "1")
+        vt_debug.set("hybrid_chain", 1)
         unwrap(nifs.flat_hybrid_search(g.ref, q, [(nifs.GEN_SEARCH, 300, [])], 10))
-        monkeypatch.delenv("VT_HYBRID_CHAIN")
+        vt_debug.reset("hybrid_chain")
         assert nifs.flat_get_profile(g.ref, reset=True)["hybrid_device_chains"] == 0
 
 
@@ -721,13 +721,13 @@ NOMINATE = {"f32": 1, "bf16": 2}   # VT_NOMINATE_*: which matrix-core pass names
 
 @pytest.mark.parametrize("nominate", ["bf16", "f32"])
 @pytest.mark.parametrize("metric", [2, 3, 4, 0, 1, 5])
-def test_batched_search_equals_single_queries(nifs, oracle_mod, metric, nominate, monkeypatch):
+def test_batched_search_equals_single_queries(nifs, oracle_mod, metric, nominate, monkeypatch, vt_debug):
     """vt_flat_search_batch: dot-family metrics go through a matrix-core candidate pass (K2b:
     operands rounded to bf16, the default; K2: FP32 matrix cores) + exact rescoring; every query
     must still equal the oracle bit for bit under both (BASELINE.json configs[2] shape, scaled
     down).  L2 / L2^2 nominate by 2 q.x - |x|^2; manhattan has no GEMM form and takes the
     per-query path."""
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")   # the cost model would send these small corpora to single scans
+    vt_debug.set("force_batch_mfma", 1)   # the cost model would send these small corpora to single scans
     n, d = 20000, 192
     x, ids = make_corpus(n, d, 500 + metric, metric == 2, oracle_mod, tie_block=48)
     packed = oracle_mod.pack_ids(ids)
@@ -737,14 +737,18 @@ def test_batched_search_equals_single_queries(nifs, oracle_mod, metric, nominate
     unwrap(nifs.flat_load_matrix(g.ref, ids, x))
     rng = np.random.default_rng(8)
     nifs.flat_set_profiling(g.ref, True)
-    for nq, k in ((8, 10), (37, 1), (100, 10), (128, 3), (256, 10), (300, 64)):
+    # (600 and 4 096: three and sixteen groups of 256 in one call -- consecutive groups alternate between two contexts,
+    # group g + 1 queued before group g is waited for; SURVEY 8d writes config 3 as "16 batches x 256")
+    for nq, k in ((8, 10), (37, 1), (100, 10), (128, 3), (256, 10), (300, 64), (600, 10), (4096, 10)):
         qs = rng.uniform(-1, 1, size=(nq, d)).astype(np.float32)
         qs[0] = x[n // 2]  # sits on the block of identical rows
         if metric == 2:
             qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
         got = unwrap(nifs.flat_search_batch(g.ref, qs, k))
         assert len(got) == nq
-        for i in range(nq):
+        # (the largest batch: the first and last query of every group and every fifth in between against the oracle)
+        check = range(nq) if nq <= 600 else sorted(set(range(0, nq, 5)) | set(range(255, nq, 256)) | set(range(0, nq, 256)))
+        for i in check:
             assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, x, packed, qs[i], k)), (metric, nq, k, i)
     prof = nifs.flat_get_profile(g.ref)
     key = "nominate" if nominate == "bf16" else "batch"
@@ -763,10 +767,10 @@ def test_batched_search_equals_single_queries(nifs, oracle_mod, metric, nominate
 
 
 @pytest.mark.parametrize("nominate", ["bf16", "f32"])
-def test_batched_search_large_values_fall_back_safely(nifs, oracle_mod, nominate, monkeypatch):
+def test_batched_search_large_values_fall_back_safely(nifs, oracle_mod, nominate, monkeypatch, vt_debug):
     """Huge coordinates blow the error margin (or overflow the MFMA sum): the
     bound must refuse and the per-query path must still give the exact answer."""
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    vt_debug.set("force_batch_mfma", 1)
     scale = 1e18
     n, d = 6000, 64
     rng = np.random.default_rng(21)
@@ -783,12 +787,12 @@ def test_batched_search_large_values_fall_back_safely(nifs, oracle_mod, nominate
 
 
 @pytest.mark.parametrize("nominate", ["bf16", "f32"])
-def test_rows_that_round_to_infinity_in_bf16_are_not_lost(nifs, oracle_mod, nominate, monkeypatch):
+def test_rows_that_round_to_infinity_in_bf16_are_not_lost(nifs, oracle_mod, nominate, monkeypatch, vt_debug):
     """A coordinate at f32's largest value rounds to +inf in bf16; against a query that is zero
     there the exact dot product is finite (and these rows are the best hits), the bf16 one is
     inf * 0 = NaN and nominates nothing.  The handle knows its largest row norm: such a corpus
     is never certified by K2b, the exact paths answer."""
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    vt_debug.set("force_batch_mfma", 1)
     n, d = 6000, 64
     rng = np.random.default_rng(22)
     x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
@@ -811,13 +815,13 @@ def test_rows_that_round_to_infinity_in_bf16_are_not_lost(nifs, oracle_mod, nomi
 
 
 @pytest.mark.parametrize("metric", [2, 3, 0])
-def test_bf16_nomination_second_pass(nifs, oracle_mod, metric, monkeypatch):
+def test_bf16_nomination_second_pass(nifs, oracle_mod, metric, monkeypatch, vt_debug):
     """K2b with a threshold that leaves no margin (VT_BF16_RANK = limit: tau is the k-th best
     bf16 score itself): the bound cannot certify anything in the first pass, every query names
     the threshold its k exact hits DO clear, and one more pass with those certifies them all --
     same hits as the oracle, no query left to the single-query path."""
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
-    monkeypatch.setenv("VT_BF16_RANK", "10")
+    vt_debug.set("force_batch_mfma", 1)
+    vt_debug.set("bf16_rank", 10)
     n, d = 30000, 256
     x, ids = make_corpus(n, d, 900 + metric, metric == 2, oracle_mod, tie_block=0)
     packed = oracle_mod.pack_ids(ids)
@@ -1021,11 +1025,11 @@ def test_quantized_histogram_pass_survives_dimension_changes(nifs, oracle_mod):
         assert len(g) == 0 and g.dimension is None
 
 
-def test_padding_columns_of_a_small_batch_nominate_nothing(nifs, oracle_mod, monkeypatch):
+def test_padding_columns_of_a_small_batch_nominate_nothing(nifs, oracle_mod, monkeypatch, vt_debug):
     """A batch of 8 is padded to 32 query columns; the all-zero padding columns once passed
     every row as a candidate.  Parity of the small batch here; the timing guard that caught
     it lives in tests/test_gpu_perf.py (-m gpu_perf)."""
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    vt_debug.set("force_batch_mfma", 1)
     n, d = 300_000, 128
     rng = np.random.default_rng(5)
     x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
@@ -1044,20 +1048,20 @@ def test_padding_columns_of_a_small_batch_nominate_nothing(nifs, oracle_mod, mon
 
 
 @pytest.fixture
-def force_threshold(monkeypatch):
+def force_threshold(monkeypatch, vt_debug):
     """The library picks the threshold path by a cost model (large corpora); the parity tests
     force it so that it runs at oracle-sized inputs too.  getenv is read per call."""
-    monkeypatch.setenv("VT_FORCE_THRESHOLD_SELECT", "1")
+    vt_debug.set("force_threshold_select", 1)
 
 
 @pytest.mark.parametrize("forced", [True, False])
 @pytest.mark.parametrize("metric", [2, 0, 5])
-def test_limits_above_256_in_one_scan(nifs, oracle_mod, metric, forced, monkeypatch):
+def test_limits_above_256_in_one_scan(nifs, oracle_mod, metric, forced, monkeypatch, vt_debug):
     """Above 65 536 rows a limit of 257..4096 is answered from a key column and a radix
     threshold instead of one scan per 256 hits; 5 000 still takes the pass-per-256 loop.
     Both must equal the oracle's full sort, ties by id bytes included."""
     if forced:
-        monkeypatch.setenv("VT_FORCE_THRESHOLD_SELECT", "1")
+        vt_debug.set("force_threshold_select", 1)
     n, d = 70_000, 24
     x, ids = make_corpus(n, d, 1200 + metric, metric == 2, oracle_mod, tie_block=600)
     g = GpuIndex(nifs, metric)
@@ -1254,11 +1258,11 @@ def test_equal_keys_among_unranked_rows(nifs, oracle_mod):
         assert bits(g.search(q, k)) == bits(o.search(q, k)), k
 
 
-def test_derived_data_is_patched_after_mutations(nifs, oracle_mod, monkeypatch):
+def test_derived_data_is_patched_after_mutations(nifs, oracle_mod, monkeypatch, vt_debug):
     """Sign bits (quantized_search) and row norms (batched L2) are kept per row and patched for the
     rows an insert / upsert / delete touched instead of being rebuilt; every search in between
     must still agree with the oracle."""
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    vt_debug.set("force_batch_mfma", 1)
     n, d = 20_000, 64
     rng = np.random.default_rng(404)
     x = rng.uniform(-1, 1, (n + 200, d)).astype(np.float32)
@@ -1537,11 +1541,11 @@ def test_funnel_batches_of_the_k1_families_share_the_prefix_sweep(nifs, oracle_m
 
 
 @pytest.mark.parametrize("metric", [2, 0, 5])
-def test_concurrent_funnel_callers_share_sweeps(nifs, oracle_mod, monkeypatch, metric):
+def test_concurrent_funnel_callers_share_sweeps(nifs, oracle_mod, monkeypatch, metric, vt_debug):
     """funnel_search callers that meet on one handle (cosine: K6bm; L2 / manhattan: K1p) travel in groups -- only
     those with the same stages and candidates together; every answer equals the call made alone."""
     import threading
-    monkeypatch.setenv("VT_COALESCE_SLOTS", "1")
+    vt_debug.set("coalesce_slots", 1)
     n, d = 40_000, 128
     x, ids = make_corpus(n, d, 4600 + metric, metric == 2, oracle_mod)
     g = GpuIndex(nifs, metric)
@@ -1596,11 +1600,11 @@ def test_quantized_groups_with_massive_ties_fall_back(nifs, oracle_mod):
         assert bits(got[i]) == bits(unwrap(nifs.flat_quantized_search(g.ref, qs[i], 100, 10)))
 
 
-def test_concurrent_quantized_callers_share_sweeps(nifs, oracle_mod, monkeypatch):
+def test_concurrent_quantized_callers_share_sweeps(nifs, oracle_mod, monkeypatch, vt_debug):
     """quantized_search callers that meet on one handle (collection.ex:276-295 under the read lock)
     travel in groups like plain searches do; every answer equals the call made alone."""
     import threading
-    monkeypatch.setenv("VT_COALESCE_SLOTS", "1")
+    vt_debug.set("coalesce_slots", 1)
     n, d = 40_000, 128
     x, ids = make_corpus(n, d, 4200, True, oracle_mod)
     g = GpuIndex(nifs, 2)
@@ -1697,13 +1701,13 @@ def test_pattern_metrics_read_the_non_zero_bits(nifs, oracle_mod, metric, d):
         check()
 
 
-def test_no_room_for_the_non_zero_bits_means_reading_the_rows(nifs, oracle_mod, request, monkeypatch):
+def test_no_room_for_the_non_zero_bits_means_reading_the_rows(nifs, oracle_mod, request, monkeypatch, vt_debug):
     """The non-zero-bit column is an accelerator: when the card has no room for it the searches keep
     reading the rows, with the same hits.  (The refused allocation is injected --
     VT_TEST_REFUSE_NZBITS, libvettore_hip_hooks.so only: the test re-runs itself there.)"""
     if support.rerun_with_hooks_library(request):
         return
-    monkeypatch.setenv("VT_TEST_REFUSE_NZBITS", "1")
+    vt_debug.set("test_refuse_nzbits", 1)
     n, d = 20_000, 100
     rng = np.random.default_rng(77)
     x = (rng.uniform(-1, 1, (n, d)) * (rng.uniform(0, 1, (n, d)) < 0.4)).astype(np.float32)
@@ -1721,11 +1725,11 @@ def test_no_room_for_the_non_zero_bits_means_reading_the_rows(nifs, oracle_mod, 
 
 
 @pytest.mark.parametrize("metric", [7, 8])
-def test_concurrent_pattern_metric_callers_share_sweeps(nifs, oracle_mod, metric, monkeypatch):
+def test_concurrent_pattern_metric_callers_share_sweeps(nifs, oracle_mod, metric, monkeypatch, vt_debug):
     """flat_search callers that meet on a float hamming / jaccard handle travel as a batch, and the batch
     is sweeps of the non-zero-bit column (K4p); every answer equals the call made alone and the oracle's."""
     import threading
-    monkeypatch.setenv("VT_COALESCE_SLOTS", "1")
+    vt_debug.set("coalesce_slots", 1)
     n, d = 30_000, 256
     rng = np.random.default_rng(900 + metric)
     x = (rng.uniform(-1, 1, (n, d)) * (rng.uniform(0, 1, (n, d)) < 0.3)).astype(np.float32)

@@ -12,9 +12,9 @@ from test_gpu_parity import GpuIndex, bits, make_corpus, nifs, unwrap  # noqa: F
 pytestmark = pytest.mark.gpu_perf
 
 
-def test_small_batch_costs_no_more_than_a_full_one(nifs, monkeypatch):
+def test_small_batch_costs_no_more_than_a_full_one(nifs, monkeypatch, vt_debug):
     """A batch of 8 (padded to 32 columns) once cost 45x a batch of 32."""
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    vt_debug.set("force_batch_mfma", 1)
     n, d = 300_000, 128
     rng = np.random.default_rng(5)
     x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
@@ -116,7 +116,7 @@ def test_readers_on_one_handle_overlap(nifs, oracle_mod):
     assert large[1] > 0.95 * large[0], large
 
 
-def test_callers_that_meet_travel_together(nifs, monkeypatch):
+def test_callers_that_meet_travel_together(nifs, monkeypatch, vt_debug):
     """on a corpus a pass over which takes a millisecond, 16 callers side by side
     share the card's bandwidth (no more queries/s than one caller); coalesced they share the
     passes.  Floor: twice the side-by-side rate (measured: 5-7x)."""
@@ -133,7 +133,7 @@ def test_callers_that_meet_travel_together(nifs, monkeypatch):
     _throughput(nifs, g, qs, 16, 0.3)
     together = _throughput(nifs, g, qs, 16)
     stats = nifs.flat_coalesce_stats(g.ref)
-    monkeypatch.setenv("VT_COALESCE", "0")
+    vt_debug.set("coalesce", 0)
     apart = _throughput(nifs, g, qs, 16)
     print("16 callers, queries/s: together %.0f, side by side %.0f; batches %d carrying %d" % (together, apart, stats[0], stats[1]))
     assert together > 2 * apart and stats[0] > 0

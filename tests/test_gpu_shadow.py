@@ -27,10 +27,10 @@ def check_batch(nifs, oracle_mod, g, metric, x, ids, qs, k, note=""):
 
 @pytest.mark.parametrize("metric", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("d", [192, 100])
-def test_batches_from_the_shadow_equal_the_oracle(nifs, oracle_mod, metric, d, monkeypatch):
+def test_batches_from_the_shadow_equal_the_oracle(nifs, oracle_mod, metric, d, monkeypatch, vt_debug):
     """All five matrix-core metrics, rows on and off the 64-float grid (d = 100 pads to 128), the
     three pass widths (64 / 128 / 256 query columns), a trailing group, limits 1..64."""
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")   # the cost model would send these small corpora to single scans
+    vt_debug.set("force_batch_mfma", 1)   # the cost model would send these small corpora to single scans
     n = 20000
     x, ids = make_corpus(n, d, 4100 + metric, metric == 2, oracle_mod, tie_block=48)
     g = GpuIndex(nifs, metric)
@@ -54,11 +54,11 @@ def test_batches_from_the_shadow_equal_the_oracle(nifs, oracle_mod, metric, d, m
     assert prof["nominate_bytes"] == prof["nominate_launches"] * n * d * 2, prof
 
 
-def test_mutations_patch_the_shadow(nifs, oracle_mod, monkeypatch):
+def test_mutations_patch_the_shadow(nifs, oracle_mod, monkeypatch, vt_debug):
     """Upserts, deletes (swap with the last row), appends past the slab's capacity, emptying and
     re-dimensioning: the shadow follows (patched rows, rebuilds) and the batches keep equalling
     the oracle over the current rows."""
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    vt_debug.set("force_batch_mfma", 1)
     n, d = 9000, 128
     metric = 3
     x, ids = make_corpus(n, d, 4242, False, oracle_mod, tie_block=20)
@@ -113,8 +113,8 @@ def test_mutations_patch_the_shadow(nifs, oracle_mod, monkeypatch):
     assert prof["nominate_shadow_launches"] == prof["nominate_launches"] >= 5, prof
 
 
-def test_an_emptied_index_gives_the_shadow_back(nifs, oracle_mod, monkeypatch):
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+def test_an_emptied_index_gives_the_shadow_back(nifs, oracle_mod, monkeypatch, vt_debug):
+    vt_debug.set("force_batch_mfma", 1)
     n, d = 6000, 64
     x, ids = make_corpus(n, d, 77, False, oracle_mod)
     g = GpuIndex(nifs, 0)
@@ -135,9 +135,9 @@ def test_an_emptied_index_gives_the_shadow_back(nifs, oracle_mod, monkeypatch):
     assert nifs.flat_batch_shadow(g.ref) == "current"
 
 
-def test_the_shadow_switched_off_and_on(nifs, oracle_mod, monkeypatch):
+def test_the_shadow_switched_off_and_on(nifs, oracle_mod, monkeypatch, vt_debug):
     """VT_SHADOW_OFF: the pass streams the f32 rows (K2b) -- same hits; switching it back on builds anew."""
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    vt_debug.set("force_batch_mfma", 1)
     n, d = 12000, 192
     x, ids = make_corpus(n, d, 9, True, oracle_mod, tie_block=30)
     g = GpuIndex(nifs, 2)
@@ -165,14 +165,14 @@ def test_the_shadow_switched_off_and_on(nifs, oracle_mod, monkeypatch):
     assert nifs.flat_batch_shadow(g.ref) == "none"
 
 
-def test_no_room_for_the_shadow_means_streaming_the_rows(nifs, oracle_mod, request, monkeypatch):
+def test_no_room_for_the_shadow_means_streaming_the_rows(nifs, oracle_mod, request, monkeypatch, vt_debug):
     """The shadow is an accelerator: when the card has no room for it the batches keep reading the f32
     rows, with the same hits.  (The refused allocation is injected -- VT_TEST_REFUSE_SHADOW,
     libvettore_hip_hooks.so only: the test re-runs itself there.)"""
     if support.rerun_with_hooks_library(request):
         return
-    monkeypatch.setenv("VT_TEST_REFUSE_SHADOW", "1")
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    vt_debug.set("test_refuse_shadow", 1)
+    vt_debug.set("force_batch_mfma", 1)
     n, d = 10000, 128
     x, ids = make_corpus(n, d, 31, False, oracle_mod)
     g = GpuIndex(nifs, 1)
@@ -186,11 +186,11 @@ def test_no_room_for_the_shadow_means_streaming_the_rows(nifs, oracle_mod, reque
     assert prof["nominate_launches"] == 2 and prof["nominate_shadow_launches"] == 0 and prof["shadow_builds"] == 0, prof
 
 
-def test_rows_that_round_to_infinity_through_the_shadow(nifs, oracle_mod, monkeypatch):
+def test_rows_that_round_to_infinity_through_the_shadow(nifs, oracle_mod, monkeypatch, vt_debug):
     """f32's largest values round to +inf in bf16 -- in the shadow as in K2b's registers: inf * 0 = NaN
     nominates nothing, the handle's largest row norm keeps such a corpus from ever being certified,
     the exact paths answer."""
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
+    vt_debug.set("force_batch_mfma", 1)
     n, d = 6000, 64
     rng = np.random.default_rng(22)
     x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
@@ -206,12 +206,12 @@ def test_rows_that_round_to_infinity_through_the_shadow(nifs, oracle_mod, monkey
     check_batch(nifs, oracle_mod, g, 3, x, ids, qs, 5)
 
 
-def test_concurrent_callers_travel_through_the_shadow(nifs, oracle_mod, monkeypatch):
+def test_concurrent_callers_travel_through_the_shadow(nifs, oracle_mod, monkeypatch, vt_debug):
     """flat_search callers that meet on a handle go as one batch (vt_coalesce.h); with a shadow that
     batch is a K2s pass, and a reader that finds the shadow stale escalates once to patch it."""
     import threading
-    monkeypatch.setenv("VT_FORCE_BATCH_MFMA", "1")
-    monkeypatch.setenv("VT_COALESCE_SLOTS", "1")
+    vt_debug.set("force_batch_mfma", 1)
+    vt_debug.set("coalesce_slots", 1)
     n, d = 30000, 256
     x, ids = make_corpus(n, d, 61, True, oracle_mod, tie_block=16)
     packed = oracle_mod.pack_ids(ids)

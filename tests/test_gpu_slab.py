@@ -23,8 +23,8 @@ def _check(g, o, qs, limits=(1, 10, 40)):
 
 
 @pytest.mark.parametrize("devices", [None, [0, 0]])
-def test_slab_grows_by_mapping_chunks(nifs, oracle_mod, monkeypatch, devices):
-    monkeypatch.setenv("VT_SLAB_CHUNK_MB", "2")
+def test_slab_grows_by_mapping_chunks(nifs, oracle_mod, monkeypatch, devices, vt_debug):
+    vt_debug.set("slab_chunk_mb", 2)
     d, row_bytes = 64, 256
     rng = np.random.default_rng(21)
     g = GpuIndex(nifs, 0)
@@ -80,15 +80,15 @@ def test_slab_grows_by_mapping_chunks(nifs, oracle_mod, monkeypatch, devices):
     assert g.search(np.ones(200, np.float32), 1) == [(b"fresh", 0.0)]
 
 
-def test_forced_plain_allocation_gives_the_same_answers(nifs, oracle_mod, monkeypatch):
-    monkeypatch.setenv("VT_SLAB_CHUNK_MB", "2")
+def test_forced_plain_allocation_gives_the_same_answers(nifs, oracle_mod, monkeypatch, vt_debug):
+    vt_debug.set("slab_chunk_mb", 2)
     d = 96
     rng = np.random.default_rng(5)
     x = rng.uniform(-1, 1, (30_000, d)).astype(np.float32)
     ids = [b"v-%d" % i for i in range(len(x))]
     a = GpuIndex(nifs, 2)
     unwrap(nifs.flat_load_matrix(a.ref, ids, x))
-    monkeypatch.setenv("VT_SLAB", "malloc")
+    vt_debug.set("slab", 1)
     b = GpuIndex(nifs, 2)
     unwrap(nifs.flat_load_matrix(b.ref, ids, x))
     want_chunks = -(-(30_016 * 128 * 4) // CHUNK)      # rows are padded to 128 floats; capacity in whole 32-row tiles
@@ -163,7 +163,7 @@ def test_large_appends_leave_the_ranking_to_the_next_search(nifs, oracle_mod):
 
 
 @pytest.mark.parametrize("d", [64, 40])
-def test_rows_from_another_device_reach_a_mapped_slab_through_a_staging_block(nifs, oracle_mod, monkeypatch, d, request):
+def test_rows_from_another_device_reach_a_mapped_slab_through_a_staging_block(nifs, oracle_mod, monkeypatch, d, request, vt_debug):
     """Only the owning device is given access to a mapped slab's chunks, so rows resident on
     another GPU of the node are first copied into an ordinary buffer on this one and placed from
     there (`VT_TEST_FOREIGN_ROWS` makes the one GPU of this box count as "another"): appends,
@@ -172,8 +172,8 @@ def test_rows_from_another_device_reach_a_mapped_slab_through_a_staging_block(ni
     if support.rerun_with_hooks_library(request):   # (VT_TEST_FOREIGN_ROWS only exists in libvettore_hip_hooks.so)
         return
     import torch
-    monkeypatch.setenv("VT_SLAB_CHUNK_MB", "2")
-    monkeypatch.setenv("VT_TEST_FOREIGN_ROWS", "1")
+    vt_debug.set("slab_chunk_mb", 2)
+    vt_debug.set("test_foreign_rows", 1)
     rng = np.random.default_rng(3)
     n = 30_000
     x = rng.uniform(-1, 1, (n, d)).astype(np.float32)

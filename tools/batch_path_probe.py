@@ -17,9 +17,9 @@ from bench import build_shard, doc_ids  # noqa: E402
 
 WAYS = {
     "default": {},
-    "k2": {"VT_NO_MULTI_SCAN": "1"},
-    "k1m": {"VT_BATCH_NO_MFMA": "1"},
-    "singles": {"VT_NO_MULTI_SCAN": "1", "VT_BATCH_NO_MFMA": "1"},
+    "k2": {"no_multi_scan": 1},
+    "k1m": {"batch_no_mfma": 1},
+    "singles": {"no_multi_scan": 1, "batch_no_mfma": 1},
 }
 
 
@@ -41,9 +41,8 @@ def main():
                 qs /= np.linalg.norm(qs, axis=1, keepdims=True)
                 row = {"d": d, "rows": n, "metric": metric, "nq": nq}
                 for way, env in WAYS.items():
-                    for k in ("VT_NO_MULTI_SCAN", "VT_BATCH_NO_MFMA"):
-                        os.environ.pop(k, None)
-                    os.environ.update(env)
+                    for k in ("no_multi_scan", "batch_no_mfma"):   # (vt_debug_set: the environment is read once, at load)
+                        nifs.debug_set(k, env.get(k, 0))
                     for _ in range(3):
                         r = nifs.flat_search_batch(ref, qs, 10)
                     assert r[0] == "ok"
@@ -52,8 +51,8 @@ def main():
                     for _ in range(reps):
                         nifs.flat_search_batch(ref, qs, 10)
                     row[way + "_us"] = round((time.perf_counter() - t0) / reps * 1e6)
-                for k in ("VT_NO_MULTI_SCAN", "VT_BATCH_NO_MFMA"):
-                    os.environ.pop(k, None)
+                for k in ("no_multi_scan", "batch_no_mfma"):
+                    nifs.debug_set(k, 0)
                 best = min(row[w + "_us"] for w in ("k2", "k1m", "singles"))
                 row["default_over_best"] = round(row["default_us"] / best, 2)
                 print(json.dumps(row), flush=True)

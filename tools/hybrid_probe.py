@@ -36,10 +36,7 @@ def main():
     per = calls // rounds
     for r in range(rounds + 1):
         for mode in ("chain", "host"):
-            if mode == "chain":
-                os.environ["VT_HYBRID_CHAIN"] = "1"
-            else:
-                os.environ.pop("VT_HYBRID_CHAIN", None)
+            nifs.debug_set("hybrid_chain", 1 if mode == "chain" else 0)
             t0 = time.perf_counter()
             for q in qs[20 + (r % rounds) * per: 20 + (r % rounds) * per + per]:
                 results[mode] = nifs.flat_hybrid_search(ref, q, gens, 10)

@@ -66,7 +66,7 @@ def big():
     L.vt_hits_free(h)
     for label, env in (("lazy", None), ("eager", "1")):
         if env:
-            os.environ["VT_EAGER_RANKS"] = env
+            nifs.debug_set("eager_ranks", int(env))
         t0 = time.perf_counter()
         for i in range(30):
             id_ = b"new-%s-%d" % (label.encode(), i)

@@ -21,7 +21,7 @@ L = _lib.load()
 def main():
     rows = int(os.environ.get("ROWS", 2_000_000))
     dim = int(os.environ.get("DIM", 768))
-    os.environ["VT_BATCH_NO_MFMA"] = "1"
+    nifs.debug_set("batch_no_mfma", 1)
     rng = np.random.default_rng(0)
     for metric in (int(m) for m in os.environ.get("METRICS", "5,2,0,7").split(",")):
         x = build_shard(torch, torch.device("cuda", 0), rows, dim, 99)

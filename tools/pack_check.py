@@ -1,9 +1,9 @@
 import os, sys
 sys.path.insert(0, os.getcwd())
-os.environ["VT_BATCH_NO_MFMA"] = "1"; os.environ["VT_FORCE_MULTI_SCAN"] = "1"
 import torch
 import numpy as np
 from vettore_amd import nifs
+nifs.debug_set("batch_no_mfma", 1); nifs.debug_set("force_multi_scan", 1)
 rng = np.random.default_rng(1)
 for metric in (0, 3):
   for d in (64, 128, 320, 384, 576, 640, 832, 896):

@@ -23,7 +23,7 @@ def main():
     rows = int(os.environ.get("ROWS", 10_000_000))
     dim = int(os.environ.get("DIM", 768))
     prefixes = [int(v) for v in os.environ.get("PREFIXES", "64,128,256,%d" % dim).split(",")]
-    os.environ["VT_BATCH_NO_MFMA"] = "1"
+    nifs.debug_set("batch_no_mfma", 1)
     rng = np.random.default_rng(0)
     x = build_shard(torch, torch.device("cuda", 0), rows, dim, 99)
     for metric in (int(m) for m in os.environ.get("METRICS", "3,0,5").split(",")):

@@ -73,12 +73,9 @@ def main():
     for threads in (int(v) for v in os.environ.get("THREADS", "1,2,4,8,16,32,64").split(",")):
         row = {"rows": n, "dim": d, "threads": threads}
         for label, env in (("coalesced", None), ("side_by_side", "0")):
-            if env is None:
-                os.environ.pop("VT_COALESCE", None)
-            else:
-                os.environ["VT_COALESCE"] = env
+            nifs.debug_set("coalesce", 1 if env is None else int(env))
             row[label] = run(ref, qs, threads, seconds, d, limit)
-        os.environ.pop("VT_COALESCE", None)
+        nifs.debug_set("coalesce", 1)
         row["gain"] = round(row["coalesced"]["qps"] / max(1e-9, row["side_by_side"]["qps"]), 2)
         print(json.dumps(row), flush=True)
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak of round 4's grouped paths on corpora large enough to take them (>= 16 384 rows): funnel batches under every
-metric (K6bm / K1p / the bit column's prefix), plain batches as K1p sweeps (VT_FORCE_SWEEP_GROUPS), after random
+metric (K6bm / K1p / the bit column's prefix), plain batches as K1p sweeps (vt_debug_set "force_sweep_groups"), after random
 mutations -- every answer against the same call made alone, two per batch against the oracle's composition.
 SECONDS / SEED / METRICS env.  Prints one line per run and a summary; diagnostic only (tests/ hold the fixed cases)."""
 import os
@@ -11,10 +11,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("VT_FORCE_SWEEP_GROUPS", "1")
-os.environ.setdefault("VT_BATCH_NO_MFMA", "1")     # (the matrix cores have their own soak: tools/soak_all.py with larger batches)
 import oracle  # noqa: E402
 from vettore_amd import nifs  # noqa: E402
+nifs.debug_set("force_sweep_groups", 1)
+nifs.debug_set("batch_no_mfma", 1)     # (the matrix cores have their own soak: tools/soak_all.py with larger batches)
 
 
 def bits(hits):

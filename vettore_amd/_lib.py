@@ -22,7 +22,7 @@ EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1
 
 # every symbol include/vettore_flat.h declares
 SYMBOLS = [
-    "vt_strerror", "vt_last_error", "vt_abi_version", "vt_device_count", "vt_device_read_peak",
+    "vt_strerror", "vt_last_error", "vt_abi_version", "vt_device_count", "vt_device_read_peak", "vt_debug_set", "vt_debug_get",
     "vt_hits_len", "vt_hits_id", "vt_hits_raw", "vt_hits_rank_key", "vt_hits_pack", "vt_hits_pack_many", "vt_hit_blocks_merge", "vt_hits_id_bytes", "vt_hits_export",
     "vt_hits_free", "vt_hits_free_many",
     "vt_flat_new", "vt_flat_new_sharded", "vt_flat_shard_count", "vt_flat_shard_device", "vt_flat_shard_len", "vt_flat_shard_memory", "vt_flat_coalesce_stats",
@@ -35,7 +35,7 @@ SYMBOLS = [
     "vt_flat_set_profiling", "vt_flat_get_profile", "vt_flat_get_profile_sized",
     "vt_flat_set_batch_shadow", "vt_flat_batch_shadow", "vt_flat_set_single_nominate", "vt_flat_single_nominate",
 ]
-ABI_VERSION = 3  # VT_ABI_VERSION of the include/vettore_flat.h this file was written against
+ABI_VERSION = 4  # VT_ABI_VERSION of the include/vettore_flat.h this file was written against
 
 
 class Profile(C.Structure):
@@ -158,6 +158,8 @@ def load() -> C.CDLL:
     L.vt_flat_batch_shadow.argtypes = [vp]
     L.vt_flat_set_single_nominate.argtypes = [vp, C.c_int]
     L.vt_flat_single_nominate.argtypes = [vp]
+    L.vt_debug_set.argtypes = [C.c_char_p, C.c_long]
+    L.vt_debug_get.argtypes = [C.c_char_p, C.POINTER(C.c_long)]
     # a library built from another header would be handed structs of the wrong size
     if L.vt_abi_version() != ABI_VERSION:
         raise ImportError("%s speaks ABI version %d, this binding %d: rebuild with `make`"

@@ -8,52 +8,30 @@ namespace {
 thread_local std::string g_last_error;
 // Lane order of wide::f32x8::reduce_add assumed for new indexes (include/vettore_flat.h;
 // DESIGN.md "summation order" says why SSE2 and how to pin it): VT_REDUCE_ORDER overrides.
-int initial_order() {
-  const char *e = std::getenv("VT_REDUCE_ORDER");
-  if (e) {
-    const std::string v(e);
-    if (v == "pair" || v == "0") return VT_ORDER_PAIR;
-    if (v == "avx" || v == "1") return VT_ORDER_AVX;
-    if (v == "seq" || v == "2") return VT_ORDER_SEQ;
-    if (v == "sse2" || v == "3") return VT_ORDER_SSE2;
-  }
-  return VT_ORDER_SSE2;
-}
-int g_default_order = initial_order();
+// (every VT_* variable is read once, when the library is loaded: csrc/vt_env.h)
+static_assert(VT_ORDER_PAIR == 0 && VT_ORDER_AVX == 1 && VT_ORDER_SEQ == 2 && VT_ORDER_SSE2 == 3, "vt_env.h parses VT_REDUCE_ORDER to these");
+inline int default_order() { return (int)vt::env::get(vt::env::REDUCE_ORDER); }  // (vt_set_default_reduce_order stores there)
 
 // Which matrix-core pass nominates a batch's candidates: K2b (operands
 // rounded to bf16, HBM-bound) unless VT_BATCH_NOMINATE=f32 asks for K2.  Results are the same
 // bit for bit either way -- the exact kernel decides.
-int initial_nominate() {
-  const char *e = std::getenv("VT_BATCH_NOMINATE");
-  if (e && (std::string(e) == "f32" || std::string(e) == "1")) return VT_NOMINATE_F32;
-  return VT_NOMINATE_BF16;
-}
-int g_default_nominate = initial_nominate();
+static_assert(VT_NOMINATE_F32 == 1 && VT_NOMINATE_BF16 == 2, "vt_env.h parses VT_BATCH_NOMINATE to these");
+inline int default_nominate() { return (int)vt::env::get(vt::env::BATCH_NOMINATE); }
 // Whether new indexes keep a bf16 shadow of their rows for that pass (include/vettore_flat.h,
 // vt_flat_set_batch_shadow): VT_BATCH_SHADOW=0 says no.
-int initial_shadow() {
-  const char *e = std::getenv("VT_BATCH_SHADOW");
-  if (e && (std::string(e) == "0" || std::string(e) == "off")) return VT_SHADOW_OFF;
-  return VT_SHADOW_AUTO;
-}
-int g_default_shadow = initial_shadow();
-int g_default_single_nominate = [] {
-  const char *e = std::getenv("VT_SINGLE_NOMINATE");
-  return e && e[0] == '1' ? 1 : 0;
-}();
+static_assert(VT_SHADOW_OFF == 0 && VT_SHADOW_AUTO == 1, "vt_env.h parses VT_BATCH_SHADOW to these");
+inline int default_shadow() { return (int)vt::env::get(vt::env::BATCH_SHADOW); }
+inline int default_single_nominate() { return vt::env::get(vt::env::SINGLE_NOMINATE) == 1 ? 1 : 0; }
 // smallest sample rank K2b's threshold is taken from (VT_BF16_MIN_RANK: tools/nominate_probe.py sweeps it).
 // The count of rows passing a threshold taken at sample rank r is Gamma(r)-distributed around its
 // mean: at r = 4 one query in ~700 drew a threshold so high that its k-th hit could not clear it by
 // the margin (one 5-ms single scan per three or four 256-query batches at 10 M x 768); at r = 6 none
 // did in 15 000 queries, for +50 % candidates (+0.07 ms in the scoring pass's append path, +0.08 ms
 // of re-scoring).  Per 256-query batch, measured: r = 4: 6.20 ms, 6: 6.09, 8: 6.23, 12: 6.39.
-uint32_t initial_bf16_min_rank() {
-  const char *e = std::getenv("VT_BF16_MIN_RANK");
-  const int v = e ? std::atoi(e) : 0;
+uint32_t bf16_min_rank() {
+  const long v = vt::env::get(vt::env::BF16_MIN_RANK);
   return v >= 1 && v <= 4096 ? (uint32_t)v : 6u;
 }
-uint32_t g_bf16_min_rank = initial_bf16_min_rank();
 
 int fail(int status, const std::string &detail) {
   g_last_error = detail;
@@ -317,13 +295,11 @@ struct Slab {
     chunks.clear();
   }
   static size_t chunk_bytes() {
-    const char *e = std::getenv("VT_SLAB_CHUNK_MB");  // (tests: small chunks, so that small corpora cross chunk borders)
-    const long mb = e ? std::atol(e) : 0;
+    const long mb = vt::env::get(vt::env::SLAB_CHUNK_MB);  // (tests: small chunks, so that small corpora cross chunk borders)
     return mb > 0 ? (size_t)mb << 20 : (size_t)1 << 30;
   }
   static bool mapping_allowed() {
-    const char *e = std::getenv("VT_SLAB");
-    return !(e && std::strcmp(e, "malloc") == 0);
+    return vt::env::get(vt::env::SLAB) != 1;  // (VT_SLAB=malloc)
   }
   // Maps chunks until `want` bytes are usable.  Failure leaves what was mapped before intact.
   int map_up_to(size_t want, int device) {

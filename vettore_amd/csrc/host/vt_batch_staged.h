@@ -17,14 +17,31 @@ namespace {
 // a sample.  retry_tau (first pass only): for every query the bound could not certify but whose
 // k exact hits exist, the threshold with which a second pass is certain to certify it (NaN
 // where there is none).
-int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit, vt_hits **out, std::vector<char> &done,
-                bool bf16, const float *tau_given, std::vector<float> *retry_tau) {
+//
+// Two phases, so that consecutive groups of one call overlap (batch_ready): batch_group_queue stages the
+// queries and queues every kernel and copy of the group on the context's stream without waiting for any of
+// it; batch_group_finish waits for that stream, judges every query and builds the accepted ones' hit lists.
+// Between the two the context belongs to the group (its pinned blocks are the group's upload and results).
+struct BatchGroupRun {
+  const float *queries = nullptr;
+  size_t nq = 0, limit = 0;
+  bool bf16 = false, shadow = false, tau_given = false;
+  uint32_t k = 0, nq_pad = 0, cand_cap = 0;
+  std::vector<double> qnorm;
+  std::chrono::steady_clock::time_point t_begin;
+  double t_staged = 0, t_queued = 0;
+};
+
+// `idle_cus` (consecutive groups of one call, batch_ready): the pass over the rows leaves that many CUs without a block
+// of its own.  K2s keeps one block per CU resident from the first row to the last (all of the CU's LDS), so whatever
+// else is queued meanwhile -- the previous group's exact rescoring and select, the next group's sample pass and
+// thresholds -- runs between two passes unless some CUs are left for it.
+int batch_group_queue(Shard *ix, Ctx &c, BatchGroupRun &run, const float *queries, size_t nq, size_t limit, bool bf16,
+                      const float *tau_given, uint32_t idle_cus = 0) {
   const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
   const uint32_t k = (uint32_t)std::min<size_t>(limit, n);
-  static const bool trace = std::getenv("VT_TRACE_BATCH") != nullptr;  // phases of a group on stderr
   const auto t_begin = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-  double t_staged = 0, t_queued = 0, t_synced = 0;
   uint32_t nq_pad = bf16 ? vt::batch_bf16_pad((uint32_t)nq) : 32;
   while (nq_pad < nq) nq_pad *= 2;
   // K2s: the pass reads the bf16 shadow of the rows when the shard keeps a current one (half the bytes, no
@@ -50,18 +67,16 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   const double ratio = (double)sample_rows / (double)n;
   const double want_cand = bf16 ? std::min(32.0 * k, std::max(8.0 * k, 4096.0)) : 8.0 * k;
   uint32_t rank = (uint32_t)std::ceil(want_cand * std::min(1.0, ratio));
-  rank = std::max<uint32_t>(bf16 ? g_bf16_min_rank : 3, std::min<uint32_t>(rank, std::min<uint32_t>(sample_rows, n)));
-  // test hook: VT_BF16_RANK=<r> takes K2b's threshold from exactly the r-th best sample score
+  rank = std::max<uint32_t>(bf16 ? bf16_min_rank() : 3, std::min<uint32_t>(rank, std::min<uint32_t>(sample_rows, n)));
+  // test hook (vt_debug_set "bf16_rank"): K2b's threshold from exactly the r-th best sample score
   // (r = limit leaves no margin at all: every query then needs the second pass)
-  if (bf16)
-    if (const char *e = std::getenv("VT_BF16_RANK")) {
-      const int v = std::atoi(e);
-      if (v >= 1) rank = std::min<uint32_t>((uint32_t)v, std::min<uint32_t>(sample_rows, n));
-    }
+  if (bf16) {
+    const long v = vt::env::get(vt::env::BF16_RANK);
+    if (v >= 1) rank = std::min<uint32_t>((uint32_t)v, std::min<uint32_t>(sample_rows, n));
+  }
   const uint32_t cand_cap = 8192;
-  static const uint32_t kBlocksPerQuery = [] {  // blocks of the exact rescoring per query (VT_RESCORE_BLOCKS: A/B)
-    const char *e = std::getenv("VT_RESCORE_BLOCKS");
-    const int v = e ? std::atoi(e) : 0;
+  const uint32_t kBlocksPerQuery = [] {  // blocks of the exact rescoring per query (VT_RESCORE_BLOCKS: A/B)
+    const long v = vt::env::get(vt::env::RESCORE_BLOCKS);
     return v >= 1 && v <= 64 ? (uint32_t)v : 8u;
   }();
 
@@ -81,10 +96,21 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   VT_TRY(c.dPartPay.ensure((size_t)nq_pad * kBlocksPerQuery * k));
   if (bf16) VT_TRY(c.dBQimage.ensure(std::max(vt::batch_bf16_image_bytes(ld), vt::batch_shadow_image_bytes(ld))));
 
-  std::vector<double> qnorm(nq);  // (filled while the device works: see below)
+  run.queries = queries;
+  run.nq = nq;
+  run.limit = limit;
+  run.bf16 = bf16;
+  run.shadow = shadow;
+  run.tau_given = tau_given != nullptr;
+  run.k = k;
+  run.nq_pad = nq_pad;
+  run.cand_cap = cand_cap;
+  run.t_begin = t_begin;
+  std::vector<double> &qnorm = run.qnorm;  // (filled while the device works: see below)
+  qnorm.assign(nq, 0.0);
   std::memset(c.hBQ.p, 0, (size_t)nq_pad * ld * sizeof(float));
   for (size_t i = 0; i < nq; ++i) std::memcpy(c.hBQ.p + i * ld, queries + i * d, (size_t)d * sizeof(float));
-  t_staged = since();
+  run.t_staged = since();
   VT_HIP(hipMemcpyAsync(c.dBQ.p, c.hBQ.p, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, c.stream));
   vt::BatchScoreArgs a{};
   a.X = ix->dX;
@@ -130,7 +156,7 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   a.cand_cap = cand_cap;
   VT_HIP(hipMemsetAsync(c.dBCount.p, 0, (size_t)nq_pad * sizeof(uint32_t), c.stream));
   if (c.profiling) VT_HIP(hipEventRecord(c.ev2, c.stream));
-  VT_HIP(scores(false, std::min<uint32_t>(ntiles_total, grid_cap)));
+  VT_HIP(scores(false, std::min<uint32_t>(ntiles_total, shadow && idle_cus < grid_cap / 2 ? grid_cap - idle_cus : grid_cap)));
   if (c.profiling) VT_HIP(hipEventRecord(c.ev3, c.stream));
   // exact rescoring of every query's candidates with the K1 arithmetic
   vt::ScanArgs sa{};
@@ -159,16 +185,29 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   if (!tau_given) VT_HIP(hipMemcpyAsync(c.hBTau.p, c.dBTau.p, (size_t)nq_pad * sizeof(float), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(hipMemcpyAsync(&c.hBOutCount.p[nq_pad], c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
-  t_queued = since();
+  run.t_queued = since();
   // the queries' norms (the acceptance bound needs them): 0.1 ms of host work per 256 x 768, done
-  // while the device runs its 6 ms
+  // while the device runs its 4 ms
   for (size_t i = 0; i < nq; ++i) {
     double s = 0.0;
     for (uint32_t j = 0; j < d; ++j) s += (double)queries[i * d + j] * (double)queries[i * d + j];
     qnorm[i] = std::sqrt(s);
   }
+  return VT_OK;
+}
+
+// `done[i]` is set for every query of the group whose exact top-k was proven complete (its hits are in out[i]).
+int batch_group_finish(Shard *ix, Ctx &c, BatchGroupRun &run, vt_hits **out, std::vector<char> &done, std::vector<float> *retry_tau) {
+  const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
+  const size_t nq = run.nq;
+  const bool bf16 = run.bf16, shadow = run.shadow, tau_given = run.tau_given;
+  const uint32_t k = run.k, nq_pad = run.nq_pad, cand_cap = run.cand_cap;
+  const std::vector<double> &qnorm = run.qnorm;
+  const bool l2_family = ix->metric == VT_L2 || ix->metric == VT_L2_SQUARED;
+  const bool trace = vt::env::on(vt::env::TRACE_BATCH);  // phases of a group on stderr
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - run.t_begin).count(); };
   VT_HIP(hipStreamSynchronize(c.stream));
-  t_synced = since();
+  const double t_synced = since();
   const int status = (int)c.hBOutCount.p[nq_pad];
   if (c.profiling) {
     float ms = 0.f;
@@ -262,7 +301,7 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
         float t = (float)tau2;
         if ((double)t > tau2) t = std::nextafterf(t, -INFINITY);
         // (only a lower bar than the one that failed can help, and only a list that did not overflow)
-        if (tau_given == nullptr && (double)t < tau && cnt <= cand_cap) (*retry_tau)[i] = t;
+        if (!tau_given && (double)t < tau && cnt <= cand_cap) (*retry_tau)[i] = t;
       }
       continue;
     }
@@ -278,14 +317,30 @@ int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit
   }
   if (trace)
     std::fprintf(stderr, "[vt] batch group nq=%zu %s: staged %.3f ms, queued %.3f, device done %.3f, hits built %.3f\n", nq,
-                 bf16 ? "bf16" : "f32", t_staged, t_queued, t_synced, since());
+                 bf16 ? "bf16" : "f32", run.t_staged, run.t_queued, t_synced, since());
+  (void)ld;
+  (void)n;
   return VT_OK;
+}
+
+constexpr uint32_t kBatchTailCus = 0;
+
+// One group, start to end, on one context.
+int batch_group(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t limit, vt_hits **out, std::vector<char> &done,
+                bool bf16, const float *tau_given, std::vector<float> *retry_tau) {
+  BatchGroupRun run;
+  const int st = batch_group_queue(ix, c, run, queries, nq, limit, bf16, tau_given);
+  if (st != VT_OK) {
+    (void)hipStreamSynchronize(c.stream);  // (whatever was queued reads the context's pinned blocks)
+    return st;
+  }
+  return batch_group_finish(ix, c, run, out, done, retry_tau);
 }
 
 // K1m serves a batch when every query's list fits its small wave buffers.
 bool multi_scan_applies(const Shard *ix, size_t limit) {
   return limit >= 1 && std::min<size_t>(limit, ix->n) <= vt::scan_multi_max_k(vt::kMultiMaxQueries) &&
-         !(ix->metric == VT_JACCARD && ix->dim >= 4096) && std::getenv("VT_NO_MULTI_SCAN") == nullptr;
+         !(ix->metric == VT_JACCARD && ix->dim >= 4096) && !vt::env::on(vt::env::NO_MULTI_SCAN);
 }
 double multi_scan_seconds(const Shard *ix, size_t nq) {
   const double sweeps = std::ceil((double)nq / vt::kMultiMaxQueries);
@@ -341,8 +396,7 @@ int multi_scan_group(Shard *ix, Ctx &c, const float *queries, const std::vector<
     a.k = k;
     a.nq = gn;
     a.first_query = (uint32_t)g0;
-    static const uint32_t dbg = std::getenv("VT_MQ_DBG") ? (uint32_t)std::atoi(std::getenv("VT_MQ_DBG")) : 0u;
-    a.dbg = dbg;
+    a.dbg = (uint32_t)vt::env::get(vt::env::MQ_DBG);
     for (uint32_t i = 0; i < gn; ++i) a.q_nonzero[i] = qnz[g0 + i];
     a.part_keys = c.dPartKeys.p;
     a.part_pay = c.dPartPay.p;
@@ -383,7 +437,7 @@ bool pattern_group_applies(const Shard *ix, size_t limit) {
   const uint32_t words = ((uint32_t)ix->dim + 63) / 64;
   return pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit) && limit >= 1 &&
          std::min<size_t>(limit, ix->n) <= (size_t)vt::kSmallK && vt::pattern_multi_supports((words + 1) / 2) &&
-         std::getenv("VT_NO_PATTERN_GROUPS") == nullptr;
+         !vt::env::on(vt::env::NO_PATTERN_GROUPS);
 }
 
 // `count` queries (rows `which[i]` of `queries`) in ceil(count / 8) sweeps of the non-zero-bit
@@ -466,8 +520,8 @@ bool batch_uses_mfma(const Shard *ix, size_t nq, size_t limit) {
   // one shared pass over the corpus costs about 1.3 single scans (HBM-bound below 33 queries),
   // so it pays from two queries on
   bool use_mfma = mfma_metric && nq >= 2 && limit <= (size_t)vt::kMaxFusedK && limit > 0 && ix->n >= 4096 &&
-                  std::getenv("VT_BATCH_NO_MFMA") == nullptr;
-  if (use_mfma && !std::getenv("VT_FORCE_BATCH_MFMA")) {  // (tests force the shared pass on small corpora)
+                  !vt::env::on(vt::env::BATCH_NO_MFMA);
+  if (use_mfma && !vt::env::on(vt::env::FORCE_BATCH_MFMA)) {  // (tests force the shared pass on small corpora)
     // nq single scans against one shared pass (K2: HBM-bound below ~33 queries, then MFMA-bound;
     // K2b: HBM-bound at every batch size)
     const double bytes = (double)ix->n * ix->ld * 4.0;
@@ -502,10 +556,10 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
 // buffers 32.  So: rows off K1m's panel grid, or lists K1m cannot hold; from 64 MB of rows (six launches and a
 // sample pass instead of two launches).
 bool sweep_group_applies(const Shard *ix, size_t limit) {
-  if (!vt::prefix_multi_supports(ix->metric) || std::getenv("VT_NO_SWEEP_GROUPS")) return false;
+  if (!vt::prefix_multi_supports(ix->metric) || vt::env::on(vt::env::NO_SWEEP_GROUPS)) return false;
   const size_t stage = (size_t)ix->dim;
   if (!funnel_group_applies(ix, &stage, 1, limit, limit)) return false;
-  if (std::getenv("VT_FORCE_SWEEP_GROUPS")) return true;  // (tests and soaks on corpora of a few MB)
+  if (vt::env::on(vt::env::FORCE_SWEEP_GROUPS)) return true;  // (tests and soaks on corpora of a few MB)
   if ((double)ix->n * ix->ld * 4.0 < 64e6) return false;
   return ix->ld % 256 != 0 || !multi_scan_applies(ix, limit);
 }
@@ -527,14 +581,56 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
   const bool bf16 = batch_nominates_bf16(ix);
   if (use_mfma) {
     std::vector<float> tau2(nq, std::numeric_limits<float>::quiet_NaN());
+    std::vector<std::pair<size_t, size_t>> groups;  // (first query, queries)
     for (size_t g0 = 0; g0 < nq; g0 += 256) {
       const size_t gn = std::min<size_t>(256, nq - g0);
-      if (gn < 2) continue;  // a lone trailing query takes the single-query path below
-      std::vector<char> gdone(gn, 0);
-      std::vector<float> gtau;
-      VT_TRY(batch_group(ix, c, queries + g0 * d, gn, limit, out + g0, gdone, bf16, nullptr, bf16 ? &gtau : nullptr));
-      for (size_t i = 0; i < gn; ++i) done[g0 + i] = gdone[i];
-      for (size_t i = 0; i < gtau.size(); ++i) tau2[g0 + i] = gtau[i];
+      if (gn >= 2) groups.emplace_back(g0, gn);  // a lone trailing query takes the single-query path below
+    }
+    // Several groups (config 3 as BASELINE.json writes it is 16 x 256 in one call): they alternate between this
+    // context and a second one, and group g + 1 is staged and queued BEFORE group g is waited for -- its upload,
+    // sample pass and threshold kernel run beside group g's exact rescoring and select, its pass over the rows
+    // starts the moment the card is free, and group g's host side (the wait, 256 verdicts, 256 hit lists: 0.25 ms
+    // of a 4.4-ms group) runs under it.  Each group's results are what it gives alone: nothing is shared but the card.
+    SpareCtxLease spare(groups.size() >= 2 && !vt::env::on(vt::env::NO_GROUP_PIPELINE) ? ix : nullptr);
+    Ctx *cx[2] = {&c, spare.c ? spare.c : &c};
+    BatchGroupRun runs[2];
+    auto settle = [&](size_t g, const std::vector<char> &gdone, const std::vector<float> &gtau) {
+      for (size_t i = 0; i < groups[g].second; ++i) done[groups[g].first + i] = gdone[i];
+      for (size_t i = 0; i < gtau.size(); ++i) tau2[groups[g].first + i] = gtau[i];
+    };
+    if (!spare.c) {
+      for (size_t g = 0; g < groups.size(); ++g) {
+        std::vector<char> gdone(groups[g].second, 0);
+        std::vector<float> gtau;
+        VT_TRY(batch_group(ix, c, queries + groups[g].first * d, groups[g].second, limit, out + groups[g].first, gdone, bf16, nullptr,
+                           bf16 ? &gtau : nullptr));
+        settle(g, gdone, gtau);
+      }
+    } else {
+      // (VT_BATCH_TAIL_CUS: CUs every pass but the last leaves to the groups around it; measured in DESIGN 5.1)
+      const long tail_cus = vt::env::get(vt::env::BATCH_TAIL_CUS);
+      const uint32_t idle = tail_cus >= 0 ? (uint32_t)tail_cus : kBatchTailCus;
+      auto queue = [&](size_t g) {
+        return batch_group_queue(ix, *cx[g & 1], runs[g & 1], queries + groups[g].first * d, groups[g].second, limit, bf16, nullptr,
+                                 idle);
+      };
+      int st = queue(0);
+      for (size_t g = 0; g < groups.size() && st == VT_OK; ++g) {
+        const int st_next = g + 1 < groups.size() ? queue(g + 1) : VT_OK;
+        std::vector<char> gdone(groups[g].second, 0);
+        std::vector<float> gtau;
+        st = batch_group_finish(ix, *cx[g & 1], runs[g & 1], out + groups[g].first, gdone, bf16 ? &gtau : nullptr);
+        if (st == VT_OK) settle(g, gdone, gtau);
+        if (st == VT_OK) st = st_next;
+      }
+      if (st != VT_OK) {  // (whatever is still queued reads and writes the two contexts' pinned blocks)
+        const std::string why = g_last_error;
+        (void)hipStreamSynchronize(cx[0]->stream);
+        (void)hipStreamSynchronize(cx[1]->stream);
+        (void)hipGetLastError();
+        g_last_error = why;
+        return st;
+      }
     }
     // K2b's second pass: a query whose k exact hits did not clear tau by the margin names the
     // threshold that its k-th hit does clear; one more pass over the rows with those thresholds
@@ -607,7 +703,7 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
   }
   if (!by_pattern && left.size() >= 2 && multi_scan_applies(ix, limit) &&
       (multi_scan_seconds(ix, left.size()) < (double)left.size() * scan_seconds((double)ix->n * ix->ld * 4.0) ||
-       std::getenv("VT_FORCE_MULTI_SCAN"))) {  // (tests force the sweep on corpora of a few thousand rows)
+       vt::env::on(vt::env::FORCE_MULTI_SCAN))) {  // (tests force the sweep on corpora of a few thousand rows)
     const int st = multi_scan_group(ix, c, queries, left, limit, out);
     if (st == VT_OK) return VT_OK;
     if (st != kRetryInternal) return st;
@@ -734,7 +830,7 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
   // K4h needs integer bins in LDS, one fused select, and enough rows to be worth two passes
   const bool hist_ok = ncand <= (size_t)vt::kSelListMax && d <= vt::kHammingHistMaxDim &&
                        (ix->n >= 16384 || ncand > (size_t)vt::kMaxFusedK) &&
-                       !std::getenv("VT_HAMMING_LISTS");
+                       !vt::env::on(vt::env::HAMMING_LISTS);
   auto run = [&](bool use_hist) -> int {
   std::vector<vt::Entry> entries, first;
   bool first_in_block = false;
@@ -847,8 +943,8 @@ bool quantized_group_applies(const Shard *ix, size_t candidates, size_t limit) {
   // (jaccard: the rerank's non-zero count of the query is one launch argument, so those go query by query -- said
   // here, before a sweep of the bit matrix has been spent on finding out)
   return ix->metric != VT_JACCARD && ix->n >= 16384 && ncand >= 1 && ncand <= (size_t)vt::kMaxFusedK && limit >= 1 && d <= vt::kHammingHistMaxDim &&
-         vt::hamming_multi_lds_bytes(d, (d + 63) / 64, 2) <= 64 * 1024 && !std::getenv("VT_HAMMING_LISTS") &&
-         !std::getenv("VT_NO_QUANTIZED_GROUPS") &&
+         vt::hamming_multi_lds_bytes(d, (d + 63) / 64, 2) <= 64 * 1024 && !vt::env::on(vt::env::HAMMING_LISTS) &&
+         !vt::env::on(vt::env::NO_QUANTIZED_GROUPS) &&
          (ix->metric == VT_COSINE ? (size_t)2 * ((d + 3) / 4 * 4) * 4 <= 160 * 1024 : vt::scan_lds_bytes(d, (uint32_t)std::min<size_t>(limit, ncand)) != 0);
 }
 // queries per sweep: what the nq histograms leave room for in 64 KiB of LDS
@@ -1088,7 +1184,7 @@ int quantized_batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, si
     // host side (staging 8 queries and their sign bits, the wait, 8 hit lists: 0.1 of its 0.38 ms)
     // then runs while the device is busy with the groups around it.  (Not while profiling: the
     // stage timing keeps one pair of events per context.)
-    if (groups.size() >= 2 && groups.size() <= 32 && !c.profiling && !std::getenv("VT_NO_GROUP_PIPELINE")) {
+    if (groups.size() >= 2 && groups.size() <= 32 && !c.profiling && !vt::env::on(vt::env::NO_GROUP_PIPELINE)) {
       const uint32_t nslots = (uint32_t)groups.size();
       const uint32_t k2 = (uint32_t)std::min<size_t>(limit, std::min<size_t>(candidates, ix->n));
       std::vector<int> queued(groups.size(), VT_OK);
@@ -1109,7 +1205,7 @@ int quantized_batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, si
       for (const auto &which : groups) {
         const auto tg = std::chrono::steady_clock::now();
         const int st = quantized_group(ix, c, queries, which, candidates, limit, out);
-        if (std::getenv("VT_TRACE_QGROUP"))
+        if (vt::env::on(vt::env::TRACE_QGROUP))
           std::fprintf(stderr, "[vt] quantized group of %zu: status %d, %.3f ms\n", which.size(), st,
                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg).count());
         VT_TRY(settle(which, st));
@@ -1203,7 +1299,7 @@ int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *
 // `candidates` rows IS the single path's stage), later stages and the rerank are K1's batch mode over the
 // candidates (queries on grid.y), the arithmetic the single path's scan_stage_dev runs.
 bool funnel_group_applies(const Shard *ix, const size_t *stages, size_t nstages, size_t candidates, size_t limit) {
-  if (nstages == 0 || std::getenv("VT_NO_FUNNEL_GROUPS")) return false;
+  if (nstages == 0 || vt::env::on(vt::env::NO_FUNNEL_GROUPS)) return false;
   if (ix->metric != VT_COSINE && !vt::prefix_multi_supports(ix->metric)) return false;
   const size_t k1 = std::min<size_t>(candidates, ix->n);
   if (ix->n < 16384 || k1 == 0 || k1 > (size_t)vt::kMaxFusedK || limit == 0) return false;
@@ -1481,7 +1577,7 @@ bool hybrid_fits_device(const Shard *ix, const int *kinds, const size_t *candida
   // funnel + quantized + search generators of 100 candidates, tools/hybrid_probe.py): the generators'
   // waits cost ~15 us each against 0.7 ms of scans, and the chain pays them back in a union kernel
   // and a rerank sized for the worst case.  profiles/r03/hybrid_probe.jsonl.
-  if (!std::getenv("VT_HYBRID_CHAIN") || ngen == 0 || ngen > 8 || limit > (size_t)vt::kMaxFusedK) return false;
+  if (!vt::env::on(vt::env::HYBRID_CHAIN) || ngen == 0 || ngen > 8 || limit > (size_t)vt::kMaxFusedK) return false;
   if (ix->metric == VT_JACCARD && ix->dim >= 4096) return false;
   const uint32_t d = (uint32_t)ix->dim;
   for (size_t i = 0; i < ngen; ++i) {
@@ -1505,7 +1601,7 @@ int hybrid_dev(Shard *ix, Ctx &c, const float *query, const int *kinds, const si
   const uint32_t d = (uint32_t)ix->dim;
   uint32_t cap = 0;  // the union holds at most every generator's candidates
   for (size_t g = 0; g < ngen; ++g) cap += (uint32_t)std::min<size_t>(candidates[g], ix->n);
-  static const bool trace = std::getenv("VT_TRACE_HYBRID") != nullptr;  // phases of a chain on stderr
+  const bool trace = vt::env::on(vt::env::TRACE_HYBRID);  // phases of a chain on stderr
   const auto t_begin = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
   VT_TRY(c.dStageB.ensure(ngen));
@@ -1539,7 +1635,7 @@ int hybrid_dev(Shard *ix, Ctx &c, const float *query, const int *kinds, const si
         count = want;
       }
     } else if (kinds[g] == VT_GEN_QUANTIZED) {
-      const bool hist = d <= vt::kHammingHistMaxDim && ix->n >= 16384 && !std::getenv("VT_HAMMING_LISTS");
+      const bool hist = d <= vt::kHammingHistMaxDim && ix->n >= 16384 && !vt::env::on(vt::env::HAMMING_LISTS);
       VT_TRY(hamming_stage_dev(ix, c, cand, hist, dst, &timed_hamming));
     } else {
       VT_TRY(scan_stage_dev(ix, c, d, nullptr, ix->n, cand, qnz_full, dst, false));

@@ -22,13 +22,12 @@ namespace {
 // corpus of a few MB are all fixed cost -- there every reader context runs side by side and
 // only the callers beyond them travel together (tools/reader_probe.cpp).
 unsigned coalesce_slots(uint64_t corpus_bytes) {
-  if (const char *e = std::getenv("VT_COALESCE_SLOTS")) return (unsigned)std::max(1, std::atoi(e));
+  if (const long v = vt::env::get(vt::env::COALESCE_SLOTS)) return (unsigned)std::max<long>(1, v);
   return corpus_bytes < (64ull << 20) ? (unsigned)kMaxContexts : corpus_bytes < (1ull << 30) ? 2u : 1u;
 }
 
 bool coalescing_enabled() {
-  const char *e = std::getenv("VT_COALESCE");
-  return !(e && e[0] == '0');
+  return vt::env::on(vt::env::COALESCE);  // (VT_COALESCE=0)
 }
 
 // vt_host::Waiting::kind; aux = candidates (quantized) / index into the handle's funnel shapes (funnel)
@@ -87,12 +86,11 @@ struct CoalesceOps {
   // a matrix-core pass carries up to 256 plain searches of the dot / L2 family; everything else
   // rides in groups of eight per sweep (K1m, the grouped Hamming and prefix passes)
   static size_t capacity(vt_flat *h, int kind) {
-    static const bool no_gather = std::getenv("VT_COALESCE_GATHER") && std::getenv("VT_COALESCE_GATHER")[0] == '0';  // A/B
-    if (no_gather) return 0;
+    if (!vt::env::on(vt::env::COALESCE_GATHER)) return 0;  // (VT_COALESCE_GATHER=0: A/B)
     if (kind != COALESCE_SEARCH) return 8;
     const int m = h->metric;
     const bool gemm = m == VT_COSINE || m == VT_INNER_PRODUCT || m == VT_NEG_INNER_PRODUCT || m == VT_L2 || m == VT_L2_SQUARED;
-    return gemm && !std::getenv("VT_BATCH_NO_MFMA") ? 256 : 8;
+    return gemm && !vt::env::on(vt::env::BATCH_NO_MFMA) ? 256 : 8;
   }
   static void run(vt_flat *h, std::vector<vt_host::Waiting *> &members) { vt_host::run_coalesced_t<vt_flat, CoalesceOps>(h, members); }
   static void drop_hits(vt_hits *hits) { delete hits; }

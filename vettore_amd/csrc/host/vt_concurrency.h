@@ -162,6 +162,42 @@ struct LeaseT {
   LeaseT &operator=(const LeaseT &) = delete;
 };
 
+// A SECOND context for a reader that already holds one (consecutive groups of one batch call alternate
+// between two: DESIGN 4.5): a spare or a new one -- never the primary (the holder may be using it without a
+// lease, under the exclusive lock or on a shard's worker) and never a wait (two readers each holding one
+// context and waiting for a second would wait for ever): `c` stays null when there is none to be had, and
+// the caller goes on with the one context it has.
+template <class Holder, class Ctx>
+struct SpareLeaseT {
+  Holder *ix;
+  Ctx *c = nullptr;
+  int status = 0;
+  template <class Make>
+  SpareLeaseT(Holder *s, size_t max_contexts, Make make) : ix(s) {  // (s == nullptr: none wanted)
+    if (!ix) return;
+    std::unique_lock<std::mutex> g(ix->pool_mu);
+    if (!ix->free_ctx.empty()) {
+      c = ix->free_ctx.back();
+      ix->free_ctx.pop_back();
+    } else if (ix->extra.size() + 1 < max_contexts) {
+      std::unique_ptr<Ctx> nc = make(ix, &status);
+      if (!nc) return;
+      c = nc.get();
+      ix->extra.push_back(std::move(nc));
+    }
+  }
+  ~SpareLeaseT() {
+    if (!c) return;
+    {
+      std::lock_guard<std::mutex> g(ix->pool_mu);
+      ix->free_ctx.push_back(c);
+    }
+    ix->pool_cv.notify_one();
+  }
+  SpareLeaseT(const SpareLeaseT &) = delete;
+  SpareLeaseT &operator=(const SpareLeaseT &) = delete;
+};
+
 // ---------------------------------------------------------------------------- coalescer
 // Searches that arrive while another one is running wait for it and then go TOGETHER: one sweep
 // of the corpus answers up to eight of them (K1m), a matrix-core pass up to 256 (K2b), where the

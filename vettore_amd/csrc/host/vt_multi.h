@@ -250,9 +250,8 @@ int exchange_setup(vt_flat *h) {
 // On expiry the handle is poisoned: its streams still hold the stuck collective, nothing queued
 // behind it will ever run.  A fresh process is the only retry.
 int wait_exchange(vt_flat *h, Ctx &c, size_t shard) {
-  static const long timeout_ms = [] {
-    const char *e = std::getenv("VT_EXCHANGE_TIMEOUT_MS");
-    const long v = e ? std::atol(e) : 0;
+  const long timeout_ms = [] {
+    const long v = vt::env::get(vt::env::EXCHANGE_TIMEOUT_MS);
     return v > 0 ? v : 20000L;
   }();
   const auto t0 = std::chrono::steady_clock::now();
@@ -281,8 +280,7 @@ int wait_exchange(vt_flat *h, Ctx &c, size_t shard) {
 // (libvettore_hip_hooks.so only) VT_TEST_EXCHANGE_STALL_MS=<ms>: the shard's stream waits that long
 // on a flag before its all-gather -- what a peer that never arrives looks like from here
 int test_stall_exchange(Ctx &c) {
-  const char *e = std::getenv("VT_TEST_EXCHANGE_STALL_MS");
-  const long ms = e ? std::atol(e) : 0;
+  const long ms = vt::env::get(vt::env::TEST_EXCHANGE_STALL_MS);
   if (ms <= 0) return VT_OK;
   uint32_t *flag = nullptr, *dflag = nullptr;
   VT_HIP(hipHostMalloc(reinterpret_cast<void **>(&flag), sizeof(uint32_t), hipHostMallocMapped));
@@ -499,7 +497,7 @@ int funnel_rows_multi(vt_flat *h, const float *query, size_t n, const size_t *st
 // exactly those rows and orders them.  One fan-out instead of one per stage.  A shard that
 // reports a metric overflow may have met it on a row the handle-wide set does not contain
 // (the reference would not have looked at it): such a call is redone round by round, below.
-bool staged_one_round() { return std::getenv("VT_STAGED_ROUNDS") == nullptr; }  // (tests force the round-per-stage path)
+bool staged_one_round() { return !vt::env::on(vt::env::STAGED_ROUNDS); }  // (tests force the round-per-stage path)
 
 std::vector<size_t> shards_with_rows(const vt_flat *h) {
   std::vector<size_t> which;

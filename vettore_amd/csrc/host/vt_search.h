@@ -19,7 +19,7 @@ bool lazy_ranks_ok(const Shard *ix, size_t limit) {
   // (one select pass only: very wide rows leave LDS for the small candidate buffer alone)
   const size_t kmax = vt::scan_lds_bytes((uint32_t)ix->dim, vt::kMaxFusedK) ? (size_t)vt::kMaxFusedK : (size_t)vt::kSmallK;
   return !ix->ranks_clean && !ix->external_ranks && lazy_want <= kmax &&
-         ix->unranked <= std::max<size_t>(65536, ix->n / 8) && !std::getenv("VT_EAGER_RANKS");
+         ix->unranked <= std::max<size_t>(65536, ix->n / 8) && !vt::env::on(vt::env::EAGER_RANKS);
 }
 
 // Float hamming and jaccard compare which coordinates are non-zero and nothing else
@@ -30,8 +30,8 @@ bool lazy_ranks_ok(const Shard *ix, size_t limit) {
 // NEED_NZBITS asks for that column and means nothing where this says no.
 constexpr size_t kPatternMinRows = 16384, kPatternMaxWant = 8 * (size_t)vt::kMaxFusedK;
 bool pattern_metric(int metric) {
-  static const bool off = std::getenv("VT_NO_PATTERN_BITS") != nullptr;  // (A/B and the parity tests' second leg)
-  return (metric == VT_HAMMING || metric == VT_JACCARD) && !off;
+  // (VT_NO_PATTERN_BITS: A/B and the parity tests' second leg)
+  return (metric == VT_HAMMING || metric == VT_JACCARD) && !vt::env::on(vt::env::NO_PATTERN_BITS);
 }
 bool pattern_search_applies(const Shard *ix, size_t limit) {
   return pattern_metric(ix->metric) && !ix->nz_refused && ix->n >= kPatternMinRows &&
@@ -528,7 +528,7 @@ int index_ensure_bits(Shard *ix, bool nonzero) {
     bool refused = col.ensure(bwords) != VT_OK;
 #ifdef VT_TEST_HOOKS
     // (libvettore_hip_hooks.so only: the allocation "fails", tests/test_gpu_parity.py checks what follows)
-    if (std::getenv("VT_TEST_REFUSE_NZBITS")) {
+    if (vt::env::on(vt::env::TEST_REFUSE_NZBITS)) {
       col.release();
       refused = true;
     }
@@ -586,7 +586,7 @@ int index_ensure_shadow(Shard *ix) {
     }
 #ifdef VT_TEST_HOOKS
     // (libvettore_hip_hooks.so only: the allocation "fails", tests/test_gpu_shadow.py checks what follows)
-    if (std::getenv("VT_TEST_REFUSE_SHADOW")) {
+    if (vt::env::on(vt::env::TEST_REFUSE_SHADOW)) {
       ix->dShadow.release();
       refused = true;
     }

@@ -93,9 +93,9 @@ constexpr uint32_t kThresholdListCap = 65536;
 // One scan + radix threshold, or one scan per 256 hits?  Whichever the model says is shorter.
 bool threshold_applies(size_t total, uint32_t n, double scan_bytes, double pass_fixed_s = kScanFixedS) {
   if (total <= (size_t)vt::kMaxFusedK || total > (size_t)vt::kSelListMax || n < kThresholdMinRows ||
-      std::getenv("VT_NO_THRESHOLD_SELECT"))
+      vt::env::on(vt::env::NO_THRESHOLD_SELECT))
     return false;
-  if (std::getenv("VT_FORCE_THRESHOLD_SELECT")) return true;  // tests: exercise the path on small corpora
+  if (vt::env::on(vt::env::FORCE_THRESHOLD_SELECT)) return true;  // tests: exercise the path on small corpora
   const double passes = std::ceil((double)total / vt::kMaxFusedK);
   const double t_pass = pass_fixed_s + scan_bytes / kScanBytesPerS;
   const double t_loop = passes * t_pass;
@@ -234,7 +234,7 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
   bool has_lo = false;
   const size_t total = std::min<size_t>(want, j.n);
   if (!j.gather && out.empty() && total > (size_t)vt::kSelListMax && j.n >= kThresholdMinRows &&
-      !std::getenv("VT_NO_THRESHOLD_SELECT")) {
+      !vt::env::on(vt::env::NO_THRESHOLD_SELECT)) {
     vt::ScanArgs a{};
     a.X = j.X;
     a.stride = j.stride;

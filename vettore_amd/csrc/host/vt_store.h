@@ -394,7 +394,7 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   const uint32_t ld = ix->ld;
   const uint32_t n_before = ix->n;
   const size_t unranked_before = ix->unranked;
-  const bool trace = std::getenv("VT_TRACE_INGEST") != nullptr;
+  const bool trace = vt::env::on(vt::env::TRACE_INGEST);
   const auto t0 = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   // (1) the check.  Fused (the default): the threads that fill the pinned quarters look at every row they copy -- the
@@ -403,7 +403,7 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   // (`verified`); the id thread follows that mark and TAKES BACK what it inserted if a later row fails (rollback below:
   // flat.rs:69-85 stores nothing of a rejected batch).  VT_INGEST_SEPARATE_CHECK=1: the r04 first form, a checker on 32
   // threads beside the copy, the ids only once it has passed.
-  const bool fused = src.unvalidated && std::getenv("VT_INGEST_SEPARATE_CHECK") == nullptr;
+  const bool fused = src.unvalidated && !vt::env::on(vt::env::INGEST_SEPARATE_CHECK);
   std::atomic<int> checked{src.unvalidated ? 0 : 1};  // 0 running, 1 passed, 2 failed
   std::atomic<size_t> verified{src.unvalidated ? (size_t)0 : count};  // rows [0, verified) are known to be finite
   std::atomic<bool> aborted{false};                   // the copy gave up (device error): nobody will finish the check
@@ -579,7 +579,7 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
       }
       t_ids = since();
 #ifdef VT_TEST_HOOKS
-      if (std::getenv("VT_TEST_FAIL_AFTER_ID_UPDATE")) return fail(VT_ERR_DEVICE, "injected failure after the id table changed");
+      if (vt::env::on(vt::env::TEST_FAIL_AFTER_ID_UPDATE)) return fail(VT_ERR_DEVICE, "injected failure after the id table changed");
 #endif
       // the host half of the ranking (index_sync_ranks sorts ids; its upload waits for the rows' stream below)
       if (in_order && !ix->ranks_clean && count >= (size_t)n_before / 4) {
@@ -618,15 +618,11 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
     const size_t row_bytes = (size_t)ld * sizeof(float);
     // Four pinned quarters of 128 MiB, their DMAs alternating between two streams: two copies are in flight while a
     // third quarter is being filled (one stream = one SDMA queue: 41 GB/s of the link's 64; VT_INGEST_STREAMS=1: A/B)
-    static const int kStreams = [] {
-      const char *e = std::getenv("VT_INGEST_STREAMS");
-      return e && e[0] == '1' ? 1 : 2;
-    }();
+    const int kStreams = vt::env::get(vt::env::INGEST_STREAMS) == 1 ? 1 : 2;
     constexpr int kQuarters = 4;
     // (VT_INGEST_STAGE_MB: tests take quarters of 1 MiB, so that a batch of a few MB crosses many of them)
     const size_t kQuarterBytes = [] {  // (read per call: tests set it for one load)
-      const char *e = std::getenv("VT_INGEST_STAGE_MB");
-      const long v = e ? std::atol(e) : 0;
+      const long v = vt::env::get(vt::env::INGEST_STAGE_MB);
       return (size_t)(v >= 1 && v <= 1024 ? v : 128) << 20;
     }();
     const size_t stage_rows = std::max<size_t>(1, std::min<size_t>(count, kQuarterBytes / row_bytes));
@@ -667,7 +663,7 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
 #ifdef VT_TEST_HOOKS
         // (libvettore_hip_hooks.so only: the ids keep step with the verified rows, so a bad row in the last quarter is
         // found with every earlier id in the table -- tests/test_gpu_ingest.py checks that they all come out again)
-        if (std::getenv("VT_TEST_INGEST_LOCKSTEP"))
+        if (vt::env::on(vt::env::TEST_INGEST_LOCKSTEP))
           while (ids_done.load(std::memory_order_acquire) < i + chunk && !id_exited.load()) std::this_thread::yield();
 #endif
         if (i + chunk == count) {
@@ -774,7 +770,7 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
   Ctx &c = ix->ctx;
   const size_t d = (size_t)ix->dim;
   if ((uint64_t)ix->n + count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
-  if (src.host && !src.device && !src.off && !src.pick && count >= 65536 && std::getenv("VT_INGEST_SERIAL") == nullptr) {
+  if (src.host && !src.device && !src.off && !src.pick && count >= 65536 && !vt::env::on(vt::env::INGEST_SERIAL)) {
     const int st = index_store_bulk_host(ix, count, ids, id_off, src, began);  // (makes room itself, beside the check)
     if (st != kRetryGeneral) return st;
   } else {
@@ -795,7 +791,7 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     if (need > ix->rank_host.capacity()) ix->rank_host.reserve(std::max(need, 2 * ix->rank_host.capacity()));
   }
   *began = true;
-  const bool trace = count > 100000 && std::getenv("VT_TRACE_INGEST") != nullptr;  // phase timings on stderr (tools/ingest_probe.py)
+  const bool trace = count > 100000 && vt::env::on(vt::env::TRACE_INGEST);  // phase timings on stderr (tools/ingest_probe.py)
   const auto t_ids = std::chrono::steady_clock::now();
   {
     // the table's slots are fetched a few ids ahead of their use: a bulk load walks a table far
@@ -822,7 +818,7 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
   // (test hook, libvettore_hip_hooks.so only: a device failure between the id table's change and
   // the rows' arrival, the one window in which a mutation cannot be taken back --
   // tests/test_gpu_multishard.py checks that the handle is poisoned from then on)
-  if (std::getenv("VT_TEST_FAIL_AFTER_ID_UPDATE")) return fail(VT_ERR_DEVICE, "injected failure after the id table changed");
+  if (vt::env::on(vt::env::TEST_FAIL_AFTER_ID_UPDATE)) return fail(VT_ERR_DEVICE, "injected failure after the id table changed");
 #endif
   if (count > kMaxDerivedDirty) {
     ix->bits_valid = false;
@@ -846,7 +842,7 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     // (test hook: a one-GPU box has no other device to own the rows)
     bool foreign = device_of_pointer(src.device) != c.device;
 #ifdef VT_TEST_HOOKS
-    foreign = foreign || std::getenv("VT_TEST_FOREIGN_ROWS") != nullptr;  // (libvettore_hip_hooks.so only)
+    foreign = foreign || vt::env::on(vt::env::TEST_FOREIGN_ROWS);  // (libvettore_hip_hooks.so only)
 #endif
     if (foreign) {
       // Rows that live on another device of the node.  A mapped slab admits no peer copy at all

@@ -85,14 +85,8 @@ struct Ctx {
     hipDeviceProp_t prop;
     VT_HIP(hipGetDeviceProperties(&prop, dev));
     num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char *e = std::getenv("VT_HAMMING_BLOCKS_PER_CU")) {
-      const int v = std::atoi(e);
-      if (v >= 1 && v <= 8) hamming_blocks_per_cu = v;
-    }
-    if (const char *e = std::getenv("VT_BLOCKS_PER_CU")) {
-      const int v = std::atoi(e);
-      if (v >= 1 && v <= 8) blocks_per_cu = v;
-    }
+    if (const long v = vt::env::get(vt::env::HAMMING_BLOCKS_PER_CU); v >= 1 && v <= 8) hamming_blocks_per_cu = (int)v;
+    if (const long v = vt::env::get(vt::env::BLOCKS_PER_CU); v >= 1 && v <= 8) blocks_per_cu = (int)v;
     VT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     VT_HIP(hipEventCreate(&ev0));
     VT_HIP(hipEventCreate(&ev1));
@@ -156,8 +150,8 @@ struct Shard {
   std::vector<Ctx *> free_ctx;
   bool ctx0_busy = false;
   int metric = 0;
-  int order = g_default_order;
-  int nominate = g_default_nominate;  // VT_NOMINATE_*
+  int order = default_order();
+  int nominate = default_nominate();  // VT_NOMINATE_*
   // corpus
   uint32_t n = 0, cap = 0;
   long dim = -1;    // FlatIndex.dimension (None = -1)
@@ -182,8 +176,9 @@ struct Shard {
   // the card has room for it (vt_search.h, index_ensure_shadow).  Kept like the bit columns: built
   // by the first batch that wants it, patched per mutated row, given back when the slab needs the room.
   DevBuf<uint16_t> dShadow;
-  int shadow_mode = g_default_shadow;  // VT_SHADOW_*
-  int single_nominate = g_default_single_nominate;  // vt_flat_set_single_nominate: lone searches through the shadow
+  int shadow_mode = default_shadow();  // VT_SHADOW_*
+  // (atomic: search_direct looks at it before it takes the handle's lock, vt_flat_set_single_nominate writes it under the exclusive one)
+  std::atomic<int> single_nominate{default_single_nominate()};  // vt_flat_set_single_nominate: lone searches through the shadow
   bool sh_valid = false;
   bool sh_refused = false;  // no room (or the slab took the room back): batches stream the f32 rows until the index is emptied
   std::vector<uint32_t> sh_dirty;
@@ -234,6 +229,18 @@ struct CtxLease : vt_host::LeaseT<Shard, Ctx> {
           nc->profiling = ix->ctx.profiling;
           return nc;
         }) {}
+};
+
+inline std::unique_ptr<Ctx> make_reader_ctx(Shard *ix, int *status) {
+  auto nc = std::make_unique<Ctx>();
+  *status = nc->init(ix->ctx.device);
+  if (*status != VT_OK) return nullptr;
+  nc->profiling = ix->ctx.profiling;
+  return nc;
+}
+// A second context beside the one a reader holds (vt_host::SpareLeaseT): null when none is free.
+struct SpareCtxLease : vt_host::SpareLeaseT<Shard, Ctx> {
+  explicit SpareCtxLease(Shard *s) : vt_host::SpareLeaseT<Shard, Ctx>(s, kMaxContexts, make_reader_ctx) {}
 };
 
 // ---- RCCL, loaded on first use (librccl is half a gigabyte: a single-GPU index never maps it)

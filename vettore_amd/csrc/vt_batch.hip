@@ -766,8 +766,7 @@ hipError_t launch_scores3(const BatchScoreArgs &a, bool dense, uint32_t blocks, 
 
 // VT_BATCH_KERNEL=3 selects the 128 x 128 register tile for 256-query batches.
 bool batch_wide_tile(uint32_t nq_pad) {
-  static const bool v = std::getenv("VT_BATCH_KERNEL") && std::atoi(std::getenv("VT_BATCH_KERNEL")) == 3;
-  return v && nq_pad == 256;
+  return env::get(env::BATCH_KERNEL) == 3 && nq_pad == 256;
 }
 
 }  // namespace
@@ -777,8 +776,7 @@ uint32_t batch_rows_per_block(uint32_t nq_pad) { return batch_wide_tile(nq_pad) 
 hipError_t launch_batch_scores(const BatchScoreArgs &a0, bool dense, uint32_t blocks, hipStream_t s) {
   BatchScoreArgs a = a0;
 #ifdef VT_BATCH_TIMING_EXPERIMENTS
-  static const uint32_t dbg = std::getenv("VT_BATCH_DEBUG") ? (uint32_t)std::atoi(std::getenv("VT_BATCH_DEBUG")) : 0u;
-  a.debug = dense ? 0u : dbg;
+  a.debug = dense ? 0u : (uint32_t)env::get(env::BATCH_DEBUG);
 #else
   a.debug = 0u;
 #endif

@@ -383,17 +383,8 @@ hipError_t launch_qs(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipSt
 
 // stages of the LDS ring: 5 x 32 KiB is all of a CU's LDS at 256 query columns
 int shadow_stages() {
-  auto from_env = [] {
-    const char *e = std::getenv("VT_SHADOW_STAGES");
-    const int v = e ? std::atoi(e) : 0;
-    return v == 4 || v == 5 ? v : 5;
-  };
-#ifdef VT_BATCH_TIMING_EXPERIMENTS
-  return from_env();  // (the probe switches between its runs)
-#else
-  static const int s = from_env();
-  return s;
-#endif
+  const long v = env::get(env::SHADOW_STAGES);  // (VT_SHADOW_STAGES=4|5)
+  return v == 4 ? 4 : 5;
 }
 
 }  // namespace

@@ -1,6 +1,7 @@
 // vt_common.cuh -- device helpers shared by the gfx950 kernels (wave64 only).
 #pragma once
 #include "vt_device.h"
+#include "vt_env.h"
 
 #include <float.h>
 

@@ -5,6 +5,8 @@
 // all metric arithmetic and all selection run on the GPU.
 #include "../../include/vettore_flat.h"
 #include "vt_device.h"
+#define VT_ENV_IMPLEMENTATION  // the library's one copy of the settings table (filled when the library is loaded)
+#include "vt_env.h"
 
 #include <algorithm>
 #include <atomic>
@@ -65,6 +67,19 @@ const char *vt_strerror(int status) {
 
 const char *vt_last_error(void) { return g_last_error.c_str(); }
 int vt_abi_version(void) { return VT_ABI_VERSION; }
+
+int vt_debug_set(const char *name, long value) {
+  const int k = vt::env::find(name);
+  if (k < 0) return VT_ERR_ARGUMENT;
+  vt::env::set((vt::env::Key)k, value);
+  return VT_OK;
+}
+int vt_debug_get(const char *name, long *value) {
+  const int k = vt::env::find(name);
+  if (k < 0 || !value) return VT_ERR_ARGUMENT;
+  *value = vt::env::get((vt::env::Key)k);
+  return VT_OK;
+}
 
 int vt_device_count(void) {
   int n = 0;
@@ -249,7 +264,7 @@ int vt_flat_new_sharded(int metric_code, const int *devices, size_t ndev, vt_fla
     VT_TRY(ix->ctx.init(devices[s]));
     h->shards.push_back(std::move(ix));
   }
-  if (ndev > 1 || std::getenv("VT_SHARD_FORCE_WORKERS")) {
+  if (ndev > 1 || vt::env::on(vt::env::SHARD_FORCE_WORKERS)) {
     bool distinct = true;
     for (size_t a = 0; a < ndev; ++a)
       for (size_t b = a + 1; b < ndev; ++b) {
@@ -274,9 +289,9 @@ int vt_flat_new_sharded(int metric_code, const int *devices, size_t ndev, vt_fla
     }
     // the shards' lists meet over RCCL when every shard has a device of its own
     // (VT_SHARD_EXCHANGE=host|rccl overrides; vt_flat_set_exchange later)
-    const char *want = std::getenv("VT_SHARD_EXCHANGE");
-    const bool want_host = want && std::string(want) == "host";
-    const bool want_rccl = want && std::string(want) == "rccl";
+    const long want = vt::env::get(vt::env::SHARD_EXCHANGE);  // (VT_SHARD_EXCHANGE=host|rccl)
+    const bool want_host = want == 1;
+    const bool want_rccl = want == 2;
     std::string note = std::to_string(ndev) + " shards: ";
     if (want_host) {
       note += "host exchange (VT_SHARD_EXCHANGE=host)";
@@ -295,7 +310,7 @@ int vt_flat_new_sharded(int metric_code, const int *devices, size_t ndev, vt_fla
       }
     }
     h->exchange_note = note;
-    if (std::getenv("VT_LOG")) std::fprintf(stderr, "[vt] %s\n", note.c_str());
+    if (vt::env::on(vt::env::LOG)) std::fprintf(stderr, "[vt] %s\n", note.c_str());
   }
   *out = h.release();
   return VT_OK;
@@ -378,7 +393,7 @@ int vt_flat_rccl_ranks(const vt_flat *h) {
 
 int vt_set_default_reduce_order(int order) {
   if (order < VT_ORDER_PAIR || order > VT_ORDER_SSE2) return VT_ERR_ARGUMENT;
-  g_default_order = order;
+  vt::env::set(vt::env::REDUCE_ORDER, order);
   return VT_OK;
 }
 
@@ -428,7 +443,7 @@ int vt_flat_set_single_nominate(vt_flat *h, int enabled) {
   return VT_OK;
   });
 }
-int vt_flat_single_nominate(const vt_flat *h) { return h && !h->shards.empty() ? h->shards[0]->single_nominate : -1; }
+int vt_flat_single_nominate(const vt_flat *h) { return h && !h->shards.empty() ? h->shards[0]->single_nominate.load() : -1; }
 int vt_flat_batch_shadow(const vt_flat *h) {
   if (!h || h->shards.empty()) return -1;
   std::shared_lock<std::shared_mutex> rl(h->rw);
@@ -487,7 +502,7 @@ int vt_flat_load_matrix(vt_flat *h, size_t count, size_t d, const char *ids, con
   if (expected < 0 && count > 0) expected = (long)d;
   // A bulk load on a one-shard handle checks finiteness beside the copy to the device (index_store_bulk_host:
   // the index is not touched before the whole batch has passed, flat.rs:69-85); everything else here, up front.
-  const bool check_beside_copy = !h->multi() && count >= 65536 && std::getenv("VT_INGEST_SERIAL") == nullptr;
+  const bool check_beside_copy = !h->multi() && count >= 65536 && !vt::env::on(vt::env::INGEST_SERIAL);
   if (check_beside_copy) {
     if (d == 0) return VT_ERR_EMPTY;
     if ((long)d != expected) return VT_ERR_DIMENSION;
@@ -809,7 +824,7 @@ int vt_vector_top_k(int device, size_t count, const char *ids, const size_t *id_
       j.n = n;
       j.d = d;
       j.metric = metric_code;
-      j.order = g_default_order;
+      j.order = default_order();
       j.q_nonzero = qnz;
       // limit == 0 still has to surface "metric overflow": scan for one hit
       VT_TRY(run_scan(c, j, std::max<size_t>(want, 1), entries, false));

@@ -624,7 +624,7 @@ constexpr size_t mq_lds(bool slim) {
 }
 // which launches take the slim build: see launch_multi_op
 inline bool mq_slim(uint32_t d, uint32_t k, int metric) {
-  static const bool off = std::getenv("VT_MULTI_NO_SLIM") != nullptr;  // A/B
+  const bool off = env::on(env::MULTI_NO_SLIM);  // A/B
   const int op = metric_op(metric);
   return !off && d % kRowAlign == 0 && k <= kMqSlimMaxK && (op == OP_DOT || op == OP_L2 || op == OP_L1 || op == OP_LINF);
 }
@@ -648,7 +648,7 @@ static hipError_t launch_multi_op(const MultiScanArgs &a, uint32_t blocks, hipSt
   // aligned shapes 9 %, so they do not carry it): padding is zero in rows and queries alike,
   // the scalar tail's products are filed beside the chunk sums.  The variant with run-time lane
   // order and compiler-scheduled loads stays as an A/B switch (VT_MULTI_GENERAL).
-  static const bool general = std::getenv("VT_MULTI_GENERAL") != nullptr;
+  const bool general = env::on(env::MULTI_GENERAL);
   if (a.d % kRowAlign != 0) {
     if (general) return launch_multi_t<OP, ORDERED ? -1 : 0, false>(a, blocks, s);
     if (!ORDERED || a.order == 0) return launch_multi_t<OP, 0, true, true>(a, blocks, s);
@@ -660,7 +660,7 @@ static hipError_t launch_multi_op(const MultiScanArgs &a, uint32_t blocks, hipSt
     if (mq_slim(a.d, a.k, a.metric)) {
       // a last panel of 128 or 64 floats (d = 384, 128, 64, 320 ...): two or four rows per load there
       // (the default lane order only: two more builds per operation)
-      static const bool no_pack = std::getenv("VT_MULTI_NO_PACK") != nullptr;  // A/B
+      const bool no_pack = env::on(env::MULTI_NO_PACK);  // A/B
       constexpr int kOrd = ORDERED ? kDefaultReduceOrder : 0;
       if (!no_pack && (!ORDERED || a.order == kDefaultReduceOrder)) {
         if (a.ld % kMqPanel == 128) return launch_multi_t<OP, kOrd, true, false, true, 2>(a, blocks, s);

@@ -587,6 +587,38 @@ def set_default_reduce_order(order: int):
     return "ok" if st == 0 else _err(st)
 
 
+def debug_set(name: str, value: int):
+    """A library setting by name (vt_debug_set, include/vettore_flat.h): the VT_* variables are read once,
+    when the library is loaded; afterwards -- and for the switches that have no variable ("force_batch_mfma"
+    ...) -- this is the way in.  Process-wide; tests and probes only."""
+    st = _lib.load().vt_debug_set(name.encode(), int(value))
+    if st != 0:
+        raise KeyError("libvettore_hip has no setting %r" % name)
+
+
+def debug_get(name: str) -> int:
+    v = C.c_long()
+    if _lib.load().vt_debug_get(name.encode(), C.byref(v)) != 0:
+        raise KeyError("libvettore_hip has no setting %r" % name)
+    return int(v.value)
+
+
+class debug_setting:
+    """`with nifs.debug_setting("batch_no_mfma", 1): ...` -- the old value comes back afterwards."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = debug_get(self.name)
+        debug_set(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        debug_set(self.name, self.old)
+        return False
+
+
 def device_read_peak(device: int = 0, nbytes: int = 8 << 30, reps: int = 5):
     """GB/s of the plainest read-only streaming kernel on this box (diagnostic, bench.py)."""
     g = C.c_double()
