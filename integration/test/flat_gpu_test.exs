@@ -122,6 +122,44 @@ defmodule Vettore.Index.FlatGpuTest do
     assert triples({:ok, b}) == triples({:ok, exact})
   end
 
+  test "hybrid search and the batched staged searches on the resident corpus" do
+    c = @cases["full_candidate_adaptive_modes_agree_with_exact_flat_search"]
+    cs = collection(c["metric"], length(hd(c["rows"]) |> Enum.at(1)))
+    put_rows(cs, c["rows"])
+    {cpu, gpu} = cs
+    query = c["query"]
+    n = c["candidates"]
+    {:ok, exact} = Vettore.search(cpu, query, limit: c["limit"])
+    ids = Enum.map(exact, & &1.id)
+    generators = [funnel: [stages: [2, 4], candidates: n], quantized: [candidates: n], search: [candidates: n]]
+    # the collection's own hybrid search (ETS + CPU NIFs) and the adapter's (one call on the resident rows) agree
+    want = Vettore.hybrid_search(cpu, query, generators: generators, limit: c["limit"])
+    got = Vettore.Index.FlatGpu.hybrid_search(gpu, query, generators: generators, limit: c["limit"])
+    assert triples(got) == triples(want)
+    assert Enum.map(elem(got, 1), & &1.id) == ids
+    # default generators ([:funnel, :quantized], collection.ex:512-513) and a bare atom
+    assert triples(Vettore.Index.FlatGpu.hybrid_search(gpu, query, limit: 3)) == triples(Vettore.hybrid_search(cpu, query, limit: 3))
+    assert {:ok, [_ | _]} = Vettore.Index.FlatGpu.hybrid_search(gpu, query, generators: [:search], limit: 3)
+    # errors as run_hybrid_generator's (collection.ex:536-556, :1136-1142)
+    assert Vettore.Index.FlatGpu.hybrid_search(gpu, query, generators: []) == {:error, :invalid_generators}
+    assert Vettore.Index.FlatGpu.hybrid_search(gpu, query, generators: [:nope]) == {:error, {:unknown_generator, :nope}}
+    assert Vettore.Index.FlatGpu.hybrid_search(gpu, query, generators: [:hnsw]) == {:error, :hnsw_index_required}
+    assert Vettore.Index.FlatGpu.hybrid_search(gpu, query, generators: [funnel: [stages: [5]]]) == {:error, :invalid_stages}
+    assert Vettore.Index.FlatGpu.hybrid_search(gpu, query, generators: [quantized: [stages: [2]]]) == {:error, {:unsupported_option, :stages}}
+    assert Vettore.Index.FlatGpu.hybrid_search(gpu, query, rerank: :nope) == {:error, {:invalid_rerank, :nope}}
+    # batches: every query's list equals its own call
+    queries = [query, Enum.map(query, &(&1 / 2)), [0.0, 0.0, 0.0, 0.0]]
+    {:ok, qb} = Vettore.Index.FlatGpu.quantized_search_batch(gpu, queries, candidates: n, limit: c["limit"])
+    {:ok, fb} = Vettore.Index.FlatGpu.funnel_search_batch(gpu, queries, stages: [2, 4], candidates: n, limit: c["limit"])
+    for {q, i} <- Enum.with_index(queries) do
+      assert triples({:ok, Enum.at(qb, i)}) == triples(Vettore.Index.FlatGpu.quantized_search(gpu, q, candidates: n, limit: c["limit"]))
+      assert triples({:ok, Enum.at(fb, i)}) == triples(Vettore.Index.FlatGpu.funnel_search(gpu, q, stages: [2, 4], candidates: n, limit: c["limit"]))
+    end
+    assert Enum.map(hd(qb), & &1.id) == ids and Enum.map(hd(fb), & &1.id) == ids
+    assert Vettore.Index.FlatGpu.quantized_search_batch(gpu, queries, candidates: 3, limit: 10) == {:error, :invalid_candidates}
+    assert Vettore.Index.FlatGpu.funnel_search_batch(gpu, [[1.0]], limit: 1) == {:error, :dimension_mismatch}
+  end
+
   test "adapter validation: limits and query length" do
     c = @cases["adapter_validation"]
     {:ok, gpu} = Vettore.new(dimensions: c["dimensions"], metric: String.to_atom(c["metric"]), index: Vettore.Index.FlatGpu)

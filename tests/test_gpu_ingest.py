@@ -103,6 +103,58 @@ def test_upserts_and_duplicates_inside_a_bulk_load(nifs, oracle_mod):
         assert bits(g.search(q, 10)) == bits(want.search(q, 10))
 
 
+@pytest.mark.parametrize("start", ["empty", "sorted corpus"])
+@pytest.mark.parametrize("case", ["one duplicate", "upserts and newcomers"])
+def test_sorted_ids_that_are_not_all_new_keep_the_rank_column_current(nifs, oracle_mod, start, case):
+    """a bulk load whose ids are ascending (the id ranks stay valid, extended in place) but not all new and
+    distinct -- one duplicate, or a sorted snapshot reloaded over the ids that are there plus new ones -- hands over to
+    the general path AFTER every id is in the table.  The device's rank column must still receive the new rows' ranks
+    (it was left stale, or null on a first load): identical rows, which only the id order tells apart, single searches
+    and a batch, on an empty index and on one whose ranks are clean."""
+    d = 16
+    width = 7
+    sid = lambda i: b"s%0*d" % (width, i)          # bytewise order == numeric order
+    g = GpuIndex(nifs, 1)
+    want = oracle_mod.FlatIndex(1)
+    n0 = 0
+    if start == "sorted corpus":
+        n0 = 70_000
+        x0 = corpus(n0, d, 61)
+        ids0 = [sid(2 * i) for i in range(n0)]     # even numbers
+        unwrap(nifs.flat_load_matrix(g.ref, ids0, x0))
+        want.insert_matrix(ids0, x0)
+    n = 80_000
+    x = corpus(n, d, 62)
+    x[5000:5040] = x[100]                            # rows only the id bytes order
+    if case == "one duplicate":
+        ids = [sid(2 * n0 + 10 + i) for i in range(n)]     # all above what is there, ascending ...
+        ids[40_001] = ids[40_000]                          # ... with one id twice (the last one wins, flat.rs:270-281)
+    else:
+        # ascending ids: 30 000 that are in the index already (upserts, a sorted snapshot loaded again), then new ones above
+        ids = [sid(2 * i) for i in range(0, 60_000, 2)] + [sid(2 * n0 + 10 + j) for j in range(n - 30_000)]
+        if start == "empty":
+            ids = [sid(10 + i) for i in range(n)]
+            ids[123] = ids[122]
+            ids[70_000] = ids[69_999]
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    want.insert_matrix(ids, x)
+    assert len(g) == len(want)
+    rng = np.random.default_rng(63)
+    qs = np.stack([x[100], x[5010], x[40_001], x[n - 1], rng.uniform(-1, 1, d).astype(np.float32)])
+    for q in qs:
+        assert bits(g.search(q, 50)) == bits(want.search(q, 50))
+    got = unwrap(nifs.flat_search_batch(g.ref, qs, 50))
+    for i, q in enumerate(qs):
+        assert bits(got[i]) == bits(want.search(q, 50)), i
+    # and the index goes on: a sorted append behind it, another search
+    more = corpus(70_000, d, 64)
+    ids_more = [sid(9_000_000 + i) for i in range(len(more))]
+    unwrap(nifs.flat_load_matrix(g.ref, ids_more, more))
+    want.insert_matrix(ids_more, more)
+    for q in (x[5010], more[len(more) // 3 + 3]):
+        assert bits(g.search(q, 50)) == bits(want.search(q, 50))
+
+
 def test_the_serial_path_gives_the_same_index(nifs, oracle_mod, monkeypatch, vt_debug):
     n, d = 70_000, 16
     x = corpus(n, d, 31)

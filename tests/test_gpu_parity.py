@@ -627,6 +627,47 @@ def test_elixir_funnel_equals_flat_with_full_candidates(nifs):
     assert [r.id for r in hybrid] == [r.id for r in exact]
 
 
+def test_adapter_staged_searches_their_batches_and_their_errors(nifs):
+    """Vettore.Index.FlatGpu's quantized / funnel / hybrid wrappers and their batch forms (integration/lib/vettore/index/
+    flat_gpu.ex, mirrored in vettore_amd/index_flat.py), reached through the collection's dispatch (INTEGRATION.md
+    section 3): the scenario of test/vector_adversarial_test.exs:376-421, every batched list equal to the single call,
+    error atoms and their order as run_hybrid_generator's (collection.ex:536-556, :1136-1142)."""
+    from vettore_amd.collection import Collection
+    from vettore_amd.index_flat import FlatGpu
+    c = load("elixir_nif.json")["full_candidate_adaptive_modes_agree_with_exact_flat_search"]
+    ok, col = Collection.new(dimensions=4, metric=c["metric"], index="flat")
+    assert col.put_many([{"id": r[0], "vector": r[1]} for r in c["rows"]]) == "ok"
+    q, n, k = c["query"], c["candidates"], c["limit"]
+    ids = [r.id for r in col.search(q, {"limit": k})[1]]
+    gens = [("funnel", {"stages": [2, 4], "candidates": n}), ("quantized", {"candidates": n}), ("search", {"candidates": n})]
+    ok, hybrid = col.hybrid_search(q, {"generators": gens, "limit": k})
+    assert ok == "ok" and [r.id for r in hybrid] == ids
+    assert [r.id for r in FlatGpu.hybrid_search(col, q, {"generators": gens, "limit": k})[1]] == ids
+    assert col.hybrid_search(q, {"limit": 3})[0] == "ok" and col.hybrid_search(q, {"generators": ["search"], "limit": 3})[0] == "ok"
+    assert col.hybrid_search(q, {"generators": []}) == ("error", "invalid_generators")
+    assert col.hybrid_search(q, {"generators": ["nope"]}) == ("error", ("unknown_generator", "nope"))
+    assert col.hybrid_search(q, {"generators": ["hnsw"]}) == ("error", "hnsw_index_required")
+    assert col.hybrid_search(q, {"generators": [("funnel", {"stages": [5]})]}) == ("error", "invalid_stages")
+    assert col.hybrid_search(q, {"generators": [("quantized", {"stages": [2]})]}) == ("error", ("unsupported_option", "stages"))
+    assert col.hybrid_search(q, {"rerank": "nope"}) == ("error", ("invalid_rerank", "nope"))
+    assert col.hybrid_search(q, {"limit": 0}) == ("error", "invalid_limit")
+    assert col.hybrid_search(q, {"candidates": 5}) == ("error", ("unsupported_option", "candidates"))
+    triples = lambda rs: [(r.id, r.score, r.distance) for r in rs]
+    queries = [q, [v / 2 for v in q], [0.0, 0.0, 0.0, 0.0]]
+    ok, qb = col.quantized_search_batch(queries, {"candidates": n, "limit": k})
+    ok2, fb = col.funnel_search_batch(queries, {"stages": [2, 4], "candidates": n, "limit": k})
+    ok3, sb = col.search_batch(queries, {"limit": k})
+    assert (ok, ok2, ok3) == ("ok", "ok", "ok")
+    for i, qi in enumerate(queries):
+        assert triples(qb[i]) == triples(col.quantized_search(qi, {"candidates": n, "limit": k})[1])
+        assert triples(fb[i]) == triples(col.funnel_search(qi, {"stages": [2, 4], "candidates": n, "limit": k})[1])
+        assert triples(sb[i]) == triples(col.search(qi, {"limit": k})[1])
+    assert [r.id for r in qb[0]] == ids and [r.id for r in fb[0]] == ids
+    assert col.quantized_search_batch(queries, {"candidates": 3, "limit": 10}) == ("error", "invalid_candidates")
+    assert col.funnel_search_batch([[1.0]], {"limit": 1}) == ("error", "dimension_mismatch")
+    assert col.quantized_search(q, {"stages": [2]}) == ("error", ("unsupported_option", "stages"))
+
+
 @pytest.mark.parametrize("metric", [2, 0])
 def test_hybrid_search_matches_oracle_composition(nifs, oracle_mod, metric):
     """collection.ex:325-345, :515-592: union of generator candidates (funnel stages,

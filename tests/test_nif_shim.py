@@ -119,6 +119,29 @@ def test_every_nif_call_from_elixir_matches_a_stub():
     assert seen >= 12
 
 
+def test_no_nif_without_a_caller_in_the_adapter():
+    """Every NIF the Elixir stub module declares is reachable from Vettore.Index.FlatGpu (a call, or a delegate):
+    VERDICT r4 found flat_hybrid_search and the two batch forms registered but never called."""
+    ex = open(EX_NIFS).read()
+    stubs = {m.group(1): len([a for a in m.group(2).split(",") if a.strip()])
+             for m in re.finditer(r"def ([a-z0-9_]+)\(([^)]*)\), do: :erlang\.nif_error", ex)}
+    adapter = open(os.path.join(INTEGRATION, "lib", "vettore", "index", "flat_gpu.ex")).read()
+    called = {f for f, _ in elixir_calls(adapter, "Nifs")}
+    delegated = {m.group(1): len([a for a in m.group(2).split(",") if a.strip()])
+                 for m in re.finditer(r"defdelegate ([a-z0-9_]+)\(([^)]*)\), to: Nifs", adapter)}
+    for fun, arity in stubs.items():
+        assert fun in called or delegated.get(fun) == arity, fun
+    # ... and the staged searches have their public wrappers, which the ExUnit file exercises
+    test = open(os.path.join(INTEGRATION, "test", "flat_gpu_test.exs")).read()
+    for wrapper in ("hybrid_search", "quantized_search_batch", "funnel_search_batch", "quantized_search", "funnel_search", "search_batch"):
+        assert re.search(r"def %s\(%%Collection\{" % wrapper, adapter), wrapper
+        assert "Vettore.Index.FlatGpu.%s(" % wrapper in test, wrapper
+    # the Python mirror of the adapter has the same entry points (vettore_amd/index_flat.py)
+    from vettore_amd.index_flat import FlatGpu
+    for wrapper in ("search", "search_batch", "quantized_search", "quantized_search_batch", "funnel_search", "funnel_search_batch", "hybrid_search"):
+        assert callable(getattr(FlatGpu, wrapper)), wrapper
+
+
 def test_the_plugin_module_exports_the_behaviour():
     text = open(os.path.join(INTEGRATION, "lib", "vettore", "index", "flat_gpu.ex")).read()
     assert "@behaviour Vettore.Index" in text

@@ -7,6 +7,7 @@
 //   3. does a kernel on the complementary mask really run beside the pass, and what does the pass lose then?
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ivettore_amd/csrc tools/cumask_probe.hip -o tools/cumask_probe
 // Run:   tools/cumask_probe [rows]            one JSON line per measurement
+#define VT_ENV_IMPLEMENTATION  // (this program's own copy of the library's settings table: csrc/vt_env.h)
 #include "../vettore_amd/csrc/vt_batch_shadow.hip"
 
 #include <cmath>

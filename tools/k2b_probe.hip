@@ -2,6 +2,7 @@
 // vt_batch_bf16.hip (what does the barrier / the query DMA / the MFMAs / the append cost?).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DVT_BATCH_TIMING_EXPERIMENTS -Ivettore_amd/csrc tools/k2b_probe.hip -o tools/k2b_probe
 // Run:   tools/k2b_probe [rows] [d] [tau]      one line per switch combination
+#define VT_ENV_IMPLEMENTATION  // (this program's own copy of the library's settings table: csrc/vt_env.h)
 #include "../vettore_amd/csrc/vt_batch_bf16.hip"
 
 #include <cstdio>

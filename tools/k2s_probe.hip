@@ -3,6 +3,7 @@
 // and K2s under its timing switches (what do the barrier / the DMA / the fragment reads / the MFMAs cost?).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DVT_BATCH_TIMING_EXPERIMENTS -Ivettore_amd/csrc tools/k2s_probe.hip -o tools/k2s_probe
 // Run:   tools/k2s_probe [rows] [d] [nq_pad] [tau]      one JSON line per variant
+#define VT_ENV_IMPLEMENTATION  // (this program's own copy of the library's settings table: csrc/vt_env.h)
 #include "../vettore_amd/csrc/vt_batch_bf16.hip"
 #include "../vettore_amd/csrc/vt_batch_shadow.hip"
 

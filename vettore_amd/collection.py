@@ -193,117 +193,39 @@ class Collection:
             return ("error", ("unsupported_option", bad[0]))
         return self.index_mod.search(self, query, opts)
 
-    # -- collection.ex:234-260 -----------------------------------------------
+    # -- collection.ex:234-345: funnel_search / quantized_search / hybrid_search --------------------
+    # The reference checks the option keys (validate_options, collection.ex:237, :267, :330) and then runs its own
+    # ETS + CPU-NIF composition whatever the index module is.  With the dispatch INTEGRATION.md section 3 adds to
+    # collection.ex -- `if function_exported?(collection.index_mod, :quantized_search, 3), do: ...` -- an index module
+    # that keeps the corpus resident answers instead.  This mirror has no ETS composition of its own (the store is out
+    # of scope): an index module without the function is {:error, :not_supported_by_index} here.
+    def _staged(self, name, allowed, query, opts):
+        opts = {} if opts is None else opts
+        if not isinstance(opts, dict):
+            return ("error", "invalid_options")                         # collection.ex:1133
+        bad = [k for k in opts if k not in allowed]
+        if bad:
+            return ("error", ("unsupported_option", bad[0]))            # collection.ex:1125-1126
+        fn = getattr(self.index_mod, name, None)
+        if fn is None:
+            return ("error", "not_supported_by_index")
+        return fn(self, query, opts)
+
     def funnel_search(self, query, opts=None):
-        opts = {} if opts is None else opts
-        if not isinstance(opts, dict):
-            return ("error", "invalid_options")
-        bad = [k for k in opts if k not in ("limit", "candidates", "stages", "dimensions")]
-        if bad:
-            return ("error", ("unsupported_option", bad[0]))
-        limit = opts.get("limit", 10)
-        if not (isinstance(limit, int) and 0 < limit <= MAX_NIF_USIZE):
-            return ("error", "invalid_limit")
-        candidates = opts.get("candidates", max(limit * 10, limit))
-        if not (isinstance(candidates, int) and candidates >= limit and 0 < candidates <= MAX_NIF_USIZE):
-            return ("error", "invalid_candidates")
-        if "stages" in opts:                                        # collection.ex:660-672
-            stages = opts["stages"]
-        elif "dimensions" in opts:
-            stages = [opts["dimensions"]]
-        else:
-            stages = [min(self.dimensions, 128)]
-        if not (isinstance(stages, list) and stages and
-                all(isinstance(s, int) and 0 < s <= self.dimensions for s in stages)):
-            return ("error", "invalid_stages")                      # collection.ex:905-913
-        q = self.prepare_query(query)
-        if q[0] != "ok":
-            return q
-        res = nifs.flat_funnel_search(self.index_state, q[1], stages, candidates, limit)
-        if res[0] != "ok":
-            return res
-        return ("ok", self._hydrate(res[1]))
+        return self._staged("funnel_search", ("limit", "candidates", "stages", "dimensions"), query, opts)   # :56
 
-    # -- collection.ex:325-345, :515-592 ---------------------------------------
-    def hybrid_search(self, query, opts=None):
-        opts = {} if opts is None else opts
-        if not isinstance(opts, dict):
-            return ("error", "invalid_options")
-        bad = [k for k in opts if k not in ("limit", "generators", "rerank")]
-        if bad:
-            return ("error", ("unsupported_option", bad[0]))
-        limit = opts.get("limit", 10)
-        if not (isinstance(limit, int) and 0 < limit <= MAX_NIF_USIZE):
-            return ("error", "invalid_limit")
-        if opts.get("rerank", "exact") != "exact":
-            return ("error", ("invalid_rerank", opts.get("rerank")))   # multi-vector rerank: out of scope
-        generators = opts.get("generators", ["funnel", "quantized"])   # collection.ex:512-513
-        if not isinstance(generators, list) or not generators:
-            return ("error", "invalid_generators")
-        spec = []
-        for gen in generators:
-            name, gopts = (gen, {}) if isinstance(gen, str) else gen
-            if name not in ("funnel", "quantized", "search") or not isinstance(gopts, dict):
-                return ("error", ("invalid_generator", gen))
-            cand = gopts.get("candidates", max(limit * 10, limit))      # collection.ex:547
-            if not (isinstance(cand, int) and 0 < cand <= MAX_NIF_USIZE):
-                return ("error", "invalid_candidates")
-            if name == "funnel":
-                stages = gopts["stages"] if "stages" in gopts else (
-                    [gopts["dimensions"]] if "dimensions" in gopts else [min(self.dimensions, 128)])
-                if not (isinstance(stages, list) and stages and
-                        all(isinstance(s, int) and 0 < s <= self.dimensions for s in stages)):
-                    return ("error", "invalid_stages")
-                spec.append((nifs.GEN_FUNNEL, cand, stages))
-            elif name == "quantized":
-                spec.append((nifs.GEN_QUANTIZED, cand, []))
-            else:
-                spec.append((nifs.GEN_SEARCH, cand, []))
-        q = self.prepare_query(query)
-        if q[0] != "ok":
-            return q
-        res = nifs.flat_hybrid_search(self.index_state, q[1], spec, limit)
-        if res[0] != "ok":
-            return res
-        return ("ok", self._hydrate(res[1]))
-
-    def _hydrate(self, hits):
-        out: List[Result] = []
-        for id_, raw in hits:
-            got = self.get(id_)
-            if got[0] != "ok":
-                continue
-            score, distance = result_values(self.metric, raw, self.score)
-            out.append(Result(id=id_, value=got[1].value, score=score, distance=distance, metric=self.metric,
-                              metadata=got[1].metadata))
-        return out
-
-    # -- collection.ex:266-295 -----------------------------------------------
     def quantized_search(self, query, opts=None):
-        opts = {} if opts is None else opts
-        if not isinstance(opts, dict):
-            return ("error", "invalid_options")
-        bad = [k for k in opts if k not in ("limit", "candidates")]
-        if bad:
-            return ("error", ("unsupported_option", bad[0]))
-        limit = opts.get("limit", 10)
-        if not (isinstance(limit, int) and 0 < limit <= MAX_NIF_USIZE):
-            return ("error", "invalid_limit")
-        candidates = opts.get("candidates", max(limit * 10, limit))   # collection.ex:510
-        if not (isinstance(candidates, int) and candidates >= limit and 0 < candidates <= MAX_NIF_USIZE):
-            return ("error", "invalid_candidates")                     # collection.ex:889-895
-        q = self.prepare_query(query)
-        if q[0] != "ok":
-            return q
-        res = nifs.flat_quantized_search(self.index_state, q[1], candidates, limit)
-        if res[0] != "ok":
-            return res
-        out: List[Result] = []
-        for id_, raw in res[1]:
-            got = self.get(id_)
-            if got[0] != "ok":
-                continue
-            score, distance = result_values(self.metric, raw, self.score)
-            out.append(Result(id=id_, value=got[1].value, score=score, distance=distance, metric=self.metric,
-                              metadata=got[1].metadata))
-        return ("ok", out)
+        return self._staged("quantized_search", ("limit", "candidates"), query, opts)                        # :57
+
+    def hybrid_search(self, query, opts=None):
+        return self._staged("hybrid_search", ("limit", "generators", "rerank"), query, opts)                 # :59
+
+    # (extensions of the adapter: lists of queries, one call)
+    def search_batch(self, queries, opts=None):
+        return self._staged("search_batch", ("limit",), queries, opts)
+
+    def quantized_search_batch(self, queries, opts=None):
+        return self._staged("quantized_search_batch", ("limit", "candidates"), queries, opts)
+
+    def funnel_search_batch(self, queries, opts=None):
+        return self._staged("funnel_search_batch", ("limit", "candidates", "stages", "dimensions"), queries, opts)

@@ -84,7 +84,12 @@ int batch_group_queue(Shard *ix, Ctx &c, BatchGroupRun &run, const float *querie
   VT_TRY(c.hBQ.ensure((size_t)nq_pad * ld));
   VT_TRY(c.dBTau.ensure(nq_pad));
   VT_TRY(c.hBTau.ensure(nq_pad));
-  if (!tau_given) VT_TRY(c.dBSample.ensure((size_t)nq_pad * sample_rows));
+  // K2s: the sample pass files one value per query and 64-row group (the group's best score) and the threshold is the
+  // rank-th largest of those -- as long as the rank is small beside the groups (two of the `rank` best rarely share one);
+  // otherwise, and for K2 / K2b, the whole sample matrix and the radix select over it
+  const uint32_t sample_groups = vt::batch_shadow_sample_groups(ntiles_sample);
+  const bool by_maxima = shadow && !tau_given && (uint64_t)rank * 16 <= sample_groups && sample_groups <= 1024;
+  if (!tau_given) VT_TRY(c.dBSample.ensure((size_t)nq_pad * (by_maxima ? sample_groups : sample_rows)));
   VT_TRY(c.dBCand.ensure((size_t)nq_pad * cand_cap));
   VT_TRY(c.dBCount.ensure(nq_pad));
   VT_TRY(c.hBCount.ensure(nq_pad));
@@ -144,8 +149,14 @@ int batch_group_queue(Shard *ix, Ctx &c, BatchGroupRun &run, const float *querie
     a.sample_stride = stride;
     a.sample = c.dBSample.p;
     a.sample_rows = sample_rows;
-    VT_HIP(scores(true, std::min<uint32_t>(ntiles_sample, grid_cap)));
-    VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, nq_pad, (uint32_t)nq, rank, c.dBTau.p, c.stream));
+    if (by_maxima) {
+      a.sample_rows = sample_groups;
+      VT_HIP(vt::launch_batch_sample_maxima_shadow(a, std::min<uint32_t>(ntiles_sample, grid_cap), c.stream));
+      VT_HIP(vt::launch_sample_tau_groups(c.dBSample.p, sample_groups, nq_pad, (uint32_t)nq, rank, c.dBTau.p, c.stream));
+    } else {
+      VT_HIP(scores(true, std::min<uint32_t>(ntiles_sample, grid_cap)));
+      VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, nq_pad, (uint32_t)nq, rank, c.dBTau.p, c.stream));
+    }
   }
   // pass 1: all rows, candidates with score >= tau
   a.n = n;

@@ -409,6 +409,7 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   std::atomic<bool> aborted{false};                   // the copy gave up (device error): nobody will finish the check
   std::atomic<size_t> ids_done{0};                    // ids the id thread has placed (the lock-step test hook waits on it)
   std::atomic<bool> id_exited{false};
+  std::atomic<bool> id_failed_early{false};           // the id thread could not even reserve its room: the copy need not go on
   std::thread checker;
   double t_checked = 0.0;
   if (src.unvalidated && !fused)
@@ -522,9 +523,12 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
       return VT_OK;
     });
     if (hst != VT_OK) {
-      while (checked.load() == 0 && !aborted.load()) std::this_thread::yield();
+      // (no room for the ids: nothing has changed yet -- the copy loop stops at its next quarter, the rows it
+      // has already put behind the index are zeroed again below)
       id_status = hst;
       id_error = g_last_error;
+      id_failed_early.store(true);
+      id_exited.store(true);
       return;
     }
     // what index_row_for changes, for the way back
@@ -636,7 +640,7 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
       copy_status = fail(VT_ERR_DEVICE, "hipStreamCreate (staging)");
     bool used[kQuarters] = {};
     size_t i = 0;
-    for (int q = 0; i < count && copy_status == VT_OK && checked.load() != 2; q = (q + 1) % kQuarters) {
+    for (int q = 0; i < count && copy_status == VT_OK && checked.load() != 2 && !id_failed_early.load(); q = (q + 1) % kQuarters) {
       float *stage = reinterpret_cast<float *>(c.hStage.p) + (size_t)q * stage_rows * ld;
       const size_t chunk = std::min(stage_rows, count - i);
       if (used[q] && hipEventSynchronize(done[q]) != hipSuccess) copy_status = fail(VT_ERR_DEVICE, "hipEventSynchronize (staging quarter)");
@@ -716,7 +720,15 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
     if (ix->n == 0) ix->dim = -1;  // (the dimension was set for this batch: a rejected first batch leaves none behind)
     return VT_ERR_NON_FINITE;
   }
-  if (id_status != VT_OK) return fail(id_status, id_error);    // (*began is set: the caller poisons the handle)
+  if (id_status != VT_OK) {
+    // (*began set: ids went in and something failed behind them -- the caller poisons the handle; not set: the id
+    // thread never started on the table, the index is what it was once the free rows are zeros again)
+    if (!*began) {
+      zero_free_rows();
+      if (ix->n == 0) ix->dim = -1;
+    }
+    return fail(id_status, id_error);
+  }
   if (copy_status != VT_OK) {
     if (rolled_back) zero_free_rows();  // (the ids came out again: nothing of the batch stays)
     return fail(copy_status, copy_error);
@@ -770,6 +782,12 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
   Ctx &c = ix->ctx;
   const size_t d = (size_t)ix->dim;
   if ((uint64_t)ix->n + count > 0xFFFFFFF0ull) return fail(VT_ERR_UNSUPPORTED, "more than 2^32-16 rows");
+  // rows when the call began.  (A bulk load that hands over to this path -- kRetryGeneral: its ids were not all new and
+  // distinct -- has already put every id into the table and grown n and rank_host: the rank bookkeeping at the end must
+  // cover the rows IT added, not only the ones added below -- none.  ADVICE r4: ids ascending above max_id with one
+  // duplicate, or a sorted snapshot reloaded over existing ids plus new ones, kept ranks_clean and left the device
+  // column without the new rows' ranks, null on a first load.)
+  const uint32_t n_entry = ix->n;
   if (src.host && !src.device && !src.off && !src.pick && count >= 65536 && !vt::env::on(vt::env::INGEST_SERIAL)) {
     const int st = index_store_bulk_host(ix, count, ids, id_off, src, began);  // (makes room itself, beside the check)
     if (st != kRetryGeneral) return st;
@@ -960,20 +978,20 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
   // small part of what is already there: re-ranking costs a pass over ALL ids, and a corpus that
   // arrives in many appends would pay it every time (84 M rows in 21 appends: 14 s each); the
   // next search does it once.  Trickling inserts leave their rows unranked for the lazy search path.
-  const bool rank_now = !ix->ranks_clean && count >= kBulkRankRows && count >= (size_t)n_before / 4;
+  const bool rank_now = !ix->ranks_clean && count >= kBulkRankRows && count >= (size_t)n_entry / 4;
   if (!ix->ranks_clean && !rank_now) {
     // the device column is brought up to date lazily (index_lazy_ranks) or by the next re-rank
     if (count < kBulkRankRows)
-      for (uint32_t r = n_before; r < ix->n; ++r) ix->rank_dirty.push_back(r);
+      for (uint32_t r = n_entry; r < ix->n; ++r) ix->rank_dirty.push_back(r);
     else
       ix->rank_dirty_all = true;
     if (ix->rank_dirty.size() > kMaxDirtyRanks) ix->rank_dirty_all = true;
   }
   // keep device ranks current when they stayed valid (sorted appends)
-  if (ix->ranks_clean && ix->n > n_before) {
-    uint32_t from = n_before;
-    if (ix->dRank.count < ix->cap) {
-      VT_TRY(ix->dRank.ensure(ix->cap));
+  if (ix->ranks_clean && ix->n > n_entry) {
+    uint32_t from = n_entry;
+    if (ix->dRank.count < std::max<size_t>(ix->cap, ix->n)) {
+      VT_TRY(ix->dRank.ensure(std::max<size_t>(ix->cap, ix->n)));
       from = 0;
     }
     VT_HIP(hipMemcpyAsync(ix->dRank.p + from, ix->rank_host.data() + from, (size_t)(ix->n - from) * sizeof(uint32_t),

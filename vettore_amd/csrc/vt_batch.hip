@@ -791,6 +791,60 @@ hipError_t launch_batch_scores(const BatchScoreArgs &a0, bool dense, uint32_t bl
   }
 }
 
+// tau_b from the sample's GROUP MAXIMA (K2s since r05: the sample pass files, per query, the best score of every
+// 64-row group of its tiles -- `groups` <= 1 024 values -- instead of every score): the `rank`-th largest of them.
+// Every maximum is one of the sample's scores, so this is at most the `rank`-th largest score of the whole sample
+// (equal to it unless two of the `rank` best share a group: the host only comes here with rank * 16 <= groups) -- a
+// threshold that is a little lower nominates a few more rows and changes nothing else.  One wave per query, 16 keys
+// per lane in registers, the answer bit by bit from the top: 32 steps of 16 compares and a count -- ~3 us per launch
+// where the radix select over 65 536 scores took 45 (and wrote / read 64 MB around it).
+constexpr int kTauGroupsPerLane = 16;
+__global__ __launch_bounds__(256) void sample_tau_groups_kernel(const float *__restrict__ maxima, uint32_t groups, uint32_t rank,
+                                                                float *__restrict__ tau, uint32_t nq, uint32_t nq_real) {
+  const uint32_t q = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+  const int lane = threadIdx.x & (kWave - 1);
+  if (q >= nq) return;
+  if (q >= nq_real) {  // padding columns of the batch (all-zero queries) must never nominate a row
+    if (lane == 0) tau[q] = INFINITY;
+    return;
+  }
+  const float *v = maxima + (size_t)q * groups;
+  uint32_t key[kTauGroupsPerLane];  // ascending with the score; 0 = absent (below every real score's key)
+#pragma unroll
+  for (int u = 0; u < kTauGroupsPerLane; ++u) {
+    const uint32_t i = (uint32_t)lane + (uint32_t)u * kWave;
+    key[u] = i < groups ? orderable(v[i]) : 0u;
+  }
+  uint32_t t = 0;
+  for (int b = 31; b >= 0; --b) {
+    const uint32_t cand = t | (1u << b);
+    uint32_t c = 0;
+#pragma unroll
+    for (int u = 0; u < kTauGroupsPerLane; ++u) c += (uint32_t)__builtin_popcountll(__ballot(key[u] >= cand));
+    if (c >= rank) t = cand;  // (wave-uniform: every lane counted the same ballots)
+  }
+  // fewer than `rank` values (t stayed 0): the smallest score of the sample
+  if (t == 0u) {
+    uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < kTauGroupsPerLane; ++u) mn = (key[u] != 0u && key[u] < mn) ? key[u] : mn;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const uint32_t x = (uint32_t)__shfl_xor((int)mn, o, kWave);
+      mn = x < mn ? x : mn;
+    }
+    t = mn;
+  }
+  if (lane == 0) tau[q] = __uint_as_float((t & 0x80000000u) ? (t & 0x7FFFFFFFu) : ~t);
+}
+
+hipError_t launch_sample_tau_groups(const float *maxima, uint32_t groups, uint32_t nq, uint32_t nq_real, uint32_t rank, float *tau,
+                                    hipStream_t s) {
+  if (groups == 0 || groups > (uint32_t)kTauGroupsPerLane * kWave || rank == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sample_tau_groups_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, maxima, groups, rank, tau, nq, nq_real);
+  return hipGetLastError();
+}
+
 hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t nq_real, uint32_t rank,
                              float *tau, hipStream_t s) {
   hipLaunchKernelGGL(sample_tau_kernel, dim3(nq), dim3(kTauThreads), 0, s, sample, sample_rows, rank, tau, nq_real);

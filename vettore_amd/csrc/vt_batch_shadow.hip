@@ -148,12 +148,21 @@ __device__ __forceinline__ void append_candidates16(const BatchScoreArgs &a, f32
 }
 
 // A wave's finished 64-row x (16 QTW)-query tile (C layout of 16x16x32: column = lane & 15 = query,
-// row = 4 (lane >> 4) + register): pass 0 writes the dense sample matrix, pass 1 appends the scores
-// that reach the query's threshold.  grow0 / srow0: the wave's first row in the index / the sample.
-template <bool DENSE, int QTW, unsigned DBG>
+// row = 4 (lane >> 4) + register).  MODE 0 (the pass): scores that reach the query's threshold are appended.
+// MODE 1 (dense): the whole sample matrix is written (tools/k2s_probe compares it with K2b's).  MODE 2 (r05, what the
+// sample pass runs): per query only the LARGEST score of the wave's 64 rows -- sample[q][4 tile + rg]; the threshold
+// is then taken from those maxima (sample_tau_groups_kernel), 4 KB per query instead of 256.
+// grow0 / srow0: the wave's first row in the index / the sample; gslot: the wave's slot in the maxima.
+enum { kModePass = 0, kModeDense = 1, kModeMaxima = 2 };
+template <int MODE, int QTW, unsigned DBG>
 __device__ __forceinline__ void tile_epilogue16(const BatchScoreArgs &a, f32x4 (&acc)[kRT][QTW], const float (&tau)[QTW],
-                                                uint32_t grow0, uint32_t srow0, uint32_t qbase, int lane) {
+                                                uint32_t grow0, uint32_t srow0, uint32_t gslot, uint32_t qbase, int lane) {
   const int c16 = lane & 15, g = lane >> 4;
+  float gmax[QTW];
+  if (MODE == kModeMaxima) {
+#pragma unroll
+    for (int j = 0; j < QTW; ++j) gmax[j] = -INFINITY;
+  }
 #pragma unroll
   for (int i = 0; i < kRT; ++i) {
     // L2 family: the 16 row norms of this sub-tile through the scalar cache (a vector load would sit in
@@ -183,21 +192,35 @@ __device__ __forceinline__ void tile_epilogue16(const BatchScoreArgs &a, f32x4 (
         for (int e = 0; e < 4; ++e) v[e] = 2.0f * v[e] - xn[e];
       }
       uint32_t qcol = qbase + 16 * j + c16;
-      if (DENSE) {
+      if (MODE == kModeDense) {
         asm volatile("" : "+v"(qcol));
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           a.sample[(size_t)qcol * a.sample_rows + srow0 + 16 * i + 4 * g + e] = row0 + e < a.n_total ? v[e] : -INFINITY;
+      } else if (MODE == kModeMaxima) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gmax[j] = fmaxf(gmax[j], row0 + e < a.n_total ? v[e] : -INFINITY);
       } else {
         const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
         if (mx >= tau[j] && !VT_SDBG(a, 8u)) append_candidates16(a, v, tau[j], qcol, row0);
       }
     }
   }
+  if (MODE == kModeMaxima) {
+    // the four lanes that hold a query's rows (c16, c16 + 16, + 32, + 48) meet; lane group 0 files the maximum
+#pragma unroll
+    for (int j = 0; j < QTW; ++j) {
+      float m = gmax[j];
+      m = fmaxf(m, __shfl_xor(m, 16, kWave));
+      m = fmaxf(m, __shfl_xor(m, 32, kWave));
+      if (g == 0) a.sample[(size_t)(qbase + 16 * j + c16) * a.sample_rows + gslot] = m;
+    }
+  }
 }
 
-template <bool DENSE, int QTW, int S, unsigned DBG>
+template <int MODE, int QTW, int S, unsigned DBG>
 __global__ __launch_bounds__(kWavesS *kWave, 1) void shadow_scores_kernel(const BatchScoreArgs a) {
+  constexpr bool DENSE = MODE != kModePass;  // (the sample's tiles: every sample_stride-th, no thresholds)
   constexpr uint32_t kBStage = b_stage(QTW);
   constexpr uint32_t kStage = kAStage + kBStage;
   constexpr int kPieces = 2 + b_pieces(QTW);  // per wave and chunk
@@ -352,7 +375,8 @@ __global__ __launch_bounds__(kWavesS *kWave, 1) void shadow_scores_kernel(const 
     }
 
     const uint32_t tile = tile_index(k);
-    tile_epilogue16<DENSE, QTW, DBG>(a, acc, tau, tile * kRowsS + rg * 64, (blockIdx.x + k * gridDim.x) * kRowsS + rg * 64, qbase, lane);
+    tile_epilogue16<MODE, QTW, DBG>(a, acc, tau, tile * kRowsS + rg * 64, (blockIdx.x + k * gridDim.x) * kRowsS + rg * 64,
+                                    (blockIdx.x + k * gridDim.x) * 4 + rg, qbase, lane);
   }
 }
 
@@ -365,20 +389,22 @@ hipError_t launch_one_s(K kern, size_t lds_bytes, const BatchScoreArgs &a, uint3
 }
 
 template <int QTW, int S>
-hipError_t launch_qs(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
+hipError_t launch_qs(const BatchScoreArgs &a, int mode, uint32_t blocks, hipStream_t s) {
+  const bool dense = mode != kModePass;
   const size_t lds_bytes = (size_t)S * (kAStage + b_stage(QTW));
 #ifdef VT_BATCH_TIMING_EXPERIMENTS
   if (a.debug && !dense && QTW == 8 && S == 5) {  // (the modes tools/k2s_probe.hip asks for: 256 columns, five stages)
     switch (a.debug) {
-#define VT_MODE(M) case M: return launch_one_s(shadow_scores_kernel<false, 8, 5, M>, lds_bytes, a, blocks, s);
+#define VT_MODE(M) case M: return launch_one_s(shadow_scores_kernel<kModePass, 8, 5, M>, lds_bytes, a, blocks, s);
       VT_MODE(2u) VT_MODE(8u) VT_MODE(10u) VT_MODE(1u) VT_MODE(3u) VT_MODE(5u) VT_MODE(16u) VT_MODE(20u) VT_MODE(22u) VT_MODE(48u) VT_MODE(52u) VT_MODE(54u)
 #undef VT_MODE
       default: return hipErrorInvalidValue;
     }
   }
 #endif
-  return dense ? launch_one_s(shadow_scores_kernel<true, QTW, S, 0u>, lds_bytes, a, blocks, s)
-               : launch_one_s(shadow_scores_kernel<false, QTW, S, 0u>, lds_bytes, a, blocks, s);
+  if (mode == kModeMaxima) return launch_one_s(shadow_scores_kernel<kModeMaxima, QTW, S, 0u>, lds_bytes, a, blocks, s);
+  return dense ? launch_one_s(shadow_scores_kernel<kModeDense, QTW, S, 0u>, lds_bytes, a, blocks, s)
+               : launch_one_s(shadow_scores_kernel<kModePass, QTW, S, 0u>, lds_bytes, a, blocks, s);
 }
 
 // stages of the LDS ring: 5 x 32 KiB is all of a CU's LDS at 256 query columns
@@ -421,7 +447,19 @@ hipError_t launch_batch_q_image16(const float *Q, uint32_t ld, uint32_t nq_pad, 
   return hipGetLastError();
 }
 
+static hipError_t launch_shadow_mode(const BatchScoreArgs &a0, int mode, uint32_t blocks, hipStream_t s);
 hipError_t launch_batch_scores_shadow(const BatchScoreArgs &a0, bool dense, uint32_t blocks, hipStream_t s) {
+  return launch_shadow_mode(a0, dense ? kModeDense : kModePass, blocks, s);
+}
+// The sample pass as the library runs it since r05: a.sample is [nq_pad][a.sample_rows] with a.sample_rows = 4 x the
+// launch's tiles -- the best score of every 64-row group of the sample (batch_shadow_sample_groups) -- and
+// launch_sample_tau_groups takes the thresholds from it.
+hipError_t launch_batch_sample_maxima_shadow(const BatchScoreArgs &a, uint32_t blocks, hipStream_t s) {
+  return launch_shadow_mode(a, kModeMaxima, blocks, s);
+}
+uint32_t batch_shadow_sample_groups(uint32_t sample_tiles) { return sample_tiles * (kRowsS / 64); }
+
+static hipError_t launch_shadow_mode(const BatchScoreArgs &a0, int dense, uint32_t blocks, hipStream_t s) {
   BatchScoreArgs a = a0;
 #ifndef VT_BATCH_TIMING_EXPERIMENTS
   a.debug = 0u;

@@ -395,7 +395,14 @@ hipError_t launch_shadow_rows(const float *X, size_t stride, const uint32_t *lis
                               hipStream_t s);
 hipError_t launch_batch_q_image16(const float *Q, uint32_t ld, uint32_t nq_pad, void *image, hipStream_t s);
 hipError_t launch_batch_scores_shadow(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s);
+// the sample pass in its r05 form: per query the best score of every 64-row group of the sampled tiles --
+// a.sample is [nq_pad][a.sample_rows], a.sample_rows = batch_shadow_sample_groups(tiles of the launch)
+hipError_t launch_batch_sample_maxima_shadow(const BatchScoreArgs &a, uint32_t blocks, hipStream_t s);
+uint32_t batch_shadow_sample_groups(uint32_t sample_tiles);
 // tau[b] for the nq_real real queries; +inf for the padding columns b >= nq_real.
+// (K2s since r05: the threshold from the sample's group maxima, [nq][groups] with groups <= 1 024)
+hipError_t launch_sample_tau_groups(const float *maxima, uint32_t groups, uint32_t nq, uint32_t nq_real, uint32_t rank, float *tau,
+                                    hipStream_t s);
 hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t nq, uint32_t nq_real, uint32_t rank,
                              float *tau, hipStream_t s);
 // xnorm2[i] = (f32) sum_j x_ij^2 (f64 accumulation); *out_bits = bit pattern of

@@ -92,14 +92,6 @@ __device__ __forceinline__ float pm_chunk(float acc, const f32x2 (&x)[4], const 
   return comb<OP>(0, acc, pm_reduce<OP, ORDER>(e));
 }
 
-// recover_overflow (vt_scan.cuh) with the result by value -- NaN where there is none: an out-parameter lives in scratch
-// memory, and the s_waitcnt vmcnt(0) the compiler puts behind the (rare) branch that reloads it sits in EVERY tile's
-// epilogue, once per query, where it waits for the next tile's sixteen panel loads
-__device__ __noinline__ static float recover_or_nan(int metric, const float *q, const float *x, uint32_t d) {
-  float rec;
-  return recover_overflow(metric, q, x, d, &rec) ? rec : __builtin_nanf("");
-}
-
 template <int OP, int ORDER>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(const PrefixMultiArgs a) {
   extern __shared__ __align__(16) float pm_lds[];
@@ -194,7 +186,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
       else if (metric == M_L2) raw = finite_f32(raw) ? __builtin_sqrtf(raw) : raw;
       bool valid = valid_row;
       if (valid && !finite_f32(raw)) {
-        raw = recover_or_nan(metric, a.Q + (size_t)q * qst, a.X + (size_t)grow * a.stride, a.d);
+        raw = recover_overflow(metric, a.Q + (size_t)q * qst, a.X + (size_t)grow * a.stride, a.d);
         if (raw != raw) {
           if (!dense) atomicMax(a.status, kErrOverflow);
           valid = false;

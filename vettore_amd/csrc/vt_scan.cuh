@@ -160,8 +160,14 @@ __device__ __forceinline__ float chunk_sum(int op_rt, int order_rt, float p0, fl
 
 // distances.rs:70-90 recover_metric_overflow (+ the f64 branch of l2(),
 // distances.rs:140-147), run by the one lane whose f32 result was non-finite.
-__device__ __noinline__ static bool recover_overflow(int metric, const float *q, const float *x, uint32_t d,
-                                                     float *out) {
+// The recovered value comes back BY VALUE -- NaN where there is none (a recovered value is finite by
+// construction, f64_to_f32): an out-parameter of a function that is not inlined lives in scratch memory, every
+// launch of a kernel that may call it then sets up a scratch segment, and the reload behind the (rare) branch puts
+// an s_waitcnt vmcnt(0) into every tile's epilogue (K1p, r04; K1 and K1m carried 16 bytes per lane until r05).
+__device__ __forceinline__ float f64_as_f32_or_nan(double v) {  // distances.rs:92-98 f64_to_f32
+  return isfinite(v) && v >= -(double)FLT_MAX && v <= (double)FLT_MAX ? (float)v : __builtin_nanf("");
+}
+__device__ __noinline__ static float recover_overflow(int metric, const float *q, const float *x, uint32_t d) {
   double acc = 0.0;
   switch (metric) {
     case M_L2:
@@ -174,25 +180,21 @@ __device__ __noinline__ static bool recover_overflow(int metric, const float *q,
         // l2(): (f64 sqrt) as f32, accepted when finite; compute()'s later
         // recovery reaches the same value or fails identically.
         const float v = (float)sqrt(acc);
-        if (finite_f32(v)) {
-          *out = v;
-          return true;
-        }
-        return false;
+        return finite_f32(v) ? v : __builtin_nanf("");
       }
-      return f64_to_f32(acc, out);
+      return f64_as_f32_or_nan(acc);
     case M_COS:
     case M_IP:
     case M_NIP:
       for (uint32_t i = 0; i < d; ++i) acc += (double)q[i] * (double)x[i];
-      return f64_to_f32(metric == M_NIP ? -acc : acc, out);
+      return f64_as_f32_or_nan(metric == M_NIP ? -acc : acc);
     case M_L1:
       for (uint32_t i = 0; i < d; ++i) acc += fabs((double)q[i] - (double)x[i]);
-      return f64_to_f32(acc, out);
+      return f64_as_f32_or_nan(acc);
     case M_LINF:
       for (uint32_t i = 0; i < d; ++i) acc = fmax(acc, fabs((double)q[i] - (double)x[i]));
-      return f64_to_f32(acc, out);
-    default: return false;
+      return f64_as_f32_or_nan(acc);
+    default: return __builtin_nanf("");
   }
 }
 
@@ -439,8 +441,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void scan_topk_kernel(const 
       }
       bool valid = row_valid;
       if (valid && !finite_f32(raw)) {
-        float rec;
-        if (recover_overflow(metric, QGLOBAL ? qsrc : lds, a.X + (size_t)src_row * a.stride, a.d, &rec)) {
+        const float rec = recover_overflow(metric, QGLOBAL ? qsrc : lds, a.X + (size_t)src_row * a.stride, a.d);
+        if (rec == rec) {
           raw = rec;
         } else {
           atomicMax(a.status, kErrOverflow);

@@ -580,9 +580,13 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, SLIM ? 3 : 2) void scan_mult
         const uint32_t row = mine ? s_redo[wib][lane] : 0u, rq = mine ? s_redo_q[wib][lane] : 0u;
         float raw = 0.0f;
         bool valid = mine;
-        if (mine && !recover_overflow(a.metric, a.Q + (size_t)rq * ld, a.X + (size_t)row * a.stride, a.d, &raw)) {
-          atomicMax(a.status, kErrOverflow);
-          valid = false;
+        if (mine) {
+          raw = recover_overflow(a.metric, a.Q + (size_t)rq * ld, a.X + (size_t)row * a.stride, a.d);
+          if (raw != raw) {  // (NaN: no f32 holds the value, distances.rs:92-98)
+            atomicMax(a.status, kErrOverflow);
+            valid = false;
+            raw = 0.0f;
+          }
         }
         float rank = raw;
         if (a.metric == M_COS) rank = 1.0f - raw;
