@@ -1,0 +1,42 @@
+#!/bin/bash
+# The round's run records that the driver does not produce itself (VERDICT r4 #3c): the `-m gpu_perf` guards and the
+# soaks on the build that is in the tree, kept under profiles/<round>/.
+#   gpurun --timeout 2700 -- 'RND=r05 bash tools/evidence.sh'      (then: cp -r gpurun_out/evidence/r05/* profiles/r05/)
+# SOAK_SCALE (default 1.0) scales every soak's seconds; PERF=0 / SOAKS=0 skip a part.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+RND=${RND:-r05}
+OUT=$R/gpurun_out/evidence/$RND
+mkdir -p $OUT
+cd $R
+S=${SOAK_SCALE:-1.0}
+secs() { python3 -c "print(max(20, int($1 * $S)))"; }
+if [ "${PERF:-1}" != "0" ]; then
+  # (-s: the guards print what they measured)
+  timeout 1500 python3 -m pytest tests -m gpu_perf -s -q > $OUT/gpu_perf.log 2>&1
+  tail -3 $OUT/gpu_perf.log
+fi
+if [ "${SOAKS:-1}" != "0" ]; then
+  {
+    echo "# $(date -u +%Y-%m-%dT%H:%MZ) soaks on $(git -C $R rev-parse --short HEAD 2>/dev/null || echo 'the tree as sent'), SOAK_SCALE=$S"
+    echo "# soak_groups (grouped paths: funnel batches under nine metrics, plain batches as K1p sweeps)"
+    SECONDS=$(secs 240) python3 tools/soak_groups.py 2>&1 | tail -1
+    echo "# soak_all (every search entry point, plain handle)"
+    SECONDS=$(secs 200) python3 tools/soak_all.py 2>&1 | tail -1
+    echo "# soak_all SHARDS=3"
+    SECONDS=$(secs 150) SHARDS=3 python3 tools/soak_all.py 2>&1 | tail -1
+    echo "# soak_all METRICS=1,4,6,7,8"
+    SECONDS=$(secs 150) METRICS=1,4,6,7,8 python3 tools/soak_all.py 2>&1 | tail -1
+    echo "# soak_mutations"
+    SECONDS=$(secs 120) python3 tools/soak_mutations.py 2>&1 | tail -1
+    echo "# soak_pattern"
+    SECONDS=$(secs 90) python3 tools/soak_pattern.py 2>&1 | tail -1
+    echo "# soak_upsert_search"
+    SECONDS=$(secs 90) python3 tools/soak_upsert_search.py 2>&1 | tail -1
+    echo "# soak_concurrent (8 readers + a writer), then SHARDS=3"
+    SECONDS=$(secs 150) python3 tools/soak_concurrent.py 2>&1 | tail -1
+    SECONDS=$(secs 120) SHARDS=3 python3 tools/soak_concurrent.py 2>&1 | tail -1
+    echo "# soak_batch_pipeline (r05: batch calls of 2..5 groups of 256 on two contexts, every list against the oracle)"
+    SECONDS=$(secs 150) python3 tools/soak_batch_pipeline.py 2>&1 | tail -1
+  } > $OUT/soaks.log 2>&1
+  cat $OUT/soaks.log
+fi

@@ -247,11 +247,21 @@ template <typename T>
 struct PinnedBuf {
   T *p = nullptr;
   size_t count = 0;
+  T *dev = nullptr;  // the same block as a kernel sees it (mapped()), while it is the same block
   ~PinnedBuf() { release(); }
   void release() {
     if (p) (void)hipHostFree(p);
     p = nullptr;
+    dev = nullptr;
     count = 0;
+  }
+  // the device-side address of the (host-mapped) block: kernels write results straight into it
+  T *mapped() {
+    if (!dev && p && hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), p, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      dev = nullptr;
+    }
+    return dev;
   }
   int ensure(size_t want) {
     if (want <= count) return VT_OK;

@@ -37,7 +37,7 @@ struct BatchGroupRun {
 // else is queued meanwhile -- the previous group's exact rescoring and select, the next group's sample pass and
 // thresholds -- runs between two passes unless some CUs are left for it.
 int batch_group_queue(Shard *ix, Ctx &c, BatchGroupRun &run, const float *queries, size_t nq, size_t limit, bool bf16,
-                      const float *tau_given, uint32_t idle_cus = 0) {
+                      const float *tau_given, uint32_t idle_cus = 0, bool pipelined = false) {
   const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
   const uint32_t k = (uint32_t)std::min<size_t>(limit, n);
   const auto t_begin = std::chrono::steady_clock::now();
@@ -55,25 +55,45 @@ int batch_group_queue(Shard *ix, Ctx &c, BatchGroupRun &run, const float *querie
   // A larger sample gives a tighter tau: fewer candidates to rescore and, above
   // all, fewer trips through the epilogue's append path (a returning global
   // atomic, ~2 us with the matrix pipe idle: 5 % of the pass at 128 tiles).
-  // (at most 65 536 sample rows: sample_tau_kernel holds a query's sample in registers)
-  const uint32_t want_tiles = std::min<uint32_t>(std::min<uint32_t>(512, 65536 / rows_per_block),
-                                                 std::max<uint32_t>(128, ntiles_total / 64));
-  const uint32_t stride = std::max<uint32_t>(1, (ntiles_total + want_tiles - 1) / want_tiles);
-  const uint32_t ntiles_sample = (ntiles_total + stride - 1) / stride;
-  const uint32_t sample_rows = ntiles_sample * rows_per_block;
-  // tau = rank-th best sample score: about rank * n / sample_rows rows pass.  K2b's margin is
-  // ~0.2 sigma of a score distribution where K2's is ~1e-4, so its tau sits lower: the k-th hit
-  // must clear it by that margin or the query costs a second pass.
-  const double ratio = (double)sample_rows / (double)n;
-  const double want_cand = bf16 ? std::min(32.0 * k, std::max(8.0 * k, 4096.0)) : 8.0 * k;
-  uint32_t rank = (uint32_t)std::ceil(want_cand * std::min(1.0, ratio));
-  rank = std::max<uint32_t>(bf16 ? bf16_min_rank() : 3, std::min<uint32_t>(rank, std::min<uint32_t>(sample_rows, n)));
-  // test hook (vt_debug_set "bf16_rank"): K2b's threshold from exactly the r-th best sample score
-  // (r = limit leaves no margin at all: every query then needs the second pass)
-  if (bf16) {
-    const long v = vt::env::get(vt::env::BF16_RANK);
-    if (v >= 1) rank = std::min<uint32_t>((uint32_t)v, std::min<uint32_t>(sample_rows, n));
-  }
+  // (at most 65 536 sample rows where the whole sample matrix is kept: sample_tau_kernel holds a query's sample in
+  // registers.  K2s files one value per query and 64-row GROUP instead -- the group's best score -- and takes the
+  // threshold from those, as long as the rank is small beside the groups (two of the `rank` best rarely share one);
+  // it may then sample more tiles for the same money: VT_BATCH_SAMPLE_TILES, A/B.)
+  struct SamplePlan {
+    uint32_t stride, ntiles, rows, rank, groups;
+    bool by_maxima;
+  };
+  auto plan_sample = [&](uint32_t tiles_cap) {
+    SamplePlan sp{};
+    const uint32_t want_tiles = std::min<uint32_t>(std::min<uint32_t>(512, tiles_cap), std::max<uint32_t>(128, ntiles_total / 64));
+    sp.stride = std::max<uint32_t>(1, (ntiles_total + want_tiles - 1) / want_tiles);
+    sp.ntiles = (ntiles_total + sp.stride - 1) / sp.stride;
+    sp.rows = sp.ntiles * rows_per_block;
+    // tau = rank-th best sample score: about rank * n / sample_rows rows pass.  K2b's margin is
+    // ~0.2 sigma of a score distribution where K2's is ~1e-4, so its tau sits lower: the k-th hit
+    // must clear it by that margin or the query costs a second pass.
+    const double ratio = (double)sp.rows / (double)n;
+    const double want_cand = bf16 ? std::min(32.0 * k, std::max(8.0 * k, 4096.0)) : 8.0 * k;
+    uint32_t rank = (uint32_t)std::ceil(want_cand * std::min(1.0, ratio));
+    rank = std::max<uint32_t>(bf16 ? bf16_min_rank() : 3, std::min<uint32_t>(rank, std::min<uint32_t>(sp.rows, n)));
+    // test hook (vt_debug_set "bf16_rank"): K2b's threshold from exactly the r-th best sample score
+    // (r = limit leaves no margin at all: every query then needs the second pass)
+    if (bf16) {
+      const long v = vt::env::get(vt::env::BF16_RANK);
+      if (v >= 1) rank = std::min<uint32_t>((uint32_t)v, std::min<uint32_t>(sp.rows, n));
+    }
+    sp.rank = rank;
+    sp.groups = vt::batch_shadow_sample_groups(sp.ntiles);
+    sp.by_maxima = shadow && !tau_given && (uint64_t)rank * 16 <= sp.groups && sp.groups <= 2048;
+    return sp;
+  };
+  const uint32_t dense_cap = 65536 / rows_per_block;
+  const long tiles_setting = vt::env::get(vt::env::BATCH_SAMPLE_TILES);
+  // (K2s: 512 tiles by default -- 33 us -> 60 us of sample pass, half the candidates to rescore behind the pass)
+  SamplePlan sp = plan_sample(!shadow ? dense_cap : tiles_setting >= 64 && tiles_setting <= 512 ? (uint32_t)tiles_setting : 512u);
+  if (!sp.by_maxima && sp.rows > 65536) sp = plan_sample(dense_cap);
+  const uint32_t stride = sp.stride, ntiles_sample = sp.ntiles, sample_rows = sp.rows, rank = sp.rank, sample_groups = sp.groups;
+  const bool by_maxima = sp.by_maxima;
   const uint32_t cand_cap = 8192;
   const uint32_t kBlocksPerQuery = [] {  // blocks of the exact rescoring per query (VT_RESCORE_BLOCKS: A/B)
     const long v = vt::env::get(vt::env::RESCORE_BLOCKS);
@@ -84,11 +104,6 @@ int batch_group_queue(Shard *ix, Ctx &c, BatchGroupRun &run, const float *querie
   VT_TRY(c.hBQ.ensure((size_t)nq_pad * ld));
   VT_TRY(c.dBTau.ensure(nq_pad));
   VT_TRY(c.hBTau.ensure(nq_pad));
-  // K2s: the sample pass files one value per query and 64-row group (the group's best score) and the threshold is the
-  // rank-th largest of those -- as long as the rank is small beside the groups (two of the `rank` best rarely share one);
-  // otherwise, and for K2 / K2b, the whole sample matrix and the radix select over it
-  const uint32_t sample_groups = vt::batch_shadow_sample_groups(ntiles_sample);
-  const bool by_maxima = shadow && !tau_given && (uint64_t)rank * 16 <= sample_groups && sample_groups <= 1024;
   if (!tau_given) VT_TRY(c.dBSample.ensure((size_t)nq_pad * (by_maxima ? sample_groups : sample_rows)));
   VT_TRY(c.dBCand.ensure((size_t)nq_pad * cand_cap));
   VT_TRY(c.dBCount.ensure(nq_pad));
@@ -167,7 +182,13 @@ int batch_group_queue(Shard *ix, Ctx &c, BatchGroupRun &run, const float *querie
   a.cand_cap = cand_cap;
   VT_HIP(hipMemsetAsync(c.dBCount.p, 0, (size_t)nq_pad * sizeof(uint32_t), c.stream));
   if (c.profiling) VT_HIP(hipEventRecord(c.ev2, c.stream));
+  // (between groups of one call the pass keeps a four-stage ring: 32 KB of every CU's LDS stay free, so the neighbours'
+  // small kernels -- the select behind the previous group's rescoring above all, 640 B of LDS and 26 registers -- are
+  // dispatched beside the resident blocks of the pass instead of behind its last one: the trace of the five-stage
+  // form showed batch_select_kernel waiting 3.6 ms for a CU, and with it the host and the group after next)
+  if (shadow && pipelined) a.stages = 4;
   VT_HIP(scores(false, std::min<uint32_t>(ntiles_total, shadow && idle_cus < grid_cap / 2 ? grid_cap - idle_cus : grid_cap)));
+  a.stages = 0;
   if (c.profiling) VT_HIP(hipEventRecord(c.ev3, c.stream));
   // exact rescoring of every query's candidates with the K1 arithmetic
   vt::ScanArgs sa{};
@@ -188,14 +209,19 @@ int batch_group_queue(Shard *ix, Ctx &c, BatchGroupRun &run, const float *querie
   sa.batch_counts = c.dBCount.p;
   sa.batch_cap = cand_cap;
   VT_HIP(vt::launch_scan_batch(sa, kBlocksPerQuery, nq_pad, c.stream));
-  VT_HIP(vt::launch_batch_select(c.dPartKeys.p, c.dPartPay.p, nq_pad, kBlocksPerQuery * k, k, c.dBOut.p, c.dBOutCount.p,
-                                 c.stream));
-  VT_HIP(hipMemcpyAsync(c.hBOut.p, c.dBOut.p, (size_t)nq_pad * k * sizeof(vt::Entry), hipMemcpyDeviceToHost, c.stream));
-  VT_HIP(hipMemcpyAsync(c.hBOutCount.p, c.dBOutCount.p, (size_t)nq_pad * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
-  VT_HIP(hipMemcpyAsync(c.hBCount.p, c.dBCount.p, (size_t)nq_pad * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
-  if (!tau_given) VT_HIP(hipMemcpyAsync(c.hBTau.p, c.dBTau.p, (size_t)nq_pad * sizeof(float), hipMemcpyDeviceToHost, c.stream));
-  VT_HIP(hipMemcpyAsync(&c.hBOutCount.p[nq_pad], c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-  VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
+  // the lists, their counts, every query's candidate count and threshold and the status word leave with the select
+  // kernel, written straight into the host-mapped blocks (r05: four blit launches and a memset per group before)
+  vt::BatchExport ex{};
+  ex.cand_count = c.dBCount.p;
+  ex.cand_count_out = c.hBCount.mapped();
+  ex.tau = tau_given ? nullptr : c.dBTau.p;
+  ex.tau_out = tau_given ? nullptr : c.hBTau.mapped();
+  ex.status = c.dStatus.p;
+  ex.status_out = reinterpret_cast<int *>(c.hBOutCount.mapped() + nq_pad);
+  if (!c.hBOut.mapped() || !c.hBOutCount.mapped() || !ex.cand_count_out || (!tau_given && !ex.tau_out))
+    return fail(VT_ERR_DEVICE, "hipHostGetDevicePointer (batch results)");
+  VT_HIP(vt::launch_batch_select(c.dPartKeys.p, c.dPartPay.p, nq_pad, kBlocksPerQuery * k, k, c.hBOut.mapped(), c.hBOutCount.mapped(),
+                                 c.stream, &ex));
   run.t_queued = since();
   // the queries' norms (the acceptance bound needs them): 0.1 ms of host work per 256 x 768, done
   // while the device runs its 4 ms
@@ -623,7 +649,7 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
       const uint32_t idle = tail_cus >= 0 ? (uint32_t)tail_cus : kBatchTailCus;
       auto queue = [&](size_t g) {
         return batch_group_queue(ix, *cx[g & 1], runs[g & 1], queries + groups[g].first * d, groups[g].second, limit, bf16, nullptr,
-                                 idle);
+                                 idle, !vt::env::on(vt::env::BATCH_PASS_FIVE));  // (VT_BATCH_PASS_FIVE=1: A/B)
       };
       int st = queue(0);
       for (size_t g = 0; g < groups.size() && st == VT_OK; ++g) {

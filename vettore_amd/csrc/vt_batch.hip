@@ -691,9 +691,20 @@ __global__ __launch_bounds__(256) void row_sqnorm_rows_kernel(const float *__res
 }
 
 // Batched K3: block b selects the k smallest of keys[b][0..m) (rank sort; m is small).
+// `ex` (a query batch's last kernel, r05): what the host wants to read beside the lists -- every query's candidate
+// count and threshold, the status word (moved out and cleared) -- goes out with them, so that `out`, `out_count` and
+// these can all be host-mapped and no copy is queued behind the kernel (four blit launches per group before).
 __global__ __launch_bounds__(256) void batch_select_kernel(const uint64_t *__restrict__ keys,
                                                            const Payload *__restrict__ pay, uint32_t m, uint32_t k,
-                                                           Entry *__restrict__ out, uint32_t *__restrict__ out_count) {
+                                                           Entry *__restrict__ out, uint32_t *__restrict__ out_count, BatchExport ex) {
+  if (threadIdx.x == 0) {
+    if (ex.cand_count_out) ex.cand_count_out[blockIdx.x] = ex.cand_count[blockIdx.x];
+    if (ex.tau_out && ex.tau) ex.tau_out[blockIdx.x] = ex.tau[blockIdx.x];
+    if (ex.status_out && blockIdx.x == 0) {
+      *ex.status_out = *ex.status;
+      *ex.status = 0;
+    }
+  }
   extern __shared__ __align__(16) unsigned char bsm[];
   uint64_t *sk = reinterpret_cast<uint64_t *>(bsm);  // [m]
   const uint64_t *kb = keys + (size_t)blockIdx.x * m;
@@ -794,11 +805,11 @@ hipError_t launch_batch_scores(const BatchScoreArgs &a0, bool dense, uint32_t bl
 // tau_b from the sample's GROUP MAXIMA (K2s since r05: the sample pass files, per query, the best score of every
 // 64-row group of its tiles -- `groups` <= 1 024 values -- instead of every score): the `rank`-th largest of them.
 // Every maximum is one of the sample's scores, so this is at most the `rank`-th largest score of the whole sample
-// (equal to it unless two of the `rank` best share a group: the host only comes here with rank * 16 <= groups) -- a
-// threshold that is a little lower nominates a few more rows and changes nothing else.  One wave per query, 16 keys
-// per lane in registers, the answer bit by bit from the top: 32 steps of 16 compares and a count -- ~3 us per launch
+// (equal to it unless two of the `rank` best share a group: the host only comes here with rank * 16 <= groups <= 2 048) -- a
+// threshold that is a little lower nominates a few more rows and changes nothing else.  One wave per query, 32 keys
+// per lane in registers, the answer bit by bit from the top: 32 steps of 32 compares and a count -- 12-15 us per launch
 // where the radix select over 65 536 scores took 45 (and wrote / read 64 MB around it).
-constexpr int kTauGroupsPerLane = 16;
+constexpr int kTauGroupsPerLane = 32;
 __global__ __launch_bounds__(256) void sample_tau_groups_kernel(const float *__restrict__ maxima, uint32_t groups, uint32_t rank,
                                                                 float *__restrict__ tau, uint32_t nq, uint32_t nq_real) {
   const uint32_t q = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
@@ -867,9 +878,10 @@ hipError_t launch_row_sqnorms_rows(const float *X, size_t stride, const uint32_t
 }
 
 hipError_t launch_batch_select(const uint64_t *keys, const Payload *pay, uint32_t nq, uint32_t m, uint32_t k, Entry *out,
-                               uint32_t *out_count, hipStream_t s) {
+                               uint32_t *out_count, hipStream_t s, const BatchExport *ex) {
   if (m == 0 || m > 4096) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(batch_select_kernel, dim3(nq), dim3(256), (size_t)m * 8, s, keys, pay, m, k, out, out_count);
+  hipLaunchKernelGGL(batch_select_kernel, dim3(nq), dim3(256), (size_t)m * 8, s, keys, pay, m, k, out, out_count,
+                     ex ? *ex : BatchExport{});
   return hipGetLastError();
 }
 

@@ -466,7 +466,9 @@ static hipError_t launch_shadow_mode(const BatchScoreArgs &a0, int dense, uint32
 #endif
   if (a.ld % 64 != 0 || (a.nq_pad != 256 && a.nq_pad != 128 && a.nq_pad != 64) || a.Qimage == nullptr || a.Xshadow == nullptr)
     return hipErrorInvalidValue;
-  const bool five = shadow_stages() == 5;
+  // (five stages are all of a CU's LDS at 256 columns; four leave 32 KB -- room for the small kernels of the groups
+  // around this pass, batch_ready)
+  const bool five = (a.stages == 4 || a.stages == 5 ? (int)a.stages : shadow_stages()) == 5;
   if (a.nq_pad == 256) return five ? launch_qs<8, 5>(a, dense, blocks, s) : launch_qs<8, 4>(a, dense, blocks, s);
   if (a.nq_pad == 128) return five ? launch_qs<4, 5>(a, dense, blocks, s) : launch_qs<4, 4>(a, dense, blocks, s);
   return five ? launch_qs<2, 5>(a, dense, blocks, s) : launch_qs<2, 4>(a, dense, blocks, s);

@@ -364,6 +364,7 @@ struct BatchScoreArgs {
   uint32_t debug;         // VT_BATCH_DEBUG timing experiments (results invalid when non-zero)
   const void *Qimage;     // K2b / K2s: the queries rounded to bf16, in fragment order (launch_batch_q_image / _q_image16)
   const void *Xshadow;    // K2s only: the rows rounded to bf16, in fragment order (shadow_index; launch_shadow_build)
+  uint32_t stages;        // K2s only: depth of the LDS ring for this launch -- 4 or 5; 0: the library's default (VT_SHADOW_STAGES)
 };
 uint32_t batch_rows_per_block(uint32_t nq_pad);
 hipError_t launch_batch_scores(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s);
@@ -410,8 +411,17 @@ hipError_t launch_sample_tau(const float *sample, uint32_t sample_rows, uint32_t
 hipError_t launch_row_sqnorms(const float *X, size_t stride, uint32_t n, uint32_t d, float *xnorm2,
                               unsigned long long *out_bits, hipStream_t s);
 // Block b: the k smallest of keys[b][0..m) sorted ascending -> out[b][0..k), out_count[b].
+// (`ex`: see batch_select_kernel -- the host-side numbers of a query batch leave with the lists)
+struct BatchExport {
+  const uint32_t *cand_count;  // [nq] -> cand_count_out
+  uint32_t *cand_count_out;
+  const float *tau;            // [nq] -> tau_out (null: not wanted)
+  float *tau_out;
+  int *status;                 // -> *status_out, then 0
+  int *status_out;
+};
 hipError_t launch_batch_select(const uint64_t *keys, const Payload *pay, uint32_t nq, uint32_t m, uint32_t k, Entry *out,
-                               uint32_t *out_count, hipStream_t s);
+                               uint32_t *out_count, hipStream_t s, const BatchExport *ex = nullptr);
 
 // K6b: exact f64 cosine (distances.rs:160-177) of the first d coordinates of
 // EVERY row against the query, fused top-k -- stage 1 of funnel_search on a
