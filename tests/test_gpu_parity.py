@@ -627,6 +627,38 @@ def test_elixir_funnel_equals_flat_with_full_candidates(nifs):
     assert [r.id for r in hybrid] == [r.id for r in exact]
 
 
+@pytest.mark.parametrize("metric", [2, 0, 5, 7])
+def test_the_query_read_in_place_or_copied_gives_the_same_hits(nifs, oracle_mod, metric, vt_debug):
+    """Under `direct_query` (an A/B of r05 that measured no gain and stays off) short chains read the query straight
+    from the caller-side pinned block, no H2D copy in front of the first kernel.  Same hits either way, and the oracle's:
+    flat_search on a corpus of few blocks, quantized_search, funnel_search (incl. the sign / non-zero bits that ride
+    behind the floats)."""
+    n, d = 3000, 200
+    x, ids = make_corpus(n, d, 900 + metric, metric == 2, oracle_mod, tie_block=20)
+    if metric == 7:
+        x[np.random.default_rng(5).uniform(size=x.shape) < 0.5] = 0.0
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    packed = oracle_mod.pack_ids(ids)
+    rng = np.random.default_rng(77)
+    rows = list(zip(ids, x))
+    for step in range(6):
+        q = x[int(rng.integers(0, n))].copy() if step % 3 == 0 else rng.uniform(-1, 1, d).astype(np.float32)
+        if metric == 2:
+            q = oracle_mod.normalize_l2(q)
+        got = {}
+        for mode in (0, 1):
+            vt_debug.set("direct_query", mode)
+            got[mode] = (bits(unwrap(nifs.flat_search(g.ref, q, 25))),
+                         bits(unwrap(nifs.flat_quantized_search(g.ref, q, 100, 10))),
+                         bits(unwrap(nifs.flat_funnel_search(g.ref, q, [64, 128], 100, 10))))
+        assert got[0] == got[1], (metric, step)
+        assert got[0][0] == bits(oracle_mod.matrix_search(metric, x, packed, q, 25)), (metric, step)
+        cands = oracle_mod.binary_top_k([(i, oracle_mod.compress_sign_bits(v)) for i, v in rows], oracle_mod.compress_sign_bits(q), d, 100)
+        by_id = dict(rows)
+        assert got[0][1] == bits(oracle_mod.vector_top_k([(i, by_id[i]) for i, _ in cands], q, metric, d, 10)), (metric, step)
+
+
 def test_adapter_staged_searches_their_batches_and_their_errors(nifs):
     """Vettore.Index.FlatGpu's quantized / funnel / hybrid wrappers and their batch forms (integration/lib/vettore/index/
     flat_gpu.ex, mirrored in vettore_amd/index_flat.py), reached through the collection's dispatch (INTEGRATION.md

@@ -861,7 +861,8 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
   const uint32_t d = (uint32_t)ix->dim;
   const uint32_t words = (d + 63) / 64;
   uint32_t qnz = 0;
-  VT_TRY(upload_query(c, query, n, &qnz, true));
+  // (the distance pass fetches the query's 12 words per block, the rerank its floats for a few dozen blocks: no copy)
+  VT_TRY(upload_query(c, query, n, &qnz, true, /*direct=*/candidates <= (size_t)vt::kSelListMax));
   const size_t ncand = std::min<size_t>(candidates, ix->n);
   const size_t keep = local ? ncand : limit;
   // K4h needs integer bins in LDS, one fused select, and enough rows to be worth two passes
@@ -920,7 +921,7 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
     vt::CosineRerankArgs a{};
     a.X = ix->dX;
     a.stride = ix->ld;
-    a.q = c.dQ.p;
+    a.q = c.qsrc;
     a.id_rank = ix->dRank.p;
     a.gather = gather;
     a.gather_stride = gather_stride;
@@ -1266,7 +1267,8 @@ int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *
   if (ix->n == 0 || candidates == 0 || limit == 0) return empty_hits(out);
   uint32_t qnz_full = 0;
   // (float hamming / jaccard: the query's non-zero bits ride along -- the stage over all rows reads the bit column)
-  VT_TRY(upload_query(c, query, n, &qnz_full, pattern_metric(ix->metric) ? 2 : 0));
+  // (stage 1 fetches a prefix per block, the later stages and the rerank a few dozen blocks' worth: no copy)
+  VT_TRY(upload_query(c, query, n, &qnz_full, pattern_metric(ix->metric) ? 2 : 0, /*direct=*/stages[0] <= 256 && candidates <= (size_t)vt::kSelListMax));
   std::vector<vt::Entry> entries;
   // (`local`: the rerank keeps every candidate -- see LocalStages)
   if (funnel_fits_device(ix, stages, nstages, candidates, local ? candidates : limit)) {
@@ -1687,7 +1689,7 @@ int hybrid_dev(Shard *ix, Ctx &c, const float *query, const int *kinds, const si
     vt::CosineRerankArgs a{};
     a.X = ix->dX;
     a.stride = ix->ld;
-    a.q = c.dQ.p;
+    a.q = c.qsrc;
     a.id_rank = ix->dRank.p;
     a.gather = c.dRows.p;
     a.gather_stride = 1;
@@ -1708,7 +1710,7 @@ int hybrid_dev(Shard *ix, Ctx &c, const float *query, const int *kinds, const si
     vt::ScanArgs sa{};
     sa.X = ix->dX;
     sa.stride = ix->ld;
-    sa.q = c.dQ.p;
+    sa.q = c.qsrc;
     sa.id_rank = ix->dRank.p;
     sa.gather = c.dRows.p;
     sa.gather_stride = 1;

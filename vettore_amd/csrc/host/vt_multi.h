@@ -144,7 +144,7 @@ int shard_begin(Shard *ix, Ctx &c, const float *query, size_t n, size_t limit, v
   vt::ScanArgs a{};
   a.X = ix->dX;
   a.stride = ix->ld;
-  a.q = c.dQ.p;
+  a.q = c.qsrc;
   a.id_rank = ix->dRank.p;
   a.n = ix->n;
   a.d = d;
@@ -254,25 +254,35 @@ int wait_exchange(vt_flat *h, Ctx &c, size_t shard) {
     const long v = vt::env::get(vt::env::EXCHANGE_TIMEOUT_MS);
     return v > 0 ? v : 20000L;
   }();
+  // An event behind everything the shard has queued, polled with a back-off: a short busy phase (the exchange of a small
+  // shard is over in tens of microseconds), then sleeps that grow to 50 us -- through r04 every in-flight search parked
+  // one worker per shard in a hipStreamQuery / yield spin for the whole scan (2 ms per shard at config 4's size: eight
+  // cores burning beside the BEAM's schedulers).  HIP has no timed wait: the deadline is kept here.
+  if (!c.ev_wait) VT_HIP(hipEventCreateWithFlags(&c.ev_wait, hipEventDisableTiming));
+  VT_HIP(hipEventRecord(c.ev_wait, c.stream));
   const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned spins = 0;; ++spins) {
-    const hipError_t e = hipStreamQuery(c.stream);
+  long nap_us = 0;
+  for (;;) {
+    const hipError_t e = hipEventQuery(c.ev_wait);
     if (e == hipSuccess) return VT_OK;
     if (e != hipErrorNotReady) {
       (void)hipGetLastError();
-      return fail(VT_ERR_DEVICE, std::string("hipStreamQuery behind the exchange: ") + hipGetErrorString(e));
+      return fail(VT_ERR_DEVICE, std::string("hipEventQuery behind the exchange: ") + hipGetErrorString(e));
     }
-    if ((spins & 63u) == 63u) {
-      const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
-      if (waited >= timeout_ms) {
-        h->poisoned = true;
-        h->wedged = true;
-        return fail(VT_ERR_DEVICE, "RCCL exchange timed out on shard " + std::to_string(shard) + " (device " +
-                                       std::to_string(c.device) + ") after " + std::to_string(waited) +
-                                       " ms: the all-gather of the shards' top-k lists did not complete; the handle is unusable");
-      }
+    const auto waited_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (waited_us >= timeout_ms * 1000) {
+      h->poisoned = true;
+      h->wedged = true;
+      return fail(VT_ERR_DEVICE, "RCCL exchange timed out on shard " + std::to_string(shard) + " (device " +
+                                     std::to_string(c.device) + ") after " + std::to_string(waited_us / 1000) +
+                                     " ms: the all-gather of the shards' top-k lists did not complete; the handle is unusable");
     }
-    std::this_thread::yield();
+    if (waited_us < 40) {
+      std::this_thread::yield();  // (busy: about to finish)
+    } else {
+      nap_us = std::min<long>(50, nap_us ? nap_us * 2 : 5);
+      std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
+    }
   }
 }
 

@@ -124,7 +124,15 @@ int search_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t limit, 
   // (a non-zero-bit column that is not current is simply not used: the rows always are)
   const bool by_pattern = pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit);
   uint32_t qnz = 0;
-  VT_TRY(upload_query(c, query, n, &qnz, by_pattern ? 2 : 0));
+  // (a scan of few blocks reads the query straight from the pinned block: every block fetches all of it once, so only
+  // while that stays within half a megabyte over the link -- a 4 096-row corpus, not a million rows)
+  bool direct = by_pattern;
+  if (!by_pattern && limit <= (size_t)vt::kMaxFusedK && vt::scan_lds_bytes((uint32_t)ix->dim, (uint32_t)limit) != 0) {
+    const uint32_t tr = vt::scan_tile_rows(ix->n, (uint32_t)ix->dim, c.resident_waves());
+    const uint32_t blocks = c.grid_for((ix->n + tr - 1) / tr, vt::scan_lds_bytes((uint32_t)ix->dim, (uint32_t)limit));
+    direct = (size_t)blocks * ix->ld * sizeof(float) <= (512u << 10);
+  }
+  VT_TRY(upload_query(c, query, n, &qnz, by_pattern ? 2 : 0, direct));
   ScanJob j{};
   j.X = ix->dX;
   j.stride = ix->ld;
@@ -193,7 +201,7 @@ int run_cosine_scan(Ctx &c, Shard *ix, uint32_t d, double qq, size_t want, std::
     vt::CosineScanArgs a{};
     a.X = ix->dX;
     a.stride = ix->ld;
-    a.q = c.dQ.p;
+    a.q = c.qsrc;
     a.qq = qq;
     a.id_rank = ix->dRank.p;
     a.n = ix->n;
@@ -212,7 +220,7 @@ int run_cosine_scan(Ctx &c, Shard *ix, uint32_t d, double qq, size_t want, std::
     vt::CosineRerankArgs g{};
     g.X = ix->dX;
     g.stride = ix->ld;
-    g.q = c.dQ.p;
+    g.q = c.qsrc;
     g.id_rank = ix->dRank.p;
     g.gather = &c.dListPay.p->row;
     g.gather_stride = sizeof(vt::Payload) / sizeof(uint32_t);
@@ -241,7 +249,7 @@ int run_cosine_scan(Ctx &c, Shard *ix, uint32_t d, double qq, size_t want, std::
     vt::CosineScanArgs a{};
     a.X = ix->dX;
     a.stride = ix->ld;
-    a.q = c.dQ.p;
+    a.q = c.qsrc;
     a.qq = qq;
     a.id_rank = ix->dRank.p;
     a.n = ix->n;
@@ -302,7 +310,7 @@ int funnel_stage(Shard *ix, Ctx &c, const float *query, uint32_t d, const std::v
     vt::CosineRerankArgs a{};
     a.X = ix->dX;
     a.stride = ix->ld;
-    a.q = c.dQ.p;
+    a.q = c.qsrc;
     a.id_rank = ix->dRank.p;
     a.gather = c.dRows.p;
     a.gather_stride = 1;
@@ -379,7 +387,7 @@ int scan_stage_dev(Shard *ix, Ctx &c, uint32_t d, const ResultBlock *src, uint32
   vt::ScanArgs a{};
   a.X = ix->dX;
   a.stride = ix->ld;
-  a.q = c.dQ.p;
+  a.q = c.qsrc;
   a.id_rank = ix->dRank.p;
   a.gather = gather;
   a.gather_stride = gather ? gstride : 0;
@@ -427,7 +435,7 @@ int funnel_stage_dev(Shard *ix, Ctx &c, const float *query, uint32_t d, const Re
       vt::CosineScanArgs a{};
       a.X = ix->dX;
       a.stride = ix->ld;
-      a.q = c.dQ.p;
+      a.q = c.qsrc;
       a.qq = qq;
       a.id_rank = ix->dRank.p;
       a.n = ix->n;
@@ -452,7 +460,7 @@ int funnel_stage_dev(Shard *ix, Ctx &c, const float *query, uint32_t d, const Re
     vt::CosineRerankArgs a{};
     a.X = ix->dX;
     a.stride = ix->ld;
-    a.q = c.dQ.p;
+    a.q = c.qsrc;
     a.id_rank = ix->dRank.p;
     a.gather = gather;
     a.gather_stride = gstride;

@@ -13,7 +13,10 @@ struct Ctx {
   int hamming_blocks_per_cu = 2;
   hipStream_t stream = nullptr;
   DevBuf<float> dQ;
-  uint64_t *dQbits = nullptr;  // the query's sign bits, behind the query in dQ (upload_query with_bits)
+  // where the kernels of the current call read the query from (upload_query): c.dQ.p after a copy, or -- under
+  // VT_DIRECT_QUERY=1, an A/B that measured no gain -- the pinned staging block itself through its host mapping
+  const float *qsrc = nullptr;
+  uint64_t *dQbits = nullptr;  // the query's sign bits, behind the query in qsrc (upload_query with_bits)
   int qbits_kind = 0;          // what dQbits holds for the query last uploaded: 0 nothing, 1 sign bits, 2 non-zero bits
   DevBuf<uint64_t> dPartKeys;
   DevBuf<vt::Payload> dPartPay;
@@ -65,6 +68,7 @@ struct Ctx {
   uint32_t begin_rows = 0, begin_dim = 0;  // scan of the last vt_flat_search_begin (profiling)
   bool profiling = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_wait = nullptr;  // wait_exchange: behind a shard's all-gather (created on first use)
   vt_profile prof{};
 
   ~Ctx() {
@@ -72,6 +76,7 @@ struct Ctx {
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev2) (void)hipEventDestroy(ev2);
     if (ev3) (void)hipEventDestroy(ev3);
+    if (ev_wait) (void)hipEventDestroy(ev_wait);
     if (stream) (void)hipStreamDestroy(stream);
   }
 

@@ -73,6 +73,7 @@ enum Parse {
   X(BATCH_TAIL_CUS, "batch_tail_cus", P_INT, -1)                                                                          \
   X(BATCH_SAMPLE_TILES, "batch_sample_tiles", P_INT, 0)                                                                   \
   X(BATCH_PASS_FIVE, "batch_pass_five", P_FLAG, 0)                                                                        \
+  X(DIRECT_QUERY, "direct_query", P_FLAG, 0)                                                                              \
   X(SHADOW_STAGES, "shadow_stages", P_INT, 5)                                                                             \
   X(BATCH_KERNEL, "batch_kernel", P_INT, 0)                                                                               \
   X(BATCH_DEBUG, "batch_debug", P_INT, 0)                                                                                 \

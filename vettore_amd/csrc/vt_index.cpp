@@ -803,7 +803,7 @@ int vt_vector_top_k(int device, size_t count, const char *ids, const size_t *id_
       vt::CosineRerankArgs a{};
       a.X = dX.p;
       a.stride = ld;
-      a.q = c.dQ.p;
+      a.q = c.qsrc;
       a.id_rank = dRank.p;
       a.gather = nullptr;
       a.gather_stride = 0;
