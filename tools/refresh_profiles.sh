@@ -15,13 +15,17 @@ pmc() {  # name, counter, bench args...
   local name=$1 ctr=$2; shift 2
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$name -o p -- python3 $R/bench.py "$@" > $OUT/$name.log 2>&1
 }
-export RND=${RND:-r04}
+export RND=${RND:-r05}
 stats single --no-side          # the headline alone: the scan kernel's average is the bench line's avg_launch_ms
 stats default                   # the driver's command: headline + side legs (config 2 shares the scan kernel: 1 100 launches at N=1M)
 pmc single_fetch FETCH_SIZE --steps 20 --warmup 2 --no-cpu --no-side
 pmc single_write WRITE_SIZE --steps 20 --warmup 2 --no-cpu --no-side
 stats batch --mode batch --nominate f32 --steps 6 --warmup 1 --no-cpu          # K2: FP32 matrix cores
 stats batch_bf16 --mode batch --nominate bf16 --steps 24 --warmup 3 --no-cpu   # K2s: bf16 nomination from the bf16 shadow (the default since r04)
+# config 3 as BASELINE.json writes it: 16 x 256 in ONE call (r05: groups alternate between two contexts) -- stats, and the
+# kernel trace the excerpt below is cut from (group g's rescoring / select inside group g + 1's pass)
+stats batch16 --mode batch --nominate bf16 --batch 4096 --steps 4 --warmup 1 --no-cpu
+rocprofv3 --kernel-trace --output-format csv -d $OUT/batch16_trace -o t -- python3 $R/bench.py --mode batch --nominate bf16 --batch 4096 --steps 2 --warmup 1 --no-cpu > $OUT/batch16_trace.log 2>&1
 stats batch_k2b --mode batch --nominate bf16 --shadow off --steps 12 --warmup 3 --no-cpu   # K2b: the same pass streaming the f32 rows (no shadow)
 stats quantized --mode quantized --steps 300 --warmup 20 --no-cpu
 pmc quantized_fetch FETCH_SIZE --mode quantized --steps 20 --warmup 2 --no-cpu
@@ -46,7 +50,7 @@ cd $R
 python3 - <<'PY'
 import csv, glob, json, os
 out = 'gpurun_out/prof'
-RND = os.environ.get('RND', 'r04')
+RND = os.environ.get('RND', 'r05')
 def trim(src, dst):
     rows = list(csv.reader(open(src)))
     with open(dst, 'w', newline='') as f:
@@ -54,7 +58,7 @@ def trim(src, dst):
         for r in rows:
             r[0] = r[0][:140]
             w.writerow(r)
-for name in ('single', 'default', 'batch', 'batch_bf16', 'batch_k2b', 'quantized', 'funnel', 'multi', 'pattern_hamming', 'prefix_multi'):
+for name in ('single', 'default', 'batch', 'batch_bf16', 'batch16', 'batch_k2b', 'quantized', 'funnel', 'multi', 'pattern_hamming', 'prefix_multi'):
     trim('%s/%s/p_kernel_stats.csv' % (out, name), '%s/%s_%s_kernel_stats.csv' % (out, RND, name))
 def per_launch(path, kernel_substr, counter):
     vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
@@ -94,9 +98,9 @@ hf, _ = per_launch(out + '/quantized_fetch/p_counter_collection.csv', 'hamming_d
 print("hamming FETCH_SIZE KiB per launch", hf, "x2 bytes", 2 * hf * 1024)
 ff, _ = per_launch(out + '/funnel_fetch/p_counter_collection.csv', 'cosine_scan_kernel', 'FETCH_SIZE')
 bf, _ = per_launch(out + '/batch_fetch/p_counter_collection.csv', 'mfma_scores_kernel<8, false>', 'FETCH_SIZE')
-# (the 256-column candidate pass of a 256-query batch: shadow_scores_kernel<DENSE = false, QTW = 8, ...> from the bf16
+# (the 256-column candidate pass of a 256-query batch: shadow_scores_kernel<MODE = 0, QTW = 8, ...> from the bf16
 # shadow -- the default --, bf16_scores_kernel<DENSE = false, QT = 8> from the f32 rows with --shadow off)
-K2S, K2B = 'shadow_scores_kernel<false, 8', 'bf16_scores_kernel<false, 8>'
+K2S, K2B = 'shadow_scores_kernel<0, 8', 'bf16_scores_kernel<false, 8>'   # (K2s: <MODE = 0 the pass, QTW = 8, stages, DBG>)
 s16, _ = per_launch(out + '/batch_bf16_fetch/p_counter_collection.csv', K2S, 'FETCH_SIZE')
 keep(out + '/batch_bf16_fetch/p_counter_collection.csv', out + '/%s_batch_bf16_pmc_fetch.csv' % RND, K2S)
 b16, _ = per_launch(out + '/batch_k2b_fetch/p_counter_collection.csv', K2B, 'FETCH_SIZE')
@@ -111,7 +115,11 @@ json.dump({k: {"rows": 10000000, "dim": 768, "hbm_bytes_per_launch": 2 * v * 102
            for k, v in (("hamming_dist_kernel", hf), ("cosine_scan_kernel", ff), ("mfma_scores_kernel", bf), ("scan_multi_kernel", mf),
                         ("bf16_scores_kernel", b16), ("shadow_scores_kernel", s16))},
           open(out + '/pmc_side.json', 'w'), indent=1)
-for name in ('single', 'batch', 'batch_bf16', 'batch_k2b', 'quantized', 'funnel'):
+import subprocess
+with open('%s/%s_batch16_trace_excerpt.txt' % (out, RND), 'w') as f:
+    f.write(subprocess.run(['python3', 'tools/trace_excerpt.py', glob.glob(out + '/batch16_trace/**/t_kernel_trace.csv', recursive=True)[0]],
+                           capture_output=True, text=True).stdout)
+for name in ('single', 'batch', 'batch_bf16', 'batch16', 'batch_k2b', 'quantized', 'funnel'):
     print(open('%s/%s.json' % (out, name)).read().strip())
     for r in csv.DictReader(open('%s/%s/p_kernel_stats.csv' % (out, name))):
         if 'vt::' in r['Name']:
@@ -119,7 +127,7 @@ for name in ('single', 'batch', 'batch_bf16', 'batch_k2b', 'quantized', 'funnel'
 PY
 # counters of the two matrix-core passes (MFMA-busy and friends; VERDICT r3 missing #5): K2 on the FP32 pipe, K2s on the bf16 one
 bash $R/tools/pmc_kernel.sh "mfma_scores_kernel<8, false>" $OUT/${RND}_k2_pmc.txt -- --mode batch --nominate f32 --steps 2 --warmup 1 --no-cpu
-bash $R/tools/pmc_kernel.sh "shadow_scores_kernel<false, 8" $OUT/${RND}_k2s_pmc.txt -- --mode batch --nominate bf16 --steps 4 --warmup 1 --no-cpu
+bash $R/tools/pmc_kernel.sh "shadow_scores_kernel<0, 8" $OUT/${RND}_k2s_pmc.txt -- --mode batch --nominate bf16 --steps 4 --warmup 1 --no-cpu
 # probes without the profiler: K1p beside K1m and the single prefix scan; pattern funnels from the bit column and from the rows
 cd /tmp
 python3 $R/tools/prefix_multi_probe.py 2>/dev/null | grep "^{" > $OUT/${RND}_prefix_multi_probe.jsonl
