@@ -952,19 +952,38 @@ def run_child(argv, exchange, note, port_shift, timeout):
     return rc, out.decode(errors="replace"), time.perf_counter() - t0
 
 
+def launch_key():
+    """What names THIS launch and nothing else: the launcher's pid together with its start time (a recycled pid has
+    another one), torch's run id and the rendezvous port.  Every rank of a launch computes the same key."""
+    ppid = os.getppid()
+    started = "0"
+    try:
+        with open("/proc/%d/stat" % ppid) as f:
+            started = f.read().rsplit(")", 1)[1].split()[19]   # field 22: start time in clock ticks since boot
+    except (OSError, IndexError):
+        pass
+    run_id = "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "none") if ch.isalnum())[:32]
+    return "%d_%s_%s_%s" % (ppid, started, run_id, os.environ.get("MASTER_PORT", "0"))
+
+
 def ranks_agree(tag, rank, world, ok, wait_s):
     """Under torch.distributed.run every rank supervises its own child, and all of them must take
     the same next step (a rank that goes on to the host exchange alone would wait for the others
-    for ever).  Each writes its verdict into a directory named after this launch (the launcher's
-    pid and the rendezvous port) and reads the others'; a rank that never reports counts as failed."""
+    for ever).  Each writes its verdict into a directory named after this launch (launch_key: a directory left behind
+    by an earlier launch, or made by somebody else, is never this one -- ADVICE r4) and reads the others'; a rank that
+    never reports counts as failed.  Rank 0 removes the directory once every rank has read it."""
+    import shutil
     import tempfile
-    d = os.path.join(tempfile.gettempdir(), "vt_bench_%d_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), tag))
-    os.makedirs(d, exist_ok=True)
+    d = os.path.join(tempfile.gettempdir(), "vt_bench_%s_%s" % (launch_key(), tag))
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    if os.stat(d).st_uid != os.getuid():
+        return False   # (somebody else's directory under our name: no agreement through it)
     tmp = os.path.join(d, "rank%d.tmp" % rank)
     with open(tmp, "w") as f:
         f.write("1" if ok else "0")
     os.replace(tmp, os.path.join(d, "rank%d" % rank))
     deadline = time.perf_counter() + wait_s
+    verdict = False
     while time.perf_counter() < deadline:
         seen = []
         for r in range(world):
@@ -974,9 +993,21 @@ def ranks_agree(tag, rank, world, ok, wait_s):
             except OSError:
                 break
         if len(seen) == world:
-            return all(v == "1" for v in seen)
+            verdict = all(v == "1" for v in seen)
+            break
         time.sleep(0.05)
-    return False
+    else:
+        return False
+    try:
+        open(os.path.join(d, "read%d" % rank), "w").close()
+        if rank == 0:
+            until = time.perf_counter() + 5.0
+            while time.perf_counter() < until and not all(os.path.exists(os.path.join(d, "read%d" % r)) for r in range(world)):
+                time.sleep(0.02)
+            shutil.rmtree(d, ignore_errors=True)
+    except OSError:
+        pass
+    return verdict
 
 
 def supervise(a, argv):

@@ -254,35 +254,41 @@ int wait_exchange(vt_flat *h, Ctx &c, size_t shard) {
     const long v = vt::env::get(vt::env::EXCHANGE_TIMEOUT_MS);
     return v > 0 ? v : 20000L;
   }();
-  // An event behind everything the shard has queued, polled with a back-off: a short busy phase (the exchange of a small
-  // shard is over in tens of microseconds), then sleeps that grow to 50 us -- through r04 every in-flight search parked
-  // one worker per shard in a hipStreamQuery / yield spin for the whole scan (2 ms per shard at config 4's size: eight
-  // cores burning beside the BEAM's schedulers).  HIP has no timed wait: the deadline is kept here.
+  // An event behind everything the shard has queued.  HIP has no timed wait, so the deadline is kept here -- but not by
+  // spinning through the whole scan as r04 did (every in-flight search parked one worker per shard in a hipStreamQuery /
+  // yield loop: eight cores burning for 2 ms per query at config 4's size, beside the BEAM's schedulers).  The context
+  // remembers how long its last waits took: the worker SLEEPS through most of that (one sleep of 0.7 x the expected
+  // time, when that is worth a timer at all) and only then polls, yielding between polls, so a search ends within
+  // microseconds of its exchange -- a first form that napped 5..50 us between polls cost 30-50 us per query (a nap of
+  // 5 us is 60 on this kernel; 0.615 -> 0.668 ms per step at 1.25 M rows per shard).
   if (!c.ev_wait) VT_HIP(hipEventCreateWithFlags(&c.ev_wait, hipEventDisableTiming));
   VT_HIP(hipEventRecord(c.ev_wait, c.stream));
   const auto t0 = std::chrono::steady_clock::now();
-  long nap_us = 0;
-  for (;;) {
+  auto waited_us = [&]() { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
+  if (c.wait_expect_us > 400.0) std::this_thread::sleep_for(std::chrono::microseconds((long)(0.7 * c.wait_expect_us)));
+  for (unsigned spins = 0;; ++spins) {
     const hipError_t e = hipEventQuery(c.ev_wait);
-    if (e == hipSuccess) return VT_OK;
+    if (e == hipSuccess) {
+      c.wait_expect_us = 0.75 * c.wait_expect_us + 0.25 * (double)waited_us();
+      return VT_OK;
+    }
     if (e != hipErrorNotReady) {
       (void)hipGetLastError();
       return fail(VT_ERR_DEVICE, std::string("hipEventQuery behind the exchange: ") + hipGetErrorString(e));
     }
-    const auto waited_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
-    if (waited_us >= timeout_ms * 1000) {
-      h->poisoned = true;
-      h->wedged = true;
-      return fail(VT_ERR_DEVICE, "RCCL exchange timed out on shard " + std::to_string(shard) + " (device " +
-                                     std::to_string(c.device) + ") after " + std::to_string(waited_us / 1000) +
-                                     " ms: the all-gather of the shards' top-k lists did not complete; the handle is unusable");
+    if ((spins & 63u) == 63u) {
+      const long w = waited_us();
+      if (w >= timeout_ms * 1000) {
+        h->poisoned = true;
+        h->wedged = true;
+        return fail(VT_ERR_DEVICE, "RCCL exchange timed out on shard " + std::to_string(shard) + " (device " +
+                                       std::to_string(c.device) + ") after " + std::to_string(w / 1000) +
+                                       " ms: the all-gather of the shards' top-k lists did not complete; the handle is unusable");
+      }
+      // far beyond what this context has ever waited (a peer that is late, not dead yet): stop burning the core
+      if ((double)w > 4.0 * c.wait_expect_us + 2000.0) std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
-    if (waited_us < 40) {
-      std::this_thread::yield();  // (busy: about to finish)
-    } else {
-      nap_us = std::min<long>(50, nap_us ? nap_us * 2 : 5);
-      std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
-    }
+    std::this_thread::yield();
   }
 }
 

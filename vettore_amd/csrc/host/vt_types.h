@@ -69,6 +69,7 @@ struct Ctx {
   bool profiling = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_wait = nullptr;  // wait_exchange: behind a shard's all-gather (created on first use)
+  double wait_expect_us = 0.0;   // ... and how long the last waits there took (the worker sleeps through most of it)
   vt_profile prof{};
 
   ~Ctx() {
