@@ -1,6 +1,6 @@
 // reader_probe.cpp -- native threads searching ONE handle through the C ABI (what BEAM dirty
 // schedulers do): queries/s and mean latency with the coalescing of concurrent searches on and
-// off (VT_COALESCE=0), for several thread counts.  The Python twin (reader_probe.py) measures the
+// off (vt_debug_set "coalesce" 0), for several thread counts.  The Python twin (reader_probe.py) measures the
 // same, but its threads also queue for the interpreter lock, which hides the cost of a hand-over
 // on small corpora.
 //   g++ -O2 -std=c++17 tools/reader_probe.cpp -Iinclude -Lvettore_amd/lib -lvettore_hip -lpthread \
@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
     double qps[2] = {0, 0}, lat[2] = {0, 0};
     unsigned long long carried[2] = {0, 0};
     for (int mode = 0; mode < 2; ++mode) {
-      if (mode == 0) unsetenv("VT_COALESCE"); else setenv("VT_COALESCE", "0", 1);
+      vt_debug_set("coalesce", mode == 0 ? 1 : 0);  // (the library reads its environment once, at load: settings by name since r05)
       std::atomic<bool> stop{false};
       std::vector<unsigned long long> count(T, 0);
       std::vector<double> busy(T, 0.0);
@@ -84,7 +84,7 @@ int main(int argc, char **argv) {
       lat[mode] = busy_total / (total ? total : 1) * 1e3;
       carried[mode] = q1 - q0;
     }
-    unsetenv("VT_COALESCE");
+    vt_debug_set("coalesce", 1);
     printf("{\"rows\": %zu, \"dim\": %zu, \"threads\": %d, \"coalesced_qps\": %.0f, \"coalesced_latency_ms\": %.3f, \"in_batches\": %llu, "
            "\"side_by_side_qps\": %.0f, \"side_by_side_latency_ms\": %.3f, \"gain\": %.2f}\n",
            rows, d, T, qps[0], lat[0], carried[0], qps[1], lat[1], qps[0] / (qps[1] > 0 ? qps[1] : 1));
