@@ -394,10 +394,24 @@ int batch_multi(vt_flat *h, const float *queries, size_t nq, size_t d, size_t li
     if (shard_stale(ix, need, limit)) VT_TRY(shard_prepare(ix, need, limit));
     return batch_ready(ix, ix->ctx, queries, nq, d, limit, per[s].data());
   });
-  std::vector<vt_hits *> lists(S);
-  for (size_t i = 0; i < nq && rc == VT_OK; ++i) {
-    for (size_t s = 0; s < S; ++s) lists[s] = per[s][i];
-    rc = merge_hit_lists(lists, limit, &out[i]);
+  // The shards' lists of every query meet by (rank key, id bytes).  On one thread that is nq x (S k items, a partial
+  // sort, k id copies) -- a quarter of a millisecond per 256 queries at eight shards, serial behind passes that got
+  // eight times shorter.  The workers are idle by now: each merges its share of the queries (r05).
+  if (rc == VT_OK && S > 1 && nq >= 4 * S) {
+    rc = on_all_shards(h, [&](size_t s) -> int {
+      std::vector<vt_hits *> lists(S);
+      for (size_t i = nq * s / S; i < nq * (s + 1) / S; ++i) {
+        for (size_t t = 0; t < S; ++t) lists[t] = per[t][i];
+        VT_TRY(merge_hit_lists(lists, limit, &out[i]));
+      }
+      return VT_OK;
+    });
+  } else {
+    std::vector<vt_hits *> lists(S);
+    for (size_t i = 0; i < nq && rc == VT_OK; ++i) {
+      for (size_t s = 0; s < S; ++s) lists[s] = per[s][i];
+      rc = merge_hit_lists(lists, limit, &out[i]);
+    }
   }
   for (auto &v : per)
     for (vt_hits *l : v) delete l;
