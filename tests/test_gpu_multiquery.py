@@ -114,7 +114,7 @@ def test_multi_query_scan_at_config_shape(nifs, oracle_mod):
                                               (5, 256, 70_000, 100), (1, 768, 22_000, 256), (4, 64, 300_000, 33)])
 def test_batches_as_k1p_sweeps_equal_single_queries(nifs, oracle_mod, metric, d, n, limit):
     """flat_search_batch on rows off K1m's 256-float panel grid, or with lists longer than K1m's wave buffers hold (32):
-    groups of eight as K1p sweeps -- prefix_multi_kernel over the WHOLE row, `limit` candidates (host/vt_batch_staged.h
+    groups of eight as K1p sweeps -- prefix_multi_kernel over the WHOLE row, `limit` candidates (host/vt_batch.h
     sweep_group_applies).  Every query's hits are its own flat_search's, bit for bit, and the oracle's."""
     x, ids = make_corpus(n, d, 9100 + metric + d, False, oracle_mod, tie_block=60)
     g = GpuIndex(nifs, metric)

@@ -3,7 +3,7 @@
 // K2 (vt_batch.hip) runs S = X * Q^T on v_mfma_f32_32x32x2_f32 and is bound by that pipe:
 // 28 ms per 256 queries at N = 10 M, d = 768, six times what reading the rows takes.  But the
 // matrix pass only NOMINATES candidates -- the exact K1 arithmetic re-scores them and the host
-// certifies that nothing else can reach the top k (host/vt_batch_staged.h) -- so its
+// certifies that nothing else can reach the top k (host/vt_batch.h) -- so its
 // operands need not be exact: here the f32 rows are streamed as they lie in HBM, rounded to
 // bf16 in registers (v_cvt_pk_bf16_f32) and fed to v_mfma_f32_32x32x16_bf16 (16x the FP32
 // rate, f32 accumulators); the queries are rounded once (q_image_kernel).  The host's bound

@@ -39,7 +39,10 @@
 #include "host/vt_select.h"
 #include "host/vt_store.h"
 #include "host/vt_search.h"
-#include "host/vt_batch_staged.h"
+#include "host/vt_batch.h"
+#include "host/vt_quantized.h"
+#include "host/vt_funnel.h"
+#include "host/vt_hybrid.h"
 #include "host/vt_multi.h"
 #include "host/vt_coalesce.h"
 
