@@ -194,7 +194,7 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   a.sample_stride = pa.sample_stride = sstride;
   a.sample_rows = pa.sample_rows = sample_rows;
   if (cosine) VT_HIP(vt::launch_cosine_scan_multi(a, c.grid_for(stiles, lds), c.stream));
-  else VT_HIP(vt::launch_prefix_multi(pa, c.grid_for(stiles, lds), c.stream));
+  else VT_HIP(vt::launch_prefix_multi(pa, c.grid_for(stiles, lds, vt::prefix_multi_blocks_per_cu()), c.stream));
   VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, vt::kCosineMultiMax, nq, rank, c.dBTau.p, c.stream));
   // pass 1: every row's prefix once; (query, row) pairs at or above the thresholds into the lists
   a.sample = pa.sample = nullptr;
@@ -205,7 +205,7 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   a.cand_cap = pa.cand_cap = kListCap;
   if (c.profiling) VT_HIP(hipEventRecord(c.ev0, c.stream));
   if (cosine) VT_HIP(vt::launch_cosine_scan_multi(a, c.grid_for(ntiles, lds), c.stream));
-  else VT_HIP(vt::launch_prefix_multi(pa, c.grid_for(ntiles, lds), c.stream));
+  else VT_HIP(vt::launch_prefix_multi(pa, c.grid_for(ntiles, lds, vt::prefix_multi_blocks_per_cu()), c.stream));
   if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
   VT_HIP(hipMemcpyAsync(hListCount, c.dBCount.p, vt::kCosineMultiMax * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(vt::launch_select_lists(c.dPartKeys.p, c.dPartPay.p, nq, kListCap, c.dBCount.p, k1, c.dStageB.p,

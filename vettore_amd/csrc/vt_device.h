@@ -502,6 +502,7 @@ struct PrefixMultiArgs {
 };
 bool prefix_multi_supports(int metric);
 size_t prefix_multi_lds_bytes();
+int prefix_multi_blocks_per_cu();  // resident blocks per CU the launch is sized for (2; 3 with the 32-float panel, VT_PM_PANEL=32)
 hipError_t launch_prefix_multi(const PrefixMultiArgs &a, uint32_t blocks, hipStream_t s);
 
 // Diagnostic (vt_device_read_peak): one pass of the bare LDS-DMA read stream over the whole 384-KiB tiles of

@@ -21,7 +21,15 @@ using namespace dev;
 
 namespace {
 
-constexpr int kPmRows = 64, kPmPanel = 64, kPmStride = 68;  // K6b's panel: 64 rows x 64 floats, rows 272 B apart
+// K6b's panel: 64 rows x 64 floats, rows 272 B apart in LDS.  PANEL = 32 (r05, A/B: VT_PM_PANEL): half the panel -- 8 wave
+// loads of 8 rows x 128 B, 9 KB of LDS per wave and half the prefetch registers, so that three or four waves share a SIMD
+// where two did (the chunk loop waits on scalar and LDS loads three times per chunk; with two waves per SIMD the VALU
+// idles through half of that).
+constexpr int kPmRows = 64;
+template <int PANEL> struct PmShape {
+  static constexpr int kPanel = PANEL, kStride = PANEL + 4;
+  static constexpr int kLanesPerRow = PANEL / 4, kRowsPerLoad = 64 / kLanesPerRow, kLoads = kPmRows / kRowsPerLoad;
+};
 
 template <int OP>
 __device__ __forceinline__ float pm_elem(float q, float x) {
@@ -92,8 +100,10 @@ __device__ __forceinline__ float pm_chunk(float acc, const f32x2 (&x)[4], const 
   return comb<OP>(0, acc, pm_reduce<OP, ORDER>(e));
 }
 
-template <int OP, int ORDER>
+template <int OP, int ORDER, int PANEL>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(const PrefixMultiArgs a) {
+  using Sh = PmShape<PANEL>;
+  constexpr int kPmPanel = Sh::kPanel, kPmStride = Sh::kStride;
   extern __shared__ __align__(16) float pm_lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -120,14 +130,15 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
     for (uint32_t q = 0; q < kPrefixMultiMax; ++q)
       if (q < a.nq) tauv[q] = tp[q];
   }
-  f32x4 v[16];
+  f32x4 v[Sh::kLoads];
+  const int lrow = lane / Sh::kLanesPerRow, lcol = (lane % Sh::kLanesPerRow) * 4;  // this lane's row within a load, its column
   auto issue = [&](uint32_t ti, uint32_t p) {
     const uint32_t t = ti * step;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      uint32_t r = t * kPmRows + 4 * s + (lane >> 4);
+    for (int s = 0; s < Sh::kLoads; ++s) {
+      uint32_t r = t * kPmRows + Sh::kRowsPerLoad * s + lrow;
       r = r < a.n ? r : a.n - 1;
-      v[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.X + (size_t)r * a.stride + p * kPmPanel + (lane & 15) * 4));
+      v[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.X + (size_t)r * a.stride + p * kPmPanel + lcol));
     }
   };
   if (wave_global < ntiles) issue(wave_global, 0);
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
     for (uint32_t q = 0; q < kPrefixMultiMax; ++q) acc[q] = 0.0f;
     for (uint32_t p = 0; p < npanel; ++p) {
 #pragma unroll
-      for (int s = 0; s < 16; ++s) *reinterpret_cast<f32x4 *>(S + (4 * s + (lane >> 4)) * kPmStride + (lane & 15) * 4) = v[s];
+      for (int s = 0; s < Sh::kLoads; ++s) *reinterpret_cast<f32x4 *>(S + (Sh::kRowsPerLoad * s + lrow) * kPmStride + lcol) = v[s];
       wave_lds_fence();
       if (p + 1 < npanel) issue(ti, p + 1);
       else if (ti + total_waves < ntiles) issue(ti + total_waves, 0);
@@ -220,11 +231,19 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
   }
 }
 
+int prefix_multi_panel() { return env::get(env::PM_PANEL) == 32 ? 32 : 64; }  // (VT_PM_PANEL=32: A/B)
+
 template <int OP, int ORDER>
 hipError_t launch_pm(const PrefixMultiArgs &a, uint32_t blocks, size_t lds, hipStream_t s) {
-  hipError_t e = allow_lds(prefix_multi_kernel<OP, ORDER>, lds);
+  if (prefix_multi_panel() == 32) {
+    hipError_t e = allow_lds(prefix_multi_kernel<OP, ORDER, 32>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((prefix_multi_kernel<OP, ORDER, 32>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+    return hipGetLastError();
+  }
+  hipError_t e = allow_lds(prefix_multi_kernel<OP, ORDER, 64>, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((prefix_multi_kernel<OP, ORDER>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+  hipLaunchKernelGGL((prefix_multi_kernel<OP, ORDER, 64>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
   return hipGetLastError();
 }
 
@@ -244,7 +263,12 @@ bool prefix_multi_supports(int metric) {
   return metric == M_L2 || metric == M_L2SQ || metric == M_IP || metric == M_NIP || metric == M_L1 || metric == M_LINF;
 }
 
-size_t prefix_multi_lds_bytes() { return (size_t)kWavesPerBlock * kPmRows * kPmStride * sizeof(float); }
+size_t prefix_multi_lds_bytes() { return (size_t)kWavesPerBlock * kPmRows * (prefix_multi_panel() + 4) * sizeof(float); }
+int prefix_multi_blocks_per_cu() {
+  const long v = env::get(env::PM_BLOCKS);  // (VT_PM_BLOCKS: A/B)
+  if (v >= 1 && v <= 4) return (int)v;
+  return prefix_multi_panel() == 32 ? 4 : 2;
+}
 
 hipError_t launch_prefix_multi(const PrefixMultiArgs &a, uint32_t blocks, hipStream_t s) {
   if (!prefix_multi_supports(a.metric) || !a.Q || ((uintptr_t)a.Q & 31) || a.q_stride % 8 != 0 || a.q_stride < a.d || a.nq == 0 ||
