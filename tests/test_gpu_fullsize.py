@@ -187,6 +187,24 @@ def test_config3_shape_dot_batch_equals_single_queries(corpus, oracle_mod, nomin
                 assert support.close(raw, float(x[row].double() @ qd.double()), 1e-5)
             for row in true_rows - set(got_rows):
                 assert abs(float(x[row].double() @ qd.double()) - kth) <= 1e-5 * max(1.0, abs(kth))
+        if nominate == "bf16":
+            # the config as SURVEY 8d writes it -- several groups of 256 in ONE call (four here): consecutive groups
+            # alternate between two contexts, group g + 1 queued before group g is waited for.  Every list equals the
+            # list its query gets in a call of its own group alone, bit for bit; one pass per group, no fallbacks to speak of
+            qs4 = np.concatenate([qs, np.random.default_rng(20260723).uniform(-1, 1, size=(768, D)).astype(np.float32)])
+            nifs.flat_get_profile(ref, reset=True)
+            st, big = nifs.flat_search_batch(ref, qs4, 10)
+            assert st == "ok" and len(big) == 1024
+            prof = nifs.flat_get_profile(ref, reset=True)
+            assert prof["nominate_launches"] == 4 and prof["nominate_queries"] == 1024 and prof["batch_fallbacks"] <= 16, prof
+            bits_of = lambda hits: [(h[0], np.float32(h[1]).tobytes()) for h in hits]
+            for i in range(256):
+                assert bits_of(big[i]) == bits_of(batch[i]), i
+            for g4 in range(1, 4):
+                st, part = nifs.flat_search_batch(ref, qs4[256 * g4:256 * (g4 + 1)], 10)
+                assert st == "ok"
+                for i in range(256):
+                    assert bits_of(big[256 * g4 + i]) == bits_of(part[i]), (g4, i)
         del ref
     finally:
         x.div_(scale)   # the fixture is shared (module scope); later tests see (almost) the same rows again

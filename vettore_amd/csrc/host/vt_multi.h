@@ -206,9 +206,13 @@ int merged_hits(std::vector<MergeItem> &items, size_t limit, vt_hits **out) {
 }
 int merge_hit_lists(const std::vector<vt_hits *> &lists, size_t limit, vt_hits **out) {
   std::vector<MergeItem> items;
-  for (const vt_hits *l : lists)
-    if (l)
+  for (const vt_hits *l : lists) {
+    if (!l) continue;
+    if (l->by_row_of)  // (a shard's batch list: rows named, ids where they live)
+      for (size_t i = 0; i < l->rows.size(); ++i) items.push_back(MergeItem{l->rank_key[i], l->raw[i], &l->by_row_of->ids[l->rows[i]]});
+    else
       for (size_t i = 0; i < l->ids.size(); ++i) items.push_back(MergeItem{l->rank_key[i], l->raw[i], &l->ids[i]});
+  }
   return merged_hits(items, limit, out);
 }
 
@@ -392,7 +396,13 @@ int batch_multi(vt_flat *h, const float *queries, size_t nq, size_t d, size_t li
     Shard *ix = h->shards[s].get();
     const unsigned need = NEED_STRICT_RANKS | NEED_NZBITS | (batch_uses_mfma(ix, nq, limit) ? NEED_NORMS : 0u);
     if (shard_stale(ix, need, limit)) VT_TRY(shard_prepare(ix, need, limit));
-    return batch_ready(ix, ix->ctx, queries, nq, d, limit, per[s].data());
+    // (this worker's lists go into the merge below and nowhere else: they name their rows, the ids -- 2 560 string
+    // copies per 256 queries and shard -- are copied once, for the winners.  The flag is this shard's, and a shard's
+    // jobs run one at a time on its worker.)
+    ix->hits_by_row = true;
+    const int st = guarded([&]() -> int { return batch_ready(ix, ix->ctx, queries, nq, d, limit, per[s].data()); });
+    ix->hits_by_row = false;
+    return st;
   });
   // The shards' lists of every query meet by (rank key, id bytes).  On one thread that is nq x (S k items, a partial
   // sort, k id copies) -- a quarter of a millisecond per 256 queries at eight shards, serial behind passes that got

@@ -1012,6 +1012,19 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
 int make_hits(const Shard *ix, const std::vector<vt::Entry> &entries, vt_hits **out) {
   auto h = std::make_unique<vt_hits>();
   const size_t m = entries.size();
+  if (ix->hits_by_row) {
+    h->by_row_of = ix;
+    h->rows.reserve(m);
+    h->raw.reserve(m);
+    h->rank_key.reserve(m);
+    for (const auto &e : entries) {
+      h->rows.push_back(e.row);
+      h->raw.push_back(e.raw);
+      h->rank_key.push_back(rank_key_of(e.key));
+    }
+    *out = h.release();
+    return VT_OK;
+  }
   if (m >= (1u << 17)) {
     // limits in the hundreds of thousands (flat.ex:98-103 allows them): the id copies are most of
     // the call -- one string per hit, picked from all over the table -- so they go on several threads

@@ -137,10 +137,15 @@ struct Ctx {
 
 }  // namespace
 
+struct Shard;
 struct vt_hits {
   std::vector<std::string> ids;
   std::vector<float> raw;
   std::vector<uint32_t> rank_key;
+  // A shard's contribution to a cross-shard merge (batch_multi) names its rows instead of copying their ids: the
+  // merge compares the id bytes where they live and copies only the winners' (r05).  Never handed to a caller.
+  const Shard *by_row_of = nullptr;
+  std::vector<uint32_t> rows;
 };
 
 // One shard = one GPU's share of the rows: the slab, its derived columns, the ids of
@@ -201,6 +206,7 @@ struct Shard {
   bool rank_dirty_all = false;
   size_t unranked = 0;  // rows carrying kUnranked: past a bound the next search rebuilds instead of going lazy
   bool external_ranks = false;      // rank column supplied by vt_flat_set_id_ranks (valid until the next mutation)
+  bool hits_by_row = false;         // make_hits leaves the ids where they are (set by this shard's worker around a batch of a sharded handle)
   uint64_t epoch = 0;               // bumped by every mutation of the row set (insert of a new id, delete)
   uint64_t external_epoch = 0;      // epoch at which the external ranks were installed
   bool external_expected = false;   // vt_flat_set_id_ranks has been used on this shard: search_begin insists on current ranks
