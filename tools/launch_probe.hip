@@ -87,6 +87,64 @@ int main() {
     k_use<<<G, 256, 0, s>>>(dq, dout, 768); k_flag<<<1, 64, 0, s>>>(hflag_dev, (unsigned)i + 1);
     while (*(volatile unsigned *)hflag != (unsigned)i + 1) {} }));
   hipStreamSynchronize(s);
+  // the same chain as an instantiated graph (r05: the one form the earlier rounds had not priced): captured once,
+  // launched per call; then with one kernel node's parameters rewritten before every launch (what a search would do:
+  // limit, thresholds and pointers change from call to call)
+  {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipMemcpyAsync(dq, hq, 3072, hipMemcpyHostToDevice, s);
+    k_use<<<G, 256, 0, s>>>(dq, dout, 768);
+    k_empty<<<1, 1024, 0, s>>>(dout);
+    CK(hipStreamEndCapture(s, &graph));
+    CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    printf("graph(memcpy + 2 kernels) + sync  %7.2f us\n", bench([&](int) { hipGraphLaunch(exec, s); hipStreamSynchronize(s); }));
+    size_t nn = 0;
+    CK(hipGraphGetNodes(graph, nullptr, &nn));
+    hipGraphNode_t nodes[8];
+    CK(hipGraphGetNodes(graph, nodes, &nn));
+    hipGraphNode_t knode = nullptr;
+    for (size_t i = 0; i < nn; ++i) {
+      hipGraphNodeType t;
+      CK(hipGraphNodeGetType(nodes[i], &t));
+      if (t == hipGraphNodeTypeKernel && !knode) knode = nodes[i];
+    }
+    if (knode) {
+      hipKernelNodeParams kp;
+      CK(hipGraphKernelNodeGetParams(knode, &kp));
+      int n768 = 768;
+      void *args[3] = {&dq, &dout, &n768};
+      kp.kernelParams = args;
+      printf("graph + node params set + sync    %7.2f us\n", bench([&](int i) {
+        n768 = 768 - (i & 1);
+        hipGraphExecKernelNodeSetParams(exec, knode, &kp);
+        hipGraphLaunch(exec, s); hipStreamSynchronize(s); }));
+    }
+    // two kernels only (the query already on the device)
+    hipGraph_t g2;
+    hipGraphExec_t e2;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    k_use<<<G, 256, 0, s>>>(dq, dout, 768);
+    k_empty<<<1, 1024, 0, s>>>(dout);
+    CK(hipStreamEndCapture(s, &g2));
+    CK(hipGraphInstantiate(&e2, g2, nullptr, nullptr, 0));
+    printf("graph(2 kernels) + sync           %7.2f us\n", bench([&](int) { hipGraphLaunch(e2, s); hipStreamSynchronize(s); }));
+    // five kernels (config 5's chain) plain against graph
+    printf("memcpy + 5 kernels + sync         %7.2f us\n", bench([&](int) {
+      hipMemcpyAsync(dq, hq, 3072, hipMemcpyHostToDevice, s);
+      k_use<<<G, 256, 0, s>>>(dq, dout, 768); k_empty<<<256, 256, 0, s>>>(dout); k_empty<<<1, 1024, 0, s>>>(dout);
+      k_use<<<32, 256, 0, s>>>(dq, dout, 768); k_empty<<<1, 1024, 0, s>>>(dout); hipStreamSynchronize(s); }));
+    hipGraph_t g5;
+    hipGraphExec_t e5;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipMemcpyAsync(dq, hq, 3072, hipMemcpyHostToDevice, s);
+    k_use<<<G, 256, 0, s>>>(dq, dout, 768); k_empty<<<256, 256, 0, s>>>(dout); k_empty<<<1, 1024, 0, s>>>(dout);
+    k_use<<<32, 256, 0, s>>>(dq, dout, 768); k_empty<<<1, 1024, 0, s>>>(dout);
+    CK(hipStreamEndCapture(s, &g5));
+    CK(hipGraphInstantiate(&e5, g5, nullptr, nullptr, 0));
+    printf("graph(memcpy + 5 kernels) + sync  %7.2f us\n", bench([&](int) { hipGraphLaunch(e5, s); hipStreamSynchronize(s); }));
+  }
   // events around the pair (what profiling mode adds)
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
