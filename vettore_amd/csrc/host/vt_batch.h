@@ -591,14 +591,17 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
 // d = 64 / 128 / 320 / 640 where K1m walks 2.5 / 3.4 / 4.2 / 4.5 -- rows that are not whole 256-float panels -- and
 // level with it where they are (d = 768: 5.21 against 5.24-5.37 ms); and it takes lists of up to 256, K1m's wave
 // buffers 32.  So: rows off K1m's panel grid, or lists K1m cannot hold; from 64 MB of rows (six launches and a
-// sample pass instead of two launches).
+// sample pass instead of two launches).  r05: on 32-float panels K1p is 7 % faster than it was at full width -- at
+// d = 768, N = 10 M: 4.74 / 5.74 / 4.84 ms per sweep (dot / L2 / L1) where K1m takes 5.45 / 6.13 / 5.31 -- so wide rows of
+// a corpus of 2 GB and more go to K1p as well (at d = 384 the two are level: K1m keeps those, with its two launches).
 bool sweep_group_applies(const Shard *ix, size_t limit) {
   if (!vt::prefix_multi_supports(ix->metric) || vt::env::on(vt::env::NO_SWEEP_GROUPS)) return false;
   const size_t stage = (size_t)ix->dim;
   if (!funnel_group_applies(ix, &stage, 1, limit, limit)) return false;
   if (vt::env::on(vt::env::FORCE_SWEEP_GROUPS)) return true;  // (tests and soaks on corpora of a few MB)
-  if ((double)ix->n * ix->ld * 4.0 < 64e6) return false;
-  return ix->ld % 256 != 0 || !multi_scan_applies(ix, limit);
+  const double bytes = (double)ix->n * ix->ld * 4.0;
+  if (bytes < 64e6) return false;
+  return ix->ld % 256 != 0 || !multi_scan_applies(ix, limit) || (bytes >= 2e9 && ix->ld >= 512);
 }
 
 // Rank column strictly current, norms current when batch_uses_mfma (shard_prepare).

@@ -76,6 +76,7 @@ enum Parse {
   X(DIRECT_QUERY, "direct_query", P_FLAG, 0)                                                                              \
   X(PM_PANEL, "pm_panel", P_INT, 0)                                                                                       \
   X(PM_BLOCKS, "pm_blocks", P_INT, 0)                                                                                     \
+  X(CS_PANEL, "cs_panel", P_INT, 0)                                                                                       \
   X(SHADOW_STAGES, "shadow_stages", P_INT, 5)                                                                             \
   X(BATCH_KERNEL, "batch_kernel", P_INT, 0)                                                                               \
   X(BATCH_DEBUG, "batch_debug", P_INT, 0)                                                                                 \

@@ -1919,7 +1919,12 @@ hipError_t launch_cosine_rerank_batch(const CosineRerankArgs &a, uint32_t nq, hi
 // from LDS as f32 like the single kernel's one query, eight queries cost 8 LDS reads and 32
 // conversions per 4 row elements and lane beside the 36 FMAs, and the pass was LDS / VALU bound
 // at 3.5 TB/s of prefix bytes.
+// PANEL (r05): K1p's finding carried over -- the same walk on 64 x 32-float panels (8 wave loads of 8 rows x 128 B, half
+// the prefetch registers) at the same two blocks per CU; VT_CS_PANEL=64 is the r04 form (A/B, DESIGN_APPENDIX A.15).
+template <int PANEL>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_multi_kernel(const CosineScanMultiArgs a) {
+  constexpr int kCsPanel = PANEL, kCsStride = PANEL + 4;  // (shadow the single kernel's 64 / 68)
+  constexpr int kLanesPerRow = PANEL / 4, kRowsPerLoad = 64 / kLanesPerRow, kLoads = kCsRows / kRowsPerLoad;
   extern __shared__ __align__(16) float csm_lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1946,15 +1951,15 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_multi_kerne
     for (uint32_t q = 0; q < kCosineMultiMax; ++q)
       if (q < a.nq) tauv[q] = tp[q];
   }
-  f32x4 v[16];
+  f32x4 v[kLoads];
+  const int lrow = lane / kLanesPerRow, lcol = (lane % kLanesPerRow) * 4;  // this lane's row within a load, its column
   auto issue = [&](uint32_t ti, uint32_t p) {
     const uint32_t t = ti * step;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      uint32_t r = t * kCsRows + 4 * s + (lane >> 4);
+    for (int s = 0; s < kLoads; ++s) {
+      uint32_t r = t * kCsRows + kRowsPerLoad * s + lrow;
       r = r < a.n ? r : a.n - 1;
-      v[s] = __builtin_nontemporal_load(
-          reinterpret_cast<const f32x4 *>(a.X + (size_t)r * a.stride + p * kCsPanel + (lane & 15) * 4));
+      v[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.X + (size_t)r * a.stride + p * kCsPanel + lcol));
     }
   };
   if (wave_global < ntiles) issue(wave_global, 0);
@@ -1966,8 +1971,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_multi_kerne
     for (uint32_t q = 0; q < kCosineMultiMax; ++q) qx[q] = 0.0;
     for (uint32_t p = 0; p < npanel; ++p) {
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        *reinterpret_cast<f32x4 *>(S + (4 * s + (lane >> 4)) * kCsStride + (lane & 15) * 4) = v[s];
+      for (int s = 0; s < kLoads; ++s) *reinterpret_cast<f32x4 *>(S + (kRowsPerLoad * s + lrow) * kCsStride + lcol) = v[s];
       wave_lds_fence();
       if (p + 1 < npanel) issue(ti, p + 1);
       else if (ti + total_waves < ntiles) issue(ti + total_waves, 0);
@@ -2053,16 +2057,23 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_multi_kerne
   }
 }
 
-size_t cosine_scan_multi_lds_bytes() { return (size_t)kWavesPerBlock * kCsRows * kCsStride * sizeof(float); }
+int cosine_scan_multi_panel() { return env::get(env::CS_PANEL) == 64 ? 64 : 32; }
+size_t cosine_scan_multi_lds_bytes() { return (size_t)kWavesPerBlock * kCsRows * (cosine_scan_multi_panel() + 4) * sizeof(float); }
 
 hipError_t launch_cosine_scan_multi(const CosineScanMultiArgs &a, uint32_t blocks, hipStream_t s) {
   const size_t lds = cosine_scan_multi_lds_bytes();
   if (!a.Qd || ((uintptr_t)a.Qd & 31) || a.nq == 0 || a.nq > kCosineMultiMax || a.n == 0 || a.d == 0) return hipErrorInvalidValue;
   if (a.sample ? (a.sample_stride == 0 || a.sample_rows == 0) : (!a.tau || !a.cand_keys || !a.cand_pay || !a.cand_count))
     return hipErrorInvalidValue;
-  hipError_t e = allow_lds(cosine_scan_multi_kernel, lds);
+  if (cosine_scan_multi_panel() == 64) {
+    hipError_t e = allow_lds(cosine_scan_multi_kernel<64>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cosine_scan_multi_kernel<64>, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+    return hipGetLastError();
+  }
+  hipError_t e = allow_lds(cosine_scan_multi_kernel<32>, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(cosine_scan_multi_kernel, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+  hipLaunchKernelGGL(cosine_scan_multi_kernel<32>, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
   return hipGetLastError();
 }
 

@@ -21,10 +21,10 @@ using namespace dev;
 
 namespace {
 
-// K6b's panel: 64 rows x 64 floats, rows 272 B apart in LDS.  PANEL = 32 (r05, A/B: VT_PM_PANEL): half the panel -- 8 wave
-// loads of 8 rows x 128 B, 9 KB of LDS per wave and half the prefetch registers, so that three or four waves share a SIMD
-// where two did (the chunk loop waits on scalar and LDS loads three times per chunk; with two waves per SIMD the VALU
-// idles through half of that).
+// K6b's panel is 64 rows x 64 floats, rows 272 B apart in LDS (PANEL = 64, K1p's r04 form).  PANEL = 32 (r05, the
+// default): half the panel -- 8 wave loads of 8 rows x 128 B, 9 KB of LDS per wave, half the prefetch registers (109-113
+// VGPRs against 173-192).  It was built to put three or four waves on a SIMD where two were; that is SLOWER -- but at the
+// same two blocks per CU the narrow panel is 1-7 % ahead everywhere (A.15), so it stays.
 constexpr int kPmRows = 64;
 template <int PANEL> struct PmShape {
   static constexpr int kPanel = PANEL, kStride = PANEL + 4;
@@ -231,7 +231,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
   }
 }
 
-int prefix_multi_panel() { return env::get(env::PM_PANEL) == 32 ? 32 : 64; }  // (VT_PM_PANEL=32: A/B)
+// (r05: 32-float panels are the default -- alternating in one process they are 1-7 % ahead of the 64-float ones at every
+// prefix length and metric, 7 % at full width under dot: DESIGN_APPENDIX A.15; VT_PM_PANEL=64: the r04 form, A/B)
+int prefix_multi_panel() { return env::get(env::PM_PANEL) == 64 ? 64 : 32; }
 
 template <int OP, int ORDER>
 hipError_t launch_pm(const PrefixMultiArgs &a, uint32_t blocks, size_t lds, hipStream_t s) {
@@ -267,7 +269,7 @@ size_t prefix_multi_lds_bytes() { return (size_t)kWavesPerBlock * kPmRows * (pre
 int prefix_multi_blocks_per_cu() {
   const long v = env::get(env::PM_BLOCKS);  // (VT_PM_BLOCKS: A/B)
   if (v >= 1 && v <= 4) return (int)v;
-  return prefix_multi_panel() == 32 ? 4 : 2;
+  return 2;  // (three or four blocks of the narrow panel fit a CU, and are slower: A.15)
 }
 
 hipError_t launch_prefix_multi(const PrefixMultiArgs &a, uint32_t blocks, hipStream_t s) {
