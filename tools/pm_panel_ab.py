@@ -23,6 +23,7 @@ def main():
     dim = int(os.environ.get("DIM", 768))
     prefixes = [int(v) for v in os.environ.get("PREFIXES", "64,128,256,%d" % dim).split(",")]
     rounds = int(os.environ.get("ROUNDS", 5))
+    nq = int(os.environ.get("NQ", 8))   # (NQ=1: the single-query kernels -- K6b under cosine, K1 on the prefix otherwise)
     nifs.debug_set("batch_no_mfma", 1)
     rng = np.random.default_rng(0)
     x = build_shard(torch, torch.device("cuda", 0), rows, dim, 99)
@@ -40,12 +41,16 @@ def main():
             def sweep_ms(panel, blocks):
                 nifs.debug_set("cs_panel" if metric == 2 else "pm_panel", panel)
                 nifs.debug_set("pm_blocks", blocks)
-                assert L.vt_flat_funnel_search_batch(ref.handle, qsp, 8, dim, st, 1, 100, 10, outs) == 0
-                L.vt_hits_free_many(outs, 8)
+                def call():
+                    if nq == 1:
+                        assert L.vt_flat_funnel_search(ref.handle, qsp, dim, st, 1, 100, 10, outs) == 0
+                    else:
+                        assert L.vt_flat_funnel_search_batch(ref.handle, qsp, nq, dim, st, 1, 100, 10, outs) == 0
+                    L.vt_hits_free_many(outs, nq)
+                call()
                 nifs.flat_get_profile(ref, reset=True)
                 for _ in range(6):
-                    assert L.vt_flat_funnel_search_batch(ref.handle, qsp, 8, dim, st, 1, 100, 10, outs) == 0
-                    L.vt_hits_free_many(outs, 8)
+                    call()
                 p = nifs.flat_get_profile(ref, reset=True)
                 # (the sample pass of every call is a launch of its own: half the launches, a few tens of us each)
                 return p["prefix_ms"] / max(1, p["prefix_launches"])

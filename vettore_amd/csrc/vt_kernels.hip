@@ -1268,10 +1268,15 @@ __global__ __launch_bounds__(64) void cosine_rerank_kernel(const CosineRerankArg
 // floats; a panel is read with coalesced 16-B loads (4 rows x 256 B per wave
 // instruction), parked in a wave-private LDS panel S[64][68] (stride 4*odd), and
 // lane r then runs row r's two f64 chains over it -- 64 chains in parallel.
-constexpr int kCsRows = 64, kCsPanel = 64, kCsStride = 68;
+// (r05: PANEL = 32 -- 8 wave loads of 8 rows x 128 B per panel, half the prefetch registers -- is what K1p and K6bm run on;
+// the single-query kernel takes the setting too: VT_CS_PANEL, DESIGN_APPENDIX A.15)
+constexpr int kCsRows = 64;
+inline int cosine_scan_multi_panel() { return env::get(env::CS_PANEL) == 64 ? 64 : 32; }
 
-template <int CAP>
+template <int CAP, int PANEL>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_kernel(const CosineScanArgs a) {
+  constexpr int kCsPanel = PANEL, kCsStride = PANEL + 4;
+  constexpr int kLanesPerRow = PANEL / 4, kRowsPerLoad = 64 / kLanesPerRow, kLoads = kCsRows / kRowsPerLoad;
   extern __shared__ __align__(16) float cs_lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1295,14 +1300,14 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_kernel(cons
   // issued as soon as the current panel has been parked in LDS, so a wave keeps
   // 16 KiB in flight through its f64 chain phase (without this the kernel sat at
   // 4.3 TB/s of prefix bytes; a plain strided read of the same bytes does 6.5).
-  f32x4 v[16];
+  f32x4 v[kLoads];
+  const int lrow = lane / kLanesPerRow, lcol = (lane % kLanesPerRow) * 4;  // this lane's row within a load, its column
   auto issue = [&](uint32_t t, uint32_t p) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      uint32_t r = t * kCsRows + 4 * s + (lane >> 4);
+    for (int s = 0; s < kLoads; ++s) {
+      uint32_t r = t * kCsRows + kRowsPerLoad * s + lrow;
       r = r < a.n ? r : a.n - 1;
-      v[s] = __builtin_nontemporal_load(
-          reinterpret_cast<const f32x4 *>(a.X + (size_t)r * a.stride + p * kCsPanel + (lane & 15) * 4));
+      v[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.X + (size_t)r * a.stride + p * kCsPanel + lcol));
     }
   };
   if (wave_global < ntiles) issue(wave_global, 0);
@@ -1313,8 +1318,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_kernel(cons
     double xx = 0.0, qx = 0.0;
     for (uint32_t p = 0; p < npanel; ++p) {
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        *reinterpret_cast<f32x4 *>(S + (4 * s + (lane >> 4)) * kCsStride + (lane & 15) * 4) = v[s];
+      for (int s = 0; s < kLoads; ++s) *reinterpret_cast<f32x4 *>(S + (kRowsPerLoad * s + lrow) * kCsStride + lcol) = v[s];
       wave_lds_fence();
       if (p + 1 < npanel) issue(t, p + 1);
       else if (t + total_waves < ntiles) issue(t + total_waves, 0);
@@ -2057,7 +2061,6 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_multi_kerne
   }
 }
 
-int cosine_scan_multi_panel() { return env::get(env::CS_PANEL) == 64 ? 64 : 32; }
 size_t cosine_scan_multi_lds_bytes() { return (size_t)kWavesPerBlock * kCsRows * (cosine_scan_multi_panel() + 4) * sizeof(float); }
 
 hipError_t launch_cosine_scan_multi(const CosineScanMultiArgs &a, uint32_t blocks, hipStream_t s) {
@@ -2079,7 +2082,7 @@ hipError_t launch_cosine_scan_multi(const CosineScanMultiArgs &a, uint32_t block
 
 size_t cosine_scan_lds_bytes(uint32_t d, uint32_t k) {
   const size_t buf = k <= (uint32_t)kSmallK ? WaveTopK<kCapSmall>::lds_bytes() : WaveTopK<kCapLarge>::lds_bytes();
-  const size_t bytes = ((size_t)padded_dim(d) + (size_t)kWavesPerBlock * kCsRows * kCsStride) * sizeof(float) +
+  const size_t bytes = ((size_t)padded_dim(d) + (size_t)kWavesPerBlock * kCsRows * (cosine_scan_multi_panel() + 4)) * sizeof(float) +
                        kWavesPerBlock * buf;
   return bytes <= kMaxLds ? bytes : 0;
 }
@@ -2087,18 +2090,15 @@ size_t cosine_scan_lds_bytes(uint32_t d, uint32_t k) {
 hipError_t launch_cosine_scan(const CosineScanArgs &a, uint32_t blocks, hipStream_t s) {
   const size_t lds = cosine_scan_lds_bytes(a.d, a.k);
   if (lds == 0 || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.n == 0) return hipErrorInvalidValue;
-  if (a.k <= (uint32_t)kSmallK) {
-    auto kern = cosine_scan_kernel<kCapSmall>;
+  const bool narrow = cosine_scan_multi_panel() == 32;
+  auto go = [&](auto kern) -> hipError_t {
     hipError_t e = allow_lds(kern, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
-  } else {
-    auto kern = cosine_scan_kernel<kCapLarge>;
-    hipError_t e = allow_lds(kern, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
-  }
-  return hipGetLastError();
+    return hipGetLastError();
+  };
+  if (a.k <= (uint32_t)kSmallK) return narrow ? go(cosine_scan_kernel<kCapSmall, 32>) : go(cosine_scan_kernel<kCapSmall, 64>);
+  return narrow ? go(cosine_scan_kernel<kCapLarge, 32>) : go(cosine_scan_kernel<kCapLarge, 64>);
 }
 
 // The yardstick bench.py quotes beside the 8 TB/s spec figure (vt_device_read_peak): a read-only
