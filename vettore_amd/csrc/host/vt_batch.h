@@ -108,9 +108,7 @@ int batch_group_queue(Shard *ix, Ctx &c, BatchGroupRun &run, const float *querie
   VT_TRY(c.dBCand.ensure((size_t)nq_pad * cand_cap));
   VT_TRY(c.dBCount.ensure(nq_pad));
   VT_TRY(c.hBCount.ensure(nq_pad));
-  VT_TRY(c.dBOut.ensure((size_t)nq_pad * k));
   VT_TRY(c.hBOut.ensure((size_t)nq_pad * k));
-  VT_TRY(c.dBOutCount.ensure(nq_pad));
   VT_TRY(c.hBOutCount.ensure(nq_pad + 1));  // (+ the status word: a copy into pageable memory would wait for the stream)
   VT_TRY(c.dPartKeys.ensure((size_t)nq_pad * kBlocksPerQuery * k));
   VT_TRY(c.dPartPay.ensure((size_t)nq_pad * kBlocksPerQuery * k));
@@ -355,8 +353,6 @@ int batch_group_finish(Shard *ix, Ctx &c, BatchGroupRun &run, vt_hits **out, std
   if (trace)
     std::fprintf(stderr, "[vt] batch group nq=%zu %s: staged %.3f ms, queued %.3f, device done %.3f, hits built %.3f\n", nq,
                  bf16 ? "bf16" : "f32", run.t_staged, run.t_queued, t_synced, since());
-  (void)ld;
-  (void)n;
   return VT_OK;
 }
 
