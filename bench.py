@@ -893,8 +893,13 @@ def measure_batches(a, torch, dist, nifs, _lib, L, ref, sharded, use_dist, launc
     }
     launches = max(1, prof["nominate_launches"] + prof["batch_launches"])
     pass_ms = (prof["nominate_ms"] + prof["batch_ms"]) / launches
+    # passes per step and shard: one per 256 queries of the batch (a 4 096-query call pipelines 16 of them)
+    groups = launches / a.steps / max(1, shards_in_process)
     out["config"]["per_shard_pass_ms"] = pass_ms
-    out["config"]["exchange_ms"] = dt / a.steps * 1e3 - pass_ms   # rescoring, select, hand-off, exchange, merge: everything but the pass
+    out["config"]["passes_per_step"] = groups
+    # rescoring, select, hand-off, exchange, merge: everything but the passes (what of it hides under the next group's pass
+    # inside one call is not in this figure any more)
+    out["config"]["exchange_ms"] = dt / a.steps * 1e3 - pass_ms * groups
     if shards_in_process > 1 or force_sharded:
         out["config"]["exchange_note"] = nifs.flat_exchange_note(ref)
         out["config"]["devices"] = devices

@@ -285,6 +285,78 @@ static void check_workers(int callers, int per_caller) {
   std::fprintf(stderr, "workers: %zu jobs per worker in one order, %d failures reported\n", seen[0].size(), failures.load());
 }
 
+// ------------------------------------------------------------------ 3b. the posting thread put to use
+// batch_multi's shape: every worker settles its items one by one (plain store, then a release flag); the caller
+// consumes an item once every worker has flagged it, while the jobs still run; whatever is left when they end it
+// takes afterwards.  Under TSan a read of an item that was not published yet is a report.
+static void check_workers_meanwhile(int callers, int per_caller) {
+  constexpr size_t S = 3, N = 64;
+  std::vector<std::unique_ptr<TestWorker>> workers;
+  for (size_t s = 0; s < S; ++s) {
+    workers.push_back(std::make_unique<TestWorker>());
+    workers.back()->start((int)s);
+  }
+  std::mutex post_mu;
+  std::atomic<uint64_t> early{0}, late{0};
+  std::vector<std::thread> pool;
+  for (int c = 0; c < callers; ++c)
+    pool.emplace_back([&, c] {
+      for (int it = 0; it < per_caller; ++it) {
+        std::vector<uint64_t> item(S * N, 0);
+        std::unique_ptr<std::atomic<unsigned char>[]> fin(new std::atomic<unsigned char>[S * N]);
+        for (size_t i = 0; i < S * N; ++i) fin[i].store(0, std::memory_order_relaxed);
+        std::vector<char> taken(N, 0);
+        uint64_t sum = 0;
+        const bool fails = (it % 29) == 7;
+        auto take_ready = [&]() -> bool {
+          bool any = false;
+          for (size_t i = 0; i < N; ++i) {
+            if (taken[i]) continue;
+            bool ready = true;
+            for (size_t s = 0; s < S && ready; ++s) ready = fin[s * N + i].load(std::memory_order_acquire) != 0;
+            if (!ready) continue;
+            for (size_t s = 0; s < S; ++s) sum += item[s * N + i];
+            taken[i] = 1;
+            any = true;
+          }
+          return any;
+        };
+        std::vector<size_t> all{0, 1, 2};
+        const int st = vt_host::run_on_workers_meanwhile(
+            workers, post_mu, all,
+            [&](size_t s) -> int {
+              for (size_t i = 0; i < N; ++i) {
+                if (fails && s == 1 && i == N / 2) return 9;
+                item[s * N + i] = (uint64_t)(c + 1) * 1000003u + i * (s + 1);
+                if (i % 3 != 2) fin[s * N + i].store(1, std::memory_order_release);  // (every third one only at the end)
+              }
+              for (size_t i = 0; i < N; ++i) fin[s * N + i].store(1, std::memory_order_release);
+              return 0;
+            },
+            take_ready, [](int status, const std::string &) { return status; });
+        size_t before = 0;
+        for (size_t i = 0; i < N; ++i) before += taken[i] ? 1 : 0;
+        early += before;
+        if (fails) {
+          CHECK(st == 9);
+          continue;
+        }
+        CHECK(st == 0);
+        take_ready();
+        late += N - before;
+        uint64_t want = 0;
+        for (size_t s = 0; s < S; ++s)
+          for (size_t i = 0; i < N; ++i) want += (uint64_t)(c + 1) * 1000003u + i * (s + 1);
+        CHECK(sum == want);
+        for (size_t i = 0; i < N; ++i) CHECK(taken[i]);
+      }
+    });
+  for (auto &th : pool) th.join();
+  workers.clear();
+  std::fprintf(stderr, "workers (caller merging meanwhile): %llu items taken while the jobs ran, %llu after\n",
+               (unsigned long long)early.load(), (unsigned long long)late.load());
+}
+
 // ------------------------------------------------------------------ 4. settings beside setenv
 static void check_settings(int readers, int per_reader) {
   // what the table holds was decided when this program was loaded (VT_COALESCE_SLOTS=3 from the test's environment)
@@ -367,6 +439,7 @@ int main(int argc, char **argv) {
   check_lease(48, 4000 * scale);
   check_spare_lease(48, 2000 * scale);
   check_workers(8, 1500 * scale);
+  check_workers_meanwhile(6, 400 * scale);
   std::printf("ok\n");
   return 0;
 }

@@ -661,3 +661,42 @@ def test_pattern_metric_readers_and_a_writer_on_one_handle(nifs, oracle_mod, met
     stop.set()
     w.join()
     assert not errors, errors[:3]
+
+
+@pytest.mark.parametrize("metric,shards,nq", [(0, 3, 700), (1, 2, 1100), (2, 4, 520)])
+def test_long_batches_on_a_sharded_handle_merge_while_the_shards_still_run(nifs, oracle_mod, vt_debug, metric, shards, nq):
+    """A batch of several 256-query groups on a sharded handle (round 5): every shard settles its lists group by group,
+    the calling thread merges a query as soon as every shard has settled it -- under the later groups' passes -- and
+    what is left when the shards are through is merged afterwards.  Whatever the timing, every list is the one-GPU
+    index's (itself checked against the oracle here) and the query's own single search on the sharded handle, bit for
+    bit; the planted duplicates sit in different shards, so their order is the id bytes' across shards."""
+    vt_debug.set("force_batch_mfma", 1)    # (the cost model would answer corpora this small with sweeps)
+    n, d = 30_000, 128
+    x, ids = make_corpus(n, d, 7700 + metric, metric == 2, oracle_mod, tie_block=30)
+    sharded = ShardedIndex(nifs, metric, [0] * shards)
+    route = nifs.flat_route_ids(sharded.ref, nifs.pack_ids(ids))
+    first = [int(np.flatnonzero(route == s)[0]) for s in range(shards)]
+    for r in first[1:]:
+        x[r] = x[first[0]]
+    unwrap(nifs.flat_load_matrix(sharded.ref, ids, x))
+    plain = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(plain.ref, ids, x))
+    rng = np.random.default_rng(91 + metric)
+    qs = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+    qs[0], qs[255], qs[256], qs[nq - 1] = x[first[0]], x[first[-1]], x[n // 2], x[first[0]]
+    if metric == 2:
+        qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+    packed = oracle_mod.pack_ids(ids)
+    for limit in (10, 3):
+        got = unwrap(nifs.flat_search_batch(sharded.ref, qs, limit))
+        one = unwrap(nifs.flat_search_batch(plain.ref, qs, limit))
+        assert len(got) == nq
+        for i in range(nq):
+            assert bits(got[i]) == bits(one[i]), (metric, limit, i)
+        for i in (0, 255, 256, 257, 511, 512, nq - 1):
+            if i < nq:
+                assert bits(got[i]) == bits(sharded.search(qs[i], limit)), (metric, limit, i)
+                assert bits(got[i]) == bits(oracle_mod.matrix_search(metric, x, packed, qs[i], limit)), (metric, limit, i)
+    # the duplicates planted across the shards come back in id order
+    top = unwrap(nifs.flat_search_batch(sharded.ref, qs, shards))[0]
+    assert [h[0] for h in top] == sorted(ids[r] for r in first)

@@ -42,7 +42,9 @@ double bench(F f, int n = 2000) {
   return std::chrono::duration<double, std::micro>(t1 - t0).count() / n;
 }
 
-int main() {
+int main(int argc, char **argv) {
+  if (argc > 1 && !strcmp(argv[1], "spin")) { CK(hipSetDeviceFlags(hipDeviceScheduleSpin)); printf("(hipDeviceScheduleSpin)\n"); }
+  if (argc > 1 && !strcmp(argv[1], "yield")) { CK(hipSetDeviceFlags(hipDeviceScheduleYield)); printf("(hipDeviceScheduleYield)\n"); }
   hipStream_t s;
   CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   float *hq, *dq, *dout, *hq_dev;
@@ -87,6 +89,25 @@ int main() {
     k_use<<<G, 256, 0, s>>>(dq, dout, 768); k_flag<<<1, 64, 0, s>>>(hflag_dev, (unsigned)i + 1);
     while (*(volatile unsigned *)hflag != (unsigned)i + 1) {} }));
   hipStreamSynchronize(s);
+  // waiting by polling the runtime instead of sleeping on the completion interrupt
+  printf("memcpy + 2 kernels + query spin   %7.2f us\n", bench([&](int) {
+    hipMemcpyAsync(dq, hq, 3072, hipMemcpyHostToDevice, s);
+    k_use<<<G, 256, 0, s>>>(dq, dout, 768); k_empty<<<1, 1024, 0, s>>>(dout);
+    while (hipStreamQuery(s) == hipErrorNotReady) {} }));
+  {
+    hipEvent_t ev;
+    hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    printf("memcpy + 2 kernels + event spin   %7.2f us\n", bench([&](int) {
+      hipMemcpyAsync(dq, hq, 3072, hipMemcpyHostToDevice, s);
+      k_use<<<G, 256, 0, s>>>(dq, dout, 768); k_empty<<<1, 1024, 0, s>>>(dout);
+      hipEventRecord(ev, s);
+      while (hipEventQuery(ev) == hipErrorNotReady) {} }));
+    printf("memcpy + 2 kernels + event sync   %7.2f us\n", bench([&](int) {
+      hipMemcpyAsync(dq, hq, 3072, hipMemcpyHostToDevice, s);
+      k_use<<<G, 256, 0, s>>>(dq, dout, 768); k_empty<<<1, 1024, 0, s>>>(dout);
+      hipEventRecord(ev, s);
+      hipEventSynchronize(ev); }));
+  }
   // the same chain as an instantiated graph (r05: the one form the earlier rounds had not priced): captured once,
   // launched per call; then with one kernel node's parameters rewritten before every launch (what a search would do:
   // limit, thresholds and pointers change from call to call)

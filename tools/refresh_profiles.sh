@@ -62,5 +62,6 @@ cd /tmp
 python3 $R/bench.py --gpus 1 --exchange rccl --rows 1250000 --no-cpu > $OUT/${RND}_shard_10m_of_8.json 2> $OUT/shard_a.log
 python3 $R/bench.py --gpus 1 --exchange rccl --metric l2 --rows 5000000 --no-cpu > $OUT/${RND}_shard_40m_of_8.json 2> $OUT/shard_b.log
 python3 $R/bench.py --gpus 1 --exchange rccl --mode batch --metric l2 --rows 5000000 --steps 60 --warmup 5 --no-cpu > $OUT/${RND}_shard_40m_of_8_batch.json 2> $OUT/shard_c.log
+python3 $R/bench.py --gpus 1 --exchange rccl --mode batch --metric l2 --rows 5000000 --batch 4096 --steps 6 --warmup 1 --no-cpu > $OUT/${RND}_shard_40m_of_8_batch16.json 2> $OUT/shard_d.log
 cd $R
-tail -n 1 $OUT/${RND}_shard_10m_of_8.json $OUT/${RND}_shard_40m_of_8.json $OUT/${RND}_shard_40m_of_8_batch.json
+tail -n 1 $OUT/${RND}_shard_10m_of_8.json $OUT/${RND}_shard_40m_of_8.json $OUT/${RND}_shard_40m_of_8_batch.json $OUT/${RND}_shard_40m_of_8_batch16.json

@@ -633,6 +633,11 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
     auto settle = [&](size_t g, const std::vector<char> &gdone, const std::vector<float> &gtau) {
       for (size_t i = 0; i < groups[g].second; ++i) done[groups[g].first + i] = gdone[i];
       for (size_t i = 0; i < gtau.size(); ++i) tau2[groups[g].first + i] = gtau[i];
+      // (a shard of a sharded handle: the lists this group settled are final -- nothing below rewrites a done query --
+      // and the handle's calling thread may start merging them with the other shards' while the next groups run)
+      if (ix->batch_final)
+        for (size_t i = 0; i < groups[g].second; ++i)
+          if (gdone[i]) ix->batch_final[groups[g].first + i].store(1, std::memory_order_release);
     };
     if (!spare.c) {
       for (size_t g = 0; g < groups.size(); ++g) {

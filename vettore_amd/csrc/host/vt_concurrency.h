@@ -84,6 +84,10 @@ struct WorkerT {
     std::unique_lock<std::mutex> g(mu);
     done_cv.wait(g, [job] { return job->done; });
   }
+  bool finished(Job *job) {
+    std::lock_guard<std::mutex> g(mu);
+    return job->done;
+  }
   ~WorkerT() {
     {
       std::lock_guard<std::mutex> g(mu);
@@ -110,6 +114,34 @@ int run_on_workers(std::vector<std::unique_ptr<Worker>> &workers, std::mutex &po
     for (size_t i = 0; i < which.size(); ++i) workers[which[i]]->post(&jobs[i]);
   }
   for (size_t i = 0; i < which.size(); ++i) workers[which[i]]->wait(&jobs[i]);
+  for (size_t i = 0; i < which.size(); ++i)
+    if (jobs[i].status != 0) return on_error(jobs[i].status, jobs[i].error);
+  return 0;
+}
+
+// The same, with the posting thread put to use while the workers run: `meanwhile()` is called over and over until
+// every job is done (it returns whether it found something to do; when it did not, the thread naps for 100 us -- the
+// jobs here are passes over a corpus, milliseconds long).  What `meanwhile` may touch of the jobs' results is the
+// callers' business (batch_multi: hit lists published query by query through release stores).
+template <class Worker, class F, class M, class OnError>
+int run_on_workers_meanwhile(std::vector<std::unique_ptr<Worker>> &workers, std::mutex &post_mu, const std::vector<size_t> &which,
+                             F fn, M meanwhile, OnError on_error) {
+  std::vector<typename Worker::Job> jobs(which.size());
+  for (size_t i = 0; i < which.size(); ++i) {
+    const size_t s = which[i];
+    jobs[i].fn = [&fn, s]() -> int { return fn(s); };
+  }
+  {
+    std::lock_guard<std::mutex> g(post_mu);
+    for (size_t i = 0; i < which.size(); ++i) workers[which[i]]->post(&jobs[i]);
+  }
+  for (size_t next = 0; next < which.size();) {
+    if (workers[which[next]]->finished(&jobs[next])) {
+      ++next;
+      continue;
+    }
+    if (!meanwhile()) std::this_thread::sleep_for(std::chrono::microseconds(100));
+  }
   for (size_t i = 0; i < which.size(); ++i)
     if (jobs[i].status != 0) return on_error(jobs[i].status, jobs[i].error);
   return 0;

@@ -1040,6 +1040,8 @@ int make_hits(const Shard *ix, const std::vector<vt::Entry> &entries, vt_hits **
     });
   } else {
     h->ids.reserve(m);
+    h->raw.reserve(m);
+    h->rank_key.reserve(m);
     for (const auto &e : entries) {
       h->ids.push_back(ix->ids[e.row]);
       h->raw.push_back(e.raw);

@@ -207,6 +207,9 @@ struct Shard {
   size_t unranked = 0;  // rows carrying kUnranked: past a bound the next search rebuilds instead of going lazy
   bool external_ranks = false;      // rank column supplied by vt_flat_set_id_ranks (valid until the next mutation)
   bool hits_by_row = false;         // make_hits leaves the ids where they are (set by this shard's worker around a batch of a sharded handle)
+  // (the same worker, the same batch) one flag per query of the batch, set -- with release order -- once that query's list
+  // is final: the handle's calling thread merges the shards' lists of such queries while later groups still run
+  std::atomic<unsigned char> *batch_final = nullptr;
   uint64_t epoch = 0;               // bumped by every mutation of the row set (insert of a new id, delete)
   uint64_t external_epoch = 0;      // epoch at which the external ranks were installed
   bool external_expected = false;   // vt_flat_set_id_ranks has been used on this shard: search_begin insists on current ranks
