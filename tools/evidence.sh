@@ -37,6 +37,8 @@ if [ "${SOAKS:-1}" != "0" ]; then
     SECONDS=$(secs 120) SHARDS=3 python3 tools/soak_concurrent.py 2>&1 | tail -1
     echo "# soak_batch_pipeline (r05: batch calls of 2..5 groups of 256 on two contexts, every list against the oracle)"
     SECONDS=$(secs 150) python3 tools/soak_batch_pipeline.py 2>&1 | tail -1
+    echo "# soak_batch_pipeline SHARDS=3 (the same calls on a sharded handle: the calling thread merges under the later groups)"
+    SHARDS=3 SECONDS=$(secs 90) python3 tools/soak_batch_pipeline.py 2>&1 | tail -1
   } > $OUT/soaks.log 2>&1
   cat $OUT/soaks.log
 fi

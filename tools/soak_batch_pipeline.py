@@ -4,7 +4,7 @@ alternate between two contexts, group g + 1 queued before group g is waited for;
 on corpora of 17 000-40 000 rows under the five metrics that take the matrix cores, both nominations, after random
 mutations, with a second thread running batches of its own on the same handle (it competes for the spare contexts) --
 every list against the same query searched alone, a handful per batch against the oracle.
-SECONDS / SEED / METRICS env.  Prints one line per run and a summary; diagnostic only (tests/ hold the fixed cases)."""
+SECONDS / SEED / METRICS / SHARDS env.  Prints one line per run and a summary; diagnostic only (tests/ hold the fixed cases)."""
 import os
 import sys
 import threading
@@ -44,7 +44,10 @@ def run(seed, metric):
     if metric == 2:
         x = np.stack([oracle.normalize_l2(r) for r in x])
     ids = [b"doc-%d" % (i + 1) for i in range(n)]
-    ref = nifs._flat_new(metric)
+    shards = int(os.environ.get("SHARDS", "0"))
+    # (SHARDS=n: a sharded handle with n shards on device 0 -- the groups pipeline inside every shard, and the calling
+    # thread merges the shards' lists query by query while later groups still run)
+    ref = nifs.flat_new_sharded(metric, [0] * shards) if shards else nifs._flat_new(metric)
     assert nifs.flat_set_batch_nominate(ref, 1 if rng.integers(0, 4) == 0 else 2) == "ok"   # (mostly bf16, the default)
     ok(nifs.flat_load_matrix(ref, ids, x))
     nifs.flat_set_profiling(ref, True)
