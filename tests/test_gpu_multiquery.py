@@ -134,3 +134,75 @@ def test_batches_as_k1p_sweeps_equal_single_queries(nifs, oracle_mod, metric, d,
         for i in (0, nq - 1):
             want = oracle_mod.matrix_search(metric, x, packed, qs[i], limit)
             assert bits(got[i]) == bits(want), (metric, d, nq, i)
+
+
+@pytest.mark.parametrize("metric", [2, 0, 5, 3])
+def test_many_groups_of_one_call_alternate_between_two_contexts(nifs, oracle_mod, vt_debug, metric):
+    """Round 5 (host/vt_funnel.h funnel_groups): the groups of eight of ONE funnel_search_batch / flat_search_batch call
+    alternate between the caller's context and a second one -- group g + 1 is queued before group g is waited for.  43
+    queries = five groups and a straggler (plus a lone one that goes alone).  Every list equals the query's single call,
+    the oracle's composition for a few, and the same call with the groups in series (`no_group_pipeline`); an overflow
+    inside the MIDDLE group sends that group's queries on one by one and the call reports what the loop of single
+    calls would."""
+    n, d, nq = 30_000, 136, 43
+    x, ids = make_corpus(n, d, 5900 + metric, metric == 2, oracle_mod, tie_block=200)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rows = [(ids[i], x[i]) for i in range(n)]
+    by_id = dict(rows)
+    rng = np.random.default_rng(77 + metric)
+    qs = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+    qs[0], qs[20] = x[n // 2], x[n // 2 + 3]                 # inside the block of identical rows, in two groups
+    if metric == 2:
+        qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+    stages, cand, limit = [40, 96], 60, 10
+    nifs.flat_set_profiling(g.ref, True)
+    nifs.flat_get_profile(g.ref, reset=True)
+    got = unwrap(nifs.flat_funnel_search_batch(g.ref, qs, stages, cand, limit))
+    prof = nifs.flat_get_profile(g.ref, reset=True)
+    assert prof["prefix_queries"] >= nq - 1 - nq // 8, prof       # the sweeps took them (a threshold may miss now and then)
+    nifs.flat_set_profiling(g.ref, False)
+    for i in range(nq):
+        assert bits(got[i]) == bits(unwrap(nifs.flat_funnel_search(g.ref, qs[i], stages, cand, limit))), (metric, i)
+    for i in (0, 20, nq - 1):
+        cur = rows
+        for st in stages:
+            cur = [(j, by_id[j]) for j, _ in oracle_mod.vector_top_k(cur, qs[i], metric, st, cand)]
+        assert bits(got[i]) == bits(oracle_mod.vector_top_k(cur, qs[i], metric, d, limit)), (metric, i)
+    vt_debug.set("no_group_pipeline", 1)
+    series = unwrap(nifs.flat_funnel_search_batch(g.ref, qs, stages, cand, limit))
+    vt_debug.set("no_group_pipeline", 0)
+    assert [bits(h) for h in series] == [bits(h) for h in got]
+    # plain searches of a metric without a GEMM form travel as whole-row sweeps of eight through the same groups
+    if metric == 5:
+        vt_debug.set("force_sweep_groups", 1)
+        nifs.flat_set_profiling(g.ref, True)
+        nifs.flat_get_profile(g.ref, reset=True)
+        plain = unwrap(nifs.flat_search_batch(g.ref, qs, limit))
+        assert nifs.flat_get_profile(g.ref, reset=True)["sweep_queries"] >= nq - 1 - nq // 8
+        packed = oracle_mod.pack_ids(ids)
+        for i in range(nq):
+            assert bits(plain[i]) == bits(unwrap(nifs.flat_search(g.ref, qs[i], limit))), i
+        for i in (0, 20, nq - 1):
+            assert bits(plain[i]) == bits(oracle_mod.matrix_search(metric, x, packed, qs[i], limit)), i
+    # an overflow in the third group of five (inner product): one query's own, then a stored row's (every group's)
+    if metric == 3:
+        bad = qs.copy()
+        bad[19, :8] = 3e38
+        singles = [nifs.flat_funnel_search(g.ref, q, [16], 50, 5) for q in bad]
+        res = nifs.flat_funnel_search_batch(g.ref, bad, [16], 50, 5)
+        firsterr = next((r for r in singles if r[0] == "error"), None)
+        assert firsterr is not None and res == firsterr
+        ok_part = unwrap(nifs.flat_funnel_search_batch(g.ref, np.delete(bad, 19, axis=0), [16], 50, 5))
+        assert [bits(h) for h in ok_part] == [bits(unwrap(r)) for i, r in enumerate(singles) if i != 19]
+        big = GpuIndex(nifs, 3)
+        xb = x[:20_000].copy()
+        xb[77, :8] = 3e38
+        unwrap(nifs.flat_load_matrix(big.ref, ids[:20_000], xb))
+        singles = [nifs.flat_funnel_search(big.ref, q, [16], 50, 5) for q in bad[:30]]
+        res = nifs.flat_funnel_search_batch(big.ref, bad[:30], [16], 50, 5)
+        firsterr = next((r for r in singles if r[0] == "error"), None)
+        if firsterr is not None:
+            assert res == firsterr
+        else:
+            assert [bits(h) for h in unwrap(res)] == [bits(unwrap(r)) for r in singles]

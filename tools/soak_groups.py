@@ -71,7 +71,7 @@ def run(seed, metric):
         return oracle.normalize_l2(q) if metric == 2 else q
 
     for step in range(6):
-        nq = int(rng.integers(2, 18))
+        nq = int(rng.integers(2, 18)) if rng.integers(0, 4) else int(rng.integers(18, 60))   # (now and then five or more groups: they alternate between two contexts)
         qs = np.stack([query() for _ in range(nq)])
         COUNTS["queries"] += nq
         COUNTS["oracle_checks"] += 2

@@ -580,6 +580,8 @@ bool batch_uses_mfma(const Shard *ix, size_t nq, size_t limit) {
 bool funnel_group_applies(const Shard *ix, const size_t *stages, size_t nstages, size_t candidates, size_t limit);
 int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size_t> &which, const size_t *stages, size_t nstages,
                  size_t candidates, size_t limit, vt_hits **out, std::vector<char> &done, bool as_scan = false);
+int funnel_groups(Shard *ix, Ctx &c, const float *queries, const std::vector<std::vector<size_t>> &groups, const size_t *stages,
+                  size_t nstages, size_t candidates, size_t limit, vt_hits **out, std::vector<char> &done, bool as_scan);
 
 // A batch of plain searches as K1p sweeps (funnel_group with the whole row as its one stage and `limit` candidates:
 // the sweep's arithmetic over all d coordinates is K1's, the lists' `limit` best are flat_search's hits).  Measured
@@ -724,19 +726,12 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
                            (double)left.size() * pattern_s < multi_scan_seconds(ix, left.size()));
   if (!by_pattern && left.size() >= 2 && sweep_group_applies(ix, limit)) {
     const size_t stage = (size_t)ix->dim;
-    for (size_t g0 = 0; g0 + 2 <= left.size(); g0 += vt::kPrefixMultiMax) {
-      const std::vector<size_t> which(left.begin() + g0, left.begin() + std::min(left.size(), g0 + vt::kPrefixMultiMax));
-      const int st = funnel_group(ix, c, queries, which, &stage, 1, limit, limit, out, done, true);
-      if (st == kRetryInternal) {  // an overflow somewhere: these go on below, each reporting its own
-        for (size_t i : which) {
-          delete out[i];
-          out[i] = nullptr;
-          done[i] = 0;
-        }
-      } else if (st != VT_OK) {
-        return st;
-      }
-    }
+    std::vector<std::vector<size_t>> sweeps;
+    for (size_t g0 = 0; g0 + 2 <= left.size(); g0 += vt::kPrefixMultiMax)
+      sweeps.emplace_back(left.begin() + g0, left.begin() + std::min(left.size(), g0 + vt::kPrefixMultiMax));
+    // (a group with an overflow somewhere comes back undone: its queries go on below, each reporting its own; the
+    // groups alternate between two contexts, funnel_groups)
+    VT_TRY(funnel_groups(ix, c, queries, sweeps, &stage, 1, limit, limit, out, done, true));
     std::vector<size_t> rest;
     for (size_t i : left)
       if (!done[i]) rest.push_back(i);

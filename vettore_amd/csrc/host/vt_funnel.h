@@ -96,8 +96,23 @@ bool funnel_group_applies(const Shard *ix, const size_t *stages, size_t nstages,
   return (size_t)2 * (((size_t)ix->dim + 3) / 4 * 4) * 4 <= 160 * 1024;  // the rerank keeps row + query in LDS
 }
 
-int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size_t> &which, const size_t *stages,
-                 size_t nstages, size_t candidates, size_t limit, vt_hits **out, std::vector<char> &done, bool as_scan) {
+// A group in flight: funnel_group_queue leaves everything queued on the context's stream, funnel_group_finish waits for
+// it and files the lists.  Between the two the context's pinned blocks belong to the group (one group per context at a
+// time); the views below point into them.
+struct FunnelGroupRun {
+  std::vector<size_t> which;
+  uint32_t nq = 0, k1 = 0, k2 = 0, n = 0, d1 = 0;
+  bool cosine = false, as_scan = false;
+  const vt::Entry *hOut = nullptr;
+  const uint32_t *hOutCount = nullptr;
+  const int *hStatus = nullptr;
+  const uint32_t *hListCount = nullptr;
+  const float *hTau = nullptr;
+  const uint64_t *hLastKey = nullptr;
+};
+
+int funnel_group_queue(Shard *ix, Ctx &c, FunnelGroupRun &run, const float *queries, const std::vector<size_t> &which,
+                       const size_t *stages, size_t nstages, size_t candidates, size_t limit, bool as_scan) {
   const uint32_t d = (uint32_t)ix->dim, ld = ix->ld, n = ix->n;
   const uint32_t nq = (uint32_t)which.size();
   const uint32_t d1 = (uint32_t)stages[0], ldq = vt::padded_dim(d1);
@@ -275,6 +290,33 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   }
   VT_HIP(hipMemcpyAsync(hStatus, c.dStatus.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));  // (pinned: stays asynchronous)
   VT_HIP(hipMemsetAsync(c.dStatus.p, 0, sizeof(int), c.stream));
+  run.which = which;
+  run.nq = nq;
+  run.k1 = k1;
+  run.k2 = k2;
+  run.n = n;
+  run.d1 = d1;
+  run.cosine = cosine;
+  run.as_scan = as_scan;
+  run.hOut = hOut;
+  run.hOutCount = hOutCount;
+  run.hStatus = hStatus;
+  run.hListCount = hListCount;
+  run.hTau = hTau;
+  run.hLastKey = hLastKey;
+  return VT_OK;
+}
+
+int funnel_group_finish(Shard *ix, Ctx &c, const FunnelGroupRun &run, vt_hits **out, std::vector<char> &done) {
+  const std::vector<size_t> &which = run.which;
+  const uint32_t nq = run.nq, k1 = run.k1, k2 = run.k2, n = run.n, d1 = run.d1;
+  const bool cosine = run.cosine, as_scan = run.as_scan;
+  const vt::Entry *hOut = run.hOut;
+  const uint32_t *hOutCount = run.hOutCount, *hListCount = run.hListCount;
+  const int *hStatus = run.hStatus;
+  const float *hTau = run.hTau;
+  const uint64_t *hLastKey = run.hLastKey;
+  constexpr uint32_t kListCap = 8192;
   VT_HIP(hipStreamSynchronize(c.stream));
   if (c.profiling) {
     float ms = 0.f;
@@ -315,6 +357,67 @@ int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size
   return VT_OK;
 }
 
+// One group, start to end, on one context.
+int funnel_group(Shard *ix, Ctx &c, const float *queries, const std::vector<size_t> &which, const size_t *stages,
+                 size_t nstages, size_t candidates, size_t limit, vt_hits **out, std::vector<char> &done, bool as_scan) {
+  FunnelGroupRun run;
+  const int st = funnel_group_queue(ix, c, run, queries, which, stages, nstages, candidates, limit, as_scan);
+  if (st != VT_OK) {  // (whatever was queued reads the context's pinned blocks)
+    const std::string why = g_last_error;
+    (void)hipStreamSynchronize(c.stream);
+    (void)hipGetLastError();
+    g_last_error = why;
+    return st;
+  }
+  return funnel_group_finish(ix, c, run, out, done);
+}
+
+// The groups of one call (r05).  A group is a sweep of the corpus for up to eight queries (0.9 ms over a 128-float
+// prefix, 4.7-5.7 ms over whole rows) and then a tail nobody else can use the card under: list selects, the later
+// stages' rescoring of 8 x `candidates` rows, the exact rerank, a select, the wait, eight hit lists -- 0.3-0.5 ms,
+// a third of a prefix-128 group (a batch of 64 cosine funnels: 11.0 ms = 8 x 1.375 for 8 x 0.89 ms of sweeps).  With a
+// second context the groups alternate: group g + 1 is staged and queued BEFORE group g is waited for, its sample pass
+// and sweep start while g's tail kernels run, g's host side runs under g + 1's sweep.  Each group's lists are what it
+// gives alone: nothing is shared but the card.  A group that reports kRetryInternal (an overflow somewhere in it) hands
+// its queries back undone; any other failure ends the call once both streams are idle.
+int funnel_groups(Shard *ix, Ctx &c, const float *queries, const std::vector<std::vector<size_t>> &groups, const size_t *stages,
+                  size_t nstages, size_t candidates, size_t limit, vt_hits **out, std::vector<char> &done, bool as_scan) {
+  auto settle = [&](const std::vector<size_t> &which, int st) -> int {
+    if (st != kRetryInternal) return st;
+    for (size_t i : which) {
+      delete out[i];
+      out[i] = nullptr;
+      done[i] = 0;
+    }
+    return VT_OK;
+  };
+  SpareCtxLease spare(groups.size() >= 2 && !vt::env::on(vt::env::NO_GROUP_PIPELINE) ? ix : nullptr);
+  if (!spare.c) {
+    for (const auto &which : groups) VT_TRY(settle(which, funnel_group(ix, c, queries, which, stages, nstages, candidates, limit, out, done, as_scan)));
+    return VT_OK;
+  }
+  VT_TRY(spare.c->bind());
+  Ctx *cx[2] = {&c, spare.c};
+  FunnelGroupRun runs[2];
+  auto queue = [&](size_t g) {
+    return funnel_group_queue(ix, *cx[g & 1], runs[g & 1], queries, groups[g], stages, nstages, candidates, limit, as_scan);
+  };
+  int st = queue(0);
+  for (size_t g = 0; g < groups.size() && st == VT_OK; ++g) {
+    const int st_next = g + 1 < groups.size() ? queue(g + 1) : VT_OK;
+    st = settle(groups[g], funnel_group_finish(ix, *cx[g & 1], runs[g & 1], out, done));
+    if (st == VT_OK) st = st_next;
+  }
+  if (st != VT_OK) {  // (whatever is still queued reads and writes the two contexts' pinned blocks)
+    const std::string why = g_last_error;
+    (void)hipStreamSynchronize(cx[0]->stream);
+    (void)hipStreamSynchronize(cx[1]->stream);
+    (void)hipGetLastError();
+    g_last_error = why;
+  }
+  return st;
+}
+
 // funnel_search for nq queries (rows of `queries`) with one set of stages: groups of up to eight
 // share the stage-1 sweep; what the groups cannot take goes through funnel_ready one by one.
 int funnel_batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, const size_t *stages, size_t nstages,
@@ -329,21 +432,14 @@ int funnel_batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_
   }
   std::vector<char> done(nq, 0);
   if (nq >= 2 && funnel_group_applies(ix, stages, nstages, candidates, limit)) {
+    std::vector<std::vector<size_t>> groups;
     for (size_t g0 = 0; g0 < nq; g0 += vt::kCosineMultiMax) {
       std::vector<size_t> which;
       for (size_t i = g0; i < std::min<size_t>(nq, g0 + vt::kCosineMultiMax); ++i) which.push_back(i);
       if (which.size() < 2) break;
-      const int st = funnel_group(ix, c, queries, which, stages, nstages, candidates, limit, out, done);
-      if (st == kRetryInternal) {
-        for (size_t i : which) {
-          delete out[i];
-          out[i] = nullptr;
-          done[i] = 0;
-        }
-      } else if (st != VT_OK) {
-        return st;
-      }
+      groups.push_back(std::move(which));
     }
+    VT_TRY(funnel_groups(ix, c, queries, groups, stages, nstages, candidates, limit, out, done, false));
   }
   for (size_t i = 0; i < nq; ++i)
     if (!done[i]) VT_TRY(funnel_ready(ix, c, queries + i * d, d, stages, nstages, candidates, limit, &out[i]));
