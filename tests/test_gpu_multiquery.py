@@ -206,3 +206,34 @@ def test_many_groups_of_one_call_alternate_between_two_contexts(nifs, oracle_mod
             assert res == firsterr
         else:
             assert [bits(h) for h in unwrap(res)] == [bits(unwrap(r)) for r in singles]
+
+
+@pytest.mark.parametrize("metric", [2, 0])
+def test_quantized_batches_of_many_groups_on_two_streams(nifs, oracle_mod, vt_debug, metric):
+    """quantized_search_batch with several groups of eight (profiling off: the timed form waits group by group): every
+    group is queued before anything is waited for, even groups on the caller's context, odd groups on a second one
+    (round 5; `qgroup_streams=1` is the one-stream form, `no_group_pipeline=1` waits group by group).  All three forms
+    give every query its own quantized_search's hits, bit for bit, and the oracle's composition (binary_top_k, then
+    vector_top_k over the candidates: collection.ex:276-295)."""
+    n, d, nq, cand, limit = 40_000, 200, 45, 80, 10
+    x, ids = make_corpus(n, d, 6400 + metric, metric == 2, oracle_mod, tie_block=150)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(5 + metric)
+    qs = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+    qs[0], qs[9], qs[44] = x[n // 2], x[n // 2 + 5], x[n // 2]        # the block of identical rows, from three groups
+    if metric == 2:
+        qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+    singles = [bits(unwrap(nifs.flat_quantized_search(g.ref, q, cand, limit))) for q in qs]
+    for name, value in (("qgroup_streams", 0), ("qgroup_streams", 1), ("no_group_pipeline", 1)):
+        vt_debug.set(name, value)
+        for _ in range(2):      # (the second call reuses both contexts' slots)
+            got = unwrap(nifs.flat_quantized_search_batch(g.ref, qs, cand, limit))
+            assert [bits(h) for h in got] == singles, (metric, name, value)
+        vt_debug.set(name, 0)
+    sign = x >= 0
+    for i in (0, 9, 44):
+        ham = (sign != (qs[i] >= 0)[None, :]).sum(axis=1)
+        order = sorted(range(n), key=lambda r: (int(ham[r]), ids[r]))[:cand]
+        want = oracle_mod.vector_top_k([(ids[r], x[r]) for r in order], qs[i], metric, d, limit)
+        assert singles[i] == bits(want), (metric, i)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The groups of one call over two contexts (r05, funnel_groups): funnel_search batches (stage-1 sweeps of eight: K6bm
-under cosine, K1p under L2) and plain search batches that run as K1p sweeps (manhattan), with the pipeline on and off
+under cosine, K1p under L2), plain search batches that run as K1p sweeps (manhattan) and quantized_search batches (K4hm), with the pipeline on and off
 alternating in ONE process on one index (`no_group_pipeline` by name).  Every batched list is compared with the same
-query's single call.  ROWS / DIM / NQS / REPS env.  Diagnostic only."""
+query's single call.  ROWS / DIM / NQS / REPS / LEGS (funnel,search,quantized) env.  Diagnostic only."""
 import ctypes as C
 import json
 import os
@@ -27,7 +27,13 @@ def main():
     nqs = [int(v) for v in os.environ.get("NQS", "16,64,256").split(",")]
     rng = np.random.default_rng(5)
     st_arr = (C.c_size_t * 1)(min(dim, 128))
-    for name, metric, funnel in (("funnel cosine", 2, True), ("funnel l2", 0, True), ("search manhattan", 5, False)):
+    legs = (("funnel cosine", 2, "funnel"), ("funnel l2", 0, "funnel"), ("search manhattan", 5, "search"),
+            ("quantized cosine", 2, "quantized"))
+    only = os.environ.get("LEGS")
+    for name, metric, kind in legs:
+        if only and name.split()[0] not in only.split(","):
+            continue
+        funnel = kind == "funnel"
         x = build_shard(torch, torch.device("cuda", 0), rows, dim, 99, normalize=(metric == 2))
         ref = nifs._flat_new(metric)
         assert nifs.flat_load_device_matrix(ref, doc_ids(0, rows), x.data_ptr(), rows, dim) == ("ok", ())
@@ -35,7 +41,7 @@ def main():
         torch.cuda.empty_cache()
         out = {"leg": name, "rows": rows, "dim": dim}
         for nq in nqs:
-            if not funnel and nq > 64:
+            if kind == "search" and nq > 64:
                 continue
             qs = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
             if metric == 2:
@@ -46,6 +52,8 @@ def main():
             def call(keep=False):
                 if funnel:
                     st = L.vt_flat_funnel_search_batch(ref.handle, qsp, nq, dim, st_arr, 1, 100, 10, outs)
+                elif kind == "quantized":
+                    st = L.vt_flat_quantized_search_batch(ref.handle, qsp, nq, dim, 100, 10, outs)
                 else:
                     st = L.vt_flat_search_batch(ref.handle, qsp, nq, dim, 10, outs)
                 assert st == 0, (L.vt_last_error() or b"").decode()
@@ -58,6 +66,8 @@ def main():
                 qp = qs[i].ctypes.data_as(C.POINTER(C.c_float))
                 if funnel:
                     assert L.vt_flat_funnel_search(ref.handle, qp, dim, st_arr, 1, 100, 10, C.byref(h)) == 0
+                elif kind == "quantized":
+                    assert L.vt_flat_quantized_search(ref.handle, qp, dim, 100, 10, C.byref(h)) == 0
                 else:
                     assert L.vt_flat_search(ref.handle, qp, dim, 10, C.byref(h)) == 0
                 return hits_of(L, h)
@@ -73,11 +83,24 @@ def main():
                 key = "series" if off else "pipelined"
                 res[key] = min(res.get(key, 1e9), dt * 1e3)
             nifs.debug_set("no_group_pipeline", 0)
+            if kind == "quantized":   # (its groups were queued behind each other on ONE stream before r05's second context)
+                for streams in (1, 0, 1, 0):
+                    nifs.debug_set("qgroup_streams", streams)
+                    call()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        call()
+                    dt = (time.perf_counter() - t0) / reps * 1e3
+                    key = "one_stream" if streams else "pipelined"
+                    res[key] = min(res.get(key, 1e9), dt)
+                nifs.debug_set("qgroup_streams", 0)
             got = call(keep=True)
             for i in (0, 7, 8, nq // 2, nq - 1):
                 assert got[i] == single(i), (name, nq, i)
             out["nq%d" % nq] = {"series_ms": round(res["series"], 3), "pipelined_ms": round(res["pipelined"], 3),
                                 "queries_per_s": round(nq / res["pipelined"] * 1e3), "was": round(nq / res["series"] * 1e3)}
+            if "one_stream" in res:
+                out["nq%d" % nq]["one_stream_ms"] = round(res["one_stream"], 3)
         print(json.dumps(out), flush=True)
         del ref
         torch.cuda.empty_cache()

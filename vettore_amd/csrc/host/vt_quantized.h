@@ -475,19 +475,39 @@ int quantized_batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, si
     // then runs while the device is busy with the groups around it.  (Not while profiling: the
     // stage timing keeps one pair of events per context.)
     if (groups.size() >= 2 && groups.size() <= 32 && !c.profiling && !vt::env::on(vt::env::NO_GROUP_PIPELINE)) {
-      const uint32_t nslots = (uint32_t)groups.size();
+      // (r05) ... on TWO contexts when a second one is to be had: even groups here, odd groups there, each stream its
+      // own slots.  A group is a sweep of the bits (0.20 ms for eight queries) and a tail of small kernels -- collect,
+      // list select, rerank of 8 x `candidates` rows, select: 0.07 ms -- that then runs beside the other stream's sweep
+      // instead of in front of it (VT_QGROUP_STREAMS=1: the one-stream form, A/B).
+      const uint32_t ng = (uint32_t)groups.size();
+      SpareCtxLease spare(vt::env::get(vt::env::QGROUP_STREAMS) != 1 ? ix : nullptr);
+      if (spare.c) VT_TRY(spare.c->bind());
+      Ctx *cx[2] = {&c, spare.c ? spare.c : &c};
+      const uint32_t lanes = spare.c ? 2u : 1u;
+      auto ctx_of = [&](uint32_t g) -> Ctx & { return *cx[g % lanes]; };
+      auto slot_of = [&](uint32_t g) { return g / lanes; };
+      auto slots_of = [&](uint32_t g) { return (ng - (g % lanes) + lanes - 1) / lanes; };  // groups on this group's context
+      auto drain = [&]() {
+        (void)hipStreamSynchronize(cx[0]->stream);
+        if (lanes == 2) (void)hipStreamSynchronize(cx[1]->stream);
+      };
       const uint32_t k2 = (uint32_t)std::min<size_t>(limit, std::min<size_t>(candidates, ix->n));
       std::vector<int> queued(groups.size(), VT_OK);
-      for (uint32_t g = 0; g < nslots; ++g) {
-        queued[g] = quantized_group(ix, c, queries, groups[g], candidates, limit, out, g, nslots, true);
+      for (uint32_t g = 0; g < ng; ++g) {
+        queued[g] = quantized_group(ix, ctx_of(g), queries, groups[g], candidates, limit, out, slot_of(g), slots_of(g), true);
         if (queued[g] != VT_OK && queued[g] != kRetryInternal) {
-          (void)hipStreamSynchronize(c.stream);
+          const std::string why = g_last_error;
+          drain();
+          (void)hipGetLastError();
+          g_last_error = why;
           return queued[g];
         }
       }
-      VT_HIP(hipStreamSynchronize(c.stream));
-      for (uint32_t g = 0; g < nslots; ++g) {
-        const int st = queued[g] == VT_OK ? quantized_group_finish(ix, c, quantized_group_slot(ix, g, nslots), groups[g], k2, out)
+      VT_HIP(hipStreamSynchronize(cx[0]->stream));
+      if (lanes == 2) VT_HIP(hipStreamSynchronize(cx[1]->stream));
+      for (uint32_t g = 0; g < ng; ++g) {
+        const int st = queued[g] == VT_OK ? quantized_group_finish(ix, ctx_of(g), quantized_group_slot(ix, slot_of(g), slots_of(g)),
+                                                                   groups[g], k2, out)
                                           : queued[g];
         VT_TRY(settle(groups[g], st));
       }

@@ -61,6 +61,7 @@ enum Parse {
   X(NO_MULTI_SCAN, "no_multi_scan", P_FLAG, 0)                                                                            \
   X(NO_SWEEP_GROUPS, "no_sweep_groups", P_FLAG, 0)                                                                        \
   X(NO_GROUP_PIPELINE, "no_group_pipeline", P_FLAG, 0)                                                                    \
+  X(QGROUP_STREAMS, "qgroup_streams", P_INT, 0)                                                                           \
   X(NO_PATTERN_BITS, "no_pattern_bits", P_FLAG, 0)                                                                        \
   X(NO_PATTERN_GROUPS, "no_pattern_groups", P_FLAG, 0)                                                                    \
   X(NO_QUANTIZED_GROUPS, "no_quantized_groups", P_FLAG, 0)                                                                \
