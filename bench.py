@@ -621,6 +621,22 @@ def side_legs(a, torch, nifs, L, device, main_ref):
                            note="end to end = upload + five launches + one wait around a distance pass that sits at the small-transfer "
                                 "floor (a bare read of the same 0.96 GB: 0.153 ms); fusing the chain was measured and lost to L2 "
                                 "write-back (DESIGN_APPENDIX A.12)")
+    # ... and as ONE quantized_search_batch call of 64: groups of eight share a sweep of the sign bits, the groups of
+    # the call are queued on two streams
+    outs64 = (C.c_void_p * 64)()
+    qb = np.ascontiguousarray(qs[:64])
+    times = []
+    for rep in range(6):
+        t1 = time.perf_counter()
+        assert L.vt_flat_quantized_search_batch(main_ref.handle, qb.ctypes.data_as(C.POINTER(C.c_float)), 64, a.dim, 100, a.limit, outs64) == 0
+        times.append(time.perf_counter() - t1)
+        got = [hits_of(L, C.c_void_p(outs64[j])) for j in range(64)]
+    for j in range(0, 64, 9):
+        h = C.c_void_p()
+        assert L.vt_flat_quantized_search(main_ref.handle, qb[j].ctypes.data_as(C.POINTER(C.c_float)), a.dim, 100, a.limit, C.byref(h)) == 0
+        assert hits_of(L, h) == got[j], "batched quantized search differs from the single call"
+    side["config5"]["batch64"] = {"ms": min(times[1:]) * 1e3, "queries_per_s": 64 / min(times[1:]), "kernel": "hamming_dist_multi_kernel",
+                                  "verified": True}
     # funnel_search, prefix 128
     qs = normalized_queries(110, a.dim, SEED_QUERY + 6)
     side["funnel"] = dict(leg(a, L, nifs, main_ref, "funnel", qs, 100, 10, stages=(min(a.dim, 128),), candidates=100),
