@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Single-row insert / upsert / delete rates through the C ABI (the reference's put/delete are
-host-only and take microseconds).  Diagnostic only."""
+"""What one mutation costs through the C ABI: vt_flat_insert of new ids one by one (flat.rs:60-74; Vettore.put/2 ->
+Index.Flat.put/2 -> one NIF call per record), upserts of existing ids, deletes, and vt_flat_insert_many in blocks of
+100 / 10 000 -- on an index that already holds ROWS rows (default 1 M x 768).  Diagnostic only."""
 import ctypes as C
 import json
 import os
@@ -11,72 +12,61 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch  # noqa: E402,F401
+import torch  # noqa: E402
 from vettore_amd import nifs, _lib  # noqa: E402
+from bench import build_shard, doc_ids  # noqa: E402
 
 L = _lib.load()
 
 
 def main():
-    d, n = 768, 20000
-    rng = np.random.default_rng(1)
-    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
-    ids = [b"doc-%08d" % i for i in range(n)]
-    ref = nifs.flat_new_cosine()
+    rows = int(os.environ.get("ROWS", 1_000_000))
+    dim = int(os.environ.get("DIM", 768))
+    x = build_shard(torch, torch.device("cuda", 0), rows, dim, 7)
+    ref = nifs._flat_new(2)
+    assert nifs.flat_load_device_matrix(ref, doc_ids(0, rows), x.data_ptr(), rows, dim) == ("ok", ())
+    del x
+    rng = np.random.default_rng(3)
+    n = 5000
+    vecs = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    vecs /= np.linalg.norm(vecs, axis=1, keepdims=True)
+    out = {"rows": rows, "dim": dim}
+    ids = [b"new-%07d" % i for i in range(n)]
+    # (the first append behind a bulk load doubles the id table, the id vector and the host rank column -- 80 ms for a
+    # million ids, once: not what a steady trickle pays)
+    warm = rng.uniform(-1, 1, dim).astype(np.float32)
+    assert L.vt_flat_insert(ref.handle, b"warm", 4, warm.ctypes.data_as(C.POINTER(C.c_float)), dim) == 0
     t0 = time.perf_counter()
     for i in range(n):
-        assert L.vt_flat_insert(ref.handle, ids[i], len(ids[i]), x[i].ctypes.data_as(C.POINTER(C.c_float)), d) == 0
-    t1 = time.perf_counter()
-    print(json.dumps({"op": "insert (sorted ids)", "per_call_us": round((t1 - t0) / n * 1e6, 2)}), flush=True)
+        assert L.vt_flat_insert(ref.handle, ids[i], len(ids[i]), vecs[i].ctypes.data_as(C.POINTER(C.c_float)), dim) == 0
+    out["insert_new_us"] = round((time.perf_counter() - t0) / n * 1e6, 2)
     t0 = time.perf_counter()
-    for i in range(0, n, 4):
-        assert L.vt_flat_insert(ref.handle, ids[i], len(ids[i]), x[(i + 1) % n].ctypes.data_as(C.POINTER(C.c_float)), d) == 0
-    t1 = time.perf_counter()
-    print(json.dumps({"op": "upsert", "per_call_us": round((t1 - t0) / (n // 4) * 1e6, 2)}), flush=True)
-    h = C.c_void_p()
+    for i in range(n):
+        assert L.vt_flat_insert(ref.handle, ids[i], len(ids[i]), vecs[n - 1 - i].ctypes.data_as(C.POINTER(C.c_float)), dim) == 0
+    out["upsert_us"] = round((time.perf_counter() - t0) / n * 1e6, 2)
+    q = vecs[0]
     t0 = time.perf_counter()
-    for i in range(200):
-        assert L.vt_flat_insert(ref.handle, b"zz-%d" % i, len(b"zz-%d" % i), x[i].ctypes.data_as(C.POINTER(C.c_float)), d) == 0
-        assert L.vt_flat_search(ref.handle, x[i].ctypes.data_as(C.POINTER(C.c_float)), d, 3, C.byref(h)) == 0
+    for i in range(200):   # a search between inserts: the id ranks are brought up to date lazily
+        assert L.vt_flat_insert(ref.handle, ids[i], len(ids[i]), vecs[i].ctypes.data_as(C.POINTER(C.c_float)), dim) == 0
+        h = C.c_void_p()
+        assert L.vt_flat_search(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), dim, 10, C.byref(h)) == 0
         L.vt_hits_free(h)
-    t1 = time.perf_counter()
-    print(json.dumps({"op": "insert + search alternating", "per_pair_us": round((t1 - t0) / 200 * 1e6, 2)}), flush=True)
+    out["insert_then_search_us"] = round((time.perf_counter() - t0) / 200 * 1e6, 1)
     t0 = time.perf_counter()
-    for i in range(0, n, 5):
+    for i in range(n):
         assert L.vt_flat_delete(ref.handle, ids[i], len(ids[i])) == 0
-    t1 = time.perf_counter()
-    print(json.dumps({"op": "delete", "per_call_us": round((t1 - t0) / (n // 5) * 1e6, 2)}), flush=True)
+    out["delete_us"] = round((time.perf_counter() - t0) / n * 1e6, 2)
+    for block in (100, 10_000):
+        m = 20_000
+        v = rng.uniform(-1, 1, (m, dim)).astype(np.float32)
+        bid = [b"blk%d-%07d" % (block, i) for i in range(m)]
+        t0 = time.perf_counter()
+        for lo in range(0, m, block):
+            res = nifs.flat_insert_many(ref, list(zip(bid[lo:lo + block], v[lo:lo + block])))
+            assert res[0] == "ok", res
+        out["insert_many_%d_us_per_row" % block] = round((time.perf_counter() - t0) / m * 1e6, 2)
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
     main()
-
-
-def big():
-    """unsorted inserts interleaved with searches on a 2M-row corpus (lazy rank path)"""
-    d, n = 768, 2_000_000
-    rng = np.random.default_rng(1)
-    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
-    ids = [b"doc-%d" % (i + 1) for i in range(n)]
-    ref = nifs.flat_new_cosine()
-    assert nifs.flat_load_matrix(ref, ids, x) == ("ok", ())
-    h = C.c_void_p()
-    q = x[5].ctypes.data_as(C.POINTER(C.c_float))
-    assert L.vt_flat_search(ref.handle, q, d, 10, C.byref(h)) == 0
-    L.vt_hits_free(h)
-    for label, env in (("lazy", None), ("eager", "1")):
-        if env:
-            nifs.debug_set("eager_ranks", int(env))
-        t0 = time.perf_counter()
-        for i in range(30):
-            id_ = b"new-%s-%d" % (label.encode(), i)
-            v = x[i + 100]
-            assert L.vt_flat_insert(ref.handle, id_, len(id_), v.ctypes.data_as(C.POINTER(C.c_float)), d) == 0
-            assert L.vt_flat_search(ref.handle, q, d, 10, C.byref(h)) == 0
-            L.vt_hits_free(h)
-        t1 = time.perf_counter()
-        print(json.dumps({"op": "2M rows: unsorted insert + search, " + label, "per_pair_ms": round((t1 - t0) / 30 * 1e3, 3)}), flush=True)
-
-
-if __name__ == "__main__" and os.environ.get("BIG"):
-    big()

@@ -809,7 +809,7 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     if (need > ix->rank_host.capacity()) ix->rank_host.reserve(std::max(need, 2 * ix->rank_host.capacity()));
   }
   *began = true;
-  const bool trace = count > 100000 && vt::env::on(vt::env::TRACE_INGEST);  // phase timings on stderr (tools/ingest_probe.py)
+  const bool trace = (count > 100000 && vt::env::on(vt::env::TRACE_INGEST)) || vt::env::get(vt::env::TRACE_INGEST) == 2;  // phase timings on stderr (tools/ingest_probe.py)
   const auto t_ids = std::chrono::steady_clock::now();
   {
     // the table's slots are fetched a few ids ahead of their use: a bulk load walks a table far
@@ -994,8 +994,18 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
       VT_TRY(ix->dRank.ensure(std::max<size_t>(ix->cap, ix->n)));
       from = 0;
     }
-    VT_HIP(hipMemcpyAsync(ix->dRank.p + from, ix->rank_host.data() + from, (size_t)(ix->n - from) * sizeof(uint32_t),
-                          hipMemcpyHostToDevice, c.stream));
+    if (ix->n - from <= 64) {
+      // a trickle of sorted appends (Vettore.put/2 record by record: one rank per call): through a pinned block of
+      // its own (rank_host is pageable: the runtime would stage the copy itself).  One appended row is 21 us, an
+      // upsert 15 (tools/insert_probe.py, VT_TRACE_INGEST=2): the row's copy, this one, one wait
+      VT_TRY(c.hRankStage.ensure(64));
+      std::memcpy(c.hRankStage.p, ix->rank_host.data() + from, (size_t)(ix->n - from) * sizeof(uint32_t));
+      VT_HIP(hipMemcpyAsync(ix->dRank.p + from, c.hRankStage.p, (size_t)(ix->n - from) * sizeof(uint32_t), hipMemcpyHostToDevice,
+                            c.stream));
+    } else {
+      VT_HIP(hipMemcpyAsync(ix->dRank.p + from, ix->rank_host.data() + from, (size_t)(ix->n - from) * sizeof(uint32_t),
+                            hipMemcpyHostToDevice, c.stream));
+    }
     pending = true;
   }
   if (pending) VT_HIP(hipStreamSynchronize(c.stream));
@@ -1003,8 +1013,12 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
   if (rank_now) VT_TRY(index_sync_ranks(ix, false));
   if (trace) {
     auto s_of = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
-    std::fprintf(stderr, "[vt ingest] %zu rows: id table %.3f s, rows to the device %.3f s, id ranks %.3f s\n", count,
-                 s_of(t_ids, t_rows), s_of(t_rows, t_rank), s_of(t_rank, std::chrono::steady_clock::now()));
+    if (count < 1000)  // (VT_TRACE_INGEST=2: a trickle, in microseconds)
+      std::fprintf(stderr, "[vt ingest] %zu rows: id table %.1f us, rows to the device %.1f us, id ranks %.1f us\n", count,
+                   1e6 * s_of(t_ids, t_rows), 1e6 * s_of(t_rows, t_rank), 1e6 * s_of(t_rank, std::chrono::steady_clock::now()));
+    else
+      std::fprintf(stderr, "[vt ingest] %zu rows: id table %.3f s, rows to the device %.3f s, id ranks %.3f s\n", count,
+                   s_of(t_ids, t_rows), s_of(t_rows, t_rank), s_of(t_rank, std::chrono::steady_clock::now()));
   }
   return VT_OK;
 }

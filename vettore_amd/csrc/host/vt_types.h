@@ -13,6 +13,7 @@ struct Ctx {
   int hamming_blocks_per_cu = 2;
   hipStream_t stream = nullptr;
   DevBuf<float> dQ;
+  PinnedBuf<uint32_t> hRankStage;  // the ranks of a few appended rows on their way to the device column (index_store_rows)
   // where the kernels of the current call read the query from (upload_query): c.dQ.p after a copy, or -- under
   // VT_DIRECT_QUERY=1, an A/B that measured no gain -- the pinned staging block itself through its host mapping
   const float *qsrc = nullptr;
