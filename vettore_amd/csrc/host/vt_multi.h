@@ -433,25 +433,27 @@ int batch_multi(vt_flat *h, const float *queries, size_t nq, size_t d, size_t li
   };
   std::vector<size_t> all(S);
   for (size_t s = 0; s < S; ++s) all[s] = s;
-  int rc = vt_host::run_on_workers_meanwhile(
-      h->workers, h->post_mu, all,
-      [&](size_t s) -> int {
-        Shard *ix = h->shards[s].get();
-        const unsigned need = NEED_STRICT_RANKS | NEED_NZBITS | (batch_uses_mfma(ix, nq, limit) ? NEED_NORMS : 0u);
-        if (shard_stale(ix, need, limit)) VT_TRY(shard_prepare(ix, need, limit));
-        // (this worker's lists go into the merge and nowhere else: they name their rows, the ids -- 2 560 string
-        // copies per 256 queries and shard -- are copied once, for the winners.  The flags are this shard's, and a
-        // shard's jobs run one at a time on its worker.)
-        ix->hits_by_row = true;
-        ix->batch_final = fin.get() + s * nq;
-        const int st = guarded([&]() -> int { return batch_ready(ix, ix->ctx, queries, nq, d, limit, per[s].data()); });
-        ix->hits_by_row = false;
-        ix->batch_final = nullptr;
-        if (st == VT_OK)
-          for (size_t i = 0; i < nq; ++i) fin[s * nq + i].store(1, std::memory_order_release);
-        return st;
-      },
-      merge_ready, [](int status, const std::string &error) { return fail(status, error); });
+  auto shard_job = [&](size_t s) -> int {
+    Shard *ix = h->shards[s].get();
+    const unsigned need = NEED_STRICT_RANKS | NEED_NZBITS | (batch_uses_mfma(ix, nq, limit) ? NEED_NORMS : 0u);
+    if (shard_stale(ix, need, limit)) VT_TRY(shard_prepare(ix, need, limit));
+    // (this worker's lists go into the merge and nowhere else: they name their rows, the ids -- 2 560 string
+    // copies per 256 queries and shard -- are copied once, for the winners.  The flags are this shard's, and a
+    // shard's jobs run one at a time on its worker.)
+    ix->hits_by_row = true;
+    ix->batch_final = fin.get() + s * nq;
+    const int st = guarded([&]() -> int { return batch_ready(ix, ix->ctx, queries, nq, d, limit, per[s].data()); });
+    ix->hits_by_row = false;
+    ix->batch_final = nullptr;
+    if (st == VT_OK)
+      for (size_t i = 0; i < nq; ++i) fin[s * nq + i].store(1, std::memory_order_release);
+    return st;
+  };
+  // (one group or less: nothing is settled before the shards end, and a caller that polls hears of that end up to a
+  // nap later than one that sleeps on the workers' condition variable)
+  int rc = nq > 256 ? vt_host::run_on_workers_meanwhile(h->workers, h->post_mu, all, shard_job, merge_ready,
+                                                        [](int status, const std::string &error) { return fail(status, error); })
+                    : on_all_shards(h, shard_job);
   if (rc == VT_OK) rc = merge_rc;
   // What is left when the last shard is through: on the workers, idle by now, each its share (a quarter of a
   // millisecond per 256 queries at eight shards on one thread); a handful, here.
