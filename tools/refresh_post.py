@@ -73,7 +73,11 @@ import subprocess
 with open('%s/%s_batch16_trace_excerpt.txt' % (out, RND), 'w') as f:
     f.write(subprocess.run(['python3', 'tools/trace_excerpt.py', glob.glob(out + '/batch16_trace/**/t_kernel_trace.csv', recursive=True)[0]],
                            capture_output=True, text=True).stdout)
+import shutil
+shutil.copyfile('%s/default.json' % out, '%s/%s_bench_default_under_rocprof.json' % (out, RND))
 for name in ('single', 'batch', 'batch_bf16', 'batch16', 'batch_k2b', 'quantized', 'funnel'):
+    # (the JSON line of every profiled leg under the name profiles/ keeps it by: <round>_bench_<leg>.json)
+    shutil.copyfile('%s/%s.json' % (out, name), '%s/%s_bench_%s.json' % (out, RND, name))
     print(open('%s/%s.json' % (out, name)).read().strip())
     for r in csv.DictReader(open('%s/%s/p_kernel_stats.csv' % (out, name))):
         if 'vt::' in r['Name']:
