@@ -352,6 +352,27 @@ static void check_workers_meanwhile(int callers, int per_caller) {
       }
     });
   for (auto &th : pool) th.join();
+  // a `meanwhile` that throws: the exception leaves only after every job has ended (they write into this frame)
+  {
+    std::vector<uint64_t> cell(S, 0);
+    std::vector<size_t> all{0, 1, 2};
+    bool caught = false;
+    try {
+      (void)vt_host::run_on_workers_meanwhile(
+          workers, post_mu, all,
+          [&](size_t s) -> int {
+            for (int i = 0; i < 2000; ++i) cell[s] += (uint64_t)i;
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            cell[s] += 1;
+            return 0;
+          },
+          []() -> bool { throw std::runtime_error("meanwhile failed"); }, [](int status, const std::string &) { return status; });
+    } catch (const std::runtime_error &) {
+      caught = true;
+    }
+    CHECK(caught);
+    for (size_t s = 0; s < S; ++s) CHECK(cell[s] == 1999000u + 1u);
+  }
   workers.clear();
   std::fprintf(stderr, "workers (caller merging meanwhile): %llu items taken while the jobs ran, %llu after\n",
                (unsigned long long)early.load(), (unsigned long long)late.load());

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <exception>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -135,13 +136,25 @@ int run_on_workers_meanwhile(std::vector<std::unique_ptr<Worker>> &workers, std:
     std::lock_guard<std::mutex> g(post_mu);
     for (size_t i = 0; i < which.size(); ++i) workers[which[i]]->post(&jobs[i]);
   }
+  // (the jobs point into this frame -- `jobs`, `fn` and whatever `fn` captured: nothing may unwind out of here before
+  // the last of them has ended.  An exception of `meanwhile` is kept and rethrown then.)
+  std::exception_ptr thrown;
   for (size_t next = 0; next < which.size();) {
     if (workers[which[next]]->finished(&jobs[next])) {
       ++next;
       continue;
     }
-    if (!meanwhile()) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    bool worked = false;
+    if (!thrown) {
+      try {
+        worked = meanwhile();
+      } catch (...) {
+        thrown = std::current_exception();
+      }
+    }
+    if (!worked) std::this_thread::sleep_for(std::chrono::microseconds(100));
   }
+  if (thrown) std::rethrow_exception(thrown);
   for (size_t i = 0; i < which.size(); ++i)
     if (jobs[i].status != 0) return on_error(jobs[i].status, jobs[i].error);
   return 0;

@@ -420,7 +420,8 @@ int batch_multi(vt_flat *h, const float *queries, size_t nq, size_t d, size_t li
       for (size_t s = 0; s < S && ready; ++s) ready = fin[s * nq + i].load(std::memory_order_acquire) != 0;
       if (!ready) continue;
       for (size_t s = 0; s < S; ++s) lists[s] = per[s][i];
-      merge_rc = merge_hit_lists(lists, limit, &out[i]);
+      // (nothing may unwind out of here: the workers' jobs point into this frame until the last of them has ended)
+      merge_rc = no_throw([&]() -> int { return merge_hit_lists(lists, limit, &out[i]); });
       if (merge_rc != VT_OK) return false;
       for (size_t s = 0; s < S; ++s) {  // (final means the shard is through with it)
         delete per[s][i];
