@@ -237,3 +237,39 @@ def test_quantized_batches_of_many_groups_on_two_streams(nifs, oracle_mod, vt_de
         order = sorted(range(n), key=lambda r: (int(ham[r]), ids[r]))[:cand]
         want = oracle_mod.vector_top_k([(ids[r], x[r]) for r in order], qs[i], metric, d, limit)
         assert singles[i] == bits(want), (metric, i)
+
+
+@pytest.mark.parametrize("metric", [2, 0, 5])
+def test_funnel_groups_take_their_thresholds_from_tile_maxima_on_larger_corpora(nifs, oracle_mod, vt_debug, metric):
+    """Round 5: where the sample is a fraction of the corpus (here 200 000 rows: every fourth 64-row tile) the sample pass
+    of a funnel group files the best score of each tile and the threshold is the rank-th largest maximum
+    (launch_sample_tau_groups) instead of a radix select over every sampled score (`funnel_dense_sample=1`: that form).
+    A threshold only decides which rows are LISTED: both forms must give every query its own funnel_search's hits and
+    the oracle's composition, bit for bit -- rows identical to the query included."""
+    n, d, nq = 200_000, 64, 21
+    x, ids = make_corpus(n, d, 7300 + metric, metric == 2, oracle_mod, tie_block=40)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(17 + metric)
+    qs = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+    qs[0], qs[12] = x[n // 2], x[77]
+    if metric == 2:
+        qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+    stages, cand, limit = [24], 10, 5
+    nifs.flat_set_profiling(g.ref, True)
+    nifs.flat_get_profile(g.ref, reset=True)
+    got = unwrap(nifs.flat_funnel_search_batch(g.ref, qs, stages, cand, limit))
+    prof = nifs.flat_get_profile(g.ref, reset=True)
+    nifs.flat_set_profiling(g.ref, False)
+    assert prof["prefix_queries"] >= nq - 1 - nq // 8 - 2, prof      # the sweeps took them (a threshold may miss now and then)
+    singles = [bits(unwrap(nifs.flat_funnel_search(g.ref, q, stages, cand, limit))) for q in qs]
+    assert [bits(h) for h in got] == singles
+    vt_debug.set("funnel_dense_sample", 1)
+    dense = unwrap(nifs.flat_funnel_search_batch(g.ref, qs, stages, cand, limit))
+    vt_debug.set("funnel_dense_sample", 0)
+    assert [bits(h) for h in dense] == singles
+    rows = [(ids[i], x[i]) for i in range(n)]
+    by_id = dict(rows)
+    for i in (0, 12):
+        cur = [(j, by_id[j]) for j, _ in oracle_mod.vector_top_k(rows, qs[i], metric, stages[0], cand)]
+        assert singles[i] == bits(oracle_mod.vector_top_k(cur, qs[i], metric, d, limit)), (metric, i)

@@ -127,6 +127,13 @@ int funnel_group_queue(Shard *ix, Ctx &c, FunnelGroupRun &run, const float *quer
   // at rank >= 6 a list shorter than `candidates` is a 1e-4 event; it costs a single search)
   uint32_t rank = (uint32_t)std::ceil(6.0 * k1 * std::min(1.0, (double)sample_rows / (double)n));
   rank = std::max<uint32_t>(6, std::min<uint32_t>(rank, std::min<uint32_t>(sample_rows, n)));
+  // (r05) the sample pass files only the best score of each of its 64-row tiles and the threshold is the rank-th
+  // largest of those maxima (launch_sample_tau_groups, the K2s sample's scheme: every maximum is one of the sample's
+  // scores, so the threshold is at most the dense one -- a few rows more pass).  The radix select over 8 x 65 536
+  // scores took 41 us alone and 0.4-0.7 ms beside the other context's sweep (a string of dependent trips to a
+  // saturated memory: profiles/r05_funnel64_trace_excerpt.txt); this one reads 4 KB per query.  Where the rank is not
+  // small against the number of tiles (small corpora: the sample is most of the rows) the dense form stays.
+  const bool by_maxima = (uint64_t)rank * 16 <= stiles && stiles <= 2048 && !vt::env::on(vt::env::FUNNEL_DENSE_SAMPLE);
   // one upload: full queries [nq][ld] (f32), their prefixes as f64 [8][ldq] (what stage 1 reads, through
   // the scalar cache; ld and ldq are multiples of 64, so the block stays 32-byte aligned), list lengths
   const bool cosine = ix->metric == VT_COSINE;
@@ -207,12 +214,15 @@ int funnel_group_queue(Shard *ix, Ctx &c, FunnelGroupRun &run, const float *quer
   // pass 0: the sample's scores -> one threshold per query
   a.sample = pa.sample = c.dBSample.p;
   a.sample_stride = pa.sample_stride = sstride;
-  a.sample_rows = pa.sample_rows = sample_rows;
+  a.sample_rows = pa.sample_rows = by_maxima ? stiles : sample_rows;
+  a.sample_maxima = pa.sample_maxima = by_maxima ? 1u : 0u;
   if (cosine) VT_HIP(vt::launch_cosine_scan_multi(a, c.grid_for(stiles, lds), c.stream));
   else VT_HIP(vt::launch_prefix_multi(pa, c.grid_for(stiles, lds, vt::prefix_multi_blocks_per_cu()), c.stream));
-  VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, vt::kCosineMultiMax, nq, rank, c.dBTau.p, c.stream));
+  if (by_maxima) VT_HIP(vt::launch_sample_tau_groups(c.dBSample.p, stiles, vt::kCosineMultiMax, nq, rank, c.dBTau.p, c.stream));
+  else VT_HIP(vt::launch_sample_tau(c.dBSample.p, sample_rows, vt::kCosineMultiMax, nq, rank, c.dBTau.p, c.stream));
   // pass 1: every row's prefix once; (query, row) pairs at or above the thresholds into the lists
   a.sample = pa.sample = nullptr;
+  a.sample_maxima = pa.sample_maxima = 0;
   a.tau = pa.tau = c.dBTau.p;
   a.cand_keys = pa.cand_keys = c.dPartKeys.p;
   a.cand_pay = pa.cand_pay = c.dPartPay.p;

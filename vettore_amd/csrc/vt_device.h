@@ -463,6 +463,9 @@ struct CosineScanMultiArgs {
   uint32_t n, d, nq;
   float *sample;             // dense mode when set
   uint32_t sample_stride, sample_rows;
+  // (r05) dense mode files only the BEST score of every sampled 64-row tile: sample[q * sample_rows + tile], with
+  // sample_rows = the launch's tiles; the threshold then comes from launch_sample_tau_groups (the K2s sample's scheme)
+  uint32_t sample_maxima;
   const float *tau;          // [nq] sweep mode
   uint64_t *cand_keys;       // [nq][cand_cap]
   Payload *cand_pay;
@@ -493,6 +496,7 @@ struct PrefixMultiArgs {
   int metric, order;         // metrics of the dot / L2 / L1 / Linf families (not cosine, not the pattern metrics)
   float *sample;
   uint32_t sample_stride, sample_rows;
+  uint32_t sample_maxima;    // as in CosineScanMultiArgs
   const float *tau;
   uint64_t *cand_keys;       // [nq][cand_cap]
   Payload *cand_pay;

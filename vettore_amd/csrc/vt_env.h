@@ -66,6 +66,7 @@ enum Parse {
   X(NO_PATTERN_GROUPS, "no_pattern_groups", P_FLAG, 0)                                                                    \
   X(NO_QUANTIZED_GROUPS, "no_quantized_groups", P_FLAG, 0)                                                                \
   X(NO_FUNNEL_GROUPS, "no_funnel_groups", P_FLAG, 0)                                                                      \
+  X(FUNNEL_DENSE_SAMPLE, "funnel_dense_sample", P_FLAG, 0)                                                                \
   X(NO_THRESHOLD_SELECT, "no_threshold_select", P_FLAG, 0)                                                                \
   X(HAMMING_LISTS, "hamming_lists", P_FLAG, 0)                                                                            \
   X(HYBRID_CHAIN, "hybrid_chain", P_FLAG, 0)                                                                              \

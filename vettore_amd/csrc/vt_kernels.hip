@@ -2037,6 +2037,13 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_multi_kerne
         }
       }
       if (dense) {
+        if (a.sample_maxima) {  // the tile's best score, one value per query and tile
+          float m = valid ? raw : -INFINITY;
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+          if (lane == 0 && ti < a.sample_rows) a.sample[(size_t)q * a.sample_rows + ti] = m;
+          continue;
+        }
         const uint32_t i = ti * kCsRows + lane;  // position in the sample
         if (i < a.sample_rows) a.sample[(size_t)q * a.sample_rows + i] = valid ? raw : -INFINITY;
         continue;

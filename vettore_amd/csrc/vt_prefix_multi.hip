@@ -206,6 +206,13 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
       const float rank = metric == M_IP ? -raw : raw;
       const float good = -rank;  // larger = better: the order the sample's threshold is taken in
       if (dense) {
+        if (a.sample_maxima) {  // the tile's best score, one value per query and tile
+          float m = valid ? good : -INFINITY;
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+          if (lane == 0 && ti < a.sample_rows) a.sample[(size_t)q * a.sample_rows + ti] = m;
+          continue;
+        }
         const uint32_t i = ti * kPmRows + lane;  // position in the sample
         if (i < a.sample_rows) a.sample[(size_t)q * a.sample_rows + i] = valid ? good : -INFINITY;
         continue;
