@@ -20,6 +20,8 @@ if [ "${SOAKS:-1}" != "0" ]; then
     echo "# $(date -u +%Y-%m-%dT%H:%MZ) soaks on $(git -C $R rev-parse --short HEAD 2>/dev/null || echo 'the tree as sent'), SOAK_SCALE=$S"
     echo "# soak_groups (grouped paths: funnel batches under nine metrics, plain batches as K1p sweeps)"
     SECONDS=$(secs 240) python3 tools/soak_groups.py 2>&1 | tail -1
+    echo "# soak_groups on corpora of 150 000-400 000 rows (the groups' thresholds from tile maxima, as on a 10 M-row corpus)"
+    ROWS_MIN=150000 ROWS_MAX=400000 SECONDS=$(secs 150) python3 tools/soak_groups.py 2>&1 | tail -1
     echo "# soak_all (every search entry point, plain handle)"
     SECONDS=$(secs 200) python3 tools/soak_all.py 2>&1 | tail -1
     echo "# soak_all SHARDS=3"

@@ -31,7 +31,9 @@ COUNTS = {"funnel_batches": 0, "plain_batches": 0, "queries": 0, "oracle_checks"
 
 def run(seed, metric):
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(17_000, 40_000))
+    # (ROWS_MIN / ROWS_MAX: corpora of a few hundred thousand rows put the groups' sample on every n-th tile and take
+    # their thresholds from tile maxima -- the form a 10 M-row corpus runs)
+    n = int(rng.integers(int(os.environ.get("ROWS_MIN", 17_000)), int(os.environ.get("ROWS_MAX", 40_000))))
     d = int(rng.choice([24, 40, 64, 100, 130, 200, 260]))
     x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
     if rng.integers(0, 2):
