@@ -83,6 +83,17 @@ def main():
                 key = "series" if off else "pipelined"
                 res[key] = min(res.get(key, 1e9), dt * 1e3)
             nifs.debug_set("no_group_pipeline", 0)
+            if funnel:   # (r03's threshold and list select -- radix over every sampled score, one block per list -- against r05's)
+                for old in (1, 0, 1, 0):
+                    nifs.debug_set("funnel_dense_sample", old)
+                    call()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        call()
+                    dt = (time.perf_counter() - t0) / reps * 1e3
+                    key = "dense_sample_ms" if old else "pipelined"
+                    res[key] = min(res.get(key, 1e9), dt)
+                nifs.debug_set("funnel_dense_sample", 0)
             if kind == "quantized":   # (its groups were queued behind each other on ONE stream before r05's second context)
                 for streams in (1, 0, 1, 0):
                     nifs.debug_set("qgroup_streams", streams)
@@ -99,6 +110,8 @@ def main():
                 assert got[i] == single(i), (name, nq, i)
             out["nq%d" % nq] = {"series_ms": round(res["series"], 3), "pipelined_ms": round(res["pipelined"], 3),
                                 "queries_per_s": round(nq / res["pipelined"] * 1e3), "was": round(nq / res["series"] * 1e3)}
+            if "dense_sample_ms" in res:
+                out["nq%d" % nq]["dense_sample_ms"] = round(res["dense_sample_ms"], 3)
             if "one_stream" in res:
                 out["nq%d" % nq]["one_stream_ms"] = round(res["one_stream"], 3)
         print(json.dumps(out), flush=True)

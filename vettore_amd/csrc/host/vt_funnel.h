@@ -234,7 +234,7 @@ int funnel_group_queue(Shard *ix, Ctx &c, FunnelGroupRun &run, const float *quer
   if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
   VT_HIP(hipMemcpyAsync(hListCount, c.dBCount.p, vt::kCosineMultiMax * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(vt::launch_select_lists(c.dPartKeys.p, c.dPartPay.p, nq, kListCap, c.dBCount.p, k1, c.dStageB.p,
-                                 (uint32_t)sizeof(ResultBlock), c.stream));
+                                 (uint32_t)sizeof(ResultBlock), c.stream, !vt::env::on(vt::env::FUNNEL_DENSE_SAMPLE)));
   // what the acceptance test below looks at: the thresholds and the key of every list's last kept row
   // (copied out here: later stages reuse the blocks)
   VT_HIP(hipMemcpyAsync(hTau, c.dBTau.p, vt::kCosineMultiMax * sizeof(float), hipMemcpyDeviceToHost, c.stream));

@@ -270,7 +270,7 @@ hipError_t launch_hamming_collect_multi(const HammingCollectArgs &a, uint32_t bl
 // K3 for nq lists whose lengths were decided on the device: list y = keys / pay + y * m_stride,
 // m_dev[y] entries; winners (sorted) to the block at out + y * out_stride bytes.
 hipError_t launch_select_lists(const uint64_t *keys, const Payload *pay, uint32_t nq, uint32_t m_stride, const uint32_t *m_dev,
-                               uint32_t k, void *out, uint32_t out_stride, hipStream_t s);
+                               uint32_t k, void *out, uint32_t out_stride, hipStream_t s, bool spread = false);
 size_t hamming_hist_lds_bytes(uint32_t d);
 hipError_t launch_hamming_dist(const HammingHistArgs &a, uint32_t blocks, hipStream_t s);
 hipError_t launch_hamming_collect(const HammingCollectArgs &a, uint32_t blocks, hipStream_t s);

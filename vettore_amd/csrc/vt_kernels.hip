@@ -81,11 +81,13 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
                                                            ResultBlock *out, uint32_t slice,
                                                            uint64_t *__restrict__ part_keys,
                                                            Payload *__restrict__ part_pay,
-                                                           const uint32_t *__restrict__ m_dev, uint32_t out_stride) {
+                                                           const uint32_t *__restrict__ m_dev, uint32_t out_stride,
+                                                           uint32_t skip_upto = 0) {
   extern __shared__ __align__(16) unsigned char smem[];
   const uint32_t m_stride = m;
   // list length decided on the device (hamming_collect_kernel): one count per query
   if (m_dev) m = m_dev[blockIdx.y] < m ? m_dev[blockIdx.y] : m;
+  if (m_dev && skip_upto && m <= skip_upto) return;  // (select_lists_spread_kernel, launched beside this one, takes those)
   if (gridDim.y > 1) {
     // one list of up to m keys per query (grid.y = queries): query y's winners go to the block
     // `out_stride` bytes after query y - 1's (header + k entries when packed tightly)
@@ -369,6 +371,60 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const uint64_t *__res
     // and reaches the host with the last select of the chain
     out->status = dev_status ? *dev_status : 0;
     if (dev_status) *dev_status = 0;
+  }
+}
+
+// The k best of each query's list, for lists of up to kSpreadKeys keys, on kSpreadBlocks blocks per list (r05).  A key's
+// place among the winners is the number of smaller keys -- computable for every key on its own -- so each block stages the
+// whole list in LDS (one sweep of <= 16 KB) and places ITS 128 keys; nothing is exchanged between blocks.  Against the
+// one-block forms above: counting on one block is m x m / 64 wave-iterations on ONE CU (60 us at 1 000 keys), the radix
+// form four or five DEPENDENT sweeps of the keys in global memory -- 47 us alone, 0.6 ms beside another context's sweep
+// of the corpus, which is where a funnel group's list select runs (profiles/r05_funnel64_trace_excerpt.txt).  Longer
+// lists return at once: select_topk_kernel is launched beside this kernel with skip_upto = kSpreadKeys.
+constexpr uint32_t kSpreadKeys = 2048, kSpreadBlocks = 16, kSpreadThreads = kSpreadKeys / kSpreadBlocks;
+__global__ __launch_bounds__(kSpreadThreads) void select_lists_spread_kernel(const uint64_t *__restrict__ keys,
+                                                                            const Payload *__restrict__ pay, uint32_t m_stride,
+                                                                            const uint32_t *__restrict__ m_dev, uint32_t k,
+                                                                            ResultBlock *out, uint32_t out_stride) {
+  __shared__ uint64_t sk[kSpreadKeys];
+  __shared__ uint32_t s_live;
+  const uint32_t y = blockIdx.y;
+  const uint32_t m = m_dev[y] < m_stride ? m_dev[y] : m_stride;
+  if (m > kSpreadKeys) return;
+  keys += (size_t)y * m_stride;
+  pay += (size_t)y * m_stride;
+  out = reinterpret_cast<ResultBlock *>(reinterpret_cast<unsigned char *>(out) + (size_t)y * out_stride);
+  const uint32_t t = threadIdx.x;
+  if (t == 0) s_live = 0;
+  for (uint32_t i = t; i < m; i += kSpreadThreads) sk[i] = keys[i];
+  __syncthreads();
+  if (blockIdx.x == 0) {  // the list's header
+    uint32_t live = 0;
+    for (uint32_t i = t; i < m; i += kSpreadThreads) live += sk[i] != kEmptyKey ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) live += __shfl_xor(live, o, kWave);
+    if ((t & (kWave - 1)) == 0) atomicAdd(&s_live, live);
+    __syncthreads();
+    if (t == 0) {
+      out->count = s_live < k ? s_live : k;
+      out->status = 0;  // (an intermediate stage: the overflow flag reaches the host with the chain's last select)
+    }
+  }
+  const uint32_t i = blockIdx.x * kSpreadThreads + t;
+  const uint64_t key = i < m ? sk[i] : kEmptyKey;
+  if (__ballot(key != kEmptyKey) == 0) return;  // (wave-uniform: a wave without keys does not walk the list)
+  uint32_t pos = 0;
+  for (uint32_t x = 0; x < m; ++x) {
+    const uint64_t kx = sk[x];
+    pos += (kx < key || (kx == key && x < i)) ? 1u : 0u;
+  }
+  if (key != kEmptyKey && pos < k) {
+    const Payload p = pay[i];
+    Entry e;
+    e.key = key;
+    e.row = p.row;
+    e.raw = p.raw;
+    out->e[pos] = e;
   }
 }
 
@@ -1791,15 +1847,21 @@ hipError_t launch_hamming_dist_multi(const HammingMultiArgs &a, uint32_t blocks,
 }
 
 hipError_t launch_select_lists(const uint64_t *keys, const Payload *pay, uint32_t nq, uint32_t m_stride, const uint32_t *m_dev,
-                               uint32_t k, void *out, uint32_t out_stride, hipStream_t s) {
+                               uint32_t k, void *out, uint32_t out_stride, hipStream_t s, bool spread) {
   if (k == 0 || k > (uint32_t)kMaxFusedK || nq == 0 || nq > 65535 || !m_dev || out_stride < 16 + k * sizeof(Entry) || out_stride % 16)
     return hipErrorInvalidValue;
   const size_t lds = ((size_t)k + kSelCand) * 12;
   hipError_t e = allow_lds(select_topk_kernel, lds);
   if (e != hipSuccess) return e;
+  // `spread` (lists of several hundred to a few thousand keys, a funnel group's): lists of up to kSpreadKeys keys go to
+  // select_lists_spread_kernel, sixteen blocks each; the one-block kernel beside it takes the longer ones only
+  const uint32_t skip = spread && m_stride > 1024 ? kSpreadKeys : 0u;
+  if (skip)
+    hipLaunchKernelGGL(select_lists_spread_kernel, dim3(kSpreadBlocks, nq), dim3(kSpreadThreads), 0, s, keys, pay, m_stride, m_dev, k,
+                       static_cast<ResultBlock *>(out), out_stride);
   // (grid.y >= 2 is what makes the kernel index its lists by query: a batch of one goes through launch_select)
   hipLaunchKernelGGL(select_topk_kernel, dim3(1, nq), dim3(1024), lds, s, keys, pay, m_stride, k, 0ull, 0, nullptr,
-                     static_cast<ResultBlock *>(out), 0u, nullptr, nullptr, m_dev, out_stride);
+                     static_cast<ResultBlock *>(out), 0u, nullptr, nullptr, m_dev, out_stride, skip);
   return hipGetLastError();
 }
 
