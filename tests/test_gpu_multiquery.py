@@ -273,3 +273,34 @@ def test_funnel_groups_take_their_thresholds_from_tile_maxima_on_larger_corpora(
     for i in (0, 12):
         cur = [(j, by_id[j]) for j, _ in oracle_mod.vector_top_k(rows, qs[i], metric, stages[0], cand)]
         assert singles[i] == bits(oracle_mod.vector_top_k(cur, qs[i], metric, d, limit)), (metric, i)
+
+
+@pytest.mark.parametrize("metric", [2, 0])
+def test_funnel_group_lists_of_every_length_are_cut_alike(nifs, oracle_mod, metric):
+    """The list select of a funnel group (round 5): lists of up to 2 048 keys are cut on sixteen blocks per list
+    (select_lists_spread_kernel), longer ones by the one-block radix form beside it, lists beyond the cap send their
+    query down the single path.  Three thousand rows identical to the query put 3 000 equal scores into its list (only
+    the id ranks order them), six thousand two hundred overflow nothing but fill most of the cap; their neighbours in the
+    same group have short lists.  Every query: its own funnel_search's hits and the oracle's."""
+    n, d = 40_000, 72
+    x, ids = make_corpus(n, d, 8800 + metric, metric == 2, oracle_mod)
+    x[5000:8000] = x[5000]          # 3 000 equal rows
+    x[20000:26200] = x[20000]       # 6 200 equal rows
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    rng = np.random.default_rng(3 + metric)
+    qs = rng.uniform(-1, 1, (13, d)).astype(np.float32)
+    if metric == 2:
+        qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+    qs[1], qs[6], qs[9] = x[5000], x[20000], x[5001]
+    stages, cand, limit = [32], 70, 12
+    got = unwrap(nifs.flat_funnel_search_batch(g.ref, qs, stages, cand, limit))
+    rows = [(ids[i], x[i]) for i in range(n)]
+    by_id = dict(rows)
+    for i in range(13):
+        assert bits(got[i]) == bits(unwrap(nifs.flat_funnel_search(g.ref, qs[i], stages, cand, limit))), (metric, i)
+    for i in (1, 6, 9, 12):
+        cur = [(j, by_id[j]) for j, _ in oracle_mod.vector_top_k(rows, qs[i], metric, stages[0], cand)]
+        assert bits(got[i]) == bits(oracle_mod.vector_top_k(cur, qs[i], metric, d, limit)), (metric, i)
+    # the duplicates come back in id order, the first of them first
+    assert [h[0] for h in got[1]] == sorted(ids[5000:8000])[:limit]
