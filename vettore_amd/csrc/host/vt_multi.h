@@ -414,11 +414,18 @@ int batch_multi(vt_flat *h, const float *queries, size_t nq, size_t d, size_t li
     if (merge_rc != VT_OK) return false;
     bool any = false;
     while (first_open < nq && merged[first_open]) ++first_open;
-    for (size_t i = first_open; i < nq; ++i) {
+    // (lists settle group by group, in order, with a hole here and there -- a query the matrix cores could not certify,
+    // settled when its shard ends: two groups' worth of unsettled queries in a row and the rest is not looked at this
+    // time round.  A poll of a million-query call is not a walk over a million flags per shard.)
+    size_t unsettled = 0;
+    for (size_t i = first_open; i < nq && unsettled < 512; ++i) {
       if (merged[i]) continue;
       bool ready = true;
       for (size_t s = 0; s < S && ready; ++s) ready = fin[s * nq + i].load(std::memory_order_acquire) != 0;
-      if (!ready) continue;
+      if (!ready) {
+        unsettled += 1;
+        continue;
+      }
       for (size_t s = 0; s < S; ++s) lists[s] = per[s][i];
       // (nothing may unwind out of here: the workers' jobs point into this frame until the last of them has ended)
       merge_rc = no_throw([&]() -> int { return merge_hit_lists(lists, limit, &out[i]); });
