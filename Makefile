@@ -19,7 +19,7 @@ DEVSRC  := vt_kernels vt_batch vt_batch_bf16 vt_batch_shadow vt_scan_dot vt_scan
 DEVOBJ  := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(DEVSRC)))
 DEVHDR  := $(CSRC)/vt_device.h $(CSRC)/vt_common.cuh $(CSRC)/vt_scan.cuh $(CSRC)/vt_env.h
 
-all: $(LIBDIR)/libvettore_hip.so $(LIBDIR)/libvettore_hip_hooks.so $(LIBDIR)/libvt_callers.so oracle
+all: $(LIBDIR)/libvettore_hip.so $(LIBDIR)/libvettore_hip_hooks.so $(LIBDIR)/libvt_callers.so $(LIBDIR)/libvt_callers_hooks.so oracle
 
 $(LIBDIR)/%.o: $(CSRC)/%.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
@@ -81,6 +81,10 @@ mqdbg: $(LIBDIR)/libvettore_hip_mqdbg.so
 # bench.py's native caller threads (tools/callers_native.cpp): measurement infrastructure, not product
 $(LIBDIR)/libvt_callers.so: tools/callers_native.cpp include/vettore_flat.h $(LIBDIR)/libvettore_hip.so
 	g++ -O2 -std=c++17 -fPIC -shared tools/callers_native.cpp -Iinclude -L$(LIBDIR) -lvettore_hip -lpthread -Wl,-rpath,'$$ORIGIN' -o $@
+
+# the same callers bound to the hooks build (tests that force callers to meet: vt_callers_meet with `hold`)
+$(LIBDIR)/libvt_callers_hooks.so: tools/callers_native.cpp include/vettore_flat.h $(LIBDIR)/libvettore_hip_hooks.so
+	g++ -O2 -std=c++17 -fPIC -shared tools/callers_native.cpp -Iinclude -L$(LIBDIR) -lvettore_hip_hooks -lpthread -Wl,-rpath,'$$ORIGIN' -o $@
 
 oracle:
 	$(MAKE) -C oracle -s

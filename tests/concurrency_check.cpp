@@ -52,6 +52,7 @@ struct FakeHandle {
   vt_host::Coalescer co;
   std::atomic<unsigned> slots{1};
   std::atomic<bool> ranks_lazy{false};     // the writer's doing: batches must disband
+  std::atomic<size_t> hold{0};             // the test hook: an idle handle's first caller waits for this many
   std::atomic<uint64_t> alone{0}, batched{0}, batches{0}, failed_batches{0}, thrown{0};
 };
 
@@ -118,6 +119,7 @@ struct FakeOps {
   }
   static bool must_disband(FakeHandle *h, int, size_t) { return h->ranks_lazy.load(); }
   static size_t capacity(FakeHandle *, int kind) { return kind ? 8 : 256; }
+  static size_t hold_until(FakeHandle *h) { return h->hold.load(); }
   static void run(FakeHandle *h, std::vector<vt_host::Waiting *> &members) { vt_host::run_coalesced_t<FakeHandle, FakeOps>(h, members); }
   static void drop_hits(vt_hits *hits) { free_hits(hits); }
   static void set_last_error(const std::string &msg) { t_last_error = msg; }
@@ -177,6 +179,54 @@ static void check_coalescer(int threads, int per_thread) {
                (unsigned long long)ok.load(), (unsigned long long)h.batched.load(), (unsigned long long)h.batches.load(),
                (unsigned long long)h.alone.load(), (unsigned long long)bad.load(), (unsigned long long)oom.load(),
                (unsigned long long)h.failed_batches.load());
+}
+
+// the test hook (Ops::hold_until): `threads` callers that leave a barrier together must travel as ONE batch, round after
+// round -- what tests/test_gpu_coalesce.py relies on when it asserts which kernels ran
+static void check_forced_meeting(int threads, int rounds) {
+  FakeHandle h;
+  h.hold = (size_t)threads;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0, generation = 0;
+  auto barrier = [&] {
+    std::unique_lock<std::mutex> g(mu);
+    const int gen = generation;
+    if (++arrived == threads) {
+      arrived = 0;
+      generation += 1;
+      cv.notify_all();
+    } else {
+      cv.wait(g, [&] { return generation != gen; });
+    }
+  };
+  std::atomic<uint64_t> ok{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t)
+    pool.emplace_back([&, t] {
+      for (int r = 0; r < rounds; ++r) {
+        std::vector<float> q(16);
+        for (size_t i = 0; i < q.size(); ++i) q[i] = (float)(1 + t * 131 + r * 17 + (int)i);   // (no injected roll hits these)
+        barrier();
+        vt_hits *out = nullptr;
+        const int st = vt_host::coalesced_search_t<FakeHandle, FakeOps>(&h, q.data(), q.size(), 5, &out, 0, 0);
+        if (st == 0) {
+          CHECK(out != nullptr && out->tag == answer(q.data(), q.size(), 5));
+          free_hits(out);
+          ok += 1;
+        } else {
+          CHECK(st == 4 || st == FakeOps::kOutOfMemory || out != nullptr);
+        }
+      }
+    });
+  for (auto &th : pool) th.join();
+  {
+    std::lock_guard<std::mutex> g(h.co.mu);
+    CHECK(h.co.waiting.empty() && h.co.active == 0);
+    // every round: one batch of everybody (a batch the stub fails or throws still counts as one that met)
+    CHECK(h.co.batches == (uint64_t)rounds && h.co.batched_queries == (uint64_t)rounds * threads);
+  }
+  std::fprintf(stderr, "forced meeting: %d rounds of %d callers, %llu batches\n", rounds, threads, (unsigned long long)h.co.batches);
 }
 
 // ------------------------------------------------------------------ 2. lease
@@ -457,6 +507,7 @@ int main(int argc, char **argv) {
   const int scale = argc > 1 ? std::atoi(argv[1]) : 1;
   check_settings(16, 20000 * scale);
   check_coalescer(64, 1600 * scale);  // 10^5 operations at scale 1
+  check_forced_meeting(24, 40 * scale);
   check_lease(48, 4000 * scale);
   check_spare_lease(48, 2000 * scale);
   check_workers(8, 1500 * scale);

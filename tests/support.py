@@ -119,3 +119,32 @@ def rerun_with_hooks_library(request):
                          cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     return True
+
+
+def callers_meet(ref, queries, limit, kinds, params=None, candidates=None, rounds=4, hold=True):
+    """Native threads that leave a barrier together, `rounds` times (tools/callers_native.cpp: vt_callers_meet), one
+    thread per entry of `kinds` (0: flat_search, 1: quantized_search, 2: funnel_search over one stage).  With the hooks
+    build loaded (rerun_with_hooks_library) and `hold`, the handle's first caller of a round keeps its slot until all the
+    others have queued: who travels with whom is then a fact.  Every answer is compared inside with the same call made
+    alone.  Returns (mismatches, failures)."""
+    import ctypes as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hooks = "hooks" in os.path.basename(os.environ.get("VETTORE_HIP_LIB", ""))
+    assert hooks or not hold, "callers are only held in libvettore_hip_hooks.so"
+    path = os.path.join(root, "vettore_amd", "lib", "libvt_callers_hooks.so" if hooks else "libvt_callers.so")
+    assert os.path.exists(path), "build it with `make` (%s)" % os.path.basename(path)
+    lib = C.CDLL(path)
+    lib.vt_callers_meet.restype = C.c_int
+    lib.vt_callers_meet.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_int),
+                                    C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    t = len(kinds)
+    kinds_a = (C.c_int * t)(*kinds)
+    params_a = (C.c_size_t * t)(*(params or [0] * t))
+    cands_a = (C.c_size_t * t)(*(candidates or [0] * t))
+    wrong, failed = C.c_ulonglong(), C.c_ulonglong()
+    rc = lib.vt_callers_meet(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), q.shape[0], q.shape[1], limit, kinds_a,
+                             params_a, cands_a, t, rounds, 1 if hold else 0, C.byref(wrong), C.byref(failed))
+    assert rc == 0, "vt_callers_meet: %d" % rc
+    return int(wrong.value), int(failed.value)

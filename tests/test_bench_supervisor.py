@@ -88,6 +88,52 @@ def test_ranks_under_a_launcher_take_the_second_step_together():
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
 
 
+def _driver_command(nproc, port, extra=()):
+    """The driver's own launch line (the task's contract), at the width of the node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), BENCH, "--gpus", str(nproc), "--steps", "20", "--warmup", "5"] + list(extra)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_eight_ranks_as_the_driver_launches_them_meet_and_print_one_line():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8 --steps 20 --warmup 5` on a CPU
+    box: eight supervisors, eight children that really meet (the stand-in initialises a process group over the environment
+    the supervisor hands down -- gloo here, RCCL on the node -- and all_gathers the ranks), ONE line from rank 0 that
+    carries the width: n_gpus 8, rccl_ranks 8, the scaling the command asked for, the driver's steps and warmup.
+    (The eight-GPU wire itself has never been available to this build: DESIGN 6.)"""
+    env = dict(os.environ, VT_BENCH_CHILD=FAKE, FAKE_CHILD="meet", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "FAKE_FAIL_RANKS"):
+        env.pop(k, None)
+    r = subprocess.run(_driver_command(8, _free_port()), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = last_json(r.stdout)
+    assert (line["n_gpus"], line["gpus_argument"], line["rccl_ranks"], line["met"]) == (8, 8, 8, list(range(8))), line
+    assert (line["scaling"], line["steps"], line["warmup"]) == ("strong", 20, 5), line
+    assert line["config"]["exchange"] == "rccl" and line["config"]["exchange_note"] is None, line
+
+
+def test_eight_ranks_take_the_second_step_together_when_one_of_them_fails():
+    """The same launch with rank 5's first child dying before the collective: its seven peers wait in the rendezvous until
+    their timeout, every supervisor learns that the attempt failed somewhere, and all eight go on to the host exchange --
+    on the next port, with a store of their own -- where they meet and rank 0 prints the line with the reason in it."""
+    env = dict(os.environ, VT_BENCH_CHILD=FAKE, FAKE_CHILD="meet", FAKE_FAIL_RANKS="5", FAKE_MEET_TIMEOUT="8", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    port = _free_port()
+    r = subprocess.run(_driver_command(8, port, ["--scaling", "weak"]), env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = last_json(r.stdout)
+    assert (line["n_gpus"], line["rccl_ranks"], line["met"], line["scaling"]) == (8, 8, list(range(8)), "weak"), line
+    assert line["config"]["exchange"] == "host" and line["config"]["master_port"] == str(port + 1), line
+    assert line["config"]["agent_store"] == "False" and "the rccl-exchange run" in line["config"]["exchange_note"], line
+
+
 def test_json_line_of_takes_the_last_object():
     sys.path.insert(0, ROOT)
     import bench

@@ -7,6 +7,7 @@ import threading
 import numpy as np
 import pytest
 
+import support
 from test_gpu_parity import GpuIndex, bits, make_corpus, nifs, unwrap  # noqa: F401  (nifs is a fixture)
 
 pytestmark = pytest.mark.gpu
@@ -61,7 +62,10 @@ def test_coalesced_searches_equal_searches_alone(nifs, oracle_mod, monkeypatch, 
     bad = _hammer(nifs, g.ref, jobs, threads=16, rounds=60)
     after = nifs.flat_coalesce_stats(g.ref)
     assert not bad, bad[:3]
-    assert after[0] > before[0] and after[1] - before[1] >= 2 * (after[0] - before[0])   # batches ran, >= 2 searches each
+    # (whether any of these Python threads met is a matter of timing -- test_callers_made_to_meet_* below force it;
+    # here: whoever met, everybody got the answer of a search alone, and a batch never carries fewer than two)
+    assert after[1] - before[1] >= 2 * (after[0] - before[0])
+    print("coalesced: %d batches, %d calls in batches" % (after[0] - before[0], after[1] - before[1]))
 
 
 def test_coalescing_steps_aside_for_lazy_ranks_and_survives_mutations(nifs, oracle_mod, monkeypatch, vt_debug):
@@ -96,3 +100,79 @@ def test_coalescing_steps_aside_for_lazy_ranks_and_survives_mutations(nifs, orac
         stop.set()
         w.join()
     assert not bad, bad[:3]
+
+
+# ---- callers that are MADE to meet ------------------------------------------------------------------------------
+# The tests above use Python threads and assert answers only.  These assert the PATH -- which batches formed, which
+# kernels carried them -- and therefore take timing out of it: native threads leave a barrier together, and the handle's
+# first caller of a round keeps its slot until all the others have queued behind it (test_coalesce_hold_until, a hook of
+# libvettore_hip_hooks.so; each test re-runs itself in a process that loads that build).  What happens after they have
+# met -- take_along, judge, the batch paths, waking the members -- is the product's code, unchanged.
+
+@pytest.mark.parametrize("metric,devices", [(2, None), (0, None), (5, None), (7, None), (2, [0, 0, 0])])
+def test_callers_made_to_meet_travel_as_one_batch(nifs, oracle_mod, request, vt_debug, metric, devices):
+    """16 flat_search callers per round: one batch of 16 every round -- a matrix-core pass (cosine, L2), sweeps of eight
+    (manhattan: K1m), sweeps of the non-zero-bit column (float hamming: K4p), a batch on every shard of a three-shard
+    handle -- and every answer the oracle's."""
+    if support.rerun_with_hooks_library(request):
+        return
+    vt_debug.set("coalesce_slots", 1)
+    vt_debug.set("force_batch_mfma", 1)
+    vt_debug.set("force_multi_scan", 1)
+    n, d, callers, rounds = 40_000, 96, 16, 4
+    x, ids = make_corpus(n, d, 910 + metric, metric == 2, oracle_mod, tie_block=40)
+    if metric == 7:
+        x = (x * (np.random.default_rng(3).uniform(0, 1, x.shape) < 0.4)).astype(np.float32)
+    packed = oracle_mod.pack_ids(ids)
+    g = GpuIndex(nifs, metric)
+    if devices:
+        g.ref = nifs.flat_new_sharded(metric, devices)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    nifs.flat_set_profiling(g.ref, True)
+    rng = np.random.default_rng(5)
+    qs = np.stack([x[n // 2], x[3]] + [rng.uniform(-1, 1, d).astype(np.float32) for _ in range(21)])
+    if metric == 2:
+        qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
+    for q in qs:
+        assert bits(unwrap(nifs.flat_search(g.ref, q, 10))) == bits(oracle_mod.matrix_search(metric, x, packed, q, 10))
+    b0, p0 = nifs.flat_coalesce_stats(g.ref), nifs.flat_get_profile(g.ref)
+    wrong, failed = support.callers_meet(g.ref, qs, 10, [0] * callers, rounds=rounds)
+    b1, p1 = nifs.flat_coalesce_stats(g.ref), nifs.flat_get_profile(g.ref)
+    assert (wrong, failed) == (0, 0)
+    assert (b1[0] - b0[0], b1[1] - b0[1]) == (rounds, rounds * callers), (b0, b1)
+    moved = {k: p1[k] - p0[k] for k in p1 if isinstance(p1[k], int)}
+    if devices:
+        return                                             # (profiles are per shard; the batch count above is the handle's)
+    if metric in (2, 0):
+        assert moved["nominate_launches"] >= rounds and moved["nominate_queries"] >= rounds * callers, moved
+    elif metric == 5:
+        assert moved["sweep_queries"] >= rounds * (callers - 2), moved      # (a threshold may miss now and then)
+    else:
+        assert moved["hamming_queries"] == rounds * callers and moved["scan_launches"] == 0, moved
+
+
+def test_callers_of_three_entry_points_made_to_meet_travel_with_their_equals(nifs, oracle_mod, request, vt_debug):
+    """24 callers per round -- 8 flat_search, 6 quantized_search(100), 2 quantized_search(50), 5 funnel_search([32], 100),
+    3 funnel_search([64], 100): they queue on one handle and leave in five batches, equals with equals
+    (collection.ex:234-295 under one read lock); every answer is that of the call made alone."""
+    if support.rerun_with_hooks_library(request):
+        return
+    vt_debug.set("coalesce_slots", 1)
+    n, d, rounds = 40_000, 128, 3
+    x, ids = make_corpus(n, d, 4200, True, oracle_mod)
+    g = GpuIndex(nifs, 2)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    nifs.flat_set_profiling(g.ref, True)
+    rng = np.random.default_rng(12)
+    qs = np.stack([oracle_mod.normalize_l2(q) for q in rng.uniform(-1, 1, (32, d)).astype(np.float32)])
+    kinds = [0] * 8 + [1] * 8 + [2] * 8
+    params = [0] * 16 + [32] * 5 + [64] * 3
+    cands = [0] * 8 + [100] * 6 + [50] * 2 + [100] * 8
+    b0, p0 = nifs.flat_coalesce_stats(g.ref), nifs.flat_get_profile(g.ref)
+    wrong, failed = support.callers_meet(g.ref, qs, 10, kinds, params, cands, rounds=rounds)
+    b1, p1 = nifs.flat_coalesce_stats(g.ref), nifs.flat_get_profile(g.ref)
+    assert (wrong, failed) == (0, 0)
+    # five groups of equals per round; all 24 callers travelled in one of them
+    assert (b1[0] - b0[0], b1[1] - b0[1]) == (5 * rounds, 24 * rounds), (b0, b1)
+    assert p1["hamming_queries"] - p0["hamming_queries"] >= 8 * rounds, (p0, p1)      # the quantized groups shared sweeps of the bits
+    assert p1["prefix_queries"] - p0["prefix_queries"] >= 6 * rounds, (p0, p1)        # the funnel groups shared stage-1 sweeps

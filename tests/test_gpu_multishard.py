@@ -700,3 +700,64 @@ def test_long_batches_on_a_sharded_handle_merge_while_the_shards_still_run(nifs,
     # the duplicates planted across the shards come back in id order
     top = unwrap(nifs.flat_search_batch(sharded.ref, qs, shards))[0]
     assert [h[0] for h in top] == sorted(ids[r] for r in first)
+
+
+def test_eight_shards_answer_4096_queries_in_one_call(nifs, oracle_mod, vt_debug):
+    """The width of the node on one card: vt_flat_new_sharded(metric, [0] * 8), 200 000 rows, 4 096 queries in ONE call --
+    sixteen groups of 256 per shard, the calling thread merging every query as soon as all eight shards have settled it
+    (run_on_workers_meanwhile, host/vt_multi.h).  A row whose f32 products overflow against the queries of a MIDDLE group
+    (distances.rs:61-68: recomputed in f64, representable again) sits in one shard; every list equals the one-GPU index's,
+    a sample the oracle's, bit for bit.  Then one query of that group is made to overflow for good: the call reports
+    "metric overflow" as that query's own search does, and the handle answers the next call as before."""
+    vt_debug.set("force_batch_mfma", 1)
+    metric, n, d, shards, nq = 3, 200_000, 64, 8, 4096
+    x, ids = make_corpus(n, d, 8800, False, oracle_mod, tie_block=40)
+    x = x.copy()
+    sharded = ShardedIndex(nifs, metric, [0] * shards)
+    assert nifs.flat_shard_count(sharded.ref) == shards
+    route = nifs.flat_route_ids(sharded.ref, nifs.pack_ids(ids))
+    assert set(route.tolist()) == set(range(shards))
+    big = np.finfo(np.float32).max
+    hot = int(np.flatnonzero(route == 5)[1000])           # a row in the middle of shard 5
+    x[hot, 0] = x[hot, 1] = big
+    x[hot, 2:] = 4.0                                       # (the rest of its dot product makes it every middle query's best hit or worst)
+    rng = np.random.default_rng(88)
+    qs = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+    qs[:, 0:2] = 0.0
+    middle = range(1900, 2200)                             # queries 1900..2199: groups 7 and 8 of 16
+    for i in middle:
+        qs[i, 0], qs[i, 1] = 2.0, -2.0                     # 2 * max - 2 * max: inf - inf in f32, 0 in f64
+    first = [int(np.flatnonzero(route == s)[0]) for s in range(shards)]
+    for r in first[1:]:
+        x[r] = x[first[0]]                                 # identical rows in all eight shards: the id bytes order them
+    qs[0], qs[4095] = x[first[0]], x[first[3]]
+    qs[0, 0:2] = qs[4095, 0:2] = 0.0
+    unwrap(nifs.flat_load_matrix(sharded.ref, ids, x))
+    plain = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(plain.ref, ids, x))
+    packed = oracle_mod.pack_ids(ids)
+    got = unwrap(nifs.flat_search_batch(sharded.ref, qs, 10))
+    one = unwrap(nifs.flat_search_batch(plain.ref, qs, 10))
+    assert len(got) == nq
+    for i in range(nq):
+        assert bits(got[i]) == bits(one[i]), i
+    sample = [0, 1, 255, 256, 1899, 1900, 1901, 2047, 2048, 2199, 2200, 4095] + [int(v) for v in rng.integers(0, nq, 60)]
+    for i in sample:
+        want = oracle_mod.matrix_search(metric, x, packed, qs[i], 10)
+        assert bits(got[i]) == bits(want), i
+        assert bits(sharded.search(qs[i], 10)) == bits(want), i
+    # the overflowing row was recomputed, not dropped: it is the best hit of many a middle query
+    assert np.isfinite(oracle_mod.compute(metric, qs[2000], x[hot]))
+    assert sum(1 for i in middle if got[i][0][0] == ids[hot]) >= 30
+    assert [h[0] for h in unwrap(nifs.flat_search_batch(sharded.ref, qs[:1], shards))[0]] == sorted(ids[r] for r in first)
+    # one query of the middle group overflows for good
+    bad = qs.copy()
+    bad[2000, 0] = bad[2000, 1] = 2.0
+    with pytest.raises(oracle_mod.OracleError, match="metric overflow"):
+        oracle_mod.matrix_search(metric, x, packed, bad[2000], 10)
+    assert nifs.flat_search(sharded.ref, bad[2000], 10) == ("error", "metric overflow")
+    assert nifs.flat_search_batch(sharded.ref, bad, 10) == ("error", "metric overflow")
+    assert nifs.flat_search_batch(plain.ref, bad, 10) == ("error", "metric overflow")
+    again = unwrap(nifs.flat_search_batch(sharded.ref, qs[1800:2400], 10))
+    for j, i in enumerate(range(1800, 2400)):
+        assert bits(again[j]) == bits(one[i]), i

@@ -1653,7 +1653,8 @@ def test_concurrent_funnel_callers_share_sweeps(nifs, oracle_mod, monkeypatch, m
         th.join()
     b1 = nifs.flat_coalesce_stats(g.ref)
     assert not wrong, wrong[:5]
-    assert b1[1] - b0[1] > 0, "no caller ever travelled in a batch"
+    # (how many calls met is a matter of timing -- Python threads on 0.1-ms calls; callers that are MADE to meet, and the
+    # sweeps they then share, are tests/test_gpu_coalesce.py::test_callers_of_three_entry_points_made_to_meet_...)
     print("coalesced: %d batches, %d calls in batches" % (b1[0] - b0[0], b1[1] - b0[1]))
 
 

@@ -206,9 +206,10 @@ def test_rows_that_round_to_infinity_through_the_shadow(nifs, oracle_mod, monkey
     check_batch(nifs, oracle_mod, g, 3, x, ids, qs, 5)
 
 
-def test_concurrent_callers_travel_through_the_shadow(nifs, oracle_mod, monkeypatch, vt_debug):
-    """flat_search callers that meet on a handle go as one batch (vt_coalesce.h); with a shadow that
-    batch is a K2s pass, and a reader that finds the shadow stale escalates once to patch it."""
+def test_concurrent_callers_get_their_own_answers_beside_a_shadow(nifs, oracle_mod, monkeypatch, vt_debug):
+    """flat_search callers on a handle whose batches go through the shadow: every answer is the oracle's, whoever
+    travelled with whom.  (How many of these Python threads meet is a matter of timing and is not asserted: the test
+    below makes callers meet.)"""
     import threading
     vt_debug.set("force_batch_mfma", 1)
     vt_debug.set("coalesce_slots", 1)
@@ -217,14 +218,15 @@ def test_concurrent_callers_travel_through_the_shadow(nifs, oracle_mod, monkeypa
     packed = oracle_mod.pack_ids(ids)
     g = GpuIndex(nifs, 2)
     unwrap(nifs.flat_load_matrix(g.ref, ids, x))
-    nifs.flat_set_profiling(g.ref, True)
     rng = np.random.default_rng(6)
     qs = np.stack([oracle_mod.normalize_l2(q) for q in rng.uniform(-1, 1, size=(24, d)).astype(np.float32)])
     want = [bits(oracle_mod.matrix_search(2, x, packed, q, 10)) for q in qs]
     errors = []
+    start = threading.Barrier(len(qs))
 
     def caller(i):
         try:
+            start.wait()
             for _ in range(6):
                 got = unwrap(nifs.flat_search(g.ref, qs[i], 10))
                 if bits(got) != want[i]:
@@ -238,8 +240,46 @@ def test_concurrent_callers_travel_through_the_shadow(nifs, oracle_mod, monkeypa
     for t in threads:
         t.join()
     assert not errors, errors
-    prof = nifs.flat_get_profile(g.ref)
-    assert prof["nominate_shadow_launches"] >= 1 and prof["nominate_shadow_launches"] == prof["nominate_launches"], prof
+
+
+def test_callers_made_to_meet_travel_through_the_shadow(nifs, oracle_mod, request, vt_debug):
+    """flat_search callers that meet on a handle go as one batch (vt_coalesce.h); with a shadow that batch is a K2s
+    pass.  The meeting is FORCED: 24 native threads leave a barrier together and the handle's first caller keeps its
+    slot until the other 23 have queued (test_coalesce_hold_until -- libvettore_hip_hooks.so only: the test re-runs
+    itself there), so every round is one batch of 24 whatever the box's timing; a row upserted between two runs leaves
+    the shadow stale and the next batch patches it."""
+    if support.rerun_with_hooks_library(request):
+        return
+    vt_debug.set("force_batch_mfma", 1)
+    vt_debug.set("coalesce_slots", 1)
+    n, d, callers, rounds = 30000, 256, 24, 5
+    x, ids = make_corpus(n, d, 61, True, oracle_mod, tie_block=16)
+    x = x.copy()
+    packed = oracle_mod.pack_ids(ids)
+    g = GpuIndex(nifs, 2)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    nifs.flat_set_profiling(g.ref, True)
+    rng = np.random.default_rng(6)
+    qs = np.stack([oracle_mod.normalize_l2(q) for q in rng.uniform(-1, 1, size=(31, d)).astype(np.float32)])
+    qs[0] = x[n // 2]                                      # on the block of identical rows
+    for run in range(2):
+        # alone, every query equals the oracle; callers_meet compares every answer of a batch with the call made alone
+        for q in qs:
+            assert bits(unwrap(nifs.flat_search(g.ref, q, 10))) == bits(oracle_mod.matrix_search(2, x, packed, q, 10))
+        b0, p0 = nifs.flat_coalesce_stats(g.ref), nifs.flat_get_profile(g.ref)
+        wrong, failed = support.callers_meet(g.ref, qs, 10, [0] * callers, rounds=rounds)
+        b1, p1 = nifs.flat_coalesce_stats(g.ref), nifs.flat_get_profile(g.ref)
+        assert (wrong, failed) == (0, 0)
+        assert (b1[0] - b0[0], b1[1] - b0[1]) == (rounds, rounds * callers), (b0, b1)
+        passes = p1["nominate_launches"] - p0["nominate_launches"]
+        assert passes >= rounds and p1["nominate_shadow_launches"] - p0["nominate_shadow_launches"] == passes, (p0, p1)
+        assert p1["nominate_queries"] - p0["nominate_queries"] >= rounds * callers, (p0, p1)
+        assert p1["shadow_builds"] == 1, p1
+        if run == 0:
+            x[7] = qs[3]                                   # an upsert: the shadow is stale until the next batch patches the row
+            unwrap(nifs.flat_insert(g.ref, ids[7], x[7]))
+            assert nifs.flat_batch_shadow(g.ref) == "stale"
+    assert nifs.flat_batch_shadow(g.ref) == "current" and p1["shadow_patched_rows"] >= 1, p1
 
 
 def test_a_lone_search_through_the_shadow(nifs, oracle_mod):

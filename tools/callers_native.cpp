@@ -12,7 +12,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -78,6 +80,72 @@ extern "C" int vt_callers_run(vt_flat *h, const float *queries, size_t nq, size_
   stop = true;
   for (auto &th : pool) th.join();
   *searches = total.load();
+  *mismatches = wrong.load();
+  *failures = failed.load();
+  return 0;
+}
+
+// ---- callers that MEET (tests/test_gpu_coalesce.py, tests/test_gpu_shadow.py) ------------------------------------
+// `threads` native threads make `rounds` calls each, all of them leaving a barrier together at the start of every
+// round.  With libvettore_hip_hooks.so and `hold` != 0 the handle's first caller of a round keeps its slot until the
+// other threads have queued behind it (test_coalesce_hold_until, host/vt_concurrency.h), so that who travels with whom
+// is a fact the test can assert instead of a matter of timing.  Thread t calls entry point kinds[t] with params[t] /
+// candidates[t]; in round r its query is number (7 t + r) mod nq.  Every answer is compared (ids, raw bits) with the
+// same call made alone before the threads start.
+// Returns 0, 1 (arguments), 2 (a call alone failed), 3 (the library has no hold hook: not the hooks build).
+namespace {
+struct Barrier {
+  std::mutex mu;
+  std::condition_variable cv;
+  int waiting = 0, generation = 0, parties;
+  explicit Barrier(int n) : parties(n) {}
+  void arrive() {
+    std::unique_lock<std::mutex> g(mu);
+    const int gen = generation;
+    if (++waiting == parties) {
+      waiting = 0;
+      generation += 1;
+      cv.notify_all();
+    } else {
+      cv.wait(g, [&] { return generation != gen; });
+    }
+  }
+};
+}  // namespace
+
+extern "C" int vt_callers_meet(vt_flat *h, const float *queries, size_t nq, size_t d, size_t limit, const int *kinds,
+                               const size_t *params, const size_t *candidates, int threads, int rounds, int hold,
+                               unsigned long long *mismatches, unsigned long long *failures) {
+  if (!h || !queries || nq == 0 || threads <= 0 || rounds <= 0 || !kinds || !params || !candidates || !mismatches || !failures)
+    return 1;
+  auto query_of = [&](int t, int r) { return (size_t)(7 * t + r) % nq; };
+  std::vector<std::vector<Answer>> alone((size_t)threads, std::vector<Answer>((size_t)rounds));
+  for (int t = 0; t < threads; ++t)
+    for (int r = 0; r < rounds; ++r) {
+      vt_hits *hits = nullptr;
+      if (call(h, kinds[t], queries + query_of(t, r) * d, d, limit, params[t], candidates[t], &hits) != 0) return 2;
+      alone[t][r] = take(hits);
+      vt_hits_free(hits);
+    }
+  if (hold && vt_debug_set("test_coalesce_hold_until", threads) != 0) return 3;
+  std::atomic<unsigned long long> wrong{0}, failed{0};
+  Barrier barrier(threads);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t)
+    pool.emplace_back([&, t] {
+      for (int r = 0; r < rounds; ++r) {
+        barrier.arrive();
+        vt_hits *hits = nullptr;
+        if (call(h, kinds[t], queries + query_of(t, r) * d, d, limit, params[t], candidates[t], &hits) != 0) {
+          failed += 1;  // (and stays for the barriers: the others must not wait for ever)
+          continue;
+        }
+        if (!same(take(hits), alone[t][r])) wrong += 1;
+        vt_hits_free(hits);
+      }
+    });
+  for (auto &th : pool) th.join();
+  if (hold) vt_debug_set("test_coalesce_hold_until", 0);
   *mismatches = wrong.load();
   *failures = failed.load();
   return 0;

@@ -92,6 +92,12 @@ struct CoalesceOps {
     const bool gemm = m == VT_COSINE || m == VT_INNER_PRODUCT || m == VT_NEG_INNER_PRODUCT || m == VT_L2 || m == VT_L2_SQUARED;
     return gemm && !vt::env::on(vt::env::BATCH_NO_MFMA) ? 256 : 8;
   }
+  // tests that need callers to MEET (tests/test_gpu_coalesce.py, libvettore_hip_hooks.so only): the product never holds
+#ifdef VT_TEST_HOOKS
+  static size_t hold_until(vt_flat *) { return (size_t)std::max<long>(0, vt::env::get(vt::env::TEST_COALESCE_HOLD_UNTIL)); }
+#else
+  static constexpr size_t hold_until(vt_flat *) { return 0; }
+#endif
   static void run(vt_flat *h, std::vector<vt_host::Waiting *> &members) { vt_host::run_coalesced_t<vt_flat, CoalesceOps>(h, members); }
   static void drop_hits(vt_hits *hits) { delete hits; }
   static void set_last_error(const std::string &msg) { g_last_error = msg; }

@@ -308,6 +308,7 @@ void run_coalesced_t(H *h, std::vector<Waiting *> &members) {
 //   Ops::search_direct(h, kind, aux, query, n, limit, out) -> st  a search outside the coalescer
 //   Ops::must_disband(h, kind, limit) -> bool          a batch would force work a lone search avoids
 //   Ops::capacity(h, kind) -> size_t                   callers one pass over the corpus carries at no extra cost
+//   Ops::hold_until(h) -> size_t                       0; test builds: callers an idle handle's first caller waits for
 //   Ops::run(h, members)                               normally run_coalesced_t<H, Ops>
 //   Ops::drop_hits(hits)                               frees a hit list
 //   Ops::set_last_error(msg)                           the calling thread's error text
@@ -355,6 +356,14 @@ int coalesced_search_t(H *h, const float *query, size_t n, size_t limit, vt_hits
     std::unique_lock<std::mutex> lk(co.mu);
     if (co.active < max_active && co.waiting.empty()) {
       co.active += 1;  // nobody to wait for ...
+      // (builds with the test hooks only -- Ops::hold_until is the constant 0 in the product: the caller that finds the
+      // handle idle keeps its slot until `hold` callers are here or five seconds have passed, so that a test's callers
+      // MEET instead of hoping to; what happens once they have met is the code below, unchanged)
+      if (const size_t hold = Ops::hold_until(h)) {
+        co.gather.wait_until(lk, std::chrono::system_clock::now() + std::chrono::seconds(5),
+                             [&] { return co.waiting.size() + 1 >= hold; });
+        take_along();
+      } else
       // ... unless a batch has only just ended: its callers are on their way back, and the first
       // of them to arrive would otherwise run alone, the others queue behind it, and the handle
       // settles into passes of 1 and N - 1 callers (or two alternating halves) -- N callers per

@@ -112,7 +112,8 @@ enum Parse {
   X(TEST_REFUSE_SHADOW, "test_refuse_shadow", P_FLAG, 0)                                                                  \
   X(TEST_FAIL_AFTER_ID_UPDATE, "test_fail_after_id_update", P_FLAG, 0)                                                    \
   X(TEST_INGEST_LOCKSTEP, "test_ingest_lockstep", P_FLAG, 0)                                                              \
-  X(TEST_FOREIGN_ROWS, "test_foreign_rows", P_FLAG, 0)
+  X(TEST_FOREIGN_ROWS, "test_foreign_rows", P_FLAG, 0)                                                                    \
+  X(TEST_COALESCE_HOLD_UNTIL, "test_coalesce_hold_until", P_INT, 0)
 
 enum Key : int {
 #define VT_ENV_ENUM(key, name, parse, dflt) key,
