@@ -10,9 +10,16 @@ LIBDIR  := vettore_amd/lib
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
             -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function
 
-# make EXPERIMENTS=1: K2's timing switches (VT_BATCH_DEBUG, tools/batch_debug.sh) are compiled in
+# `make experiments`: the same library with the timing experiments of K2 / K2b / K2s / K1m compiled in and their
+# settings named (batch_debug, mq_dbg, shadow_stages, trace_batch: csrc/vt_env.h) -> vettore_amd/lib/experiments/
+# libvettore_hip.so.  Wrong results on purpose (barriers removed, stages skipped): for the cost breakdowns in
+# DESIGN_APPENDIX only, never loaded by a test.  The product build carries neither the switches nor the code behind them.
+# Kernels that must not spill are checked after they are compiled (tools/check_scratch.py says why); the experiments' extra
+# registers do spill, and nobody ships that build.
+CHECK_SCRATCH := python3 tools/check_scratch.py
 ifdef EXPERIMENTS
-HIPFLAGS += -DVT_BATCH_TIMING_EXPERIMENTS
+HIPFLAGS += -DVT_EXPERIMENTS -DVT_BATCH_TIMING_EXPERIMENTS -DVT_MULTI_TIMING_EXPERIMENTS
+CHECK_SCRATCH := @true
 endif
 
 DEVSRC  := vt_kernels vt_batch vt_batch_bf16 vt_batch_shadow vt_scan_dot vt_scan_l2 vt_scan_l1 vt_scan_misc vt_scan_general vt_scan_gather vt_scan_multi vt_prefix_multi
@@ -30,27 +37,27 @@ $(LIBDIR)/%.o: $(CSRC)/%.hip $(DEVHDR)
 $(LIBDIR)/vt_scan_%.o: $(CSRC)/vt_scan_%.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_scan_$*.resources
-	python3 tools/check_scratch.py --no-scratch $(LIBDIR)/vt_scan_$*.resources scan_topk_kernel
+	$(CHECK_SCRATCH) --no-scratch $(LIBDIR)/vt_scan_$*.resources scan_topk_kernel
 
 # Kernels that must not spill (tools/check_scratch.py says why): the build fails if one does.
 $(LIBDIR)/vt_scan_multi.o: $(CSRC)/vt_scan_multi.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_scan_multi.resources
-	python3 tools/check_scratch.py --no-scratch $(LIBDIR)/vt_scan_multi.resources scan_multi_kernel
+	$(CHECK_SCRATCH) --no-scratch $(LIBDIR)/vt_scan_multi.resources scan_multi_kernel
 $(LIBDIR)/vt_batch_bf16.o: $(CSRC)/vt_batch_bf16.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_batch_bf16.resources
-	python3 tools/check_scratch.py $(LIBDIR)/vt_batch_bf16.resources bf16_scores_kernel
+	$(CHECK_SCRATCH) $(LIBDIR)/vt_batch_bf16.resources bf16_scores_kernel
 # (-fno-slp-vectorize: K1p packs two ELEMENTS of a query per instruction by hand; the SLP pass re-packs two QUERIES
 # instead, with a register move per operand pair -- 22-26 % more VALU cycles per chunk, measured)
 $(LIBDIR)/vt_prefix_multi.o: $(CSRC)/vt_prefix_multi.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_prefix_multi.resources
-	python3 tools/check_scratch.py --no-scratch $(LIBDIR)/vt_prefix_multi.resources prefix_multi_kernel
+	$(CHECK_SCRATCH) --no-scratch $(LIBDIR)/vt_prefix_multi.resources prefix_multi_kernel
 $(LIBDIR)/vt_batch_shadow.o: $(CSRC)/vt_batch_shadow.hip $(DEVHDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(LIBDIR)/vt_batch_shadow.resources
-	python3 tools/check_scratch.py $(LIBDIR)/vt_batch_shadow.resources shadow_scores_kernel
+	$(CHECK_SCRATCH) $(LIBDIR)/vt_batch_shadow.resources shadow_scores_kernel
 
 HOSTHDR := $(wildcard $(CSRC)/host/*.h)
 $(LIBDIR)/vt_index.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h $(CSRC)/vt_env.h include/vettore_flat.h
@@ -70,13 +77,8 @@ $(LIBDIR)/vt_index_hooks.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h 
 $(LIBDIR)/libvettore_hip_hooks.so: $(DEVOBJ) $(LIBDIR)/vt_index_hooks.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread -ldl
 
-# K1m with its timing experiments compiled in (VT_MQ_DBG=<bits>: wrong results, for the cost
-# breakdown in DESIGN 4.4 only): `make mqdbg`, then VETTORE_HIP_LIB=.../libvettore_hip_mqdbg.so
-$(LIBDIR)/vt_scan_multi_dbg.o: $(CSRC)/vt_scan_multi.hip $(DEVHDR)
-	$(HIPCC) $(HIPFLAGS) -DVT_MULTI_TIMING_EXPERIMENTS -c $< -o $@
-$(LIBDIR)/libvettore_hip_mqdbg.so: $(filter-out %/vt_scan_multi.o,$(DEVOBJ)) $(LIBDIR)/vt_scan_multi_dbg.o $(LIBDIR)/vt_index.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread -ldl
-mqdbg: $(LIBDIR)/libvettore_hip_mqdbg.so
+experiments:
+	$(MAKE) EXPERIMENTS=1 LIBDIR=vettore_amd/lib/experiments vettore_amd/lib/experiments/libvettore_hip.so
 
 # bench.py's native caller threads (tools/callers_native.cpp): measurement infrastructure, not product
 $(LIBDIR)/libvt_callers.so: tools/callers_native.cpp include/vettore_flat.h $(LIBDIR)/libvettore_hip.so
@@ -98,4 +100,4 @@ tools/%: tools/%.hip
 clean:
 	rm -rf $(LIBDIR) oracle/libvt_oracle.so $(PROBES)
 
-.PHONY: all oracle clean probes mqdbg
+.PHONY: all oracle clean probes experiments

@@ -445,7 +445,7 @@ static void check_settings(int readers, int per_reader) {
     }
   });
   std::thread setter([&] {  // vt_debug_set from a test thread
-    for (unsigned i = 0; !stop.load(); ++i) vt::env::set(vt::env::RESCORE_BLOCKS, 4 + (long)(i & 7u));
+    for (unsigned i = 0; !stop.load(); ++i) vt::env::set(vt::env::BF16_MIN_RANK, 4 + (long)(i & 7u));
   });
   std::atomic<long> sum{0};
   std::vector<std::thread> pool;
@@ -455,9 +455,9 @@ static void check_settings(int readers, int per_reader) {
       for (int i = 0; i < per_reader; ++i) {
         // batch_uses_mfma / multi_scan_applies / sweep_group_applies / coalesce_slots, as the library asks them
         CHECK(!vt::env::on(vt::env::BATCH_NO_MFMA) && !vt::env::on(vt::env::FORCE_BATCH_MFMA));
-        CHECK(!vt::env::on(vt::env::NO_MULTI_SCAN) && !vt::env::on(vt::env::NO_SWEEP_GROUPS) && !vt::env::on(vt::env::NO_GROUP_PIPELINE));
+        CHECK(!vt::env::on(vt::env::NO_MULTI_SCAN) && !vt::env::on(vt::env::NO_GROUP_PIPELINE));
         CHECK(vt::env::get(vt::env::COALESCE_SLOTS) == 3);  // not 7, not 9: the environment is not looked at again
-        const long b = vt::env::get(vt::env::RESCORE_BLOCKS);
+        const long b = vt::env::get(vt::env::BF16_MIN_RANK);
         CHECK(b >= 4 && b <= 11);
         local += b;
       }

@@ -153,10 +153,10 @@ def test_the_environment_is_read_when_the_library_is_loaded():
     import sys
     code = ("import ctypes as C, vettore_amd._lib as L; l = L.load(); v = C.c_long()\n"
             "out = []\n"
-            "for n in (b'reduce_order', b'batch_nominate', b'batch_shadow', b'slab', b'shard_exchange', b'coalesce', b'no_multi_scan', b'rescore_blocks'):\n"
+            "for n in (b'reduce_order', b'batch_nominate', b'batch_shadow', b'slab', b'shard_exchange', b'coalesce', b'no_multi_scan', b'ingest_stage_mb'):\n"
             "    assert l.vt_debug_get(n, C.byref(v)) == 0; out.append(v.value)\n"
             "print(out)")
     env = dict(os.environ, VT_REDUCE_ORDER="avx", VT_BATCH_NOMINATE="f32", VT_BATCH_SHADOW="off", VT_SLAB="malloc",
-               VT_SHARD_EXCHANGE="rccl", VT_COALESCE="0", VT_NO_MULTI_SCAN="1", VT_RESCORE_BLOCKS="16")
+               VT_SHARD_EXCHANGE="rccl", VT_COALESCE="0", VT_NO_MULTI_SCAN="1", VT_INGEST_STAGE_MB="16")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "[1, 1, 0, 1, 2, 0, 1, 16]", (r.stdout, r.stderr[-2000:])

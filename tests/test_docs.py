@@ -14,6 +14,13 @@ def test_design_quotes_the_collected_test_counts():
     assert res.returncode == 0, res.stdout + res.stderr
 
 
+def test_the_settings_table_is_the_librarys_and_stays_short():
+    """DESIGN_APPENDIX A.10 is generated from csrc/vt_env.h (tools/env_table.py), and the product's list holds at most 30
+    settings (VERDICT r5 #3: every kept knob is a path a maintainer must trust; nifs.rs has none)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "env_table.py"), "--check"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+
+
 def test_quoted_headline_ranges_include_the_drivers_own_runs():
     """README.md and DESIGN.md quote the headline as a range; every BENCH_rNN.json the driver has written must lie inside
     it (VERDICT r4 weak #4: the documents quoted builder-box numbers no driver run had reached)."""

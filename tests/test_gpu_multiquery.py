@@ -212,7 +212,7 @@ def test_many_groups_of_one_call_alternate_between_two_contexts(nifs, oracle_mod
 def test_quantized_batches_of_many_groups_on_two_streams(nifs, oracle_mod, vt_debug, metric):
     """quantized_search_batch with several groups of eight (profiling off: the timed form waits group by group): every
     group is queued before anything is waited for, even groups on the caller's context, odd groups on a second one
-    (round 5; `qgroup_streams=1` is the one-stream form, `no_group_pipeline=1` waits group by group).  All three forms
+    (round 5; `no_group_pipeline=1` waits group by group: the form profiled calls take).  Both forms
     give every query its own quantized_search's hits, bit for bit, and the oracle's composition (binary_top_k, then
     vector_top_k over the candidates: collection.ex:276-295)."""
     n, d, nq, cand, limit = 40_000, 200, 45, 80, 10
@@ -225,7 +225,7 @@ def test_quantized_batches_of_many_groups_on_two_streams(nifs, oracle_mod, vt_de
     if metric == 2:
         qs = np.stack([oracle_mod.normalize_l2(q) for q in qs])
     singles = [bits(unwrap(nifs.flat_quantized_search(g.ref, q, cand, limit))) for q in qs]
-    for name, value in (("qgroup_streams", 0), ("qgroup_streams", 1), ("no_group_pipeline", 1)):
+    for name, value in (("no_group_pipeline", 0), ("no_group_pipeline", 1)):
         vt_debug.set(name, value)
         for _ in range(2):      # (the second call reuses both contexts' slots)
             got = unwrap(nifs.flat_quantized_search_batch(g.ref, qs, cand, limit))
@@ -243,9 +243,9 @@ def test_quantized_batches_of_many_groups_on_two_streams(nifs, oracle_mod, vt_de
 def test_funnel_groups_take_their_thresholds_from_tile_maxima_on_larger_corpora(nifs, oracle_mod, vt_debug, metric):
     """Round 5: where the sample is a fraction of the corpus (here 200 000 rows: every fourth 64-row tile) the sample pass
     of a funnel group files the best score of each tile and the threshold is the rank-th largest maximum
-    (launch_sample_tau_groups) instead of a radix select over every sampled score (`funnel_dense_sample=1`: that form).
-    A threshold only decides which rows are LISTED: both forms must give every query its own funnel_search's hits and
-    the oracle's composition, bit for bit -- rows identical to the query included."""
+    (launch_sample_tau_groups) instead of a radix select over every sampled score (the form small corpora keep).
+    A threshold only decides which rows are LISTED: every query must get its own funnel_search's hits and the oracle's
+    composition, bit for bit -- rows identical to the query included."""
     n, d, nq = 200_000, 64, 21
     x, ids = make_corpus(n, d, 7300 + metric, metric == 2, oracle_mod, tie_block=40)
     g = GpuIndex(nifs, metric)
@@ -264,10 +264,6 @@ def test_funnel_groups_take_their_thresholds_from_tile_maxima_on_larger_corpora(
     assert prof["prefix_queries"] >= nq - 1 - nq // 8 - 2, prof      # the sweeps took them (a threshold may miss now and then)
     singles = [bits(unwrap(nifs.flat_funnel_search(g.ref, q, stages, cand, limit))) for q in qs]
     assert [bits(h) for h in got] == singles
-    vt_debug.set("funnel_dense_sample", 1)
-    dense = unwrap(nifs.flat_funnel_search_batch(g.ref, qs, stages, cand, limit))
-    vt_debug.set("funnel_dense_sample", 0)
-    assert [bits(h) for h in dense] == singles
     rows = [(ids[i], x[i]) for i in range(n)]
     by_id = dict(rows)
     for i in (0, 12):

@@ -628,11 +628,10 @@ def test_elixir_funnel_equals_flat_with_full_candidates(nifs):
 
 
 @pytest.mark.parametrize("metric", [2, 0, 5, 7])
-def test_the_query_read_in_place_or_copied_gives_the_same_hits(nifs, oracle_mod, metric, vt_debug):
-    """Under `direct_query` (an A/B of r05 that measured no gain and stays off) short chains read the query straight
-    from the caller-side pinned block, no H2D copy in front of the first kernel.  Same hits either way, and the oracle's:
-    flat_search on a corpus of few blocks, quantized_search, funnel_search (incl. the sign / non-zero bits that ride
-    behind the floats)."""
+def test_short_chains_on_a_corpus_of_few_blocks(nifs, oracle_mod, metric):
+    """flat_search on a corpus of few blocks, quantized_search, funnel_search (incl. the sign / non-zero bits that ride
+    behind the query's floats in one copy): the oracle's hits.  (r05 also read the query in place from the pinned block
+    here, `direct_query`; that form measured no gain and has left the library.)"""
     n, d = 3000, 200
     x, ids = make_corpus(n, d, 900 + metric, metric == 2, oracle_mod, tie_block=20)
     if metric == 7:
@@ -646,17 +645,17 @@ def test_the_query_read_in_place_or_copied_gives_the_same_hits(nifs, oracle_mod,
         q = x[int(rng.integers(0, n))].copy() if step % 3 == 0 else rng.uniform(-1, 1, d).astype(np.float32)
         if metric == 2:
             q = oracle_mod.normalize_l2(q)
-        got = {}
-        for mode in (0, 1):
-            vt_debug.set("direct_query", mode)
-            got[mode] = (bits(unwrap(nifs.flat_search(g.ref, q, 25))),
-                         bits(unwrap(nifs.flat_quantized_search(g.ref, q, 100, 10))),
-                         bits(unwrap(nifs.flat_funnel_search(g.ref, q, [64, 128], 100, 10))))
-        assert got[0] == got[1], (metric, step)
+        got = {0: (bits(unwrap(nifs.flat_search(g.ref, q, 25))),
+                   bits(unwrap(nifs.flat_quantized_search(g.ref, q, 100, 10))),
+                   bits(unwrap(nifs.flat_funnel_search(g.ref, q, [64, 128], 100, 10))))}
         assert got[0][0] == bits(oracle_mod.matrix_search(metric, x, packed, q, 25)), (metric, step)
         cands = oracle_mod.binary_top_k([(i, oracle_mod.compress_sign_bits(v)) for i, v in rows], oracle_mod.compress_sign_bits(q), d, 100)
         by_id = dict(rows)
         assert got[0][1] == bits(oracle_mod.vector_top_k([(i, by_id[i]) for i, _ in cands], q, metric, d, 10)), (metric, step)
+        cur = rows
+        for st in (64, 128):
+            cur = [(i, by_id[i]) for i, _ in oracle_mod.vector_top_k(cur, q, metric, st, 100)]
+        assert got[0][2] == bits(oracle_mod.vector_top_k(cur, q, metric, d, 10)), (metric, step)
 
 
 def test_adapter_staged_searches_their_batches_and_their_errors(nifs):
@@ -732,16 +731,20 @@ def test_hybrid_search_matches_oracle_composition(nifs, oracle_mod, metric):
 
 
 @pytest.mark.parametrize("metric", [2, 0, 1, 3, 5, 6, 7, 8])
-def test_hybrid_device_chain_equals_host_composition(nifs, oracle_mod, metric, monkeypatch, vt_debug):
-    """hybrid_search with every generator <= 256 candidates can run as ONE device chain (generator
-    blocks -> union of rows -> exact rerank; one host wait; opt-in, VT_HYBRID_CHAIN=1, because it
-    measured no faster): its hits equal the default host-composed path's bit for bit, for every metric, generator mix and overlap, on a corpus large
-    enough for the histogram Hamming pass and on a small one; the profile counts the chains."""
-    for n, d in ((40_000, 128), (900, 40)):
+def test_hybrid_generator_mixes_match_oracle_composition(nifs, oracle_mod, metric):
+    """hybrid_search (collection.ex:325-345, :515-592) for every metric, generator mix and overlap -- repeated generators
+    (all repeats), a generator of one candidate, eight generators, funnels of one and of three stages -- on a corpus large
+    enough for the histogram Hamming pass and on a small one: the union of the generators' candidates in order of first
+    appearance, exact rerank, composed here from the oracle's pieces.  (Through r05 this test compared the host-composed
+    path with a one-chain device form of it, VT_HYBRID_CHAIN; that form measured no faster and has left the library.)"""
+    for n, d in ((20_000, 64), (900, 40)):
         x, ids = make_corpus(n, d, 470 + metric, metric == 2, oracle_mod, tie_block=25)
+        packed = oracle_mod.pack_ids(ids)
         g = GpuIndex(nifs, metric)
         unwrap(nifs.flat_load_matrix(g.ref, ids, x))
-        nifs.flat_set_profiling(g.ref, True)
+        rows = [(ids[i], x[i]) for i in range(n)]
+        by_id = dict(rows)
+        obits = [(ids[i], oracle_mod.compress_sign_bits(x[i])) for i in range(n)]
         rng = np.random.default_rng(16 + metric)
         mixes = [
             [(nifs.GEN_FUNNEL, 60, [d // 4, d // 2]), (nifs.GEN_QUANTIZED, 80, []), (nifs.GEN_SEARCH, 30, [])],
@@ -749,6 +752,7 @@ def test_hybrid_device_chain_equals_host_composition(nifs, oracle_mod, metric, m
             [(nifs.GEN_QUANTIZED, 200, []), (nifs.GEN_QUANTIZED, 200, [])],       # the same rows twice: all repeats
             [(nifs.GEN_FUNNEL, 256, [d]), (nifs.GEN_SEARCH, 1, []), (nifs.GEN_FUNNEL, 7, [3, 5, d])],
             [(nifs.GEN_SEARCH, 100, [])] * 8,
+            [(nifs.GEN_SEARCH, 300, []), (nifs.GEN_QUANTIZED, 300, [])],          # beyond one fused list
         ]
         for gens in mixes:
             for limit in (1, 10, 256):
@@ -756,22 +760,21 @@ def test_hybrid_device_chain_equals_host_composition(nifs, oracle_mod, metric, m
                 if metric == 2:
                     q = oracle_mod.normalize_l2(q)
                 q[:2] = x[n // 2][:2]
-                nifs.flat_get_profile(g.ref, reset=True)
-                vt_debug.set("hybrid_chain", 1)
-                got = nifs.flat_hybrid_search(g.ref, q, gens, limit)
-                chains = nifs.flat_get_profile(g.ref, reset=True)["hybrid_device_chains"]
-                vt_debug.reset("hybrid_chain")
-                want = nifs.flat_hybrid_search(g.ref, q, gens, limit)
-                assert nifs.flat_get_profile(g.ref, reset=True)["hybrid_device_chains"] == 0
-                assert got[0] == want[0] == "ok", (metric, gens, got, want)
-                assert bits(got[1]) == bits(want[1]), (metric, n, gens, limit)
-                assert chains == 1, (metric, n, gens, limit)
-        # beyond what one chain holds: the host-composed path serves it
-        nifs.flat_get_profile(g.ref, reset=True)
-        vt_debug.set("hybrid_chain", 1)
-        unwrap(nifs.flat_hybrid_search(g.ref, q, [(nifs.GEN_SEARCH, 300, [])], 10))
-        vt_debug.reset("hybrid_chain")
-        assert nifs.flat_get_profile(g.ref, reset=True)["hybrid_device_chains"] == 0
+                union = []
+                for kind, cand, stages in gens:
+                    if kind == nifs.GEN_FUNNEL:
+                        cur = rows
+                        for st in stages:
+                            cur = [(i, by_id[i]) for i, _ in oracle_mod.vector_top_k(cur, q, metric, st, cand)]
+                        union += [i for i, _ in cur]
+                    elif kind == nifs.GEN_QUANTIZED:
+                        union += [i for i, _ in oracle_mod.binary_top_k(obits, oracle_mod.compress_sign_bits(q), d, cand)]
+                    else:
+                        union += [i for i, _ in oracle_mod.matrix_search(metric, x, packed, q, cand)]
+                uniq = list(dict.fromkeys(union))
+                want = oracle_mod.vector_top_k([(i, by_id[i]) for i in uniq], q, metric, d, limit)
+                got = unwrap(nifs.flat_hybrid_search(g.ref, q, gens, limit))
+                assert bits(got) == bits(want), (metric, n, gens, limit)
 
 
 def test_binary_top_k_with_massive_ties(nifs, oracle_mod):
@@ -993,22 +996,6 @@ def test_config2_full_size_properties_and_spot_parity(nifs, oracle_mod):
         assert keys == sorted(keys)
         # limit monotonicity: top-5 is a prefix of top-10
         assert bits(g.search(x[row], 5)) == bits(hits[:5])
-
-
-def test_batched_search_with_the_wide_register_tile_kernel():
-    """VT_BATCH_KERNEL=3 (128 x 128 register tile per wave for 256-query batches) is read once
-    per process, so the batched parity tests are re-run in a child process with it set."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("VT_BATCH_KERNEL") == "3":
-        pytest.skip("already the child")
-    env = dict(os.environ, VT_BATCH_KERNEL="3")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x",
-                          "-m", "gpu", "-k", "batch and not wide_register", "-p", "no:cacheprovider"],
-                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
 
 
 def test_concurrent_callers_on_shared_and_separate_handles(nifs, oracle_mod):

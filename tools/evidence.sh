@@ -1,15 +1,29 @@
 #!/bin/bash
 # The round's run records that the driver does not produce itself (VERDICT r4 #3c): the `-m gpu_perf` guards and the
 # soaks on the build that is in the tree, kept under profiles/<round>/.
-#   gpurun --timeout 2700 -- 'RND=r05 bash tools/evidence.sh'      (then: cp -r gpurun_out/evidence/r05/* profiles/r05/)
-# SOAK_SCALE (default 1.0) scales every soak's seconds; PERF=0 / SOAKS=0 skip a part.
+#   gpurun --timeout 2700 -- 'RND=r06 bash tools/evidence.sh'      (then: cp -r gpurun_out/evidence/r06/* profiles/r06/)
+# SOAK_SCALE (default 1.0) scales every soak's seconds; PERF=0 / SOAKS=0 skip a part; SUITE=<n> adds n runs of the GPU suite.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-RND=${RND:-r05}
+RND=${RND:-r06}
 OUT=$R/gpurun_out/evidence/$RND
 mkdir -p $OUT
 cd $R
 S=${SOAK_SCALE:-1.0}
 secs() { python3 -c "print(max(20, int($1 * $S)))"; }
+# SUITE=<n>: the whole `-m gpu` suite n times on THIS lease (VERDICT r5 #1d: five runs over at least three leases); every
+# run's verdict line goes to gpu_suite_runs.<lease>.log with the GPU's unique id -- the logs of the round's leases are
+# concatenated into profiles/<round>/gpu_suite_runs.log.
+if [ "${SUITE:-0}" != "0" ]; then
+  LEASE=$(date -u +%Y%m%dT%H%M%SZ)
+  GPUID=$(rocm-smi --showuniqueid 2>/dev/null | grep -i -m1 "unique id" | sed 's/.*: *//')
+  for i in $(seq 1 $SUITE); do
+    t0=$(date +%s)
+    timeout 1700 python3 -m pytest tests -m gpu -x -q -p no:cacheprovider > $OUT/suite_${LEASE}_$i.full 2>&1
+    rc=$?
+    echo "$(date -u +%Y-%m-%dT%H:%MZ) lease $LEASE gpu ${GPUID:-?} run $i: rc $rc, $(tail -1 $OUT/suite_${LEASE}_$i.full) [wall $(( $(date +%s) - t0 )) s, pytest -m gpu -x on $(git -C $R rev-parse --short HEAD 2>/dev/null || echo 'the tree as sent')]" | tee -a $OUT/gpu_suite_runs.$LEASE.log
+    [ $rc -ne 0 ] && tail -60 $OUT/suite_${LEASE}_$i.full
+  done
+fi
 if [ "${PERF:-1}" != "0" ]; then
   # (-s: the guards print what they measured)
   timeout 1500 python3 -m pytest tests -m gpu_perf -s -q > $OUT/gpu_perf.log 2>&1

@@ -83,28 +83,6 @@ def main():
                 key = "series" if off else "pipelined"
                 res[key] = min(res.get(key, 1e9), dt * 1e3)
             nifs.debug_set("no_group_pipeline", 0)
-            if funnel:   # (r03's threshold and list select -- radix over every sampled score, one block per list -- against r05's)
-                for old in (1, 0, 1, 0):
-                    nifs.debug_set("funnel_dense_sample", old)
-                    call()
-                    t0 = time.perf_counter()
-                    for _ in range(reps):
-                        call()
-                    dt = (time.perf_counter() - t0) / reps * 1e3
-                    key = "dense_sample_ms" if old else "pipelined"
-                    res[key] = min(res.get(key, 1e9), dt)
-                nifs.debug_set("funnel_dense_sample", 0)
-            if kind == "quantized":   # (its groups were queued behind each other on ONE stream before r05's second context)
-                for streams in (1, 0, 1, 0):
-                    nifs.debug_set("qgroup_streams", streams)
-                    call()
-                    t0 = time.perf_counter()
-                    for _ in range(reps):
-                        call()
-                    dt = (time.perf_counter() - t0) / reps * 1e3
-                    key = "one_stream" if streams else "pipelined"
-                    res[key] = min(res.get(key, 1e9), dt)
-                nifs.debug_set("qgroup_streams", 0)
             got = call(keep=True)
             for i in (0, 7, 8, nq // 2, nq - 1):
                 assert got[i] == single(i), (name, nq, i)

@@ -22,7 +22,7 @@ def main():
     rows = int(os.environ.get("ROWS", 2_000_000))
     dim = int(os.environ.get("DIM", 768))
     nifs.debug_set("batch_no_mfma", 1)
-    nifs.debug_set("no_sweep_groups", 1)   # (K1m itself: since r05 wide rows of a large corpus would go to K1p)
+    # (since r05 wide rows of a corpus of 2 GB and more go to K1p: K1m itself is what DIM=384, or ROWS below 650 000 at 768, shows)
     rng = np.random.default_rng(0)
     for metric in (int(m) for m in os.environ.get("METRICS", "5,2,0,7").split(",")):
         x = build_shard(torch, torch.device("cuda", 0), rows, dim, 99)

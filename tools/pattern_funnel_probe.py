@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """funnel_search under float hamming / jaccard: stage 1 from the prefix of the non-zero-bit column (K4 with a
-prefix mask) against the same call with the column switched off (VT_NO_PATTERN_BITS=1: K1 over the rows' prefixes).
-One JSON line per metric.  ROWS / DIM / PREFIX env.  Diagnostic only."""
+prefix mask).  One JSON line per metric.  (Through r05 a second leg ran the same call with the column switched off --
+VT_NO_PATTERN_BITS=1, K1 over the rows' prefixes: profiles/r04_pattern_funnel_probe.jsonl, r05_pattern_funnel_probe.jsonl;
+the switch left the library in r06.)  ROWS / DIM / PREFIX env.  Diagnostic only."""
 import ctypes as C
 import json
 import os
@@ -30,7 +31,7 @@ def leg():
         x[s0:e0] *= (torch.rand((e0 - s0, dim), generator=g, device=dev) < 0.5)
     rng = np.random.default_rng(3)
     qs = (rng.uniform(-1, 1, (40, dim)) * (rng.uniform(0, 1, (40, dim)) < 0.5)).astype(np.float32)
-    out = {"bits": os.environ.get("VT_NO_PATTERN_BITS") is None, "rows": rows, "dim": dim, "prefix": prefix}
+    out = {"bits": True, "rows": rows, "dim": dim, "prefix": prefix}
     for metric in (7, 8):
         ref = nifs._flat_new(metric)
         assert nifs.flat_load_device_matrix(ref, doc_ids(0, rows), x.data_ptr(), rows, dim) == ("ok", ())
@@ -55,7 +56,4 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "leg":
         leg()
     else:
-        for env in ({}, {"VT_NO_PATTERN_BITS": "1"}):
-            e = dict(os.environ)
-            e.update(env)
-            subprocess.run([sys.executable, os.path.abspath(__file__), "leg"], env=e, check=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "leg"], env=dict(os.environ), check=True)

@@ -1,5 +1,7 @@
 """flat_search under float hamming / jaccard: the K4 pass over the non-zero-bit column against
-the K1 scan of the rows (VT_NO_PATTERN_BITS=1 in a second process).  One JSON line per metric.
+the K1 scan of the rows.  One JSON line per metric.  (The K1 leg was a second process under VT_NO_PATTERN_BITS=1, a switch
+that left the library in r06 with the other A/B switches: its numbers are profiles/r04_pattern_* / r05_pattern_*; corpora
+below 16 384 rows still take K1.)
     ROWS=10000000 D=768 python3 tools/pattern_probe.py
 """
 import json
@@ -46,7 +48,7 @@ for metric, name in ((7, "hamming"), (8, "jaccard")):
     t0 = time.perf_counter()
     nifs.flat_search_batch(ref, qs, 10)
     dt64 = time.perf_counter() - t0
-    print(json.dumps({"metric": name, "rows": rows, "d": d, "pattern_bits": os.environ.get("VT_NO_PATTERN_BITS") is None,
+    print(json.dumps({"metric": name, "rows": rows, "d": d, "pattern_bits": True,
                       "ms_per_search": round(dt * 1e3, 4), "ms_per_batch_of_16": round(dt16 * 1e3, 3), "ms_per_batch_of_64": round(dt64 * 1e3, 3),
                       "hamming_launches": prof["hamming_launches"], "hamming_ms_per_launch":
                       round(prof["hamming_ms"] / max(1, prof["hamming_launches"]), 4),

@@ -88,17 +88,13 @@ int batch_group_queue(Shard *ix, Ctx &c, BatchGroupRun &run, const float *querie
     return sp;
   };
   const uint32_t dense_cap = 65536 / rows_per_block;
-  const long tiles_setting = vt::env::get(vt::env::BATCH_SAMPLE_TILES);
-  // (K2s: 512 tiles by default -- 33 us -> 60 us of sample pass, half the candidates to rescore behind the pass)
-  SamplePlan sp = plan_sample(!shadow ? dense_cap : tiles_setting >= 64 && tiles_setting <= 512 ? (uint32_t)tiles_setting : 512u);
+  // (K2s: 512 tiles -- 33 us -> 60 us of sample pass, half the candidates to rescore behind the pass: A.15)
+  SamplePlan sp = plan_sample(!shadow ? dense_cap : 512u);
   if (!sp.by_maxima && sp.rows > 65536) sp = plan_sample(dense_cap);
   const uint32_t stride = sp.stride, ntiles_sample = sp.ntiles, sample_rows = sp.rows, rank = sp.rank, sample_groups = sp.groups;
   const bool by_maxima = sp.by_maxima;
   const uint32_t cand_cap = 8192;
-  const uint32_t kBlocksPerQuery = [] {  // blocks of the exact rescoring per query (VT_RESCORE_BLOCKS: A/B)
-    const long v = vt::env::get(vt::env::RESCORE_BLOCKS);
-    return v >= 1 && v <= 64 ? (uint32_t)v : 8u;
-  }();
+  constexpr uint32_t kBlocksPerQuery = 8;  // blocks of the exact rescoring per query (2 / 4 / 8 / 16: 339 / 241 / 171 / 168 us per 256 queries)
 
   VT_TRY(c.dBQ.ensure((size_t)nq_pad * ld));
   VT_TRY(c.hBQ.ensure((size_t)nq_pad * ld));
@@ -469,8 +465,7 @@ int multi_scan_group(Shard *ix, Ctx &c, const float *queries, const std::vector<
 bool pattern_group_applies(const Shard *ix, size_t limit) {
   const uint32_t words = ((uint32_t)ix->dim + 63) / 64;
   return pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit) && limit >= 1 &&
-         std::min<size_t>(limit, ix->n) <= (size_t)vt::kSmallK && vt::pattern_multi_supports((words + 1) / 2) &&
-         !vt::env::on(vt::env::NO_PATTERN_GROUPS);
+         std::min<size_t>(limit, ix->n) <= (size_t)vt::kSmallK && vt::pattern_multi_supports((words + 1) / 2);
 }
 
 // `count` queries (rows `which[i]` of `queries`) in ceil(count / 8) sweeps of the non-zero-bit
@@ -593,7 +588,7 @@ int funnel_groups(Shard *ix, Ctx &c, const float *queries, const std::vector<std
 // d = 768, N = 10 M: 4.74 / 5.74 / 4.84 ms per sweep (dot / L2 / L1) where K1m takes 5.45 / 6.13 / 5.31 -- so wide rows of
 // a corpus of 2 GB and more go to K1p as well (at d = 384 the two are level: K1m keeps those, with its two launches).
 bool sweep_group_applies(const Shard *ix, size_t limit) {
-  if (!vt::prefix_multi_supports(ix->metric) || vt::env::on(vt::env::NO_SWEEP_GROUPS)) return false;
+  if (!vt::prefix_multi_supports(ix->metric)) return false;
   const size_t stage = (size_t)ix->dim;
   if (!funnel_group_applies(ix, &stage, 1, limit, limit)) return false;
   if (vt::env::on(vt::env::FORCE_SWEEP_GROUPS)) return true;  // (tests and soaks on corpora of a few MB)
@@ -650,12 +645,11 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
         settle(g, gdone, gtau);
       }
     } else {
-      // (VT_BATCH_TAIL_CUS: CUs every pass but the last leaves to the groups around it; measured in DESIGN 5.1)
-      const long tail_cus = vt::env::get(vt::env::BATCH_TAIL_CUS);
-      const uint32_t idle = tail_cus >= 0 ? (uint32_t)tail_cus : kBatchTailCus;
+      // (kBatchTailCus: CUs every pass but the last leaves to the groups around it; the four-stage ring between groups:
+      // both measured in DESIGN 5.1 / A.15)
       auto queue = [&](size_t g) {
         return batch_group_queue(ix, *cx[g & 1], runs[g & 1], queries + groups[g].first * d, groups[g].second, limit, bf16, nullptr,
-                                 idle, !vt::env::on(vt::env::BATCH_PASS_FIVE));  // (VT_BATCH_PASS_FIVE=1: A/B)
+                                 kBatchTailCus, /*four_stages=*/true);
       };
       int st = queue(0);
       for (size_t g = 0; g < groups.size() && st == VT_OK; ++g) {

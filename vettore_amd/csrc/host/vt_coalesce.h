@@ -86,7 +86,6 @@ struct CoalesceOps {
   // a matrix-core pass carries up to 256 plain searches of the dot / L2 family; everything else
   // rides in groups of eight per sweep (K1m, the grouped Hamming and prefix passes)
   static size_t capacity(vt_flat *h, int kind) {
-    if (!vt::env::on(vt::env::COALESCE_GATHER)) return 0;  // (VT_COALESCE_GATHER=0: A/B)
     if (kind != COALESCE_SEARCH) return 8;
     const int m = h->metric;
     const bool gemm = m == VT_COSINE || m == VT_INNER_PRODUCT || m == VT_NEG_INNER_PRODUCT || m == VT_L2 || m == VT_L2_SQUARED;

@@ -18,7 +18,7 @@ int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *
   uint32_t qnz_full = 0;
   // (float hamming / jaccard: the query's non-zero bits ride along -- the stage over all rows reads the bit column)
   // (stage 1 fetches a prefix per block, the later stages and the rerank a few dozen blocks' worth: no copy)
-  VT_TRY(upload_query(c, query, n, &qnz_full, pattern_metric(ix->metric) ? 2 : 0, /*direct=*/stages[0] <= 256 && candidates <= (size_t)vt::kSelListMax));
+  VT_TRY(upload_query(c, query, n, &qnz_full, pattern_metric(ix->metric) ? 2 : 0));
   std::vector<vt::Entry> entries;
   // (`local`: the rerank keeps every candidate -- see LocalStages)
   if (funnel_fits_device(ix, stages, nstages, candidates, local ? candidates : limit)) {
@@ -88,7 +88,7 @@ int funnel_ready(Shard *ix, Ctx &c, const float *query, size_t n, const size_t *
 // `candidates` rows IS the single path's stage), later stages and the rerank are K1's batch mode over the
 // candidates (queries on grid.y), the arithmetic the single path's scan_stage_dev runs.
 bool funnel_group_applies(const Shard *ix, const size_t *stages, size_t nstages, size_t candidates, size_t limit) {
-  if (nstages == 0 || vt::env::on(vt::env::NO_FUNNEL_GROUPS)) return false;
+  if (nstages == 0) return false;
   if (ix->metric != VT_COSINE && !vt::prefix_multi_supports(ix->metric)) return false;
   const size_t k1 = std::min<size_t>(candidates, ix->n);
   if (ix->n < 16384 || k1 == 0 || k1 > (size_t)vt::kMaxFusedK || limit == 0) return false;
@@ -133,7 +133,7 @@ int funnel_group_queue(Shard *ix, Ctx &c, FunnelGroupRun &run, const float *quer
   // scores took 41 us alone and 0.4-0.7 ms beside the other context's sweep (a string of dependent trips to a
   // saturated memory: profiles/r05_funnel64_trace_excerpt.txt); this one reads 4 KB per query.  Where the rank is not
   // small against the number of tiles (small corpora: the sample is most of the rows) the dense form stays.
-  const bool by_maxima = (uint64_t)rank * 16 <= stiles && stiles <= 2048 && !vt::env::on(vt::env::FUNNEL_DENSE_SAMPLE);
+  const bool by_maxima = (uint64_t)rank * 16 <= stiles && stiles <= 2048;
   // one upload: full queries [nq][ld] (f32), their prefixes as f64 [8][ldq] (what stage 1 reads, through
   // the scalar cache; ld and ldq are multiples of 64, so the block stays 32-byte aligned), list lengths
   const bool cosine = ix->metric == VT_COSINE;
@@ -234,7 +234,7 @@ int funnel_group_queue(Shard *ix, Ctx &c, FunnelGroupRun &run, const float *quer
   if (c.profiling) VT_HIP(hipEventRecord(c.ev1, c.stream));
   VT_HIP(hipMemcpyAsync(hListCount, c.dBCount.p, vt::kCosineMultiMax * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
   VT_HIP(vt::launch_select_lists(c.dPartKeys.p, c.dPartPay.p, nq, kListCap, c.dBCount.p, k1, c.dStageB.p,
-                                 (uint32_t)sizeof(ResultBlock), c.stream, !vt::env::on(vt::env::FUNNEL_DENSE_SAMPLE)));
+                                 (uint32_t)sizeof(ResultBlock), c.stream, /*sixteen blocks per list=*/true));
   // what the acceptance test below looks at: the thresholds and the key of every list's last kept row
   // (copied out here: later stages reuse the blocks)
   VT_HIP(hipMemcpyAsync(hTau, c.dBTau.p, vt::kCosineMultiMax * sizeof(float), hipMemcpyDeviceToHost, c.stream));

@@ -114,13 +114,12 @@ int quantized_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t cand
   const uint32_t words = (d + 63) / 64;
   uint32_t qnz = 0;
   // (the distance pass fetches the query's 12 words per block, the rerank its floats for a few dozen blocks: no copy)
-  VT_TRY(upload_query(c, query, n, &qnz, true, /*direct=*/candidates <= (size_t)vt::kSelListMax));
+  VT_TRY(upload_query(c, query, n, &qnz, true));
   const size_t ncand = std::min<size_t>(candidates, ix->n);
   const size_t keep = local ? ncand : limit;
   // K4h needs integer bins in LDS, one fused select, and enough rows to be worth two passes
   const bool hist_ok = ncand <= (size_t)vt::kSelListMax && d <= vt::kHammingHistMaxDim &&
-                       (ix->n >= 16384 || ncand > (size_t)vt::kMaxFusedK) &&
-                       !vt::env::on(vt::env::HAMMING_LISTS);
+                       (ix->n >= 16384 || ncand > (size_t)vt::kMaxFusedK);
   auto run = [&](bool use_hist) -> int {
   std::vector<vt::Entry> entries, first;
   bool first_in_block = false;
@@ -233,8 +232,7 @@ bool quantized_group_applies(const Shard *ix, size_t candidates, size_t limit) {
   // (jaccard: the rerank's non-zero count of the query is one launch argument, so those go query by query -- said
   // here, before a sweep of the bit matrix has been spent on finding out)
   return ix->metric != VT_JACCARD && ix->n >= 16384 && ncand >= 1 && ncand <= (size_t)vt::kMaxFusedK && limit >= 1 && d <= vt::kHammingHistMaxDim &&
-         vt::hamming_multi_lds_bytes(d, (d + 63) / 64, 2) <= 64 * 1024 && !vt::env::on(vt::env::HAMMING_LISTS) &&
-         !vt::env::on(vt::env::NO_QUANTIZED_GROUPS) &&
+         vt::hamming_multi_lds_bytes(d, (d + 63) / 64, 2) <= 64 * 1024 &&
          (ix->metric == VT_COSINE ? (size_t)2 * ((d + 3) / 4 * 4) * 4 <= 160 * 1024 : vt::scan_lds_bytes(d, (uint32_t)std::min<size_t>(limit, ncand)) != 0);
 }
 // queries per sweep: what the nq histograms leave room for in 64 KiB of LDS
@@ -478,9 +476,9 @@ int quantized_batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, si
       // (r05) ... on TWO contexts when a second one is to be had: even groups here, odd groups there, each stream its
       // own slots.  A group is a sweep of the bits (0.20 ms for eight queries) and a tail of small kernels -- collect,
       // list select, rerank of 8 x `candidates` rows, select: 0.07 ms -- that then runs beside the other stream's sweep
-      // instead of in front of it (VT_QGROUP_STREAMS=1: the one-stream form, A/B).
+      // instead of in front of it (the one-stream form of r04 is what runs when no second context is to be had).
       const uint32_t ng = (uint32_t)groups.size();
-      SpareCtxLease spare(vt::env::get(vt::env::QGROUP_STREAMS) != 1 ? ix : nullptr);
+      SpareCtxLease spare(ix);
       if (spare.c) VT_TRY(spare.c->bind());
       Ctx *cx[2] = {&c, spare.c ? spare.c : &c};
       const uint32_t lanes = spare.c ? 2u : 1u;
@@ -513,12 +511,7 @@ int quantized_batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, si
       }
     } else {
       for (const auto &which : groups) {
-        const auto tg = std::chrono::steady_clock::now();
-        const int st = quantized_group(ix, c, queries, which, candidates, limit, out);
-        if (vt::env::on(vt::env::TRACE_QGROUP))
-          std::fprintf(stderr, "[vt] quantized group of %zu: status %d, %.3f ms\n", which.size(), st,
-                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg).count());
-        VT_TRY(settle(which, st));
+        VT_TRY(settle(which, quantized_group(ix, c, queries, which, candidates, limit, out)));
       }
     }
   }

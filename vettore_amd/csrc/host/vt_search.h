@@ -19,7 +19,7 @@ bool lazy_ranks_ok(const Shard *ix, size_t limit) {
   // (one select pass only: very wide rows leave LDS for the small candidate buffer alone)
   const size_t kmax = vt::scan_lds_bytes((uint32_t)ix->dim, vt::kMaxFusedK) ? (size_t)vt::kMaxFusedK : (size_t)vt::kSmallK;
   return !ix->ranks_clean && !ix->external_ranks && lazy_want <= kmax &&
-         ix->unranked <= std::max<size_t>(65536, ix->n / 8) && !vt::env::on(vt::env::EAGER_RANKS);
+         ix->unranked <= std::max<size_t>(65536, ix->n / 8);
 }
 
 // Float hamming and jaccard compare which coordinates are non-zero and nothing else
@@ -30,8 +30,7 @@ bool lazy_ranks_ok(const Shard *ix, size_t limit) {
 // NEED_NZBITS asks for that column and means nothing where this says no.
 constexpr size_t kPatternMinRows = 16384, kPatternMaxWant = 8 * (size_t)vt::kMaxFusedK;
 bool pattern_metric(int metric) {
-  // (VT_NO_PATTERN_BITS: A/B and the parity tests' second leg)
-  return (metric == VT_HAMMING || metric == VT_JACCARD) && !vt::env::on(vt::env::NO_PATTERN_BITS);
+  return metric == VT_HAMMING || metric == VT_JACCARD;
 }
 bool pattern_search_applies(const Shard *ix, size_t limit) {
   return pattern_metric(ix->metric) && !ix->nz_refused && ix->n >= kPatternMinRows &&
@@ -124,15 +123,7 @@ int search_ready(Shard *ix, Ctx &c, const float *query, size_t n, size_t limit, 
   // (a non-zero-bit column that is not current is simply not used: the rows always are)
   const bool by_pattern = pattern_search_applies(ix, limit) && !shard_stale(ix, NEED_NZBITS, limit);
   uint32_t qnz = 0;
-  // (a scan of few blocks reads the query straight from the pinned block: every block fetches all of it once, so only
-  // while that stays within half a megabyte over the link -- a 4 096-row corpus, not a million rows)
-  bool direct = by_pattern;
-  if (!by_pattern && limit <= (size_t)vt::kMaxFusedK && vt::scan_lds_bytes((uint32_t)ix->dim, (uint32_t)limit) != 0) {
-    const uint32_t tr = vt::scan_tile_rows(ix->n, (uint32_t)ix->dim, c.resident_waves());
-    const uint32_t blocks = c.grid_for((ix->n + tr - 1) / tr, vt::scan_lds_bytes((uint32_t)ix->dim, (uint32_t)limit));
-    direct = (size_t)blocks * ix->ld * sizeof(float) <= (512u << 10);
-  }
-  VT_TRY(upload_query(c, query, n, &qnz, by_pattern ? 2 : 0, direct));
+  VT_TRY(upload_query(c, query, n, &qnz, by_pattern ? 2 : 0));
   ScanJob j{};
   j.X = ix->dX;
   j.stride = ix->ld;

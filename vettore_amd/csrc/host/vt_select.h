@@ -92,8 +92,7 @@ constexpr uint32_t kThresholdListCap = 65536;
 
 // One scan + radix threshold, or one scan per 256 hits?  Whichever the model says is shorter.
 bool threshold_applies(size_t total, uint32_t n, double scan_bytes, double pass_fixed_s = kScanFixedS) {
-  if (total <= (size_t)vt::kMaxFusedK || total > (size_t)vt::kSelListMax || n < kThresholdMinRows ||
-      vt::env::on(vt::env::NO_THRESHOLD_SELECT))
+  if (total <= (size_t)vt::kMaxFusedK || total > (size_t)vt::kSelListMax || n < kThresholdMinRows)
     return false;
   if (vt::env::on(vt::env::FORCE_THRESHOLD_SELECT)) return true;  // tests: exercise the path on small corpora
   const double passes = std::ceil((double)total / vt::kMaxFusedK);
@@ -233,8 +232,7 @@ int run_scan(Ctx &c, const ScanJob &j, size_t want, std::vector<vt::Entry> &out,
   uint64_t lo = 0;
   bool has_lo = false;
   const size_t total = std::min<size_t>(want, j.n);
-  if (!j.gather && out.empty() && total > (size_t)vt::kSelListMax && j.n >= kThresholdMinRows &&
-      !vt::env::on(vt::env::NO_THRESHOLD_SELECT)) {
+  if (!j.gather && out.empty() && total > (size_t)vt::kSelListMax && j.n >= kThresholdMinRows) {
     vt::ScanArgs a{};
     a.X = j.X;
     a.stride = j.stride;
@@ -413,12 +411,11 @@ int run_hamming(Ctx &c, const uint64_t *bits, const uint64_t *qbits, const uint3
 // and ride behind the floats in the same copy; c.dQbits points at them.
 // with_bits == 2: the non-zero bits instead (bit set iff v[i] != 0.0: what float hamming / jaccard
 // compare, distances.rs:319-347).
-// `direct` (honoured only under VT_DIRECT_QUERY=1 -- measured in r05 and left off): no copy, the kernels read the pinned
-// block through its host mapping (c.qsrc).  For chains whose kernels fetch little of the query this takes a blit kernel,
-// its launch and the gap behind it out of the call -- and puts every block's first fetch on the link instead: a
-// 4 096-row search 38.2 us in place against 35.7 copied, quantized 52.8 / 50.7, funnel 71.7 / 66.8; N = 10 M quantized
-// 204.0 us either way (profiles/r05/latency_floor_*.jsonl).  A wash at best, so the copy stays.
-int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero, int with_bits = 0, bool direct = false) {
+// (Reading the pinned block in place through its host mapping instead of copying it -- VT_DIRECT_QUERY in r05 -- takes a
+// blit kernel and its launch out of the call and puts every block's first fetch on the link: a 4 096-row search 38.2 us
+// in place against 35.7 copied, quantized 52.8 / 50.7, funnel 71.7 / 66.8, profiles/r05/latency_floor_*.jsonl.  It lost
+// and has left the library: c.qsrc is always the device copy.)
+int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero, int with_bits = 0) {
   const uint32_t ld = vt::padded_dim((uint32_t)n);
   const size_t words = ((n + 63) / 64 + 1) / 2 * 2;  // an even count (the odd one out zero): K4 / K4h read whole word pairs
   const size_t total = (size_t)ld + (with_bits ? 2 * words : 0);  // in floats (ld is a multiple of 64: the words are 8-byte aligned)
@@ -438,13 +435,8 @@ int upload_query(Ctx &c, const float *q, size_t n, uint32_t *q_nonzero, int with
       if (with_bits == 2 ? q[i] != 0.0f : q[i] >= 0.0f) w[i / 64] |= 1ull << (i % 64);
   }
   c.qbits_kind = with_bits;
-  float *mapped = direct && vt::env::on(vt::env::DIRECT_QUERY) ? c.hQ.mapped() : nullptr;
-  if (mapped) {
-    c.qsrc = mapped;
-  } else {
-    c.qsrc = c.dQ.p;
-    VT_HIP(hipMemcpyAsync(c.dQ.p, c.hQ.p, total * sizeof(float), hipMemcpyHostToDevice, c.stream));
-  }
+  c.qsrc = c.dQ.p;
+  VT_HIP(hipMemcpyAsync(c.dQ.p, c.hQ.p, total * sizeof(float), hipMemcpyHostToDevice, c.stream));
   if (with_bits) c.dQbits = reinterpret_cast<uint64_t *>(const_cast<float *>(c.qsrc) + ld);
   return VT_OK;
 }

@@ -401,30 +401,16 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   // caller's matrix is read from host memory ONCE (a checker of its own read the same 30 GB beside them, and both slowed
   // down together: 0.85-1.04 s for the rows of 10 M x 768) -- and publish how far the batch is known to be finite
   // (`verified`); the id thread follows that mark and TAKES BACK what it inserted if a later row fails (rollback below:
-  // flat.rs:69-85 stores nothing of a rejected batch).  VT_INGEST_SEPARATE_CHECK=1: the r04 first form, a checker on 32
-  // threads beside the copy, the ids only once it has passed.
-  const bool fused = src.unvalidated && !vt::env::on(vt::env::INGEST_SEPARATE_CHECK);
+  // flat.rs:69-85 stores nothing of a rejected batch).  (r04's first form -- a checker on 32 threads beside the copy, the ids
+  // only once it had passed -- left the library in r06.)
+  const bool fused = src.unvalidated;
   std::atomic<int> checked{src.unvalidated ? 0 : 1};  // 0 running, 1 passed, 2 failed
   std::atomic<size_t> verified{src.unvalidated ? (size_t)0 : count};  // rows [0, verified) are known to be finite
   std::atomic<bool> aborted{false};                   // the copy gave up (device error): nobody will finish the check
   std::atomic<size_t> ids_done{0};                    // ids the id thread has placed (the lock-step test hook waits on it)
   std::atomic<bool> id_exited{false};
   std::atomic<bool> id_failed_early{false};           // the id thread could not even reserve its room: the copy need not go on
-  std::thread checker;
   double t_checked = 0.0;
-  if (src.unvalidated && !fused)
-    checker = std::thread([&] {
-      std::atomic<bool> bad{false};
-      parallel_for(count, 8192, [&](size_t lo, size_t hi) {
-        for (size_t i = lo; i < hi && !bad.load(std::memory_order_relaxed); i += 256) {
-          const size_t e = std::min(hi, i + 256);
-          if (!all_finite_bits(src.host + i * d, (e - i) * d)) bad.store(true);
-        }
-      }, 32u);
-      t_checked = since();
-      if (!bad.load()) verified.store(count, std::memory_order_release);
-      checked.store(bad.load() ? 2 : 1);
-    });
   // (1a) the batch's ids in bytewise order, for the ranking behind the id table: needs nothing but the bytes, so it starts
   // now (ids that arrive in order -- a snapshot rebuild sorts by id, collection.ex:427-433 -- are found out in one pass)
   std::vector<uint32_t> batch_order;
@@ -457,7 +443,6 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   std::thread mapper;
   bool progressive = false;
   auto join_helpers = [&]() {
-    if (checker.joinable()) checker.join();
     if (mapper.joinable()) mapper.join();
     if (sorter.joinable()) sorter.join();
   };
@@ -621,8 +606,8 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   {
     const size_t row_bytes = (size_t)ld * sizeof(float);
     // Four pinned quarters of 128 MiB, their DMAs alternating between two streams: two copies are in flight while a
-    // third quarter is being filled (one stream = one SDMA queue: 41 GB/s of the link's 64; VT_INGEST_STREAMS=1: A/B)
-    const int kStreams = vt::env::get(vt::env::INGEST_STREAMS) == 1 ? 1 : 2;
+    // third quarter is being filled (one stream = one SDMA queue: 41 GB/s of the link's 64)
+    constexpr int kStreams = 2;
     constexpr int kQuarters = 4;
     // (VT_INGEST_STAGE_MB: tests take quarters of 1 MiB, so that a batch of a few MB crosses many of them)
     const size_t kQuarterBytes = [] {  // (read per call: tests set it for one load)
@@ -788,7 +773,7 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
   // duplicate, or a sorted snapshot reloaded over existing ids plus new ones, kept ranks_clean and left the device
   // column without the new rows' ranks, null on a first load.)
   const uint32_t n_entry = ix->n;
-  if (src.host && !src.device && !src.off && !src.pick && count >= 65536 && !vt::env::on(vt::env::INGEST_SERIAL)) {
+  if (src.host && !src.device && !src.off && !src.pick && count >= 65536) {
     const int st = index_store_bulk_host(ix, count, ids, id_off, src, began);  // (makes room itself, beside the check)
     if (st != kRetryGeneral) return st;
   } else {

@@ -92,8 +92,6 @@ struct Ctx {
     hipDeviceProp_t prop;
     VT_HIP(hipGetDeviceProperties(&prop, dev));
     num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const long v = vt::env::get(vt::env::HAMMING_BLOCKS_PER_CU); v >= 1 && v <= 8) hamming_blocks_per_cu = (int)v;
-    if (const long v = vt::env::get(vt::env::BLOCKS_PER_CU); v >= 1 && v <= 8) blocks_per_cu = (int)v;
     VT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     VT_HIP(hipEventCreate(&ev0));
     VT_HIP(hipEventCreate(&ev1));

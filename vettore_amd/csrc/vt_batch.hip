@@ -307,204 +307,8 @@ __global__ __launch_bounds__(kRowWaves *kWave) void mfma_scores_kernel(const Bat
   }
 }
 
-// ---------------------------------------------------------------------------
-// 256-query batches, 128 x 128 register tile per wave (VT_BATCH_KERNEL=3): the four
-// waves of a block sit 2 x 2 over a 256-row x 256-query block tile, each with
-// 4 x 4 accumulator tiles (256 registers, the whole AGPR file; the epilogue spills).  A quarter chunk is
-// then 64 MFMAs fed by 4 + 4 fragment reads (the 32 x 256 shape needs 1 + 8 per 32),
-// and a chunk's DMA is 16 pieces per 256 MFMAs instead of 12 per 128: half the
-// issue slots taken from the matrix pipe.  Two 64-KiB LDS stages; a chunk lasts
-// 16 384 MFMA cycles, so chunk m+1's DMA (issued under the first three quarters of
-// chunk m) has landed when the chunk ends.
-// ---------------------------------------------------------------------------
-template <bool DENSE>
-__global__ __launch_bounds__(kRowWaves *kWave, 1) void mfma_scores_kernel3(const BatchScoreArgs a) {
-  extern __shared__ __align__(16) float qlds[];  // [2][256][32] queries, then [2][256][32] rows
-  constexpr int NS = 2, NQ = 256, kTileRowsB = 256, G = 4, T = 4;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wid >> 1, wq = wid & 1;  // row half, query half
-  const int r = lane & 31, h = lane >> 5;
-  const uint32_t nchunk = a.ld / 32;
-  const uint32_t ntiles = (a.n + kTileRowsB - 1) / kTileRowsB;
-  if (blockIdx.x >= ntiles) return;
-  const uint32_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
-
-  float tau[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) tau[t] = DENSE ? 0.f : a.tau[wq * 128 + t * 32 + r];
-
-  // DMA: 32 Q pieces + 32 X pieces of 8 rows per chunk; wave w issues pieces w*8 .. w*8+7 of
-  // each, addressed as (SGPR base of the chunk) + (32-bit lane offset), see dma16
-  constexpr int kDma = 8;
-  auto qslot = [&](uint32_t q, uint32_t s) { return s ^ ((q >> 1) & 7); };
-  uint32_t qoff[kDma], xoff[kDma];
-#pragma unroll
-  for (int i = 0; i < kDma; ++i) {
-    const uint32_t qrow = (uint32_t)(wid * kDma + i) * 8 + (lane >> 3);
-    qoff[i] = (qrow * a.ld + qslot(qrow, lane & 7) * 4) * 4;
-  }
-  float *xlds0 = qlds + NS * (NQ * kQStride);
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)qlds;
-  const char *xbase = nullptr;  // first row of the DMA cursor's block tile
-  const char *qb_p = nullptr, *xb_p = nullptr;  // bases of the chunk being fetched
-  auto dma_q = [&](int i, int stage) {
-    dma16(lds0 + (uint32_t)(stage * (NQ * kQStride) + (wid * kDma + i) * 8 * kQStride) * 4u, qb_p, qoff[i]);
-  };
-  auto dma_x = [&](int i, int stage) {
-    dma16(lds0 + (uint32_t)(NS * (NQ * kQStride) + stage * (kTileRowsB * kQStride) + (wid * kDma + i) * 8 * kQStride) * 4u,
-          xb_p, xoff[i]);
-  };
-  auto tile_base = [&](uint32_t k) {
-    const uint32_t tile = blockIdx.x + k * gridDim.x;
-    return (DENSE ? tile * a.sample_stride : tile) * kTileRowsB;
-  };
-  auto set_xsrc = [&](uint32_t k) {
-    const uint32_t block0 = tile_base(k);
-    const uint32_t row0 = block0 + wid * (kDma * 8);
-    xbase = reinterpret_cast<const char *>(a.X + (size_t)block0 * a.stride);
-#pragma unroll
-    for (int i = 0; i < kDma; ++i) {
-      const uint32_t xr = (uint32_t)i * 8 + (lane >> 3);  // row within this wave's 64 DMA rows
-      uint32_t grow = row0 + xr;
-      grow = grow < a.n_total ? grow : a.n_total - 1;
-      xoff[i] = ((grow - block0) * (uint32_t)a.stride + qslot(xr, lane & 7) * 4) * 4;  // (wid * 64 is a multiple of 16: same swizzle)
-    }
-  };
-  auto set_chunk = [&](uint32_t c) {
-    qb_p = reinterpret_cast<const char *>(a.Q) + (size_t)c * 128;
-    xb_p = xbase + (size_t)c * 128;
-  };
-  uint32_t dk = 0, dc = 0;  // DMA cursor; stays on the last chunk past the end
-  auto dma_advance = [&]() {
-    if (dc + 1 == nchunk && dk + 1 == my_tiles) return;
-    dc += 1;
-    if (dc == nchunk) {
-      dc = 0;
-      dk += 1;
-      set_xsrc(dk);
-    }
-  };
-  // piece p (0..15) of a chunk: 0..7 X, 8..15 Q
-  auto dma_piece = [&](int p, int stage) {
-    if (p < kDma) dma_x(p, stage);
-    else dma_q(p - kDma, stage);
-  };
-
-  set_xsrc(0);
-  set_chunk(0);
-#pragma unroll
-  for (int p = 0; p < 2 * kDma; ++p) dma_piece(p, 0);
-  dma_advance();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  f32x4 xa[G], qv[T], xa_n[G], qv_n[T];
-  auto frag_x = [&](int stage, int j, int g) {
-    const uint32_t so = qslot(r, 4 * h + j) * 4;
-    return *reinterpret_cast<const f32x4 *>(xlds0 + stage * (kTileRowsB * kQStride) + (wr * 128 + g * 32 + r) * kQStride + so);
-  };
-  auto frag_q = [&](int stage, int j, int t) {
-    const uint32_t so = qslot(r, 4 * h + j) * 4;
-    return *reinterpret_cast<const f32x4 *>(qlds + stage * (NQ * kQStride) + (wq * 128 + t * 32 + r) * kQStride + so);
-  };
-
-  int stage = 0;
-  for (uint32_t k = 0; k < my_tiles; ++k) {
-    f32x16 acc[G][T];
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[g][t][i] = 0.f;
-
-    for (uint32_t c = 0; c < nchunk; ++c) {
-      stage = __builtin_amdgcn_readfirstlane(stage);
-      const int stage_n = stage ^ 1;
-      set_chunk(dc);
-#pragma unroll
-      for (int g = 0; g < G; ++g) xa[g] = frag_x(stage, 0, g);
-#pragma unroll
-      for (int t = 0; t < T; ++t) qv[t] = frag_q(stage, 0, t);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // 64 MFMAs; under the first eight the fragments of the next quarter are read,
-        // then one DMA piece of chunk m+1 per eight MFMAs (quarters 0..2: 6 + 5 + 5)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-          for (int g = 0; g < G; ++g) {
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-              acc[g][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[g][e], qv[t][e], acc[g][t], 0, 0, 0);
-              const int m = (e * G + g) * T + t;  // 0..63 within the quarter
-              if (j < 3) {
-                if (m < G) xa_n[m] = frag_x(stage, j + 1, m);
-                else if (m < G + T) qv_n[m - G] = frag_q(stage, j + 1, m - G);
-                else if (m % 8 == 0) {
-                  const int slot = m / 8 - 1;                       // 0..6
-                  const int first = j == 0 ? 0 : (j == 1 ? 6 : 11);  // pieces 0-5, 6-10, 11-15
-                  const int count = j == 0 ? 6 : 5;
-                  if (slot < count) dma_piece(first + slot, stage_n);
-                }
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        }
-        if (j < 3) {
-#pragma unroll
-          for (int g = 0; g < G; ++g) xa[g] = xa_n[g];
-#pragma unroll
-          for (int t = 0; t < T; ++t) qv[t] = qv_n[t];
-        }
-      }
-      // my pieces of chunk m+1 have landed and my reads of chunk m are done
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      dma_advance();
-      stage = stage_n;
-    }
-
-    // epilogue: 16 tiles of 32 x 32 (C layout: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5))
-    const uint32_t base = tile_base(k) + wr * 128;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const uint32_t grow0 = base + g * 32;
-      float xn[16];
-      if (a.xnorm2) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const uint32_t row = grow0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          xn[i] = a.xnorm2[row < a.n_total ? row : a.n_total - 1];
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const uint32_t qcol = wq * 128 + t * 32 + r;
-        f32x16 v = acc[g][t];
-        if (a.xnorm2) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = 2.0f * v[i] - xn[i];
-        }
-        if (DENSE) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const uint32_t off = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const uint32_t srow = (blockIdx.x + k * gridDim.x) * kTileRowsB + wr * 128 + g * 32 + off;
-            a.sample[(size_t)qcol * a.sample_rows + srow] = grow0 + off < a.n_total ? v[i] : -INFINITY;
-          }
-        } else {
-          float mx = v[0];
-#pragma unroll
-          for (int i = 1; i < 16; ++i) mx = fmaxf(mx, v[i]);
-          if (mx >= tau[t]) append_candidates(a, v, tau[t], qcol, grow0, h);
-        }
-      }
-    }
-  }
-}
+// (r06: the 128 x 128 register-tile variant for 256-query batches -- VT_BATCH_KERNEL=3: 140 TFLOP/s, no faster than the
+// kernel above, DESIGN_APPENDIX A.3 -- has left the library)
 
 // tau_b = the `rank`-th largest of the query's sample scores (one block per query), by an
 // MSD radix select on the order-preserving u32 image of the scores: the block keeps its
@@ -756,33 +560,9 @@ hipError_t launch_scores_nt(const BatchScoreArgs &a, bool dense, uint32_t blocks
   return hipGetLastError();
 }
 
-hipError_t launch_scores3(const BatchScoreArgs &a, bool dense, uint32_t blocks, hipStream_t s) {
-  const size_t lds = (size_t)2 * (256 + 256) * kQStride * sizeof(float);
-  const dim3 block(kRowWaves * kWave);
-  if (dense) {
-    auto kern = mfma_scores_kernel3<true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
-  } else {
-    auto kern = mfma_scores_kernel3<false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), block, lds, s, a);
-  }
-  return hipGetLastError();
-}
-
-// VT_BATCH_KERNEL=3 selects the 128 x 128 register tile for 256-query batches.
-bool batch_wide_tile(uint32_t nq_pad) {
-  return env::get(env::BATCH_KERNEL) == 3 && nq_pad == 256;
-}
-
 }  // namespace
 
-uint32_t batch_rows_per_block(uint32_t nq_pad) { return batch_wide_tile(nq_pad) ? 256 : kRowWaves * 32; }
+uint32_t batch_rows_per_block(uint32_t) { return kRowWaves * 32; }
 
 hipError_t launch_batch_scores(const BatchScoreArgs &a0, bool dense, uint32_t blocks, hipStream_t s) {
   BatchScoreArgs a = a0;
@@ -792,7 +572,6 @@ hipError_t launch_batch_scores(const BatchScoreArgs &a0, bool dense, uint32_t bl
   a.debug = 0u;
 #endif
   if (a.ld % 32 != 0 || a.nq_pad % 32 != 0 || a.nq_pad == 0 || a.nq_pad > 256) return hipErrorInvalidValue;
-  if (batch_wide_tile(a.nq_pad)) return launch_scores3(a, dense, blocks, s);
   switch (a.nq_pad / 32) {
     case 1: return launch_scores_nt<1>(a, dense, blocks, s);
     case 2: return launch_scores_nt<2>(a, dense, blocks, s);

@@ -321,17 +321,11 @@ struct CosineRerankArgs {
   // q + y * q_stride, gather + y * gather_qstride and writes to out_keys / out_pay + y * n
   uint32_t q_stride, gather_qstride;
   // when set (single-query launches): only the first min(n, *n_dev) candidates exist, the other
-  // slots get the empty key -- a candidate list whose length only the device knows (launch_union_rows)
+  // slots get the empty key -- a candidate list whose length only the device knows
   const uint32_t *n_dev;
 };
 hipError_t launch_cosine_rerank(const CosineRerankArgs &a, hipStream_t s);
 hipError_t launch_cosine_rerank_batch(const CosineRerankArgs &a, uint32_t nq, hipStream_t s);
-
-// hybrid_candidates (collection.ex:515-532) on the device: the rows of `nblocks` <= 8 candidate
-// blocks (each a top-k list, so without repeats of its own), every row once, in order of first
-// appearance, to rows_out[0 .. *count_out); rows_out holds the sum of the blocks' counts.
-hipError_t launch_union_rows(const ResultBlock *blocks, uint32_t nblocks, uint32_t *rows_out, uint32_t *count_out,
-                             hipStream_t s);
 
 // Cross-shard merge on the device: `blocks` is `world` ResultBlock prefixes
 // (16-B header + k entries each, `block_bytes` apart) as gathered from the shards;
@@ -506,7 +500,7 @@ struct PrefixMultiArgs {
 };
 bool prefix_multi_supports(int metric);
 size_t prefix_multi_lds_bytes();
-int prefix_multi_blocks_per_cu();  // resident blocks per CU the launch is sized for (2; 3 with the 32-float panel, VT_PM_PANEL=32)
+int prefix_multi_blocks_per_cu();  // resident blocks per CU the launch is sized for (2)
 hipError_t launch_prefix_multi(const PrefixMultiArgs &a, uint32_t blocks, hipStream_t s);
 
 // Diagnostic (vt_device_read_peak): one pass of the bare LDS-DMA read stream over the whole 384-KiB tiles of

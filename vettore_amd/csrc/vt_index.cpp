@@ -73,14 +73,16 @@ int vt_abi_version(void) { return VT_ABI_VERSION; }
 
 int vt_debug_set(const char *name, long value) {
   const int k = vt::env::find(name);
-  if (k < 0) return VT_ERR_ARGUMENT;
+  // (a value the setting's own parser could not have produced is refused: reduce_order = 7 would hand new indexes a lane
+  // order no kernel has -- ADVICE r5)
+  if (k < 0 || !vt::env::valid(k, value)) return VT_ERR_ARGUMENT;
   vt::env::set((vt::env::Key)k, value);
   return VT_OK;
 }
 int vt_debug_get(const char *name, long *value) {
   const int k = vt::env::find(name);
   if (k < 0 || !value) return VT_ERR_ARGUMENT;
-  *value = vt::env::get((vt::env::Key)k);
+  *value = vt::env::load((vt::env::Key)k);
   return VT_OK;
 }
 
@@ -505,7 +507,7 @@ int vt_flat_load_matrix(vt_flat *h, size_t count, size_t d, const char *ids, con
   if (expected < 0 && count > 0) expected = (long)d;
   // A bulk load on a one-shard handle checks finiteness beside the copy to the device (index_store_bulk_host:
   // the index is not touched before the whole batch has passed, flat.rs:69-85); everything else here, up front.
-  const bool check_beside_copy = !h->multi() && count >= 65536 && !vt::env::on(vt::env::INGEST_SERIAL);
+  const bool check_beside_copy = !h->multi() && count >= 65536;
   if (check_beside_copy) {
     if (d == 0) return VT_ERR_EMPTY;
     if ((long)d != expected) return VT_ERR_DIMENSION;

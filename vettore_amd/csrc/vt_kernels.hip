@@ -1324,10 +1324,9 @@ __global__ __launch_bounds__(64) void cosine_rerank_kernel(const CosineRerankArg
 // floats; a panel is read with coalesced 16-B loads (4 rows x 256 B per wave
 // instruction), parked in a wave-private LDS panel S[64][68] (stride 4*odd), and
 // lane r then runs row r's two f64 chains over it -- 64 chains in parallel.
-// (r05: PANEL = 32 -- 8 wave loads of 8 rows x 128 B per panel, half the prefetch registers -- is what K1p and K6bm run on;
-// the single-query kernel takes the setting too: VT_CS_PANEL, DESIGN_APPENDIX A.15)
-constexpr int kCsRows = 64;
-inline int cosine_scan_multi_panel() { return env::get(env::CS_PANEL) == 64 ? 64 : 32; }
+// (r05: PANEL = 32 -- 8 wave loads of 8 rows x 128 B per panel, half the prefetch registers -- is what K1p, K6bm and this
+// kernel run on, DESIGN_APPENDIX A.15; r06: the 64-float builds of r04 have left the library)
+constexpr int kCsRows = 64, kCsPanelFloats = 32;
 
 template <int CAP, int PANEL>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_kernel(const CosineScanArgs a) {
@@ -1911,60 +1910,6 @@ hipError_t launch_gather_rows(const float *src, uint32_t d, const uint32_t *map,
   return hipGetLastError();
 }
 
-// One block.  Entry (g, j) survives when no block before g holds its row (a block's own rows are
-// distinct: it is a top-k list); survivors keep their order.
-__global__ __launch_bounds__(1024) void union_rows_kernel(const ResultBlock *blocks, uint32_t nblocks, uint32_t *rows_out,
-                                                          uint32_t *count_out) {
-  __shared__ __align__(16) uint32_t s_rows[8 * kMaxFusedK];
-  __shared__ uint32_t s_wave[16];
-  __shared__ uint32_t s_base;
-  const uint32_t total = nblocks * (uint32_t)kMaxFusedK;
-  for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
-    const uint32_t g = e / kMaxFusedK, j = e % kMaxFusedK;
-    s_rows[e] = j < blocks[g].count ? blocks[g].e[j].row : 0xFFFFFFFFu;
-  }
-  if (threadIdx.x == 0) s_base = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  for (uint32_t e0 = 0; e0 < total; e0 += blockDim.x) {
-    const uint32_t e = e0 + threadIdx.x;
-    const uint32_t row = e < total ? s_rows[e] : 0xFFFFFFFFu;
-    bool keep = row != 0xFFFFFFFFu;
-    const uint32_t before = e < total ? (e / kMaxFusedK) * kMaxFusedK : 0u;  // entries of earlier blocks
-    // (no early exit: sixteen rows per step, four independent 16-byte LDS reads in flight -- a loop
-    // that stops at the first match waits out one LDS round trip per row: 35 us for three blocks)
-    for (uint32_t o = 0; o < before; o += 16) {
-      const uint4 r0 = *reinterpret_cast<const uint4 *>(s_rows + o), r1 = *reinterpret_cast<const uint4 *>(s_rows + o + 4),
-                  r2 = *reinterpret_cast<const uint4 *>(s_rows + o + 8), r3 = *reinterpret_cast<const uint4 *>(s_rows + o + 12);
-      keep = keep && r0.x != row && r0.y != row && r0.z != row && r0.w != row && r1.x != row && r1.y != row && r1.z != row &&
-             r1.w != row && r2.x != row && r2.y != row && r2.z != row && r2.w != row && r3.x != row && r3.y != row &&
-             r3.z != row && r3.w != row;
-    }
-    const uint64_t m = __ballot(keep);
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t pos = s_base;
-    for (int w = 0; w < wave; ++w) pos += s_wave[w];
-    pos += (uint32_t)__popcll(m & ((1ull << lane) - 1));
-    if (keep) rows_out[pos] = row;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t sum = 0;
-      for (int w = 0; w < 16; ++w) sum += s_wave[w];
-      s_base += sum;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *count_out = s_base;
-}
-
-hipError_t launch_union_rows(const ResultBlock *blocks, uint32_t nblocks, uint32_t *rows_out, uint32_t *count_out,
-                             hipStream_t s) {
-  if (nblocks == 0 || nblocks > 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(union_rows_kernel, dim3(1), dim3(1024), 0, s, blocks, nblocks, rows_out, count_out);
-  return hipGetLastError();
-}
-
 hipError_t launch_cosine_rerank(const CosineRerankArgs &a, hipStream_t s) { return launch_cosine_rerank_batch(a, 1, s); }
 
 hipError_t launch_cosine_rerank_batch(const CosineRerankArgs &a, uint32_t nq, hipStream_t s) {
@@ -2130,28 +2075,22 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void cosine_scan_multi_kerne
   }
 }
 
-size_t cosine_scan_multi_lds_bytes() { return (size_t)kWavesPerBlock * kCsRows * (cosine_scan_multi_panel() + 4) * sizeof(float); }
+size_t cosine_scan_multi_lds_bytes() { return (size_t)kWavesPerBlock * kCsRows * (kCsPanelFloats + 4) * sizeof(float); }
 
 hipError_t launch_cosine_scan_multi(const CosineScanMultiArgs &a, uint32_t blocks, hipStream_t s) {
   const size_t lds = cosine_scan_multi_lds_bytes();
   if (!a.Qd || ((uintptr_t)a.Qd & 31) || a.nq == 0 || a.nq > kCosineMultiMax || a.n == 0 || a.d == 0) return hipErrorInvalidValue;
   if (a.sample ? (a.sample_stride == 0 || a.sample_rows == 0) : (!a.tau || !a.cand_keys || !a.cand_pay || !a.cand_count))
     return hipErrorInvalidValue;
-  if (cosine_scan_multi_panel() == 64) {
-    hipError_t e = allow_lds(cosine_scan_multi_kernel<64>, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cosine_scan_multi_kernel<64>, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
-    return hipGetLastError();
-  }
-  hipError_t e = allow_lds(cosine_scan_multi_kernel<32>, lds);
+  hipError_t e = allow_lds(cosine_scan_multi_kernel<kCsPanelFloats>, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(cosine_scan_multi_kernel<32>, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+  hipLaunchKernelGGL(cosine_scan_multi_kernel<kCsPanelFloats>, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
   return hipGetLastError();
 }
 
 size_t cosine_scan_lds_bytes(uint32_t d, uint32_t k) {
   const size_t buf = k <= (uint32_t)kSmallK ? WaveTopK<kCapSmall>::lds_bytes() : WaveTopK<kCapLarge>::lds_bytes();
-  const size_t bytes = ((size_t)padded_dim(d) + (size_t)kWavesPerBlock * kCsRows * (cosine_scan_multi_panel() + 4)) * sizeof(float) +
+  const size_t bytes = ((size_t)padded_dim(d) + (size_t)kWavesPerBlock * kCsRows * (kCsPanelFloats + 4)) * sizeof(float) +
                        kWavesPerBlock * buf;
   return bytes <= kMaxLds ? bytes : 0;
 }
@@ -2159,15 +2098,14 @@ size_t cosine_scan_lds_bytes(uint32_t d, uint32_t k) {
 hipError_t launch_cosine_scan(const CosineScanArgs &a, uint32_t blocks, hipStream_t s) {
   const size_t lds = cosine_scan_lds_bytes(a.d, a.k);
   if (lds == 0 || a.k == 0 || a.k > (uint32_t)kMaxFusedK || a.n == 0) return hipErrorInvalidValue;
-  const bool narrow = cosine_scan_multi_panel() == 32;
   auto go = [&](auto kern) -> hipError_t {
     hipError_t e = allow_lds(kern, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
     return hipGetLastError();
   };
-  if (a.k <= (uint32_t)kSmallK) return narrow ? go(cosine_scan_kernel<kCapSmall, 32>) : go(cosine_scan_kernel<kCapSmall, 64>);
-  return narrow ? go(cosine_scan_kernel<kCapLarge, 32>) : go(cosine_scan_kernel<kCapLarge, 64>);
+  if (a.k <= (uint32_t)kSmallK) return go(cosine_scan_kernel<kCapSmall, kCsPanelFloats>);
+  return go(cosine_scan_kernel<kCapLarge, kCsPanelFloats>);
 }
 
 // The yardstick bench.py quotes beside the 8 TB/s spec figure (vt_device_read_peak): a read-only

@@ -238,21 +238,15 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void prefix_multi_kernel(con
   }
 }
 
-// (r05: 32-float panels are the default -- alternating in one process they are 1-7 % ahead of the 64-float ones at every
-// prefix length and metric, 7 % at full width under dot: DESIGN_APPENDIX A.15; VT_PM_PANEL=64: the r04 form, A/B)
-int prefix_multi_panel() { return env::get(env::PM_PANEL) == 64 ? 64 : 32; }
+// (r05: 32-float panels -- alternating in one process they were 1-7 % ahead of the 64-float ones of r04 at every prefix
+// length and metric, 7 % at full width under dot: DESIGN_APPENDIX A.15; r06: the 64-float build has left the library)
+constexpr int kPmPanel = 32;
 
 template <int OP, int ORDER>
 hipError_t launch_pm(const PrefixMultiArgs &a, uint32_t blocks, size_t lds, hipStream_t s) {
-  if (prefix_multi_panel() == 32) {
-    hipError_t e = allow_lds(prefix_multi_kernel<OP, ORDER, 32>, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((prefix_multi_kernel<OP, ORDER, 32>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
-    return hipGetLastError();
-  }
-  hipError_t e = allow_lds(prefix_multi_kernel<OP, ORDER, 64>, lds);
+  hipError_t e = allow_lds(prefix_multi_kernel<OP, ORDER, kPmPanel>, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((prefix_multi_kernel<OP, ORDER, 64>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
+  hipLaunchKernelGGL((prefix_multi_kernel<OP, ORDER, kPmPanel>), dim3(blocks), dim3(kWavesPerBlock * kWave), lds, s, a);
   return hipGetLastError();
 }
 
@@ -272,12 +266,8 @@ bool prefix_multi_supports(int metric) {
   return metric == M_L2 || metric == M_L2SQ || metric == M_IP || metric == M_NIP || metric == M_L1 || metric == M_LINF;
 }
 
-size_t prefix_multi_lds_bytes() { return (size_t)kWavesPerBlock * kPmRows * (prefix_multi_panel() + 4) * sizeof(float); }
-int prefix_multi_blocks_per_cu() {
-  const long v = env::get(env::PM_BLOCKS);  // (VT_PM_BLOCKS: A/B)
-  if (v >= 1 && v <= 4) return (int)v;
-  return 2;  // (three or four blocks of the narrow panel fit a CU, and are slower: A.15)
-}
+size_t prefix_multi_lds_bytes() { return (size_t)kWavesPerBlock * kPmRows * (kPmPanel + 4) * sizeof(float); }
+int prefix_multi_blocks_per_cu() { return 2; }  // (three or four blocks of the narrow panel fit a CU, and are slower: A.15)
 
 hipError_t launch_prefix_multi(const PrefixMultiArgs &a, uint32_t blocks, hipStream_t s) {
   if (!prefix_multi_supports(a.metric) || !a.Q || ((uintptr_t)a.Q & 31) || a.q_stride % 8 != 0 || a.q_stride < a.d || a.nq == 0 ||

@@ -628,9 +628,8 @@ constexpr size_t mq_lds(bool slim) {
 }
 // which launches take the slim build: see launch_multi_op
 inline bool mq_slim(uint32_t d, uint32_t k, int metric) {
-  const bool off = env::on(env::MULTI_NO_SLIM);  // A/B
   const int op = metric_op(metric);
-  return !off && d % kRowAlign == 0 && k <= kMqSlimMaxK && (op == OP_DOT || op == OP_L2 || op == OP_L1 || op == OP_LINF);
+  return d % kRowAlign == 0 && k <= kMqSlimMaxK && (op == OP_DOT || op == OP_L2 || op == OP_L1 || op == OP_LINF);
 }
 
 template <int OP, int ORDER, bool FAST, bool TAILED = false, bool SLIM = false, int PACK = 1>
@@ -650,11 +649,9 @@ static hipError_t launch_multi_op(const MultiScanArgs &a, uint32_t blocks, hipSt
   // groups of four -- the variants measured in DESIGN 4.4.  Other lengths (d = 100, 300, 1000 ...)
   // take the same scheduled-load kernels compiled with the tail handling in (it costs the
   // aligned shapes 9 %, so they do not carry it): padding is zero in rows and queries alike,
-  // the scalar tail's products are filed beside the chunk sums.  The variant with run-time lane
-  // order and compiler-scheduled loads stays as an A/B switch (VT_MULTI_GENERAL).
-  const bool general = env::on(env::MULTI_GENERAL);
+  // the scalar tail's products are filed beside the chunk sums.  (The variant with run-time lane order and
+  // compiler-scheduled loads -- 2.2-2.7x slower, VT_MULTI_GENERAL through r05 -- has left the library.)
   if (a.d % kRowAlign != 0) {
-    if (general) return launch_multi_t<OP, ORDERED ? -1 : 0, false>(a, blocks, s);
     if (!ORDERED || a.order == 0) return launch_multi_t<OP, 0, true, true>(a, blocks, s);
     if (a.order == 1) return launch_multi_t<OP, ORDERED ? 1 : 0, true, true>(a, blocks, s);
     if (a.order == 2) return launch_multi_t<OP, ORDERED ? 2 : 0, true, true>(a, blocks, s);
@@ -664,9 +661,8 @@ static hipError_t launch_multi_op(const MultiScanArgs &a, uint32_t blocks, hipSt
     if (mq_slim(a.d, a.k, a.metric)) {
       // a last panel of 128 or 64 floats (d = 384, 128, 64, 320 ...): two or four rows per load there
       // (the default lane order only: two more builds per operation)
-      const bool no_pack = env::on(env::MULTI_NO_PACK);  // A/B
       constexpr int kOrd = ORDERED ? kDefaultReduceOrder : 0;
-      if (!no_pack && (!ORDERED || a.order == kDefaultReduceOrder)) {
+      if (!ORDERED || a.order == kDefaultReduceOrder) {
         if (a.ld % kMqPanel == 128) return launch_multi_t<OP, kOrd, true, false, true, 2>(a, blocks, s);
         if (a.ld % kMqPanel == 64) return launch_multi_t<OP, kOrd, true, false, true, 4>(a, blocks, s);
       }
