@@ -238,3 +238,64 @@ def test_every_id_placed_before_the_bad_row_is_taken_back(nifs, oracle_mod, requ
     check(nifs, oracle_mod, g, 0, x, ids, 53)
     unwrap(nifs.flat_load_matrix(g.ref, ids_more, more))
     check(nifs, oracle_mod, g, 0, np.concatenate([x, more]), ids + ids_more, 54)
+
+
+def test_a_row_is_seen_by_every_reader_the_moment_its_insert_has_returned(nifs, oracle_mod):
+    """One-row inserts, upserts and deletes return with their copies QUEUED (round 6: the landing ring, host/vt_types.h):
+    readers on other contexts make their streams wait for the newest mutation's event.  So, round after round: a row is
+    upserted to equal a query (or inserted under a new id, or the previous best hit deleted), and the moment the call is
+    back four threads search -- each on a context of its own, the primary one and three leased ones -- and every one of
+    them must already see it: hits equal to the oracle's over the rows as they now are, bit for bit.  flat.rs:59-93 under
+    nifs.rs:259-309's lock: a write that has returned is visible to every later read."""
+    import threading
+    n, d, metric = 6000, 96, 3
+    rng = np.random.default_rng(31)
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    ids = [b"doc-%05d" % i for i in range(n)]
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    want = oracle_mod.FlatIndex(metric)
+    want.insert_matrix(ids, x)
+    barrier = threading.Barrier(5)
+    state = {"q": None, "stop": False, "bad": []}
+
+    def reader(t):
+        while True:
+            barrier.wait()                       # the writer's call has returned
+            if state["stop"]:
+                return
+            got = unwrap(nifs.flat_search(g.ref, state["q"], 5))
+            if bits(got) != state["want"]:
+                state["bad"].append((t, state["step"]))
+            barrier.wait()                       # everybody has looked
+
+    ths = [threading.Thread(target=reader, args=(t,)) for t in range(4)]
+    for th in ths:
+        th.start()
+    try:
+        for step in range(120):
+            q = (rng.uniform(-1, 1, d) * 3.0).astype(np.float32)
+            kind = step % 3
+            if kind == 0:      # upsert an existing row to be the query's best hit
+                key = ids[int(rng.integers(0, n))]
+                unwrap(nifs.flat_insert(g.ref, key, q))
+                want.insert(key, q)
+            elif kind == 1:    # a new id
+                key = b"new-%04d" % step
+                unwrap(nifs.flat_insert(g.ref, key, q))
+                want.insert(key, q)
+            else:              # delete the row the last round made the best hit (the last row moves into its place)
+                unwrap(nifs.flat_delete(g.ref, last_key))
+                want.delete(last_key)
+                q = last_q
+            last_key, last_q = key, q
+            state.update(q=q, want=bits(want.search(q, 5)), step=step)
+            barrier.wait()
+            barrier.wait()
+    finally:
+        state["stop"] = True
+        barrier.wait()
+        for th in ths:
+            th.join()
+    assert not state["bad"], state["bad"][:5]
+    assert len(g) == len(want)

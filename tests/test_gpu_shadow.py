@@ -186,6 +186,31 @@ def test_no_room_for_the_shadow_means_streaming_the_rows(nifs, oracle_mod, reque
     assert prof["nominate_launches"] == 2 and prof["nominate_shadow_launches"] == 0 and prof["shadow_builds"] == 0, prof
 
 
+def test_a_second_context_that_cannot_get_its_scratch_is_dropped(nifs, oracle_mod, request, vt_debug):
+    """A batch call of several 256-query groups alternates between two contexts (round 5), which roughly doubles its device
+    and pinned scratch.  When the second context's buffers do not fit -- a card nearly filled by corpus and shadow -- the
+    call must go on in series on the first one, as it did before there was a second, not fail.
+    (test_refuse_spare_scratch, libvettore_hip_hooks.so only: the test re-runs itself there.)"""
+    if support.rerun_with_hooks_library(request):
+        return
+    vt_debug.set("force_batch_mfma", 1)
+    n, d, metric = 20000, 128, 3
+    x, ids = make_corpus(n, d, 515, False, oracle_mod, tie_block=30)
+    g = GpuIndex(nifs, metric)
+    unwrap(nifs.flat_load_matrix(g.ref, ids, x))
+    nifs.flat_set_profiling(g.ref, False)
+    qs = np.random.default_rng(8).uniform(-1, 1, size=(700, d)).astype(np.float32)
+    qs[0], qs[300], qs[699] = x[n // 2], x[n // 2 + 3], x[n // 2]
+    both = unwrap(nifs.flat_search_batch(g.ref, qs, 10))           # two contexts
+    vt_debug.set("test_refuse_spare_scratch", 1)
+    alone = unwrap(nifs.flat_search_batch(g.ref, qs, 10))          # the second one refused: in series on the first
+    vt_debug.set("test_refuse_spare_scratch", 0)
+    assert [bits(h) for h in alone] == [bits(h) for h in both]
+    packed = oracle_mod.pack_ids(ids)
+    for i in (0, 255, 256, 300, 511, 512, 699):
+        assert bits(alone[i]) == bits(oracle_mod.matrix_search(metric, x, packed, qs[i], 10)), i
+
+
 def test_rows_that_round_to_infinity_through_the_shadow(nifs, oracle_mod, monkeypatch, vt_debug):
     """f32's largest values round to +inf in bf16 -- in the shadow as in K2b's registers: inf * 0 = NaN
     nominates nothing, the handle's largest row norm keeps such a corpus from ever being certified,

@@ -15,12 +15,12 @@ secs() { python3 -c "print(max(20, int($1 * $S)))"; }
 # concatenated into profiles/<round>/gpu_suite_runs.log.
 if [ "${SUITE:-0}" != "0" ]; then
   LEASE=$(date -u +%Y%m%dT%H%M%SZ)
-  GPUID=$(rocm-smi --showuniqueid 2>/dev/null | grep -i -m1 "unique id" | sed 's/.*: *//')
+  GPUID=$(rocm-smi --showuniqueid 2>/dev/null | grep -i "unique id" | grep -v "====" | head -1 | sed 's/.*: *//')
   for i in $(seq 1 $SUITE); do
     t0=$(date +%s)
     timeout 1700 python3 -m pytest tests -m gpu -x -q -p no:cacheprovider > $OUT/suite_${LEASE}_$i.full 2>&1
     rc=$?
-    echo "$(date -u +%Y-%m-%dT%H:%MZ) lease $LEASE gpu ${GPUID:-?} run $i: rc $rc, $(tail -1 $OUT/suite_${LEASE}_$i.full) [wall $(( $(date +%s) - t0 )) s, pytest -m gpu -x on $(git -C $R rev-parse --short HEAD 2>/dev/null || echo 'the tree as sent')]" | tee -a $OUT/gpu_suite_runs.$LEASE.log
+    echo "$(date -u +%Y-%m-%dT%H:%MZ) lease $LEASE gpu ${GPUID:-?} run $i: rc $rc, $(grep -E "[0-9]+ (passed|failed)" $OUT/suite_${LEASE}_$i.full | tail -1) [wall $(( $(date +%s) - t0 )) s, pytest -m gpu -x on $(git -C $R rev-parse --short HEAD 2>/dev/null || echo 'the tree as sent')]" | tee -a $OUT/gpu_suite_runs.$LEASE.log
     [ $rc -ne 0 ] && tail -60 $OUT/suite_${LEASE}_$i.full
   done
 fi

@@ -597,6 +597,11 @@ bool sweep_group_applies(const Shard *ix, size_t limit) {
   return ix->ld % 256 != 0 || !multi_scan_applies(ix, limit) || (bytes >= 2e9 && ix->ld >= 512);
 }
 
+// a status that says "a buffer could not be had" (hipMalloc / hipHostMalloc refused, or the host's allocator did)
+bool allocation_failed(int st, const std::string &why) {
+  return st == VT_ERR_NOMEM || (st == VT_ERR_DEVICE && (why.find("hipMalloc") != std::string::npos || why.find("hipHostMalloc") != std::string::npos));
+}
+
 // Rank column strictly current, norms current when batch_uses_mfma (shard_prepare).
 int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, size_t limit, vt_hits **out) {
   // every query is validated like flat_search would (flat.rs:97-101), in order
@@ -632,32 +637,44 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
       for (size_t i = 0; i < gtau.size(); ++i) tau2[groups[g].first + i] = gtau[i];
       // (a shard of a sharded handle: the lists this group settled are final -- nothing below rewrites a done query --
       // and the handle's calling thread may start merging them with the other shards' while the next groups run)
-      if (ix->batch_final)
+      if (const MergeRequest *mr = merge_request_of(ix))
         for (size_t i = 0; i < groups[g].second; ++i)
-          if (gdone[i]) ix->batch_final[groups[g].first + i].store(1, std::memory_order_release);
+          if (gdone[i]) mr->final_flags[groups[g].first + i].store(1, std::memory_order_release);
     };
-    if (!spare.c) {
-      for (size_t g = 0; g < groups.size(); ++g) {
-        std::vector<char> gdone(groups[g].second, 0);
-        std::vector<float> gtau;
-        VT_TRY(batch_group(ix, c, queries + groups[g].first * d, groups[g].second, limit, out + groups[g].first, gdone, bf16, nullptr,
-                           bf16 ? &gtau : nullptr));
-        settle(g, gdone, gtau);
-      }
-    } else {
+    // groups [in_series, end) run one after the other on `c`: all of them when there is no second context, and whatever is
+    // left when the second context could not get its scratch (below)
+    size_t in_series = spare.c ? groups.size() : 0;
+    if (spare.c) {
+      VT_TRY(reader_ready(ix, *spare.c));
       // (kBatchTailCus: CUs every pass but the last leaves to the groups around it; the four-stage ring between groups:
       // both measured in DESIGN 5.1 / A.15)
       auto queue = [&](size_t g) {
+#ifdef VT_TEST_HOOKS
+        if ((g & 1) == 1 && vt::env::on(vt::env::TEST_REFUSE_SPARE_SCRATCH))
+          return fail(VT_ERR_DEVICE, "hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T)): out of memory (injected)");
+#endif
         return batch_group_queue(ix, *cx[g & 1], runs[g & 1], queries + groups[g].first * d, groups[g].second, limit, bf16, nullptr,
                                  kBatchTailCus, /*four_stages=*/true);
       };
       int st = queue(0);
       for (size_t g = 0; g < groups.size() && st == VT_OK; ++g) {
         const int st_next = g + 1 < groups.size() ? queue(g + 1) : VT_OK;
+        const std::string why_next = st_next != VT_OK ? g_last_error : std::string();
         std::vector<char> gdone(groups[g].second, 0);
         std::vector<float> gtau;
         st = batch_group_finish(ix, *cx[g & 1], runs[g & 1], out + groups[g].first, gdone, bf16 ? &gtau : nullptr);
         if (st == VT_OK) settle(g, gdone, gtau);
+        // The second context roughly doubles a call's device and pinned scratch.  On a card nearly filled by corpus and
+        // shadow its buffers may not fit where the one-context path of r04 did: then the spare is dropped and the rest of
+        // the call runs in series on `c`, as it would have without one.  Nothing of the refused group is in
+        // flight: every buffer is ensured before the first launch of a group.
+        if (st == VT_OK && st_next != VT_OK && ((g + 1) & 1) == 1 && allocation_failed(st_next, why_next)) {
+          (void)hipStreamSynchronize(cx[1]->stream);
+          (void)hipGetLastError();
+          in_series = g + 1;
+          break;
+        }
+        if (st == VT_OK && st_next != VT_OK) g_last_error = why_next;
         if (st == VT_OK) st = st_next;
       }
       if (st != VT_OK) {  // (whatever is still queued reads and writes the two contexts' pinned blocks)
@@ -668,6 +685,13 @@ int batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, size_t d, si
         g_last_error = why;
         return st;
       }
+    }
+    for (size_t g = in_series; g < groups.size(); ++g) {
+      std::vector<char> gdone(groups[g].second, 0);
+      std::vector<float> gtau;
+      VT_TRY(batch_group(ix, c, queries + groups[g].first * d, groups[g].second, limit, out + groups[g].first, gdone, bf16, nullptr,
+                         bf16 ? &gtau : nullptr));
+      settle(g, gdone, gtau);
     }
     // K2b's second pass: a query whose k exact hits did not clear tau by the margin names the
     // threshold that its k-th hit does clear; one more pass over the rows with those thresholds

@@ -406,7 +406,7 @@ int funnel_groups(Shard *ix, Ctx &c, const float *queries, const std::vector<std
     for (const auto &which : groups) VT_TRY(settle(which, funnel_group(ix, c, queries, which, stages, nstages, candidates, limit, out, done, as_scan)));
     return VT_OK;
   }
-  VT_TRY(spare.c->bind());
+  VT_TRY(reader_ready(ix, *spare.c));
   Ctx *cx[2] = {&c, spare.c};
   FunnelGroupRun runs[2];
   auto queue = [&](size_t g) {

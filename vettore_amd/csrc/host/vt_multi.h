@@ -54,7 +54,7 @@ int read_single(vt_flat *h, unsigned need, size_t limit, F &&fn) {
     if (!shard_stale(ix, need, limit)) {
       CtxLease lease(ix);
       if (!lease.c) return lease.status;
-      VT_TRY(lease.c->bind());
+      VT_TRY(reader_ready(ix, *lease.c));
       const int st = fn(ix, *lease.c);
       if (st != kEscalate) return st;
       escalated = true;
@@ -106,7 +106,12 @@ int shard_delete(Shard *ix, const char *id, size_t id_len, bool *began) {
       }
     }
     VT_HIP(hipMemsetAsync(ix->dX + (size_t)last * ix->ld, 0, (size_t)ix->ld * sizeof(float), c.stream));
-    VT_HIP(hipStreamSynchronize(c.stream));
+    // (device-side moves only, queued on the primary stream: nothing to wait for here -- an event behind them is what
+    // readers on other streams wait for, Shard::Landing; the slot's buffer goes unused)
+    unsigned char *unused = nullptr;
+    hipEvent_t ev = nullptr;
+    VT_TRY(landing_slot(ix, &unused, &ev));
+    VT_TRY(landing_record(ix, ev));
     ix->ids.pop_back();
     ix->rank_host.pop_back();
     ix->n -= 1;
@@ -446,13 +451,11 @@ int batch_multi(vt_flat *h, const float *queries, size_t nq, size_t d, size_t li
     const unsigned need = NEED_STRICT_RANKS | NEED_NZBITS | (batch_uses_mfma(ix, nq, limit) ? NEED_NORMS : 0u);
     if (shard_stale(ix, need, limit)) VT_TRY(shard_prepare(ix, need, limit));
     // (this worker's lists go into the merge and nowhere else: they name their rows, the ids -- 2 560 string
-    // copies per 256 queries and shard -- are copied once, for the winners.  The flags are this shard's, and a
-    // shard's jobs run one at a time on its worker.)
-    ix->hits_by_row = true;
-    ix->batch_final = fin.get() + s * nq;
-    const int st = guarded([&]() -> int { return batch_ready(ix, ix->ctx, queries, nq, d, limit, per[s].data()); });
-    ix->hits_by_row = false;
-    ix->batch_final = nullptr;
+    // copies per 256 queries and shard -- are copied once, for the winners.  The request is this job's, on this thread.)
+    const int st = guarded([&]() -> int {
+      MergeRequestScope by_row(ix, fin.get() + s * nq);
+      return batch_ready(ix, ix->ctx, queries, nq, d, limit, per[s].data());
+    });
     if (st == VT_OK)
       for (size_t i = 0; i < nq; ++i) fin[s * nq + i].store(1, std::memory_order_release);
     return st;

@@ -479,7 +479,7 @@ int quantized_batch_ready(Shard *ix, Ctx &c, const float *queries, size_t nq, si
       // instead of in front of it (the one-stream form of r04 is what runs when no second context is to be had).
       const uint32_t ng = (uint32_t)groups.size();
       SpareCtxLease spare(ix);
-      if (spare.c) VT_TRY(spare.c->bind());
+      if (spare.c) VT_TRY(reader_ready(ix, *spare.c));
       Ctx *cx[2] = {&c, spare.c ? spare.c : &c};
       const uint32_t lanes = spare.c ? 2u : 1u;
       auto ctx_of = [&](uint32_t g) -> Ctx & { return *cx[g % lanes]; };

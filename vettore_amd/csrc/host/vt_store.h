@@ -409,7 +409,11 @@ int index_store_bulk_host(Shard *ix, size_t count, const char *ids, const size_t
   std::atomic<bool> aborted{false};                   // the copy gave up (device error): nobody will finish the check
   std::atomic<size_t> ids_done{0};                    // ids the id thread has placed (the lock-step test hook waits on it)
   std::atomic<bool> id_exited{false};
-  std::atomic<bool> id_failed_early{false};           // the id thread could not even reserve its room: the copy need not go on
+  // the id thread could not even reserve its room: the copy need not go on.  (Error precedence, ADVICE r5: the check rides on
+  // the copy, so a batch that ALSO holds a non-finite row behind the point the copy had reached reports the host's
+  // "out of memory", not flat.rs:69-85's "vector contains a non-finite value".  Either way nothing of the batch is stored;
+  // the reference, whose id table is a hash map that aborts the VM when it cannot grow, has no such case to order.)
+  std::atomic<bool> id_failed_early{false};
   double t_checked = 0.0;
   // (1a) the batch's ids in bytewise order, for the ranking behind the id table: needs nothing but the bytes, so it starts
   // now (ids that arrive in order -- a snapshot rebuild sorts by id, collection.ex:427-433 -- are found out in one pass)
@@ -837,6 +841,8 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
   }
   const uint32_t ld = ix->ld;
   bool pending = false;
+  unsigned char *land_buf = nullptr;  // a trickle's slot of the landing ring, and the event behind its copies
+  hipEvent_t land_ev = nullptr;
   if (src.device) {
     bool picks_dense = true;  // the batch is one contiguous block of the source
     if (src.pick)
@@ -923,6 +929,28 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
       VT_HIP(hipStreamSynchronize(c.stream));  // (map and dMap die with this scope)
     }
     VT_HIP(hipStreamSynchronize(c.stream));
+  } else if ((size_t)count * ((size_t)ld * sizeof(float) + sizeof(uint32_t)) <= Shard::Landing::kSlotBytes) {
+    // A trickle (Vettore.put/2 record by record; up to 21 rows of 768 floats): the rows are staged in a slot of the landing
+    // ring, their copies queued, and the call returns without waiting for them (Shard::Landing, host/vt_types.h): readers
+    // on other streams wait for the slot's event on the device.  The rows' ranks, if they are to go up now, ride in
+    // the same slot behind the rows (below).
+    const size_t row_bytes = (size_t)ld * sizeof(float);
+    VT_TRY(landing_slot(ix, &land_buf, &land_ev));
+    float *stage = reinterpret_cast<float *>(land_buf);
+    for (size_t j = 0; j < count; ++j) {
+      const size_t p = src.pick ? src.pick[j] : j;
+      const float *row = src.off ? src.host + src.off[p] : src.host + p * src.d;
+      float *dst = stage + j * ld;
+      std::memcpy(dst, row, d * sizeof(float));
+      for (size_t t = d; t < ld; ++t) dst[t] = 0.0f;
+    }
+    for (size_t j = 0; j < count;) {
+      size_t e = j + 1;
+      while (e < count && target[e] == target[e - 1] + 1) ++e;
+      VT_HIP(hipMemcpyAsync(ix->dX + (size_t)target[j] * ld, stage + j * ld, (e - j) * row_bytes, hipMemcpyHostToDevice, c.stream));
+      j = e;
+    }
+    pending = true;
   } else {
     // two pinned staging halves: host threads fill one (rows padded to ld) while the DMA
     // of the other is in flight; runs of consecutive target rows go in one copy
@@ -979,21 +1007,29 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
       VT_TRY(ix->dRank.ensure(std::max<size_t>(ix->cap, ix->n)));
       from = 0;
     }
-    if (ix->n - from <= 64) {
-      // a trickle of sorted appends (Vettore.put/2 record by record: one rank per call): through a pinned block of
-      // its own (rank_host is pageable: the runtime would stage the copy itself).  One appended row is 21 us, an
-      // upsert 15 (tools/insert_probe.py, VT_TRACE_INGEST=2): the row's copy, this one, one wait
+    if (land_ev && ix->n - from <= count) {
+      // a trickle of sorted appends (one rank per call): the ranks ride in the landing slot, behind the rows
+      uint32_t *ranks = reinterpret_cast<uint32_t *>(land_buf + (size_t)count * ld * sizeof(float));
+      std::memcpy(ranks, ix->rank_host.data() + from, (size_t)(ix->n - from) * sizeof(uint32_t));
+      VT_HIP(hipMemcpyAsync(ix->dRank.p + from, ranks, (size_t)(ix->n - from) * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+    } else if (ix->n - from <= 64) {
+      // a few sorted appends: through a pinned block of their own (rank_host is pageable: the runtime would stage the
+      // copy itself), waited for below
+      land_ev = nullptr;
       VT_TRY(c.hRankStage.ensure(64));
       std::memcpy(c.hRankStage.p, ix->rank_host.data() + from, (size_t)(ix->n - from) * sizeof(uint32_t));
       VT_HIP(hipMemcpyAsync(ix->dRank.p + from, c.hRankStage.p, (size_t)(ix->n - from) * sizeof(uint32_t), hipMemcpyHostToDevice,
                             c.stream));
     } else {
+      land_ev = nullptr;  // (a copy from pageable memory: waited for below)
       VT_HIP(hipMemcpyAsync(ix->dRank.p + from, ix->rank_host.data() + from, (size_t)(ix->n - from) * sizeof(uint32_t),
                             hipMemcpyHostToDevice, c.stream));
     }
     pending = true;
   }
-  if (pending) VT_HIP(hipStreamSynchronize(c.stream));
+  // a trickle returns with its copies queued and an event behind them; everything else waits here, once
+  if (pending && land_ev) VT_TRY(landing_record(ix, land_ev));
+  else if (pending) VT_HIP(hipStreamSynchronize(c.stream));
   const auto t_rank = std::chrono::steady_clock::now();
   if (rank_now) VT_TRY(index_sync_ranks(ix, false));
   if (trace) {
@@ -1011,7 +1047,7 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
 int make_hits(const Shard *ix, const std::vector<vt::Entry> &entries, vt_hits **out) {
   auto h = std::make_unique<vt_hits>();
   const size_t m = entries.size();
-  if (ix->hits_by_row) {
+  if (merge_request_of(ix)) {
     h->by_row_of = ix;
     h->rows.reserve(m);
     h->raw.reserve(m);

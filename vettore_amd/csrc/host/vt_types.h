@@ -66,6 +66,7 @@ struct Ctx {
   PinnedBuf<uint32_t> hShard;  // shard of each winner of a cross-shard merge (host mapped)
   uint32_t *dShardMapped = nullptr;
   PinnedBuf<unsigned char> hStage;
+  uint64_t seen_landing = 0;  // Shard::landing.seq this context's stream has been made to wait for (see_writes)
   uint32_t begin_rows = 0, begin_dim = 0;  // scan of the last vt_flat_search_begin (profiling)
   bool profiling = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -147,6 +148,28 @@ struct vt_hits {
   std::vector<uint32_t> rows;
 };
 
+// What a shard's worker asks of the batch it is about to run for a sharded handle's cross-shard merge (batch_multi): hit
+// lists that name their rows instead of copying ids, and one flag per query, set -- with release order -- once that query's
+// list is final, so that the handle's calling thread can merge the shards' lists of such queries while later groups still
+// run.  Per CALL and per THREAD (r06, ADVICE r5: these were two mutable fields of the shared Shard): the request lives on
+// the worker's stack for the length of its job, and a reader on any other thread -- a leased context, a search that
+// arrives meanwhile -- never sees it, so a by-row list cannot reach a caller.
+struct MergeRequest {
+  const Shard *shard;
+  std::atomic<unsigned char> *final_flags;  // [queries of the batch]
+};
+static thread_local const MergeRequest *t_merge_request = nullptr;
+struct MergeRequestScope {
+  MergeRequest req;
+  MergeRequestScope(const Shard *s, std::atomic<unsigned char> *flags) : req{s, flags} { t_merge_request = &req; }
+  ~MergeRequestScope() { t_merge_request = nullptr; }
+  MergeRequestScope(const MergeRequestScope &) = delete;
+  MergeRequestScope &operator=(const MergeRequestScope &) = delete;
+};
+inline const MergeRequest *merge_request_of(const Shard *ix) {
+  return t_merge_request && t_merge_request->shard == ix ? t_merge_request : nullptr;
+}
+
 // One shard = one GPU's share of the rows: the slab, its derived columns, the ids of
 // its rows.  A plain index has exactly one; vt_flat_new_sharded deals rows to several.
 struct Shard {
@@ -205,18 +228,35 @@ struct Shard {
   bool rank_dirty_all = false;
   size_t unranked = 0;  // rows carrying kUnranked: past a bound the next search rebuilds instead of going lazy
   bool external_ranks = false;      // rank column supplied by vt_flat_set_id_ranks (valid until the next mutation)
-  bool hits_by_row = false;         // make_hits leaves the ids where they are (set by this shard's worker around a batch of a sharded handle)
-  // (the same worker, the same batch) one flag per query of the batch, set -- with release order -- once that query's list
-  // is final: the handle's calling thread merges the shards' lists of such queries while later groups still run
-  std::atomic<unsigned char> *batch_final = nullptr;
   uint64_t epoch = 0;               // bumped by every mutation of the row set (insert of a new id, delete)
   uint64_t external_epoch = 0;      // epoch at which the external ranks were installed
   bool external_expected = false;   // vt_flat_set_id_ranks has been used on this shard: search_begin insists on current ranks
   std::string max_id;               // upper bound of all ids while ranks_clean
   uint32_t max_rank = 0;
 
+  // Trickle mutations land BEHIND the call (r06; the reference's flat_insert is a hash-map insert, nifs.rs:259-271).  A
+  // one-row insert, upsert or delete used to end in a wait for its copies under the exclusive lock: ~12 of its 13-25 us.
+  // Now the row (and its rank) is staged in one of eight pinned slots, the copies are queued on the primary context's
+  // stream, an event is recorded behind them and the call returns.  Whoever reads next on another stream -- a leased
+  // reader context, a second context of a grouped path -- makes that stream wait for the newest event first
+  // (see_writes: one hipStreamWaitEvent per context and mutation, no host wait; the primary stream is in order by
+  // itself).  `seq` and `newest` change under the handle's exclusive lock and are read under its shared lock.
+  struct Landing {
+    static constexpr int kSlots = 8;
+    static constexpr size_t kSlotBytes = 64u << 10;
+    PinnedBuf<unsigned char> stage;  // kSlots * kSlotBytes, on first use
+    hipEvent_t ev[kSlots] = {};
+    bool used[kSlots] = {};
+    int next = 0;
+    uint64_t seq = 0;
+    hipEvent_t newest = nullptr;
+  } landing;
+
   ~Shard() {
     (void)hipSetDevice(ctx.device);
+    if (landing.newest) (void)hipStreamSynchronize(ctx.stream);  // (copies out of the pinned slots may still be queued)
+    for (hipEvent_t e : landing.ev)
+      if (e) (void)hipEventDestroy(e);
     slab.release();
   }
 
@@ -256,6 +296,43 @@ inline std::unique_ptr<Ctx> make_reader_ctx(Shard *ix, int *status) {
 struct SpareCtxLease : vt_host::SpareLeaseT<Shard, Ctx> {
   explicit SpareCtxLease(Shard *s) : vt_host::SpareLeaseT<Shard, Ctx>(s, kMaxContexts, make_reader_ctx) {}
 };
+
+// A slot of the landing ring (Shard::Landing): its buffer once whatever was copied out of it last time has left, and the
+// event to record behind the copies queued from it.
+int landing_slot(Shard *ix, unsigned char **buf, hipEvent_t *ev) {
+  Shard::Landing &l = ix->landing;
+  if (!l.stage.p) {
+    VT_TRY(l.stage.ensure((size_t)Shard::Landing::kSlots * Shard::Landing::kSlotBytes));
+    for (hipEvent_t &e : l.ev) VT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const int s = l.next;
+  l.next = (s + 1) % Shard::Landing::kSlots;
+  if (l.used[s]) VT_HIP(hipEventSynchronize(l.ev[s]));  // (eight mutations ago: long done)
+  l.used[s] = true;
+  *buf = l.stage.p + (size_t)s * Shard::Landing::kSlotBytes;
+  *ev = l.ev[s];
+  return VT_OK;
+}
+// ... recorded: the mutation's device work is queued on the primary stream, nothing is waited for.
+int landing_record(Shard *ix, hipEvent_t ev) {
+  VT_HIP(hipEventRecord(ev, ix->ctx.stream));
+  ix->landing.newest = ev;
+  ix->landing.seq += 1;
+  return VT_OK;
+}
+// Before a reader's first kernel on a stream other than the primary one: that stream waits (on the device) for the
+// newest landed mutation.  Under the shared or the exclusive lock.
+int see_writes(Shard *ix, Ctx &c) {
+  if (&c == &ix->ctx || c.seen_landing == ix->landing.seq) return VT_OK;
+  VT_HIP(hipStreamWaitEvent(c.stream, ix->landing.newest, 0));
+  c.seen_landing = ix->landing.seq;
+  return VT_OK;
+}
+// what a reader context does before its first kernel
+int reader_ready(Shard *ix, Ctx &c) {
+  VT_TRY(c.bind());
+  return see_writes(ix, c);
+}
 
 // ---- RCCL, loaded on first use (librccl is half a gigabyte: a single-GPU index never maps it)
 struct Rccl {

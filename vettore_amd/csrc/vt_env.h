@@ -91,6 +91,7 @@ enum Parse {
   X(TEST_FAIL_AFTER_ID_UPDATE, "test_fail_after_id_update", P_FLAG, 0, "a mutation fails after it changed the id table (the handle must come out poisoned)") \
   X(TEST_INGEST_LOCKSTEP, "test_ingest_lockstep", P_FLAG, 0, "the id thread of a bulk load keeps step with the verified rows") \
   X(TEST_FOREIGN_ROWS, "test_foreign_rows", P_FLAG, 0, "device-resident rows are treated as living on another GPU (they reach a mapped slab through a staging block)") \
+  X(TEST_REFUSE_SPARE_SCRATCH, "test_refuse_spare_scratch", P_FLAG, 0, "the second context of a pipelined batch call cannot get its scratch: the call must go on in series on the first") \
   X(TEST_COALESCE_HOLD_UNTIL, "test_coalesce_hold_until", P_INT, 0, "an idle handle's first caller keeps its slot until this many callers have queued (callers MEET: `vt_callers_meet`)")
 
 enum Key : int {
