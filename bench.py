@@ -88,6 +88,8 @@ def parse():
                          "weak = --rows per GPU (N x --rows in all), reported as \"scaling\": \"weak\"")
     ap.add_argument("--shadow", choices=["auto", "off"], default="auto",
                     help="batch mode: let the bf16 pass keep a bf16 shadow of the rows (K2s) or stream the f32 rows (K2b)")
+    ap.add_argument("--config4-rows", type=int, default=5_000_000,
+                    help="--gpus 8 only: rows PER GPU of the side.config4 leg (BASELINE configs[3]: L2, N = 40 M over 8 GPUs)")
     ap.add_argument("--supervise", action="store_true",
                     help="run the measurement in a child process and, should it fail or hang, once more over the host exchange "
                          "(always on for N > 1; this flag switches it on at N = 1, with --exchange rccl|host)")
@@ -925,6 +927,174 @@ def measure_batches(a, torch, dist, nifs, _lib, L, ref, sharded, use_dist, launc
     print(json.dumps(out), flush=True)
 
 
+def config4_leg(a, torch, dist, nifs, _lib, L, rank, world, launched, devices, device, host_exchange):
+    """BASELINE configs[3] -- `index: :flat, metric: :l2, d=768, N=40M row-sharded across 8xMI355X, RCCL top-k merge` --
+    measured beside the headline when (and only when) the run is `--gpus 8` (the driver passes no flags, so
+    the one 8-GPU run there may ever be has to carry this itself): L2, --config4-rows (5 M) rows per GPU generated on the
+    device, 200 single queries and ONE call of 4 096 queries, every rank taking part; a roofline of its own (one shard's
+    scan: rows x d x 4 bytes = 15.36 GB per GPU and query) and two checks -- a batched list equals its query's single search,
+    and a brute-force pass in torch over every shard's own rows finds nothing closer than the reported hits.  Budget: well
+    under a minute at the default size between ranks (the in-process form, `--devices`, builds every shard in turn and is
+    for rehearsals with a small --config4-rows).  Returns the leg's dictionary (identical on every rank)."""
+    from vettore_amd.sharded import ShardedFlat
+    t_leg = time.perf_counter()
+    if launched and host_exchange:
+        # (the fallback child between ranks: gloo, no RCCL -- nothing of configs[3]'s "RCCL top-k merge" would be measured)
+        return {"skipped": "this child runs over the host exchange between ranks (the fallback): the config 4 leg is measured over RCCL only"}
+    rows, dim, limit = a.config4_rows, a.dim, a.limit
+    metric = nifs.METRIC_CODE["l2"]
+    n_gpus = world if launched else len(devices)
+    total = rows * n_gpus
+    nsingle, nbatch = 200, 4096
+    rng = np.random.default_rng(SEED_QUERY + 4)
+    qs = rng.uniform(-1, 1, size=(nsingle, dim)).astype(np.float32)
+    qb = rng.uniform(-1, 1, size=(nbatch, dim)).astype(np.float32)
+    shards = []   # (torch device, ids of its rows as a list index -> global doc number, seed) for the brute-force check
+    if launched:
+        x = build_shard(torch, device, rows, dim, SEED_CORPUS + 400 + rank, normalize=False)
+        ids = doc_ids(rank * rows, rows)
+        ref = nifs._flat_new(metric)
+        nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
+        res = nifs.flat_load_device_matrix(ref, ids, x.data_ptr(), rows, dim)
+        assert res == ("ok", ()), res
+        sf = ShardedFlat(ref, dist, device)   # (64-byte records over RCCL, merged on the host: no global id ranking to pay for)
+        rccl_ranks = dist.get_world_size()
+        exchange = "one rank per GPU: all_gather of per-shard top-k records over RCCL, merge by (rank key, id bytes) on the host"
+
+        def single(q):
+            return [(h[0], np.float32(h[1]).tobytes()) for h in sf.search(q, limit)]
+
+        def batch(Q):
+            return [[(h[0], np.float32(h[1]).tobytes()) for h in hits] for hits in sf.search_batch(Q, limit)]
+        mine = [(device, x, np.arange(rank * rows + 1, (rank + 1) * rows + 1, dtype=np.int64))]
+    else:
+        ref = nifs.flat_new_sharded(metric, devices)
+        nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
+        all_idx = np.arange(1, total + 1, dtype=np.int64)
+        route = nifs.flat_route_ids(ref, doc_ids(0, total))
+        mine = []
+        for s in range(n_gpus):
+            idx = all_idx[route == s]
+            dev_s = torch.device("cuda", devices[s])
+            with torch.cuda.device(dev_s):
+                x = build_shard(torch, dev_s, len(idx), dim, SEED_CORPUS + 400 + s, normalize=False)
+                res = nifs.flat_load_device_matrix(ref, doc_ids(0, 0, idx), x.data_ptr(), len(idx), dim)
+                assert res == ("ok", ()), res
+                mine.append((dev_s, None, idx))   # (rebuilt from its seed for the check: eight matrices need not stay)
+                del x
+                torch.cuda.empty_cache()
+        rccl_ranks = nifs.flat_rccl_ranks(ref)
+        exchange = "one handle over %d devices (hash of id), %s exchange, merge by (rank key, id bytes)" % (
+            n_gpus, "rccl" if nifs.flat_exchange(ref) == _lib.EXCHANGE_RCCL else "host")
+        hp = C.c_void_p()
+        outs = (C.c_void_p * nbatch)()
+
+        def single(q):
+            st = L.vt_flat_search(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), dim, limit, C.byref(hp))
+            if st != 0:
+                sys.exit("bench.py: config 4 leg: flat_search failed with status %d: %s" % (st, (L.vt_last_error() or b"").decode()))
+            return hits_of(L, hp)
+
+        def batch(Q):
+            Q = np.ascontiguousarray(Q)
+            st = L.vt_flat_search_batch(ref.handle, Q.ctypes.data_as(C.POINTER(C.c_float)), len(Q), dim, limit, outs)
+            if st != 0:
+                sys.exit("bench.py: config 4 leg: flat_search_batch failed with status %d: %s" % (st, (L.vt_last_error() or b"").decode()))
+            return [hits_of(L, C.c_void_p(outs[j])) for j in range(len(Q))]
+
+    def sync():
+        if launched:
+            dist.barrier()
+        for dv in set(d for d, _, _ in mine):
+            torch.cuda.synchronize(dv)
+
+    def reduced_max(dt):
+        if not launched:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    for q in qs[:5]:
+        single(q)            # (also settles the id ranks: setup)
+    nifs.flat_set_profiling(ref, True)
+    nifs.flat_get_profile(ref, reset=True)
+    sync()
+    t0 = time.perf_counter()
+    for q in qs:
+        hits = single(q)
+    sync()
+    dt_single = reduced_max(time.perf_counter() - t0)
+    prof = nifs.flat_get_profile(ref, reset=True)
+    nifs.flat_set_profiling(ref, False)
+    batch(qb[:256])          # (norms, the bf16 shadow: setup)
+    sync()
+    t0 = time.perf_counter()
+    lists = batch(qb)
+    sync()
+    dt_batch = reduced_max(time.perf_counter() - t0)
+    # ---- checks, outside every timed region ------------------------------------------------------------------------------
+    batched_equals_single = all(lists[j] == single(qb[j]) for j in (0, nbatch // 2 - 1, nbatch - 1))
+    # brute force over every shard's own rows: nothing closer than the k-th reported hit has been missed, and the reported
+    # hits' distances are the rows' (f32 arithmetic in another order: 1e-5 relative, north_star's tolerance)
+    check_ok, better = True, 0
+    for q in (qs[0], qs[nsingle - 1]):
+        hits = single(q)
+        raw = {h[0]: float(np.frombuffer(h[1], dtype=np.float32)[0]) for h in hits}
+        kth = max(raw.values())
+        for dv, x, idx in mine:
+            with torch.cuda.device(dv):
+                if x is None:
+                    s_no = [i for i, m in enumerate(mine) if m[2] is idx][0]
+                    xs = build_shard(torch, dv, len(idx), dim, SEED_CORPUS + 400 + s_no, normalize=False)
+                else:
+                    xs = x
+                qv = torch.from_numpy(q).to(dv)
+                dist2 = torch.empty(len(idx), dtype=torch.float64, device=dv)
+                for lo in range(0, len(idx), 1 << 20):
+                    hi = min(len(idx), lo + (1 << 20))
+                    dist2[lo:hi] = (xs[lo:hi].double() - qv.double()).pow(2).sum(dim=1)
+                d = dist2.sqrt()
+                better += int((d < kth * (1.0 - 1e-5)).sum().item())
+                for key, r in raw.items():
+                    num = int(key[4:])                                # ids are "doc-<number>", idx is ascending
+                    pos = int(np.searchsorted(idx, num))
+                    if pos >= len(idx) or int(idx[pos]) != num:
+                        continue                                      # (another shard's row)
+                    ref_d = float(d[pos].item())
+                    if abs(r - ref_d) > 1e-5 * max(1.0, abs(ref_d)):
+                        check_ok = False
+                if x is None:
+                    del xs
+                    torch.cuda.empty_cache()
+    if launched:
+        t = torch.tensor([better, 0 if check_ok else 1], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        better, check_ok = int(t[0].item()), int(t[1].item()) == 0
+    # (two queries, ten hits each: at most nine rows are strictly closer than a query's tenth hit)
+    brute_force_ok = check_ok and better <= 2 * (limit - 1)
+    launches = max(1, prof["scan_launches"])
+    scan_ms = prof["scan_ms"] / launches
+    bytes_per_launch = prof["scan_bytes"] / launches
+    achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    del mine
+    return {
+        "workload": "index: :flat, metric: :l2, d=%d, N=%d row-sharded across %d GPUs (%d rows each), RCCL top-k merge; "
+                    "%d single queries, then %d queries in one call" % (dim, total, n_gpus, rows, nsingle, nbatch),
+        "n_gpus": n_gpus, "rows_per_gpu": rows, "rccl_ranks": rccl_ranks, "exchange": exchange, "dtype": "f32", "data": "synthetic",
+        "single": {"value": nsingle / dt_single, "unit": "queries/s", "steps": nsingle, "ms_per_step": dt_single / nsingle * 1e3,
+                   "roofline": {"bound": "hbm", "kernel": "scan_topk_kernel (one shard's scan)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": scan_ms},
+                   "everything_but_the_scan_ms": dt_single / nsingle * 1e3 - scan_ms},
+        "batch_4096_one_call": {"value": nbatch / dt_batch, "unit": "queries/s", "ms": dt_batch * 1e3},
+        "verified": bool(batched_equals_single and brute_force_ok),
+        "checks": {"batched_list_equals_single_search": bool(batched_equals_single), "brute_force_over_every_shard": bool(brute_force_ok),
+                   "rows_closer_than_a_tenth_hit": better},
+        "seconds": round(time.perf_counter() - t_leg, 1),
+    }
+
+
 def json_line_of(text):
     """The last line of `text` that parses as a JSON object (a child's result), or None."""
     for line in reversed(text.splitlines()):
@@ -1353,6 +1523,11 @@ def measure(a):
                 "variants": [{"build": v["build"], "shape": v["shape"], "threads": v["threads"],
                               "value": v["rows_per_s"] / a.rows, "effective_GBps": v["effective_GBps"]} for v in cb["variants"]],
             }
+    # BASELINE configs[3] beside the headline -- at the width of the node, and only there (every rank takes part)
+    if a.gpus == 8 and not a.no_side:
+        leg4 = config4_leg(a, torch, dist, nifs, _lib, L, rank, world, launched, devices, device, host_exchange)
+        if rank == 0:
+            out.setdefault("side", {})["config4"] = leg4
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
@@ -1376,6 +1551,11 @@ def measure(a):
             "oracle_verified": (all(at("verified_against_oracle", "equal_bit_for_bit").values())
                                 if at("verified_against_oracle", "equal_bit_for_bit") else None),
         }
+        if at("config4"):
+            summary["config4_single_queries_per_s"] = at("config4", "single", "value")
+            summary["config4_single_scan_frac"] = at("config4", "single", "roofline", "frac")
+            summary["config4_batch_4096_queries_per_s"] = at("config4", "batch_4096_one_call", "value")
+            summary["config4_verified"] = at("config4", "verified")
         out["config"]["summary"] = summary
         out["summary"] = summary
         # RCCL's version banner sits in libc's stdout buffer: flush it first so

@@ -85,3 +85,33 @@ def test_the_fallback_under_the_launcher_meets_on_a_store_of_its_own():
     assert line is not None and line["n_gpus"] == 2 and line["config"]["processes"] == 2, line
     assert "rccl-exchange run exited with status" in line["config"]["exchange_note"], line
     assert "gloo" in line["config"]["sharding"], line
+
+
+def test_the_width_of_the_node_rehearsed_on_one_gpu_carries_config_4():
+    """`bench.py --gpus 8` also measures BASELINE configs[3] (L2, rows sharded over eight GPUs, single queries and 4 096 in
+    one call) as side.config4 -- the driver passes no flags, so the one 8-GPU run there may ever be has to carry it.  Here:
+    eight shards on the one card, small sizes; the leg's keys, its own roofline, both checks, the summary."""
+    r, line = bench(["--gpus", "8", "--devices", "0,0,0,0,0,0,0,0", "--rows", "4000000", "--config4-rows", "250000", "--steps", "20",
+                     "--warmup", "5", "--no-cpu"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 8 and line["config"]["devices"] == [0] * 8, line
+    leg = line["side"]["config4"]
+    assert leg["n_gpus"] == 8 and leg["rows_per_gpu"] == 250000 and "metric: :l2" in leg["workload"] and "N=2000000" in leg["workload"], leg
+    assert leg["verified"] and leg["checks"]["batched_list_equals_single_search"] and leg["checks"]["brute_force_over_every_shard"], leg
+    assert leg["single"]["steps"] == 200 and leg["single"]["value"] > 0 and leg["batch_4096_one_call"]["value"] > 0, leg
+    roof = leg["single"]["roofline"]
+    assert roof["bound"] == "hbm" and 0 < roof["frac"] <= 1 and roof["algorithmic_bytes_per_launch"] > 0, roof
+    assert leg["seconds"] < 120, leg
+    assert line["summary"]["config4_verified"] is True and line["summary"]["config4_batch_4096_queries_per_s"] == leg["batch_4096_one_call"]["value"]
+
+
+def test_eight_ranks_under_the_launcher_on_one_gpu_skip_config_4_over_the_host_exchange():
+    """The driver's own command for N = 8 -- torch.distributed.run, eight ranks -- on the one GPU of this box: RCCL cannot
+    serve eight ranks on one device, so the line comes from the host-exchange children (gloo), eight real processes that
+    each hold a shard on the card; that fallback says that it skipped the config 4 leg instead of measuring something else
+    under its name."""
+    r, line = bench(["--gpus", "8", "--devices", "0,0,0,0,0,0,0,0", "--exchange", "host", "--rows", "800000", "--config4-rows", "50000",
+                     "--steps", "5", "--warmup", "2", "--no-cpu"], launcher=8, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 8 and line["config"]["processes"] == 8 and "gloo" in line["config"]["sharding"], line
+    assert "skipped" in line["side"]["config4"], line["side"]
