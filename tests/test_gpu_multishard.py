@@ -318,7 +318,7 @@ def test_a_wedged_exchange_times_out_with_a_message(nifs, oracle_mod, monkeypatc
     res = nifs.flat_search(g.ref, [0.9, 0.0], 2)
     waited = time.perf_counter() - t0
     assert res[0] == "error" and "RCCL exchange timed out on shard 0" in res[1], res
-    assert 0.2 < waited < 1.2, waited
+    assert 0.2 < waited < 1.45, waited                      # (after the deadline, before the 1.5-s stall ends: the deadline cut it)
     vt_debug.reset("test_exchange_stall_ms")
     assert nifs.flat_search(g.ref, [0.9, 0.0], 2) == ("error", "flat lock poisoned")
     assert nifs.flat_insert(g.ref, "d", [3.0, 0.0]) == ("error", "flat lock poisoned")

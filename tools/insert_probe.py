@@ -65,6 +65,25 @@ def main():
             res = nifs.flat_insert_many(ref, list(zip(bid[lo:lo + block], v[lo:lo + block])))
             assert res[0] == "ok", res
         out["insert_many_%d_us_per_row" % block] = round((time.perf_counter() - t0) / m * 1e6, 2)
+    # The figures above time the Python loop as r04 / r05 did (a ctypes pointer conversion per call rides along).  The C ABI
+    # call alone, pointers prepared beforehand, per call: a tight loop runs at the speed the device drains the landing ring
+    # (one small kernel and an event per mutation), a lone call returns at about the median.
+    ptrs = [vecs[i].ctypes.data_as(C.POINTER(C.c_float)) for i in range(n)]
+    ids2 = [b"again-%07d" % i for i in range(n)]
+    for name, keys in (("abi_insert_new", ids2), ("abi_upsert", ids2), ("abi_delete", ids2)):
+        t = np.empty(n)
+        t_all = time.perf_counter()
+        for i in range(n):
+            t0 = time.perf_counter()
+            if name == "abi_delete":
+                st = L.vt_flat_delete(ref.handle, keys[i], len(keys[i]))
+            else:
+                st = L.vt_flat_insert(ref.handle, keys[i], len(keys[i]), ptrs[i], dim)
+            t[i] = time.perf_counter() - t0
+            assert st == 0
+        out[name] = {"mean_us": round((time.perf_counter() - t_all) / n * 1e6, 2), "p10_us": round(float(np.percentile(t, 10)) * 1e6, 2),
+                     "p50_us": round(float(np.percentile(t, 50)) * 1e6, 2), "p90_us": round(float(np.percentile(t, 90)) * 1e6, 2),
+                     "p99_us": round(float(np.percentile(t, 99)) * 1e6, 2)}
     print(json.dumps(out))
 
 

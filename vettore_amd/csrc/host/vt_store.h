@@ -841,8 +841,10 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
   }
   const uint32_t ld = ix->ld;
   bool pending = false;
-  unsigned char *land_buf = nullptr;  // a trickle's slot of the landing ring, and the event behind its copies
+  unsigned char *land_buf = nullptr;  // a trickle's slot of the landing ring (host and device view), the event behind it,
+  const unsigned char *land_dev = nullptr;  // and the id ranks that land with the rows
   hipEvent_t land_ev = nullptr;
+  uint32_t land_rank_first = 0, land_ranks = 0;
   if (src.device) {
     bool picks_dense = true;  // the batch is one contiguous block of the source
     if (src.pick)
@@ -929,26 +931,25 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
       VT_HIP(hipStreamSynchronize(c.stream));  // (map and dMap die with this scope)
     }
     VT_HIP(hipStreamSynchronize(c.stream));
-  } else if ((size_t)count * ((size_t)ld * sizeof(float) + sizeof(uint32_t)) <= Shard::Landing::kSlotBytes) {
+  } else if ((size_t)count * ((size_t)ld * sizeof(float) + 2 * sizeof(uint32_t)) <= Shard::Landing::kSlotBytes) {
     // A trickle (Vettore.put/2 record by record; up to 21 rows of 768 floats): the rows are staged in a slot of the landing
-    // ring, their copies queued, and the call returns without waiting for them (Shard::Landing, host/vt_types.h): readers
-    // on other streams wait for the slot's event on the device.  The rows' ranks, if they are to go up now, ride in
-    // the same slot behind the rows (below).
-    const size_t row_bytes = (size_t)ld * sizeof(float);
-    VT_TRY(landing_slot(ix, &land_buf, &land_ev));
+    // ring -- rows, then the slab row of each, then (below) the id ranks that are to go up with them -- ONE kernel moves
+    // all of it (launch_land_rows, queued at the end of this function), and the call returns without waiting for it
+    // (Shard::Landing, host/vt_types.h): readers on other streams wait for the slot's event on the device.
+    VT_TRY(landing_slot(ix, &land_buf, &land_ev, &land_dev));
     float *stage = reinterpret_cast<float *>(land_buf);
+    uint32_t *slab_rows = reinterpret_cast<uint32_t *>(stage + count * ld);
     for (size_t j = 0; j < count; ++j) {
       const size_t p = src.pick ? src.pick[j] : j;
       const float *row = src.off ? src.host + src.off[p] : src.host + p * src.d;
       float *dst = stage + j * ld;
       std::memcpy(dst, row, d * sizeof(float));
       for (size_t t = d; t < ld; ++t) dst[t] = 0.0f;
-    }
-    for (size_t j = 0; j < count;) {
-      size_t e = j + 1;
-      while (e < count && target[e] == target[e - 1] + 1) ++e;
-      VT_HIP(hipMemcpyAsync(ix->dX + (size_t)target[j] * ld, stage + j * ld, (e - j) * row_bytes, hipMemcpyHostToDevice, c.stream));
-      j = e;
+      slab_rows[j] = target[j];
+      // (an id that comes twice in one batch: the LAST occurrence is the row, flat.rs:270-281 -- the blocks of one launch
+      // are not ordered, so the earlier ones are marked and skipped)
+      for (size_t e = 0; e < j; ++e)
+        if (slab_rows[e] == target[j]) slab_rows[e] = 0xFFFFFFFFu;
     }
     pending = true;
   } else {
@@ -1007,11 +1008,13 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
       VT_TRY(ix->dRank.ensure(std::max<size_t>(ix->cap, ix->n)));
       from = 0;
     }
-    if (land_ev && ix->n - from <= count) {
-      // a trickle of sorted appends (one rank per call): the ranks ride in the landing slot, behind the rows
-      uint32_t *ranks = reinterpret_cast<uint32_t *>(land_buf + (size_t)count * ld * sizeof(float));
+    if (land_dev && ix->n - from <= count) {
+      // a trickle of sorted appends (one rank per call): the ranks ride in the landing slot, behind the rows and their
+      // slab rows, and go up in the same launch
+      uint32_t *ranks = reinterpret_cast<uint32_t *>(land_buf + (size_t)count * ld * sizeof(float)) + count;
       std::memcpy(ranks, ix->rank_host.data() + from, (size_t)(ix->n - from) * sizeof(uint32_t));
-      VT_HIP(hipMemcpyAsync(ix->dRank.p + from, ranks, (size_t)(ix->n - from) * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+      land_rank_first = from;
+      land_ranks = ix->n - from;
     } else if (ix->n - from <= 64) {
       // a few sorted appends: through a pinned block of their own (rank_host is pageable: the runtime would stage the
       // copy itself), waited for below
@@ -1027,7 +1030,11 @@ int index_store_rows(Shard *ix, size_t count, const char *ids, const size_t *id_
     }
     pending = true;
   }
-  // a trickle returns with its copies queued and an event behind them; everything else waits here, once
+  // a trickle: one launch moves its rows (and ranks) out of the slot; it returns with that launch queued and an event
+  // behind it.  Everything else waits here, once.
+  if (land_dev)
+    VT_HIP(vt::launch_land_rows(reinterpret_cast<const float *>(land_dev), (uint32_t)count, ld, ix->dX, land_ranks ? ix->dRank.p : nullptr,
+                                land_rank_first, land_ranks, c.stream));
   if (pending && land_ev) VT_TRY(landing_record(ix, land_ev));
   else if (pending) VT_HIP(hipStreamSynchronize(c.stream));
   const auto t_rank = std::chrono::steady_clock::now();

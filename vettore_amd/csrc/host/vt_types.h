@@ -299,7 +299,7 @@ struct SpareCtxLease : vt_host::SpareLeaseT<Shard, Ctx> {
 
 // A slot of the landing ring (Shard::Landing): its buffer once whatever was copied out of it last time has left, and the
 // event to record behind the copies queued from it.
-int landing_slot(Shard *ix, unsigned char **buf, hipEvent_t *ev) {
+int landing_slot(Shard *ix, unsigned char **buf, hipEvent_t *ev, const unsigned char **buf_dev = nullptr) {
   Shard::Landing &l = ix->landing;
   if (!l.stage.p) {
     VT_TRY(l.stage.ensure((size_t)Shard::Landing::kSlots * Shard::Landing::kSlotBytes));
@@ -311,6 +311,11 @@ int landing_slot(Shard *ix, unsigned char **buf, hipEvent_t *ev) {
   l.used[s] = true;
   *buf = l.stage.p + (size_t)s * Shard::Landing::kSlotBytes;
   *ev = l.ev[s];
+  if (buf_dev) {  // (the slot as a kernel sees it: the landing kernel reads the rows straight out of the pinned block)
+    unsigned char *m = l.stage.mapped();
+    if (!m) return fail(VT_ERR_DEVICE, "hipHostGetDevicePointer (landing ring)");
+    *buf_dev = m + (size_t)s * Shard::Landing::kSlotBytes;
+  }
   return VT_OK;
 }
 // ... recorded: the mutation's device work is queued on the primary stream, nothing is waited for.

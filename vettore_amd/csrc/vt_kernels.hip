@@ -1182,6 +1182,27 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
   }
 }
 
+// A trickle of rows lands (host/vt_types.h, Shard::Landing): `stage` is a slot of PINNED HOST memory as the device sees it
+// -- `count` rows of `ld` floats, already zero padded, then their slab rows (0xFFFFFFFF: an earlier occurrence of an id that
+// comes again in the same batch -- skipped, the last one wins, flat.rs:270-281), then `nranks` id ranks for the rows
+// rank_first .. of the rank column.  One launch instead of a copy per run of rows and another for the ranks: back to back
+// on one stream a small copy costs as much device time as this whole kernel.  One block per row, 16-byte moves.
+__global__ __launch_bounds__(256) void land_rows_kernel(const float *__restrict__ stage, uint32_t count, uint32_t ld,
+                                                        float *__restrict__ X, uint32_t *__restrict__ rank_col,
+                                                        uint32_t rank_first, uint32_t nranks) {
+  const uint32_t *targets = reinterpret_cast<const uint32_t *>(stage + (size_t)count * ld);
+  const uint32_t *ranks = targets + count;
+  if (blockIdx.x == 0 && rank_col)
+    for (uint32_t i = threadIdx.x; i < nranks; i += blockDim.x) rank_col[rank_first + i] = ranks[i];
+  for (uint32_t j = blockIdx.x; j < count; j += gridDim.x) {
+    const uint32_t t = targets[j];
+    if (t == 0xFFFFFFFFu) continue;
+    const float4 *from = reinterpret_cast<const float4 *>(stage + (size_t)j * ld);
+    float4 *to = reinterpret_cast<float4 *>(X + (size_t)t * ld);
+    for (uint32_t c = threadIdx.x; c < ld / 4; c += blockDim.x) to[c] = from[c];
+  }
+}
+
 // K6 (cosine part): exact rerank value of distances.rs:160-177.  One wave per
 // candidate: the wave stages the row and the query in LDS with coalesced loads,
 // then lanes 0..2 run the three sequential f64 sums |q|^2, |x|^2, q.x in index
@@ -1907,6 +1928,13 @@ hipError_t launch_gather_rows(const float *src, uint32_t d, const uint32_t *map,
   if (count == 0) return hipSuccess;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(count < 4096 ? count : 4096), dim3(256), 0, s, src, d, map, count, dst,
                      dst_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_land_rows(const float *stage_dev, uint32_t count, uint32_t ld, float *X, uint32_t *rank_col, uint32_t rank_first,
+                            uint32_t nranks, hipStream_t s) {
+  if (count == 0 || ld % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(land_rows_kernel, dim3(count), dim3(256), 0, s, stage_dev, count, ld, X, rank_col, rank_first, nranks);
   return hipGetLastError();
 }
 
