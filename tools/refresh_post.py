@@ -4,7 +4,7 @@ FETCH_SIZE / WRITE_SIZE figures, pmc_latest.json / pmc_side.json, the 16 x 256 t
 round from $RND.  A file of its own so that it can be re-run on the merged data without a GPU."""
 import csv, glob, json, os
 out = 'gpurun_out/prof'
-RND = os.environ.get('RND', 'r05')
+RND = os.environ.get('RND', 'r06')
 def trim(src, dst):
     rows = list(csv.reader(open(src)))
     with open(dst, 'w', newline='') as f:

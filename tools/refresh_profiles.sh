@@ -15,7 +15,7 @@ pmc() {  # name, counter, bench args...
   local name=$1 ctr=$2; shift 2
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$name -o p -- python3 $R/bench.py "$@" > $OUT/$name.log 2>&1
 }
-export RND=${RND:-r05}
+export RND=${RND:-r06}
 stats single --no-side          # the headline alone: the scan kernel's average is the bench line's avg_launch_ms
 stats default                   # the driver's command: headline + side legs (config 2 shares the scan kernel: 1 100 launches at N=1M)
 pmc single_fetch FETCH_SIZE --steps 20 --warmup 2 --no-cpu --no-side
