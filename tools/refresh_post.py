@@ -66,9 +66,14 @@ print("cosine_scan FETCH_SIZE x2 bytes", 2 * ff * 1024, "mfma_scores<8> FETCH_SI
 # what the side legs of bench.py report as `traffic` (reads only: these kernels write a few KB of lists)
 json.dump({k: {"rows": 10000000, "dim": 768, "hbm_bytes_per_launch": 2 * v * 1024,
                "source": "FETCH_SIZE x 2 (gfx950 correction as in pmc_latest.json), %s pass of tools/refresh_profiles.sh" % k}
-           for k, v in (("hamming_dist_kernel", hf), ("cosine_scan_kernel", ff), ("mfma_scores_kernel", bf), ("scan_multi_kernel", mf),
+           for k, v in (("hamming_dist_kernel", hf), ("cosine_scan_kernel", ff), ("mfma_scores_kernel", bf),
                         ("bf16_scores_kernel", b16), ("shadow_scores_kernel", s16))},
           open(out + '/pmc_side.json', 'w'), indent=1)
+side = json.load(open(out + '/pmc_side.json'))
+# (K1m is profiled at d = 256 since r06: tools/refresh_profiles.sh says why)
+side["scan_multi_kernel"] = {"rows": 10000000, "dim": 256, "hbm_bytes_per_launch": 2 * mf * 1024,
+                             "source": "FETCH_SIZE x 2 (gfx950 correction as in pmc_latest.json), scan_multi_kernel pass of tools/refresh_profiles.sh"}
+json.dump(side, open(out + '/pmc_side.json', 'w'), indent=1)
 import subprocess
 with open('%s/%s_batch16_trace_excerpt.txt' % (out, RND), 'w') as f:
     f.write(subprocess.run(['python3', 'tools/trace_excerpt.py', glob.glob(out + '/batch16_trace/**/t_kernel_trace.csv', recursive=True)[0]],

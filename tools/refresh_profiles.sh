@@ -36,11 +36,13 @@ pmc batch_bf16_fetch FETCH_SIZE --mode batch --nominate bf16 --steps 4 --warmup 
 pmc batch_k2b_fetch FETCH_SIZE --mode batch --nominate bf16 --shadow off --steps 4 --warmup 1 --no-cpu
 # float hamming alone (K4 over the non-zero-bit column): the pass bench.py's side.pattern_hamming prices
 ROWS=10000000 METRICS=7 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pattern_hamming -o p -- python3 $R/tools/pattern_probe.py > $OUT/pattern_hamming.log 2>&1
-# K1m: 8 queries per sweep (manhattan, N=10M, d=768); the program after `--` is python3 itself
-export ROWS=10000000 NQS=8 METRICS=5
+# K1m: 8 queries per sweep (manhattan, N=10M, d=256 -- since r05 rows of 512 floats and more of a corpus this size go to K1p,
+# and the switch that forced K1m there left in r06: the profile is of a shape the product sends to K1m); the program
+# after `--` is python3 itself
+export ROWS=10000000 DIM=256 NQS=8 METRICS=5
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/multi -o p -- python3 $R/tools/multi_probe.py > $OUT/multi.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/multi_fetch -o p -- python3 $R/tools/multi_probe.py > $OUT/multi_fetch.log 2>&1
-unset ROWS NQS METRICS
+unset ROWS DIM NQS METRICS
 # K1p: eight L2 funnel searches per sweep of the 128-float prefixes (N=10M, d=768) -- stats pass, FETCH pass
 export METRICS=0 PREFIXES=128 K1M=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prefix_multi -o p -- python3 $R/tools/prefix_multi_probe.py > $OUT/prefix_multi.log 2>&1
