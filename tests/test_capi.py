@@ -120,6 +120,10 @@ def test_product_library_carries_no_test_hooks():
     lib_dir = os.path.join(ROOT, "vettore_amd", "lib")
     product = open(os.path.join(lib_dir, "libvettore_hip.so"), "rb").read()
     assert b"VT_TEST_" not in product and b"VT_FORCE_" not in product and b"test_fail_after_id_update" not in product
+    # (r06) ... nor the timing experiments' switches, nor a kernel of a path that lost its A/B
+    for gone in (b"batch_debug", b"mq_dbg", b"trace_batch", b"hybrid_chain", b"test_coalesce_hold_until", b"union_rows_kernel",
+                 b"mfma_scores_kernel3"):
+        assert gone not in product, gone
     hooks = os.path.join(lib_dir, "libvettore_hip_hooks.so")
     if os.path.exists(hooks):
         data = open(hooks, "rb").read()
@@ -139,6 +143,20 @@ def test_settings_by_name(lib):
     for bad in (b"VT_FORCE_BATCH_MFMA", b"no_such_switch", b"test_refuse_shadow", b""):
         assert lib.vt_debug_set(bad, 1) == 19, bad      # VT_ERR_ARGUMENT
     assert lib.vt_debug_set(None, 1) == 19 and lib.vt_debug_get(b"coalesce", None) == 19
+    # r06: the A/B switches whose alternative lost are gone with their paths, the timing experiments live in a build of
+    # their own (make experiments) ...
+    for gone in (b"hybrid_chain", b"direct_query", b"batch_kernel", b"pm_panel", b"cs_panel", b"scan_rt_order", b"multi_general",
+                 b"ingest_serial", b"ingest_separate_check", b"funnel_dense_sample", b"hamming_lists", b"batch_pass_five",
+                 b"rescore_blocks", b"no_pattern_bits", b"batch_debug", b"mq_dbg", b"trace_batch", b"test_coalesce_hold_until"):
+        assert lib.vt_debug_set(gone, 1) == 19 and lib.vt_debug_get(gone, C.byref(v)) == 19, gone
+    # ... and a value the setting's own parser could not have produced is refused (reduce_order = 7 would hand
+    # new indexes a lane order no kernel has)
+    for name, bad_values, good in ((b"reduce_order", (-1, 4, 7), 3), (b"batch_nominate", (0, 3), 2), (b"batch_shadow", (2, -1), 1),
+                                   (b"slab", (2,), 0), (b"shard_exchange", (3, -1), 0)):
+        for bad in bad_values:
+            assert lib.vt_debug_set(name, bad) == 19, (name, bad)
+        assert lib.vt_debug_get(name, C.byref(v)) == 0 and v.value == good, (name, v.value)
+        assert lib.vt_debug_set(name, good) == 0
     # the environment is not consulted again: a variable set now changes nothing
     os.environ["VT_COALESCE_SLOTS"] = "5"
     try:
