@@ -90,6 +90,7 @@ def parse():
                     help="batch mode: let the bf16 pass keep a bf16 shadow of the rows (K2s) or stream the f32 rows (K2b)")
     ap.add_argument("--config4-rows", type=int, default=5_000_000,
                     help="--gpus 8 only: rows PER GPU of the side.config4 leg (BASELINE configs[3]: L2, N = 40 M over 8 GPUs)")
+    ap.add_argument("--config4-anyway", action="store_true", help=argparse.SUPPRESS)   # (tests: the leg at any width, over any exchange)
     ap.add_argument("--supervise", action="store_true",
                     help="run the measurement in a child process and, should it fail or hang, once more over the host exchange "
                          "(always on for N > 1; this flag switches it on at N = 1, with --exchange rccl|host)")
@@ -938,9 +939,10 @@ def config4_leg(a, torch, dist, nifs, _lib, L, rank, world, launched, devices, d
     for rehearsals with a small --config4-rows).  Returns the leg's dictionary (identical on every rank)."""
     from vettore_amd.sharded import ShardedFlat
     t_leg = time.perf_counter()
-    if launched and host_exchange:
+    if launched and host_exchange and not a.config4_anyway:
         # (the fallback child between ranks: gloo, no RCCL -- nothing of configs[3]'s "RCCL top-k merge" would be measured)
         return {"skipped": "this child runs over the host exchange between ranks (the fallback): the config 4 leg is measured over RCCL only"}
+    xdev = torch.device("cpu") if host_exchange else device   # where collectives' tensors live (gloo: the host)
     rows, dim, limit = a.config4_rows, a.dim, a.limit
     metric = nifs.METRIC_CODE["l2"]
     n_gpus = world if launched else len(devices)
@@ -957,9 +959,10 @@ def config4_leg(a, torch, dist, nifs, _lib, L, rank, world, launched, devices, d
         nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
         res = nifs.flat_load_device_matrix(ref, ids, x.data_ptr(), rows, dim)
         assert res == ("ok", ()), res
-        sf = ShardedFlat(ref, dist, device)   # (64-byte records over RCCL, merged on the host: no global id ranking to pay for)
-        rccl_ranks = dist.get_world_size()
-        exchange = "one rank per GPU: all_gather of per-shard top-k records over RCCL, merge by (rank key, id bytes) on the host"
+        sf = ShardedFlat(ref, dist, xdev)   # (64-byte records over RCCL, merged on the host: no global id ranking to pay for)
+        rccl_ranks = 0 if host_exchange else dist.get_world_size()
+        exchange = "one rank per GPU: all_gather of per-shard top-k records over %s, merge by (rank key, id bytes) on the host" % (
+            "gloo" if host_exchange else "RCCL")
 
         def single(q):
             return [(h[0], np.float32(h[1]).tobytes()) for h in sf.search(q, limit)]
@@ -992,14 +995,14 @@ def config4_leg(a, torch, dist, nifs, _lib, L, rank, world, launched, devices, d
         def single(q):
             st = L.vt_flat_search(ref.handle, q.ctypes.data_as(C.POINTER(C.c_float)), dim, limit, C.byref(hp))
             if st != 0:
-                sys.exit("bench.py: config 4 leg: flat_search failed with status %d: %s" % (st, (L.vt_last_error() or b"").decode()))
+                raise RuntimeError("flat_search failed with status %d: %s" % (st, (L.vt_last_error() or b"").decode()))
             return hits_of(L, hp)
 
         def batch(Q):
             Q = np.ascontiguousarray(Q)
             st = L.vt_flat_search_batch(ref.handle, Q.ctypes.data_as(C.POINTER(C.c_float)), len(Q), dim, limit, outs)
             if st != 0:
-                sys.exit("bench.py: config 4 leg: flat_search_batch failed with status %d: %s" % (st, (L.vt_last_error() or b"").decode()))
+                raise RuntimeError("flat_search_batch failed with status %d: %s" % (st, (L.vt_last_error() or b"").decode()))
             return [hits_of(L, C.c_void_p(outs[j])) for j in range(len(Q))]
 
     def sync():
@@ -1011,7 +1014,7 @@ def config4_leg(a, torch, dist, nifs, _lib, L, rank, world, launched, devices, d
     def reduced_max(dt):
         if not launched:
             return dt
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -1068,7 +1071,7 @@ def config4_leg(a, torch, dist, nifs, _lib, L, rank, world, launched, devices, d
                     del xs
                     torch.cuda.empty_cache()
     if launched:
-        t = torch.tensor([better, 0 if check_ok else 1], dtype=torch.int64, device=device)
+        t = torch.tensor([better, 0 if check_ok else 1], dtype=torch.int64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         better, check_ok = int(t[0].item()), int(t[1].item()) == 0
     # (two queries, ten hits each: at most nine rows are strictly closer than a query's tenth hit)
@@ -1524,8 +1527,13 @@ def measure(a):
                               "value": v["rows_per_s"] / a.rows, "effective_GBps": v["effective_GBps"]} for v in cb["variants"]],
             }
     # BASELINE configs[3] beside the headline -- at the width of the node, and only there (every rank takes part)
-    if a.gpus == 8 and not a.no_side:
-        leg4 = config4_leg(a, torch, dist, nifs, _lib, L, rank, world, launched, devices, device, host_exchange)
+    if (a.gpus == 8 or a.config4_anyway) and not a.no_side:
+        # (a failure of the side leg must not take the headline with it: every rank runs the same code on the same seeds,
+        # so what raises on one raises on all of them, at the same place)
+        try:
+            leg4 = config4_leg(a, torch, dist, nifs, _lib, L, rank, world, launched, devices, device, host_exchange)
+        except Exception as e:  # noqa: BLE001
+            leg4 = {"failed": "%s: %s" % (type(e).__name__, e), "verified": False}
         if rank == 0:
             out.setdefault("side", {})["config4"] = leg4
     if use_dist:

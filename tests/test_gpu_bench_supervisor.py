@@ -115,3 +115,19 @@ def test_eight_ranks_under_the_launcher_on_one_gpu_skip_config_4_over_the_host_e
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["n_gpus"] == 8 and line["config"]["processes"] == 8 and "gloo" in line["config"]["sharding"], line
     assert "skipped" in line["side"]["config4"], line["side"]
+
+
+def test_config_4_between_rank_processes_rehearsed_with_two_ranks():
+    """side.config4 in its other form -- one rank process per GPU, records exchanged between the ranks, what the driver's
+    launch at N = 8 runs -- with two rank processes on the one GPU over gloo (`--config4-anyway`: the leg at this width and
+    over this exchange is for this rehearsal only; RCCL itself wants a device per rank): both ranks take part in every
+    collective of the leg, the batched lists equal the single searches, the brute-force pass over each rank's own rows finds
+    nothing closer, rank 0 prints one line."""
+    r, line = bench(["--gpus", "2", "--devices", "0,0", "--exchange", "host", "--rows", "300000", "--config4-rows", "150000", "--config4-anyway",
+                     "--steps", "5", "--warmup", "2", "--no-cpu"], launcher=2, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    leg = line["side"]["config4"]
+    assert "failed" not in leg and "skipped" not in leg, leg
+    assert leg["n_gpus"] == 2 and leg["rows_per_gpu"] == 150000 and "N=300000" in leg["workload"] and "gloo" in leg["exchange"], leg
+    assert leg["verified"] and leg["checks"]["batched_list_equals_single_search"] and leg["checks"]["brute_force_over_every_shard"], leg
+    assert leg["single"]["roofline"]["algorithmic_bytes_per_launch"] == 150000 * 768 * 4, leg["single"]

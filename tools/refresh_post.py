@@ -12,7 +12,7 @@ def trim(src, dst):
         for r in rows:
             r[0] = r[0][:140]
             w.writerow(r)
-for name in ('single', 'default', 'batch', 'batch_bf16', 'batch16', 'batch_k2b', 'quantized', 'funnel', 'multi', 'pattern_hamming', 'prefix_multi'):
+for name in ('single', 'default', 'driver_cmd', 'batch', 'batch_bf16', 'batch16', 'batch_k2b', 'quantized', 'funnel', 'multi', 'pattern_hamming', 'prefix_multi'):
     trim('%s/%s/p_kernel_stats.csv' % (out, name), '%s/%s_%s_kernel_stats.csv' % (out, RND, name))
 def per_launch(path, kernel_substr, counter):
     vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
@@ -80,7 +80,7 @@ with open('%s/%s_batch16_trace_excerpt.txt' % (out, RND), 'w') as f:
                            capture_output=True, text=True).stdout)
 import shutil
 shutil.copyfile('%s/default.json' % out, '%s/%s_bench_default_under_rocprof.json' % (out, RND))
-for name in ('single', 'batch', 'batch_bf16', 'batch16', 'batch_k2b', 'quantized', 'funnel'):
+for name in ('single', 'driver_cmd', 'batch', 'batch_bf16', 'batch16', 'batch_k2b', 'quantized', 'funnel'):
     # (the JSON line of every profiled leg under the name profiles/ keeps it by: <round>_bench_<leg>.json)
     shutil.copyfile('%s/%s.json' % (out, name), '%s/%s_bench_%s.json' % (out, RND, name))
     print(open('%s/%s.json' % (out, name)).read().strip())

@@ -17,7 +17,8 @@ pmc() {  # name, counter, bench args...
 }
 export RND=${RND:-r06}
 stats single --no-side          # the headline alone: the scan kernel's average is the bench line's avg_launch_ms
-stats default                   # the driver's command: headline + side legs (config 2 shares the scan kernel: 1 100 launches at N=1M)
+stats default                   # no flags (1 000 timed steps): headline + side legs (config 2 shares the scan kernel: 1 100 launches at N=1M)
+stats driver_cmd --gpus 1 --steps 20 --warmup 5   # LITERALLY the driver's command under the profiler (VERDICT r5 #4a): the line's avg_launch_ms beside rocprofv3's own average
 pmc single_fetch FETCH_SIZE --steps 20 --warmup 2 --no-cpu --no-side
 pmc single_write WRITE_SIZE --steps 20 --warmup 2 --no-cpu --no-side
 stats batch --mode batch --nominate f32 --steps 6 --warmup 1 --no-cpu          # K2: FP32 matrix cores
