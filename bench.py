@@ -888,28 +888,6 @@ def measure_batches(a, torch, dist, nifs, _lib, L, ref, sharded, use_dist, launc
             dt = float(t.item())
         return dt, prof
 
-    #
-    # r06 -- a card that has only just been loaded is not in its steady state.  On every box of the pool the FIRST ~1.2 s of
-    # HBM-bound scanning in a process run 2.8 % slower per kernel than everything after (rocprofv3 kernel traces of this
-    # script: 4.57 ms per scan of the 10 M-row corpus for the first ~260 dispatches, 4.44-4.45 ms from then on, whatever
-    # ran before -- profiles/r06_driver_cmd_trace_summary.txt).  The driver's --warmup 5 --steps 20 are 0.11 s of work: they
-    # sit entirely inside that ramp, and five driver runs read 216-219 queries/s where 1 000-step runs read 222-224.  What a
-    # service under load delivers is the settled rate, what a lone burst after a (re)load sees is the other: the line
-    # carries BOTH, measured in this process one after the other with the same W warm-up steps and the same bracket --
-    # `cold_start` (right after the build, as rounds 1-5 measured `value`), then ~1.3 s of the same searches untimed, then
-    # `value`.  Nothing is skipped or shortened inside either timed region.  (--no-settle: `value` is the cold figure.)
-    cold_start = None
-    if not a.no_settle and a.steps > 0:
-        cold_steps = min(a.steps, 100)
-        dt_cold, _ = timed_run(False, cold_steps)
-        per_step = max(dt_cold / cold_steps, 1e-6)
-        settle_steps = int(math.ceil(1.3 / per_step))
-        t0 = time.perf_counter()
-        for i in range(settle_steps):
-            search(qs[i % nq])
-        sync()
-        cold_start = {"steps": cold_steps, "warmup": a.warmup, "ms_per_step": dt_cold / cold_steps * 1e3, "value": cold_steps / dt_cold,
-                      "then_settled_for_s": round(time.perf_counter() - t0, 2), "settle_steps": settle_steps}
     dt_events, prof = timed_run(True)
     dt, _ = timed_run(False)
 
@@ -1443,6 +1421,28 @@ def measure(a):
     # HIP-event bookkeeping -- the dominant kernel's own duration, measured live on the stream it is
     # launched on: the roofline figure --, then WITHOUT it -- two event records per call are two
     # barrier packets in a chain of three launches -- end to end: `value` and `ms_per_step`.
+    #
+    # r06 -- a card that has only just been loaded is not in its steady state.  On every box of the pool the FIRST ~1.2 s of
+    # HBM-bound scanning in a process run 2.8 % slower per kernel than everything after (rocprofv3 kernel traces of this
+    # script: 4.57 ms per scan of the 10 M-row corpus for the first ~260 dispatches, 4.44-4.45 ms from then on, whatever
+    # ran before -- profiles/r06_driver_cmd_trace_summary.txt).  The driver's --warmup 5 --steps 20 are 0.11 s of work: they
+    # sit entirely inside that ramp, and five driver runs read 216-219 queries/s where 1 000-step runs read 222-224.  What a
+    # service under load delivers is the settled rate, what a lone burst after a (re)load sees is the other: the line
+    # carries BOTH, measured in this process one after the other with the same W warm-up steps and the same bracket --
+    # `cold_start` (right after the build, as rounds 1-5 measured `value`), then ~1.3 s of the same searches untimed, then
+    # `value`.  Nothing is skipped or shortened inside either timed region.  (--no-settle: `value` is the cold figure.)
+    cold_start = None
+    if not a.no_settle and a.steps > 0:
+        cold_steps = min(a.steps, 100)
+        dt_cold, _ = timed_run(False, cold_steps)
+        per_step = max(dt_cold / cold_steps, 1e-6)
+        settle_steps = int(math.ceil(1.3 / per_step))
+        t0 = time.perf_counter()
+        for i in range(settle_steps):
+            search(qs[i % nq])
+        sync()
+        cold_start = {"steps": cold_steps, "warmup": a.warmup, "ms_per_step": dt_cold / cold_steps * 1e3, "value": cold_steps / dt_cold,
+                      "then_settled_for_s": round(time.perf_counter() - t0, 2), "settle_steps": settle_steps}
     dt_events, prof = timed_run(True)
     dt, _ = timed_run(False)
 
