@@ -92,7 +92,7 @@ def parse():
                     help="--gpus 8 only: rows PER GPU of the side.config4 leg (BASELINE configs[3]: L2, N = 40 M over 8 GPUs)")
     ap.add_argument("--config4-anyway", action="store_true", help=argparse.SUPPRESS)   # (tests: the leg at any width, over any exchange)
     ap.add_argument("--no-settle", action="store_true",
-                    help="time the K steps right after the build (rounds 1-5's protocol) instead of after ~1.3 s of the same searches")
+                    help="time the K steps right after the build (rounds 1-5's protocol) instead of after ~1.8 s of the same searches")
     ap.add_argument("--supervise", action="store_true",
                     help="run the measurement in a child process and, should it fail or hang, once more over the host exchange "
                          "(always on for N > 1; this flag switches it on at N = 1, with --exchange rccl|host)")
@@ -1429,14 +1429,14 @@ def measure(a):
     # sit entirely inside that ramp, and five driver runs read 216-219 queries/s where 1 000-step runs read 222-224.  What a
     # service under load delivers is the settled rate, what a lone burst after a (re)load sees is the other: the line
     # carries BOTH, measured in this process one after the other with the same W warm-up steps and the same bracket --
-    # `cold_start` (right after the build, as rounds 1-5 measured `value`), then ~1.3 s of the same searches untimed, then
+    # `cold_start` (right after the build, as rounds 1-5 measured `value`), then ~1.8 s of the same searches untimed, then
     # `value`.  Nothing is skipped or shortened inside either timed region.  (--no-settle: `value` is the cold figure.)
     cold_start = None
     if not a.no_settle and a.steps > 0:
         cold_steps = min(a.steps, 100)
         dt_cold, _ = timed_run(False, cold_steps)
         per_step = max(dt_cold / cold_steps, 1e-6)
-        settle_steps = int(math.ceil(1.3 / per_step))
+        settle_steps = int(math.ceil(1.8 / per_step))
         t0 = time.perf_counter()
         for i in range(settle_steps):
             search(qs[i % nq])
@@ -1496,7 +1496,7 @@ def measure(a):
                 "sharding": sharding,
                 "processes": world,
                 "setup_s": round(t_build, 1),
-                "protocol": ("W warm-up + K timed steps right after the build (cold_start), ~1.3 s of the same searches untimed, then W warm-up + "
+                "protocol": ("W warm-up + K timed steps right after the build (cold_start), ~1.8 s of the same searches untimed, then W warm-up + "
                              "K timed steps (value): the first ~1.2 s of HBM-bound work on a freshly loaded card run 2.8 % slower per kernel"
                              if cold_start else "W warm-up + K timed steps right after the build (--no-settle)"),
             },
