@@ -80,9 +80,13 @@ with open('%s/%s_batch16_trace_excerpt.txt' % (out, RND), 'w') as f:
                            capture_output=True, text=True).stdout)
 import shutil
 shutil.copyfile('%s/default.json' % out, '%s/%s_bench_default_under_rocprof.json' % (out, RND))
-for name in ('single', 'driver_cmd', 'batch', 'batch_bf16', 'batch16', 'batch_k2b', 'quantized', 'funnel'):
+for name in ('single', 'batch', 'batch_bf16', 'batch16', 'batch_k2b', 'quantized', 'funnel'):
     # (the JSON line of every profiled leg under the name profiles/ keeps it by: <round>_bench_<leg>.json)
     shutil.copyfile('%s/%s.json' % (out, name), '%s/%s_bench_%s.json' % (out, RND, name))
+# (the driver's literal command: <round>_bench_driver_cmd.json is its UN-profiled line, written by hand from a plain run)
+shutil.copyfile('%s/driver_cmd.json' % out, '%s/%s_bench_driver_cmd_under_rocprof.json' % (out, RND))
+with open('%s/%s_driver_cmd_trace_summary.txt' % (out, RND), 'w') as f:
+    f.write(subprocess.run(['python3', 'tools/driver_cmd_trace_summary.py'], capture_output=True, text=True).stdout)
     print(open('%s/%s.json' % (out, name)).read().strip())
     for r in csv.DictReader(open('%s/%s/p_kernel_stats.csv' % (out, name))):
         if 'vt::' in r['Name']:
