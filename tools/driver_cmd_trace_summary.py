@@ -2,8 +2,9 @@
 """tools/driver_cmd_trace_summary.py [<dir with p_kernel_trace.csv> [<the run's JSON line>]] -- what rocprofv3's kernel trace of
 LITERALLY the driver's command (`rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5`,
 tools/refresh_profiles.sh: driver_cmd) says about the headline kernel: the dispatches over the 10 M-row corpus in the order
-they ran, by the time since the first of them -- the first ~1.2 s of scanning on a freshly loaded card run ~2.8 % slower per
-kernel than everything after (bench.py: cold_start / value) -- beside the line's own figures.  Writes the text that is kept as
+they ran, by the time since the first of them, beside the line's own figures.  (Through round 5 the first ~1.2 s of scanning
+-- the stretch after bench.py handed its 30-GB source tensor back to the driver -- ran 2.5 % slower per kernel, and the driver's
+20 steps sat inside it; since r06 setup ends with a pause, --release-wait: the table should be flat from the first row on.)  Writes the text that is kept as
 profiles/<round>_driver_cmd_trace_summary.txt to stdout.  No GPU needed: it reads the merged gpurun_out/prof/."""
 import csv
 import json
@@ -26,10 +27,7 @@ line = json.loads(open(line_path).read().strip().splitlines()[-1])
 
 print("command: rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5   (literally the driver's command)")
 print("the JSON line of that run:")
-if line.get("cold_start"):
-    c = line["cold_start"]
-    print("  cold_start (W warm-up + %d timed steps right after the build): %.2f queries/s, %.4f ms per step" % (c["steps"], c["value"], c["ms_per_step"]))
-    print("  then %d of the same searches untimed (%.2f s)" % (c["settle_steps"], c["then_settled_for_s"]))
+print("  config.release_wait_s: %s" % line.get("config", {}).get("release_wait_s"))
 print("  value (W warm-up + %d timed steps): %.2f queries/s, %.4f ms per step; long_run %.2f queries/s over %d steps" % (
     line["steps"], line["value"], line["ms_per_step"], line["long_run"]["value"], line["long_run"]["steps"]))
 print("  roofline.avg_launch_ms (HIP events on the library's stream over the timed steps) %.4f ms -> frac %.4f of 8 TB/s" % (
@@ -48,6 +46,5 @@ for lo, hi in zip(edges, edges[1:]):
 early = [ms for t, ms in big if t < 1.0]
 late = [ms for t, ms in big if t >= 1.5]
 if early and late:
-    print("  first second %.4f ms, from 1.5 s on %.4f ms: the settled kernel is %.1f %% faster.  The two timed regions of the line sit one on" % (
+    print("  first second %.4f ms, from 1.5 s on %.4f ms (%+.1f %%); kernel time <= ms_per_step." % (
         statistics.mean(early), statistics.mean(late), (statistics.mean(early) / statistics.mean(late) - 1) * 100))
-    print("  either side of that step; kernel time <= ms_per_step in both.")
