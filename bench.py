@@ -149,6 +149,13 @@ def build_shard(torch, device, rows, dim, seed, chunk=1 << 20, normalize=True):
     return x
 
 
+def release_pause(a):
+    """After a build has handed its source tensor back to the driver (`del x; empty_cache()`): for ~1.2 s after a 30-GB release
+    every scan of the card runs 2.5 % slower (measure(); tools/ramp_probe.py).  Setup, never inside a timed region."""
+    if getattr(a, "release_wait", 0) > 0:
+        time.sleep(a.release_wait)
+
+
 def cpu_baseline(dim, limit, budget_s):
     """The CPU beside it: the oracle -- the reference's algorithm restated in C, pinned to
     the reference's own test vectors -- timed on this box's host cores on a bounded sample of the same
@@ -487,6 +494,7 @@ def run_side_mode(a, torch, nifs, device):
     assert nifs.flat_load_device_matrix(ref, doc_ids(0, a.rows), x.data_ptr(), a.rows, a.dim) == ("ok", ())
     del x
     torch.cuda.empty_cache()
+    release_pause(a)
     per = a.batch if batch else 1
     nq = (a.steps + a.warmup) * per
     if batch:
@@ -695,6 +703,7 @@ def side_legs(a, torch, nifs, L, device, main_ref):
     assert nifs.flat_load_device_matrix(ref0, doc_ids(0, a.rows), x.data_ptr(), a.rows, a.dim) == ("ok", ())
     del x
     torch.cuda.empty_cache()
+    release_pause(a)
     # funnel_search on an L2 collection: stage 1 is K1's arithmetic on the prefix (one caller: K1 itself over the
     # rows' first 128 floats; callers that meet: K1p, up to eight per sweep of the prefixes)
     p128 = min(a.dim, 128)
@@ -766,6 +775,7 @@ def side_legs(a, torch, nifs, L, device, main_ref):
     assert nifs.flat_load_device_matrix(ref7, doc_ids(0, a.rows), x.data_ptr(), a.rows, a.dim) == ("ok", ())
     del x
     torch.cuda.empty_cache()
+    release_pause(a)
     rng = np.random.default_rng(SEED_QUERY + 7)
     qs = (rng.uniform(-1, 1, (330, a.dim)) * (rng.uniform(0, 1, (330, a.dim)) < 0.5)).astype(np.float32)
     side["pattern_hamming"] = dict(leg(a, L, nifs, ref7, "pattern", qs, 300, 30),

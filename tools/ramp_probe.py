@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Is the slow first second of scanning (bench.py: cold_start / value) a one-time effect after a load, or the card's
+"""Is the slow first second of scanning (bench.py --release-wait) a one-time effect after a load, or the card's
 state after any idle stretch?  Scans the 10 M x 768 corpus in bursts separated by idle pauses of growing length and prints
 the mean time of each burst's searches in windows of 50.  Diagnostic only."""
 import ctypes as C
