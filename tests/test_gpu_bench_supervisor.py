@@ -22,6 +22,8 @@ def bench(args, timeout=600, launcher=None, **env):
     if launcher:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher), "--master-addr", "127.0.0.1",
                 "--master-port", "29713"]
+    if "--release-wait" not in args:
+        args = list(args) + ["--release-wait", "0"]      # (setup's pause is for measurements; these runs check behaviour)
     r = subprocess.run(cmd + [BENCH] + args, env=e, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     return r, (json.loads(lines[-1]) if lines else None)

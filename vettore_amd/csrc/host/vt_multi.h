@@ -93,20 +93,16 @@ int shard_delete(Shard *ix, const char *id, size_t id_len, bool *began) {
     if (r != last) {
       // (the table learns the last row's new place while ids[last] still holds its bytes)
       ix->row_of.move_row(ix->ids[last].data(), ix->ids[last].size(), vt_host::hash_id(ix->ids[last].data(), ix->ids[last].size()), r);
-      // swap-delete: the last row moves into the hole and keeps its rank
-      VT_HIP(hipMemcpyAsync(ix->dX + (size_t)r * ix->ld, ix->dX + (size_t)last * ix->ld, (size_t)ix->ld * sizeof(float),
-                            hipMemcpyDeviceToDevice, c.stream));
+      // swap-delete: the last row moves into the hole and keeps its rank (the device side: one launch, below)
       ix->ids[r] = std::move(ix->ids[last]);
       ix->rank_host[r] = ix->rank_host[last];
-      if (ix->ranks_clean && ix->dRank.p)
-        VT_HIP(hipMemcpyAsync(ix->dRank.p + r, ix->dRank.p + last, sizeof(uint32_t), hipMemcpyDeviceToDevice, c.stream));
       if (!ix->ranks_clean) {
         ix->rank_dirty.push_back(r);
         if (ix->rank_dirty.size() > kMaxDirtyRanks) ix->rank_dirty_all = true;
       }
     }
-    VT_HIP(hipMemsetAsync(ix->dX + (size_t)last * ix->ld, 0, (size_t)ix->ld * sizeof(float), c.stream));
-    // (device-side moves only, queued on the primary stream: nothing to wait for here -- an event behind them is what
+    VT_HIP(vt::launch_swap_delete(ix->dX, ix->ld, r, last, ix->ranks_clean && ix->dRank.p ? ix->dRank.p : nullptr, c.stream));
+    // (a device-side move, queued on the primary stream: nothing to wait for here -- an event behind it is what
     // readers on other streams wait for, Shard::Landing; the slot's buffer goes unused)
     unsigned char *unused = nullptr;
     hipEvent_t ev = nullptr;

@@ -293,6 +293,8 @@ hipError_t launch_pad_rows(const float *src, uint32_t n, uint32_t d, float *dst,
 // A trickle of host rows lands from a pinned slot (layout in vt_kernels.hip: rows, their slab rows, id ranks): one launch.
 hipError_t launch_land_rows(const float *stage_dev, uint32_t count, uint32_t ld, float *X, uint32_t *rank_col, uint32_t rank_first,
                             uint32_t nranks, hipStream_t s);
+// Swap-delete on the slab: row `last` moves into row r (with its rank when rank_col is given), row `last` is zeroed.
+hipError_t launch_swap_delete(float *X, uint32_t ld, uint32_t r, uint32_t last, uint32_t *rank_col, hipStream_t s);
 hipError_t launch_gather_rows(const float *src, uint32_t d, const uint32_t *map, uint32_t count, float *dst,
                               size_t dst_stride, hipStream_t s);
 

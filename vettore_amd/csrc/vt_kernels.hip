@@ -1203,6 +1203,20 @@ __global__ __launch_bounds__(256) void land_rows_kernel(const float *__restrict_
   }
 }
 
+// flat.rs:88-93 on the slab: the last row moves into the hole (with its rank, when the rank column is current) and its old
+// place is zeroed -- rows n..cap are scanned by the last tile and must stay defined.  r == last: only the zeroing.  One
+// launch where the host used to queue a copy, a rank copy and a memset.
+__global__ __launch_bounds__(256) void swap_delete_kernel(float *__restrict__ X, uint32_t ld, uint32_t r, uint32_t last,
+                                                          uint32_t *__restrict__ rank_col) {
+  float4 *hole = reinterpret_cast<float4 *>(X + (size_t)r * ld);
+  float4 *tail = reinterpret_cast<float4 *>(X + (size_t)last * ld);
+  for (uint32_t c = threadIdx.x; c < ld / 4; c += blockDim.x) {
+    if (r != last) hole[c] = tail[c];
+    tail[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  if (threadIdx.x == 0 && rank_col && r != last) rank_col[r] = rank_col[last];
+}
+
 // K6 (cosine part): exact rerank value of distances.rs:160-177.  One wave per
 // candidate: the wave stages the row and the query in LDS with coalesced loads,
 // then lanes 0..2 run the three sequential f64 sums |q|^2, |x|^2, q.x in index
@@ -1935,6 +1949,12 @@ hipError_t launch_land_rows(const float *stage_dev, uint32_t count, uint32_t ld,
                             uint32_t nranks, hipStream_t s) {
   if (count == 0 || ld % 4 != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(land_rows_kernel, dim3(count), dim3(256), 0, s, stage_dev, count, ld, X, rank_col, rank_first, nranks);
+  return hipGetLastError();
+}
+
+hipError_t launch_swap_delete(float *X, uint32_t ld, uint32_t r, uint32_t last, uint32_t *rank_col, hipStream_t s) {
+  if (ld % 4 != 0 || r > last) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(swap_delete_kernel, dim3(1), dim3(256), 0, s, X, ld, r, last, rank_col);
   return hipGetLastError();
 }
 
