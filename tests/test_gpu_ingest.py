@@ -299,3 +299,67 @@ def test_a_row_is_seen_by_every_reader_the_moment_its_insert_has_returned(nifs, 
             th.join()
     assert not state["bad"], state["bad"][:5]
     assert len(g) == len(want)
+
+
+@pytest.mark.parametrize("d", [8, 100, 768])
+def test_trickles_of_one_to_a_slotful_of_rows_land_as_the_oracle_says(nifs, oracle_mod, d):
+    """Batches small enough for a slot of the landing ring (64 KiB: 21 rows of 768 floats, 126 of 100, 248 of 8) go down in ONE
+    kernel launch -- rows, their slab rows, the ranks of ascending new ids -- and the call returns before it has run (round 6).
+    Every shape of such a batch against the oracle index, searched right behind it: one row, a slotful, one row more than
+    a slot holds (the staged path), ascending new ids (ranks ride along), ids out of order (lazy ranks), upserts mixed
+    with new ids, an id twice in one batch (the LAST occurrence is the row, flat.rs:270-281) and three times, deletes in
+    between (the last row moves into the hole in one launch)."""
+    metric = 0
+    ld = (d + 63) // 64 * 64
+    slotful = (64 << 10) // (ld * 4 + 8)
+    rng = np.random.default_rng(700 + d)
+    g = GpuIndex(nifs, metric)
+    want = oracle_mod.FlatIndex(metric)
+    serial = [0]
+
+    def vec():
+        return rng.uniform(-1, 1, d).astype(np.float32)
+
+    def both(items):
+        g.insert_many(items)
+        want.insert_many(items)
+        assert len(g) == len(want)
+        for q in (items[-1][1], vec()):
+            assert bits(g.search(q, 12)) == bits(want.search(q, 12))
+
+    def fresh(n, ascending=True):
+        keys = []
+        for _ in range(n):
+            serial[0] += 1
+            keys.append("k-%08d" % serial[0] if ascending else "u-%d" % ((serial[0] * 7919) % 100003))
+        return keys
+
+    both([(k, vec()) for k in fresh(1)])                                   # one row into an empty index
+    both([(k, vec()) for k in fresh(slotful)])                             # a slotful of ascending new ids
+    both([(k, vec()) for k in fresh(slotful + 1)])                         # one more than a slot holds: the staged path
+    both([(k, vec()) for k in fresh(5, ascending=False)])                  # out of order: ranks go lazy
+    both([(k, vec()) for k in fresh(3)])                                   # ascending again, on lazy ranks
+    live = ["k-%08d" % i for i in range(1, 6)]
+    both([(live[0], vec()), ("k-%08d" % (serial[0] + 1), vec()), (live[3], vec())])   # upserts around a new id
+    serial[0] += 1
+    twice = vec()
+    both([("dup", vec()), ("k-%08d" % 2, vec()), ("dup", twice)])          # an id twice: the last occurrence is the row
+    assert bits(g.search(twice, 1)) == bits(want.search(twice, 1)) and g.search(twice, 1)[0][0] == b"dup"
+    thrice = vec()
+    both([("tri", vec()), ("tri", vec()), ("tri", thrice)])
+    assert g.search(thrice, 1)[0][0] == b"tri"
+    for victim in ("dup", live[1], "tri"):                                 # deletes: swap with the last row, one launch
+        g.delete(victim)
+        want.delete(victim)
+        q = vec()
+        assert len(g) == len(want) and bits(g.search(q, 12)) == bits(want.search(q, 12))
+    both([(k, vec()) for k in fresh(min(slotful, 9))])                     # and on it goes
+    for _ in range(30):                                                    # a run of single puts and deletes, searched each time
+        if rng.integers(0, 3) == 0 and len(want) > 3:
+            victim = "k-%08d" % int(rng.integers(1, serial[0] + 1))
+            g.delete(victim)
+            want.delete(victim)
+        else:
+            both([(fresh(1)[0] if rng.integers(0, 2) else "k-%08d" % int(rng.integers(1, serial[0] + 1)), vec())])
+    q = vec()
+    assert len(g) == len(want) and bits(g.search(q, 40)) == bits(want.search(q, 40))
