@@ -1472,9 +1472,9 @@ def measure(a):
             t = torch.tensor([dt_long], dtype=torch.float64, device=torch.device("cpu") if host_exchange else device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_long = float(t.item())
-        # (r06: every step of it timed as well.  The 255th search call of a process takes ~40 ms -- once, whatever the corpus:
-        # ~1 020 commands into the process, a pool of the HIP runtime by the look of it -- and with the driver's W and K that
-        # call falls into this loop and moves its mean by 3 %: the median and the longest step say so)
+        # (r06: every step of it timed as well.  The 255th search call of a fresh process takes ~40 ms -- once, whatever the
+        # corpus: a one-time event of the runtime by the look of it, DESIGN 5 -- and with the driver's W and K that call falls
+        # into this loop and moves its mean by 3 %: the median and the longest step say so)
         long_run = {"steps": long_steps, "ms_per_step": dt_long / long_steps * 1e3, "value": long_steps / dt_long,
                     "seconds": dt_long, "ms_per_step_median": float(np.median(each)) * 1e3, "longest_step_ms": float(each.max()) * 1e3,
                     "steps_over_twice_the_median": int((each > 2.0 * np.median(each)).sum())}
