@@ -168,6 +168,18 @@ def _worker_uneven(rank, world, port, outq):
                     checks += 1
                     if len(owners) < 3:
                         failed.append(("tie block owners", sorted(owners)))
+        # the global id ranking behind the device-side exchange (enable_device_exchange) at this width: every rank gathers
+        # every shard's ids -- the empty shard's none, the odd ranks' long ones -- and ranks them once, identically
+        from vettore_amd.sharded import gather_global_ranks
+        x, ids, cuts, _ = _uneven_corpus(world, 0)
+        blob, off, bases, ranks = gather_global_ranks(dist, world, oracle.pack_ids(ids[cuts[rank]:cuts[rank + 1]]))
+        order = sorted(range(len(ids)), key=lambda i: ids[i])
+        want_ranks = np.empty(len(ids), dtype=np.int64)
+        want_ranks[order] = np.arange(len(ids))
+        checks += 1
+        if list(bases) != list(cuts) or not np.array_equal(np.asarray(ranks, dtype=np.int64), want_ranks) or \
+                any(blob[int(off[i]):int(off[i + 1])] != ids[i] for i in (0, len(ids) // 2, len(ids) - 1)):
+            failed.append(("global ranks", list(bases)))
         outq.put((rank, not failed, checks if not failed else failed[:4]))
     except Exception as e:  # surface the failure instead of letting the parent time out
         outq.put((rank, False, repr(e)))
@@ -196,7 +208,7 @@ def test_uneven_shards_an_empty_one_ties_across_every_boundary_and_long_ids(worl
         assert p.exitcode == 0
     assert sorted(o[0] for o in outs) == list(range(world))
     per_scenario = 3 * (3 * 4) + (1 if world > 2 else 0)
-    assert all(o[1] for o in outs) and all(o[2] == per_scenario * (2 if world == 2 else 1) for o in outs), outs
+    assert all(o[1] for o in outs) and all(o[2] == per_scenario * (2 if world == 2 else 1) + 1 for o in outs), outs
 
 
 def test_pack_unpack_roundtrip():
