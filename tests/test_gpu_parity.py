@@ -917,28 +917,28 @@ def test_bf16_nomination_second_pass(nifs, oracle_mod, metric, monkeypatch, vt_d
     assert prof["batch_fallbacks"] == 0, prof
 
 
-@pytest.mark.parametrize("metric", [2, 0])
-def test_device_side_shard_merge_equals_single_index(nifs, oracle_mod, metric):
-    """The multi-GPU exchange path on one GPU: 4 row-block shards whose id_rank
-    columns are slices of ONE ordering of all ids (vt_rank_ids), per-shard
-    vt_flat_search_begin into a gathered device buffer, vt_flat_merge_gathered --
+@pytest.mark.parametrize("metric,world", [(2, 4), (0, 4), (2, 8), (0, 8)])
+def test_device_side_shard_merge_equals_single_index(nifs, oracle_mod, metric, world):
+    """The multi-GPU exchange path on one GPU: 4 even / 8 UNEVEN row-block shards (the width of the node: one of them
+    holds five rows, fewer than a list is long) whose id_rank columns are slices of ONE ordering of all ids
+    (vt_rank_ids), per-shard vt_flat_search_begin into a gathered device buffer, vt_flat_merge_gathered --
     must equal the oracle over all rows, ties (identical rows across shards)
     included."""
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library already loaded (torch must not come second)
-    n, d, world = 40_000, 96, 4
+    n, d = 40_000, 96
     x, ids = make_corpus(n, d, 900 + metric, metric == 2, oracle_mod, tie_block=0)
+    cuts = [s * (n // world) for s in range(world)] + [n] if world == 4 else [0, 3000, 3005, 11000, 12500, 21000, 30500, 39000, n]
     # identical rows living in different shards: only the global id order can rank them
     for s in range(world):
-        x[s * (n // world) + 17] = x[5]
+        x[cuts[s] + min(17, cuts[s + 1] - cuts[s] - 1)] = x[5]
     packed = oracle_mod.pack_ids(ids)
     ranks = nifs.rank_ids(nifs.pack_ids(ids))
-    per = n // world
     shards = []
     for s in range(world):
         g = GpuIndex(nifs, metric)
-        unwrap(nifs.flat_load_matrix(g.ref, ids[s * per:(s + 1) * per], x[s * per:(s + 1) * per]))
-        assert nifs.flat_set_id_ranks(g.ref, ranks[s * per:(s + 1) * per]) == "ok"
+        unwrap(nifs.flat_load_matrix(g.ref, ids[cuts[s]:cuts[s + 1]], x[cuts[s]:cuts[s + 1]]))
+        assert nifs.flat_set_id_ranks(g.ref, ranks[cuts[s]:cuts[s + 1]]) == "ok"
         shards.append(g)
     rng = np.random.default_rng(12)
     bufs = nifs.MergeBuffers()
@@ -956,7 +956,7 @@ def test_device_side_shard_merge_equals_single_index(nifs, oracle_mod, metric):
             assert hip.hipDeviceSynchronize() == 0
             st, cnt = nifs.flat_merge_gathered(shards[0].ref, gathered.value, world, limit, block_bytes, bufs)
             assert st == "ok" and cnt == limit
-            got = [(ids[int(bufs.shard[i]) * per + int(bufs.rows[i])], float(bufs.raw[i])) for i in range(cnt)]
+            got = [(ids[cuts[int(bufs.shard[i])] + int(bufs.rows[i])], float(bufs.raw[i])) for i in range(cnt)]
             assert bits(got) == bits(oracle_mod.matrix_search(metric, x, packed, q, limit)), (metric, limit, qi)
         assert hip.hipFree(gathered) == 0
     # a mutation invalidates the external ranks; the shard re-ranks locally and still answers alone
