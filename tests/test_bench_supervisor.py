@@ -122,11 +122,11 @@ def test_eight_ranks_take_the_second_step_together_when_one_of_them_fails():
     """The same launch with rank 5's first child dying before the collective: its seven peers wait in the rendezvous until
     their timeout, every supervisor learns that the attempt failed somewhere, and all eight go on to the host exchange --
     on the next port, with a store of their own -- where they meet and rank 0 prints the line with the reason in it."""
-    env = dict(os.environ, VT_BENCH_CHILD=FAKE, FAKE_CHILD="meet", FAKE_FAIL_RANKS="5", FAKE_MEET_TIMEOUT="8", OMP_NUM_THREADS="1")
+    env = dict(os.environ, VT_BENCH_CHILD=FAKE, FAKE_CHILD="meet", FAKE_FAIL_RANKS="5", FAKE_MEET_TIMEOUT="20", OMP_NUM_THREADS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     port = _free_port()
-    r = subprocess.run(_driver_command(8, port, ["--scaling", "weak"]), env=env, capture_output=True, text=True, timeout=400)
+    r = subprocess.run(_driver_command(8, port, ["--scaling", "weak"]), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = last_json(r.stdout)
     assert (line["n_gpus"], line["rccl_ranks"], line["met"], line["scaling"]) == (8, 8, list(range(8)), "weak"), line
