@@ -64,8 +64,10 @@ $(LIBDIR)/vt_index.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h $(CSRC
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
-$(LIBDIR)/libvettore_hip.so: $(DEVOBJ) $(LIBDIR)/vt_index.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread -ldl
+# (only the C ABI is exported: csrc/exports.map)
+EXPORTS := -Wl,--version-script=$(CSRC)/exports.map
+$(LIBDIR)/libvettore_hip.so: $(DEVOBJ) $(LIBDIR)/vt_index.o $(CSRC)/exports.map
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(filter %.o,$^) $(EXPORTS) -lpthread -ldl
 
 # The same library with the fault-injection hooks compiled into the host side (VT_TEST_FAIL_AFTER_ID_UPDATE,
 # VT_TEST_FOREIGN_ROWS): test infrastructure, loaded only by the two tests that need them
@@ -74,8 +76,8 @@ $(LIBDIR)/vt_index_hooks.o: $(CSRC)/vt_index.cpp $(HOSTHDR) $(CSRC)/vt_device.h 
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DVT_TEST_HOOKS -x hip -c $< -o $@
 
-$(LIBDIR)/libvettore_hip_hooks.so: $(DEVOBJ) $(LIBDIR)/vt_index_hooks.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread -ldl
+$(LIBDIR)/libvettore_hip_hooks.so: $(DEVOBJ) $(LIBDIR)/vt_index_hooks.o $(CSRC)/exports.map
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(filter %.o,$^) $(EXPORTS) -lpthread -ldl
 
 experiments:
 	$(MAKE) EXPERIMENTS=1 LIBDIR=vettore_amd/lib/experiments vettore_amd/lib/experiments/libvettore_hip.so

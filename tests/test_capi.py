@@ -30,6 +30,21 @@ def test_header_symbols_are_exported(lib):
         assert hasattr(lib, name), "libvettore_hip.so does not export " + name
 
 
+def test_nothing_but_the_header_is_exported():
+    """... and the other direction (r06, csrc/exports.map): the dynamic symbol table of libvettore_hip.so -- and of the hooks
+    build -- holds the C ABI and nothing else.  No kernel's host stub, no launcher of csrc/vt_device.h, no instantiation of the
+    standard library can collide with, or be interposed by, whatever else lives in the process that loads it (a BEAM)."""
+    import subprocess
+    declared = set(declared_functions())
+    for name in ("libvettore_hip.so", "libvettore_hip_hooks.so"):
+        so = os.path.join(ROOT, "vettore_amd", "lib", name)
+        if not os.path.exists(so):
+            continue
+        out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+        exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+        assert exported == declared, (name, sorted(exported - declared)[:5], sorted(declared - exported)[:5])
+
+
 def test_python_binding_covers_the_header():
     import vettore_amd._lib as L
     assert sorted(L.SYMBOLS) == declared_functions()
