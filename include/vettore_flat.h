@@ -116,7 +116,10 @@ int vt_device_read_peak(int device, size_t bytes, int reps, double *gbps);
  * "force_threshold_select" (take a path on corpora the cost model would never send there) and
  * "bf16_rank" (K2b's threshold from exactly that sample rank): tests and soaks only.  A debugging and
  * testing aid, process-wide, effective for calls that start afterwards; VT_ERR_ARGUMENT for a name this
- * build does not know (the fault hooks "test_*" exist in libvettore_hip_hooks.so only). */
+ * build does not know (the fault hooks "test_*" exist in libvettore_hip_hooks.so only, the timing experiments'
+ * switches in `make experiments` only; r06 retired the A/B switches whose alternative had lost -- 24 settings are
+ * left, DESIGN_APPENDIX.md A.10) and for a value the setting's own parser could not have produced
+ * (reduce_order outside 0..3, batch_nominate outside 1..2 ...). */
 int vt_debug_set(const char *name, long value);
 int vt_debug_get(const char *name, long *value);
 
