@@ -82,7 +82,7 @@ def test_the_fallback_under_the_launcher_meets_on_a_store_of_its_own():
     Under the launcher the store at MASTER_PORT belongs to the launcher's agent (workers are told to come as clients);
     the second run shifts the port, so its rank 0 has to host the store itself -- when it did not, both ranks waited
     2 x 120 s for a listener that never came and the run ended without a line."""
-    r, line = bench(["--gpus", "2", "--devices", "0,0", "--rows", "200000", "--steps", "10", "--warmup", "2", "--no-cpu"], launcher=2, timeout=300)
+    r, line = bench(["--gpus", "2", "--devices", "0,0", "--rows", "200000", "--steps", "10", "--warmup", "2", "--no-cpu"], launcher=2, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert line is not None and line["n_gpus"] == 2 and line["config"]["processes"] == 2, line
     assert "rccl-exchange run exited with status" in line["config"]["exchange_note"], line
