@@ -133,3 +133,16 @@ def test_config_4_between_rank_processes_rehearsed_with_two_ranks():
     assert leg["n_gpus"] == 2 and leg["rows_per_gpu"] == 150000 and "N=300000" in leg["workload"] and "gloo" in leg["exchange"], leg
     assert leg["verified"] and leg["checks"]["batched_list_equals_single_search"] and leg["checks"]["brute_force_over_every_shard"], leg
     assert leg["single"]["roofline"]["algorithmic_bytes_per_launch"] == 150000 * 768 * 4, leg["single"]
+
+
+def test_the_rank_per_gpu_path_over_rccl_with_one_rank():
+    """What every rank of the driver's N > 1 launch runs -- torch.distributed over nccl (= RCCL), the global id ranking
+    installed as the shard's rank column, per query vt_flat_search_begin into a device block, all_gather_into_tensor on
+    the library's stream, vt_flat_merge_gathered -- with the one rank a one-GPU box can give it (`--force-exchange`): the
+    collective really is RCCL's, only the peers are missing."""
+    r, line = bench(["--gpus", "1", "--force-exchange", "--rows", "300000", "--steps", "20", "--warmup", "5", "--no-cpu", "--no-side"],
+                    MASTER_ADDR="127.0.0.1", MASTER_PORT="29733")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["value"] > 0, line
+    assert "all_gather of per-shard top-k over RCCL (device merge)" in line["config"]["sharding"], line["config"]
+    assert line["config"]["processes"] == 1 and 0 < line["roofline"]["frac"] <= 1, line
