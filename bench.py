@@ -1315,7 +1315,7 @@ def measure(a):
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=120))
     nifs.set_device(local_rank)
-    multi = a.gpus > 1 or launched or force_sharded
+    multi = a.gpus > 1 or launched or force_sharded or a.force_exchange   # (--force-exchange: the rank-per-GPU path with the one rank)
     if a.mode != "single" and not (a.mode == "batch" and multi):
         if multi:
             sys.exit("--mode %s is a single-GPU measurement" % a.mode)

@@ -146,3 +146,8 @@ def test_the_rank_per_gpu_path_over_rccl_with_one_rank():
     assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["value"] > 0, line
     assert "all_gather of per-shard top-k over RCCL (device merge)" in line["config"]["sharding"], line["config"]
     assert line["config"]["processes"] == 1 and 0 < line["roofline"]["frac"] <= 1, line
+    # ... and its batched leg: every rank answers the whole batch on its rows, ONE all_gather of wire blocks over RCCL
+    r, line = bench(["--gpus", "1", "--force-exchange", "--mode", "batch", "--metric", "l2", "--batch", "64", "--rows", "300000", "--steps", "3",
+                     "--warmup", "1", "--no-cpu", "--debug-set", "force_batch_mfma=1"], MASTER_ADDR="127.0.0.1", MASTER_PORT="29734")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["config"]["verified"] and line["rccl_ranks"] == 1 and "RCCL" in line["config"]["sharding"], line
