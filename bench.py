@@ -966,21 +966,22 @@ def config4_leg(a, torch, dist, nifs, _lib, L, rank, world, launched, devices, d
     xdev = torch.device("cpu") if host_exchange else device   # where collectives' tensors live (gloo: the host)
     rows, dim, limit = a.config4_rows, a.dim, a.limit
     metric = nifs.METRIC_CODE["l2"]
-    n_gpus = world if launched else len(devices)
+    between_ranks = launched or a.force_exchange   # (--force-exchange: the rank-per-GPU form with the one rank of a one-GPU box)
+    n_gpus = world if between_ranks else len(devices)
     total = rows * n_gpus
     nsingle, nbatch = 200, 4096
     rng = np.random.default_rng(SEED_QUERY + 4)
     qs = rng.uniform(-1, 1, size=(nsingle, dim)).astype(np.float32)
     qb = rng.uniform(-1, 1, size=(nbatch, dim)).astype(np.float32)
-    shards = []   # (torch device, ids of its rows as a list index -> global doc number, seed) for the brute-force check
-    if launched:
+    if between_ranks:
         x = build_shard(torch, device, rows, dim, SEED_CORPUS + 400 + rank, normalize=False)
         ids = doc_ids(rank * rows, rows)
         ref = nifs._flat_new(metric)
         nifs.flat_set_reduce_order(ref, ORDER_CODE[a.reduce_order])
         res = nifs.flat_load_device_matrix(ref, ids, x.data_ptr(), rows, dim)
         assert res == ("ok", ()), res
-        sf = ShardedFlat(ref, dist, xdev)   # (64-byte records over RCCL, merged on the host: no global id ranking to pay for)
+        # (64-byte records over RCCL, merged on the host: no global id ranking to pay for)
+        sf = ShardedFlat(ref, dist, xdev, force_exchange=a.force_exchange)
         rccl_ranks = 0 if host_exchange else dist.get_world_size()
         exchange = "one rank per GPU: all_gather of per-shard top-k records over %s, merge by (rank key, id bytes) on the host" % (
             "gloo" if host_exchange else "RCCL")

@@ -151,3 +151,9 @@ def test_the_rank_per_gpu_path_over_rccl_with_one_rank():
                      "--warmup", "1", "--no-cpu", "--debug-set", "force_batch_mfma=1"], MASTER_ADDR="127.0.0.1", MASTER_PORT="29734")
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["config"]["verified"] and line["rccl_ranks"] == 1 and "RCCL" in line["config"]["sharding"], line
+    # ... and side.config4 in the form the driver's launch at N = 8 runs it, records gathered over RCCL
+    r, line = bench(["--gpus", "1", "--force-exchange", "--config4-anyway", "--config4-rows", "200000", "--rows", "200000", "--steps", "5",
+                     "--warmup", "2", "--no-cpu"], MASTER_ADDR="127.0.0.1", MASTER_PORT="29735")
+    assert r.returncode == 0, r.stderr[-3000:]
+    leg = line["side"]["config4"]
+    assert "failed" not in leg and leg["verified"] and leg["rccl_ranks"] == 1 and "over RCCL" in leg["exchange"], leg
